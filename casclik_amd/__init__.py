@@ -1,0 +1,18 @@
+"""casclik_amd - MI355X-native batched CLIK with the casclik API.
+
+Import surface of the reference package (casclik/__init__.py:1-3):
+``import casclik_amd as cc`` then ``cc.EqualityConstraint``,
+``cc.SkillSpecification``, ``cc.PseudoInverseController`` ...
+The CasADi-free expression front-end is ``casclik_amd.sym`` (use it where the
+reference scripts say ``import casadi as cs``) and the URDF converter is
+``casclik_amd.converter``.
+"""
+from casclik_amd.constraints import (BaseConstraint, EqualityConstraint,
+                                     SetConstraint, VelocityEqualityConstraint,
+                                     VelocitySetConstraint)
+from casclik_amd.skill_specification import SkillSpecification
+from casclik_amd.controllers import PseudoInverseController, ReactiveQPController
+from casclik_amd.urdf import converter
+from casclik_amd import sym
+
+__version__ = "0.1.0"

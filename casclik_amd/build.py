@@ -1,0 +1,62 @@
+"""Build the HIP hot-path library in-tree (casclik_amd/libclik_hip.so).
+
+hipcc cross-compiles for gfx950 without a GPU; the objects are cached under
+casclik_amd/csrc/_obj and rebuilt when a source or header is newer.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libclik_hip.so")
+SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_qp.hip"]
+HEADERS = [os.path.join(CSRC, "clik_device.hpp"), os.path.join(ROOT, "include", "clik.h")]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in HEADERS)
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(op)
+        stale = (force or not os.path.exists(op)
+                 or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_time))
+        if stale:
+            cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE,
+                                               stderr=subprocess.STDOUT)))
+    for src, proc in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode("utf-8", "replace")))
+    if jobs or not os.path.exists(LIB) or force:
+        # -no-hip-rt: leave the HIP runtime symbols undefined so the library
+        # binds to the ONE libamdhip64 the host process already uses (torch
+        # wheels bundle their own; a second runtime cannot open the device)
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-no-hip-rt"] + objs + ["-o", LIB]
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,270 @@
+"""PseudoInverseController: set-based task-priority CLIK, batched on the GPU.
+
+Same constructor, options, setup and ``solve`` surface as the reference class
+(reference: casclik/controllers/pseudo_inverse.py:10-556); ``solve_batch`` and
+``rollout_batch`` are the additions that expose the batch dimension.  Where the
+reference builds and JIT-compiles one CasADi function per mode
+(:259-483), ``setup_problem_functions`` lowers the skill to the flat device
+descriptor and uploads it; ``solve`` launches the HIP kernel (B = 1) instead
+of scanning modes in Python (:512-556).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _capi
+from .. import sym as cs
+from ..lowering import lower_skill
+from .base_controller import (BaseController, current_stream, device_of, ptr,
+                              to_device_matrix, _torch)
+
+
+class PseudoInverseController(BaseController):
+    """Pseudo inverse controller (Moe's set-based task priority scheme).
+
+    Args:
+        skill_spec (SkillSpecification): skill specification
+        options (dict): see ``options`` setter for keys and defaults
+    """
+    controller_type = "PseudoInverseController"
+    options_info = """feedforward (bool, True), multidim_sets (bool, False),
+    converge_final_set_to_max (bool, False), pinv_method ("damped"|"standard"),
+    damping_factor (float, 1e-7), function_opts (dict, accepted and ignored:
+    there is no CasADi JIT on this path), device (torch device, optional)"""
+
+    def __init__(self, skill_spec, options=None):
+        self._handle = None
+        self._lib = None
+        self.skill_spec = skill_spec
+        self.options = options
+        self.current_mode = None
+        self.modes = None
+
+    def __del__(self):
+        self._release()
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None and self._lib is not None:
+            try:
+                self._lib.clik_pinv_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    # -- options (pseudo_inverse.py:42-66) --------------------------------
+    @property
+    def options(self):
+        return self._options
+
+    @options.setter
+    def options(self, opt):
+        if opt is None:
+            opt = {}
+        opt.setdefault("feedforward", True)
+        opt.setdefault("multidim_sets", False)
+        opt.setdefault("converge_final_set_to_max", False)
+        opt.setdefault("pinv_method", "damped")
+        opt.setdefault("damping_factor", 1e-7)
+        fopts = opt.setdefault("function_opts", {})
+        fopts.setdefault("jit", True)
+        fopts.setdefault("print_time", False)
+        fopts.setdefault("jit_options", {"flags": "-O2"})
+        self._options = opt
+
+    # -- skill (pseudo_inverse.py:74-90) ----------------------------------
+    @property
+    def skill_spec(self):
+        return self._skill_spec
+
+    @skill_spec.setter
+    def skill_spec(self, spec):
+        cnt = spec.count_constraints()
+        self.n_set_constraints = cnt["set"]
+        self.n_modes = 2 ** cnt["set"]
+        self.n_state_var = spec.n_robot_var + (spec.n_virtual_var
+                                               if spec.virtual_var is not None else 0)
+        self._skill_spec = spec
+        self.create_activation_map()
+
+    def create_activation_map(self):
+        """Mode order (pseudo_inverse.py:107-130): bit patterns with set 0 as
+        least significant bit, stably sorted by the number of active sets."""
+        n_sets = self.n_set_constraints
+        if n_sets == 0:
+            self.activation_map = []
+            return
+        patterns = [[(idx >> k) & 1 for k in range(n_sets)]
+                    for idx in range(2 ** n_sets)]
+        self.activation_map = sorted(patterns, key=sum)
+
+    # -- setup --------------------------------------------------------------
+    def get_problem_expressions(self):
+        """Per-mode bookkeeping (which sets are active / tested); the
+        arithmetic itself lives in the device kernel."""
+        set_labels = [c.label for c in self.skill_spec.constraints
+                      if c.constraint_class == "SetConstraint"]
+        modes = []
+        for mode_idx in range(self.n_modes):
+            bits = self.activation_map[mode_idx] if self.activation_map else []
+            modes.append({
+                "active_set_names": [l for l, b in zip(set_labels, bits) if b],
+                "in_tangent_cone_set_names": [l for l, b in zip(set_labels, bits) if not b],
+            })
+        self.modes = modes
+        return modes
+
+    def setup_problem_functions(self):
+        """Lower the skill and create the device handle (replaces the
+        per-mode ``cs.Function`` JIT of pseudo_inverse.py:453-483)."""
+        self.get_problem_expressions()
+        self._release()
+        self._lib = _capi.load_library()
+        self.descriptor = lower_skill(self.skill_spec)
+        cdesc = _capi.desc_to_c(self.descriptor)
+        copts = _capi.pinv_opts_to_c(self.options)
+        self._device = device_of(self.options.get("device"))
+        handle = C.c_void_p()
+        torch = _torch()
+        with torch.cuda.device(self._device):
+            rc = self._lib.clik_pinv_create(C.byref(cdesc), C.byref(copts), C.byref(handle))
+        _capi.check(self._lib, rc)
+        self._handle = handle
+
+    def setup_solver(self):
+        """Reference parity: re-runs the problem setup (pseudo_inverse.py:506-510)."""
+        self.setup_problem_functions()
+
+    def setup_initial_problem_solver(self):
+        """Does nothing, as in the reference (pseudo_inverse.py:485-488)."""
+        pass
+
+    def solve_initial_problem(self, time_var0, robot_var0, virtual_var0=None,
+                              robot_vel_var0=None, input_var0=None):
+        """Zeros, as in the reference (pseudo_inverse.py:490-504)."""
+        spec = self.skill_spec
+        res_virt = cs.DM.zeros(spec.n_virtual_var, 1) if virtual_var0 is not None else None
+        res_slack = cs.DM.zeros(spec.n_slack_var, 1) if spec.slack_var is not None else None
+        return res_virt, res_slack
+
+    # -- per-tick -------------------------------------------------------------
+    def _require_handle(self):
+        if self._handle is None:
+            raise RuntimeError("call setup_problem_functions() / setup_solver() first")
+
+    def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
+                    out=None, return_mode=True):
+        """One controller tick for a batch.
+
+        robot_var [B, n_q], virtual_var [B, n_x], input_var [B, n_y] as numpy
+        arrays or torch tensors (tensors on the controller's device are used
+        in place).  Returns (robot_vel [B,n_q], virtual_vel | None, mode [B])
+        in the container type of ``robot_var``.  The launch is asynchronous on
+        torch's current stream when tensors are passed."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        X = None
+        if d.n_x > 0:
+            if virtual_var is None:
+                raise ValueError("skill has virtual_var: pass virtual_var")
+            X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+        Y = None
+        if d.n_y > 0:
+            if input_var is None:
+                raise ValueError("skill has input_var: pass input_var")
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        if out is not None:
+            dQ = out
+        else:
+            dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
+        mode = torch.empty((B,), dtype=torch.int32, device=dev) if return_mode else None
+        tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_pinv_solve_batch(
+                self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
+                ptr(mode), current_stream(dev))
+        _capi.check(self._lib, rc)
+        if was_np:
+            return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),
+                    None if mode is None else mode.cpu().numpy())
+        return dQ, dX, mode
+
+    def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008,
+                      max_speed=0.0):
+        """``len(time_vars)`` ticks of solve -> clamp(+-max_speed) -> Euler
+        ``q += dq*dt`` in one launch (the host loop of
+        ur5_moe2016_example2.ipynb:537-545).  Returns (q_final, dq_last, mode_last)."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        if not was_np:
+            Q = Q.clone()
+        B = Q.shape[0]
+        Y = None
+        if d.n_y > 0:
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        times = np.asarray(time_vars, dtype=float).reshape(-1)
+        tt = np.concatenate([d.time_terms(t) for t in times]) if d.n_tslots else np.zeros(0)
+        tt, ttp = _capi.tterms_arg(tt)
+        dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        mode = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_pinv_rollout_batch(
+                self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
+                ptr(Q), ptr(Y), ptr(dQ), ptr(mode), current_stream(dev))
+        _capi.check(self._lib, rc)
+        if was_np:
+            return Q.cpu().numpy(), dQ.cpu().numpy(), mode.cpu().numpy()
+        return Q, dQ, mode
+
+    def solve(self, time_var, robot_var, virtual_var=None, input_var=None,
+              warmstart_robot_vel_var=None, warmstart_virtual_vel_var=None,
+              warmstart_slack_var=None):
+        """Single-instance tick with the reference's signature and return
+        convention (pseudo_inverse.py:512-556): ``(robot_vel DM n x 1,
+        virtual_vel DM | None, None)`` and ``self.current_mode``."""
+        spec = self.skill_spec
+        q = _flat(robot_var, spec.n_robot_var, "robot_var")
+        x = None
+        if spec.n_virtual_var > 0:
+            # the reference forwards virtual_var only when it is used (:521-525);
+            # the device descriptor always carries the full state vector
+            x = _flat(virtual_var if virtual_var is not None
+                      else np.zeros(spec.n_virtual_var), spec.n_virtual_var, "virtual_var")
+        y = None
+        if spec.n_input_var > 0:
+            y = _flat(input_var if input_var is not None
+                      else np.zeros(spec.n_input_var), spec.n_input_var, "input_var")
+        dq, dx, mode = self.solve_batch(
+            float(_scalar(time_var)), q.reshape(1, -1),
+            None if x is None else x.reshape(1, -1),
+            None if y is None else y.reshape(1, -1))
+        self.current_mode = int(mode[0])
+        cntrl_rob = cs.DM(dq[0])
+        cntrl_virt = None
+        if spec.n_virtual_var > 0 and virtual_var is not None and spec._has_virtual:
+            cntrl_virt = cs.DM(dx[0])
+        return cntrl_rob, cntrl_virt, None
+
+
+def _scalar(v):
+    if hasattr(v, "toarray"):
+        v = v.toarray()
+    return np.asarray(v, dtype=float).reshape(-1)[0]
+
+
+def _flat(v, n, what):
+    if hasattr(v, "toarray"):
+        v = v.toarray()
+    arr = np.asarray(v, dtype=np.float64).reshape(-1)
+    if arr.size != n:
+        raise ValueError("%s must have %d entries, got %d" % (what, n, arr.size))
+    return arr

@@ -1,0 +1,291 @@
+"""ReactiveQPController: the skill as a small dense QP per instance, batched
+on the GPU.
+
+Same constructor, weights, options, setup and ``solve`` surface as the
+reference class (reference: casclik/controllers/reactive_qp.py:10-528).  The
+QP  min 1/2 v'Hv  s.t.  lbA <= A v <= ubA  with H = diag(mu*w_rob, mu*w_virt,
+mu + w_slack) (:175-189) and one row block per constraint (:191-246) is
+assembled and solved inside one HIP kernel; ``cs.conic``/qpOASES (:248-260,
+:491-513) is replaced by an exact dual active-set solve per lane.  H is
+strictly positive, so the minimiser is unique and does not depend on the
+solver or on warm starts: the ``warmstart_*`` arguments are accepted and
+ignored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _capi
+from .. import sym as cs
+from ..lowering import lower_skill
+from .base_controller import (BaseController, current_stream, device_of, ptr,
+                              to_device_matrix, _torch)
+from .pseudo_inverse import _flat, _scalar
+
+
+def _weights(weights, n, what):
+    """Weight vectors (reactive_qp.py:65-133): None -> ones; list / ndarray of
+    the right length; CasADi-typed weights always raise in the reference
+    (it compares the bound method ``weights.size2`` to 1), so symbolic weights
+    are rejected here too."""
+    if weights is None:
+        return np.ones(n)
+    if isinstance(weights, cs.MX):
+        raise ValueError(what + " must be a vector.")
+    if isinstance(weights, cs.DM):
+        weights = weights.toarray().reshape(-1)
+    if isinstance(weights, (list, tuple, np.ndarray)):
+        arr = np.asarray(weights, dtype=float).reshape(-1)
+        if arr.size != n:
+            raise ValueError(what + " and variable dimensions do not match")
+        return arr
+    raise TypeError("unsupported type for " + what)
+
+
+class ReactiveQPController(BaseController):
+    """Reactive QP controller.
+
+    Args:
+        skill_spec (SkillSpecification): skill specification
+        robot_var_weights (list): cost weights of robot_vel_var
+        virtual_var_weights (list): cost weights of virtual_vel_var
+        slack_var_weights (list): cost weights of the slack variables
+        options (dict): accepted for API parity; solver_name/solver_opts/
+            function_opts configure CasADi in the reference and have no effect
+            here; ``device`` selects the GPU; ``max_iter`` caps the active-set
+            iterations.
+    """
+    controller_type = "ReactiveQPController"
+    weight_shifter = 0.001   # mu of the eTaSL paper (reactive_qp.py:44)
+
+    def __init__(self, skill_spec, robot_var_weights=None,
+                 virtual_var_weights=None, slack_var_weights=None, options=None):
+        self._handle = None
+        self._lib = None
+        self._has_initial = False
+        self.skill_spec = skill_spec
+        self.robot_var_weights = robot_var_weights
+        self.virtual_var_weights = virtual_var_weights
+        self.slack_var_weights = slack_var_weights
+        self.options = options
+
+    def __del__(self):
+        self._release()
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None and self._lib is not None:
+            try:
+                self._lib.clik_qp_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    # -- weights ------------------------------------------------------------
+    @property
+    def robot_var_weights(self):
+        return self._robot_var_weights
+
+    @robot_var_weights.setter
+    def robot_var_weights(self, weights):
+        self._robot_var_weights = _weights(weights, self.skill_spec.n_robot_var,
+                                           "robot_var_weights")
+
+    @property
+    def virtual_var_weights(self):
+        return self._virtual_var_weights
+
+    @virtual_var_weights.setter
+    def virtual_var_weights(self, weights):
+        self._virtual_var_weights = _weights(weights, self.skill_spec.n_virtual_var,
+                                             "virtual_var_weights")
+
+    @property
+    def slack_var_weights(self):
+        return self._slack_var_weights
+
+    @slack_var_weights.setter
+    def slack_var_weights(self, weights):
+        if weights is None:
+            w = []
+            for cnstr in self.skill_spec.constraints:
+                if cnstr.constraint_type == "soft":
+                    w += [float(cnstr.slack_weight)] * cnstr.expression.size()[0]
+            self._slack_var_weights = np.asarray(w, dtype=float)
+        else:
+            self._slack_var_weights = _weights(weights, self.skill_spec.n_slack_var,
+                                               "slack_var_weights")
+
+    # -- options (reactive_qp.py:141-173) ---------------------------------------
+    @property
+    def options(self):
+        return self._options
+
+    @options.setter
+    def options(self, opt):
+        if opt is None or not isinstance(opt, dict):
+            opt = {}
+        opt.setdefault("solver_name", "qpoases")
+        sopts = opt.setdefault("solver_opts", {})
+        sopts.setdefault("print_time", False)
+        opt.setdefault("initial_solver_opts", sopts)
+        fopts = opt.setdefault("function_opts", {})
+        fopts.setdefault("print_time", False)
+        self._options = opt
+
+    # -- setup ------------------------------------------------------------------
+    def setup_problem_functions(self):
+        """Lower the skill, upload it with the cost weights (replaces the
+        H/A/Blb/Bub ``cs.Function`` objects of reactive_qp.py:262-298)."""
+        self._release()
+        self._lib = _capi.load_library()
+        spec = self.skill_spec
+        self.descriptor = lower_skill(spec)
+        d = self.descriptor
+        cdesc = _capi.desc_to_c(d)
+        state_w = np.concatenate([self._robot_var_weights,
+                                  self._virtual_var_weights[:d.n_x]])
+        if self._slack_var_weights.size != d.n_slack:
+            raise ValueError("slack_var_weights and slack_var dimensions do not match")
+        copts = _capi.qp_opts_to_c(self.weight_shifter, state_w,
+                                   self._slack_var_weights,
+                                   int(self.options.get("max_iter", 0)))
+        self._device = device_of(self.options.get("device"))
+        handle = C.c_void_p()
+        torch = _torch()
+        with torch.cuda.device(self._device):
+            rc = self._lib.clik_qp_create(C.byref(cdesc), C.byref(copts), C.byref(handle))
+        _capi.check(self._lib, rc)
+        self._handle = handle
+        self.n_qp_vars = self._lib.clik_qp_n_vars(handle)
+        self.n_qp_rows = self._lib.clik_qp_n_rows(handle)
+
+    def setup_solver(self):
+        """The solver lives inside the kernel; make sure the handle exists
+        (reference: cs.conic construction, reactive_qp.py:248-260)."""
+        if self._handle is None:
+            self.setup_problem_functions()
+
+    def _require_handle(self):
+        if self._handle is None:
+            raise RuntimeError("call setup_problem_functions() / setup_solver() first")
+
+    def setup_initial_problem_solver(self):
+        """The reference solves a second QP over (virtual_vel, slack) with the
+        robot velocity fixed (reactive_qp.py:300-424); its result is only used
+        as a warm start, which an exact solver does not need.  Kept for call
+        compatibility."""
+        spec = self.skill_spec
+        self._has_initial = (spec.n_slack_var > 0) or (spec.n_virtual_var > 0
+                                                      and spec._has_virtual)
+
+    def solve_initial_problem(self, time_var0, robot_var0, virtual_var0=None,
+                              robot_vel_var0=None, input_var0=None):
+        """Returns (virtual_vel0, slack0) like reactive_qp.py:426-459.  The
+        values come from the full QP at the initial state (the reference fixes
+        robot_vel to ``robot_vel_var0`` and re-optimises the rest); callers
+        use them only as ``warmstart_*`` arguments."""
+        if not self._has_initial:
+            return None, None
+        res = self.solve(time_var0, robot_var0, virtual_var0, input_var0)
+        return res[1], res[2]
+
+    # -- per tick -----------------------------------------------------------------
+    def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
+                    return_status=True):
+        """One QP tick for a batch: returns (robot_vel [B,n_q], virtual_vel |
+        None, slack [B,n_slack] | None, status [B]) - status 0 optimal,
+        1 iteration cap, 2 infeasible (then the velocities are NaN)."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        X = Y = None
+        if d.n_x > 0:
+            if virtual_var is None:
+                raise ValueError("skill has virtual_var: pass virtual_var")
+            X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+        if d.n_y > 0:
+            if input_var is None:
+                raise ValueError("skill has input_var: pass input_var")
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
+        ns = d.n_slack
+        SL = torch.empty((B, ns), dtype=torch.float64, device=dev) if ns else None
+        status = torch.empty((B,), dtype=torch.int32, device=dev) if return_status else None
+        tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_qp_solve_batch(
+                self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
+                ptr(SL), ptr(status), current_stream(dev))
+        _capi.check(self._lib, rc)
+        if was_np:
+            return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),
+                    None if SL is None else SL.cpu().numpy(),
+                    None if status is None else status.cpu().numpy())
+        return dQ, dX, SL, status
+
+    def qp_data_batch(self, time_var, robot_var, virtual_var=None, input_var=None):
+        """H diagonal, A, lbA, ubA per instance - what the reference's
+        H_func/A_func/Blb_func/Bub_func return (reactive_qp.py:483-486)."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        X = Y = None
+        if d.n_x > 0:
+            X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+        if d.n_y > 0:
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        nv, nc = self.n_qp_vars, self.n_qp_rows
+        Hd = torch.empty((B, nv), dtype=torch.float64, device=dev)
+        A = torch.empty((B, nc, nv), dtype=torch.float64, device=dev)
+        lb = torch.empty((B, nc), dtype=torch.float64, device=dev)
+        ub = torch.empty((B, nc), dtype=torch.float64, device=dev)
+        tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_qp_data_batch(
+                self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(Hd), ptr(A),
+                ptr(lb), ptr(ub), current_stream(dev))
+        _capi.check(self._lib, rc)
+        if was_np:
+            return Hd.cpu().numpy(), A.cpu().numpy(), lb.cpu().numpy(), ub.cpu().numpy()
+        return Hd, A, lb, ub
+
+    def solve(self, time_var, robot_var, virtual_var=None, input_var=None,
+              warmstart_robot_vel_var=None, warmstart_virtual_vel_var=None,
+              warmstart_slack_var=None):
+        """Single-instance tick, reference signature and return convention
+        (reactive_qp.py:461-528): ``(robot_vel DM, virtual_vel DM | None,
+        slack DM | None)``; raises RuntimeError when the QP is infeasible (the
+        reference surfaces qpOASES failure as a CasADi RuntimeError)."""
+        spec = self.skill_spec
+        q = _flat(robot_var, spec.n_robot_var, "robot_var")
+        x = y = None
+        if spec.n_virtual_var > 0:
+            x = _flat(virtual_var if virtual_var is not None
+                      else np.zeros(spec.n_virtual_var), spec.n_virtual_var, "virtual_var")
+        if spec.n_input_var > 0:
+            y = _flat(input_var if input_var is not None
+                      else np.zeros(spec.n_input_var), spec.n_input_var, "input_var")
+        dq, dx, slack, status = self.solve_batch(
+            float(_scalar(time_var)), q.reshape(1, -1),
+            None if x is None else x.reshape(1, -1),
+            None if y is None else y.reshape(1, -1))
+        if int(status[0]) != 0:
+            raise RuntimeError("ReactiveQPController: QP %s"
+                               % ("infeasible" if int(status[0]) == 2
+                                  else "hit the iteration cap"))
+        res_robot_vel = cs.DM(dq[0])
+        res_virtual_vel = cs.DM(dx[0]) if (dx is not None and spec._has_virtual) else None
+        res_slack = cs.DM(slack[0]) if slack is not None else None
+        self.res = {"x": cs.DM(np.concatenate(
+            [dq[0]] + ([dx[0]] if dx is not None else [])
+            + ([slack[0]] if slack is not None else [])))}
+        return res_robot_vel, res_virtual_vel, res_slack

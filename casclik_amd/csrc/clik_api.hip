@@ -1,0 +1,382 @@
+// C ABI (include/clik.h) of the MI355X batched CLIK hot path: handle
+// management, descriptor validation, mode table, kernel dispatch.
+//
+// Every entry point replaces a piece of the reference's controller setup/solve:
+//   clik_pinv_create       <- PseudoInverseController.setup_problem_functions
+//                             (pseudo_inverse.py:453-483) + create_activation_map (:107-130)
+//   clik_pinv_solve_batch  <- PseudoInverseController.solve (:512-556)
+//   clik_qp_create         <- ReactiveQPController.setup_problem_functions / setup_solver
+//                             (reactive_qp.py:248-298)
+//   clik_qp_solve_batch    <- ReactiveQPController.solve (:461-528)
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "clik_device.hpp"
+
+namespace clik {
+hipError_t pinv_launch_solve(int N, const DevSkill* dS, const TickArgs& tk, long long B, int ny,
+                             const double* q, const double* x, const double* y, double* dq,
+                             double* dx, int32_t* mode, hipStream_t stream);
+hipError_t pinv_launch_rollout(int N, const DevSkill* dS, const double* d_tterms, int n_ticks,
+                               double dt, double max_speed, long long B, int ny, double* q,
+                               const double* y, double* dq, int32_t* mode, hipStream_t stream);
+int pinv_lds_slots_host(int N, int ny);
+hipError_t qp_launch_solve(int NV, const DevSkill* dS, const TickArgs& tk, long long B,
+                           const double* q, const double* x, const double* y, double* dq,
+                           double* dx, double* slack, int32_t* status, hipStream_t stream);
+hipError_t qp_launch_data(const DevSkill* dS, const TickArgs& tk, long long B, const double* q,
+                          const double* x, const double* y, double* Hd, double* A, double* lb,
+                          double* ub, hipStream_t stream);
+int qp_pick_variant(int n, int nv, int nc);
+}  // namespace clik
+
+using clik::DevSkill;
+using clik::TickArgs;
+
+struct clik_pinv {
+    DevSkill  host;
+    DevSkill* dev;
+    int       N;            // kernel template instance
+    double*   d_tterms;     // rollout workspace
+    size_t    d_tterms_cap;
+};
+
+struct clik_qp {
+    DevSkill  host;
+    DevSkill* dev;
+    int       variant;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hipfail(hipError_t e, const char* what)
+{
+    return fail(CLIK_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+extern "C" const char* clik_last_error(void) { return g_err; }
+extern "C" int32_t clik_abi_version(void) { return CLIK_ABI_VERSION; }
+
+static int popcount32(unsigned v)
+{
+    int c = 0;
+    while (v) { c += v & 1u; v >>= 1; }
+    return c;
+}
+
+// Structural validation shared by both controllers; fills the derived fields.
+static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
+{
+    if (!d) return fail(CLIK_EINVAL, "null skill descriptor");
+    if (d->abi_version != CLIK_ABI_VERSION)
+        return fail(CLIK_EINVAL, "descriptor ABI version %d, library %d", d->abi_version, CLIK_ABI_VERSION);
+    const int n = d->n_q + d->n_x;
+    if (d->n_q < 1 || d->n_x < 0 || n > CLIK_MAX_DOF)
+        return fail(CLIK_EUNSUPPORTED, "n_robot_var + n_virtual_var = %d outside [1, %d]", n, CLIK_MAX_DOF);
+    if (d->n_y < 0) return fail(CLIK_EINVAL, "negative n_y");
+    if (d->n_joints < 0 || d->n_joints > CLIK_MAX_JOINTS)
+        return fail(CLIK_EUNSUPPORTED, "chain has %d joints (limit %d)", d->n_joints, CLIK_MAX_JOINTS);
+    if (d->n_tasks < 0 || d->n_tasks > CLIK_MAX_TASKS)
+        return fail(CLIK_EUNSUPPORTED, "%d constraints (limit %d)", d->n_tasks, CLIK_MAX_TASKS);
+    if (d->n_rows < 0 || d->n_rows > CLIK_MAX_ROWS) return fail(CLIK_EUNSUPPORTED, "too many affine rows");
+    if (d->n_tslots < 0 || d->n_tslots > CLIK_MAX_TSLOTS) return fail(CLIK_EUNSUPPORTED, "too many time slots");
+    if (d->quat_src < 0 || d->quat_src > 2) return fail(CLIK_EINVAL, "bad quat_src");
+    if (d->quat_src == 2)
+        for (int i = 0; i < 4; ++i)
+            if (d->quat_yi[i] < 0 || d->quat_yi[i] >= d->n_y)
+                return fail(CLIK_EINVAL, "orientation target index outside input_var");
+    memset(S, 0, sizeof(*S));
+    S->d = *d;
+    S->n = n;
+    bool any_fk = false, any_o = false;
+    for (int j = 0; j < d->n_joints; ++j) {
+        const clik_joint& jt = d->joints[j];
+        if (jt.type == CLIK_JOINT_FIXED) continue;
+        if (jt.type != CLIK_JOINT_REVOLUTE && jt.type != CLIK_JOINT_PRISMATIC)
+            return fail(CLIK_EINVAL, "joint %d: unknown type %d", j, jt.type);
+        if (jt.q_index < 0 || jt.q_index >= n) return fail(CLIK_EINVAL, "joint %d: q_index out of range", j);
+        if (S->used_mask & (1u << jt.q_index))
+            return fail(CLIK_EUNSUPPORTED, "state variable %d drives two joints", jt.q_index);
+        S->used_mask |= 1u << jt.q_index;
+        if (jt.type == CLIK_JOINT_REVOLUTE) S->rev_mask |= 1u << jt.q_index;
+    }
+    int n_sets = 0, n_slack = 0, n_rows_qp = 0;
+    for (int ti = 0; ti < d->n_tasks; ++ti) {
+        const clik_task& t = d->tasks[ti];
+        if (t.cls < CLIK_CLS_EQ || t.cls > CLIK_CLS_VELSET) return fail(CLIK_EINVAL, "task %d: bad class", ti);
+        if (t.m < 1 || t.m > CLIK_MAX_M)
+            return fail(CLIK_EUNSUPPORTED, "task %d: %d rows (limit %d)", ti, t.m, CLIK_MAX_M);
+        for (int i = 0; i < t.m; ++i) {
+            const int r0 = t.out_row0[i];
+            const int nr = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+            if (t.out_kind[i] != CLIK_OUT_AFFINE && t.out_kind[i] != CLIK_OUT_NORM2)
+                return fail(CLIK_EINVAL, "task %d row %d: bad out_kind", ti, i);
+            if (nr < 0 || r0 < 0 || r0 + nr > d->n_rows) return fail(CLIK_EINVAL, "task %d row %d: row range", ti, i);
+            for (int k = r0; k < r0 + nr; ++k) {
+                const clik_row& r = d->rows[k];
+                if (r.flags & (CLIK_ROW_HAS_P | CLIK_ROW_HAS_R | CLIK_ROW_HAS_O)) any_fk = true;
+                if (r.flags & CLIK_ROW_HAS_O) any_o = true;
+                if ((r.flags & CLIK_ROW_HAS_T) && (r.t_slot < 0 || r.t_slot >= d->n_tslots))
+                    return fail(CLIK_EINVAL, "row %d: t_slot out of range", k);
+                if (r.n_y < 0 || r.n_y > CLIK_MAX_YTERMS) return fail(CLIK_EINVAL, "row %d: n_y", k);
+                for (int q = 0; q < r.n_y; ++q)
+                    if (r.yi[q] < 0 || r.yi[q] >= d->n_y) return fail(CLIK_EINVAL, "row %d: input index", k);
+            }
+        }
+        if (t.cls == CLIK_CLS_SET) ++n_sets;
+        if (t.soft) n_slack += t.m;
+        n_rows_qp += t.m;
+    }
+    if (any_fk && d->n_joints == 0) return fail(CLIK_EINVAL, "rows use the tool frame but the chain is empty");
+    if (any_o && d->quat_src == 0) return fail(CLIK_EINVAL, "rows use the orientation error but no target is set");
+    S->d.uses_fk = any_fk ? 1 : 0;
+    S->n_sets = n_sets;
+    S->n_slack = n_slack;
+    S->n_qp_rows = n_rows_qp;
+    S->n_qp_vars = n + n_slack;
+    return CLIK_OK;
+}
+
+static int pick_N(const DevSkill& S)
+{
+    int need = S.n;
+    for (int ti = 0; ti < S.d.n_tasks; ++ti)
+        if (S.d.tasks[ti].m > need) need = S.d.tasks[ti].m;
+    if (need <= 6) return 6;
+    if (need <= 7) return 7;
+    return 8;
+}
+
+extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts, clik_pinv** out)
+{
+    if (!out) return fail(CLIK_EINVAL, "null out pointer");
+    *out = nullptr;
+    if (!opts) return fail(CLIK_EINVAL, "null options");
+    clik_pinv* h = new (std::nothrow) clik_pinv();
+    if (!h) return fail(CLIK_ENOMEM, "out of host memory");
+    int rc = validate_and_derive(desc, &h->host);
+    if (rc) { delete h; return rc; }
+    DevSkill& S = h->host;
+    S.po = *opts;
+    if (opts->pinv_method != CLIK_PINV_DAMPED && opts->pinv_method != CLIK_PINV_STANDARD) {
+        delete h;
+        return fail(CLIK_EINVAL, "pinv_method must be damped or standard");
+    }
+    if (S.n_sets > CLIK_MAX_SETS) {
+        delete h;
+        return fail(CLIK_EUNSUPPORTED, "%d SetConstraints give 2^%d modes (limit %d sets)", S.n_sets, S.n_sets,
+                    CLIK_MAX_SETS);
+    }
+    for (int ti = 0; ti < S.d.n_tasks; ++ti) {
+        const clik_task& t = S.d.tasks[ti];
+        if (t.cls == CLIK_CLS_SET && t.m > 1 && !opts->multidim_sets) {
+            // same refusal as pseudo_inverse.py:299-312
+            delete h;
+            return fail(CLIK_EUNSUPPORTED,
+                        "PseudoInverseController does not yet have guaranteed stable support for "
+                        "multidimensional SetConstraints (task %d has %d rows). Set the multidim_sets "
+                        "field in options to True for experimental support.", ti, t.m);
+        }
+    }
+    // mode table (pseudo_inverse.py:107-130): bit k <-> k-th SetConstraint in
+    // priority order; patterns stably sorted by the number of active sets
+    S.n_modes = 1 << S.n_sets;
+    {
+        int k = 0;
+        for (int pc = 0; pc <= S.n_sets; ++pc)
+            for (int v = 0; v < S.n_modes; ++v)
+                if (popcount32((unsigned)v) == pc) S.act[k++] = (uint32_t)v;
+    }
+    S.last_set_converges = (S.d.n_tasks > 0 && S.d.tasks[S.d.n_tasks - 1].cls == CLIK_CLS_SET &&
+                            opts->converge_final_set_to_max) ? 1 : 0;
+    h->N = pick_N(S);
+    S.lds_slots = clik::pinv_lds_slots_host(h->N, S.d.n_y);
+    if ((size_t)S.lds_slots * clik::WAVE * sizeof(double) > 160u * 1024u) {
+        delete h;
+        return fail(CLIK_EUNSUPPORTED, "skill needs %d LDS slots per lane (input_var too large)", S.lds_slots);
+    }
+    hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
+    if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
+    e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    h->d_tterms = nullptr;
+    h->d_tterms_cap = 0;
+    *out = h;
+    return CLIK_OK;
+}
+
+extern "C" int clik_pinv_destroy(clik_pinv* h)
+{
+    if (!h) return CLIK_OK;
+    if (h->d_tterms) hipFree(h->d_tterms);
+    if (h->dev) hipFree(h->dev);
+    delete h;
+    return CLIK_OK;
+}
+
+extern "C" int clik_pinv_n_modes(const clik_pinv* h) { return h ? h->host.n_modes : 0; }
+
+static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk)
+{
+    memset(tk, 0, sizeof(*tk));
+    const int nts = S.d.n_tslots;
+    if (nts > 0) {
+        if (!tterms) return fail(CLIK_EINVAL, "skill has %d time slots but tterms is NULL", nts);
+        memcpy(tk->tv, tterms, sizeof(double) * 2 * nts);
+    }
+    return CLIK_OK;
+}
+
+extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double* tterms, const double* q,
+                                     const double* x, const double* y, double* dq, double* dx,
+                                     int32_t* mode, void* stream)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (B < 0) return fail(CLIK_EINVAL, "negative batch size");
+    if (B == 0) return CLIK_OK;
+    const DevSkill& S = h->host;
+    if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
+    if (S.d.n_x > 0 && (!x || !dx)) return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required");
+    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    TickArgs tk;
+    int rc = fill_tick(S, tterms, &tk);
+    if (rc) return rc;
+    hipError_t e = clik::pinv_launch_solve(h->N, h->dev, tk, (long long)B, S.d.n_y, q, x, y, dq, dx, mode,
+                                           (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
+    return CLIK_OK;
+}
+
+extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n_ticks, double dt,
+                                       double max_speed, const double* tterms, double* q, const double* y,
+                                       double* dq, int32_t* mode, void* stream)
+{
+    clik_pinv* h = const_cast<clik_pinv*>(hc);
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
+    if (B == 0 || n_ticks == 0) return CLIK_OK;
+    const DevSkill& S = h->host;
+    if (S.d.n_x > 0) return fail(CLIK_EUNSUPPORTED, "rollout with virtual_var is not supported");
+    if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
+    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    const size_t need = (size_t)n_ticks * 2 * (size_t)S.d.n_tslots;
+    if (need > 0) {
+        if (!tterms) return fail(CLIK_EINVAL, "tterms required");
+        if (need > h->d_tterms_cap) {
+            if (h->d_tterms) hipFree(h->d_tterms);
+            hipError_t e = hipMalloc((void**)&h->d_tterms, need * sizeof(double));
+            if (e != hipSuccess) { h->d_tterms = nullptr; h->d_tterms_cap = 0; return hipfail(e, "hipMalloc(tterms)"); }
+            h->d_tterms_cap = need;
+        }
+        hipError_t e = hipMemcpyAsync(h->d_tterms, tterms, need * sizeof(double), hipMemcpyHostToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
+    }
+    hipError_t e = clik::pinv_launch_rollout(h->N, h->dev, h->d_tterms, n_ticks, dt, max_speed, (long long)B,
+                                             S.d.n_y, q, y, dq, mode, (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "pinv_rollout_kernel launch");
+    return CLIK_OK;
+}
+
+// ---------------------------------------------------------------------------- QP
+extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* opts, clik_qp** out)
+{
+    if (!out) return fail(CLIK_EINVAL, "null out pointer");
+    *out = nullptr;
+    if (!opts) return fail(CLIK_EINVAL, "null options");
+    clik_qp* h = new (std::nothrow) clik_qp();
+    if (!h) return fail(CLIK_ENOMEM, "out of host memory");
+    int rc = validate_and_derive(desc, &h->host);
+    if (rc) { delete h; return rc; }
+    DevSkill& S = h->host;
+    S.qo = *opts;
+    if (S.qo.max_iter <= 0) S.qo.max_iter = 4 * (S.n_qp_rows + S.n_qp_vars) + 16;
+    if (S.n_qp_vars > CLIK_MAX_QPVARS || S.n_qp_rows > CLIK_MAX_QPROWS) {
+        delete h;
+        return fail(CLIK_EUNSUPPORTED, "QP with %d variables x %d rows exceeds the device limits (%d x %d)",
+                    S.n_qp_vars, S.n_qp_rows, CLIK_MAX_QPVARS, CLIK_MAX_QPROWS);
+    }
+    for (int j = 0; j < S.n; ++j)
+        if (!(opts->weight_shifter * opts->state_weights[j] > 0.0)) {
+            delete h;
+            return fail(CLIK_EINVAL, "QP cost weight %d is not positive", j);
+        }
+    h->variant = clik::qp_pick_variant(S.n, S.n_qp_vars, S.n_qp_rows);
+    if (h->variant < 0) {
+        delete h;
+        return fail(CLIK_EUNSUPPORTED, "no QP kernel variant for %d variables x %d rows", S.n_qp_vars, S.n_qp_rows);
+    }
+    hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
+    if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
+    e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    *out = h;
+    return CLIK_OK;
+}
+
+extern "C" int clik_qp_destroy(clik_qp* h)
+{
+    if (!h) return CLIK_OK;
+    if (h->dev) hipFree(h->dev);
+    delete h;
+    return CLIK_OK;
+}
+
+extern "C" int clik_qp_n_vars(const clik_qp* h) { return h ? h->host.n_qp_vars : 0; }
+extern "C" int clik_qp_n_rows(const clik_qp* h) { return h ? h->host.n_qp_rows : 0; }
+
+static int qp_check_args(const clik_qp* h, int64_t B, const double* q, const double* x, const double* y)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (B < 0) return fail(CLIK_EINVAL, "negative batch size");
+    const DevSkill& S = h->host;
+    if (B > 0 && !q) return fail(CLIK_EINVAL, "q must be a device pointer");
+    if (S.d.n_x > 0 && !x) return fail(CLIK_EINVAL, "skill has virtual_var: x required");
+    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    return CLIK_OK;
+}
+
+extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tterms, const double* q,
+                                   const double* x, const double* y, double* dq, double* dx, double* slack,
+                                   int32_t* status, void* stream)
+{
+    int rc = qp_check_args(h, B, q, x, y);
+    if (rc) return rc;
+    if (B == 0) return CLIK_OK;
+    if (!dq) return fail(CLIK_EINVAL, "dq must be a device pointer");
+    TickArgs tk;
+    rc = fill_tick(h->host, tterms, &tk);
+    if (rc) return rc;
+    hipError_t e = clik::qp_launch_solve(h->variant, h->dev, tk, (long long)B, q, x, y, dq, dx, slack, status,
+                                         (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "qp_solve_kernel launch");
+    return CLIK_OK;
+}
+
+extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tterms, const double* q,
+                                  const double* x, const double* y, double* Hdiag, double* A, double* lbA,
+                                  double* ubA, void* stream)
+{
+    int rc = qp_check_args(h, B, q, x, y);
+    if (rc) return rc;
+    if (B == 0) return CLIK_OK;
+    if (!Hdiag || !A || !lbA || !ubA) return fail(CLIK_EINVAL, "output pointers required");
+    TickArgs tk;
+    rc = fill_tick(h->host, tterms, &tk);
+    if (rc) return rc;
+    hipError_t e = clik::qp_launch_data(h->dev, tk, (long long)B, q, x, y, Hdiag, A, lbA, ubA,
+                                        (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "qp_data_kernel launch");
+    return CLIK_OK;
+}

@@ -1,0 +1,440 @@
+// Device-side building blocks of the batched CLIK hot path (gfx950 / wave64).
+//
+// Execution model: ONE ROBOT INSTANCE PER LANE, 64 instances per wavefront.
+// Everything an instance needs per tick (tool frame, geometric Jacobian, the
+// current task Jacobian, Gram factors) lives in that lane's VGPRs with static
+// indexing; the skill descriptor is wave-uniform and is read through scalar
+// loads; LDS holds (a) the coalesced-load staging of the joint state / inputs
+// (transposed so lane l owns instance l) and (b) the dynamically indexed,
+// cold part of the per-instance state (stacked Jacobian rows, Gram matrices).
+// LDS slots are laid out [slot][lane] so every access is bank-conflict free.
+//
+// These are tiny fp64 solves (<= 8x8): no MFMA.  See DESIGN.md for why the
+// lane-per-instance layout is used instead of wave-per-instance.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "clik.h"
+
+namespace clik {
+
+constexpr int WAVE = 64;
+
+// Device-resident skill: descriptor + controller options + derived tables.
+struct DevSkill {
+    clik_skill_desc d;
+    clik_pinv_opts  po;
+    clik_qp_opts    qo;
+    int32_t  n;                       // n_q + n_x
+    int32_t  n_sets;
+    int32_t  n_modes;
+    int32_t  last_set_converges;      // last task is a SetConstraint && converge_final_set_to_max
+    uint32_t act[1 << CLIK_MAX_SETS]; // activation bit masks in mode order (pseudo_inverse.py:107-130)
+    uint32_t used_mask;               // state indices driven by a chain joint
+    uint32_t rev_mask;                // ... that are revolute
+    int32_t  n_slack;
+    int32_t  n_qp_rows;
+    int32_t  n_qp_vars;
+    int32_t  lds_slots;               // doubles per lane of dynamic LDS
+};
+
+// per-tick values / time derivatives of the time-only sub-expressions
+struct TickArgs {
+    double tv[2 * CLIK_MAX_TSLOTS];
+};
+
+__device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }  // k <= i
+
+// uniform (wave-invariant) value -> SGPR
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------
+// LDL^T of a packed symmetric positive definite matrix of runtime size r <= N.
+// In place: strictly lower part <- unit lower factor, diagonal <- d_k;
+// rd[k] = 1/d_k.  Loops are fully unrolled with wave-uniform guards so every
+// index is static (registers, not scratch).
+template <int N>
+__device__ __forceinline__ void ldl_factor(double (&A)[N * (N + 1) / 2], double (&rd)[N], int r)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (k < r) {
+            double t[N];
+            double d = A[tri(k, k)];
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                t[j] = A[tri(k, j)] * A[tri(j, j)];
+                d = fma(-A[tri(k, j)], t[j], d);
+            }
+            A[tri(k, k)] = d;
+            const double inv = 1.0 / d;
+            rd[k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                if (i < r) {
+                    double s = A[tri(i, k)];
+#pragma unroll
+                    for (int j = 0; j < k; ++j) s = fma(-A[tri(i, j)], t[j], s);
+                    A[tri(i, k)] = s * inv;
+                }
+            }
+        }
+    }
+}
+
+// x <- A^{-1} x with the factor above.
+template <int N>
+__device__ __forceinline__ void ldl_solve(const double (&A)[N * (N + 1) / 2], const double (&rd)[N],
+                                          double (&x)[N], int r)
+{
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        if (i < r) {
+#pragma unroll
+            for (int j = 0; j < i; ++j) x[i] = fma(-A[tri(i, j)], x[j], x[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < r) x[i] *= rd[i];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) {
+        if (i < r) {
+#pragma unroll
+            for (int j = i + 1; j < N; ++j)
+                if (j < r) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-lane kinematic state of the skill's serial chain.
+template <int N>
+struct Kin {
+    double p[3];       // tool position
+    double R[9];       // tool rotation, row-major
+    double Jv[3][N];   // d p / d z_j
+    double Jw[3][N];   // angular Jacobian columns (world joint axes)
+    double o[3];       // orientation error 1/2 sum_c r_c x rd_c
+    double M[9];       // R * Rd^T
+    double tr;         // trace(Rd^T R)
+};
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Forward kinematics + geometric Jacobian.  URDF convention
+//   T = prod_j Trans(p_j) R_j [Rot(axis_j, z[q_j]) | Trans(axis_j z[q_j])]
+// (what urdf2casadi's converter.from_file builds for the reference,
+// ur5_moe2016_example2.ipynb:47).  `zs` is the LDS copy of the state
+// ([slot][lane]) used for the dynamically indexed joint value; `fr` is LDS
+// scratch (6*N slots) for per-joint axis/origin, also dynamically indexed.
+template <int N>
+__device__ __forceinline__ void forward_kinematics(const DevSkill* __restrict__ S, const double* zs,
+                                                   double* fr, int lane, Kin<N>& K)
+{
+    const clik_skill_desc& D = S->d;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double p[3] = {0, 0, 0};
+    const int nj = D.n_joints;
+    for (int j = 0; j < nj; ++j) {
+        const clik_joint& jt = D.joints[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            p[i] = fma(R[3 * i], jt.p[0], fma(R[3 * i + 1], jt.p[1], fma(R[3 * i + 2], jt.p[2], p[i])));
+        double T[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                T[3 * i + c] = R[3 * i] * jt.R[c] + R[3 * i + 1] * jt.R[3 + c] + R[3 * i + 2] * jt.R[6 + c];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = T[i];
+        const int type = jt.type;
+        if (type != CLIK_JOINT_FIXED) {
+            const int qi = jt.q_index;
+            double ax[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                ax[i] = R[3 * i] * jt.axis[0] + R[3 * i + 1] * jt.axis[1] + R[3 * i + 2] * jt.axis[2];
+            double* f = fr + (size_t)(6 * qi) * WAVE + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f[i * WAVE] = ax[i];
+                f[(3 + i) * WAVE] = p[i];
+            }
+            const double ang = zs[qi * WAVE + lane];
+            if (type == CLIK_JOINT_REVOLUTE) {
+                double s, c;
+                sincos(ang, &s, &c);
+                const double C = 1.0 - c;
+                const double x = jt.axis[0], y = jt.axis[1], z = jt.axis[2];
+                const double m[9] = {c + x * x * C, x * y * C - z * s, x * z * C + y * s,
+                                     y * x * C + z * s, c + y * y * C, y * z * C - x * s,
+                                     z * x * C - y * s, z * y * C + x * s, c + z * z * C};
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc)
+                        T[3 * i + cc] = R[3 * i] * m[cc] + R[3 * i + 1] * m[3 + cc] + R[3 * i + 2] * m[6 + cc];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) R[i] = T[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) p[i] = fma(ax[i], ang, p[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) K.R[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) K.p[i] = p[i];
+    const uint32_t used = S->used_mask, rev = S->rev_mask;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double ax[3] = {0, 0, 0}, org[3] = {0, 0, 0};
+        const bool is_used = (used >> j) & 1u;
+        const bool is_rev = (rev >> j) & 1u;
+        if (is_used) {
+            const double* f = fr + (size_t)(6 * j) * WAVE + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ax[i] = f[i * WAVE];
+                org[i] = f[(3 + i) * WAVE];
+            }
+        }
+        if (is_used && is_rev) {
+            const double r[3] = {p[0] - org[0], p[1] - org[1], p[2] - org[2]};
+            double v[3];
+            cross3(ax, r, v);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                K.Jv[i][j] = v[i];
+                K.Jw[i][j] = ax[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                K.Jv[i][j] = ax[i];     // prismatic: axis; unused: 0
+                K.Jw[i][j] = 0.0;
+            }
+        }
+    }
+}
+
+// Orientation feature  o = 1/2 sum_c r_c x rd_c  w.r.t. the skill's target
+// quaternion (constant or from input_var); M = R Rd^T and tr = trace(Rd^T R)
+// give its Jacobian in closed form:  d o / d z_j = -1/2 (tr I - M) Jw[:,j].
+template <int N>
+__device__ __forceinline__ void orientation_feature(const DevSkill* __restrict__ S, const double* ys,
+                                                    int lane, Kin<N>& K)
+{
+    const clik_skill_desc& D = S->d;
+    double q[4];
+    if (D.quat_src == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = ys[D.quat_yi[i] * WAVE + lane];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = D.quat[i];
+    }
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double Rd[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                          2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                          2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    const double* R = K.R;
+    K.o[0] = K.o[1] = K.o[2] = 0.0;
+    double tr = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double rc[3] = {R[c], R[3 + c], R[6 + c]};
+        const double dc[3] = {Rd[c], Rd[3 + c], Rd[6 + c]};
+        double v[3];
+        cross3(rc, dc, v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) K.o[i] = fma(0.5, v[i], K.o[i]);
+        tr += rc[0] * dc[0] + rc[1] * dc[1] + rc[2] * dc[2];
+    }
+    K.tr = tr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            K.M[3 * i + k] = R[3 * i] * Rd[3 * k] + R[3 * i + 1] * Rd[3 * k + 1] + R[3 * i + 2] * Rd[3 * k + 2];
+}
+
+// Value, state gradient and time derivative of one affine row (clik_row).
+template <int N>
+__device__ __forceinline__ double row_eval(const DevSkill* __restrict__ S, const clik_row& r,
+                                           const TickArgs& tk, const Kin<N>& K, const double (&z)[N],
+                                           const double* ys, int lane, int n, double (&g)[N], double& dt)
+{
+    const int flags = r.flags;
+    double v = r.c;
+    dt = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = 0.0;
+    if (flags & CLIK_ROW_HAS_Q) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j < n) {
+                const double a = r.a[j];
+                g[j] = a;
+                v = fma(a, z[j], v);
+            }
+        }
+    }
+    double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
+    bool fk = false;
+    if (flags & CLIK_ROW_HAS_P) {
+        fk = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lin[i] = r.b[i];
+            v = fma(r.b[i], K.p[i], v);
+        }
+    }
+    if (flags & CLIK_ROW_HAS_R) {
+        fk = true;
+        // d(sum_ic g_ic R_ic)/dz_j = Jw[:,j] . sum_c (r_c x g_c)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double rc[3] = {K.R[c], K.R[3 + c], K.R[6 + c]};
+            const double gc[3] = {r.g[c], r.g[3 + c], r.g[6 + c]};
+            double u[3];
+            cross3(rc, gc, u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ang[i] += u[i];
+                v = fma(gc[i], rc[i], v);
+            }
+        }
+    }
+    if (flags & CLIK_ROW_HAS_O) {
+        fk = true;
+        // d(h.o)/dz_j = Jw[:,j] . ( -1/2 (tr h - M^T h) )
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double mh = K.M[i] * r.h[0] + K.M[3 + i] * r.h[1] + K.M[6 + i] * r.h[2];
+            ang[i] += -0.5 * (K.tr * r.h[i] - mh);
+            v = fma(r.h[i], K.o[i], v);
+        }
+    }
+    if (fk) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j < n) {
+                double s = g[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) s = fma(K.Jv[i][j], lin[i], fma(K.Jw[i][j], ang[i], s));
+                g[j] = s;
+            }
+        }
+    }
+    if (flags & CLIK_ROW_HAS_Y) {
+        const int ny = r.n_y;
+        for (int k = 0; k < ny; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
+    }
+    if (flags & CLIK_ROW_HAS_T) {
+        const int slot = r.t_slot;
+        v += tk.tv[slot];
+        dt = tk.tv[S->d.n_tslots + slot];
+    }
+    return v;
+}
+
+// e (m), J (m x n) and d e/d t of constraint `ti`: the numeric content of the
+// reference's cnstr.expression / cnstr.jacobian(state) / cnstr.jacobian(time)
+// (pseudo_inverse.py:285-286, reactive_qp.py:210-216).
+template <int N, int M>
+__device__ __forceinline__ void task_eval(const DevSkill* __restrict__ S, int ti, const TickArgs& tk,
+                                          const Kin<N>& K, const double (&z)[N], const double* ys,
+                                          int lane, int n, double (&e)[M], double (&J)[M][N],
+                                          double (&Jt)[M])
+{
+    const clik_task& t = S->d.tasks[ti];
+    const int m = t.m;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        if (i < m) {
+            const int row0 = t.out_row0[i];
+            if (t.out_kind[i] == CLIK_OUT_AFFINE) {
+                double g[N], dt;
+                e[i] = row_eval<N>(S, S->d.rows[row0], tk, K, z, ys, lane, n, g, dt);
+                Jt[i] = dt;
+#pragma unroll
+                for (int j = 0; j < N; ++j) J[i][j] = g[j];
+            } else {
+                double ss = 0.0, tacc = 0.0, acc[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc[j] = 0.0;
+                const int nr = t.out_nrows[i];
+                for (int k = 0; k < nr; ++k) {
+                    double g[N], dt;
+                    const double v = row_eval<N>(S, S->d.rows[row0 + k], tk, K, z, ys, lane, n, g, dt);
+                    ss = fma(v, v, ss);
+                    tacc = fma(v, dt, tacc);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc[j] = fma(v, g[j], acc[j]);
+                }
+                const double nrm = sqrt(ss);
+                const double inv = 1.0 / nrm;
+                e[i] = nrm;
+                Jt[i] = tacc * inv;
+#pragma unroll
+                for (int j = 0; j < N; ++j) J[i][j] = acc[j] * inv;
+            }
+        }
+    }
+}
+
+// gain * v  (float or m x m matrix gain, constraints.py:32-65)
+template <int M>
+__device__ __forceinline__ void gain_apply(const clik_task& t, const double (&v)[M], double (&out)[M])
+{
+    const int m = t.m;
+    if (!t.gain_is_matrix) {
+        const double g = t.gain[0];
+#pragma unroll
+        for (int i = 0; i < M; ++i) out[i] = (i < m) ? g * v[i] : 0.0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double s = 0.0;
+            if (i < m) {
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+                    if (k < m) s = fma(t.gain[i * m + k], v[k], s);
+            }
+            out[i] = s;
+        }
+    }
+}
+
+// Cooperative, fully coalesced load of the wave's [64][w] row-major block into
+// LDS transposed to [w][64] (lane l then owns row l).  rows_valid <= 64.
+__device__ __forceinline__ void stage_in(const double* __restrict__ g, int w, int rows_valid,
+                                         double* lds, int lane)
+{
+    const int total = rows_valid * w;
+    for (int k = lane; k < total; k += WAVE) {
+        const int r = k / w, c = k - r * w;
+        lds[c * WAVE + r] = g[k];
+    }
+}
+
+__device__ __forceinline__ void stage_out(double* __restrict__ g, int w, int rows_valid,
+                                          const double* lds, int lane)
+{
+    const int total = rows_valid * w;
+    for (int k = lane; k < total; k += WAVE) {
+        const int r = k / w, c = k - r * w;
+        g[k] = lds[c * WAVE + r];
+    }
+}
+
+}  // namespace clik

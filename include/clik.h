@@ -1,0 +1,222 @@
+/*
+ * clik.h - C ABI of the MI355X batched CLIK hot path.
+ *
+ * Drop-in boundary for the per-tick solve of the reference controllers:
+ *   - PseudoInverseController.solve      casclik/controllers/pseudo_inverse.py:512-556
+ *     (evaluating the per-mode functions built at :259-483)
+ *   - ReactiveQPController.solve         casclik/controllers/reactive_qp.py:461-528
+ *     (H/A/lbA/ubA functions built at :175-298, qpOASES call at :491-513)
+ *
+ * In the reference that boundary is the CasADi-generated JIT C
+ * (`int f(const double** arg, double** res, casadi_int* iw, double* w, int mem)`,
+ * dense column-major doubles, caller-owned memory) plus `cs.conic`.  Here the
+ * symbolic setup is replaced by a flat POD "skill descriptor" and the per-tick
+ * call by one stream-ordered batched launch.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions; every entry returns
+ *     0 on success and a negative CLIK_E* code otherwise; clik_last_error()
+ *     gives the message of the calling thread's last failure.
+ *   - All batch buffers are DEVICE pointers, row-major [B][n] fp64 (what
+ *     numpy / torch hand out).  The caller owns every buffer; the library owns
+ *     only the handle (a device-resident copy of the descriptor).
+ *   - `tterms` is a HOST pointer to 2*n_tslots doubles (values then time
+ *     derivatives of the skill's time-only sub-expressions at this tick); it is
+ *     copied into the kernel arguments, so the call stays graph-capturable.
+ *   - Handles are immutable after creation: solve calls are re-entrant across
+ *     streams.  Calls are asynchronous w.r.t. the host (no hidden sync).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream) so this
+ *     header needs no HIP include.
+ */
+#ifndef CLIK_H
+#define CLIK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIK_ABI_VERSION 1
+
+#define CLIK_MAX_DOF      8   /* n_state = n_robot_var + n_virtual_var            */
+#define CLIK_MAX_JOINTS  12   /* chain joints, fixed ones included                */
+#define CLIK_MAX_TASKS   16   /* constraints per skill                            */
+#define CLIK_MAX_M        8   /* rows of one constraint expression                */
+#define CLIK_MAX_ROWS    96   /* affine rows over all constraints                 */
+#define CLIK_MAX_SETS     6   /* SetConstraints -> 2^6 modes                      */
+#define CLIK_MAX_TSLOTS  32   /* time-only sub-expressions evaluated by the host  */
+#define CLIK_MAX_YTERMS   4   /* input_var terms per affine row                   */
+#define CLIK_MAX_QPVARS  24   /* n_state + n_slack of the reactive QP             */
+#define CLIK_MAX_QPROWS  32   /* constraint rows of the reactive QP               */
+
+/* error codes */
+#define CLIK_OK            0
+#define CLIK_EINVAL       -1  /* malformed descriptor / argument                  */
+#define CLIK_EUNSUPPORTED -2  /* valid reference skill outside the device limits  */
+#define CLIK_EHIP         -3  /* HIP runtime failure                              */
+#define CLIK_ENOMEM       -4
+
+/* joint types (URDF chain:  T_i = Trans(p) * R * Rot(axis, q) | Trans(axis*q)) */
+#define CLIK_JOINT_FIXED     0
+#define CLIK_JOINT_REVOLUTE  1
+#define CLIK_JOINT_PRISMATIC 2
+
+typedef struct clik_joint {
+    int32_t type;
+    int32_t q_index;          /* index into the state vector, -1 for fixed        */
+    double  R[9];             /* origin rotation RPY(rpy), row-major              */
+    double  p[3];             /* origin translation xyz                           */
+    double  axis[3];          /* unit joint axis in the joint frame               */
+} clik_joint;
+
+/* One affine row over the task features
+ *      r = a.z + b.p(z) + g.vec(R(z)) + h.o(z,y) + sum_k yc[k]*y[yi[k]] + c + tval[t_slot]
+ * z = [robot_var; virtual_var], p / R = tool position / rotation (row-major
+ * vec), o = orientation error 1/2 sum_i r_i x r_i,des w.r.t. the skill's
+ * quaternion target.  Replaces the user's CasADi expression graph
+ * (casclik/constraints.py:21-24) for the affine-in-features family. */
+#define CLIK_ROW_HAS_Q 1
+#define CLIK_ROW_HAS_P 2
+#define CLIK_ROW_HAS_R 4
+#define CLIK_ROW_HAS_O 8
+#define CLIK_ROW_HAS_Y 16
+#define CLIK_ROW_HAS_T 32
+
+typedef struct clik_row {
+    double  a[CLIK_MAX_DOF];
+    double  b[3];
+    double  g[9];
+    double  h[3];
+    double  c;
+    double  yc[CLIK_MAX_YTERMS];
+    int32_t yi[CLIK_MAX_YTERMS];
+    int32_t n_y;
+    int32_t t_slot;           /* -1: none                                         */
+    int32_t flags;            /* CLIK_ROW_HAS_*                                   */
+    int32_t _pad;
+} clik_row;
+
+/* how output row i of a constraint is formed from affine rows */
+#define CLIK_OUT_AFFINE 0     /* e_i = r[row0]                                    */
+#define CLIK_OUT_NORM2  1     /* e_i = || r[row0 .. row0+nrows) ||_2              */
+
+/* constraint classes (casclik/constraints.py:88,148,299,336) */
+#define CLIK_CLS_EQ     0
+#define CLIK_CLS_SET    1
+#define CLIK_CLS_VELEQ  2
+#define CLIK_CLS_VELSET 3
+
+typedef struct clik_task {
+    int32_t cls;
+    int32_t m;                          /* expression rows                        */
+    int32_t soft;                       /* constraint_type == "soft"              */
+    int32_t gain_is_matrix;             /* 0: scalar gain[0]; 1: m x m row-major  */
+    int32_t out_kind[CLIK_MAX_M];
+    int32_t out_row0[CLIK_MAX_M];
+    int32_t out_nrows[CLIK_MAX_M];
+    double  gain[CLIK_MAX_M * CLIK_MAX_M];
+    double  set_min[CLIK_MAX_M];
+    double  set_max[CLIK_MAX_M];
+    double  target[CLIK_MAX_M];         /* VelocityEqualityConstraint.target      */
+    double  slack_weight;
+} clik_task;
+
+typedef struct clik_skill_desc {
+    int32_t abi_version;                /* CLIK_ABI_VERSION                       */
+    int32_t n_q;                        /* robot_var size                         */
+    int32_t n_x;                        /* virtual_var size (state = [q; x])      */
+    int32_t n_y;                        /* input_var size (0: none)               */
+    int32_t n_joints;
+    int32_t n_tasks;                    /* constraints, already priority-sorted   */
+    int32_t n_rows;
+    int32_t n_tslots;
+    int32_t uses_fk;                    /* any row with P / R / O features        */
+    int32_t quat_src;                   /* orientation target: 0 none, 1 const, 2 input */
+    int32_t quat_yi[4];                 /* indices (x,y,z,w) into y when quat_src==2 */
+    double  quat[4];                    /* (x,y,z,w) when quat_src==1             */
+    clik_joint joints[CLIK_MAX_JOINTS];
+    clik_task  tasks[CLIK_MAX_TASKS];
+    clik_row   rows[CLIK_MAX_ROWS];
+} clik_skill_desc;
+
+/* options of PseudoInverseController (pseudo_inverse.py:42-66) */
+#define CLIK_PINV_DAMPED   0
+#define CLIK_PINV_STANDARD 1
+typedef struct clik_pinv_opts {
+    int32_t feedforward;                /* default 1                              */
+    int32_t multidim_sets;              /* default 0                              */
+    int32_t converge_final_set_to_max;  /* default 0                              */
+    int32_t pinv_method;                /* default CLIK_PINV_DAMPED               */
+    double  damping_factor;             /* default 1e-7                           */
+} clik_pinv_opts;
+
+/* cost weights of ReactiveQPController (reactive_qp.py:44,58-133,175-189) */
+typedef struct clik_qp_opts {
+    double  weight_shifter;             /* mu, default 1e-3                       */
+    double  state_weights[CLIK_MAX_DOF];      /* robot then virtual weights       */
+    double  slack_weights[CLIK_MAX_QPROWS];   /* one per soft row, in row order   */
+    int32_t max_iter;                   /* active-set iteration cap (0: default)  */
+    int32_t _pad;
+} clik_qp_opts;
+
+typedef struct clik_pinv clik_pinv;     /* opaque handles                         */
+typedef struct clik_qp   clik_qp;
+
+const char* clik_last_error(void);
+int32_t     clik_abi_version(void);
+
+/* ---- PseudoInverseController path -------------------------------------- */
+/* replaces setup_problem_functions() (pseudo_inverse.py:453-483): validates the
+ * skill, builds the mode table (:107-130) and uploads the descriptor.        */
+int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts,
+                     clik_pinv** out);
+int clik_pinv_destroy(clik_pinv* h);
+int clik_pinv_n_modes(const clik_pinv* h);
+
+/* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
+ *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)
+ *   dq [B][n_q]   dx [B][n_x] or NULL                           (device, out)
+ *   mode [B] int32 or NULL: accepted mode index, -1 if none (then dq = 0)   */
+int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double* tterms,
+                          const double* q, const double* x, const double* y,
+                          double* dq, double* dx, int32_t* mode, void* stream);
+
+/* "next" row: n_ticks of solve -> clamp(+-max_speed) ->
+ * explicit Euler q += dq*dt inside one launch, the loop every notebook runs
+ * on the host (ur5_moe2016_example2.ipynb:537-545).  tterms holds
+ * n_ticks*2*n_tslots doubles (host).  q is updated in place; dq/mode receive
+ * the last tick.  max_speed <= 0 disables the clamp.                        */
+int clik_pinv_rollout_batch(const clik_pinv* h, int64_t B, int32_t n_ticks,
+                            double dt, double max_speed, const double* tterms,
+                            double* q, const double* y, double* dq,
+                            int32_t* mode, void* stream);
+
+/* ---- ReactiveQPController path ----------------------------------------- */
+/* replaces setup_problem_functions()+setup_solver() (reactive_qp.py:248-298) */
+int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* opts,
+                   clik_qp** out);
+int clik_qp_destroy(clik_qp* h);
+int clik_qp_n_vars(const clik_qp* h);   /* n_state + n_slack                     */
+int clik_qp_n_rows(const clik_qp* h);
+
+/* replaces solve() (reactive_qp.py:461-528).
+ *   dq [B][n_q], dx [B][n_x] or NULL, slack [B][n_slack] or NULL  (device, out)
+ *   status [B] int32 or NULL: 0 optimal, 1 iteration cap, 2 infeasible       */
+int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tterms,
+                        const double* q, const double* x, const double* y,
+                        double* dq, double* dx, double* slack, int32_t* status,
+                        void* stream);
+
+/* QP data only (H diag, A, lbA, ubA as the reference's H_func/A_func/Blb/Bub,
+ * reactive_qp.py:283-298) for inspection and parity tests:
+ *   Hdiag [B][nv], A [B][nc][nv] row-major, lbA [B][nc], ubA [B][nc]          */
+int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tterms,
+                       const double* q, const double* x, const double* y,
+                       double* Hdiag, double* A, double* lbA, double* ubA,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIK_H */

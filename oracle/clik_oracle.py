@@ -1,0 +1,723 @@
+"""CPU ORACLE - TEST INFRASTRUCTURE ONLY.  Never imported by casclik_amd.
+
+Line-by-line fp64 numpy restatement of the reference's per-tick hot path:
+
+  * PseudoInverseController   /root/reference/casclik/controllers/pseudo_inverse.py
+      pinv                       :92-105
+      create_activation_map      :107-130
+      in-tangent-cone (1-D)      :132-190
+      in-tangent-cone (multidim) :192-257
+      get_problem_expressions    :259-451   (incl. the first-equality double
+                                             processing :317-326 + :382-396)
+      solve (mode scan)          :512-556
+  * ReactiveQPController      /root/reference/casclik/controllers/reactive_qp.py
+      get_cost_expr              :175-189
+      get_constraints_expr       :191-246
+      solve / result slicing     :461-528
+
+PARITY UNPINNED: the reference is pure Python on top of casadi==3.4.1
+(requirements.txt:1) and urdf2casadi (un-vendored, unpinned); neither exists in
+the build container nor on the GPU box, and the reference ships no tests or
+golden outputs for ``solve()``.  What pins this
+restatement instead: the UR5 forward-kinematics KAT stored in the notebooks
+(||p_tool0|| = 1.0192 at home), the constraint-order printouts, algebraic
+invariants of the damped pseudo-inverse, KKT optimality of every QP answer,
+and agreement of the AD Jacobians below with finite differences.
+
+CasADi's algorithmic differentiation (``cs.jacobian``, constraints.py:67-73) is
+restated as forward-mode dual numbers over the same expression trees the
+product lowers to its device tables, so the oracle does NOT share the
+product's lowering or its closed-form geometric Jacobians.  ``cs.solve`` is
+restated as ``numpy.linalg.solve`` (LU with partial pivoting); CasADi's own
+linear solver differs in rounding, which is why parity is stated with a
+tolerance (tests/tolerances.py).
+
+Everything is vectorised over the instance batch where that is natural (the
+expression evaluation); the controller algebra loops over instances.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+
+# ==========================================================================
+# forward-mode AD over casclik_amd.sym scalar trees
+# ==========================================================================
+class Dual(object):
+    """value [B] and derivative [B, nd] w.r.t. (t, z_0..z_{n-1})."""
+    __slots__ = ("v", "d")
+
+    def __init__(self, v, d):
+        self.v = v
+        self.d = d
+
+    @staticmethod
+    def const(val, B, nd):
+        return Dual(np.full(B, float(val)), np.zeros((B, nd)))
+
+    def __add__(self, o):
+        return Dual(self.v + o.v, self.d + o.d)
+
+    def __sub__(self, o):
+        return Dual(self.v - o.v, self.d - o.d)
+
+    def __mul__(self, o):
+        return Dual(self.v * o.v, self.d * o.v[:, None] + o.d * self.v[:, None])
+
+    def __truediv__(self, o):
+        q = self.v / o.v
+        return Dual(q, (self.d - o.d * q[:, None]) / o.v[:, None])
+
+    def __neg__(self):
+        return Dual(-self.v, -self.d)
+
+    def scale(self, k):
+        return Dual(self.v * k, self.d * k)
+
+
+def _d_unary(x, f, df):
+    return Dual(f(x.v), x.d * df(x.v)[:, None])
+
+
+def _rpy_like_rot(axis, ang):
+    """Rodrigues rotation with Dual angle -> 3x3 list of Duals."""
+    x, y, z = axis
+    c = _d_unary(ang, np.cos, lambda v: -np.sin(v))
+    s = _d_unary(ang, np.sin, np.cos)
+    B, nd = ang.d.shape
+    one = Dual.const(1.0, B, nd)
+    C = one - c
+    def k(val):
+        return Dual.const(val, B, nd)
+    return [[c + C.scale(x * x), C.scale(x * y) - s.scale(z), C.scale(x * z) + s.scale(y)],
+            [C.scale(y * x) + s.scale(z), c + C.scale(y * y), C.scale(y * z) - s.scale(x)],
+            [C.scale(z * x) - s.scale(y), C.scale(z * y) + s.scale(x), c + C.scale(z * z)]]
+
+
+def _fk_dual(chain, qd, B, nd):
+    """Chain product  T = prod_j Trans(p_j) R_j Rot(axis_j, q_j)  with Dual
+    joint values (URDF convention).  Returns 3x3 R and
+    3-vector p as lists of Duals."""
+    R = [[Dual.const(1.0 if i == j else 0.0, B, nd) for j in range(3)] for i in range(3)]
+    p = [Dual.const(0.0, B, nd) for _ in range(3)]
+    for jt in chain.joints:
+        Rf = np.asarray(jt.R, dtype=float)
+        pf = np.asarray(jt.p, dtype=float)
+        # p <- p + R * pf ;  R <- R * Rf
+        p = [p[i] + R[i][0].scale(pf[0]) + R[i][1].scale(pf[1]) + R[i][2].scale(pf[2])
+             for i in range(3)]
+        R = [[R[i][0].scale(Rf[0, j]) + R[i][1].scale(Rf[1, j]) + R[i][2].scale(Rf[2, j])
+              for j in range(3)] for i in range(3)]
+        if jt.type == 1:      # revolute
+            M = _rpy_like_rot(jt.axis, qd[jt.q_index])
+            R = [[R[i][0] * M[0][j] + R[i][1] * M[1][j] + R[i][2] * M[2][j]
+                  for j in range(3)] for i in range(3)]
+        elif jt.type == 2:    # prismatic
+            ax = jt.axis
+            d = qd[jt.q_index]
+            p = [p[i] + (R[i][0].scale(ax[0]) + R[i][1].scale(ax[1]) + R[i][2].scale(ax[2])) * d
+                 for i in range(3)]
+    return R, p
+
+
+def _quat_rot_dual(q4, B, nd):
+    x, y, z, w = q4
+    one = Dual.const(1.0, B, nd)
+    two = 2.0
+    return [[one - (y * y + z * z).scale(two), (x * y - z * w).scale(two), (x * z + y * w).scale(two)],
+            [(x * y + z * w).scale(two), one - (x * x + z * z).scale(two), (y * z - x * w).scale(two)],
+            [(x * z - y * w).scale(two), (y * z + x * w).scale(two), one - (x * x + y * y).scale(two)]]
+
+
+class ExprEvaluator(object):
+    """Evaluates expression trees for a batch with derivatives w.r.t.
+    (time, state).  ``env`` maps id(SymFamily) -> ('t'|'z'|'y', offset)."""
+
+    def __init__(self, spec, t, Z, Y):
+        self.B = Z.shape[0]
+        self.n = Z.shape[1]
+        self.nd = 1 + self.n
+        B, nd = self.B, self.nd
+        self.memo = {}
+        self.bind = {}
+        tt = np.broadcast_to(np.asarray(t, dtype=float).reshape(-1), (B,)) \
+            if np.ndim(t) else np.full(B, float(t))
+        def fam(var):
+            if var is None or var._a.size == 0:
+                return None
+            return next(s.family for s in var._a.flat)
+        f_t, f_q, f_x, f_y = fam(spec.time_var), fam(spec.robot_var), \
+            fam(spec.virtual_var), fam(spec.input_var)
+        if f_t is not None:
+            d = np.zeros((B, nd)); d[:, 0] = 1.0
+            self.bind[id(f_t)] = [Dual(tt.copy(), d)]
+        zs = []
+        for k in range(self.n):
+            d = np.zeros((B, nd)); d[:, 1 + k] = 1.0
+            zs.append(Dual(Z[:, k].astype(float).copy(), d))
+        nq = spec.n_robot_var
+        self.bind[id(f_q)] = zs[:nq]
+        if f_x is not None:
+            self.bind[id(f_x)] = zs[nq:]
+        if f_y is not None:
+            if Y is None:
+                raise ValueError("skill has input_var but no input values given")
+            self.bind[id(f_y)] = [Dual(Y[:, k].astype(float).copy(), np.zeros((B, nd)))
+                                  for k in range(Y.shape[1])]
+
+    def ev(self, s):
+        k = id(s)
+        if k in self.memo:
+            return self.memo[k]
+        B, nd = self.B, self.nd
+        op = s.op
+        if op == "const":
+            r = Dual.const(s.value, B, nd)
+        elif op == "sym":
+            try:
+                r = self.bind[id(s.family)][s.index]
+            except KeyError:
+                raise ValueError("unbound symbol %s" % s.name)
+        elif op == "fk":
+            chain, i, j = s.aux
+            ck = ("fk", id(chain), tuple(id(a) for a in s.args))
+            if ck not in self.memo:
+                qd = [self.ev(a) for a in s.args]
+                self.memo[ck] = _fk_dual(chain, qd, B, nd)
+            R, p = self.memo[ck]
+            r = p[i] if j == 3 else R[i][j]
+        elif op == "ori_err":
+            ck = ("ori", tuple(id(a) for a in s.args))
+            if ck not in self.memo:
+                a = [self.ev(x) for x in s.args]
+                R = [a[0:3], a[3:6], a[6:9]]
+                Rd = _quat_rot_dual(a[9:13], B, nd)
+                e = [Dual.const(0.0, B, nd) for _ in range(3)]
+                for c in range(3):          # e += 1/2 * r_c x rd_c  (columns)
+                    rc = [R[0][c], R[1][c], R[2][c]]
+                    dc = [Rd[0][c], Rd[1][c], Rd[2][c]]
+                    e[0] = e[0] + (rc[1] * dc[2] - rc[2] * dc[1]).scale(0.5)
+                    e[1] = e[1] + (rc[2] * dc[0] - rc[0] * dc[2]).scale(0.5)
+                    e[2] = e[2] + (rc[0] * dc[1] - rc[1] * dc[0]).scale(0.5)
+                self.memo[ck] = e
+            r = self.memo[ck][s.aux]
+        else:
+            a = [self.ev(x) for x in s.args]
+            if op == "add":
+                r = a[0] + a[1]
+            elif op == "sub":
+                r = a[0] - a[1]
+            elif op == "mul":
+                r = a[0] * a[1]
+            elif op == "div":
+                r = a[0] / a[1]
+            elif op == "neg":
+                r = -a[0]
+            elif op == "sin":
+                r = _d_unary(a[0], np.sin, np.cos)
+            elif op == "cos":
+                r = _d_unary(a[0], np.cos, lambda v: -np.sin(v))
+            elif op == "tan":
+                r = _d_unary(a[0], np.tan, lambda v: 1.0 / np.cos(v) ** 2)
+            elif op == "sqrt":
+                r = _d_unary(a[0], np.sqrt, lambda v: 0.5 / np.sqrt(v))
+            elif op == "exp":
+                r = _d_unary(a[0], np.exp, np.exp)
+            elif op == "log":
+                r = _d_unary(a[0], np.log, lambda v: 1.0 / v)
+            elif op == "fabs":
+                r = _d_unary(a[0], np.abs, np.sign)
+            elif op == "sign":
+                r = Dual(np.sign(a[0].v), np.zeros((B, nd)))
+            elif op == "pow":
+                if np.any(a[1].d != 0.0):
+                    raise NotImplementedError("oracle: pow with variable exponent")
+                ex = a[1].v
+                r = Dual(a[0].v ** ex, a[0].d * (ex * a[0].v ** (ex - 1.0))[:, None])
+            elif op == "norm2":
+                ss = np.zeros(B)
+                dd = np.zeros((B, nd))
+                for x in a:
+                    ss += x.v * x.v
+                    dd += x.d * x.v[:, None]
+                nrm = np.sqrt(ss)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    r = Dual(nrm, dd / nrm[:, None])
+            else:
+                raise NotImplementedError("oracle: op '%s'" % op)
+        self.memo[k] = r
+        return r
+
+    def vector(self, mx):
+        """(e [B,m], Jt [B,m], Jz [B,m,n]) of a column expression."""
+        nodes = [mx._a[i, 0] for i in range(mx._a.shape[0])]
+        ds = [self.ev(s) for s in nodes]
+        e = np.stack([d.v for d in ds], axis=1)
+        D = np.stack([d.d for d in ds], axis=1)
+        return e, D[:, :, 0], D[:, :, 1:]
+
+
+# ==========================================================================
+# helpers
+# ==========================================================================
+def _cls(cnstr):
+    return cnstr.constraint_class
+
+
+def _num(val, m):
+    """float / list / ndarray / DM / constant MX -> ndarray (m,)"""
+    if hasattr(val, "toarray"):
+        val = val.toarray()
+    arr = np.asarray(val, dtype=float).reshape(-1)
+    if arr.size == 1 and m > 1:
+        arr = np.full(m, arr[0])
+    return arr
+
+
+def _gain_apply(gain, vec):
+    """cs.mtimes(gain, vec) for float or square-matrix gains."""
+    if hasattr(gain, "toarray"):
+        gain = gain.toarray()
+    g = np.asarray(gain, dtype=float)
+    if g.ndim == 0 or g.size == 1:
+        return float(g.reshape(-1)[0]) * vec
+    return g.dot(vec)
+
+
+def default_pinv_options(opt=None):
+    """Defaults of pseudo_inverse.py:42-66."""
+    opt = dict(opt or {})
+    opt.setdefault("feedforward", True)
+    opt.setdefault("multidim_sets", False)
+    opt.setdefault("converge_final_set_to_max", False)
+    opt.setdefault("pinv_method", "damped")
+    opt.setdefault("damping_factor", 1e-7)
+    return opt
+
+
+def activation_map(n_sets):
+    """pseudo_inverse.py:107-130: bit patterns of 0..2^n-1 with set 0 as the
+    least significant bit, stably sorted by the number of active sets."""
+    if n_sets == 0:
+        return []
+    binmaps = []
+    for mode_idx in range(2 ** n_sets):
+        bits = [0] * n_sets
+        for idx, ch in enumerate(reversed(bin(mode_idx)[2:])):
+            bits[-(idx + 1)] = int(ch)
+        binmaps.append(list(reversed(bits)))
+    return sorted(binmaps, key=lambda s: sum(s))
+
+
+def dpinv(J, opt):
+    """pseudo_inverse.py:92-105."""
+    rows, cols = J.shape
+    if opt["pinv_method"] == "standard":
+        # cs.pinv: solve(J^T J, J^T) for tall, solve(J J^T, J)^T otherwise
+        if rows >= cols:
+            return np.linalg.solve(J.T.dot(J), J.T)
+        return np.linalg.solve(J.dot(J.T), J).T
+    lam = opt["damping_factor"]
+    if cols >= rows:
+        inner = J.dot(J.T) + lam * np.eye(rows)
+        return np.linalg.solve(inner, J).T
+    inner = J.T.dot(J) + lam * np.eye(cols)
+    return np.linalg.solve(inner, J.T)
+
+
+def in_tangent_cone_1d(e, set_min, set_max, dexpr):
+    """pseudo_inverse.py:162-185 (boundary counts as inside, 1e-12 margin)."""
+    if set_min - e < 1e-12:
+        if e - set_max < 1e-12:
+            return True
+        return bool(dexpr < 0.0)
+    return bool(dexpr > 0.0)
+
+
+def in_tangent_cone_multidim(e, set_min, set_max, dexpr):
+    """pseudo_inverse.py:222-252."""
+    le = e - set_min
+    ue = e - set_max
+    inside = bool(np.all(le >= 1e-12) and np.all(ue <= 1e-12))
+    if inside:
+        return True
+    out_dir = (np.sign(le) + np.sign(ue)) / 2.0
+    corner = bool(np.all(np.sign(le) == np.sign(ue)))
+    od = float(out_dir.dot(dexpr))
+    if corner:
+        if od < 0.0:
+            dists = (np.linalg.norm(dexpr) + 1e-10) * np.linalg.norm(out_dir)
+            return bool(abs(-od) / dists < math.cos(math.pi / 4))
+        return False
+    return bool(od < 0.0)
+
+
+# ==========================================================================
+# PseudoInverseController
+# ==========================================================================
+def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False):
+    """Literal PseudoInverseController: returns (dZ [B,n_state], mode [B]).
+
+    dZ[:, :n_q] is robot_vel, the rest virtual_vel."""
+    opt = default_pinv_options(options)
+    Q = np.atleast_2d(np.asarray(Q, dtype=float))
+    B = Q.shape[0]
+    Z = Q if X is None else np.hstack([Q, np.atleast_2d(np.asarray(X, dtype=float))])
+    n = Z.shape[1]
+    Yb = None if Y is None else np.atleast_2d(np.asarray(Y, dtype=float))
+    evaluator = ExprEvaluator(spec, t, Z, Yb)
+    cn = spec.constraints
+    data = []
+    for c in cn:
+        e, Jt, Jz = evaluator.vector(c.expression)
+        data.append((e, Jt, Jz))
+    n_sets = sum(1 for c in cn if _cls(c) == "SetConstraint")
+    amap = activation_map(n_sets)
+    n_modes = 2 ** n_sets
+    ff = opt["feedforward"]
+    multidim = opt["multidim_sets"]
+    conv_last = opt["converge_final_set_to_max"]
+    if not multidim:
+        for c in cn:
+            if _cls(c) == "SetConstraint" and c.expression.size()[0] > 1:
+                raise NotImplementedError("multidimensional SetConstraint "
+                                          "without multidim_sets")
+    dZ = np.zeros((B, n))
+    modes = -np.ones(B, dtype=np.int32)
+    allv = np.zeros((B, n_modes, n)) if return_all_modes else None
+    I = np.eye(n)
+    for b in range(B):
+        for mode_idx in range(n_modes):
+            set_idx = 0
+            v = np.zeros(n)
+            Ja, rJa, tc = [], [], []
+            for ci, c in enumerate(cn):
+                e = data[ci][0][b]
+                Jt = data[ci][1][b]
+                Ji = data[ci][2][b]
+                m = e.shape[0]
+                kind = _cls(c)
+                is_first = len(Ja) == 0
+                is_last = ci == len(cn) - 1
+                is_set = kind == "SetConstraint"
+                is_eq = kind == "EqualityConstraint"
+                is_veleq = kind == "VelocityEqualityConstraint"
+                if multidim and is_set:
+                    smin = _num(c.set_min, m)
+                    smax = _num(c.set_max, m)
+                    S = np.diag(((e - smax > 0.0) | (e - smin < 0.0)).astype(float))
+                # chain 1 (:317-326)
+                if is_first and is_eq:
+                    des = -_gain_apply(c.gain, e)
+                    if ff:
+                        des = des - Jt
+                    v = v + dpinv(Ji, opt).dot(des)
+                    Ja.append(Ji); rJa.append(Ji)
+                # chain 2 (:327-443) - an independent if/elif ladder
+                if is_first and is_veleq:
+                    des = _num(c.target, m).copy()
+                    if ff:
+                        des = des - Jt
+                    v = v + dpinv(Ji, opt).dot(des)
+                    Ja.append(Ji); rJa.append(Ji)
+                elif is_set and is_last and conv_last:
+                    if amap[mode_idx][set_idx]:
+                        des = _gain_apply(c.gain, _num(c.set_max, m) - e)
+                        if ff:
+                            des = des - Jt
+                        if Ja:
+                            N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
+                        else:
+                            N = I   # never exercised by the reference (vertcat of nothing)
+                        v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                        Ja.append(Ji)
+                        rJa.append(S.dot(Ji) if multidim else Ji)
+                    else:
+                        tc.append(ci)
+                    set_idx += 1
+                elif is_eq:
+                    des = -_gain_apply(c.gain, e)
+                    if ff:
+                        des = des - Jt
+                    N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
+                    v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                    Ja.append(Ji); rJa.append(Ji)
+                elif is_set:
+                    if amap[mode_idx][set_idx]:
+                        Ja.append(Ji)
+                        rJa.append(S.dot(Ji) if multidim else Ji)
+                    else:
+                        tc.append(ci)
+                    set_idx += 1
+                elif is_veleq:
+                    des = _num(c.target, m).copy()
+                    if ff:
+                        des = des - Jt
+                    N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
+                    v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                    Ja.append(Ji); rJa.append(Ji)
+                # VelocitySetConstraint: no branch -> ignored
+            if return_all_modes:
+                allv[b, mode_idx] = v
+            # solve(): accept the first mode whose inactive sets are all in
+            # their tangent cone (:530-550)
+            ok = True
+            for ci in tc:
+                c = cn[ci]
+                e = data[ci][0][b]
+                m = e.shape[0]
+                dexpr = data[ci][1][b] + data[ci][2][b].dot(v)
+                smin = _num(c.set_min, m)
+                smax = _num(c.set_max, m)
+                if m == 1:
+                    good = in_tangent_cone_1d(e[0], smin[0], smax[0], dexpr[0])
+                else:
+                    good = in_tangent_cone_multidim(e, smin, smax, dexpr)
+                if not good:
+                    ok = False
+                    break
+            if ok and modes[b] < 0:
+                modes[b] = mode_idx
+                dZ[b] = v
+                if not return_all_modes:
+                    break
+    if return_all_modes:
+        return dZ, modes, allv
+    return dZ, modes
+
+
+# ==========================================================================
+# ReactiveQPController
+# ==========================================================================
+def qp_weights(spec, robot_var_weights=None, virtual_var_weights=None,
+               slack_var_weights=None):
+    """Weight defaults of reactive_qp.py:65-133."""
+    wr = np.ones(spec.n_robot_var) if robot_var_weights is None \
+        else np.asarray(robot_var_weights, dtype=float).reshape(-1)
+    wv = np.ones(spec.n_virtual_var) if virtual_var_weights is None \
+        else np.asarray(virtual_var_weights, dtype=float).reshape(-1)
+    if slack_var_weights is None:
+        ws = []
+        for c in spec.constraints:
+            if c.constraint_type == "soft":
+                ws += [float(c.slack_weight)] * c.expression.size()[0]
+        ws = np.asarray(ws, dtype=float)
+    else:
+        ws = np.asarray(slack_var_weights, dtype=float).reshape(-1)
+    return wr, wv, ws
+
+
+def qp_data_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
+    """H (diag), A, lbA, ubA per instance (reactive_qp.py:175-246).
+
+    Returns Hdiag [B,nv], A [B,nc,nv], lb [B,nc], ub [B,nc]."""
+    Q = np.atleast_2d(np.asarray(Q, dtype=float))
+    B = Q.shape[0]
+    Z = Q if X is None else np.hstack([Q, np.atleast_2d(np.asarray(X, dtype=float))])
+    Yb = None if Y is None else np.atleast_2d(np.asarray(Y, dtype=float))
+    evaluator = ExprEvaluator(spec, t, Z, Yb)
+    wr, wv, ws = weights if weights is not None else qp_weights(spec)
+    nq = spec.n_robot_var
+    nvirt = spec.n_virtual_var
+    nslack = spec.n_slack_var
+    hd = [mu * wr]
+    if nvirt > 0:
+        hd.append(mu * wv)
+    if nslack > 0:
+        hd.append(mu + ws)
+    hd = np.concatenate(hd)
+    nv = hd.size
+    A_blocks, lb_blocks, ub_blocks = [], [], []
+    slack_ind = 0
+    for c in spec.constraints:
+        e, Jt, Jz = evaluator.vector(c.expression)
+        m = e.shape[1]
+        blk = np.zeros((B, m, nv))
+        blk[:, :, :Jz.shape[2]] = Jz
+        lb = -Jt.copy()
+        ub = -Jt.copy()
+        kind = _cls(c)
+        if kind == "EqualityConstraint":
+            ke = np.stack([_gain_apply(c.gain, e[b]) for b in range(B)])
+            lb -= ke
+            ub -= ke
+        elif kind == "SetConstraint":
+            smin, smax = _num(c.set_min, m), _num(c.set_max, m)
+            lb += np.stack([_gain_apply(c.gain, smin - e[b]) for b in range(B)])
+            ub += np.stack([_gain_apply(c.gain, smax - e[b]) for b in range(B)])
+        elif kind == "VelocityEqualityConstraint":
+            tg = _num(c.target, m)
+            lb += tg
+            ub += tg
+        elif kind == "VelocitySetConstraint":
+            lb += _num(c.set_min, m)
+            ub += _num(c.set_max, m)
+        if nslack > 0 and c.constraint_type == "soft":
+            for i in range(m):
+                blk[:, i, nq + nvirt + slack_ind + i] = -1.0
+            slack_ind += m
+        A_blocks.append(blk)
+        lb_blocks.append(lb)
+        ub_blocks.append(ub)
+    A = np.concatenate(A_blocks, axis=1)
+    lbA = np.concatenate(lb_blocks, axis=1)
+    ubA = np.concatenate(ub_blocks, axis=1)
+    return np.broadcast_to(hd, (B, nv)).copy(), A, lbA, ubA
+
+
+class QPInfeasible(Exception):
+    pass
+
+
+def qp_solve_dense(hdiag, A, lb, ub, max_iter=200, eq_tol=0.0):
+    """Exact solution of   min 1/2 x'Hx  s.t. lb <= A x <= ub,  H = diag(hdiag) > 0
+    (the problem ``cs.conic`` hands to qpOASES, reactive_qp.py:491-513: no
+    linear term, no variable bounds) by the dual active-set method of
+    Goldfarb & Idnani (1983), written with explicit dense solves - clarity over
+    speed.  H is strictly positive so the minimiser is unique and
+    solver-independent; ``kkt_residuals`` proves optimality of the answer."""
+    hd = np.asarray(hdiag, dtype=float)
+    A = np.asarray(A, dtype=float)
+    nc, nv = A.shape
+    Ginv = 1.0 / hd
+    # inequality list: (row, sign) meaning sign*a_row.x >= sign*bound
+    cons = []
+    eq_rows = []
+    for i in range(nc):
+        if ub[i] - lb[i] <= eq_tol:
+            eq_rows.append(i)
+        else:
+            cons.append((i, +1.0, lb[i]))
+            cons.append((i, -1.0, -ub[i]))
+    x = np.zeros(nv)
+    act = []     # entries (normal vector, rhs, is_eq, tag)
+    u = np.zeros(0)
+
+    def normal(i, sgn):
+        return sgn * A[i]
+
+    def add_constraint(nvec, rhs, is_eq, tag):
+        nonlocal x, u, act
+        up = np.append(u, 0.0)
+        for _ in range(4 * (nc + 2)):
+            s = nvec.dot(x) - rhs
+            if act:
+                N = np.stack([a[0] for a in act], axis=1)          # nv x q
+                GN = Ginv[:, None] * N
+                M = N.T.dot(GN)
+                rvec = np.linalg.solve(M, GN.T.dot(nvec))
+                z = Ginv * (nvec - N.dot(rvec))
+            else:
+                rvec = np.zeros(0)
+                z = Ginv * nvec
+            zn = z.dot(nvec)
+            # partial step: largest step keeping the active inequality
+            # multipliers non-negative
+            t1, drop = math.inf, -1
+            for j, a in enumerate(act):
+                if not a[2] and rvec[j] > 1e-14:
+                    cand = up[j] / rvec[j]
+                    if cand < t1:
+                        t1, drop = cand, j
+            scale = max(1.0, float(np.abs(nvec).max()) ** 2 * float(Ginv.max()))
+            if zn > 1e-13 * scale:
+                t2 = -s / zn
+            else:
+                t2 = math.inf
+            if is_eq and s > 0:
+                # equality approached from the other side: flip the normal
+                nvec, rhs = -nvec, -rhs
+                continue
+            tstep = min(t1, t2)
+            if tstep == math.inf:
+                raise QPInfeasible("constraint %r cannot be satisfied" % (tag,))
+            if t2 == math.inf:
+                up[:-1] -= tstep * rvec
+                up[-1] += tstep
+                act.pop(drop)
+                up = np.delete(up, drop)
+                continue
+            x = x + tstep * z
+            up[:-1] -= tstep * rvec
+            up[-1] += tstep
+            if tstep == t2:
+                act.append((nvec, rhs, is_eq, tag))
+                u = up
+                return
+            act.pop(drop)
+            up = np.delete(up, drop)
+        raise QPInfeasible("active-set inner loop did not terminate")
+
+    for i in eq_rows:
+        rhs = 0.5 * (lb[i] + ub[i])
+        nvec = A[i].copy()
+        s = nvec.dot(x) - rhs
+        if s > 0:
+            nvec, rhs = -nvec, -rhs
+        if abs(s) > 0 or True:
+            add_constraint(nvec, rhs, True, (i, 0))
+    for it in range(max_iter):
+        worst, pick = -1e-11, None
+        for (i, sgn, rhs) in cons:
+            if any((a[3] == (i, sgn)) for a in act):
+                continue
+            viol = sgn * A[i].dot(x) - rhs
+            nrm = max(1.0, abs(rhs))
+            if viol / nrm < worst:
+                worst, pick = viol / nrm, (i, sgn, rhs)
+        if pick is None:
+            return x
+        i, sgn, rhs = pick
+        add_constraint(normal(i, sgn), rhs, False, (i, sgn))
+    raise QPInfeasible("iteration cap reached")
+
+
+def kkt_residuals(hdiag, A, lb, ub, x, act_tol=1e-8):
+    """(primal infeasibility, stationarity residual, worst multiplier sign
+    violation) of ``x`` for the QP above.  Multipliers are recovered by least
+    squares on the rows active at ``x``."""
+    hd = np.asarray(hdiag, dtype=float)
+    Ax = A.dot(x)
+    scale = np.maximum(1.0, np.maximum(np.abs(lb), np.abs(ub)))
+    prim = max(0.0, float(np.max((lb - Ax) / scale)), float(np.max((Ax - ub) / scale)))
+    at_lb = np.abs(Ax - lb) <= act_tol * scale
+    at_ub = np.abs(Ax - ub) <= act_tol * scale
+    idx = np.where(at_lb | at_ub)[0]
+    g = hd * x
+    if idx.size == 0:
+        return prim, float(np.abs(g).max()), 0.0
+    N = A[idx].T
+    lam, *_ = np.linalg.lstsq(N, g, rcond=None)
+    stat = float(np.abs(N.dot(lam) - g).max())
+    sign_bad = 0.0
+    for k, i in enumerate(idx):
+        if at_lb[i] and at_ub[i]:
+            continue                      # equality: free sign
+        if at_lb[i]:
+            sign_bad = max(sign_bad, -lam[k])   # needs lam >= 0
+        else:
+            sign_bad = max(sign_bad, lam[k])    # needs lam <= 0
+    return prim, stat, float(sign_bad)
+
+
+def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
+    """Literal ReactiveQPController.solve: (dq [B,nq], dx [B,nx] | None,
+    slack [B,ns] | None, status [B])."""
+    hd, A, lbA, ubA = qp_data_batch(spec, t, Q, X, Y, weights, mu)
+    B, nv = hd.shape
+    xs = np.zeros((B, nv))
+    status = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        try:
+            xs[b] = qp_solve_dense(hd[b], A[b], lbA[b], ubA[b])
+        except QPInfeasible:
+            status[b] = 2
+            xs[b] = np.nan
+    nq = spec.n_robot_var
+    nvirt = spec.n_virtual_var if spec.virtual_var is not None else 0
+    ns = spec.n_slack_var
+    dq = xs[:, :nq]
+    dx = xs[:, nq:nq + nvirt] if nvirt > 0 else None
+    slack = xs[:, nq + nvirt:nq + nvirt + ns] if ns > 0 else None
+    return dq, dx, slack, status
