@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLIK steps/sec on the 7-DoF 3-task priority stack.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one controller tick over the whole batch resident in HBM (one
+kernel launch per tick per GPU).  `value` = instance-steps per second =
+(N * batch * K) / time, the BASELINE.json metric "CLIK steps/sec (whole
+node), 7-DoF 3-task priority stack, batch 16384" (batch is per GPU: weak
+scaling, as in BASELINE config 5 = 131072 instances over 8 GPUs).
+
+The JSON line also carries
+  roofline      algorithmic HBM bytes (q 56 B + target 56 B +
+                dq 56 B + mode 4 B per instance-step) over the mean kernel
+                duration from HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline  the C restatement of the reference algorithm (oracle/, kind
+                "port") timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VALU_PEAK_TF = 78.6       # half of the 157.3 TF fp32 vector peak
+ALG_FLOP_PER_STEP = {"stack": 7.5e3, "pose": 2.9e3, "qp": 6.0e3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=16384, help="instances per GPU")
+    ap.add_argument("--workload", default="stack", choices=["stack", "pose", "qp"])
+    ap.add_argument("--dist", default="mixed", choices=["interior", "mixed"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=1,
+                    help="replay the K ticks from one hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--allgather", type=int, default=0,
+                    help="also all-gather dq over RCCL every tick (reported separately)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_workload(name, fk):
+    import casclik_amd as cc
+    from casclik_amd import skills
+    if name == "stack":
+        spec, opts = skills.stack_skill(fk), dict(skills.STACK_OPTIONS)
+        ctrl = cc.PseudoInverseController(skill_spec=spec, options=opts)
+    elif name == "pose":
+        spec, opts = skills.pose_skill(fk), None
+        ctrl = cc.PseudoInverseController(skill_spec=spec)
+    else:
+        spec, opts = skills.qp_skill(fk), None
+        ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    return spec, opts, ctrl
+
+
+def cpu_baseline(workload, spec, opts, Q, Y, seconds):
+    """Time the C restatement (oracle/clik_oracle_c.c) on the host cores."""
+    from oracle import c_oracle
+    if workload == "qp":
+        return None
+    co = c_oracle.CPinvOracle(spec, opts)
+    cores = os.cpu_count() or 1
+    sample = min(len(Q), 16384)
+    Qs, Ys = Q[:sample], Y[:sample]
+    co.solve_batch(0.0, Qs, Y=Ys, nthreads=cores)          # warm up threads
+    t0 = time.perf_counter()
+    co.solve_batch(0.0, Qs, Y=Ys, nthreads=cores)
+    one = time.perf_counter() - t0
+    reps = max(1, min(2000, int(seconds / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        co.solve_batch(0.0, Qs, Y=Ys, nthreads=cores)
+    el = time.perf_counter() - t0
+    return {"value": sample * reps / el, "unit": "instance-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d ticks of the same %d-instance batch, C restatement of the reference "
+                      "algorithm (oracle/clik_oracle_c.c), OpenMP over instances" % (reps, sample)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from casclik_amd import skills
+    fk = skills.iiwa()
+    spec, opts, ctrl = make_workload(args.workload, fk)
+    B = args.batch
+    # every rank owns its own contiguous shard of the global batch (weak scaling)
+    Q, Y = skills.synthetic_inputs(fk, B, seed=args.seed + 1000 * rank, distribution=args.dist)
+    Qd = torch.from_numpy(Q).to(dev)
+    Yd = torch.from_numpy(Y).to(dev)
+    dQ = torch.empty((B, Q.shape[1]), dtype=torch.float64, device=dev)
+    gathered = None
+    if args.allgather and world > 1:
+        gathered = torch.empty((world * B, Q.shape[1]), dtype=torch.float64, device=dev)
+
+    if args.workload == "qp":
+        def tick():
+            ctrl.solve_batch(0.0, Qd, input_var=Yd, return_status=False)
+    else:
+        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ)
+
+    def step():
+        tick()
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, dQ)
+
+    stream = torch.cuda.Stream(device=dev)
+    K, W = args.steps, args.warmup
+    with torch.cuda.stream(stream):
+        for _ in range(W):
+            step()
+        stream.synchronize()
+        graph = None
+        if args.graph and gathered is None and args.workload != "qp":
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for _ in range(K):
+                    tick()
+            graph.replay()          # untimed first replay (upload)
+            stream.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(K):
+                step()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        total_steps = world * B * K
+        value = total_steps / wall
+        kern_us = dev_ms * 1e3 / K
+        bytes_per_inst = 8 * (Q.shape[1] + Y.shape[1] + Q.shape[1]) + (0 if args.workload == "qp" else 4)
+        alg_bytes = bytes_per_inst * B
+        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
+        out = {
+            "metric": "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384",
+            "value": value, "unit": "instance-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": {"stack": "BASELINE config 3: %d x KUKA iiwa 7-DoF per GPU, priority stack "
+                                      "[multidim joint-limit set; 6-D pose; joint centering], "
+                                      "PseudoInverseController" % B,
+                             "pose": "BASELINE config 2: %d x iiwa, single 6-D pose task" % B,
+                             "qp": "BASELINE config 4: %d x iiwa ReactiveQPController" % B}[args.workload],
+                "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
+                "launch": "hipGraph of K ticks" if graph is not None else "eager, one launch per tick",
+                "ticks_per_s": K / wall, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_us": kern_us, "algorithmic_bytes_per_launch": alg_bytes,
+                         "fp64_valu_frac_algorithmic": (ALG_FLOP_PER_STEP[args.workload] * B / (kern_us * 1e-6))
+                                                       / (FP64_VALU_PEAK_TF * 1e12)},
+        }
+        if args.cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, spec, opts, Q, Y, args.cpu_seconds)
+            except Exception as exc:            # the baseline must never sink the bench line
+                out["cpu_baseline"] = {"error": repr(exc)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libclik_hip.so")
-SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_qp.hip"]
-HEADERS = [os.path.join(CSRC, "clik_device.hpp"), os.path.join(ROOT, "include", "clik.h")]
+SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_pinv_dyn.hip", "clik_qp.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("clik_device.hpp", "clik_pinv_static.hpp", "clik_pinv_kernels.hpp")] \
+    + [os.path.join(ROOT, "include", "clik.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

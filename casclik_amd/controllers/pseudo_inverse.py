@@ -131,6 +131,7 @@ class PseudoInverseController(BaseController):
             rc = self._lib.clik_pinv_create(C.byref(cdesc), C.byref(copts), C.byref(handle))
         _capi.check(self._lib, rc)
         self._handle = handle
+        self.kernel_name = self._lib.clik_pinv_kernel_name(handle).decode()
 
     def setup_solver(self):
         """Reference parity: re-runs the problem setup (pseudo_inverse.py:506-510)."""
@@ -194,6 +195,47 @@ class PseudoInverseController(BaseController):
             return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),
                     None if mode is None else mode.cpu().numpy())
         return dQ, dX, mode
+
+    def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None,
+                   mode_out=None, stream=None):
+        """Pre-bind device tensors and return ``tick(time_var=0.0)``: one
+        kernel launch per call with no per-call tensor handling (the lean path
+        for control loops, CUDA-graph capture and benchmarks).  All tensors
+        must already live on the controller's device."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, _ = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        X = Y = None
+        if d.n_x > 0:
+            X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+        if d.n_y > 0:
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        dQ = out if out is not None else torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
+        mode = mode_out if mode_out is not None else torch.empty((B,), dtype=torch.int32, device=dev)
+        fn = self._lib.clik_pinv_solve_batch
+        handle = self._handle
+        args = (ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(mode))
+        keep = (Q, X, Y, dQ, dX, mode)
+        static_tt = None
+        if d.n_tslots == 0:
+            static_tt = _capi.tterms_arg(np.zeros(0))
+        lib = self._lib
+
+        def tick(time_var=0.0, stream_handle=None):
+            tt, ttp = static_tt if static_tt is not None else _capi.tterms_arg(d.time_terms(time_var))
+            sh = stream_handle if stream_handle is not None else current_stream(dev)
+            rc = fn(handle, B, ttp, args[0], args[1], args[2], args[3], args[4], args[5], sh)
+            if rc != 0:
+                _capi.check(lib, rc)
+
+        tick.tensors = keep
+        tick.out = dQ
+        tick.mode = mode
+        return tick
 
     def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008,
                       max_speed=0.0):

@@ -10,16 +10,23 @@
 //   clik_qp_solve_batch    <- ReactiveQPController.solve (:461-528)
 #include <hip/hip_runtime.h>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include "clik_device.hpp"
 
 namespace clik {
-hipError_t pinv_launch_solve(int N, const DevSkill* dS, const TickArgs& tk, long long B, int ny,
+int pinv_pick_kernel(const DevSkill& S, int allow_static);
+const char* pinv_kernel_name(int k);
+int pinv_kernel_width(int k);
+hipError_t pinv_launch_solve(int N, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                              const double* q, const double* x, const double* y, double* dq,
                              double* dx, int32_t* mode, hipStream_t stream);
-hipError_t pinv_launch_rollout(int N, const DevSkill* dS, const double* d_tterms, int n_ticks,
+hipError_t pinv_launch_rollout(int N, const DevSkill* dS, const WarmArgs& wa, const double* d_tterms, int n_ticks,
                                double dt, double max_speed, long long B, int ny, double* q,
                                const double* y, double* dq, int32_t* mode, hipStream_t stream);
 int pinv_lds_slots_host(int N, int ny);
@@ -34,11 +41,13 @@ int qp_pick_variant(int n, int nv, int nc);
 
 using clik::DevSkill;
 using clik::TickArgs;
+using clik::WarmArgs;
 
 struct clik_pinv {
     DevSkill  host;
     DevSkill* dev;
-    int       N;            // kernel template instance
+    clik::WarmArgs warm;
+    int       kernel;       // index into the kernel table (static shape or dynamic)
     double*   d_tterms;     // rollout workspace
     size_t    d_tterms_cap;
 };
@@ -138,6 +147,36 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
         if (t.soft) n_slack += t.m;
         n_rows_qp += t.m;
     }
+    // per-task feature flags, constant-Jacobian detection, shape descriptor
+    S->shape.n = n;
+    S->shape.n_tasks = d->n_tasks;
+    S->shape.all_affine = 1;
+    int last_row = 0;
+    for (int ti = 0; ti < d->n_tasks; ++ti) {
+        const clik_task& t = d->tasks[ti];
+        int fl = 0, affine = 1;
+        for (int i = 0; i < t.m; ++i) {
+            const int nr = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+            if (t.out_kind[i] != CLIK_OUT_AFFINE) affine = 0;
+            for (int k = t.out_row0[i]; k < t.out_row0[i] + nr; ++k) fl |= d->rows[k].flags;
+            if (t.out_row0[i] + nr > last_row) last_row = t.out_row0[i] + nr;
+        }
+        S->task_flags[ti] = fl;
+        S->task_const_j[ti] =
+            (affine && !(fl & (CLIK_ROW_HAS_P | CLIK_ROW_HAS_R | CLIK_ROW_HAS_O))) ? 1 : 0;
+        if (!affine) S->shape.all_affine = 0;
+        if (ti < clik::SHAPE_MAX_TASKS) {
+            S->shape.cls[ti] = t.cls;
+            S->shape.m[ti] = t.m;
+            // time terms do not change the code path of a row: drop the flag from the shape
+            S->shape.flags[ti] = fl & ~CLIK_ROW_HAS_T;
+            S->shape.const_j[ti] = S->task_const_j[ti];
+        }
+        if (fl & CLIK_ROW_HAS_T) S->shape.all_affine = S->shape.all_affine;  // (time slots are run-time data)
+    }
+    S->shape.uses_fk = any_fk ? 1 : 0;
+    S->shape.quat_src = any_o ? d->quat_src : 0;
+    S->lds_slots = last_row;   // (temporarily) number of used affine rows, for the warm-up ranges
     if (any_fk && d->n_joints == 0) return fail(CLIK_EINVAL, "rows use the tool frame but the chain is empty");
     if (any_o && d->quat_src == 0) return fail(CLIK_EINVAL, "rows use the orientation error but no target is set");
     S->d.uses_fk = any_fk ? 1 : 0;
@@ -148,14 +187,67 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
     return CLIK_OK;
 }
 
-static int pick_N(const DevSkill& S)
+// dense solve A X = B (A k x k, B k x c, row-major), partial pivoting; host only
+static bool host_solve(int k, int c, double* A, double* B)
 {
-    int need = S.n;
-    for (int ti = 0; ti < S.d.n_tasks; ++ti)
-        if (S.d.tasks[ti].m > need) need = S.d.tasks[ti].m;
-    if (need <= 6) return 6;
-    if (need <= 7) return 7;
-    return 8;
+    for (int col = 0; col < k; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < k; ++r)
+            if (std::fabs(A[r * k + col]) > std::fabs(A[piv * k + col])) piv = r;
+        if (A[piv * k + col] == 0.0) return false;
+        if (piv != col) {
+            for (int j = 0; j < k; ++j) std::swap(A[col * k + j], A[piv * k + j]);
+            for (int j = 0; j < c; ++j) std::swap(B[col * c + j], B[piv * c + j]);
+        }
+        for (int r = col + 1; r < k; ++r) {
+            const double f = A[r * k + col] / A[col * k + col];
+            for (int j = col; j < k; ++j) A[r * k + j] -= f * A[col * k + j];
+            for (int j = 0; j < c; ++j) B[r * c + j] -= f * B[col * c + j];
+        }
+    }
+    for (int col = k - 1; col >= 0; --col)
+        for (int j = 0; j < c; ++j) {
+            double s = B[col * c + j];
+            for (int r = col + 1; r < k; ++r) s -= A[col * k + r] * B[r * c + j];
+            B[col * c + j] = s / A[col * k + col];
+        }
+    return true;
+}
+
+// P (n x m, ld CLIK_MAX_M) = pinv(J) with the controller's method
+// (pseudo_inverse.py:92-105) for a state-independent Jacobian J (m x n)
+static bool host_const_pinv(const clik_pinv_opts& o, int m, int n, const double* J, double* P)
+{
+    const bool standard = o.pinv_method == CLIK_PINV_STANDARD;
+    const double lam = standard ? 0.0 : o.damping_factor;
+    const bool wide = standard ? (m < n) : (n >= m);
+    double A[CLIK_MAX_M * CLIK_MAX_M], X[CLIK_MAX_M * CLIK_MAX_M];
+    if (wide) {
+        for (int i = 0; i < m; ++i)
+            for (int k = 0; k < m; ++k) {
+                double sacc = (i == k) ? lam : 0.0;
+                for (int j = 0; j < n; ++j) sacc += J[i * n + j] * J[k * n + j];
+                A[i * m + k] = sacc;
+            }
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < n; ++j) X[i * n + j] = J[i * n + j];
+        if (!host_solve(m, n, A, X)) return false;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < m; ++i) P[j * CLIK_MAX_M + i] = X[i * n + j];
+    } else {
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) {
+                double sacc = (a == b) ? lam : 0.0;
+                for (int i = 0; i < m; ++i) sacc += J[i * n + a] * J[i * n + b];
+                A[a * n + b] = sacc;
+            }
+        for (int a = 0; a < n; ++a)
+            for (int i = 0; i < m; ++i) X[a * m + i] = J[i * n + a];
+        if (!host_solve(n, m, A, X)) return false;
+        for (int a = 0; a < n; ++a)
+            for (int i = 0; i < m; ++i) P[a * CLIK_MAX_M + i] = X[a * m + i];
+    }
+    return true;
 }
 
 extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts, clik_pinv** out)
@@ -200,8 +292,53 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     }
     S.last_set_converges = (S.d.n_tasks > 0 && S.d.tasks[S.d.n_tasks - 1].cls == CLIK_CLS_SET &&
                             opts->converge_final_set_to_max) ? 1 : 0;
-    h->N = pick_N(S);
-    S.lds_slots = clik::pinv_lds_slots_host(h->N, S.d.n_y);
+    S.shape.feedforward = opts->feedforward ? 1 : 0;
+    S.shape.multidim = opts->multidim_sets ? 1 : 0;
+    S.shape.conv_last = opts->converge_final_set_to_max ? 1 : 0;
+    S.shape.standard = opts->pinv_method == CLIK_PINV_STANDARD ? 1 : 0;
+    for (int ti = 0; ti < S.d.n_tasks; ++ti) {
+        if (!S.task_const_j[ti]) continue;
+        const clik_task& t = S.d.tasks[ti];
+        double J[CLIK_MAX_M * CLIK_MAX_DOF];
+        for (int i = 0; i < t.m; ++i)
+            for (int j = 0; j < S.n; ++j) J[i * S.n + j] = S.d.rows[t.out_row0[i]].a[j];
+        if (!host_const_pinv(*opts, t.m, S.n, J, S.cpinv[ti])) {
+            // singular Gram matrix (pinv_method "standard" on a rank-deficient
+            // task): let the device run the generic solve like the reference would
+            S.task_const_j[ti] = 0;
+            if (ti < clik::SHAPE_MAX_TASKS) S.shape.const_j[ti] = 0;
+        }
+    }
+    {
+        const char* force = getenv("CLIK_FORCE_DYNAMIC");
+        h->kernel = clik::pinv_pick_kernel(S, (force && force[0] == '1') ? 0 : 1);
+    }
+    if (h->kernel < 0) {
+        delete h;
+        return fail(CLIK_EUNSUPPORTED, "no kernel variant for n = %d", S.n);
+    }
+    {
+        // scalar-cache warm-up ranges (clik_device.hpp, warm_descriptor): the
+        // used prefixes of the descriptor arrays and the derived tables
+        const int used_rows = S.lds_slots;
+        auto lo = [](size_t off) { return (int32_t)(off & ~(size_t)63); };
+        auto hi = [](size_t off) { return (int32_t)((off + 63) & ~(size_t)63); };
+        clik::WarmArgs& w = h->warm;
+        const size_t o_d = offsetof(DevSkill, d);
+        w.off[0] = lo(o_d);
+        w.end[0] = hi(o_d + offsetof(clik_skill_desc, joints) + (size_t)S.d.n_joints * sizeof(clik_joint));
+        w.off[1] = lo(o_d + offsetof(clik_skill_desc, tasks));
+        w.end[1] = hi(o_d + offsetof(clik_skill_desc, tasks) + (size_t)S.d.n_tasks * sizeof(clik_task));
+        w.off[2] = lo(o_d + offsetof(clik_skill_desc, rows));
+        w.end[2] = hi(o_d + offsetof(clik_skill_desc, rows) + (size_t)used_rows * sizeof(clik_row));
+        w.off[3] = lo(offsetof(DevSkill, shape));
+        w.end[3] = hi(offsetof(DevSkill, cpinv) + (size_t)S.d.n_tasks * sizeof(S.cpinv[0]));
+        w.off[4] = lo(offsetof(DevSkill, po));
+        w.end[4] = hi(sizeof(DevSkill));
+        w.token_off = (int32_t)offsetof(DevSkill, zero_token);
+    }
+    S.zero_token = 0;
+    S.lds_slots = clik::pinv_lds_slots_host(clik::pinv_kernel_width(h->kernel), S.d.n_y);
     if ((size_t)S.lds_slots * clik::WAVE * sizeof(double) > 160u * 1024u) {
         delete h;
         return fail(CLIK_EUNSUPPORTED, "skill needs %d LDS slots per lane (input_var too large)", S.lds_slots);
@@ -226,6 +363,10 @@ extern "C" int clik_pinv_destroy(clik_pinv* h)
 }
 
 extern "C" int clik_pinv_n_modes(const clik_pinv* h) { return h ? h->host.n_modes : 0; }
+extern "C" const char* clik_pinv_kernel_name(const clik_pinv* h)
+{
+    return h ? clik::pinv_kernel_name(h->kernel) : "none";
+}
 
 static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk)
 {
@@ -252,7 +393,7 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    hipError_t e = clik::pinv_launch_solve(h->N, h->dev, tk, (long long)B, S.d.n_y, q, x, y, dq, dx, mode,
+    hipError_t e = clik::pinv_launch_solve(h->kernel, h->dev, h->warm, tk, (long long)B, S.d.n_y, q, x, y, dq, dx, mode,
                                            (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
     return CLIK_OK;
@@ -283,7 +424,7 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
                                       (hipStream_t)stream);
         if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
     }
-    hipError_t e = clik::pinv_launch_rollout(h->N, h->dev, h->d_tterms, n_ticks, dt, max_speed, (long long)B,
+    hipError_t e = clik::pinv_launch_rollout(h->kernel, h->dev, h->warm, h->d_tterms, n_ticks, dt, max_speed, (long long)B,
                                              S.d.n_y, q, y, dq, mode, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_rollout_kernel launch");
     return CLIK_OK;

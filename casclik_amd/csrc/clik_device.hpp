@@ -14,15 +14,40 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "clik.h"
 
 namespace clik {
 
 constexpr int WAVE = 64;
 
+// Compile-time "shape" of a skill: everything that steers control flow or
+// register indexing.  A kernel instantiated for a ShapeDesc has no size guards
+// left; numeric values (gains, bounds, chain constants, row coefficients)
+// still come from the descriptor.  The dynamic fallback reads the same fields
+// from DevSkill at run time.
+constexpr int SHAPE_MAX_TASKS = 6;
+struct ShapeDesc {
+    int n;                          // n_q + n_x
+    int n_tasks;
+    int cls[SHAPE_MAX_TASKS];
+    int m[SHAPE_MAX_TASKS];
+    int flags[SHAPE_MAX_TASKS];     // OR of the CLIK_ROW_HAS_* of the task's rows
+    int const_j[SHAPE_MAX_TASKS];   // Jacobian independent of the state (rows use HAS_Q only)
+    int all_affine;                 // no NORM2 output rows
+    int uses_fk, quat_src;
+    int feedforward, multidim, conv_last, standard;
+};
+
 // Device-resident skill: descriptor + controller options + derived tables.
 struct DevSkill {
     clik_skill_desc d;
+    ShapeDesc shape;
+    int32_t  task_flags[CLIK_MAX_TASKS];   // OR of row flags per task
+    int32_t  task_const_j[CLIK_MAX_TASKS]; // 1: rows depend on the state through a.z only
+    // for constant-Jacobian tasks: P = pinv(J) (n x m, row-major ld CLIK_MAX_M),
+    // computed once on the host with the controller's pinv options
+    double   cpinv[CLIK_MAX_TASKS][CLIK_MAX_DOF * CLIK_MAX_M];
     clik_pinv_opts  po;
     clik_qp_opts    qo;
     int32_t  n;                       // n_q + n_x
@@ -36,7 +61,88 @@ struct DevSkill {
     int32_t  n_qp_rows;
     int32_t  n_qp_vars;
     int32_t  lds_slots;               // doubles per lane of dynamic LDS
+    int32_t  zero_token;              // always 0 (see warm_descriptor)
 };
+
+// ---- shape policies ---------------------------------------------------------
+struct DynShape {
+    static constexpr bool is_static = false;
+    __device__ static int n(const DevSkill* S) { return S->n; }
+    __device__ static int n_tasks(const DevSkill* S) { return S->d.n_tasks; }
+    __device__ static int cls(const DevSkill* S, int ti) { return S->d.tasks[ti].cls; }
+    __device__ static int m(const DevSkill* S, int ti) { return S->d.tasks[ti].m; }
+    __device__ static int flags(const DevSkill* S, int ti) { return S->task_flags[ti]; }
+    __device__ static bool const_j(const DevSkill* S, int ti) { return S->task_const_j[ti] != 0; }
+    __device__ static bool all_affine(const DevSkill* S) { return S->shape.all_affine != 0; }
+    __device__ static bool uses_fk(const DevSkill* S) { return S->d.uses_fk != 0; }
+    __device__ static int quat_src(const DevSkill* S) { return S->d.quat_src; }
+    __device__ static bool feedforward(const DevSkill* S) { return S->po.feedforward != 0; }
+    __device__ static bool multidim(const DevSkill* S) { return S->po.multidim_sets != 0; }
+    __device__ static bool conv_last(const DevSkill* S) { return S->po.converge_final_set_to_max != 0; }
+    __device__ static bool standard(const DevSkill* S) { return S->po.pinv_method == CLIK_PINV_STANDARD; }
+};
+
+template <const ShapeDesc& SD>
+struct StaticShape {
+    static constexpr bool is_static = true;
+    static constexpr const ShapeDesc& desc = SD;
+    __device__ static constexpr int n(const DevSkill*) { return SD.n; }
+    __device__ static constexpr int n_tasks(const DevSkill*) { return SD.n_tasks; }
+    __device__ static constexpr int cls(const DevSkill*, int ti) { return SD.cls[ti]; }
+    __device__ static constexpr int m(const DevSkill*, int ti) { return SD.m[ti]; }
+    __device__ static constexpr int flags(const DevSkill*, int ti) { return SD.flags[ti]; }
+    __device__ static constexpr bool const_j(const DevSkill*, int ti) { return SD.const_j[ti] != 0; }
+    __device__ static constexpr bool all_affine(const DevSkill*) { return SD.all_affine != 0; }
+    __device__ static constexpr bool uses_fk(const DevSkill*) { return SD.uses_fk != 0; }
+    __device__ static constexpr int quat_src(const DevSkill*) { return SD.quat_src; }
+    __device__ static constexpr bool feedforward(const DevSkill*) { return SD.feedforward != 0; }
+    __device__ static constexpr bool multidim(const DevSkill*) { return SD.multidim != 0; }
+    __device__ static constexpr bool conv_last(const DevSkill*) { return SD.conv_last != 0; }
+    __device__ static constexpr bool standard(const DevSkill*) { return SD.standard != 0; }
+};
+
+// With one wavefront per CU per launch every scalar load of the descriptor is
+// a cold miss (~0.3-1 us each, serialised by the data-dependent walk over tasks
+// and rows).  warm_descriptor() touches every 64-B line of the used descriptor
+// ranges with independent s_load_dword's and waits ONCE, so the walk afterwards
+// hits the scalar cache.
+//
+// It is one non-volatile asm without a memory clobber (a volatile or clobbering
+// asm would make the compiler give up scalar loads for the whole kernel).  Its
+// output is the always-zero `zero_token` of the skill; adding that to the skill
+// pointer creates the data dependence that keeps the warm-up ahead of every
+// descriptor access without changing any address.
+constexpr int WARM_RANGES = 5;
+struct WarmArgs {
+    int32_t off[WARM_RANGES];     // byte offsets into DevSkill, multiples of 64
+    int32_t end[WARM_RANGES];     // exclusive ends (off >= end: empty)
+    int32_t token_off;            // offset of DevSkill::zero_token
+};
+
+__device__ __forceinline__ const struct DevSkill* warm_descriptor(const struct DevSkill* S, const WarmArgs& wa)
+{
+    int tok;
+#define CLIK_WARM_RANGE(K)                                   \
+    "s_mov_b32 s96, %[o" #K "]\n"                            \
+    "1:\n"                                                   \
+    "s_cmp_ge_u32 s96, %[e" #K "]\n"                         \
+    "s_cbranch_scc1 2f\n"                                    \
+    "s_load_dword s97, %[base], s96\n"                       \
+    "s_add_u32 s96, s96, 64\n"                               \
+    "s_branch 1b\n"                                          \
+    "2:\n"
+    asm(CLIK_WARM_RANGE(0) CLIK_WARM_RANGE(1) CLIK_WARM_RANGE(2) CLIK_WARM_RANGE(3) CLIK_WARM_RANGE(4)
+        "s_load_dword %[tok], %[base], %[toff]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [tok] "=s"(tok)
+        : [base] "s"(S), [toff] "s"(wa.token_off),
+          [o0] "s"(wa.off[0]), [e0] "s"(wa.end[0]), [o1] "s"(wa.off[1]), [e1] "s"(wa.end[1]),
+          [o2] "s"(wa.off[2]), [e2] "s"(wa.end[2]), [o3] "s"(wa.off[3]), [e3] "s"(wa.end[3]),
+          [o4] "s"(wa.off[4]), [e4] "s"(wa.end[4])
+        : "s96", "s97", "scc");
+#undef CLIK_WARM_RANGE
+    return (const struct DevSkill*)((const char*)S + tok);
+}
 
 // per-tick values / time derivatives of the time-only sub-expressions
 struct TickArgs {
@@ -269,11 +375,10 @@ __device__ __forceinline__ void orientation_feature(const DevSkill* __restrict__
 
 // Value, state gradient and time derivative of one affine row (clik_row).
 template <int N>
-__device__ __forceinline__ double row_eval(const DevSkill* __restrict__ S, const clik_row& r,
+__device__ __forceinline__ double row_eval(const DevSkill* __restrict__ S, const clik_row& r, const int flags,
                                            const TickArgs& tk, const Kin<N>& K, const double (&z)[N],
                                            const double* ys, int lane, int n, double (&g)[N], double& dt)
 {
-    const int flags = r.flags;
     double v = r.c;
     dt = 0.0;
 #pragma unroll
@@ -339,32 +444,38 @@ __device__ __forceinline__ double row_eval(const DevSkill* __restrict__ S, const
         const int ny = r.n_y;
         for (int k = 0; k < ny; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
     }
-    if (flags & CLIK_ROW_HAS_T) {
+    {
+        // time slots are run-time data even in shape-specialised kernels
         const int slot = r.t_slot;
-        v += tk.tv[slot];
-        dt = tk.tv[S->d.n_tslots + slot];
+        if (slot >= 0) {
+            v += tk.tv[slot];
+            dt = tk.tv[S->d.n_tslots + slot];
+        }
     }
     return v;
 }
 
 // e (m), J (m x n) and d e/d t of constraint `ti`: the numeric content of the
 // reference's cnstr.expression / cnstr.jacobian(state) / cnstr.jacobian(time)
-// (pseudo_inverse.py:285-286, reactive_qp.py:210-216).
+// (pseudo_inverse.py:285-286, reactive_qp.py:210-216).  `m`, `tflags` (>= 0:
+// use these flags for every row) and `all_affine` are compile-time constants
+// in shape-specialised kernels.
 template <int N, int M>
-__device__ __forceinline__ void task_eval(const DevSkill* __restrict__ S, int ti, const TickArgs& tk,
+__device__ __forceinline__ void task_eval(const DevSkill* __restrict__ S, int ti, const int m,
+                                          const int tflags, const bool all_affine, const TickArgs& tk,
                                           const Kin<N>& K, const double (&z)[N], const double* ys,
                                           int lane, int n, double (&e)[M], double (&J)[M][N],
                                           double (&Jt)[M])
 {
     const clik_task& t = S->d.tasks[ti];
-    const int m = t.m;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         if (i < m) {
             const int row0 = t.out_row0[i];
-            if (t.out_kind[i] == CLIK_OUT_AFFINE) {
+            if (all_affine || t.out_kind[i] == CLIK_OUT_AFFINE) {
+                const clik_row& r = S->d.rows[row0];
                 double g[N], dt;
-                e[i] = row_eval<N>(S, S->d.rows[row0], tk, K, z, ys, lane, n, g, dt);
+                e[i] = row_eval<N>(S, r, tflags >= 0 ? tflags : r.flags, tk, K, z, ys, lane, n, g, dt);
                 Jt[i] = dt;
 #pragma unroll
                 for (int j = 0; j < N; ++j) J[i][j] = g[j];
@@ -374,8 +485,9 @@ __device__ __forceinline__ void task_eval(const DevSkill* __restrict__ S, int ti
                 for (int j = 0; j < N; ++j) acc[j] = 0.0;
                 const int nr = t.out_nrows[i];
                 for (int k = 0; k < nr; ++k) {
+                    const clik_row& r = S->d.rows[row0 + k];
                     double g[N], dt;
-                    const double v = row_eval<N>(S, S->d.rows[row0 + k], tk, K, z, ys, lane, n, g, dt);
+                    const double v = row_eval<N>(S, r, r.flags, tk, K, z, ys, lane, n, g, dt);
                     ss = fma(v, v, ss);
                     tacc = fma(v, dt, tacc);
 #pragma unroll
@@ -392,11 +504,20 @@ __device__ __forceinline__ void task_eval(const DevSkill* __restrict__ S, int ti
     }
 }
 
+// compile-time loop with the index as an integral constant
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
 // gain * v  (float or m x m matrix gain, constraints.py:32-65)
 template <int M>
-__device__ __forceinline__ void gain_apply(const clik_task& t, const double (&v)[M], double (&out)[M])
+__device__ __forceinline__ void gain_apply(const clik_task& t, const int m, const double (&v)[M], double (&out)[M])
 {
-    const int m = t.m;
     if (!t.gain_is_matrix) {
         const double g = t.gain[0];
 #pragma unroll

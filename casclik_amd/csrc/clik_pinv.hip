@@ -1,603 +1,100 @@
-// Batched PseudoInverseController tick on gfx950.
-//
-// Replaces, for B instances per launch, the per-tick body of
-//   PseudoInverseController.solve          casclik/controllers/pseudo_inverse.py:512-556
-// i.e. the evaluation of the per-mode CasADi functions built by
-//   get_problem_expressions                 :259-451
-// with damped pseudo-inverses (:92-105), the mode table (:107-130) and the
-// tangent-cone tests (:132-257).
-//
-// Algebra (equal to the reference's up to fp64 rounding):
-//   reference:  v += (I - pinv(Ja) rJa) * pinv(Ji) * des          (full matrices)
-//   here:       w  = pinv(Ji) des   by ONE solve with (Ji Ji^T + lam I)   [wide]
-//                                              or   (Ji^T Ji + lam I)     [tall]
-//               w -= pinv(Ja) (rJa w) by ONE solve with the stacked Gram matrix
-//   the reference's wide/tall branch choice (cols >= rows) is kept, so the
-//   conditioning of every solve is the reference's.  rJa = diag(s) Ja with
-//   s in {0,1} (multidim activation S, :289-298) is kept as a bit mask (wide
-//   stack) or as the second Gram matrix C = Ja^T diag(s) Ja (tall stack).
-//   The first EqualityConstraint is processed twice and stacked twice exactly
-//   as :317-326 + :382-396 do.
-#include "clik_device.hpp"
+// Kernel table of the PseudoInverseController path: AOT shape-specialised
+// instantiations (this TU) + the dynamic-shape kernels (clik_pinv_dyn.hip).
+#include "clik_pinv_kernels.hpp"
 
 namespace clik {
 
-// ---- stacked active Jacobians -------------------------------------------------
-// wide form: rows in LDS slots [k*N + j], k < r <= cap, per-lane activation bits
-// gram form: G = lam*I + Ja^T Ja (slots [0, NT)), C = Ja^T diag(s) Ja (slots [NT, 2NT))
-template <int N>
-struct Stack {
-    int      r;        // stacked rows (wave-uniform)
-    bool     gram;     // wave-uniform
-    uint32_t sbits;    // per lane: activation flag of wide rows
+// dynamic-shape launchers, instantiated in clik_pinv_dyn.hip
+hipError_t dyn_solve_6(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*, const double*, const double*, double*, double*, int32_t*, hipStream_t);
+hipError_t dyn_solve_7(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*, const double*, const double*, double*, double*, int32_t*, hipStream_t);
+hipError_t dyn_solve_8(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*, const double*, const double*, double*, double*, int32_t*, hipStream_t);
+hipError_t dyn_rollout_8(const DevSkill*, const WarmArgs&, const double*, int, double, double, long long, int, double*, const double*, double*, int32_t*, hipStream_t);
+
+// ---- AOT shapes ------------------------------------------------------------------
+// One entry per skill structure that gets a guard-free kernel.  Adding a shape
+// is one line here plus one line in kShapes[]; skills that match none of them
+// run the DynShape kernel.  P/O/Y/Q are the CLIK_ROW_HAS_* feature flags.
+namespace shapes {
+constexpr int Q = CLIK_ROW_HAS_Q, P = CLIK_ROW_HAS_P, O = CLIK_ROW_HAS_O, Y = CLIK_ROW_HAS_Y;
+constexpr int EQ = CLIK_CLS_EQ, SET = CLIK_CLS_SET;
+//                                     n nt  cls            m           flags               const_j   aff fk qs ff md cl st
+inline constexpr ShapeDesc kPos3N7  = {7, 1, {EQ},          {3},        {P | Y},            {0},       1, 1, 0, 1, 0, 0, 0};
+inline constexpr ShapeDesc kPose6N7 = {7, 1, {EQ},          {6},        {P | O | Y},        {0},       1, 1, 2, 1, 0, 0, 0};
+inline constexpr ShapeDesc kStackN7 = {7, 3, {SET, EQ, EQ}, {7, 6, 7},  {Q, P | O | Y, Q},  {1, 0, 1}, 1, 1, 2, 1, 1, 0, 0};
+inline constexpr ShapeDesc kPos3N6  = {6, 1, {EQ},          {3},        {P | Y},            {0},       1, 1, 0, 1, 0, 0, 0};
+inline constexpr ShapeDesc kPose6N6 = {6, 1, {EQ},          {6},        {P | O | Y},        {0},       1, 1, 2, 1, 0, 0, 0};
+inline constexpr ShapeDesc kStackN6 = {6, 3, {SET, EQ, EQ}, {6, 6, 6},  {Q, P | O | Y, Q},  {1, 0, 1}, 1, 1, 2, 1, 1, 0, 0};
+}  // namespace shapes
+
+struct ShapeEntry {
+    const ShapeDesc* sd;       // nullptr: dynamic kernel of width N
+    int N;
+    const char* name;
+    solve_fn solve;
+    rollout_fn rollout;
 };
 
-template <int N>
-__device__ __forceinline__ void stack_push(Stack<N>& st, double* wk, int lane, int n, int cap,
-                                           double lam, const double (&J)[N][N], int m,
-                                           uint32_t srow, int times)
+#define CLIK_STATIC_ENTRY(SD, NN) \
+    {&shapes::SD, NN, #SD, &launch_solve<NN, StaticShape<shapes::SD>>, &launch_rollout<NN, StaticShape<shapes::SD>>}
+#define CLIK_DYN_ENTRY(NN) {nullptr, NN, "dynamic", &dyn_solve_##NN, &dyn_rollout_8}
+
+static const ShapeEntry kShapes[] = {
+#ifdef CLIK_DEV_SINGLE   // developer builds: one instantiation, fast compile / ISA inspection
+    CLIK_DEV_SINGLE
+#else
+    CLIK_STATIC_ENTRY(kPos3N7, 7),  CLIK_STATIC_ENTRY(kPose6N7, 7), CLIK_STATIC_ENTRY(kStackN7, 7),
+    CLIK_STATIC_ENTRY(kPos3N6, 6),  CLIK_STATIC_ENTRY(kPose6N6, 6), CLIK_STATIC_ENTRY(kStackN6, 6),
+    CLIK_DYN_ENTRY(6), CLIK_DYN_ENTRY(7), CLIK_DYN_ENTRY(8),
+#endif
+};
+constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+
+static bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
 {
-    constexpr int NT = N * (N + 1) / 2;
-    if (!st.gram && st.r + times * m <= cap) {
-        for (int rep = 0; rep < times; ++rep) {
-            const int r0 = st.r;
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                if (i < m) {
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        if (j < n) wk[((r0 + i) * N + j) * WAVE + lane] = J[i][j];
-                }
-            }
-            st.sbits |= (srow & ((1u << m) - 1u)) << r0;
-            st.r += m;
-        }
-        return;
-    }
-    // (convert to and) accumulate in Gram form.  The row area overlaps both
-    // Gram areas, so both matrices are completed in registers before either
-    // is stored.
-    double Gm[NT], Cm[NT];
-    double* gdst = wk + lane;
-    double* cdst = wk + (size_t)NT * WAVE + lane;
-    if (st.gram) {
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            Gm[a] = gdst[a * WAVE];
-            Cm[a] = cdst[a * WAVE];
-        }
-    } else {
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                Gm[tri(a, b)] = (a == b && a < n) ? lam : 0.0;
-                Cm[tri(a, b)] = 0.0;
-            }
-        const int r_old = st.r;
-        const uint32_t old_bits = st.sbits;
-        for (int k = 0; k < r_old; ++k) {
-            double row[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) row[j] = (j < n) ? wk[(k * N + j) * WAVE + lane] : 0.0;
-            const double sk = ((old_bits >> k) & 1u) ? 1.0 : 0.0;
-#pragma unroll
-            for (int a = 0; a < N; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b) {
-                    const double pr = row[a] * row[b];
-                    Gm[tri(a, b)] += pr;
-                    Cm[tri(a, b)] = fma(sk, pr, Cm[tri(a, b)]);
-                }
-        }
-    }
-    const double tf = (double)times;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (i < m) {
-            const double si = ((srow >> i) & 1u) ? tf : 0.0;
-#pragma unroll
-            for (int a = 0; a < N; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b) {
-                    const double pr = J[i][a] * J[i][b];
-                    Gm[tri(a, b)] = fma(tf, pr, Gm[tri(a, b)]);
-                    Cm[tri(a, b)] = fma(si, pr, Cm[tri(a, b)]);
-                }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        gdst[a * WAVE] = Gm[a];
-        cdst[a * WAVE] = Cm[a];
-    }
-    st.gram = true;
-    st.r += times * m;
+    if (a.n != b.n || a.n_tasks != b.n_tasks || a.all_affine != b.all_affine || a.uses_fk != b.uses_fk ||
+        a.quat_src != b.quat_src || a.feedforward != b.feedforward || a.multidim != b.multidim ||
+        a.conv_last != b.conv_last || a.standard != b.standard)
+        return false;
+    for (int i = 0; i < a.n_tasks; ++i)
+        if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i])
+            return false;
+    return true;
 }
 
-// w <- w - pinv(vstack Ja) * (vstack rJa) * w     (pseudo_inverse.py:387-392)
-template <int N>
-__device__ __forceinline__ void stack_project(const Stack<N>& st, const double* wk, int lane, int n,
-                                              double lam, double (&w)[N])
+// Index into kShapes for a skill: the matching static shape, else the dynamic
+// kernel of the smallest sufficient width.  `allow_static` = 0 forces dynamic.
+int pinv_pick_kernel(const DevSkill& S, int allow_static)
 {
-    constexpr int NT = N * (N + 1) / 2;
-    double L[NT], rd[N], u[N];
-    if (st.gram) {
-        const double* G = wk + lane;
-        const double* Cc = wk + (size_t)NT * WAVE + lane;
-#pragma unroll
-        for (int a = 0; a < N; ++a) u[a] = 0.0;
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                const double c = Cc[tri(a, b) * WAVE];
-                u[a] = fma(c, w[b], u[a]);
-                if (b != a) u[b] = fma(c, w[a], u[b]);
-            }
-#pragma unroll
-        for (int a = 0; a < NT; ++a) L[a] = G[a * WAVE];
-        ldl_factor<N>(L, rd, n);
-        ldl_solve<N>(L, rd, u, n);
-#pragma unroll
-        for (int a = 0; a < N; ++a) w[a] -= u[a];
-    } else {
-        const int r = st.r;
-        // B = Ja Ja^T + lam I (r x r), u = diag(s) Ja w
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            u[i] = 0.0;
-            if (i < r) {
-                double ri[N];
-#pragma unroll
-                for (int j = 0; j < N; ++j) ri[j] = (j < n) ? wk[(i * N + j) * WAVE + lane] : 0.0;
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) s = fma(ri[j], w[j], s);
-                u[i] = ((st.sbits >> i) & 1u) ? s : 0.0;
-#pragma unroll
-                for (int k = 0; k <= i; ++k) {
-                    double acc = (k == i) ? lam : 0.0;
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        if (j < n) acc = fma(ri[j], wk[(k * N + j) * WAVE + lane], acc);
-                    L[tri(i, k)] = acc;
-                }
-            }
-        }
-        ldl_factor<N>(L, rd, r);
-        ldl_solve<N>(L, rd, u, r);
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (k < r) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (j < n) w[j] = fma(-u[k], wk[(k * N + j) * WAVE + lane], w[j]);
-            }
-        }
-    }
+    if (allow_static && S.d.n_tasks <= SHAPE_MAX_TASKS)
+        for (int k = 0; k < kNumShapes; ++k)
+            if (kShapes[k].sd && shape_equal(*kShapes[k].sd, S.shape)) return k;
+    int need = S.n;
+    for (int ti = 0; ti < S.d.n_tasks; ++ti)
+        if (S.d.tasks[ti].m > need) need = S.d.tasks[ti].m;
+    for (int k = 0; k < kNumShapes; ++k)
+        if (!kShapes[k].sd && kShapes[k].N >= need) return k;
+    return -1;
 }
 
-// ---- one controller tick for the lane's instance --------------------------------
-template <int N>
-__device__ __forceinline__ void pinv_tick(const DevSkill* __restrict__ S, const TickArgs& tk,
-                                          const double (&z)[N], const double* zs, const double* ys,
-                                          double* wk, int lane, bool valid, double (&vout)[N],
-                                          int& acc_mode)
-{
-    constexpr int NT = N * (N + 1) / 2;
-    const clik_skill_desc& D = S->d;
-    const int n = S->n;
-    const int n_tasks = D.n_tasks;
-    const bool ff = S->po.feedforward != 0;
-    const bool multidim = S->po.multidim_sets != 0;
-    const bool conv_last = S->po.converge_final_set_to_max != 0;
-    const bool standard = S->po.pinv_method == CLIK_PINV_STANDARD;
-    const double lam = standard ? 0.0 : S->po.damping_factor;
-    const int cap = standard ? n - 1 : n;      // rows for which the stacked pinv is "wide"
+const char* pinv_kernel_name(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].name : "none"; }
+int pinv_kernel_width(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].N : 0; }
 
-    Kin<N> K;
-    if (D.uses_fk) {
-        forward_kinematics<N>(S, zs, wk, lane, K);
-        if (D.quat_src != 0) orientation_feature<N>(S, ys, lane, K);
-    }
-
-    bool done = !valid;
-    acc_mode = -1;
-#pragma unroll
-    for (int j = 0; j < N; ++j) vout[j] = 0.0;
-
-    const int n_modes = S->n_modes;
-    for (int mk = 0; mk < n_modes; ++mk) {
-        if (__ballot(!done) == 0ull) break;
-        const uint32_t act = S->act[mk];
-        double v[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = 0.0;
-        Stack<N> st;
-        st.r = 0;
-        st.gram = false;
-        st.sbits = 0u;
-        bool ok = true;
-        for (int pass = 0; pass < 2; ++pass) {
-            int set_idx = 0;
-            for (int ti = 0; ti < n_tasks; ++ti) {
-                const clik_task& t = D.tasks[ti];
-                const int cls = t.cls;
-                const int m = t.m;
-                const bool is_set = cls == CLIK_CLS_SET;
-                const bool active = is_set && ((act >> set_idx) & 1u);
-                if (is_set) ++set_idx;
-                if (cls == CLIK_CLS_VELSET) continue;          // no branch in the reference (:274-443)
-                const bool tc_item = is_set && !active;
-                if ((pass == 0) == tc_item) continue;
-
-                double e[N], J[N][N], Jt[N];
-                task_eval<N, N>(S, ti, tk, K, z, ys, lane, n, e, J, Jt);
-
-                if (pass == 1) {
-                    // in-tangent-cone test of an inactive set with the candidate velocity
-                    double de[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        double s = 0.0;
-                        if (i < m) {
-                            s = Jt[i];
-#pragma unroll
-                            for (int j = 0; j < N; ++j)
-                                if (j < n) s = fma(J[i][j], v[j], s);
-                        }
-                        de[i] = s;
-                    }
-                    bool in_tc;
-                    if (m == 1) {
-                        // pseudo_inverse.py:162-185
-                        const double ev = e[0];
-                        if (t.set_min[0] - ev < 1e-12) {
-                            in_tc = (ev - t.set_max[0] < 1e-12) ? true : (de[0] < 0.0);
-                        } else {
-                            in_tc = de[0] > 0.0;
-                        }
-                    } else {
-                        // pseudo_inverse.py:222-252
-                        bool inside = true, corner = true;
-                        double od = 0.0, nde = 0.0, nout = 0.0;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) {
-                            if (i < m) {
-                                const double le = e[i] - t.set_min[i];
-                                const double ue = e[i] - t.set_max[i];
-                                if (!(le >= 1e-12) || !(ue <= 1e-12)) inside = false;
-                                const double sl = (le > 0.0) - (le < 0.0);
-                                const double su = (ue > 0.0) - (ue < 0.0);
-                                if (sl != su) corner = false;
-                                const double out = 0.5 * (sl + su);
-                                od = fma(out, de[i], od);
-                                nde = fma(de[i], de[i], nde);
-                                nout = fma(out, out, nout);
-                            }
-                        }
-                        bool going_in;
-                        if (corner) {
-                            const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
-                            going_in = (od < 0.0) ? (fabs(od) / dists < 0.70710678118654757) : false;
-                        } else {
-                            going_in = od < 0.0;
-                        }
-                        in_tc = inside ? true : going_in;
-                    }
-                    ok = ok && in_tc;
-                    continue;
-                }
-
-                // ---- pass 0: controller algebra
-                const bool is_first = (st.r == 0);
-                const bool is_last = (ti == n_tasks - 1);
-                const bool conv = is_set && is_last && conv_last;
-                uint32_t srow = 0xffffffffu;
-                if (multidim && is_set) {
-                    srow = 0u;
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if (i < m && ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)))
-                            srow |= 1u << i;
-                }
-                const bool contributes = (cls == CLIK_CLS_EQ) || (cls == CLIK_CLS_VELEQ) || conv;
-                if (!contributes) {
-                    // active set (pseudo_inverse.py:398-405): rows only
-                    stack_push<N>(st, wk, lane, n, cap, lam, J, m, srow, 1);
-                    continue;
-                }
-                double des[N];
-                if (cls == CLIK_CLS_EQ) {
-                    double ke[N];
-                    gain_apply<N>(t, e, ke);
-#pragma unroll
-                    for (int i = 0; i < N; ++i) des[i] = -ke[i];
-                } else if (cls == CLIK_CLS_VELEQ) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) des[i] = (i < m) ? t.target[i] : 0.0;
-                } else {
-                    double d0[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) d0[i] = (i < m) ? t.set_max[i] - e[i] : 0.0;
-                    gain_apply<N>(t, d0, des);
-                }
-                if (ff) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if (i < m) des[i] -= Jt[i];
-                }
-
-                // w = pinv(J) des  (pseudo_inverse.py:92-105)
-                double w[N], L[NT], rd[N];
-                const bool wide = standard ? (m < n) : (n >= m);
-                if (wide) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        if (i < m) {
-#pragma unroll
-                            for (int k = 0; k <= i; ++k) {
-                                double acc = (k == i) ? lam : 0.0;
-#pragma unroll
-                                for (int j = 0; j < N; ++j)
-                                    if (j < n) acc = fma(J[i][j], J[k][j], acc);
-                                L[tri(i, k)] = acc;
-                            }
-                        }
-                    }
-                    ldl_factor<N>(L, rd, m);
-                    ldl_solve<N>(L, rd, des, m);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int i = 0; i < N; ++i)
-                            if (i < m) s = fma(J[i][j], des[i], s);
-                        w[j] = s;
-                    }
-                } else {
-#pragma unroll
-                    for (int a = 0; a < N; ++a) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int i = 0; i < N; ++i)
-                            if (i < m) s = fma(J[i][a], des[i], s);
-                        w[a] = s;
-#pragma unroll
-                        for (int b = 0; b <= a; ++b) {
-                            double acc = (a == b && a < n) ? lam : 0.0;
-#pragma unroll
-                            for (int i = 0; i < N; ++i)
-                                if (i < m) acc = fma(J[i][a], J[i][b], acc);
-                            L[tri(a, b)] = acc;
-                        }
-                    }
-                    ldl_factor<N>(L, rd, n);
-                    ldl_solve<N>(L, rd, w, n);
-                }
-
-                const bool quirk = is_first && cls == CLIK_CLS_EQ;
-                if (is_first) {
-#pragma unroll
-                    for (int j = 0; j < N; ++j) v[j] += w[j];
-                }
-                if (quirk && wide) {
-                    // second processing of the first EqualityConstraint
-                    // (:382-396): the stack is [J] itself, so the factor of
-                    // J J^T + lam I is reused:  w2 = w - J^T A^{-1} (J w)
-                    double u[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        double s = 0.0;
-                        if (i < m) {
-#pragma unroll
-                            for (int j = 0; j < N; ++j)
-                                if (j < n) s = fma(J[i][j], w[j], s);
-                        }
-                        u[i] = s;
-                    }
-                    ldl_solve<N>(L, rd, u, m);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        double s = w[j];
-#pragma unroll
-                        for (int i = 0; i < N; ++i)
-                            if (i < m) s = fma(-J[i][j], u[i], s);
-                        v[j] += s;
-                    }
-                    stack_push<N>(st, wk, lane, n, cap, lam, J, m, 0xffffffffu, 2);
-                } else if (quirk) {
-                    // tall first equality: generic route (push, project, push)
-                    stack_push<N>(st, wk, lane, n, cap, lam, J, m, 0xffffffffu, 1);
-                    stack_project<N>(st, wk, lane, n, lam, w);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) v[j] += w[j];
-                    stack_push<N>(st, wk, lane, n, cap, lam, J, m, 0xffffffffu, 1);
-                } else {
-                    if (!is_first) {
-                        stack_project<N>(st, wk, lane, n, lam, w);
-#pragma unroll
-                        for (int j = 0; j < N; ++j) v[j] += w[j];
-                    }
-                    stack_push<N>(st, wk, lane, n, cap, lam, J, m,
-                                  (conv && multidim) ? srow : 0xffffffffu, 1);
-                }
-            }
-        }
-        if (!done && ok) {
-            done = true;
-            acc_mode = mk;
-#pragma unroll
-            for (int j = 0; j < N; ++j) vout[j] = v[j];
-        }
-    }
-}
-
-// LDS slots (doubles per lane) the kernels need for a skill
-__host__ __device__ inline int pinv_lds_slots(int N, int ny)
-{
-    int wk = N * (N + 1);
-    if (6 * N > wk) wk = 6 * N;
-    return N + ny + wk;
-}
-
-template <int N>
-__global__ __launch_bounds__(WAVE) void pinv_solve_kernel(
-    const DevSkill* __restrict__ S, const TickArgs tk, const long long B,
-    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ dx, int32_t* __restrict__ mode_out)
-{
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
-    const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
-    double* zs = lds;
-    double* ys = zs + N * WAVE;
-    double* wk = ys + ny * WAVE;
-
-    // zero-fill so tail lanes compute on defined data
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
-    __syncthreads();
-    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_in(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
-    __syncthreads();
-
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = (j < n) ? zs[j * WAVE + lane] : 0.0;
-
-    double vout[N];
-    int acc_mode;
-    pinv_tick<N>(S, tk, z, zs, ys, wk, lane, valid, vout, acc_mode);
-
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (j < n) zs[j * WAVE + lane] = vout[j];
-    __syncthreads();
-    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_out(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
-}
-
-// n_ticks of  solve -> clamp -> explicit Euler  in one launch (the loop every
-// reference notebook runs on the host, ur5_moe2016_example2.ipynb:537-545).
-template <int N>
-__global__ __launch_bounds__(WAVE) void pinv_rollout_kernel(
-    const DevSkill* __restrict__ S, const double* __restrict__ tterms, const int n_ticks,
-    const double dt, const double max_speed, const long long B,
-    double* __restrict__ q, const double* __restrict__ y,
-    double* __restrict__ dq, int32_t* __restrict__ mode_out)
-{
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
-    const int n = S->n, nq = S->d.n_q, ny = S->d.n_y;
-    const int nts = S->d.n_tslots;
-    double* zs = lds;
-    double* ys = zs + N * WAVE;
-    double* wk = ys + ny * WAVE;
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
-    __syncthreads();
-    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
-    __syncthreads();
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = (j < n) ? zs[j * WAVE + lane] : 0.0;
-    double vout[N];
-    int acc_mode = -1;
-#pragma unroll
-    for (int j = 0; j < N; ++j) vout[j] = 0.0;
-    for (int tick = 0; tick < n_ticks; ++tick) {
-        TickArgs tk;
-        for (int k = 0; k < 2 * nts; ++k) tk.tv[k] = tterms[(size_t)tick * 2 * nts + k];
-        pinv_tick<N>(S, tk, z, zs, ys, wk, lane, valid, vout, acc_mode);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (j < n) {
-                double d = vout[j];
-                if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
-                vout[j] = d;
-                z[j] = fma(d, dt, z[j]);
-                zs[j * WAVE + lane] = z[j];
-            }
-        }
-    }
-    __syncthreads();
-    stage_out(q + b0 * nq, nq, rows_valid, zs, lane);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (j < n) zs[j * WAVE + lane] = vout[j];
-    __syncthreads();
-    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
-    if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
-}
-
-// ---- host-side launchers (called from clik_api.hip) ----------------------------
-template <int N>
-static hipError_t launch_solve(const DevSkill* dS, const TickArgs& tk, long long B, int ny,
-                               const double* q, const double* x, const double* y, double* dq,
-                               double* dx, int32_t* mode, hipStream_t stream)
-{
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t shmem = (size_t)pinv_lds_slots(N, ny) * WAVE * sizeof(double);
-    hipLaunchKernelGGL(pinv_solve_kernel<N>, dim3(grid), dim3(WAVE), shmem, stream, dS, tk, B, q, x, y,
-                       dq, dx, mode);
-    return hipGetLastError();
-}
-
-template <int N>
-static hipError_t launch_rollout(const DevSkill* dS, const double* d_tterms, int n_ticks, double dt,
-                                 double max_speed, long long B, int ny, double* q, const double* y,
-                                 double* dq, int32_t* mode, hipStream_t stream)
-{
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t shmem = (size_t)pinv_lds_slots(N, ny) * WAVE * sizeof(double);
-    hipLaunchKernelGGL(pinv_rollout_kernel<N>, dim3(grid), dim3(WAVE), shmem, stream, dS, d_tterms,
-                       n_ticks, dt, max_speed, B, q, y, dq, mode);
-    return hipGetLastError();
-}
-
-hipError_t pinv_launch_solve(int N, const DevSkill* dS, const TickArgs& tk, long long B, int ny,
+hipError_t pinv_launch_solve(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                              const double* q, const double* x, const double* y, double* dq,
                              double* dx, int32_t* mode, hipStream_t stream)
 {
-    switch (N) {
-        case 6: return launch_solve<6>(dS, tk, B, ny, q, x, y, dq, dx, mode, stream);
-        case 7: return launch_solve<7>(dS, tk, B, ny, q, x, y, dq, dx, mode, stream);
-        case 8: return launch_solve<8>(dS, tk, B, ny, q, x, y, dq, dx, mode, stream);
-        default: return hipErrorInvalidValue;
-    }
+    if (k < 0 || k >= kNumShapes) return hipErrorInvalidValue;
+    return kShapes[k].solve(dS, wa, tk, B, ny, q, x, y, dq, dx, mode, stream);
 }
 
-hipError_t pinv_launch_rollout(int N, const DevSkill* dS, const double* d_tterms, int n_ticks,
+hipError_t pinv_launch_rollout(int k, const DevSkill* dS, const WarmArgs& wa, const double* d_tterms, int n_ticks,
                                double dt, double max_speed, long long B, int ny, double* q,
                                const double* y, double* dq, int32_t* mode, hipStream_t stream)
 {
-    switch (N) {
-        case 6: return launch_rollout<6>(dS, d_tterms, n_ticks, dt, max_speed, B, ny, q, y, dq, mode, stream);
-        case 7: return launch_rollout<7>(dS, d_tterms, n_ticks, dt, max_speed, B, ny, q, y, dq, mode, stream);
-        case 8: return launch_rollout<8>(dS, d_tterms, n_ticks, dt, max_speed, B, ny, q, y, dq, mode, stream);
-        default: return hipErrorInvalidValue;
-    }
+    if (k < 0 || k >= kNumShapes) return hipErrorInvalidValue;
+    return kShapes[k].rollout(dS, wa, d_tterms, n_ticks, dt, max_speed, B, ny, q, y, dq, mode, stream);
 }
 
-}  // namespace clik
-
-namespace clik {
 int pinv_lds_slots_host(int N, int ny) { return pinv_lds_slots(N, ny); }
+
 }  // namespace clik

@@ -1,0 +1,564 @@
+// Shape-specialised PseudoInverseController mode evaluation.
+//
+// For a skill whose structure (ShapeDesc) is known at compile time, the whole
+// control flow of one mode of reference pseudo_inverse.py:259-451 is decided by
+// a constexpr *plan*: which constraints contribute a velocity, which only stack
+// rows, when the stacked pseudo-inverse is "wide" (rows kept) or "tall" (Gram
+// matrices), where the first-equality double processing happens, and which
+// pushes nobody consumes any more.  The device code follows the plan with
+// `if constexpr` and exact array sizes, so every index is static, no branch is
+// left in the instruction stream and every matrix lives in registers.
+#pragma once
+#include "clik_device.hpp"
+
+namespace clik {
+
+struct TaskPlan {
+    bool skip;          // VelocitySetConstraint (ignored) or inactive set
+    bool cone;          // inactive SetConstraint: tangent-cone test after the scan
+    bool contributes;   // adds a velocity term
+    bool first;         // stack empty before this task
+    bool quirk;         // first EqualityConstraint: processed and stacked twice
+    bool wide_self;     // pinv(J) uses the wide (J J^T) branch
+    bool const_j;
+    bool set_rows;      // multidim SetConstraint rows: per-lane activation bits
+    bool conv;          // converge_final_set_to_max term
+    int  r_before;      // stacked rows before the task
+    bool gram_before;   // stack held as Gram matrices before the task
+    int  wide_before;   // rows held explicitly before the task (0 when gram)
+    int  push_times;    // 0: nothing consumes the stack afterwards
+    bool gram_after;
+    int  r_after;
+    bool c_is_g_before; // all stacked rows so far have activation 1 (C = G - lam I)
+    bool c_is_g_after;
+};
+
+struct ModePlan {
+    TaskPlan t[SHAPE_MAX_TASKS];
+    int max_wide;       // largest explicit row count the stack reaches
+    bool any_cone;
+};
+
+constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
+{
+    ModePlan mp{};
+    const int n = sd.n;
+    const int cap = sd.standard ? n - 1 : n;
+    int r = 0, set_idx = 0;
+    bool gram = false, c_is_g = true;
+    // last task that reads the stack (contributing, not first)
+    int last_consumer = -1;
+    {
+        int rr = 0, si = 0;
+        for (int ti = 0; ti < sd.n_tasks; ++ti) {
+            const int cls = sd.cls[ti];
+            const bool is_set = cls == CLIK_CLS_SET;
+            const bool active = is_set && ((act >> si) & 1u);
+            if (is_set) ++si;
+            if (cls == CLIK_CLS_VELSET || (is_set && !active)) continue;
+            const bool conv = is_set && ti == sd.n_tasks - 1 && sd.conv_last;
+            const bool contributes = cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ || conv;
+            if (contributes && rr > 0) last_consumer = ti;
+            rr += sd.m[ti] * ((contributes && rr == 0 && cls == CLIK_CLS_EQ) ? 2 : 1);
+        }
+    }
+    for (int ti = 0; ti < sd.n_tasks; ++ti) {
+        TaskPlan& p = mp.t[ti];
+        const int cls = sd.cls[ti];
+        const int m = sd.m[ti];
+        const bool is_set = cls == CLIK_CLS_SET;
+        const bool active = is_set && ((act >> set_idx) & 1u);
+        if (is_set) ++set_idx;
+        p.r_before = r;
+        p.gram_before = gram;
+        p.wide_before = gram ? 0 : r;
+        p.c_is_g_before = c_is_g;
+        p.const_j = sd.const_j[ti] != 0;
+        if (cls == CLIK_CLS_VELSET) { p.skip = true; p.r_after = r; p.gram_after = gram; p.c_is_g_after = c_is_g; continue; }
+        if (is_set && !active) {
+            p.skip = true; p.cone = true; mp.any_cone = true;
+            p.r_after = r; p.gram_after = gram; p.c_is_g_after = c_is_g;
+            continue;
+        }
+        p.conv = is_set && ti == sd.n_tasks - 1 && sd.conv_last;
+        p.contributes = cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ || p.conv;
+        p.first = r == 0;
+        p.quirk = p.contributes && p.first && cls == CLIK_CLS_EQ;
+        p.wide_self = sd.standard ? (m < n) : (n >= m);
+        p.set_rows = is_set && sd.multidim;
+        const bool rows_flagged = p.set_rows;           // rows may carry activation 0
+        const int times = p.quirk ? 2 : 1;
+        const bool consumed = ti < last_consumer || (p.quirk && ti <= last_consumer);
+        // a quirk task consumes its own first push even if nothing follows
+        p.push_times = (ti < last_consumer) ? times : 0;
+        if (p.quirk && !(p.wide_self && !p.const_j)) {
+            // generic quirk route needs the first push for its own projection
+            if (p.push_times == 0) p.push_times = 1;
+        }
+        (void)consumed;
+        if (p.push_times > 0) {
+            const int r_new = r + p.push_times * m;
+            if (!gram && r_new <= cap) {
+                if (r_new > mp.max_wide) mp.max_wide = r_new;
+            } else {
+                gram = true;
+            }
+            r = r_new;
+            if (rows_flagged) c_is_g = false;
+        }
+        p.r_after = r;
+        p.gram_after = gram;
+        p.c_is_g_after = c_is_g;
+    }
+    return mp;
+}
+
+template <const ShapeDesc& SD, unsigned ACT>
+struct Plan {
+    static constexpr ModePlan mode = make_plan(SD, ACT);
+};
+
+// ---- static-size linear algebra ----------------------------------------------------
+template <int K>
+__device__ __forceinline__ void ldl_factor_s(double (&A)[K * (K + 1) / 2], double (&rd)[K])
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double t[K];
+        double d = A[tri(k, k)];
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+            t[j] = A[tri(k, j)] * A[tri(j, j)];
+            d = fma(-A[tri(k, j)], t[j], d);
+        }
+        A[tri(k, k)] = d;
+        const double inv = 1.0 / d;
+        rd[k] = inv;
+#pragma unroll
+        for (int i = k + 1; i < K; ++i) {
+            double s = A[tri(i, k)];
+#pragma unroll
+            for (int j = 0; j < k; ++j) s = fma(-A[tri(i, j)], t[j], s);
+            A[tri(i, k)] = s * inv;
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void ldl_solve_s(const double (&A)[K * (K + 1) / 2], const double (&rd)[K],
+                                            double (&x)[K])
+{
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) x[i] = fma(-A[tri(i, j)], x[j], x[i]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) x[i] *= rd[i];
+#pragma unroll
+    for (int i = K - 2; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < K; ++j) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
+}
+
+// e, J, d e/d t of a task with compile-time row count and feature flags
+template <int N, int M, int FLAGS>
+__device__ __forceinline__ void task_eval_s(const DevSkill* __restrict__ S, const int ti, const TickArgs& tk,
+                                            const Kin<N>& K, const double (&z)[N], const double* ys,
+                                            const int lane, double (&e)[M], double (&J)[M][N], double (&Jt)[M])
+{
+    const clik_task& t = S->d.tasks[ti];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const clik_row& r = S->d.rows[t.out_row0[i]];
+        double g[N], dt;
+        e[i] = row_eval<N>(S, r, FLAGS, tk, K, z, ys, lane, N, g, dt);
+        Jt[i] = dt;
+#pragma unroll
+        for (int j = 0; j < N; ++j) J[i][j] = g[j];
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void gain_apply_s(const clik_task& t, const double (&v)[M], double (&out)[M])
+{
+    if (!t.gain_is_matrix) {
+        const double g = t.gain[0];
+#pragma unroll
+        for (int i = 0; i < M; ++i) out[i] = g * v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) s = fma(t.gain[i * M + k], v[k], s);
+            out[i] = s;
+        }
+    }
+}
+
+// in-tangent-cone test with compile-time row count (pseudo_inverse.py:162-185, :222-252)
+template <int N, int M>
+__device__ __forceinline__ bool in_tangent_cone_s(const clik_task& t, const double (&e)[M],
+                                                  const double (&J)[M][N], const double (&Jt)[M],
+                                                  const double (&v)[N])
+{
+    double de[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double s = Jt[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) s = fma(J[i][j], v[j], s);
+        de[i] = s;
+    }
+    if constexpr (M == 1) {
+        const double ev = e[0];
+        if (t.set_min[0] - ev < 1e-12) return (ev - t.set_max[0] < 1e-12) ? true : (de[0] < 0.0);
+        return de[0] > 0.0;
+    } else {
+        bool inside = true, corner = true;
+        double od = 0.0, nde = 0.0, nout = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const double le = e[i] - t.set_min[i];
+            const double ue = e[i] - t.set_max[i];
+            if (!(le >= 1e-12) || !(ue <= 1e-12)) inside = false;
+            const double sl = (le > 0.0) - (le < 0.0);
+            const double su = (ue > 0.0) - (ue < 0.0);
+            if (sl != su) corner = false;
+            const double out = 0.5 * (sl + su);
+            od = fma(out, de[i], od);
+            nde = fma(de[i], de[i], nde);
+            nout = fma(out, out, nout);
+        }
+        bool going_in;
+        if (corner) {
+            const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+            going_in = (od < 0.0) ? (fabs(od) / dists < 0.70710678118654757) : false;
+        } else {
+            going_in = od < 0.0;
+        }
+        return inside ? true : going_in;
+    }
+}
+
+// ---- per-mode state ------------------------------------------------------------------
+template <int N, int WIDE>
+struct StackS {
+    double   rows[WIDE > 0 ? WIDE : 1][N];   // explicit stacked rows (wide form)
+    uint32_t sbits;                          // activation of the explicit rows
+    double   G[N * (N + 1) / 2];             // lam I + Ja^T Ja       (gram form)
+    double   C[N * (N + 1) / 2];             // Ja^T diag(s) Ja       (gram form, when != G - lam I)
+};
+
+// mutable per-mode state: plain arrays only (no pointers / references) so that
+// scalar replacement keeps every element in a register
+template <const ShapeDesc& SD, unsigned ACT>
+struct ModeCtx {
+    static constexpr int N = SD.n;
+    static constexpr int WIDE = Plan<SD, ACT>::mode.max_wide;
+    double lam;
+    double v[N];
+    StackS<N, WIDE> st;
+    bool ok;
+};
+
+// read-only inputs of a mode evaluation, passed as separate parameters
+#define CLIK_MODE_IN const DevSkill* __restrict__ S, const TickArgs& tk, const Kin<SD.n>& K, \
+                     const double (&z)[SD.n], const double* ys, const int lane
+#define CLIK_MODE_ARGS S, tk, K, z, ys, lane
+
+// w <- w - pinv(stack) * rJa * w  for the stack state BEFORE task TI
+template <const ShapeDesc& SD, unsigned ACT, int TI>
+__device__ __forceinline__ void project_s(ModeCtx<SD, ACT>& c, double (&w)[SD.n])
+{
+    constexpr int N = SD.n;
+    constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
+    constexpr int NT = N * (N + 1) / 2;
+    if constexpr (P.gram_before) {
+        double u[N], L[NT], rd[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) u[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double cc;
+                if constexpr (P.c_is_g_before) cc = (a == b) ? c.st.G[tri(a, b)] - c.lam : c.st.G[tri(a, b)];
+                else cc = c.st.C[tri(a, b)];
+                u[a] = fma(cc, w[b], u[a]);
+                if (b != a) u[b] = fma(cc, w[a], u[b]);
+            }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) L[a] = c.st.G[a];
+        ldl_factor_s<N>(L, rd);
+        ldl_solve_s<N>(L, rd, u);
+#pragma unroll
+        for (int a = 0; a < N; ++a) w[a] -= u[a];
+    } else {
+        constexpr int R = P.wide_before;
+        static_assert(R > 0, "projection with an empty stack");
+        double u[R], L[R * (R + 1) / 2], rd[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) s = fma(c.st.rows[i][j], w[j], s);
+            u[i] = ((c.st.sbits >> i) & 1u) ? s : 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) {
+                double acc = (k == i) ? c.lam : 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc = fma(c.st.rows[i][j], c.st.rows[k][j], acc);
+                L[tri(i, k)] = acc;
+            }
+        }
+        ldl_factor_s<R>(L, rd);
+        ldl_solve_s<R>(L, rd, u);
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+            for (int j = 0; j < N; ++j) w[j] = fma(-u[k], c.st.rows[k][j], w[j]);
+    }
+}
+
+// stack the rows of task TI (`TIMES` times) following the plan
+template <const ShapeDesc& SD, unsigned ACT, int TI, int TIMES>
+__device__ __forceinline__ void push_s(ModeCtx<SD, ACT>& c, const double (&J)[SD.m[TI]][SD.n], const uint32_t srow,
+                                       const int r_now, const bool gram_now)
+{
+    constexpr int N = SD.n;
+    constexpr int M = SD.m[TI];
+    constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
+    constexpr int NT = N * (N + 1) / 2;
+    (void)r_now; (void)gram_now;
+    if constexpr (!P.gram_after) {
+        // stays wide: append at compile-time offsets
+        constexpr int r0 = P.r_after - TIMES * M;
+#pragma unroll
+        for (int rep = 0; rep < TIMES; ++rep)
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) c.st.rows[r0 + rep * M + i][j] = J[i][j];
+        uint32_t bits = srow & ((1u << M) - 1u);
+#pragma unroll
+        for (int rep = 0; rep < TIMES; ++rep) c.st.sbits |= bits << (r0 + rep * M);
+    } else {
+        constexpr int r_prev = P.r_after - TIMES * M;       // rows before this push
+        constexpr bool was_gram = (TIMES == P.push_times) ? P.gram_before
+                                                          : (P.gram_before || false);
+        // one Gram entry at a time (no temporaries of matrix size): old rows
+        // (when converting from the wide form), then the new rows
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double g, cc = 0.0;
+                if constexpr (!was_gram) {
+                    g = (a == b) ? c.lam : 0.0;
+#pragma unroll
+                    for (int k = 0; k < r_prev; ++k) {
+                        const double pr = c.st.rows[k][a] * c.st.rows[k][b];
+                        g += pr;
+                        if constexpr (!P.c_is_g_before) cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
+                    }
+                } else {
+                    g = c.st.G[tri(a, b)];
+                    if constexpr (!P.c_is_g_before) cc = c.st.C[tri(a, b)];
+                }
+                if constexpr (P.c_is_g_before && !P.c_is_g_after)
+                    cc = (a == b) ? g - c.lam : g;      // C starts to differ from G - lam I here
+                double acc = 0.0, accs = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const double pr = J[i][a] * J[i][b];
+                    acc += pr;
+                    if constexpr (P.set_rows) accs += ((srow >> i) & 1u) ? pr : 0.0;
+                }
+                c.st.G[tri(a, b)] = fma((double)TIMES, acc, g);
+                if constexpr (!P.c_is_g_after) c.st.C[tri(a, b)] = fma((double)TIMES, P.set_rows ? accs : acc, cc);
+            }
+    }
+}
+
+template <const ShapeDesc& SD, unsigned ACT, int TI>
+__device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+{
+    constexpr int N = SD.n;
+    constexpr int M = SD.m[TI];
+    constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
+    if constexpr (!P.skip) {
+        const clik_task& t = S->d.tasks[TI];
+        double e[M], J[M][N], Jt[M];
+        task_eval_s<N, M, SD.flags[TI]>(S, TI, tk, K, z, ys, lane, e, J, Jt);
+        uint32_t srow = 0xffffffffu;
+        if constexpr (P.set_rows) {
+            srow = 0u;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+                if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
+        }
+        if constexpr (!P.contributes) {
+            if constexpr (P.push_times > 0) push_s<SD, ACT, TI, P.push_times>(c, J, srow, 0, false);
+        } else {
+            double des[M];
+            if constexpr (SD.cls[TI] == CLIK_CLS_EQ) {
+                double ke[M];
+                gain_apply_s<M>(t, e, ke);
+#pragma unroll
+                for (int i = 0; i < M; ++i) des[i] = -ke[i];
+            } else if constexpr (SD.cls[TI] == CLIK_CLS_VELEQ) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) des[i] = t.target[i];
+            } else {
+                double d0[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) d0[i] = t.set_max[i] - e[i];
+                gain_apply_s<M>(t, d0, des);
+            }
+            if constexpr (SD.feedforward != 0) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) des[i] -= Jt[i];
+            }
+            double w[N];
+            constexpr bool own_factor = !P.const_j && P.wide_self;
+            double L[own_factor ? M * (M + 1) / 2 : 1], rd[own_factor ? M : 1];
+            if constexpr (P.const_j) {
+                const double* Pm = S->cpinv[TI];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < M; ++i) s = fma(Pm[j * CLIK_MAX_M + i], des[i], s);
+                    w[j] = s;
+                }
+            } else if constexpr (P.wide_self) {
+#pragma unroll
+                for (int i = 0; i < M; ++i)
+#pragma unroll
+                    for (int k = 0; k <= i; ++k) {
+                        double acc = (k == i) ? c.lam : 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) acc = fma(J[i][j], J[k][j], acc);
+                        L[tri(i, k)] = acc;
+                    }
+                ldl_factor_s<M>(L, rd);
+                ldl_solve_s<M>(L, rd, des);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < M; ++i) s = fma(J[i][j], des[i], s);
+                    w[j] = s;
+                }
+            } else {
+                double Lg[N * (N + 1) / 2], rg[N];
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < M; ++i) s = fma(J[i][a], des[i], s);
+                    w[a] = s;
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) {
+                        double acc = (a == b) ? c.lam : 0.0;
+#pragma unroll
+                        for (int i = 0; i < M; ++i) acc = fma(J[i][a], J[i][b], acc);
+                        Lg[tri(a, b)] = acc;
+                    }
+                }
+                ldl_factor_s<N>(Lg, rg);
+                ldl_solve_s<N>(Lg, rg, w);
+            }
+            if constexpr (P.first) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) c.v[j] += w[j];
+            }
+            if constexpr (P.quirk && own_factor) {
+                // second processing of the first EqualityConstraint (:382-396) with
+                // the stack [J]: the factor of J J^T + lam I is reused
+                double u[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) s = fma(J[i][j], w[j], s);
+                    u[i] = s;
+                }
+                ldl_solve_s<M>(L, rd, u);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double s = w[j];
+#pragma unroll
+                    for (int i = 0; i < M; ++i) s = fma(-J[i][j], u[i], s);
+                    c.v[j] += s;
+                }
+                if constexpr (P.push_times > 0) push_s<SD, ACT, TI, P.push_times>(c, J, 0xffffffffu, 0, false);
+            } else if constexpr (P.quirk) {
+                static_assert(!P.quirk || own_factor, "static shapes need a wide, state-dependent first EqualityConstraint");
+            } else {
+                if constexpr (!P.first) {
+                    project_s<SD, ACT, TI>(c, w);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) c.v[j] += w[j];
+                }
+                if constexpr (P.push_times > 0)
+                    push_s<SD, ACT, TI, P.push_times>(c, J, (P.conv && SD.multidim) ? srow : 0xffffffffu, 0, false);
+            }
+        }
+    }
+}
+
+template <const ShapeDesc& SD, unsigned ACT, int TI>
+__device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+{
+    constexpr int N = SD.n;
+    constexpr int M = SD.m[TI];
+    constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
+    if constexpr (P.cone) {
+        double e[M], J[M][N], Jt[M];
+        task_eval_s<N, M, SD.flags[TI]>(S, TI, tk, K, z, ys, lane, e, J, Jt);
+        c.ok = c.ok && in_tangent_cone_s<N, M>(S->d.tasks[TI], e, J, Jt, c.v);
+    }
+}
+
+template <const ShapeDesc& SD, unsigned ACT, int TI>
+__device__ __forceinline__ void steps_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+{
+    if constexpr (TI < SD.n_tasks) {
+        step_s<SD, ACT, TI>(CLIK_MODE_ARGS, c);
+        steps_s<SD, ACT, TI + 1>(CLIK_MODE_ARGS, c);
+    }
+}
+
+template <const ShapeDesc& SD, unsigned ACT, int TI>
+__device__ __forceinline__ void cones_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+{
+    if constexpr (TI < SD.n_tasks) {
+        cone_s<SD, ACT, TI>(CLIK_MODE_ARGS, c);
+        cones_s<SD, ACT, TI + 1>(CLIK_MODE_ARGS, c);
+    }
+}
+
+// candidate velocity of the mode with activation mask ACT; returns whether all
+// inactive sets are in their tangent cone
+template <const ShapeDesc& SD, unsigned ACT>
+__device__ __forceinline__ bool pinv_mode_static(const DevSkill* __restrict__ S, const TickArgs& tk,
+                                                 const Kin<SD.n>& K, const double (&z)[SD.n],
+                                                 const double* ys, int lane, double (&v)[SD.n])
+{
+    constexpr int N = SD.n;
+    ModeCtx<SD, ACT> c;
+    c.lam = SD.standard ? 0.0 : S->po.damping_factor;
+#pragma unroll
+    for (int j = 0; j < N; ++j) c.v[j] = 0.0;
+    c.st.sbits = 0u;
+    c.ok = true;
+    steps_s<SD, ACT, 0>(CLIK_MODE_ARGS, c);
+    cones_s<SD, ACT, 0>(CLIK_MODE_ARGS, c);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = c.v[j];
+    return c.ok;
+}
+
+}  // namespace clik

@@ -173,6 +173,9 @@ int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts,
                      clik_pinv** out);
 int clik_pinv_destroy(clik_pinv* h);
 int clik_pinv_n_modes(const clik_pinv* h);
+/* name of the kernel variant serving this skill: an AOT shape name (guard-free
+ * instantiation for the skill's structure) or "dynamic" (run-time guards).   */
+const char* clik_pinv_kernel_name(const clik_pinv* h);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)
