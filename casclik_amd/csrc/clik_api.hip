@@ -16,19 +16,28 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <utility>
+#include <vector>
 #include "clik_device.hpp"
 
 namespace clik {
+struct LaunchArgs {
+    const DevSkill* dS;
+    const void*     dImg;
+    const WarmArgs* warm;
+    int nq, nx, ny;
+};
 int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
 int pinv_kernel_width(int k);
-hipError_t pinv_launch_solve(int N, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
-                             const double* q, const double* x, const double* y, double* dq,
-                             double* dx, int32_t* mode, hipStream_t stream);
-hipError_t pinv_launch_rollout(int N, const DevSkill* dS, const WarmArgs& wa, const double* d_tterms, int n_ticks,
-                               double dt, double max_speed, long long B, int ny, double* q,
-                               const double* y, double* dq, int32_t* mode, hipStream_t stream);
+int pinv_kernel_is_static(int k);
+hipError_t pinv_launch_solve(int k, const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
+                             const double* x, const double* y, double* dq, double* dx, int32_t* mode,
+                             hipStream_t stream);
+hipError_t pinv_launch_rollout(int k, const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
+                               double max_speed, long long B, double* q, const double* y, double* dq,
+                               int32_t* mode, hipStream_t stream);
 int pinv_lds_slots_host(int N, int ny);
 hipError_t qp_launch_solve(int NV, const DevSkill* dS, const TickArgs& tk, long long B,
                            const double* q, const double* x, const double* y, double* dq,
@@ -47,6 +56,7 @@ struct clik_pinv {
     DevSkill  host;
     DevSkill* dev;
     clik::WarmArgs warm;
+    void*     d_img;        // static kernels: device copy of the compact skill image
     int       kernel;       // index into the kernel table (static shape or dynamic)
     double*   d_tterms;     // rollout workspace
     size_t    d_tterms_cap;
@@ -111,6 +121,21 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
     bool any_fk = false, any_o = false;
     for (int j = 0; j < d->n_joints; ++j) {
         const clik_joint& jt = d->joints[j];
+        int jf = 0;
+        static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        bool r_ident = true;
+        for (int k = 0; k < 9; ++k) r_ident = r_ident && (jt.R[k] == I3[k]);    // -0.0 == 0.0
+        if (r_ident) jf |= 1;
+        if (jt.p[0] == 0.0 && jt.p[1] == 0.0 && jt.p[2] == 0.0) jf |= 2;
+        if (jt.type != CLIK_JOINT_FIXED)
+            for (int k = 0; k < 3; ++k) {
+                const double a = jt.axis[k], b = jt.axis[(k + 1) % 3], c = jt.axis[(k + 2) % 3];
+                if (b == 0.0 && c == 0.0 && (a == 1.0 || a == -1.0)) jf |= ((k + 1) | (a < 0 ? 4 : 0)) << 4;
+            }
+        S->jflags[j] = jf;
+        S->shape.jtype[j] = jt.type;
+        S->shape.jq[j] = (jt.type == CLIK_JOINT_FIXED) ? -1 : jt.q_index;
+        S->shape.jflags[j] = jf;
         if (jt.type == CLIK_JOINT_FIXED) continue;
         if (jt.type != CLIK_JOINT_REVOLUTE && jt.type != CLIK_JOINT_PRISMATIC)
             return fail(CLIK_EINVAL, "joint %d: unknown type %d", j, jt.type);
@@ -149,6 +174,7 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
     }
     // per-task feature flags, constant-Jacobian detection, shape descriptor
     S->shape.n = n;
+    S->shape.nj = d->n_joints;
     S->shape.n_tasks = d->n_tasks;
     S->shape.all_affine = 1;
     int last_row = 0;
@@ -171,6 +197,12 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
             // time terms do not change the code path of a row: drop the flag from the shape
             S->shape.flags[ti] = fl & ~CLIK_ROW_HAS_T;
             S->shape.const_j[ti] = S->task_const_j[ti];
+            S->shape.gain_matrix[ti] = t.gain_is_matrix ? 1 : 0;
+            int nyt = 0;
+            for (int i = 0; i < t.m; ++i)
+                if (t.out_kind[i] == CLIK_OUT_AFFINE && d->rows[t.out_row0[i]].n_y > nyt)
+                    nyt = d->rows[t.out_row0[i]].n_y;
+            S->shape.ny_terms[ti] = nyt;
         }
         if (fl & CLIK_ROW_HAS_T) S->shape.all_affine = S->shape.all_affine;  // (time slots are run-time data)
     }
@@ -250,6 +282,91 @@ static bool host_const_pinv(const clik_pinv_opts& o, int m, int n, const double*
     return true;
 }
 
+// Compact skill image for the shape-specialised kernels; layout =
+// clik::SkillImage<nj, nt, nr> (clik_device.hpp), padded to a multiple of 1 KiB.
+// Static shapes require contiguous, all-affine rows in task order.
+static bool build_skill_image(const DevSkill& S, std::vector<char>& out)
+{
+    const int nj = S.d.n_joints, nt = S.d.n_tasks;
+    int nr = 0;
+    for (int ti = 0; ti < nt; ++ti) {
+        const clik_task& t = S.d.tasks[ti];
+        for (int i = 0; i < t.m; ++i)
+            if (t.out_kind[i] != CLIK_OUT_AFFINE || t.out_row0[i] != nr + i) return false;
+        nr += t.m;
+    }
+    const size_t o_j = 0;
+    const size_t o_t = o_j + sizeof(clik_joint) * (size_t)(nj > 0 ? nj : 1);
+    const size_t o_r = o_t + sizeof(clik_task) * (size_t)nt;
+    const size_t o_c = o_r + sizeof(clik_row) * (size_t)nr;
+    const size_t o_tail = o_c + sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M * (size_t)nt;
+    const size_t total = o_tail + sizeof(double) * 5 + sizeof(int32_t) * 6;
+    out.assign((total + 1023) / 1024 * 1024, 0);
+    memcpy(&out[o_j], S.d.joints, sizeof(clik_joint) * (size_t)nj);
+    memcpy(&out[o_t], S.d.tasks, sizeof(clik_task) * (size_t)nt);
+    memcpy(&out[o_r], S.d.rows, sizeof(clik_row) * (size_t)nr);
+    for (int ti = 0; ti < nt; ++ti)
+        memcpy(&out[o_c + sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M * (size_t)ti], S.cpinv[ti],
+               sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M);
+    // unused input_var terms must read index 0 with coefficient 0
+    for (int r = 0; r < nr; ++r) {
+        clik_row* row = reinterpret_cast<clik_row*>(&out[o_r + sizeof(clik_row) * (size_t)r]);
+        for (int k = row->n_y; k < CLIK_MAX_YTERMS; ++k) { row->yc[k] = 0.0; row->yi[k] = 0; }
+    }
+    double tail_d[5] = {S.po.pinv_method == CLIK_PINV_STANDARD ? 0.0 : S.po.damping_factor,
+                        S.d.quat[0], S.d.quat[1], S.d.quat[2], S.d.quat[3]};
+    int32_t tail_i[6] = {S.d.quat_yi[0], S.d.quat_yi[1], S.d.quat_yi[2], S.d.quat_yi[3], S.d.n_tslots, 0};
+    memcpy(&out[o_tail], tail_d, sizeof(tail_d));
+    memcpy(&out[o_tail + sizeof(tail_d)], tail_i, sizeof(tail_i));
+    return true;
+}
+
+static void finish_pinv_shape(DevSkill& S, const clik_pinv_opts* opts)
+{
+    S.po = *opts;
+    S.shape.feedforward = opts->feedforward ? 1 : 0;
+    S.shape.multidim = opts->multidim_sets ? 1 : 0;
+    S.shape.conv_last = opts->converge_final_set_to_max ? 1 : 0;
+    S.shape.standard = opts->pinv_method == CLIK_PINV_STANDARD ? 1 : 0;
+}
+
+// C++ initialiser of the ShapeDesc a skill + options map to (host only, no HIP
+// call): the input of tools/gen_shapes.py, which writes clik_shapes_gen.hpp.
+extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts, char* buf, int cap)
+{
+    if (!opts || !buf || cap <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    DevSkill* S = new (std::nothrow) DevSkill();
+    if (!S) return fail(CLIK_ENOMEM, "out of host memory");
+    int rc = validate_and_derive(desc, S);
+    if (rc) { delete S; return rc; }
+    finish_pinv_shape(*S, opts);
+    const clik::ShapeDesc& h = S->shape;
+    std::string o = "{";
+    auto num = [&](int v) { o += std::to_string(v); o += ", "; };
+    auto arr = [&](const int* a, int nn, int used) {
+        o += "{";
+        for (int i = 0; i < nn; ++i) { o += std::to_string(i < used ? a[i] : 0); if (i + 1 < nn) o += ", "; }
+        o += "}, ";
+    };
+    const int nt = h.n_tasks < clik::SHAPE_MAX_TASKS ? h.n_tasks : clik::SHAPE_MAX_TASKS;
+    num(h.n); num(h.n_tasks);
+    arr(h.cls, clik::SHAPE_MAX_TASKS, nt); arr(h.m, clik::SHAPE_MAX_TASKS, nt);
+    arr(h.flags, clik::SHAPE_MAX_TASKS, nt); arr(h.const_j, clik::SHAPE_MAX_TASKS, nt);
+    num(h.all_affine); num(h.uses_fk); num(h.quat_src);
+    num(h.feedforward); num(h.multidim); num(h.conv_last); num(h.standard);
+    num(h.nj);
+    arr(h.jtype, CLIK_MAX_JOINTS, h.nj); arr(h.jq, CLIK_MAX_JOINTS, h.nj); arr(h.jflags, CLIK_MAX_JOINTS, h.nj);
+    arr(h.gain_matrix, clik::SHAPE_MAX_TASKS, nt);
+    o += "{";
+    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.ny_terms[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
+    o += "}}";
+    const bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
+    delete S;
+    if ((int)o.size() + 1 > cap) return fail(CLIK_EINVAL, "buffer too small");
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return eligible ? 1 : 0;
+}
+
 extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts, clik_pinv** out)
 {
     if (!out) return fail(CLIK_EINVAL, "null out pointer");
@@ -260,7 +377,8 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     int rc = validate_and_derive(desc, &h->host);
     if (rc) { delete h; return rc; }
     DevSkill& S = h->host;
-    S.po = *opts;
+    h->d_img = nullptr;
+    finish_pinv_shape(S, opts);
     if (opts->pinv_method != CLIK_PINV_DAMPED && opts->pinv_method != CLIK_PINV_STANDARD) {
         delete h;
         return fail(CLIK_EINVAL, "pinv_method must be damped or standard");
@@ -292,10 +410,6 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     }
     S.last_set_converges = (S.d.n_tasks > 0 && S.d.tasks[S.d.n_tasks - 1].cls == CLIK_CLS_SET &&
                             opts->converge_final_set_to_max) ? 1 : 0;
-    S.shape.feedforward = opts->feedforward ? 1 : 0;
-    S.shape.multidim = opts->multidim_sets ? 1 : 0;
-    S.shape.conv_last = opts->converge_final_set_to_max ? 1 : 0;
-    S.shape.standard = opts->pinv_method == CLIK_PINV_STANDARD ? 1 : 0;
     for (int ti = 0; ti < S.d.n_tasks; ++ti) {
         if (!S.task_const_j[ti]) continue;
         const clik_task& t = S.d.tasks[ti];
@@ -347,6 +461,22 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    if (clik::pinv_kernel_is_static(h->kernel)) {
+        std::vector<char> img;
+        if (!build_skill_image(S, img)) {
+            // rows not laid out contiguously: serve the skill with the dynamic kernel
+            h->kernel = clik::pinv_pick_kernel(S, 0);
+        } else {
+            e = hipMalloc(&h->d_img, img.size());
+            if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (h->d_img) hipFree(h->d_img);
+                hipFree(h->dev);
+                delete h;
+                return hipfail(e, "skill image upload");
+            }
+        }
+    }
     h->d_tterms = nullptr;
     h->d_tterms_cap = 0;
     *out = h;
@@ -357,6 +487,7 @@ extern "C" int clik_pinv_destroy(clik_pinv* h)
 {
     if (!h) return CLIK_OK;
     if (h->d_tterms) hipFree(h->d_tterms);
+    if (h->d_img) hipFree(h->d_img);
     if (h->dev) hipFree(h->dev);
     delete h;
     return CLIK_OK;
@@ -393,7 +524,8 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    hipError_t e = clik::pinv_launch_solve(h->kernel, h->dev, h->warm, tk, (long long)B, S.d.n_y, q, x, y, dq, dx, mode,
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y};
+    hipError_t e = clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
                                            (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
     return CLIK_OK;
@@ -424,8 +556,9 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
                                       (hipStream_t)stream);
         if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
     }
-    hipError_t e = clik::pinv_launch_rollout(h->kernel, h->dev, h->warm, h->d_tterms, n_ticks, dt, max_speed, (long long)B,
-                                             S.d.n_y, q, y, dq, mode, (hipStream_t)stream);
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y};
+    hipError_t e = clik::pinv_launch_rollout(h->kernel, la, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y,
+                                             dq, mode, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_rollout_kernel launch");
     return CLIK_OK;
 }

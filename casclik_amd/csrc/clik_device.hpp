@@ -37,6 +37,44 @@ struct ShapeDesc {
     int all_affine;                 // no NORM2 output rows
     int uses_fk, quat_src;
     int feedforward, multidim, conv_last, standard;
+    // chain structure (static shapes are per robot structure x skill structure)
+    int nj;                         // chain joints, fixed ones included
+    int jtype[CLIK_MAX_JOINTS];     // CLIK_JOINT_*
+    int jq[CLIK_MAX_JOINTS];        // state index driven by the joint (-1 fixed)
+    int jflags[CLIK_MAX_JOINTS];    // DevSkill::jflags encoding
+    int gain_matrix[SHAPE_MAX_TASKS];
+    int ny_terms[SHAPE_MAX_TASKS];  // max input_var terms of a row of the task
+};
+
+constexpr int shape_rows(const ShapeDesc& sd)
+{
+    int r = 0;
+    for (int i = 0; i < sd.n_tasks; ++i) r += sd.m[i];
+    return r;
+}
+constexpr int shape_row_base(const ShapeDesc& sd, int ti)
+{
+    int r = 0;
+    for (int i = 0; i < ti; ++i) r += sd.m[i];
+    return r;
+}
+
+// Compact image of the numeric content of a skill, copied to LDS at kernel
+// start by shape-specialised kernels (one coalesced pass) and read from there
+// with static offsets: in-order, pipelined ds_reads into VGPRs instead of
+// out-of-order scalar loads that serialise a lone wavefront.  The host builds
+// the same layout in clik_api.hip (build_skill_image).
+template <int NJ, int NT, int NR>
+struct SkillImage {
+    clik_joint joints[NJ > 0 ? NJ : 1];
+    clik_task  tasks[NT];
+    clik_row   rows[NR];
+    double     cpinv[NT][CLIK_MAX_DOF * CLIK_MAX_M];
+    double     lam;
+    double     quat[4];
+    int32_t    quat_yi[4];
+    int32_t    n_tslots;
+    int32_t    pad;
 };
 
 // Device-resident skill: descriptor + controller options + derived tables.
@@ -55,6 +93,9 @@ struct DevSkill {
     int32_t  n_modes;
     int32_t  last_set_converges;      // last task is a SetConstraint && converge_final_set_to_max
     uint32_t act[1 << CLIK_MAX_SETS]; // activation bit masks in mode order (pseudo_inverse.py:107-130)
+    // per chain joint: bit0 origin rotation is identity, bit1 origin translation
+    // is zero, bits 4..6 joint axis code (0 generic, 1/2/3 = +x/+y/+z, 5/6/7 = -x/-y/-z)
+    int32_t  jflags[CLIK_MAX_JOINTS];
     uint32_t used_mask;               // state indices driven by a chain joint
     uint32_t rev_mask;                // ... that are revolute
     int32_t  n_slack;
@@ -214,6 +255,44 @@ __device__ __forceinline__ void ldl_solve(const double (&A)[N * (N + 1) / 2], co
 }
 
 // ---------------------------------------------------------------------------
+// sin and cos of a joint angle.  Joint angles are O(1): a three-term FMA
+// Cody-Waite reduction by pi/2 (exact to ~1e-33 relative to k) plus the fdlibm
+// kernel polynomials on |r| <= pi/4 gives <= 1 ulp in ~35 VALU instructions,
+// against ~150 for the generic library routine with its huge-argument path.
+// Arguments beyond 1e5 rad take the library routine.
+__device__ __forceinline__ void sincos_joint(const double x, double& sn, double& cs)
+{
+    if (__builtin_expect(fabs(x) > 1.0e5, 0)) {
+        sincos(x, &sn, &cs);
+        return;
+    }
+    const double k = rint(x * 0.6366197723675814);
+    double r = fma(k, -1.5707963267948966, x);
+    r = fma(k, -6.123233995736766e-17, r);
+    r = fma(k, 1.4973849048591698e-33, r);
+    const double z = r * r;
+    // __kernel_sin
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    const double sr = fma(z * r, fma(z, ps, S1), r);
+    // __kernel_cos
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * pc);
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? cr : sr;
+    const double c0 = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// ---------------------------------------------------------------------------
 // Per-lane kinematic state of the skill's serial chain.
 template <int N>
 struct Kin {
@@ -249,24 +328,38 @@ __device__ __forceinline__ void forward_kinematics(const DevSkill* __restrict__ 
     const int nj = D.n_joints;
     for (int j = 0; j < nj; ++j) {
         const clik_joint& jt = D.joints[j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            p[i] = fma(R[3 * i], jt.p[0], fma(R[3 * i + 1], jt.p[1], fma(R[3 * i + 2], jt.p[2], p[i])));
+        const int jf = S->jflags[j];
         double T[9];
+        if (!(jf & 2)) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
+                p[i] = fma(R[3 * i], jt.p[0], fma(R[3 * i + 1], jt.p[1], fma(R[3 * i + 2], jt.p[2], p[i])));
+        }
+        if (!(jf & 1)) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                T[3 * i + c] = R[3 * i] * jt.R[c] + R[3 * i + 1] * jt.R[3 + c] + R[3 * i + 2] * jt.R[6 + c];
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = T[i];
+                for (int c = 0; c < 3; ++c)
+                    T[3 * i + c] = R[3 * i] * jt.R[c] + R[3 * i + 1] * jt.R[3 + c] + R[3 * i + 2] * jt.R[6 + c];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = T[i];
+        }
         const int type = jt.type;
         if (type != CLIK_JOINT_FIXED) {
             const int qi = jt.q_index;
+            const int acode = (jf >> 4) & 7;
+            const int ak = (acode & 3) - 1;            // local coordinate axis, -1: generic
+            const double asign = (acode & 4) ? -1.0 : 1.0;
             double ax[3];
+            if (ak >= 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                ax[i] = R[3 * i] * jt.axis[0] + R[3 * i + 1] * jt.axis[1] + R[3 * i + 2] * jt.axis[2];
+                for (int i = 0; i < 3; ++i)
+                    ax[i] = asign * (ak == 0 ? R[3 * i] : (ak == 1 ? R[3 * i + 1] : R[3 * i + 2]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    ax[i] = R[3 * i] * jt.axis[0] + R[3 * i + 1] * jt.axis[1] + R[3 * i + 2] * jt.axis[2];
+            }
             double* f = fr + (size_t)(6 * qi) * WAVE + lane;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -276,19 +369,34 @@ __device__ __forceinline__ void forward_kinematics(const DevSkill* __restrict__ 
             const double ang = zs[qi * WAVE + lane];
             if (type == CLIK_JOINT_REVOLUTE) {
                 double s, c;
-                sincos(ang, &s, &c);
-                const double C = 1.0 - c;
-                const double x = jt.axis[0], y = jt.axis[1], z = jt.axis[2];
-                const double m[9] = {c + x * x * C, x * y * C - z * s, x * z * C + y * s,
-                                     y * x * C + z * s, c + y * y * C, y * z * C - x * s,
-                                     z * x * C - y * s, z * y * C + x * s, c + z * z * C};
+                sincos_joint(ang, s, c);
+                if (ak >= 0) {
+                    // rotation about a local coordinate axis mixes the two other columns
+                    s *= asign;
+                    const int c1 = (ak + 1) % 3, c2 = (ak + 2) % 3;
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < 3; ++i) {
+                        const double u = (c1 == 0 ? R[3 * i] : (c1 == 1 ? R[3 * i + 1] : R[3 * i + 2]));
+                        const double v = (c2 == 0 ? R[3 * i] : (c2 == 1 ? R[3 * i + 1] : R[3 * i + 2]));
+                        const double un = fma(c, u, s * v);
+                        const double vn = fma(c, v, -s * u);
+                        if (c1 == 0) R[3 * i] = un; else if (c1 == 1) R[3 * i + 1] = un; else R[3 * i + 2] = un;
+                        if (c2 == 0) R[3 * i] = vn; else if (c2 == 1) R[3 * i + 1] = vn; else R[3 * i + 2] = vn;
+                    }
+                } else {
+                    const double C = 1.0 - c;
+                    const double x = jt.axis[0], y = jt.axis[1], z = jt.axis[2];
+                    const double m[9] = {c + x * x * C, x * y * C - z * s, x * z * C + y * s,
+                                         y * x * C + z * s, c + y * y * C, y * z * C - x * s,
+                                         z * x * C - y * s, z * y * C + x * s, c + z * z * C};
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc)
-                        T[3 * i + cc] = R[3 * i] * m[cc] + R[3 * i + 1] * m[3 + cc] + R[3 * i + 2] * m[6 + cc];
+                    for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int i = 0; i < 9; ++i) R[i] = T[i];
+                        for (int cc = 0; cc < 3; ++cc)
+                            T[3 * i + cc] = R[3 * i] * m[cc] + R[3 * i + 1] * m[3 + cc] + R[3 * i + 2] * m[6 + cc];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) R[i] = T[i];
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) p[i] = fma(ax[i], ang, p[i]);

@@ -499,35 +499,7 @@ __device__ __forceinline__ void pinv_tick(const DevSkill* __restrict__ S, const 
         }
     };
 
-    if constexpr (SH::is_static) {
-        // static shapes carry at most one SetConstraint: modes {0: inactive, 1: active};
-        // each mode is a straight-line instantiation of its compile-time plan
-        constexpr const ShapeDesc& SDESC = SH::desc;
-        constexpr int n_sets = shape_n_sets(SH::desc);
-        static_assert(n_sets <= 1, "static shapes support at most one SetConstraint");
-        {
-            double v[N];
-            const bool ok = pinv_mode_static<SDESC, 0u>(S, tk, K, z, ys, lane, v);
-            if (!done && ok) {
-                done = true;
-                acc_mode = 0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) vout[j] = v[j];
-            }
-        }
-        if constexpr (n_sets == 1) {
-            if (__ballot(!done) != 0ull) {
-                double v[N];
-                const bool ok = pinv_mode_static<SDESC, 1u>(S, tk, K, z, ys, lane, v);
-                if (!done && ok) {
-                    done = true;
-                    acc_mode = 1;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) vout[j] = v[j];
-                }
-            }
-        }
-    } else {
+    {
         const int n_modes = S->n_modes;
         for (int mk = 0; mk < n_modes; ++mk) {
             if (__ballot(!done) == 0ull) break;
@@ -654,34 +626,229 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_kernel(
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
-typedef hipError_t (*solve_fn)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*, const double*,
+// ---- shape-specialised kernels ---------------------------------------------------
+// LDS layout: [skill image | zs (N slots) | ys (ny slots)], slot = 64 doubles.
+template <const ShapeDesc& SD>
+struct StaticLayout {
+    static constexpr int N = SD.n;
+    static constexpr int IMG_CHUNKS = (int)((sizeof(Img<SD>) + 1023) / 1024);   // 1 KiB = 64 lanes x 16 B
+    static constexpr int IMG_DOUBLES = IMG_CHUNKS * 128;
+    static constexpr int n_sets = shape_n_sets(SD);
+};
+
+template <const ShapeDesc& SD>
+__device__ __forceinline__ const Img<SD>* load_image(const void* __restrict__ img_g, double* lds, const int lane)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* src = (const d2*)img_g;
+    d2* dst = (d2*)lds;
+#pragma unroll
+    for (int k = 0; k < StaticLayout<SD>::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = src[k * WAVE + lane];
+    return (const Img<SD>*)lds;
+}
+
+template <const ShapeDesc& SD>
+__device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, const TickArgs& tk,
+                                                 const double (&z)[SD.n], const double* ys, const int lane,
+                                                 const bool valid, double (&vout)[SD.n], int& acc_mode)
+{
+    constexpr int N = SD.n;
+    static_assert(StaticLayout<SD>::n_sets <= 1, "static shapes support at most one SetConstraint");
+    Kin<N> K;
+    if constexpr (SD.uses_fk != 0) {
+        forward_kinematics_s<SD>(S, z, K);
+        if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+    }
+    bool done = !valid;
+    acc_mode = -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vout[j] = 0.0;
+    {
+        double v[N];
+        const bool ok = pinv_mode_static<SD, 0u>(S, tk, K, z, ys, lane, v);
+        if (!done && ok) {
+            done = true;
+            acc_mode = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) vout[j] = v[j];
+        }
+    }
+    if constexpr (StaticLayout<SD>::n_sets == 1) {
+        if (__ballot(!done) != 0ull) {
+            double v[N];
+            const bool ok = pinv_mode_static<SD, 1u>(S, tk, K, z, ys, lane, v);
+            if (!done && ok) {
+                done = true;
+                acc_mode = 1;
+#pragma unroll
+                for (int j = 0; j < N; ++j) vout[j] = v[j];
+            }
+        }
+    }
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
+    const void* __restrict__ img_g, const TickArgs tk, const long long B, const int nq, const int nx, const int ny,
+    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ dx, int32_t* __restrict__ mode_out)
+{
+    extern __shared__ double lds[];
+    constexpr int N = SD.n;
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
+    double* ys = zs + N * WAVE;
+    // constants and joint state / inputs travel together: one memory round trip
+    const Img<SD>* __restrict__ S = load_image<SD>(img_g, lds, lane);
+    if (rows_valid < WAVE) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
+        for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
+        __syncthreads();
+    }
+    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0) stage_in(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
+    __syncthreads();
+
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
+    double vout[N];
+    int acc_mode;
+    pinv_tick_static<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
+
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = vout[j];
+    __syncthreads();
+    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0) stage_out(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ tterms, const int n_ticks, const double dt,
+    const double max_speed, const long long B, const int nq, const int ny,
+    double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq, int32_t* __restrict__ mode_out)
+{
+    extern __shared__ double lds[];
+    constexpr int N = SD.n;
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
+    double* ys = zs + N * WAVE;
+    const Img<SD>* __restrict__ S = load_image<SD>(img_g, lds, lane);
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
+    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
+    __syncthreads();
+    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
+    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
+    __syncthreads();
+    const int nts = S->n_tslots;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
+    double vout[N];
+    int acc_mode = -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vout[j] = 0.0;
+    for (int tick = 0; tick < n_ticks; ++tick) {
+        TickArgs tk;
+        for (int k = 0; k < 2 * nts; ++k) tk.tv[k] = tterms[(size_t)tick * 2 * nts + k];
+        pinv_tick_static<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double d = vout[j];
+            if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+            vout[j] = d;
+            z[j] = fma(d, dt, z[j]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = z[j];
+    __syncthreads();
+    stage_out(q + b0 * nq, nq, rows_valid, zs, lane);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = vout[j];
+    __syncthreads();
+    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
+    if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
+}
+
+// common launcher signature of the kernel table
+struct LaunchArgs {
+    const DevSkill* dS;        // dynamic kernels
+    const void*     dImg;      // static kernels: device copy of the skill image
+    const WarmArgs* warm;
+    int nq, nx, ny;
+};
+typedef hipError_t (*solve_fn)(const LaunchArgs&, const TickArgs&, long long, const double*, const double*,
                                const double*, double*, double*, int32_t*, hipStream_t);
-typedef hipError_t (*rollout_fn)(const DevSkill*, const WarmArgs&, const double*, int, double, double, long long, int, double*,
+typedef hipError_t (*rollout_fn)(const LaunchArgs&, const double*, int, double, double, long long, double*,
                                  const double*, double*, int32_t*, hipStream_t);
 
 template <int N, class SH>
-inline hipError_t launch_solve(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
-                               const double* q, const double* x, const double* y, double* dq,
-                               double* dx, int32_t* mode, hipStream_t stream)
+inline hipError_t launch_solve(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
+                               const double* x, const double* y, double* dq, double* dx, int32_t* mode,
+                               hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t shmem = (size_t)pinv_lds_slots(N, ny) * WAVE * sizeof(double);
-    hipLaunchKernelGGL((pinv_solve_kernel<N, SH>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y,
-                       dq, dx, mode);
+    const size_t shmem = (size_t)pinv_lds_slots(N, a.ny) * WAVE * sizeof(double);
+    hipLaunchKernelGGL((pinv_solve_kernel<N, SH>), dim3(grid), dim3(WAVE), shmem, stream, a.dS, *a.warm, tk, B, q,
+                       x, y, dq, dx, mode);
     return hipGetLastError();
 }
 
 template <int N, class SH>
-inline hipError_t launch_rollout(const DevSkill* dS, const WarmArgs& wa, const double* d_tterms, int n_ticks, double dt,
-                                 double max_speed, long long B, int ny, double* q, const double* y,
-                                 double* dq, int32_t* mode, hipStream_t stream)
+inline hipError_t launch_rollout(const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
+                                 double max_speed, long long B, double* q, const double* y, double* dq,
+                                 int32_t* mode, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t shmem = (size_t)pinv_lds_slots(N, ny) * WAVE * sizeof(double);
-    hipLaunchKernelGGL((pinv_rollout_kernel<N, SH>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, d_tterms,
-                       n_ticks, dt, max_speed, B, q, y, dq, mode);
+    const size_t shmem = (size_t)pinv_lds_slots(N, a.ny) * WAVE * sizeof(double);
+    hipLaunchKernelGGL((pinv_rollout_kernel<N, SH>), dim3(grid), dim3(WAVE), shmem, stream, a.dS, *a.warm,
+                       d_tterms, n_ticks, dt, max_speed, B, q, y, dq, mode);
     return hipGetLastError();
 }
 
+template <const ShapeDesc& SD>
+inline size_t static_lds_bytes(int ny)
+{
+    return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n + ny) * WAVE) * sizeof(double);
+}
+
+template <const ShapeDesc& SD>
+inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
+                                      const double* x, const double* y, double* dq, double* dx, int32_t* mode,
+                                      hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    hipLaunchKernelGGL((pinv_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
+                       a.dImg, tk, B, a.nq, a.nx, a.ny, q, x, y, dq, dx, mode);
+    return hipGetLastError();
+}
+
+template <const ShapeDesc& SD>
+inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
+                                        double max_speed, long long B, double* q, const double* y, double* dq,
+                                        int32_t* mode, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    hipLaunchKernelGGL((pinv_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
+                       a.dImg, d_tterms, n_ticks, dt, max_speed, B, a.nq, a.ny, q, y, dq, mode);
+    return hipGetLastError();
+}
 
 }  // namespace clik

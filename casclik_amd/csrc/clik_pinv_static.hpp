@@ -118,6 +118,249 @@ struct Plan {
     static constexpr ModePlan mode = make_plan(SD, ACT);
 };
 
+template <const ShapeDesc& SD>
+using Img = SkillImage<SD.nj, SD.n_tasks, shape_rows(SD)>;
+
+// ---- forward kinematics with a compile-time chain --------------------------------
+// One joint of  T = prod_j Trans(p_j) R_j [Rot(axis_j, z[q_j]) | Trans(axis_j z[q_j])]
+// (URDF convention, what urdf2casadi builds for the reference).  Joint type,
+// state index, "origin rotation is identity", "origin translation is zero" and
+// axis alignment are compile-time, so the recursion is straight-line code and
+// the per-joint axis / origin frames stay in registers.
+template <const ShapeDesc& SD, int J>
+__device__ __forceinline__ void fk_joint_s(const Img<SD>* __restrict__ S, const double (&z)[SD.n],
+                                           double (&R)[9], double (&p)[3], double (&ax)[SD.n][3],
+                                           double (&org)[SD.n][3])
+{
+    if constexpr (J < SD.nj) {
+        constexpr int jf = SD.jflags[J];
+        constexpr int type = SD.jtype[J];
+        const clik_joint& jt = S->joints[J];
+        if constexpr (!(jf & 2)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                p[i] = fma(R[3 * i], jt.p[0], fma(R[3 * i + 1], jt.p[1], fma(R[3 * i + 2], jt.p[2], p[i])));
+        }
+        if constexpr (!(jf & 1)) {
+            double T[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    T[3 * i + c] = R[3 * i] * jt.R[c] + R[3 * i + 1] * jt.R[3 + c] + R[3 * i + 2] * jt.R[6 + c];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = T[i];
+        }
+        if constexpr (type != CLIK_JOINT_FIXED) {
+            constexpr int qi = SD.jq[J];
+            constexpr int acode = (jf >> 4) & 7;
+            constexpr int ak = (acode & 3) - 1;
+            constexpr double asign = (acode & 4) ? -1.0 : 1.0;
+            if constexpr (ak >= 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ax[qi][i] = asign * R[3 * i + ak];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    ax[qi][i] = R[3 * i] * jt.axis[0] + R[3 * i + 1] * jt.axis[1] + R[3 * i + 2] * jt.axis[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) org[qi][i] = p[i];
+            const double ang = z[qi];
+            if constexpr (type == CLIK_JOINT_REVOLUTE) {
+                double sn, cs;
+                sincos_joint(ang, sn, cs);
+                if constexpr (ak >= 0) {
+                    // rotation about a local coordinate axis mixes the two other columns
+                    const double s = asign * sn;
+                    constexpr int c1 = (ak + 1) % 3, c2 = (ak + 2) % 3;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double u = R[3 * i + c1], v = R[3 * i + c2];
+                        R[3 * i + c1] = fma(cs, u, s * v);
+                        R[3 * i + c2] = fma(cs, v, -s * u);
+                    }
+                } else {
+                    const double C = 1.0 - cs;
+                    const double x = jt.axis[0], y = jt.axis[1], zz = jt.axis[2];
+                    const double m[9] = {cs + x * x * C, x * y * C - zz * sn, x * zz * C + y * sn,
+                                         y * x * C + zz * sn, cs + y * y * C, y * zz * C - x * sn,
+                                         zz * x * C - y * sn, zz * y * C + x * sn, cs + zz * zz * C};
+                    double T[9];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc)
+                            T[3 * i + cc] = R[3 * i] * m[cc] + R[3 * i + 1] * m[3 + cc] + R[3 * i + 2] * m[6 + cc];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) R[i] = T[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) p[i] = fma(ax[qi][i], ang, p[i]);
+            }
+        }
+        fk_joint_s<SD, J + 1>(S, z, R, p, ax, org);
+    }
+}
+
+constexpr int shape_state_type(const ShapeDesc& sd, int qi)
+{
+    for (int j = 0; j < sd.nj; ++j)
+        if (sd.jtype[j] != CLIK_JOINT_FIXED && sd.jq[j] == qi) return sd.jtype[j];
+    return CLIK_JOINT_FIXED;     // state variable not driven by the chain
+}
+
+template <const ShapeDesc& SD>
+__device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__ S, const double (&z)[SD.n],
+                                                     Kin<SD.n>& K)
+{
+    constexpr int N = SD.n;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double p[3] = {0, 0, 0};
+    double ax[N][3], org[N][3];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ax[j][i] = org[j][i] = 0.0;
+    fk_joint_s<SD, 0>(S, z, R, p, ax, org);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) K.R[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) K.p[i] = p[i];
+    static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int st = shape_state_type(SD, j);
+        if constexpr (st == CLIK_JOINT_REVOLUTE) {
+            const double r[3] = {p[0] - org[j][0], p[1] - org[j][1], p[2] - org[j][2]};
+            double v[3];
+            cross3(ax[j], r, v);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                K.Jv[i][j] = v[i];
+                K.Jw[i][j] = ax[j][i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                K.Jv[i][j] = ax[j][i];      // prismatic: axis; not in the chain: 0
+                K.Jw[i][j] = 0.0;
+            }
+        }
+    });
+}
+
+template <const ShapeDesc& SD>
+__device__ __forceinline__ void orientation_feature_s(const Img<SD>* __restrict__ S, const double* ys,
+                                                      const int lane, Kin<SD.n>& K)
+{
+    double q[4];
+    if constexpr (SD.quat_src == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = ys[S->quat_yi[i] * WAVE + lane];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = S->quat[i];
+    }
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double Rd[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                          2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                          2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    const double* R = K.R;
+    K.o[0] = K.o[1] = K.o[2] = 0.0;
+    double tr = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double rc[3] = {R[c], R[3 + c], R[6 + c]};
+        const double dc[3] = {Rd[c], Rd[3 + c], Rd[6 + c]};
+        double v[3];
+        cross3(rc, dc, v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) K.o[i] = fma(0.5, v[i], K.o[i]);
+        tr += rc[0] * dc[0] + rc[1] * dc[1] + rc[2] * dc[2];
+    }
+    K.tr = tr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            K.M[3 * i + k] = R[3 * i] * Rd[3 * k] + R[3 * i + 1] * Rd[3 * k + 1] + R[3 * i + 2] * Rd[3 * k + 2];
+}
+
+// value, state gradient and time derivative of one affine row; feature flags
+// and the number of input_var terms are compile-time
+template <int N, int FLAGS, int NY>
+__device__ __forceinline__ double row_eval_s(const clik_row& r, const int n_tslots, const TickArgs& tk,
+                                             const Kin<N>& K, const double (&z)[N], const double* ys,
+                                             const int lane, double (&g)[N], double& dt)
+{
+    double v = r.c;
+    dt = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = 0.0;
+    if constexpr ((FLAGS & CLIK_ROW_HAS_Q) != 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double a = r.a[j];
+            g[j] = a;
+            v = fma(a, z[j], v);
+        }
+    }
+    constexpr bool fk = (FLAGS & (CLIK_ROW_HAS_P | CLIK_ROW_HAS_R | CLIK_ROW_HAS_O)) != 0;
+    double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
+    if constexpr ((FLAGS & CLIK_ROW_HAS_P) != 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lin[i] = r.b[i];
+            v = fma(r.b[i], K.p[i], v);
+        }
+    }
+    if constexpr ((FLAGS & CLIK_ROW_HAS_R) != 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double rc[3] = {K.R[c], K.R[3 + c], K.R[6 + c]};
+            const double gc[3] = {r.g[c], r.g[3 + c], r.g[6 + c]};
+            double u[3];
+            cross3(rc, gc, u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ang[i] += u[i];
+                v = fma(gc[i], rc[i], v);
+            }
+        }
+    }
+    if constexpr ((FLAGS & CLIK_ROW_HAS_O) != 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double mh = K.M[i] * r.h[0] + K.M[3 + i] * r.h[1] + K.M[6 + i] * r.h[2];
+            ang[i] += -0.5 * (K.tr * r.h[i] - mh);
+            v = fma(r.h[i], K.o[i], v);
+        }
+    }
+    if constexpr (fk) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s = g[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s = fma(K.Jv[i][j], lin[i], fma(K.Jw[i][j], ang[i], s));
+            g[j] = s;
+        }
+    }
+    if constexpr ((FLAGS & CLIK_ROW_HAS_Y) != 0) {
+        // unused terms carry a zero coefficient and index 0
+#pragma unroll
+        for (int k = 0; k < NY; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
+    }
+    {
+        const int slot = r.t_slot;
+        if (slot >= 0) {
+            v += tk.tv[slot];
+            dt = tk.tv[n_tslots + slot];
+        }
+    }
+    return v;
+}
+
 // ---- static-size linear algebra ----------------------------------------------------
 template <int K>
 __device__ __forceinline__ void ldl_factor_s(double (&A)[K * (K + 1) / 2], double (&rd)[K])
@@ -160,28 +403,31 @@ __device__ __forceinline__ void ldl_solve_s(const double (&A)[K * (K + 1) / 2], 
         for (int j = i + 1; j < K; ++j) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
 }
 
-// e, J, d e/d t of a task with compile-time row count and feature flags
-template <int N, int M, int FLAGS>
-__device__ __forceinline__ void task_eval_s(const DevSkill* __restrict__ S, const int ti, const TickArgs& tk,
-                                            const Kin<N>& K, const double (&z)[N], const double* ys,
-                                            const int lane, double (&e)[M], double (&J)[M][N], double (&Jt)[M])
+// e, J, d e/d t of task TI: rows are contiguous and all affine in static shapes
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const TickArgs& tk,
+                                            const Kin<SD.n>& K, const double (&z)[SD.n], const double* ys,
+                                            const int lane, double (&e)[SD.m[TI]], double (&J)[SD.m[TI]][SD.n],
+                                            double (&Jt)[SD.m[TI]])
 {
-    const clik_task& t = S->d.tasks[ti];
+    constexpr int N = SD.n;
+    constexpr int M = SD.m[TI];
+    constexpr int row0 = shape_row_base(SD, TI);
+    const int nts = S->n_tslots;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-        const clik_row& r = S->d.rows[t.out_row0[i]];
         double g[N], dt;
-        e[i] = row_eval<N>(S, r, FLAGS, tk, K, z, ys, lane, N, g, dt);
+        e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI]>(S->rows[row0 + i], nts, tk, K, z, ys, lane, g, dt);
         Jt[i] = dt;
 #pragma unroll
         for (int j = 0; j < N; ++j) J[i][j] = g[j];
     }
 }
 
-template <int M>
+template <int M, bool MATRIX>
 __device__ __forceinline__ void gain_apply_s(const clik_task& t, const double (&v)[M], double (&out)[M])
 {
-    if (!t.gain_is_matrix) {
+    if constexpr (!MATRIX) {
         const double g = t.gain[0];
 #pragma unroll
         for (int i = 0; i < M; ++i) out[i] = g * v[i];
@@ -263,7 +509,7 @@ struct ModeCtx {
 };
 
 // read-only inputs of a mode evaluation, passed as separate parameters
-#define CLIK_MODE_IN const DevSkill* __restrict__ S, const TickArgs& tk, const Kin<SD.n>& K, \
+#define CLIK_MODE_IN const Img<SD>* __restrict__ S, const TickArgs& tk, const Kin<SD.n>& K, \
                      const double (&z)[SD.n], const double* ys, const int lane
 #define CLIK_MODE_ARGS S, tk, K, z, ys, lane
 
@@ -388,9 +634,9 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
     constexpr int M = SD.m[TI];
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (!P.skip) {
-        const clik_task& t = S->d.tasks[TI];
+        const clik_task& t = S->tasks[TI];
         double e[M], J[M][N], Jt[M];
-        task_eval_s<N, M, SD.flags[TI]>(S, TI, tk, K, z, ys, lane, e, J, Jt);
+        task_eval_s<SD, TI>(S, tk, K, z, ys, lane, e, J, Jt);
         uint32_t srow = 0xffffffffu;
         if constexpr (P.set_rows) {
             srow = 0u;
@@ -404,7 +650,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
             double des[M];
             if constexpr (SD.cls[TI] == CLIK_CLS_EQ) {
                 double ke[M];
-                gain_apply_s<M>(t, e, ke);
+                gain_apply_s<M, SD.gain_matrix[TI] != 0>(t, e, ke);
 #pragma unroll
                 for (int i = 0; i < M; ++i) des[i] = -ke[i];
             } else if constexpr (SD.cls[TI] == CLIK_CLS_VELEQ) {
@@ -414,7 +660,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 double d0[M];
 #pragma unroll
                 for (int i = 0; i < M; ++i) d0[i] = t.set_max[i] - e[i];
-                gain_apply_s<M>(t, d0, des);
+                gain_apply_s<M, SD.gain_matrix[TI] != 0>(t, d0, des);
             }
             if constexpr (SD.feedforward != 0) {
 #pragma unroll
@@ -517,8 +763,8 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (P.cone) {
         double e[M], J[M][N], Jt[M];
-        task_eval_s<N, M, SD.flags[TI]>(S, TI, tk, K, z, ys, lane, e, J, Jt);
-        c.ok = c.ok && in_tangent_cone_s<N, M>(S->d.tasks[TI], e, J, Jt, c.v);
+        task_eval_s<SD, TI>(S, tk, K, z, ys, lane, e, J, Jt);
+        c.ok = c.ok && in_tangent_cone_s<N, M>(S->tasks[TI], e, J, Jt, c.v);
     }
 }
 
@@ -543,13 +789,13 @@ __device__ __forceinline__ void cones_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
 // candidate velocity of the mode with activation mask ACT; returns whether all
 // inactive sets are in their tangent cone
 template <const ShapeDesc& SD, unsigned ACT>
-__device__ __forceinline__ bool pinv_mode_static(const DevSkill* __restrict__ S, const TickArgs& tk,
+__device__ __forceinline__ bool pinv_mode_static(const Img<SD>* __restrict__ S, const TickArgs& tk,
                                                  const Kin<SD.n>& K, const double (&z)[SD.n],
                                                  const double* ys, int lane, double (&v)[SD.n])
 {
     constexpr int N = SD.n;
     ModeCtx<SD, ACT> c;
-    c.lam = SD.standard ? 0.0 : S->po.damping_factor;
+    c.lam = SD.standard ? 0.0 : S->lam;
 #pragma unroll
     for (int j = 0; j < N; ++j) c.v[j] = 0.0;
     c.st.sbits = 0u;

@@ -176,6 +176,10 @@ int clik_pinv_n_modes(const clik_pinv* h);
 /* name of the kernel variant serving this skill: an AOT shape name (guard-free
  * instantiation for the skill's structure) or "dynamic" (run-time guards).   */
 const char* clik_pinv_kernel_name(const clik_pinv* h);
+/* developer aid (host only, no GPU needed): writes the C++ ShapeDesc initialiser
+ * this skill maps to into buf; returns 1 if the skill is eligible for an AOT
+ * shape-specialised kernel, 0 if not, <0 on error (tools/gen_shapes.py).      */
+int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts, char* buf, int cap);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)
