@@ -174,6 +174,7 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
     }
     // per-task feature flags, constant-Jacobian detection, shape descriptor
     S->shape.n = n;
+    S->shape.n_y = d->n_y;
     S->shape.nj = d->n_joints;
     S->shape.n_tasks = d->n_tasks;
     S->shape.all_affine = 1;
@@ -359,7 +360,7 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     arr(h.gain_matrix, clik::SHAPE_MAX_TASKS, nt);
     o += "{";
     for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.ny_terms[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
-    o += "}}";
+    o += "}, " + std::to_string(h.n_y) + "}";
     const bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
     delete S;
     if ((int)o.size() + 1 > cap) return fail(CLIK_EINVAL, "buffer too small");

@@ -44,6 +44,7 @@ struct ShapeDesc {
     int jflags[CLIK_MAX_JOINTS];    // DevSkill::jflags encoding
     int gain_matrix[SHAPE_MAX_TASKS];
     int ny_terms[SHAPE_MAX_TASKS];  // max input_var terms of a row of the task
+    int n_y;                        // input_var width
 };
 
 constexpr int shape_rows(const ShapeDesc& sd)
@@ -260,10 +261,25 @@ __device__ __forceinline__ void ldl_solve(const double (&A)[N * (N + 1) / 2], co
 // kernel polynomials on |r| <= pi/4 gives <= 1 ulp in ~35 VALU instructions,
 // against ~150 for the generic library routine with its huge-argument path.
 // Arguments beyond 1e5 rad take the library routine.
+__device__ __attribute__((noinline)) void sincos_slow(const double x, double* sn, double* cs)
+{
+    sincos(x, sn, cs);
+}
+
+// 1/d to <= 1 ulp: hardware estimate + two Newton steps (5 instructions; the
+// IEEE division sequence is ~12).  d is a Gram / LDL pivot: positive, finite.
+__device__ __forceinline__ double recip(const double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ void sincos_joint(const double x, double& sn, double& cs)
 {
     if (__builtin_expect(fabs(x) > 1.0e5, 0)) {
-        sincos(x, &sn, &cs);
+        sincos_slow(x, &sn, &cs);
         return;
     }
     const double k = rint(x * 0.6366197723675814);
@@ -646,18 +662,87 @@ __device__ __forceinline__ void gain_apply(const clik_task& t, const int m, cons
 
 // Cooperative, fully coalesced load of the wave's [64][w] row-major block into
 // LDS transposed to [w][64] (lane l then owns row l).  rows_valid <= 64.
-__device__ __forceinline__ void stage_in(const double* __restrict__ g, int w, int rows_valid,
-                                         double* lds, int lane)
+// All loads are issued before the first LDS write (one memory round trip);
+// WMAX bounds the unrolled issue (w <= WMAX).
+// The two halves of stage_in: unconditional (index-clamped) loads so that the
+// caller can put several blocks in flight before the first LDS write.
+template <int WMAX>
+__device__ __forceinline__ void stage_load(const double* __restrict__ g, const int w, const int rows_valid,
+                                           const int lane, double (&v)[WMAX])
 {
-    const int total = rows_valid * w;
-    for (int k = lane; k < total; k += WAVE) {
-        const int r = k / w, c = k - r * w;
-        lds[c * WAVE + r] = g[k];
+    const int last = rows_valid * w - 1;
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+        int k = (i < w ? i : 0) * WAVE + lane;
+        k = k < last ? k : last;
+        v[i] = g[k];
     }
 }
 
-__device__ __forceinline__ void stage_out(double* __restrict__ g, int w, int rows_valid,
-                                          const double* lds, int lane)
+template <int WMAX>
+__device__ __forceinline__ void stage_store(const double (&v)[WMAX], const int w, const int rows_valid,
+                                            double* lds, const int lane)
+{
+    const int total = rows_valid * w;
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+        const int k = i * WAVE + lane;
+        if (i < w && k < total) {
+            const int r = k / w, c = k - r * w;
+            lds[c * WAVE + r] = v[i];
+        }
+    }
+}
+
+template <int WMAX>
+__device__ __forceinline__ void stage_in(const double* __restrict__ g, const int w, const int rows_valid,
+                                         double* lds, const int lane)
+{
+    double v[WMAX];
+    stage_load<WMAX>(g, w, rows_valid, lane, v);
+    stage_store<WMAX>(v, w, rows_valid, lds, lane);
+}
+
+template <int WMAX>
+__device__ __forceinline__ void stage_out(double* __restrict__ g, const int w, const int rows_valid,
+                                          const double* lds, const int lane)
+{
+    const int total = rows_valid * w;
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+        const int k = i * WAVE + lane;
+        if (i < w && k < total) {
+            const int r = k / w, c = k - r * w;
+            g[k] = lds[c * WAVE + r];
+        }
+    }
+}
+
+// run-time width (dynamic kernels): chunks of 8 columns
+__device__ __forceinline__ void stage_in_dyn(const double* __restrict__ g, const int w, const int rows_valid,
+                                             double* lds, const int lane)
+{
+    const int total = rows_valid * w;
+    for (int base = 0; base < w; base += 8) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = (base + i) * WAVE + lane;
+            v[i] = (base + i < w && k < total) ? g[k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = (base + i) * WAVE + lane;
+            if (base + i < w && k < total) {
+                const int r = k / w, c = k - r * w;
+                lds[c * WAVE + r] = v[i];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_out_dyn(double* __restrict__ g, const int w, const int rows_valid,
+                                              const double* lds, const int lane)
 {
     const int total = rows_valid * w;
     for (int k = lane; k < total; k += WAVE) {

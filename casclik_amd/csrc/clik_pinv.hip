@@ -46,7 +46,7 @@ static bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
 {
     if (a.n != b.n || a.n_tasks != b.n_tasks || a.all_affine != b.all_affine || a.uses_fk != b.uses_fk ||
         a.quat_src != b.quat_src || a.feedforward != b.feedforward || a.multidim != b.multidim ||
-        a.conv_last != b.conv_last || a.standard != b.standard || a.nj != b.nj)
+        a.conv_last != b.conv_last || a.standard != b.standard || a.nj != b.nj || a.n_y != b.n_y)
         return false;
     for (int i = 0; i < a.n_tasks; ++i)
         if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i] ||

@@ -542,9 +542,9 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_kernel(
         for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
         __syncthreads();
     }
-    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_in(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
+    stage_in_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0) stage_in_dyn(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    if (ny > 0) stage_in_dyn(y + b0 * ny, ny, rows_valid, ys, lane);
     __syncthreads();
 
     double z[N];
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_kernel(
     for (int j = 0; j < N; ++j)
         if (j < n) zs[j * WAVE + lane] = vout[j];
     __syncthreads();
-    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_out(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    stage_out_dyn(dq + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0) stage_out_dyn(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_kernel(
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
     for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
     __syncthreads();
-    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
+    stage_in_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
+    if (ny > 0) stage_in_dyn(y + b0 * ny, ny, rows_valid, ys, lane);
     __syncthreads();
     double z[N];
 #pragma unroll
@@ -616,13 +616,13 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_kernel(
         }
     }
     __syncthreads();
-    stage_out(q + b0 * nq, nq, rows_valid, zs, lane);
+    stage_out_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < N; ++j)
         if (j < n) zs[j * WAVE + lane] = vout[j];
     __syncthreads();
-    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
+    stage_out_dyn(dq + b0 * nq, nq, rows_valid, zs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
@@ -702,17 +702,33 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     const bool valid = lane < rows_valid;
     double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
     double* ys = zs + N * WAVE;
-    // constants and joint state / inputs travel together: one memory round trip
-    const Img<SD>* __restrict__ S = load_image<SD>(img_g, lds, lane);
+    // constants, joint state and inputs travel together: every global load is
+    // issued (index-clamped, branch-free) before the first LDS write, so the
+    // prologue costs one memory round trip (n_x == 0, n_q == N in static shapes)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 img[StaticLayout<SD>::IMG_CHUNKS];
+    {
+        const d2* src = (const d2*)img_g;
+#pragma unroll
+        for (int k = 0; k < StaticLayout<SD>::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
+    }
+    double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
+    stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+    if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+    {
+        d2* dst = (d2*)lds;
+#pragma unroll
+        for (int k = 0; k < StaticLayout<SD>::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
+    }
+    const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
     if (rows_valid < WAVE) {
 #pragma unroll
         for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
         for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
         __syncthreads();
     }
-    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_in(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
+    stage_store<N>(qv, N, rows_valid, zs, lane);
+    if constexpr (SD.n_y > 0) stage_store<SD.n_y>(yv, SD.n_y, rows_valid, ys, lane);
     __syncthreads();
 
     double z[N];
@@ -726,8 +742,7 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
 #pragma unroll
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = vout[j];
     __syncthreads();
-    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_out(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
@@ -751,8 +766,8 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
     for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
     __syncthreads();
-    stage_in(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (ny > 0) stage_in(y + b0 * ny, ny, rows_valid, ys, lane);
+    stage_in<N>(q + b0 * N, N, rows_valid, zs, lane);
+    if constexpr (SD.n_y > 0) stage_in<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, ys, lane);
     __syncthreads();
     const int nts = S->n_tslots;
     double z[N];
@@ -778,12 +793,12 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
 #pragma unroll
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = z[j];
     __syncthreads();
-    stage_out(q + b0 * nq, nq, rows_valid, zs, lane);
+    stage_out<N>(q + b0 * N, N, rows_valid, zs, lane);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = vout[j];
     __syncthreads();
-    stage_out(dq + b0 * nq, nq, rows_valid, zs, lane);
+    stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 

@@ -375,7 +375,7 @@ __device__ __forceinline__ void ldl_factor_s(double (&A)[K * (K + 1) / 2], doubl
             d = fma(-A[tri(k, j)], t[j], d);
         }
         A[tri(k, k)] = d;
-        const double inv = 1.0 / d;
+        const double inv = recip(d);
         rd[k] = inv;
 #pragma unroll
         for (int i = k + 1; i < K; ++i) {
