@@ -667,6 +667,12 @@ def qp_solve_dense(hdiag, A, lb, ub, max_iter=200, eq_tol=0.0):
             if viol / nrm < worst:
                 worst, pick = viol / nrm, (i, sgn, rhs)
         if pick is None:
+            # never hand out a point that is not primal feasible: on an
+            # infeasible problem the scan above can run out of candidates
+            Ax = A.dot(x)
+            scl = np.maximum(1.0, np.maximum(np.abs(lb), np.abs(ub)))
+            if np.any((lb - Ax) / scl > 1e-8) or np.any((Ax - ub) / scl > 1e-8):
+                raise QPInfeasible("no feasible point found")
             return x
         i, sgn, rhs = pick
         add_constraint(normal(i, sgn), rhs, False, (i, sgn))

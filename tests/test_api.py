@@ -1,0 +1,190 @@
+"""casclik API parity of the constraint / skill / front-end layer (CPU only)."""
+import io
+import sys
+
+import numpy as np
+import pytest
+
+import casclik_amd as cc
+from casclik_amd import skills
+from casclik_amd import sym as cs
+from casclik_amd.lowering import lower_skill, CLS_EQ, CLS_SET, CLS_VELSET, OUT_NORM2
+
+
+def _syms(n=3):
+    return cs.MX.sym("t"), cs.MX.sym("q", n), cs.MX.sym("dq", n)
+
+
+def test_import_surface():
+    for name in ("EqualityConstraint", "SetConstraint", "VelocityEqualityConstraint",
+                 "VelocitySetConstraint", "SkillSpecification", "PseudoInverseController",
+                 "ReactiveQPController"):
+        assert hasattr(cc, name)
+
+
+def test_constraint_defaults_and_attributes():
+    t, q, dq = _syms()
+    e = cc.EqualityConstraint("e", q[0])
+    assert (e.gain, e.constraint_type, e.priority, e.slack_weight) == (1.0, "hard", 1, 1.0)
+    s = cc.SetConstraint("s", q)
+    assert np.all(np.asarray(s.set_min) == -1e10) and np.all(np.asarray(s.set_max) == 1e10)
+    v = cc.VelocityEqualityConstraint("v", q[1])
+    assert v.target == 0.0
+    vs = cc.VelocitySetConstraint("vs", q)
+    assert vs.set_min == -1e10 and vs.set_max == 1e10
+    assert repr(e).startswith("e<EqualityConstraint at 0x")
+    assert e.size() == (1, 1) and s.size() == (3, 1)
+
+
+def test_constraint_size_errors():
+    t, q, dq = _syms()
+    with pytest.raises(ValueError):
+        cc.EqualityConstraint("bad", q, gain=np.eye(2))
+    with pytest.raises(TypeError):
+        cc.EqualityConstraint("bad", q, gain="high")
+    with pytest.raises(ValueError):
+        cc.SetConstraint("bad", q, set_min=np.zeros(2), set_max=np.ones(3))
+    with pytest.raises(TypeError):
+        cc.SetConstraint("bad", q, set_min="low")
+    cc.EqualityConstraint("ok", q, gain=np.eye(3))
+    cc.SetConstraint("ok", q[0], set_min=-1.0, set_max=1.0)
+
+
+def test_skill_specification_bookkeeping():
+    t, q, dq = _syms()
+    y = cs.MX.sym("y", 2)
+    x = cs.MX.sym("x", 1)
+    cons = [cc.EqualityConstraint("a", q[0] - y[0], constraint_type="soft"),
+            cc.SetConstraint("b", q, priority=0)]
+    s = cc.SkillSpecification("demo", t, q, dq, virtual_var=x, input_var=y, constraints=cons)
+    assert s.n_robot_var == 3 and s.n_virtual_var == 1 and s.n_input_var == 2
+    assert s.n_slack_var == 1 and s.slack_var.size() == (1, 1)
+    assert s._has_input and not s._has_virtual
+    assert [c.label for c in s.constraints] == ["b", "a"]
+    assert s.robot_vel_var is dq and s.virtual_vel_var.size() == (1, 1)
+    buf, old = io.StringIO(), sys.stdout
+    sys.stdout = buf
+    try:
+        s.print_constraints()
+    finally:
+        sys.stdout = old
+    out = buf.getvalue()
+    assert "SkillSpecification: demo" in out and "#0: b" in out and "Has input var: True" in out
+    with pytest.raises(ValueError):
+        cc.SkillSpecification("bad", t, q, robot_vel_var=cs.MX.sym("d", 2))
+    with pytest.raises(TypeError):
+        cc.SkillSpecification("bad", t, q, robot_vel_var=np.zeros(3))
+
+
+def test_controller_options_defaults_and_repr():
+    spec = skills.stack_skill()
+    c = cc.PseudoInverseController(skill_spec=spec)
+    assert c.options["feedforward"] is True and c.options["multidim_sets"] is False
+    assert c.options["pinv_method"] == "damped" and c.options["damping_factor"] == 1e-7
+    assert c.options["function_opts"]["jit"] is True
+    assert repr(c) == "PseudoInverseController<stack>"
+    qc = cc.ReactiveQPController(skill_spec=skills.qp_skill())
+    assert qc.weight_shifter == 0.001 and qc.options["solver_name"] == "qpoases"
+    assert np.allclose(qc.robot_var_weights, 1.0) and qc.slack_var_weights.shape == (6,)
+    assert repr(qc) == "ReactiveQPController<qp_pose>"
+    with pytest.raises(ValueError):
+        cc.ReactiveQPController(skill_spec=skills.qp_skill(), robot_var_weights=[1.0, 2.0])
+
+
+def test_solve_initial_problem_pinv_returns_zeros():
+    c = cc.PseudoInverseController(skill_spec=skills.pose_skill())
+    virt, slack = c.solve_initial_problem(0.0, np.zeros(7))
+    assert virt is None and np.all(slack.toarray() == 0) and slack.size() == (6, 1)
+
+
+# ------------------------------------------------------------------ front-end
+def test_sym_algebra_and_function():
+    t, q, _ = _syms()
+    expr = cs.vertcat(cs.sin(q[0]) * 2 + t, cs.norm_2(q), cs.mtimes(np.array([[1.0, 2.0, 3.0]]), q))
+    f = cs.Function("f", [t, q], [expr])
+    val = f(0.5, [0.1, 0.2, 0.3]).toarray()[:, 0]
+    assert np.allclose(val, [2 * np.sin(0.1) + 0.5, np.sqrt(0.14), 1.4])
+    g = cs.Function("g", [q], [q[::-1] + 1.0])
+    assert np.allclose(g(np.array([1.0, 2.0, 3.0])).toarray()[:, 0], [4.0, 3.0, 2.0])
+    # symbolic call substitutes
+    h = f(t, q * 2.0)
+    assert isinstance(h, cs.MX) and h.size() == (3, 1)
+    assert cs.inv(np.diag([2.0, 4.0])).toarray()[1, 1] == 0.25
+    assert cs.vertcat([1.0] * 3).toarray().shape == (3, 1)
+    d = cs.DM([1.0, 2.0])
+    assert d.toarray().shape == (2, 1) and float(d[1]) == 2.0
+
+
+def test_fk_atom_matches_chain(iiwa_fk):
+    q = cs.MX.sym("q", 7)
+    T = iiwa_fk["T_fk"](q)
+    f = cs.Function("T", [q], [T])
+    q0 = np.linspace(-1, 1, 7)
+    assert np.allclose(f(q0).toarray(), iiwa_fk["chain"].fk_numeric(q0))
+    J = cc.EqualityConstraint("p", T[:3, 3]).jacobian(q)
+    Jn = cs.Function("J", [q], [J])(q0).toarray()
+    h = 1e-6
+    for k in range(7):
+        qp, qm = q0.copy(), q0.copy()
+        qp[k] += h
+        qm[k] -= h
+        fd = (iiwa_fk["chain"].fk_numeric(qp)[:3, 3] - iiwa_fk["chain"].fk_numeric(qm)[:3, 3]) / (2 * h)
+        assert np.allclose(Jn[:, k], fd, atol=1e-8)
+
+
+# ------------------------------------------------------------------ lowering
+def test_lowering_of_baseline_skills(iiwa_fk):
+    d = lower_skill(skills.stack_skill(iiwa_fk))
+    assert (d.n_q, d.n_x, d.n_y) == (7, 0, 7) and len(d.joints) == 8 and d.n_sets == 1
+    assert [t["cls"] for t in d.tasks] == [CLS_SET, CLS_EQ, CLS_EQ]
+    assert [t["m"] for t in d.tasks] == [7, 6, 7]
+    assert d.quat_src == 2 and d.quat_yi == [3, 4, 5, 6] and d.uses_fk
+    assert np.allclose(d.tasks[0]["set_max"][:7], iiwa_fk["upper"])
+    pose_rows = [d.rows[r] for r in d.tasks[1]["out_row0"][:6]]
+    assert all(r["b"].any() for r in pose_rows[:3]) and all(r["h"].any() for r in pose_rows[3:])
+    assert [r["yi"][0] for r in pose_rows[:3]] == [0, 1, 2] and all(r["yc"][0] == -1.0 for r in pose_rows[:3])
+    dq = lower_skill(skills.qp_skill(iiwa_fk))
+    assert [t["cls"] for t in dq.tasks] == [CLS_VELSET, CLS_EQ] and dq.n_slack == 6
+
+
+def test_lowering_norm_and_time_terms(ur5_fk):
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    T = ur5_fk["T_fk"](q)
+    dist = cc.EqualityConstraint("dist", cs.norm_2(np.array([0.5, 0.5, 0.5]) - T[:3, 3]), gain=50.0)
+    track = cc.EqualityConstraint("track", T[:3, 3] - cs.vertcat(cs.sin(0.1 * t), 0.2 * t, 0.3), priority=2)
+    d = lower_skill(cc.SkillSpecification("s", t, q, constraints=[dist, track]))
+    assert d.tasks[0]["out_kind"][0] == OUT_NORM2 and d.tasks[0]["out_nrows"][0] == 3
+    assert d.n_tslots == 2
+    tt = d.time_terms(2.0)
+    # the target enters the expression with a minus sign
+    assert np.allclose(sorted(tt[:2]), sorted([-np.sin(0.2), -0.4]))
+    assert np.allclose(sorted(tt[2:]), sorted([-0.1 * np.cos(0.2), -0.2]))
+
+
+def test_lowering_rejects_what_the_device_cannot_do(iiwa_fk):
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("dq", 7)
+    T = iiwa_fk["T_fk"](q)
+    with pytest.raises(NotImplementedError, match="outside the device task family"):
+        lower_skill(cc.SkillSpecification("s", t, q, constraints=[
+            cc.EqualityConstraint("sq", T[0, 3] * T[1, 3])]))
+    with pytest.raises(NotImplementedError, match="velocity variables"):
+        lower_skill(cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint("v", dq[0])]))
+    with pytest.raises(NotImplementedError, match="rows"):
+        lower_skill(cc.SkillSpecification("s", t, q, constraints=[
+            cc.EqualityConstraint("nine", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2]))]))
+    seven_sets = [cc.SetConstraint("s%d" % i, q[i], set_min=-1.0, set_max=1.0, priority=i) for i in range(7)]
+    with pytest.raises(NotImplementedError, match="modes"):
+        lower_skill(cc.SkillSpecification("s", t, q, constraints=seven_sets))
+
+
+def test_controller_needs_the_hip_library_or_gpu():
+    """No CPU fallback: without a GPU the controller setup must fail loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    c = cc.PseudoInverseController(skill_spec=skills.pose_skill())
+    with pytest.raises(RuntimeError):
+        c.setup_problem_functions()
+    with pytest.raises(RuntimeError, match="setup"):
+        c.solve(0.0, np.zeros(7), input_var=np.zeros(7))

@@ -1,0 +1,69 @@
+"""Multi-rank path on CPU: world_size-2 gloo.  Each rank solves its contiguous
+shard (the CPU oracle stands in for the HIP launch, which needs a GPU) and the
+joint velocities are all-gathered; the result must equal the single-process
+answer on the full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from casclik_amd import skills
+from casclik_amd.distributed import shard_bounds, all_gather_rows
+
+
+def test_shard_bounds_partition():
+    for B in (0, 1, 7, 64, 16384, 131072 + 3):
+        for G in (1, 2, 3, 8):
+            cuts = [shard_bounds(B, r, G) for r in range(G)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(G - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import clik_oracle
+        fk = skills.iiwa()
+        spec = skills.stack_skill(fk)
+        Q, Y = skills.synthetic_inputs(fk, B, seed=4, distribution="mixed")
+        lo, hi = shard_bounds(B, rank, world)
+        dq, mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q[lo:hi], Y=Y[lo:hi])
+        full = all_gather_rows(torch.from_numpy(dq), n_rows_total=B)
+        modes = all_gather_rows(torch.from_numpy(mode.astype(np.int64)).reshape(-1, 1), n_rows_total=B)
+        np.save(os.path.join(out_dir, "dq_%d.npy" % rank), full.numpy())
+        np.save(os.path.join(out_dir, "mode_%d.npy" % rank), modes.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [24, 25])      # even and uneven shards
+def test_two_rank_gloo_matches_single_process(tmp_path, B):
+    from oracle import clik_oracle
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    fk = skills.iiwa()
+    Q, Y = skills.synthetic_inputs(fk, B, seed=4, distribution="mixed")
+    ref, rmode = clik_oracle.pinv_solve_batch(skills.stack_skill(fk), skills.STACK_OPTIONS, 0.0, Q, Y=Y)
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "dq_%d.npy" % rank))
+        gm = np.load(os.path.join(str(tmp_path), "mode_%d.npy" % rank))[:, 0]
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref) and np.array_equal(gm, rmode)
