@@ -181,7 +181,7 @@ class ReactiveQPController(BaseController):
                                                       and spec._has_virtual)
 
     def solve_initial_problem(self, time_var0, robot_var0, virtual_var0=None,
-                              robot_vel_var0=None, input_var0=None):
+                              robot_vel_var0=None, input_var0=None):  # noqa: D401
         """Returns (virtual_vel0, slack0) like reactive_qp.py:426-459.  The
         values come from the full QP at the initial state (the reference fixes
         robot_vel to ``robot_vel_var0`` and re-optimises the rest); callers

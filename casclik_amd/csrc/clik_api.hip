@@ -39,13 +39,14 @@ hipError_t pinv_launch_rollout(int k, const LaunchArgs& a, const double* d_tterm
                                double max_speed, long long B, double* q, const double* y, double* dq,
                                int32_t* mode, hipStream_t stream);
 int pinv_lds_slots_host(int N, int ny);
-hipError_t qp_launch_solve(int NV, const DevSkill* dS, const TickArgs& tk, long long B,
-                           const double* q, const double* x, const double* y, double* dq,
-                           double* dx, double* slack, int32_t* status, hipStream_t stream);
-hipError_t qp_launch_data(const DevSkill* dS, const TickArgs& tk, long long B, const double* q,
-                          const double* x, const double* y, double* Hd, double* A, double* lb,
+hipError_t qp_launch_solve(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                           const double* q, const double* x, const double* y, double* dq, double* dx,
+                           double* slack, int32_t* status, hipStream_t stream);
+hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                          const double* q, const double* x, const double* y, double* Hd, double* A, double* lb,
                           double* ub, hipStream_t stream);
 int qp_pick_variant(int n, int nv, int nc);
+size_t qp_variant_lds(int k, int ny);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -65,6 +66,7 @@ struct clik_pinv {
 struct clik_qp {
     DevSkill  host;
     DevSkill* dev;
+    clik::WarmArgs warm;
     int       variant;
 };
 
@@ -322,6 +324,26 @@ static bool build_skill_image(const DevSkill& S, std::vector<char>& out)
     return true;
 }
 
+// scalar-cache warm-up ranges (clik_device.hpp, warm_descriptor): the used
+// prefixes of the descriptor arrays and the derived tables
+static void compute_warm(const DevSkill& S, int used_rows, clik::WarmArgs& w)
+{
+    auto lo = [](size_t off) { return (int32_t)(off & ~(size_t)63); };
+    auto hi = [](size_t off) { return (int32_t)((off + 63) & ~(size_t)63); };
+    const size_t o_d = offsetof(DevSkill, d);
+    w.off[0] = lo(o_d);
+    w.end[0] = hi(o_d + offsetof(clik_skill_desc, joints) + (size_t)S.d.n_joints * sizeof(clik_joint));
+    w.off[1] = lo(o_d + offsetof(clik_skill_desc, tasks));
+    w.end[1] = hi(o_d + offsetof(clik_skill_desc, tasks) + (size_t)S.d.n_tasks * sizeof(clik_task));
+    w.off[2] = lo(o_d + offsetof(clik_skill_desc, rows));
+    w.end[2] = hi(o_d + offsetof(clik_skill_desc, rows) + (size_t)used_rows * sizeof(clik_row));
+    w.off[3] = lo(offsetof(DevSkill, shape));
+    w.end[3] = hi(offsetof(DevSkill, cpinv) + (size_t)S.d.n_tasks * sizeof(S.cpinv[0]));
+    w.off[4] = lo(offsetof(DevSkill, po));
+    w.end[4] = hi(sizeof(DevSkill));
+    w.token_off = (int32_t)offsetof(DevSkill, zero_token);
+}
+
 static void finish_pinv_shape(DevSkill& S, const clik_pinv_opts* opts)
 {
     S.po = *opts;
@@ -432,26 +454,7 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         delete h;
         return fail(CLIK_EUNSUPPORTED, "no kernel variant for n = %d", S.n);
     }
-    {
-        // scalar-cache warm-up ranges (clik_device.hpp, warm_descriptor): the
-        // used prefixes of the descriptor arrays and the derived tables
-        const int used_rows = S.lds_slots;
-        auto lo = [](size_t off) { return (int32_t)(off & ~(size_t)63); };
-        auto hi = [](size_t off) { return (int32_t)((off + 63) & ~(size_t)63); };
-        clik::WarmArgs& w = h->warm;
-        const size_t o_d = offsetof(DevSkill, d);
-        w.off[0] = lo(o_d);
-        w.end[0] = hi(o_d + offsetof(clik_skill_desc, joints) + (size_t)S.d.n_joints * sizeof(clik_joint));
-        w.off[1] = lo(o_d + offsetof(clik_skill_desc, tasks));
-        w.end[1] = hi(o_d + offsetof(clik_skill_desc, tasks) + (size_t)S.d.n_tasks * sizeof(clik_task));
-        w.off[2] = lo(o_d + offsetof(clik_skill_desc, rows));
-        w.end[2] = hi(o_d + offsetof(clik_skill_desc, rows) + (size_t)used_rows * sizeof(clik_row));
-        w.off[3] = lo(offsetof(DevSkill, shape));
-        w.end[3] = hi(offsetof(DevSkill, cpinv) + (size_t)S.d.n_tasks * sizeof(S.cpinv[0]));
-        w.off[4] = lo(offsetof(DevSkill, po));
-        w.end[4] = hi(sizeof(DevSkill));
-        w.token_off = (int32_t)offsetof(DevSkill, zero_token);
-    }
+    compute_warm(S, S.lds_slots, h->warm);
     S.zero_token = 0;
     S.lds_slots = clik::pinv_lds_slots_host(clik::pinv_kernel_width(h->kernel), S.d.n_y);
     if ((size_t)S.lds_slots * clik::WAVE * sizeof(double) > 160u * 1024u) {
@@ -577,6 +580,11 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     DevSkill& S = h->host;
     S.qo = *opts;
     if (S.qo.max_iter <= 0) S.qo.max_iter = 4 * (S.n_qp_rows + S.n_qp_vars) + 16;
+    for (int k = 0; k < S.n_slack; ++k)
+        if (!(opts->weight_shifter + opts->slack_weights[k] > 0.0)) {
+            delete h;
+            return fail(CLIK_EINVAL, "QP slack weight %d makes the cost non-convex", k);
+        }
     if (S.n_qp_vars > CLIK_MAX_QPVARS || S.n_qp_rows > CLIK_MAX_QPROWS) {
         delete h;
         return fail(CLIK_EUNSUPPORTED, "QP with %d variables x %d rows exceeds the device limits (%d x %d)",
@@ -587,11 +595,24 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
             delete h;
             return fail(CLIK_EINVAL, "QP cost weight %d is not positive", j);
         }
-    h->variant = clik::qp_pick_variant(S.n, S.n_qp_vars, S.n_qp_rows);
+    {
+        int need = S.n;
+        for (int ti = 0; ti < S.d.n_tasks; ++ti)
+            if (S.d.tasks[ti].m > need) need = S.d.tasks[ti].m;
+        h->variant = clik::qp_pick_variant(need, S.n_qp_vars, S.n_qp_rows);
+    }
     if (h->variant < 0) {
         delete h;
-        return fail(CLIK_EUNSUPPORTED, "no QP kernel variant for %d variables x %d rows", S.n_qp_vars, S.n_qp_rows);
+        return fail(CLIK_EUNSUPPORTED, "no QP kernel variant for %d variables x %d rows (device limit: 16 rows)",
+                    S.n_qp_vars, S.n_qp_rows);
     }
+    if (clik::qp_variant_lds(h->variant, S.d.n_y) > 160u * 1024u) {
+        delete h;
+        return fail(CLIK_EUNSUPPORTED, "QP needs more LDS than a CU has (input_var too large)");
+    }
+    compute_warm(S, S.lds_slots, h->warm);
+    S.zero_token = 0;
+    S.lds_slots = 0;
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
@@ -633,8 +654,8 @@ extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tt
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
-    hipError_t e = clik::qp_launch_solve(h->variant, h->dev, tk, (long long)B, q, x, y, dq, dx, slack, status,
-                                         (hipStream_t)stream);
+    hipError_t e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,
+                                         slack, status, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_solve_kernel launch");
     return CLIK_OK;
 }
@@ -650,8 +671,8 @@ extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tte
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
-    hipError_t e = clik::qp_launch_data(h->dev, tk, (long long)B, q, x, y, Hdiag, A, lbA, ubA,
-                                        (hipStream_t)stream);
+    hipError_t e = clik::qp_launch_data(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, Hdiag, A,
+                                        lbA, ubA, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_data_kernel launch");
     return CLIK_OK;
 }

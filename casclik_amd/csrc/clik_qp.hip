@@ -1,9 +1,504 @@
-// placeholder until the QP kernel lands
+// Batched ReactiveQPController tick on gfx950.
+//
+// Replaces, for B instances per launch, the per-tick body of
+//   ReactiveQPController.solve            casclik/controllers/reactive_qp.py:461-528
+// i.e. the H/A/lbA/ubA functions (:175-246, :262-298) and the qpOASES call
+// through cs.conic (:248-260, :491-513).
+//
+// The QP   min 1/2 v'Hv   s.t.  lbA <= A v <= ubA,   H = diag(h) > 0,
+// v = [robot_vel; virtual_vel; slack]  has a unique minimiser, so the solver is
+// free: each lane runs an exact dual active-set method (Goldfarb & Idnani 1983)
+// written in CONSTRAINT space.  With nu the signed multipliers,
+//      v = H^-1 A' nu,      c = A v = Q nu,      Q = A H^-1 A'   (nc x nc, SPD-ish)
+// so the iteration only needs Q (kept in LDS, per lane), nu and c; every change
+// of the working set re-factors the masked Schur matrix  S_W = D Q_WW D  by a
+// fixed-size LDL^T in registers (no updates/downdates, no drift, the same
+// instruction stream for every lane; lanes differ only in masks).
+//   - slack columns never materialise: a soft row i adds 1/h_slack,i to Q_ii
+//     and its slack is  -nu_i / h_slack,i
+//   - rows with lbA == ubA are equalities: once active they stay, their
+//     multiplier is sign-free
+//   - infeasible problems (hard rows only) are reported per instance, like the
+//     reference's RuntimeError from qpOASES
 #include "clik_device.hpp"
+
 namespace clik {
-int qp_pick_variant(int, int, int) { return -1; }
-hipError_t qp_launch_solve(int, const DevSkill*, const TickArgs&, long long, const double*, const double*,
-                           const double*, double*, double*, double*, int32_t*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t qp_launch_data(const DevSkill*, const TickArgs&, long long, const double*, const double*,
-                          const double*, double*, double*, double*, double*, hipStream_t) { return hipErrorNotSupported; }
+
+// LDS slots per lane: [zs N][ys ny][A rows NC*N (FK frames alias)][Q NC(NC+1)/2][lb NC][ub NC][hinv NC]
+template <int N, int NC>
+__host__ __device__ constexpr int qp_lds_slots(int ny)
+{
+    return N + ny + (NC * N > 6 * N ? NC * N : 6 * N) + NC * (NC + 1) / 2 + 3 * NC;
 }
+
+// Evaluate every constraint row of the QP for the lane's instance:
+//   A_u rows -> As[row*N + j], bounds -> lbs/ubs, slack curvature 1/h_slack (0 = hard) -> hsi
+// Returns the number of rows (wave-uniform).  reactive_qp.py:191-246.
+template <int N>
+__device__ __forceinline__ int qp_rows(const DevSkill* __restrict__ S, const TickArgs& tk, const Kin<N>& K,
+                                       const double (&z)[N], const double* ys, const int lane, const int n,
+                                       double* As, double* lbs, double* ubs, double* hsi)
+{
+    const clik_skill_desc& D = S->d;
+    int row = 0, slack = 0;
+    const double mu = S->qo.weight_shifter;
+    for (int ti = 0; ti < D.n_tasks; ++ti) {
+        const clik_task& t = D.tasks[ti];
+        const int m = t.m;
+        double e[N], J[N][N], Jt[N];
+        task_eval<N, N>(S, ti, m, -1, false, tk, K, z, ys, lane, n, e, J, Jt);
+        double lo[N], hi[N];
+        const int cls = t.cls;
+        if (cls == CLIK_CLS_EQ) {
+            double ke[N];
+            gain_apply<N>(t, m, e, ke);
+#pragma unroll
+            for (int i = 0; i < N; ++i) lo[i] = hi[i] = -Jt[i] - ke[i];
+        } else if (cls == CLIK_CLS_SET) {
+            double d0[N], g[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) d0[i] = (i < m) ? t.set_min[i] - e[i] : 0.0;
+            gain_apply<N>(t, m, d0, g);
+#pragma unroll
+            for (int i = 0; i < N; ++i) lo[i] = -Jt[i] + g[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) d0[i] = (i < m) ? t.set_max[i] - e[i] : 0.0;
+            gain_apply<N>(t, m, d0, g);
+#pragma unroll
+            for (int i = 0; i < N; ++i) hi[i] = -Jt[i] + g[i];
+        } else if (cls == CLIK_CLS_VELEQ) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) lo[i] = hi[i] = (i < m) ? t.target[i] - Jt[i] : 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                lo[i] = (i < m) ? t.set_min[i] - Jt[i] : 0.0;
+                hi[i] = (i < m) ? t.set_max[i] - Jt[i] : 0.0;
+            }
+        }
+        const bool soft = t.soft != 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i < m) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (j < n) As[((row + i) * N + j) * WAVE + lane] = J[i][j];
+                lbs[(row + i) * WAVE + lane] = lo[i];
+                ubs[(row + i) * WAVE + lane] = hi[i];
+                hsi[(row + i) * WAVE + lane] = soft ? 1.0 / (mu + S->qo.slack_weights[slack + i]) : 0.0;
+            }
+        }
+        if (soft) slack += m;
+        row += m;
+    }
+    return row;
+}
+
+// ---- dual active set in constraint space -------------------------------------------
+// Qs: packed lower triangle of Q per lane (slot tri(i,j)*WAVE + lane), lbs / ubs: bounds.
+// On return nu holds the signed multipliers of the optimum.  Returns the status
+// (0 optimal, 1 iteration cap, 2 infeasible).
+template <int NC>
+__device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs, const int lane,
+                                        const int nc, const int max_iter, const bool lane_valid,
+                                        double (&nu)[NC])
+{
+    constexpr int NT = NC * (NC + 1) / 2;
+    uint32_t W = 0u, up = 0u, eq = 0u;
+    double c[NC], lb[NC], ub[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        nu[i] = 0.0;
+        c[i] = 0.0;
+        lb[i] = (i < nc) ? lbs[i * WAVE + lane] : -1e300;
+        ub[i] = (i < nc) ? ubs[i * WAVE + lane] : 1e300;
+        if (i < nc && !(ub[i] - lb[i] > 0.0)) eq |= 1u << i;
+    }
+    int status = 0;
+    bool done = !lane_valid;
+    bool need_p = true;
+    int p = 0;
+    double sp = 1.0, bp = 0.0;
+    for (int it = 0; it < max_iter; ++it) {
+        if (__ballot(!done) == 0ull) break;
+        // (1) pick the next constraint to enforce: unsatisfied equalities first,
+        //     then the most violated inequality
+        if (need_p && !done) {
+            double best = 1e-11;
+            int pick = -1;
+            bool pick_up = false;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (i < nc && !((W >> i) & 1u)) {
+                    const double scale = fmax(1.0, fmax(fabs(lb[i]), fabs(ub[i])));
+                    const double vlo = (lb[i] - c[i]) / scale, vhi = (c[i] - ub[i]) / scale;
+                    double v = fmax(vlo, vhi);
+                    if (((eq >> i) & 1u) && v > 1e-11) v += 1e30;       // equalities take precedence
+                    if (v > best) {
+                        best = v;
+                        pick = i;
+                        pick_up = vhi > vlo;
+                    }
+                }
+            }
+            if (pick < 0) {
+                done = true;
+            } else {
+                p = pick;
+                sp = pick_up ? -1.0 : 1.0;
+                double b = 0.0;
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+                    if (i == p) b = pick_up ? -ub[i] : lb[i];
+                bp = b;
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+        // (2) step direction:  r = S_W^-1 (D Q_Wp sp),   zn = n_p' H^-1 (n_p - N_W r)
+        double L[NT], rd[NC], r[NC], rhs[NC];
+        double qpp = 0.0, cp = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const bool ai = (W >> i) & 1u;
+            const double si = ((up >> i) & 1u) ? -1.0 : 1.0;
+            // column p of Q (dynamic per lane): packed index of (max(i,p), min(i,p))
+            const int hi_ = i > p ? i : p, lo_ = i > p ? p : i;
+            const double qip = (i < nc) ? Qs[(hi_ * (hi_ + 1) / 2 + lo_) * WAVE + lane] : 0.0;
+            rhs[i] = ai ? si * sp * qip : 0.0;
+            if (i == p) {
+                qpp = qip;
+                cp = c[i];
+            }
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const bool aj = (W >> j) & 1u;
+                const double q = (i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
+                const bool flip = ((up >> i) ^ (up >> j)) & 1u;
+                L[tri(i, j)] = (ai && aj) ? (flip ? -q : q) : (i == j ? 1.0 : 0.0);
+            }
+        }
+        ldl_factor<NC>(L, rd, nc);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) r[i] = rhs[i];
+        ldl_solve<NC>(L, rd, r, nc);
+        double zn = qpp;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) zn = fma(-rhs[i], r[i], zn);
+        // (3) step lengths
+        double t1 = 1e300;
+        int l = -1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const bool ai = (W >> i) & 1u;
+            if (ai && !((eq >> i) & 1u) && r[i] > 1e-14) {
+                const double mu_i = (((up >> i) & 1u) ? -nu[i] : nu[i]);
+                const double cand = fmax(mu_i, 0.0) / r[i];
+                if (cand < t1) {
+                    t1 = cand;
+                    l = i;
+                }
+            }
+        }
+        const double gap = bp - sp * cp;
+        const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
+        const double t2 = has_primal ? gap / zn : 1e300;
+        const double t = fmin(t1, t2);
+        if (!done) {
+            if (!(t < 1e299)) {
+                status = 2;                 // constraint p cannot be satisfied
+                done = true;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const bool ai = (W >> i) & 1u;
+                    const double si = ((up >> i) & 1u) ? -1.0 : 1.0;
+                    if (ai) nu[i] = fma(-t * si, r[i], nu[i]);
+                    if (i == p) nu[i] = fma(t, sp, nu[i]);
+                }
+                if (t2 <= t1) {
+                    W |= 1u << p;
+                    if (sp < 0.0) up |= 1u << p;
+                    need_p = true;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+                        if (i == l) nu[i] = 0.0;
+                    W &= ~(1u << l);
+                    up &= ~(1u << l);
+                    need_p = false;
+                }
+            }
+        }
+        // (4) c = Q nu
+#pragma unroll
+        for (int i = 0; i < NC; ++i) c[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double q = (i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
+                c[i] = fma(q, nu[j], c[i]);
+                if (j != i) c[j] = fma(q, nu[i], c[j]);
+            }
+    }
+    if (!done) status = 1;
+    return status;
+}
+
+template <int N, int NC>
+__global__ __launch_bounds__(WAVE) void qp_solve_kernel(
+    const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
+    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ dx, double* __restrict__ slack_out,
+    int32_t* __restrict__ status_out)
+{
+    extern __shared__ double lds[];
+    constexpr int NT = NC * (NC + 1) / 2;
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    const DevSkill* __restrict__ S = warm_descriptor(S0, wa);
+    const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
+    double* zs = lds;
+    double* ys = zs + N * WAVE;
+    double* As = ys + ny * WAVE;
+    double* Qs = As + (NC * N > 6 * N ? NC * N : 6 * N) * WAVE;
+    double* lbs = Qs + NT * WAVE;
+    double* ubs = lbs + NC * WAVE;
+    double* hsi = ubs + NC * WAVE;
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
+    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
+    __syncthreads();
+    stage_in_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0) stage_in_dyn(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    if (ny > 0) stage_in_dyn(y + b0 * ny, ny, rows_valid, ys, lane);
+    __syncthreads();
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = (j < n) ? zs[j * WAVE + lane] : 0.0;
+
+    Kin<N> K;
+    if (S->d.uses_fk) {
+        forward_kinematics<N>(S, zs, As, lane, K);      // frames alias the (not yet written) row area
+        if (S->d.quat_src != 0) orientation_feature<N>(S, ys, lane, K);
+    }
+    const int nc = qp_rows<N>(S, tk, K, z, ys, lane, n, As, lbs, ubs, hsi);
+
+    // Q = A_u diag(1/h_u) A_u' + diag(1/h_slack on soft rows)        (H of reactive_qp.py:175-189)
+    double hinv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) hinv[j] = (j < n) ? 1.0 / (S->qo.weight_shifter * S->qo.state_weights[j]) : 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (i < nc) {
+            double ri[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) ri[j] = (j < n) ? As[(i * N + j) * WAVE + lane] * hinv[j] : 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) {
+                double acc = (k == i) ? hsi[i * WAVE + lane] : 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (j < n) acc = fma(ri[j], As[(k * N + j) * WAVE + lane], acc);
+                Qs[tri(i, k) * WAVE + lane] = acc;
+            }
+        }
+    }
+
+    double nu[NC];
+    const int status = gi_solve<NC>(Qs, lbs, ubs, lane, nc, S->qo.max_iter, valid, nu);
+
+    // v = H^-1 A' nu
+    double u[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (i < nc) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (j < n) u[j] = fma(nu[i], As[(i * N + j) * WAVE + lane], u[j]);
+        }
+    }
+    const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = u[j] * hinv[j] + bad;
+    if (slack_out != nullptr && valid) {
+        const int ns = S->n_slack;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (i < nc) {
+                const double hi_ = hsi[i * WAVE + lane];
+                if (hi_ != 0.0) {
+                    slack_out[(b0 + lane) * ns + k] = -nu[i] * hi_ + bad;
+                    ++k;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if (j < n) zs[j * WAVE + lane] = u[j];
+    __syncthreads();
+    stage_out_dyn(dq + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0 && dx != nullptr) stage_out_dyn(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    if (status_out != nullptr && valid) status_out[b0 + lane] = status;
+}
+
+// H diagonal, A, lbA, ubA exactly as the reference's H_func / A_func / Blb_func /
+// Bub_func return them (reactive_qp.py:283-298), for inspection and parity tests.
+template <int N, int NC>
+__global__ __launch_bounds__(WAVE) void qp_data_kernel(
+    const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
+    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
+    double* __restrict__ Hd, double* __restrict__ A, double* __restrict__ lbA, double* __restrict__ ubA)
+{
+    extern __shared__ double lds[];
+    constexpr int NT = NC * (NC + 1) / 2;
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    const DevSkill* __restrict__ S = warm_descriptor(S0, wa);
+    const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
+    double* zs = lds;
+    double* ys = zs + N * WAVE;
+    double* As = ys + ny * WAVE;
+    double* Qs = As + (NC * N > 6 * N ? NC * N : 6 * N) * WAVE;
+    double* lbs = Qs + NT * WAVE;
+    double* ubs = lbs + NC * WAVE;
+    double* hsi = ubs + NC * WAVE;
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
+    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
+    __syncthreads();
+    stage_in_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
+    if (nx > 0) stage_in_dyn(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
+    if (ny > 0) stage_in_dyn(y + b0 * ny, ny, rows_valid, ys, lane);
+    __syncthreads();
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = (j < n) ? zs[j * WAVE + lane] : 0.0;
+    Kin<N> K;
+    if (S->d.uses_fk) {
+        forward_kinematics<N>(S, zs, As, lane, K);
+        if (S->d.quat_src != 0) orientation_feature<N>(S, ys, lane, K);
+    }
+    const int nc = qp_rows<N>(S, tk, K, z, ys, lane, n, As, lbs, ubs, hsi);
+    if (!valid) return;
+    const int ns = S->n_slack, nv = n + ns;
+    const long long b = b0 + lane;
+    for (int j = 0; j < n; ++j) Hd[b * nv + j] = S->qo.weight_shifter * S->qo.state_weights[j];
+    for (int k = 0; k < ns; ++k) Hd[b * nv + n + k] = S->qo.weight_shifter + S->qo.slack_weights[k];
+    int k = 0;
+    for (int i = 0; i < nc; ++i) {
+        double* row = A + (b * nc + i) * nv;
+        for (int j = 0; j < nv; ++j) row[j] = 0.0;
+        for (int j = 0; j < n; ++j) row[j] = As[(i * N + j) * WAVE + lane];
+        if (hsi[i * WAVE + lane] != 0.0) {
+            row[n + k] = -1.0;
+            ++k;
+        }
+        lbA[b * nc + i] = lbs[i * WAVE + lane];
+        ubA[b * nc + i] = ubs[i * WAVE + lane];
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------
+struct QpVariant {
+    int N, NC;
+    hipError_t (*solve)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
+                        const double*, const double*, double*, double*, double*, int32_t*, hipStream_t);
+    hipError_t (*data)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
+                       const double*, const double*, double*, double*, double*, double*, hipStream_t);
+};
+
+template <int N, int NC>
+static hipError_t qp_solve_launch(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                                  const double* q, const double* x, const double* y, double* dq, double* dx,
+                                  double* slack, int32_t* status, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    const size_t shmem = (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)qp_solve_kernel<N, NC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((qp_solve_kernel<N, NC>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y, dq,
+                       dx, slack, status);
+    return hipGetLastError();
+}
+
+template <int N, int NC>
+static hipError_t qp_data_launch(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                                 const double* q, const double* x, const double* y, double* Hd, double* A,
+                                 double* lb, double* ub, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    const size_t shmem = (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)qp_data_kernel<N, NC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((qp_data_kernel<N, NC>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y, Hd, A,
+                       lb, ub);
+    return hipGetLastError();
+}
+
+#define CLIK_QP_VARIANT(N, NC) {N, NC, &qp_solve_launch<N, NC>, &qp_data_launch<N, NC>}
+static const QpVariant kQpVariants[] = {
+    CLIK_QP_VARIANT(6, 8),  CLIK_QP_VARIANT(6, 12), CLIK_QP_VARIANT(6, 16),
+    CLIK_QP_VARIANT(7, 8),  CLIK_QP_VARIANT(7, 13), CLIK_QP_VARIANT(7, 16),
+    CLIK_QP_VARIANT(8, 8),  CLIK_QP_VARIANT(8, 16),
+};
+constexpr int kNumQpVariants = (int)(sizeof(kQpVariants) / sizeof(kQpVariants[0]));
+
+// smallest variant that holds the skill; -1 if none (more than 16 rows)
+int qp_pick_variant(int n, int nv, int nc)
+{
+    (void)nv;
+    int best = -1;
+    for (int k = 0; k < kNumQpVariants; ++k) {
+        const QpVariant& v = kQpVariants[k];
+        if (v.N < n || v.NC < nc) continue;
+        // task_eval works on N x N blocks: a constraint may have up to N rows
+        if (best < 0 || v.N * 100 + v.NC < kQpVariants[best].N * 100 + kQpVariants[best].NC) best = k;
+    }
+    return best;
+}
+
+int qp_variant_width(int k) { return (k >= 0 && k < kNumQpVariants) ? kQpVariants[k].N : 0; }
+
+size_t qp_variant_lds(int k, int ny)
+{
+    if (k < 0 || k >= kNumQpVariants) return 0;
+    const QpVariant& v = kQpVariants[k];
+    const int wk = v.NC * v.N > 6 * v.N ? v.NC * v.N : 6 * v.N;
+    return (size_t)(v.N + ny + wk + v.NC * (v.NC + 1) / 2 + 3 * v.NC) * WAVE * sizeof(double);
+}
+
+hipError_t qp_launch_solve(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                           const double* q, const double* x, const double* y, double* dq, double* dx,
+                           double* slack, int32_t* status, hipStream_t stream)
+{
+    if (k < 0 || k >= kNumQpVariants) return hipErrorInvalidValue;
+    return kQpVariants[k].solve(dS, wa, tk, B, ny, q, x, y, dq, dx, slack, status, stream);
+}
+
+hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                          const double* q, const double* x, const double* y, double* Hd, double* A, double* lb,
+                          double* ub, hipStream_t stream)
+{
+    if (k < 0 || k >= kNumQpVariants) return hipErrorInvalidValue;
+    return kQpVariants[k].data(dS, wa, tk, B, ny, q, x, y, Hd, A, lb, ub, stream);
+}
+
+}  // namespace clik

@@ -1,0 +1,143 @@
+"""GPU parity of the ReactiveQPController path: HIP kernel (through the C ABI)
+vs the CPU oracle, plus solver-independent KKT optimality of every answer."""
+import os
+
+import numpy as np
+import pytest
+
+import casclik_amd as cc
+from casclik_amd import skills
+from casclik_amd import sym as cs
+from tolerances import QP_RTOL, KKT_TOL
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clik_golden.npz")
+
+
+def _rel(a, ref):
+    return np.abs(a - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+
+
+def _controller(spec, **kw):
+    c = cc.ReactiveQPController(skill_spec=spec, **kw)
+    c.setup_problem_functions()
+    c.setup_solver()
+    return c
+
+
+def test_qp_data_matches_oracle(iiwa_fk):
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 70, seed=1)
+    Hd, A, lb, ub = ctrl.qp_data_batch(0.0, Q, input_var=Y)
+    rH, rA, rlb, rub = clik_oracle.qp_data_batch(spec, 0.0, Q, Y=Y)
+    assert np.abs(Hd - rH).max() < 1e-15
+    assert np.abs(A - rA).max() < 1e-12
+    assert np.abs(lb - rlb).max() < 1e-11 and np.abs(ub - rub).max() < 1e-11
+
+
+@pytest.mark.parametrize("dist", ["interior", "mixed"])
+def test_qp_parity_and_kkt(iiwa_fk, dist):
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    B = 200
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=2, distribution=dist)
+    dq, dx, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+    assert dx is None and (status == 0).all()
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y)
+    assert (rstatus == 0).all()
+    assert _rel(dq, rdq).max() < QP_RTOL
+    assert _rel(slack, rslack).max() < QP_RTOL
+    hd, A, lb, ub = clik_oracle.qp_data_batch(spec, 0.0, Q, Y=Y)
+    for b in range(B):
+        prim, stat, sign = clik_oracle.kkt_residuals(hd[b], A[b], lb[b], ub[b], np.concatenate([dq[b], slack[b]]))
+        assert prim < KKT_TOL and stat < KKT_TOL and sign < KKT_TOL
+
+
+def test_qp_golden(iiwa_fk):
+    g = np.load(GOLDEN)
+    ctrl = _controller(skills.qp_skill(iiwa_fk))
+    dq, _, slack, status = ctrl.solve_batch(0.0, g["iiwa_qp_Q"], input_var=g["iiwa_qp_Y"])
+    assert (status == 0).all()
+    assert _rel(dq, g["iiwa_qp_dq"]).max() < QP_RTOL and _rel(slack, g["iiwa_qp_slack"]).max() < QP_RTOL
+
+
+def test_qp_moe_style_skill_ur5(ur5_fk):
+    """Three 1-D hard box sets on the tool position + soft tracking equality with a
+    time trajectory + joint speed limits: the 'singular' skill of
+    ur5_moe2016_example2.ipynb cells 6-8 (12 rows, 9 variables)."""
+    from oracle import clik_oracle
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    omega = 0.1
+    path = cs.vertcat(0.5 * cs.sin(omega * t) * cs.sin(omega * t) + 0.2,
+                      0.5 * cs.cos(omega * t) + 0.25 * cs.sin(omega * t),
+                      0.5 * cs.sin(omega * t) * cs.cos(omega * t) + 0.1)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    p_home = fk["chain"].fk_numeric(home)[:3, 3]
+    box = [(c - 0.15, c + 0.15) for c in p_home]       # the notebook also starts inside its box
+    cons = [cc.SetConstraint("colav_%d" % i, p[i], set_min=lo, set_max=hi, priority=7 + i, gain=5e2)
+            for i, (lo, hi) in enumerate(box)]
+    cons.append(cc.EqualityConstraint("move_point", p - path, priority=10, constraint_type="soft", gain=0.15))
+    cons.append(cc.VelocitySetConstraint("speed", q, set_min=-np.full(6, np.pi / 5), set_max=np.full(6, np.pi / 5),
+                                         priority=0))
+    spec = cc.SkillSpecification("box_move", t, q, constraints=cons)
+    ctrl = _controller(spec)
+    rng = np.random.default_rng(5)
+    Q = home + rng.normal(scale=0.06, size=(96, 6))
+    for tval in (0.0, 12.5):
+        dq, _, slack, status = ctrl.solve_batch(tval, Q)
+        rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, tval, Q)
+        assert np.array_equal(status == 2, rstatus == 2)
+        ok = rstatus == 0
+        assert ok.sum() > 48
+        assert _rel(dq[ok], rdq[ok]).max() < QP_RTOL and _rel(slack[ok], rslack[ok]).max() < QP_RTOL
+
+
+def test_qp_infeasible_is_reported(iiwa_fk):
+    """Two contradicting hard rows: status 2 and NaN velocities; the single-
+    instance API raises like the reference's CasADi RuntimeError."""
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 7)
+    cons = [cc.VelocitySetConstraint("a", q[0], set_min=1.0, set_max=2.0, priority=0),
+            cc.VelocitySetConstraint("b", q[0], set_min=-2.0, set_max=-1.0, priority=1)]
+    spec = cc.SkillSpecification("bad", t, q, constraints=cons)
+    ctrl = _controller(spec)
+    dq, _, slack, status = ctrl.solve_batch(0.0, np.zeros((3, 7)))
+    assert (status == 2).all() and np.isnan(dq).all() and slack is None
+    with pytest.raises(RuntimeError, match="infeasible"):
+        ctrl.solve(0.0, np.zeros(7))
+
+
+def test_qp_single_solve_api(iiwa_fk):
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    ctrl.setup_initial_problem_solver()
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 3, seed=8)
+    virt0, slack0 = ctrl.solve_initial_problem(0.0, Q[0], input_var0=Y[0])
+    assert virt0 is None and slack0.toarray().shape == (6, 1)
+    for b in range(3):
+        rob, virt, slack = ctrl.solve(0.0, Q[b], input_var=Y[b], warmstart_slack_var=slack0)
+        assert virt is None
+        rdq, _, rslack, _ = clik_oracle.qp_solve_batch(spec, 0.0, Q[b:b + 1], Y=Y[b:b + 1])
+        assert _rel(rob.toarray().T, rdq).max() < QP_RTOL
+        assert _rel(slack.toarray().T, rslack).max() < QP_RTOL
+
+
+def test_qp_custom_weights(iiwa_fk):
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    wr = np.linspace(0.5, 2.0, 7)
+    ws = np.linspace(1.0, 3.0, 6)
+    ctrl = _controller(spec, robot_var_weights=list(wr), slack_var_weights=list(ws))
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 64, seed=9)
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+    w = clik_oracle.qp_weights(spec, wr, None, ws)
+    rdq, _, rslack, _ = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y, weights=w)
+    assert (status == 0).all()
+    assert _rel(dq, rdq).max() < QP_RTOL and _rel(slack, rslack).max() < QP_RTOL
