@@ -229,6 +229,39 @@ class ReactiveQPController(BaseController):
                     None if status is None else status.cpu().numpy())
         return dQ, dX, SL, status
 
+    def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None):
+        """Pre-bind device tensors and return ``tick(time_var=0.0)``: one kernel
+        launch per call (lean path for control loops, graph capture, benchmarks)."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, _ = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        X = Y = None
+        if d.n_x > 0:
+            X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+        if d.n_y > 0:
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        dQ = out if out is not None else torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
+        SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        fn, handle, lib = self._lib.clik_qp_solve_batch, self._handle, self._lib
+        args = (ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(SL), ptr(status))
+        static_tt = _capi.tterms_arg(np.zeros(0)) if d.n_tslots == 0 else None
+
+        def tick(time_var=0.0, stream_handle=None):
+            tt, ttp = static_tt if static_tt is not None else _capi.tterms_arg(d.time_terms(time_var))
+            sh = stream_handle if stream_handle is not None else current_stream(dev)
+            rc = fn(handle, B, ttp, *args, sh)
+            if rc != 0:
+                _capi.check(lib, rc)
+
+        tick.tensors = (Q, X, Y, dQ, dX, SL, status)
+        tick.out, tick.slack, tick.status = dQ, SL, status
+        return tick
+
     def qp_data_batch(self, time_var, robot_var, virtual_var=None, input_var=None):
         """H diagonal, A, lbA, ubA per instance - what the reference's
         H_func/A_func/Blb_func/Bub_func return (reactive_qp.py:483-486)."""
