@@ -94,34 +94,122 @@ __device__ __forceinline__ int qp_rows(const DevSkill* __restrict__ S, const Tic
     return row;
 }
 
+// ---- small LDL^T with a compile-time or run-time size -------------------------------
+template <int NC, bool EXACT>
+__device__ __forceinline__ void qp_ldl_factor(double (&A)[NC * (NC + 1) / 2], double (&rd)[NC], const int r)
+{
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (EXACT || k < r) {
+            double t[NC];
+            double d = A[tri(k, k)];
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                t[j] = A[tri(k, j)] * A[tri(j, j)];
+                d = fma(-A[tri(k, j)], t[j], d);
+            }
+            A[tri(k, k)] = d;
+            const double inv = recip(d);
+            rd[k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < NC; ++i) {
+                if (EXACT || i < r) {
+                    double s = A[tri(i, k)];
+#pragma unroll
+                    for (int j = 0; j < k; ++j) s = fma(-A[tri(i, j)], t[j], s);
+                    A[tri(i, k)] = s * inv;
+                }
+            }
+        }
+    }
+}
+
+template <int NC, bool EXACT>
+__device__ __forceinline__ void qp_ldl_solve(const double (&A)[NC * (NC + 1) / 2], const double (&rd)[NC],
+                                             double (&x)[NC], const int r)
+{
+#pragma unroll
+    for (int i = 1; i < NC; ++i)
+        if (EXACT || i < r) {
+#pragma unroll
+            for (int j = 0; j < i; ++j) x[i] = fma(-A[tri(i, j)], x[j], x[i]);
+        }
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+        if (EXACT || i < r) x[i] *= rd[i];
+#pragma unroll
+    for (int i = NC - 2; i >= 0; --i)
+        if (EXACT || i < r) {
+#pragma unroll
+            for (int j = i + 1; j < NC; ++j)
+                if (EXACT || j < r) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
+        }
+}
+
 // ---- dual active set in constraint space -------------------------------------------
-// Qs: packed lower triangle of Q per lane (slot tri(i,j)*WAVE + lane), lbs / ubs: bounds.
-// On return nu holds the signed multipliers of the optimum.  Returns the status
-// (0 optimal, 1 iteration cap, 2 infeasible).
-template <int NC>
-__device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs, const int lane,
-                                        const int nc, const int max_iter, const bool lane_valid,
-                                        double (&nu)[NC])
+// Qs: packed lower triangle of Q per lane (slot tri(i,j)*WAVE + lane), lbs / ubs: bounds,
+// softeq: rows that are soft equalities (their Schur block is SPD, so they all start
+// active: one solve instead of one iteration each).  On return nu holds the signed
+// multipliers of the optimum.  Returns the status (0 optimal, 1 iteration cap,
+// 2 infeasible).  EXACT: nc == NC at compile time (no size guards).
+template <int NC, bool EXACT>
+__device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs,
+                                        const uint32_t softeq, const int lane, const int nc_rt,
+                                        const int max_iter, const bool lane_valid, double (&nu)[NC])
 {
     constexpr int NT = NC * (NC + 1) / 2;
-    uint32_t W = 0u, up = 0u, eq = 0u;
-    double c[NC], lb[NC], ub[NC];
+    const int nc = EXACT ? NC : nc_rt;
+    // bounds stay in LDS (read once per iteration in the selection scan): keeping
+    // them in registers next to the 13x13 factor spills to scratch
+    uint32_t W = softeq, up = 0u, eq = 0u;
+    double c[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         nu[i] = 0.0;
         c[i] = 0.0;
-        lb[i] = (i < nc) ? lbs[i * WAVE + lane] : -1e300;
-        ub[i] = (i < nc) ? ubs[i * WAVE + lane] : 1e300;
-        if (i < nc && !(ub[i] - lb[i] > 0.0)) eq |= 1u << i;
+        if ((EXACT || i < nc) && !(ubs[i * WAVE + lane] - lbs[i * WAVE + lane] > 0.0)) eq |= 1u << i;
     }
     int status = 0;
     bool done = !lane_valid;
     bool need_p = true;
+    bool init = softeq != 0u;            // wave-uniform
     int p = 0;
     double sp = 1.0, bp = 0.0;
     for (int it = 0; it < max_iter; ++it) {
         if (__ballot(!done) == 0ull) break;
-        // (1) pick the next constraint to enforce: unsatisfied equalities first,
+        // (1) one pass over Q:  c = Q nu  and the masked Schur matrix  D Q_WW D.
+        //     Masks are applied arithmetically (a_i = +-1 for active rows, 0 otherwise):
+        //     per-lane bit tests as control flow would serialise the wave.
+        double L[NT], rd[NC], r[NC], rhs[NC], a[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            c[i] = 0.0;
+            const double wi = (double)((W >> i) & 1u);
+            a[i] = wi - 2.0 * wi * (double)((up >> i) & 1u);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double q = (EXACT || i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
+                c[i] = fma(q, nu[j], c[i]);
+                if (j != i) c[j] = fma(q, nu[i], c[j]);
+                L[tri(i, j)] = (a[i] * a[j]) * q;
+            }
+            L[tri(i, i)] += 1.0 - a[i] * a[i];          // identity on inactive rows
+        }
+        if (init) {
+            // block start: all soft equalities active at once, nu_E = Q_EE^-1 b_E
+            qp_ldl_factor<NC, EXACT>(L, rd, nc);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) r[i] = ((W >> i) & 1u) ? lbs[i * WAVE + lane] : 0.0;
+            qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) nu[i] = ((W >> i) & 1u) ? r[i] : 0.0;
+            init = false;
+            continue;
+        }
+        // (2) pick the next constraint to enforce: unsatisfied equalities first,
         //     then the most violated inequality
         if (need_p && !done) {
             double best = 1e-11;
@@ -129,15 +217,17 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             bool pick_up = false;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                if (i < nc && !((W >> i) & 1u)) {
-                    const double scale = fmax(1.0, fmax(fabs(lb[i]), fabs(ub[i])));
-                    const double vlo = (lb[i] - c[i]) / scale, vhi = (c[i] - ub[i]) / scale;
+                if ((EXACT || i < nc) && !((W >> i) & 1u)) {
+                    const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
+                    const double iscale = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+                    const double vlo = (lbi - c[i]) * iscale, vhi = (c[i] - ubi) * iscale;
                     double v = fmax(vlo, vhi);
                     if (((eq >> i) & 1u) && v > 1e-11) v += 1e30;       // equalities take precedence
                     if (v > best) {
                         best = v;
                         pick = i;
                         pick_up = vhi > vlo;
+                        bp = pick_up ? -ubi : lbi;
                     }
                 }
             }
@@ -146,58 +236,40 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             } else {
                 p = pick;
                 sp = pick_up ? -1.0 : 1.0;
-                double b = 0.0;
-#pragma unroll
-                for (int i = 0; i < NC; ++i)
-                    if (i == p) b = pick_up ? -ub[i] : lb[i];
-                bp = b;
             }
         }
         if (__ballot(!done) == 0ull) break;
-        // (2) step direction:  r = S_W^-1 (D Q_Wp sp),   zn = n_p' H^-1 (n_p - N_W r)
-        double L[NT], rd[NC], r[NC], rhs[NC];
+        // (3) step direction:  r = S_W^-1 (D Q_Wp sp),   zn = n_p' H^-1 (n_p - N_W r)
         double qpp = 0.0, cp = 0.0;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const bool ai = (W >> i) & 1u;
-            const double si = ((up >> i) & 1u) ? -1.0 : 1.0;
             // column p of Q (dynamic per lane): packed index of (max(i,p), min(i,p))
             const int hi_ = i > p ? i : p, lo_ = i > p ? p : i;
-            const double qip = (i < nc) ? Qs[(hi_ * (hi_ + 1) / 2 + lo_) * WAVE + lane] : 0.0;
-            rhs[i] = ai ? si * sp * qip : 0.0;
-            if (i == p) {
-                qpp = qip;
-                cp = c[i];
-            }
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                const bool aj = (W >> j) & 1u;
-                const double q = (i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
-                const bool flip = ((up >> i) ^ (up >> j)) & 1u;
-                L[tri(i, j)] = (ai && aj) ? (flip ? -q : q) : (i == j ? 1.0 : 0.0);
-            }
+            const double qip = (EXACT || i < nc) ? Qs[(hi_ * (hi_ + 1) / 2 + lo_) * WAVE + lane] : 0.0;
+            rhs[i] = (a[i] * sp) * qip;
+            const double isp = (i == p) ? 1.0 : 0.0;
+            qpp = fma(isp, qip, qpp);
+            cp = fma(isp, c[i], cp);
         }
-        ldl_factor<NC>(L, rd, nc);
+        qp_ldl_factor<NC, EXACT>(L, rd, nc);
 #pragma unroll
         for (int i = 0; i < NC; ++i) r[i] = rhs[i];
-        ldl_solve<NC>(L, rd, r, nc);
+        qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
         double zn = qpp;
 #pragma unroll
         for (int i = 0; i < NC; ++i) zn = fma(-rhs[i], r[i], zn);
-        // (3) step lengths
+        // (4) step lengths
         double t1 = 1e300;
         int l = -1;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const bool ai = (W >> i) & 1u;
-            if (ai && !((eq >> i) & 1u) && r[i] > 1e-14) {
-                const double mu_i = (((up >> i) & 1u) ? -nu[i] : nu[i]);
-                const double cand = fmax(mu_i, 0.0) / r[i];
-                if (cand < t1) {
-                    t1 = cand;
-                    l = i;
-                }
-            }
+            // candidate only for active inequality rows with r_i > 0 (a_i = 0 on inactive rows)
+            const bool cand_ok = (a[i] != 0.0) && !((eq >> i) & 1u) && r[i] > 1e-14;
+            const double mu_i = a[i] * nu[i];
+            const double cand = cand_ok ? fmax(mu_i, 0.0) / r[i] : 1e300;
+            const bool better = cand < t1;
+            t1 = better ? cand : t1;
+            l = better ? i : l;
         }
         const double gap = bp - sp * cp;
         const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
@@ -210,10 +282,8 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             } else {
 #pragma unroll
                 for (int i = 0; i < NC; ++i) {
-                    const bool ai = (W >> i) & 1u;
-                    const double si = ((up >> i) & 1u) ? -1.0 : 1.0;
-                    if (ai) nu[i] = fma(-t * si, r[i], nu[i]);
-                    if (i == p) nu[i] = fma(t, sp, nu[i]);
+                    nu[i] = fma(-t * a[i], r[i], nu[i]);
+                    nu[i] = fma((i == p) ? t : 0.0, sp, nu[i]);
                 }
                 if (t2 <= t1) {
                     W |= 1u << p;
@@ -221,31 +291,19 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                     need_p = true;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NC; ++i)
-                        if (i == l) nu[i] = 0.0;
+                    for (int i = 0; i < NC; ++i) nu[i] = (i == l) ? 0.0 : nu[i];
                     W &= ~(1u << l);
                     up &= ~(1u << l);
                     need_p = false;
                 }
             }
         }
-        // (4) c = Q nu
-#pragma unroll
-        for (int i = 0; i < NC; ++i) c[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NC; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                const double q = (i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
-                c[i] = fma(q, nu[j], c[i]);
-                if (j != i) c[j] = fma(q, nu[i], c[j]);
-            }
     }
     if (!done) status = 1;
     return status;
 }
 
-template <int N, int NC>
+template <int N, int NC, bool EXACT>
 __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
     const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
     const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
@@ -308,8 +366,20 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
         }
     }
 
+    // soft equality rows (wave-uniform): start active
+    uint32_t softeq = 0u;
+    {
+        int row = 0;
+        for (int ti = 0; ti < S->d.n_tasks; ++ti) {
+            const clik_task& t = S->d.tasks[ti];
+            const bool se = t.soft != 0 && (t.cls == CLIK_CLS_EQ || t.cls == CLIK_CLS_VELEQ);
+            for (int i = 0; i < t.m; ++i)
+                if (se) softeq |= 1u << (row + i);
+            row += t.m;
+        }
+    }
     double nu[NC];
-    const int status = gi_solve<NC>(Qs, lbs, ubs, lane, nc, S->qo.max_iter, valid, nu);
+    const int status = gi_solve<NC, EXACT>(Qs, lbs, ubs, softeq, lane, nc, S->qo.max_iter, valid, nu);
 
     // v = H^-1 A' nu
     double u[N];
@@ -412,14 +482,14 @@ __global__ __launch_bounds__(WAVE) void qp_data_kernel(
 
 // ---- host side -----------------------------------------------------------------------
 struct QpVariant {
-    int N, NC;
+    int N, NC, exact;
     hipError_t (*solve)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
                         const double*, const double*, double*, double*, double*, int32_t*, hipStream_t);
     hipError_t (*data)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
                        const double*, const double*, double*, double*, double*, double*, hipStream_t);
 };
 
-template <int N, int NC>
+template <int N, int NC, bool EXACT>
 static hipError_t qp_solve_launch(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                                   const double* q, const double* x, const double* y, double* dq, double* dx,
                                   double* slack, int32_t* status, hipStream_t stream)
@@ -427,11 +497,11 @@ static hipError_t qp_solve_launch(const DevSkill* dS, const WarmArgs& wa, const 
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     const size_t shmem = (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
     if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)qp_solve_kernel<N, NC>,
+        hipError_t e = hipFuncSetAttribute((const void*)qp_solve_kernel<N, NC, EXACT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((qp_solve_kernel<N, NC>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y, dq,
+    hipLaunchKernelGGL((qp_solve_kernel<N, NC, EXACT>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y, dq,
                        dx, slack, status);
     return hipGetLastError();
 }
@@ -453,11 +523,14 @@ static hipError_t qp_data_launch(const DevSkill* dS, const WarmArgs& wa, const T
     return hipGetLastError();
 }
 
-#define CLIK_QP_VARIANT(N, NC) {N, NC, &qp_solve_launch<N, NC>, &qp_data_launch<N, NC>}
+// exact-size instantiations (no guards in the active-set loop) for the common
+// problem sizes, guarded ones for everything else up to 16 rows
+#define CLIK_QP_EXACT(N, NC) {N, NC, 1, &qp_solve_launch<N, NC, true>, &qp_data_launch<N, NC>}
+#define CLIK_QP_GUARD(N, NC) {N, NC, 0, &qp_solve_launch<N, NC, false>, &qp_data_launch<N, NC>}
 static const QpVariant kQpVariants[] = {
-    CLIK_QP_VARIANT(6, 8),  CLIK_QP_VARIANT(6, 12), CLIK_QP_VARIANT(6, 16),
-    CLIK_QP_VARIANT(7, 8),  CLIK_QP_VARIANT(7, 13), CLIK_QP_VARIANT(7, 16),
-    CLIK_QP_VARIANT(8, 8),  CLIK_QP_VARIANT(8, 16),
+    CLIK_QP_EXACT(7, 13), CLIK_QP_EXACT(6, 12), CLIK_QP_EXACT(7, 10), CLIK_QP_EXACT(6, 9),
+    CLIK_QP_GUARD(6, 8),  CLIK_QP_GUARD(6, 16), CLIK_QP_GUARD(7, 8),  CLIK_QP_GUARD(7, 16),
+    CLIK_QP_GUARD(8, 8),  CLIK_QP_GUARD(8, 16),
 };
 constexpr int kNumQpVariants = (int)(sizeof(kQpVariants) / sizeof(kQpVariants[0]));
 
@@ -466,9 +539,11 @@ int qp_pick_variant(int n, int nv, int nc)
 {
     (void)nv;
     int best = -1;
+    for (int k = 0; k < kNumQpVariants; ++k)
+        if (kQpVariants[k].exact && kQpVariants[k].N == n && kQpVariants[k].NC == nc) return k;
     for (int k = 0; k < kNumQpVariants; ++k) {
         const QpVariant& v = kQpVariants[k];
-        if (v.N < n || v.NC < nc) continue;
+        if (v.exact || v.N < n || v.NC < nc) continue;
         // task_eval works on N x N blocks: a constraint may have up to N rows
         if (best < 0 || v.N * 100 + v.NC < kQpVariants[best].N * 100 + kQpVariants[best].NC) best = k;
     }
