@@ -107,6 +107,17 @@ def cpu_baseline(workload, spec, opts, Q, Y, seconds):
                       "{1,8,32,64,all} threads" % (reps, sample, reps_rows)}
 
 
+def measured_traffic(workload, dist_name, batch):
+    """HBM bytes per launch from the PMC passes recorded under profiles/ (they
+    cannot be collected from inside this process); None when no profile matches."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            prof = json.load(f)
+        return prof["%s_%s_B%d" % (workload, dist_name, batch)]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,7 +213,8 @@ def main():
                 "ticks_per_s": K / wall, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.workload, args.dist, B),
                          "kernel_us": kern_us, "algorithmic_bytes_per_launch": alg_bytes,
                          "fp64_valu_frac_algorithmic": (ALG_FLOP_PER_STEP[args.workload] * B / (kern_us * 1e-6))
                                                        / (FP64_VALU_PEAK_TF * 1e12)},
