@@ -746,6 +746,106 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
+// Mode-parallel variant for small batches (fewer wavefronts than SIMDs): a
+// 128-thread block = two wavefronts on two SIMDs of one CU working on the SAME 64
+// instances; wave 0 evaluates mode 0 (set inactive), wave 1 speculatively
+// evaluates mode 1 (set active).  The mode scan of reference
+// pseudo_inverse.py:530-550 becomes a select: mode 0 if admissible, else mode 1
+// if admissible, else -1.  The tick costs max(mode 0, mode 1) instead of their
+// sum; the redundant FK of wave 1 runs on an otherwise idle SIMD.
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
+    const void* __restrict__ img_g, const TickArgs tk, const long long B, const int nq, const int nx, const int ny,
+    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ dx, int32_t* __restrict__ mode_out)
+{
+    extern __shared__ double lds[];
+    constexpr int N = SD.n;
+    static_assert(StaticLayout<SD>::n_sets == 1, "mode-parallel kernel is for shapes with one SetConstraint");
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
+    double* ys = zs + N * WAVE;
+    double* xs = ys + (SD.n_y > 0 ? SD.n_y : 0) * WAVE;      // exchange: v of mode 1 (N slots) + ok flag (1 slot)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    // the two waves split the prologue loads: wave 0 image + q, wave 1 image tail + y
+    {
+        constexpr int CH = StaticLayout<SD>::IMG_CHUNKS;
+        constexpr int H0 = (CH + 1) / 2;
+        const d2* src = (const d2*)img_g;
+        d2* dst = (d2*)lds;
+        if (wave == 0) {
+            d2 img[H0];
+#pragma unroll
+            for (int k = 0; k < H0; ++k) img[k] = src[k * WAVE + lane];
+            double qv[N];
+            stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+#pragma unroll
+            for (int k = 0; k < H0; ++k) dst[k * WAVE + lane] = img[k];
+            if (rows_valid < WAVE) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
+            }
+            stage_store<N>(qv, N, rows_valid, zs, lane);
+        } else {
+            d2 img[CH - H0 > 0 ? CH - H0 : 1];
+#pragma unroll
+            for (int k = H0; k < CH; ++k) img[k - H0] = src[k * WAVE + lane];
+            double yv[SD.n_y > 0 ? SD.n_y : 1];
+            if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+#pragma unroll
+            for (int k = H0; k < CH; ++k) dst[k * WAVE + lane] = img[k - H0];
+            if constexpr (SD.n_y > 0) {
+                if (rows_valid < WAVE) {
+#pragma unroll
+                    for (int k = 0; k < SD.n_y; ++k) ys[k * WAVE + lane] = 0.0;
+                }
+                stage_store<SD.n_y>(yv, SD.n_y, rows_valid, ys, lane);
+            }
+        }
+    }
+    __syncthreads();
+    const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
+    Kin<N> K;
+    if constexpr (SD.uses_fk != 0) {
+        forward_kinematics_s<SD>(S, z, K);
+        if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+    }
+    double v[N];
+    bool ok;
+    if (wave == 0) {
+        ok = pinv_mode_static<SD, 0u>(S, tk, K, z, ys, lane, v);
+    } else {
+        ok = pinv_mode_static<SD, 1u>(S, tk, K, z, ys, lane, v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) xs[j * WAVE + lane] = v[j];
+        xs[N * WAVE + lane] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int acc_mode = 0;
+        if (!ok) {
+            const bool ok1 = xs[N * WAVE + lane] != 0.0;
+            acc_mode = ok1 ? 1 : -1;
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = ok1 ? xs[j * WAVE + lane] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = v[j];
+        // (single wave from here on: LDS writes above are read back by the same wave)
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
+        if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
+    }
+}
+
 template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     const void* __restrict__ img_g, const double* __restrict__ tterms, const int n_ticks, const double dt,
@@ -808,6 +908,7 @@ struct LaunchArgs {
     const void*     dImg;      // static kernels: device copy of the skill image
     const WarmArgs* warm;
     int nq, nx, ny;
+    int mode_parallel;         // allow the speculative two-wave kernel for small batches
 };
 typedef hipError_t (*solve_fn)(const LaunchArgs&, const TickArgs&, long long, const double*, const double*,
                                const double*, double*, double*, int32_t*, hipStream_t);
@@ -844,12 +945,23 @@ inline size_t static_lds_bytes(int ny)
     return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n + ny) * WAVE) * sizeof(double);
 }
 
+// batches up to this many instances leave SIMDs idle (1024 SIMDs x 64 lanes / 2 waves per block)
+constexpr long long kModeParallelMaxBatch = 32768;
+
 template <const ShapeDesc& SD>
 inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
                                       const double* x, const double* y, double* dq, double* dx, int32_t* mode,
                                       hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if constexpr (StaticLayout<SD>::n_sets == 1) {
+        if (B <= kModeParallelMaxBatch && a.mode_parallel) {
+            const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)(SD.n + 1) * WAVE * sizeof(double);
+            hipLaunchKernelGGL((pinv_solve_static_mp_kernel<SD>), dim3(grid), dim3(2 * WAVE), shmem, stream,
+                               a.dImg, tk, B, a.nq, a.nx, a.ny, q, x, y, dq, dx, mode);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((pinv_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
                        a.dImg, tk, B, a.nq, a.nx, a.ny, q, x, y, dq, dx, mode);
     return hipGetLastError();

@@ -1,0 +1,138 @@
+"""GPU parity for the remaining branches of the reference's
+get_problem_expressions (pseudo_inverse.py:274-443) and controller options
+(:42-66), on skills that have no AOT shape (dynamic kernel)."""
+import numpy as np
+import pytest
+
+import casclik_amd as cc
+from casclik_amd import skills
+from casclik_amd import sym as cs
+from tolerances import PINV_RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, ref):
+    return np.abs(a - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+
+
+def _check(spec, options, Q, Y=None, t=0.0, tol=PINV_RTOL, min_modes=1):
+    from oracle import clik_oracle
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=None if options is None else dict(options))
+    ctrl.setup_problem_functions()
+    dq, _, mode = ctrl.solve_batch(t, Q, input_var=Y)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, options, t, Q, Y=Y)
+    assert np.array_equal(mode, rmode)
+    assert len(np.unique(mode)) >= min_modes
+    assert _rel(dq, ref).max() < tol, _rel(dq, ref).max()
+    return ctrl
+
+
+def _iiwa_syms(fk):
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 7)
+    return t, q, fk["T_fk"](q)
+
+
+def test_velocity_equality_first_and_not_first(iiwa_fk):
+    """First VelocityEqualityConstraint is processed once (:327-335); a later one
+    is projected (:430-443); the following EqualityConstraint is NOT 'first'."""
+    t, q, T = _iiwa_syms(iiwa_fk)
+    spin = cc.VelocityEqualityConstraint("spin", q[6], target=0.3, priority=0)
+    lift = cc.VelocityEqualityConstraint("lift", T[2, 3], target=-0.05, priority=2)
+    pos = cc.EqualityConstraint("xy", T[:2, 3] - np.array([0.3, 0.2]), gain=2.0, priority=1)
+    spec = cc.SkillSpecification("vel", t, q, constraints=[spin, pos, lift])
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 150, seed=1)
+    _check(spec, None, Q, tol=1e-8)
+
+
+def test_converge_final_set_to_max(iiwa_fk):
+    """converge_final_set_to_max (:337-379): the LAST constraint is a set; when
+    active it is driven to set_max through the null space of the others."""
+    t, q, T = _iiwa_syms(iiwa_fk)
+    pos = cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.4, 0.1, 0.6]), gain=5.0, priority=0)
+    height = cc.SetConstraint("elbow", q[3], set_min=-1.0, set_max=1.0, gain=2.0, priority=5)
+    spec = cc.SkillSpecification("conv", t, q, constraints=[pos, height])
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 200, seed=2, distribution="mixed")
+    _check(spec, {"converge_final_set_to_max": True}, Q, min_modes=2)
+    _check(spec, {"converge_final_set_to_max": False}, Q, min_modes=2)
+
+
+def test_converge_final_multidim_set(iiwa_fk):
+    t, q, T = _iiwa_syms(iiwa_fk)
+    pos = cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.4, 0.1, 0.6]), gain=5.0, priority=0)
+    # (q[6] does not move the tool position: a set on it would make the cone test a rounding tie)
+    box = cc.SetConstraint("wrist", q[3:6], set_min=-np.ones(3), set_max=np.ones(3), gain=1.5, priority=5)
+    spec = cc.SkillSpecification("convm", t, q, constraints=[pos, box])
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 200, seed=3, distribution="mixed")
+    _check(spec, {"converge_final_set_to_max": True, "multidim_sets": True}, Q, min_modes=2)
+
+
+def test_standard_pinv_single_task(iiwa_fk):
+    """pinv_method 'standard' (cs.pinv, :93-94) on a single full-rank task."""
+    spec = skills.position_skill(iiwa_fk)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 120, seed=4)
+    c = _check(spec, {"pinv_method": "standard"}, Q, Y[:, :3], tol=1e-8)
+    assert c.kernel_name == "dynamic"
+
+
+def test_feedforward_off_and_tiny_damping(ur5_fk):
+    """feedforward False drops d e/d t (:320-321); the dual-quaternion notebook
+    sets damping_factor 1e-26 (ur5_dual_quaternion_vs_transformation_matrix.ipynb:556)."""
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    path = cs.vertcat(0.3 * cs.sin(0.5 * t), 0.2 + 0.1 * t, 0.4 * cs.cos(0.5 * t))
+    spec = cc.SkillSpecification("track", t, q, constraints=[cc.EqualityConstraint("p", p - path, gain=0.5)])
+    Q, _ = skills.synthetic_inputs(fk, 100, seed=5)
+    for opts in ({"feedforward": False}, {"feedforward": True}, {"damping_factor": 1e-26}):
+        _check(spec, opts, Q, t=1.3, tol=1e-8)
+
+
+def test_matrix_gain_and_input_offset(ur5_fk):
+    """m x m gain matrices (constraints.py:46-49) and an additive input_var, the
+    expression of ur5_input_experiment.ipynb cell 11: T_fk(q)[:3,3] - T_des[:3,3] + y."""
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    y = cs.MX.sym("y", 3)
+    p = fk["T_fk"](q)[:3, 3]
+    K = np.array([[2.0, 0.1, 0.0], [0.1, 3.0, 0.2], [0.0, 0.2, 1.0]])
+    c = cc.EqualityConstraint("disturbed", p - np.array([0.4, 0.2, 0.3]) + y, gain=K, constraint_type="soft",
+                              priority=100)
+    spec = cc.SkillSpecification("inp", t, q, input_var=y, constraints=[c])
+    Q, _ = skills.synthetic_inputs(fk, 100, seed=6)
+    Y = np.random.default_rng(6).normal(scale=0.1, size=(100, 3))
+    _check(spec, None, Q, Y, tol=1e-8)
+
+
+def test_two_multidim_sets_four_modes(iiwa_fk):
+    """Two multidimensional sets -> modes 00,10,01,11 in the reference order."""
+    t, q, T = _iiwa_syms(iiwa_fk)
+    lo, hi = np.array(iiwa_fk["lower"]), np.array(iiwa_fk["upper"])
+    arm = cc.SetConstraint("arm", q[:3], set_min=0.5 * lo[:3], set_max=0.5 * hi[:3], priority=0)
+    wrist = cc.SetConstraint("wrist", q[3:6], set_min=0.5 * lo[3:6], set_max=0.5 * hi[3:6], priority=1)
+    pos = cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.4, 0.1, 0.6]), gain=5.0, priority=2)
+    spec = cc.SkillSpecification("two", t, q, constraints=[pos, wrist, arm])
+    rng = np.random.default_rng(7)
+    Q = rng.uniform(0.6 * lo, 0.6 * hi, size=(256, 7))
+    ctrl = _check(spec, {"multidim_sets": True}, Q, min_modes=3)
+    assert ctrl.n_modes == 4
+
+
+def test_velocity_set_is_ignored_by_pinv(iiwa_fk):
+    """VelocitySetConstraint has no branch in the pinv controller (:274-443)."""
+    t, q, T = _iiwa_syms(iiwa_fk)
+    pos = cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.4, 0.1, 0.6]), gain=5.0, priority=1)
+    speed = cc.VelocitySetConstraint("speed", q, set_min=-0.1 * np.ones(7), set_max=0.1 * np.ones(7), priority=0)
+    with_speed = cc.SkillSpecification("a", t, q, constraints=[pos, speed])
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 64, seed=8)
+    _check(with_speed, None, Q, tol=1e-8)
+
+
+def test_multidim_set_without_option_is_refused(iiwa_fk):
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec)          # multidim_sets defaults to False
+    with pytest.raises(NotImplementedError, match="multidim_sets"):
+        ctrl.setup_problem_functions()
