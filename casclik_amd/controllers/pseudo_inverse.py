@@ -132,6 +132,17 @@ class PseudoInverseController(BaseController):
         _capi.check(self._lib, rc)
         self._handle = handle
         self.kernel_name = self._lib.clik_pinv_kernel_name(handle).decode()
+        # no AOT shape for this skill: instantiate the static templates for it
+        # (the reference JIT-compiles at this point too, function_opts["jit"])
+        import os
+        want_jit = self.options["function_opts"].get("jit", True) and os.environ.get("CLIK_JIT", "1") != "0" \
+            and os.environ.get("CLIK_FORCE_DYNAMIC", "0") != "1"
+        if self.kernel_name == "dynamic" and want_jit:
+            from .. import jit
+            with torch.cuda.device(self._device):
+                name = jit.attach(self._lib, handle, cdesc, copts)
+            if name:
+                self.kernel_name = name
 
     def setup_solver(self):
         """Reference parity: re-runs the problem setup (pseudo_inverse.py:506-510)."""

@@ -54,12 +54,21 @@ using clik::DevSkill;
 using clik::TickArgs;
 using clik::WarmArgs;
 
+typedef hipError_t (*clik_jit_solve_fn)(const clik::LaunchArgs*, const TickArgs*, long long, const double*,
+                                        const double*, const double*, double*, double*, int32_t*, hipStream_t);
+typedef hipError_t (*clik_jit_rollout_fn)(const clik::LaunchArgs*, const double*, int, double, double, long long,
+                                          double*, const double*, double*, int32_t*, hipStream_t);
+
 struct clik_pinv {
     DevSkill  host;
     DevSkill* dev;
     clik::WarmArgs warm;
     void*     d_img;        // static kernels: device copy of the compact skill image
-    int       mode_parallel; // CLIK_MODE_PARALLEL=0 disables the speculative two-wave kernel
+    int       mode_parallel; // CLIK_MODE_PARALLEL=1 enables the speculative two-wave kernel
+    // shape-specialised kernel attached at run time (clik_pinv_attach_kernel)
+    clik_jit_solve_fn   jit_solve;
+    clik_jit_rollout_fn jit_rollout;
+    char      jit_name[64];
     int       kernel;       // index into the kernel table (static shape or dynamic)
     double*   d_tterms;     // rollout workspace
     size_t    d_tterms_cap;
@@ -304,7 +313,9 @@ static bool build_skill_image(const DevSkill& S, std::vector<char>& out)
     const size_t o_t = o_j + sizeof(clik_joint) * (size_t)(nj > 0 ? nj : 1);
     const size_t o_r = o_t + sizeof(clik_task) * (size_t)nt;
     const size_t o_c = o_r + sizeof(clik_row) * (size_t)nr;
-    const size_t o_tail = o_c + sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M * (size_t)nt;
+    const size_t o_g = o_c + sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M * (size_t)nt;
+    constexpr size_t GT = CLIK_MAX_DOF * (CLIK_MAX_DOF + 1) / 2;
+    const size_t o_tail = o_g + sizeof(double) * GT * (size_t)nt;
     const size_t total = o_tail + sizeof(double) * 5 + sizeof(int32_t) * 6;
     out.assign((total + 1023) / 1024 * 1024, 0);
     memcpy(&out[o_j], S.d.joints, sizeof(clik_joint) * (size_t)nj);
@@ -313,6 +324,19 @@ static bool build_skill_image(const DevSkill& S, std::vector<char>& out)
     for (int ti = 0; ti < nt; ++ti)
         memcpy(&out[o_c + sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M * (size_t)ti], S.cpinv[ti],
                sizeof(double) * CLIK_MAX_DOF * CLIK_MAX_M);
+    // J^T J of the constant-Jacobian tasks, packed lower triangle tri(a,b) = a(a+1)/2 + b
+    for (int ti = 0; ti < nt; ++ti) {
+        if (!S.task_const_j[ti]) continue;
+        const clik_task& t = S.d.tasks[ti];
+        double* g = reinterpret_cast<double*>(&out[o_g + sizeof(double) * GT * (size_t)ti]);
+        for (int a = 0; a < S.n; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double acc = 0.0;
+                for (int i = 0; i < t.m; ++i)
+                    acc += S.d.rows[t.out_row0[i]].a[a] * S.d.rows[t.out_row0[i]].a[b];
+                g[a * (a + 1) / 2 + b] = acc;
+            }
+    }
     // unused input_var terms must read index 0 with coefficient 0
     for (int r = 0; r < nr; ++r) {
         clik_row* row = reinterpret_cast<clik_row*>(&out[o_r + sizeof(clik_row) * (size_t)r]);
@@ -385,7 +409,25 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     o += "{";
     for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.ny_terms[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
     o += "}, " + std::to_string(h.n_y) + "}";
-    const bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
+    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
+    // the static plan handles the doubly processed first EqualityConstraint only when
+    // it owns a wide, state-dependent factor (clik_pinv_static.hpp)
+    for (unsigned act = 0; act < 2u && eligible; ++act) {
+        int r = 0;
+        for (int ti = 0; ti < h.n_tasks; ++ti) {
+            const int cls = h.cls[ti];
+            if (cls == CLIK_CLS_VELSET) continue;
+            if (cls == CLIK_CLS_SET && !(act & 1u)) continue;       // (at most one set: bit 0)
+            const bool conv = cls == CLIK_CLS_SET && ti == h.n_tasks - 1 && h.conv_last;
+            const bool contributes = cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ || conv;
+            if (contributes && r == 0 && cls == CLIK_CLS_EQ) {
+                const bool wide = h.standard ? (h.m[ti] < h.n) : (h.n >= h.m[ti]);
+                if (h.const_j[ti] || !wide) eligible = false;
+            }
+            r += h.m[ti];
+        }
+        if (S->n_sets == 0) break;
+    }
     delete S;
     if ((int)o.size() + 1 > cap) return fail(CLIK_EINVAL, "buffer too small");
     memcpy(buf, o.c_str(), o.size() + 1);
@@ -403,6 +445,9 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     if (rc) { delete h; return rc; }
     DevSkill& S = h->host;
     h->d_img = nullptr;
+    h->jit_solve = nullptr;
+    h->jit_rollout = nullptr;
+    h->jit_name[0] = 0;
     finish_pinv_shape(S, opts);
     if (opts->pinv_method != CLIK_PINV_DAMPED && opts->pinv_method != CLIK_PINV_STANDARD) {
         delete h;
@@ -496,6 +541,31 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     return CLIK_OK;
 }
 
+// Attach a shape-specialised kernel instantiated at run time for this handle's
+// skill (casclik_amd/jit.py compiles clik_pinv_kernels.hpp for the ShapeDesc that
+// clik_shape_describe printed).  Mirrors the reference's JIT at
+// setup_problem_functions (pseudo_inverse.py:476-483).
+extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn, const char* name)
+{
+    if (!h || !solve_fn || !rollout_fn) return fail(CLIK_EINVAL, "null argument");
+    if (!h->d_img) {
+        std::vector<char> img;
+        if (!build_skill_image(h->host, img))
+            return fail(CLIK_EUNSUPPORTED, "skill rows are not contiguous: no static kernel possible");
+        hipError_t e = hipMalloc(&h->d_img, img.size());
+        if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (h->d_img) hipFree(h->d_img);
+            h->d_img = nullptr;
+            return hipfail(e, "skill image upload");
+        }
+    }
+    h->jit_solve = (clik_jit_solve_fn)solve_fn;
+    h->jit_rollout = (clik_jit_rollout_fn)rollout_fn;
+    snprintf(h->jit_name, sizeof(h->jit_name), "%s", name ? name : "jit");
+    return CLIK_OK;
+}
+
 extern "C" int clik_pinv_destroy(clik_pinv* h)
 {
     if (!h) return CLIK_OK;
@@ -509,6 +579,7 @@ extern "C" int clik_pinv_destroy(clik_pinv* h)
 extern "C" int clik_pinv_n_modes(const clik_pinv* h) { return h ? h->host.n_modes : 0; }
 extern "C" const char* clik_pinv_kernel_name(const clik_pinv* h)
 {
+    if (h && h->jit_solve) return h->jit_name;
     return h ? clik::pinv_kernel_name(h->kernel) : "none";
 }
 
@@ -538,8 +609,10 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
     const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel};
-    hipError_t e = clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
-                                           (hipStream_t)stream);
+    hipError_t e = h->jit_solve
+                       ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
+                       : clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
+                                                 (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
     return CLIK_OK;
 }
@@ -570,8 +643,11 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
         if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
     }
     const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel};
-    hipError_t e = clik::pinv_launch_rollout(h->kernel, la, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y,
-                                             dq, mode, (hipStream_t)stream);
+    hipError_t e = h->jit_rollout
+                       ? h->jit_rollout(&la, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
+                                        (hipStream_t)stream)
+                       : clik::pinv_launch_rollout(h->kernel, la, h->d_tterms, n_ticks, dt, max_speed, (long long)B,
+                                                   q, y, dq, mode, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_rollout_kernel launch");
     return CLIK_OK;
 }

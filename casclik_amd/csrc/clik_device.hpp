@@ -71,6 +71,7 @@ struct SkillImage {
     clik_task  tasks[NT];
     clik_row   rows[NR];
     double     cpinv[NT][CLIK_MAX_DOF * CLIK_MAX_M];
+    double     cjtj[NT][CLIK_MAX_DOF * (CLIK_MAX_DOF + 1) / 2];   // J^T J of constant-Jacobian tasks (packed, stride n)
     double     lam;
     double     quat[4];
     int32_t    quat_yi[4];
@@ -261,9 +262,16 @@ __device__ __forceinline__ void ldl_solve(const double (&A)[N * (N + 1) / 2], co
 // kernel polynomials on |r| <= pi/4 gives <= 1 ulp in ~35 VALU instructions,
 // against ~150 for the generic library routine with its huge-argument path.
 // Arguments beyond 1e5 rad take the library routine.
-__device__ __attribute__((noinline)) void sincos_slow(const double x, double* sn, double* cs)
+// out-of-line library path for huge arguments; results are RETURNED (an out-pointer
+// would force the caller's sin/cos variables into scratch memory on the fast path too)
+struct SinCos {
+    double s, c;
+};
+__device__ __attribute__((noinline)) SinCos sincos_slow(const double x)
 {
-    sincos(x, sn, cs);
+    SinCos r;
+    sincos(x, &r.s, &r.c);
+    return r;
 }
 
 // 1/d to <= 1 ulp: hardware estimate + two Newton steps (5 instructions; the
@@ -279,7 +287,9 @@ __device__ __forceinline__ double recip(const double d)
 __device__ __forceinline__ void sincos_joint(const double x, double& sn, double& cs)
 {
     if (__builtin_expect(fabs(x) > 1.0e5, 0)) {
-        sincos_slow(x, &sn, &cs);
+        const SinCos r = sincos_slow(x);
+        sn = r.s;
+        cs = r.c;
         return;
     }
     const double k = rint(x * 0.6366197723675814);

@@ -654,10 +654,15 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 {
     constexpr int N = SD.n;
     static_assert(StaticLayout<SD>::n_sets <= 1, "static shapes support at most one SetConstraint");
-    Kin<N> K;
-    if constexpr (SD.uses_fk != 0) {
-        forward_kinematics_s<SD>(S, z, K);
-        if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+    // FK and the state-dependent task rows once per tick; the FK state dies here
+    TaskCache<SD> tc;
+    {
+        Kin<N> K;
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+        }
+        cache_task<SD, 0>(S, tk, K, z, ys, lane, tc);
     }
     bool done = !valid;
     acc_mode = -1;
@@ -665,7 +670,7 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     for (int j = 0; j < N; ++j) vout[j] = 0.0;
     {
         double v[N];
-        const bool ok = pinv_mode_static<SD, 0u>(S, tk, K, z, ys, lane, v);
+        const bool ok = pinv_mode_static<SD, 0u>(S, tk, tc, z, ys, lane, v);
         if (!done && ok) {
             done = true;
             acc_mode = 0;
@@ -676,7 +681,7 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     if constexpr (StaticLayout<SD>::n_sets == 1) {
         if (__ballot(!done) != 0ull) {
             double v[N];
-            const bool ok = pinv_mode_static<SD, 1u>(S, tk, K, z, ys, lane, v);
+            const bool ok = pinv_mode_static<SD, 1u>(S, tk, tc, z, ys, lane, v);
             if (!done && ok) {
                 done = true;
                 acc_mode = 1;
@@ -813,17 +818,21 @@ __global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
     double z[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
-    Kin<N> K;
-    if constexpr (SD.uses_fk != 0) {
-        forward_kinematics_s<SD>(S, z, K);
-        if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+    TaskCache<SD> tc;
+    {
+        Kin<N> K;
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+        }
+        cache_task<SD, 0>(S, tk, K, z, ys, lane, tc);
     }
     double v[N];
     bool ok;
     if (wave == 0) {
-        ok = pinv_mode_static<SD, 0u>(S, tk, K, z, ys, lane, v);
+        ok = pinv_mode_static<SD, 0u>(S, tk, tc, z, ys, lane, v);
     } else {
-        ok = pinv_mode_static<SD, 1u>(S, tk, K, z, ys, lane, v);
+        ok = pinv_mode_static<SD, 1u>(S, tk, tc, z, ys, lane, v);
 #pragma unroll
         for (int j = 0; j < N; ++j) xs[j * WAVE + lane] = v[j];
         xs[N * WAVE + lane] = ok ? 1.0 : 0.0;

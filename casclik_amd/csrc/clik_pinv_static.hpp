@@ -37,6 +37,12 @@ struct ModePlan {
     TaskPlan t[SHAPE_MAX_TASKS];
     int max_wide;       // largest explicit row count the stack reaches
     bool any_cone;
+    // explicit (wide-form) stack rows in push order: source task / row, and the slot
+    // of the per-lane copy (-1: constant-Jacobian row, read from the skill image)
+    int wide_task[CLIK_MAX_DOF];
+    int wide_local[CLIK_MAX_DOF];
+    int wide_store[CLIK_MAX_DOF];
+    int n_store;        // per-lane row slots needed
 };
 
 constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
@@ -100,6 +106,15 @@ constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
             const int r_new = r + p.push_times * m;
             if (!gram && r_new <= cap) {
                 if (r_new > mp.max_wide) mp.max_wide = r_new;
+                const int first_slot = mp.n_store;
+                for (int rep = 0; rep < p.push_times; ++rep)
+                    for (int i = 0; i < m; ++i) {
+                        const int idx = r + rep * m + i;
+                        mp.wide_task[idx] = ti;
+                        mp.wide_local[idx] = i;
+                        mp.wide_store[idx] = p.const_j ? -1 : first_slot + i;   // a repeated push shares the copy
+                    }
+                if (!p.const_j) mp.n_store += m;
             } else {
                 gram = true;
             }
@@ -487,13 +502,59 @@ __device__ __forceinline__ bool in_tangent_cone_s(const clik_task& t, const doub
     }
 }
 
+// ---- per-tick cache of the state-dependent task evaluations --------------------------
+// e, J, d e/d t of every constraint whose Jacobian depends on the state are
+// evaluated once per tick (they do not depend on the mode) so that the FK state
+// is dead before the mode scan starts.  Constant-Jacobian constraints are never
+// materialised: their coefficients are read from the skill image where used.
+constexpr int shape_cache_base(const ShapeDesc& sd, int ti)
+{
+    int r = 0;
+    for (int i = 0; i < ti; ++i)
+        if (!sd.const_j[i]) r += sd.m[i];
+    return r;
+}
+constexpr int shape_cache_rows(const ShapeDesc& sd) { return shape_cache_base(sd, sd.n_tasks); }
+
+template <const ShapeDesc& SD>
+struct TaskCache {
+    static constexpr int ROWS = shape_cache_rows(SD) > 0 ? shape_cache_rows(SD) : 1;
+    double e[ROWS];
+    double Jt[ROWS];
+    double J[ROWS][SD.n];
+};
+
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ void cache_task(const Img<SD>* __restrict__ S, const TickArgs& tk, const Kin<SD.n>& K,
+                                           const double (&z)[SD.n], const double* ys, const int lane,
+                                           TaskCache<SD>& tc)
+{
+    if constexpr (TI < SD.n_tasks) {
+        if constexpr (!SD.const_j[TI] && SD.cls[TI] != CLIK_CLS_VELSET) {
+            constexpr int N = SD.n;
+            constexpr int M = SD.m[TI];
+            constexpr int cb = shape_cache_base(SD, TI);
+            double e[M], J[M][N], Jt[M];
+            task_eval_s<SD, TI>(S, tk, K, z, ys, lane, e, J, Jt);
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                tc.e[cb + i] = e[i];
+                tc.Jt[cb + i] = Jt[i];
+#pragma unroll
+                for (int j = 0; j < N; ++j) tc.J[cb + i][j] = J[i][j];
+            }
+        }
+        cache_task<SD, TI + 1>(S, tk, K, z, ys, lane, tc);
+    }
+}
+
 // ---- per-mode state ------------------------------------------------------------------
-template <int N, int WIDE>
+template <int N, int STORE>
 struct StackS {
-    double   rows[WIDE > 0 ? WIDE : 1][N];   // explicit stacked rows (wide form)
-    uint32_t sbits;                          // activation of the explicit rows
-    double   G[N * (N + 1) / 2];             // lam I + Ja^T Ja       (gram form)
-    double   C[N * (N + 1) / 2];             // Ja^T diag(s) Ja       (gram form, when != G - lam I)
+    double   rows[STORE > 0 ? STORE : 1][N];  // per-lane copies of the state-dependent wide rows
+    uint32_t sbits;                           // activation of the explicit rows
+    double   G[N * (N + 1) / 2];              // lam I + Ja^T Ja       (gram form)
+    double   C[N * (N + 1) / 2];              // Ja^T diag(s) Ja       (gram form, when != G - lam I)
 };
 
 // mutable per-mode state: plain arrays only (no pointers / references) so that
@@ -501,21 +562,67 @@ struct StackS {
 template <const ShapeDesc& SD, unsigned ACT>
 struct ModeCtx {
     static constexpr int N = SD.n;
-    static constexpr int WIDE = Plan<SD, ACT>::mode.max_wide;
     double lam;
     double v[N];
-    StackS<N, WIDE> st;
+    StackS<N, Plan<SD, ACT>::mode.n_store> st;
     bool ok;
 };
 
 // read-only inputs of a mode evaluation, passed as separate parameters
-#define CLIK_MODE_IN const Img<SD>* __restrict__ S, const TickArgs& tk, const Kin<SD.n>& K, \
+#define CLIK_MODE_IN const Img<SD>* __restrict__ S, const TickArgs& tk, const TaskCache<SD>& tc, \
                      const double (&z)[SD.n], const double* ys, const int lane
-#define CLIK_MODE_ARGS S, tk, K, z, ys, lane
+#define CLIK_MODE_ARGS S, tk, tc, z, ys, lane
+
+// J[i][j] of task TI: cached per-lane value or image coefficient
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ double jac(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc, const int i,
+                                      const int j)
+{
+    if constexpr (SD.const_j[TI] != 0) return S->rows[shape_row_base(SD, TI) + i].a[j];
+    else return tc.J[shape_cache_base(SD, TI) + i][j];
+}
+
+// element j of explicit stack row R (compile-time R)
+template <const ShapeDesc& SD, unsigned ACT, int R>
+__device__ __forceinline__ double stack_row(const Img<SD>* __restrict__ S, const ModeCtx<SD, ACT>& c, const int j)
+{
+    constexpr ModePlan MP = Plan<SD, ACT>::mode;
+    if constexpr (MP.wide_store[R] >= 0) return c.st.rows[MP.wide_store[R]][j];
+    else return S->rows[shape_row_base(SD, MP.wide_task[R]) + MP.wide_local[R]].a[j];
+}
+
+// e (and d e/d t) of task TI without materialising a Jacobian
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ void task_values(const Img<SD>* __restrict__ S, const TickArgs& tk,
+                                            const TaskCache<SD>& tc, const double (&z)[SD.n], const double* ys,
+                                            const int lane, double (&e)[SD.m[TI]], double (&Jt)[SD.m[TI]])
+{
+    constexpr int N = SD.n;
+    constexpr int M = SD.m[TI];
+    if constexpr (SD.const_j[TI] != 0) {
+        constexpr int row0 = shape_row_base(SD, TI);
+        const int nts = S->n_tslots;
+        Kin<N> nokin;       // constant-Jacobian rows use no kinematic feature (flags exclude P/R/O)
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double g[N], dt;
+            e[i] = row_eval_s<N, SD.flags[TI] & (CLIK_ROW_HAS_Q | CLIK_ROW_HAS_Y), SD.ny_terms[TI]>(
+                S->rows[row0 + i], nts, tk, nokin, z, ys, lane, g, dt);
+            Jt[i] = dt;
+        }
+    } else {
+        constexpr int cb = shape_cache_base(SD, TI);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            e[i] = tc.e[cb + i];
+            Jt[i] = tc.Jt[cb + i];
+        }
+    }
+}
 
 // w <- w - pinv(stack) * rJa * w  for the stack state BEFORE task TI
 template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void project_s(ModeCtx<SD, ACT>& c, double (&w)[SD.n])
+__device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx<SD, ACT>& c, double (&w)[SD.n])
 {
     constexpr int N = SD.n;
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
@@ -544,86 +651,98 @@ __device__ __forceinline__ void project_s(ModeCtx<SD, ACT>& c, double (&w)[SD.n]
         constexpr int R = P.wide_before;
         static_assert(R > 0, "projection with an empty stack");
         double u[R], L[R * (R + 1) / 2], rd[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
+        static_for<0, R>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
             double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) s = fma(c.st.rows[i][j], w[j], s);
+            for (int j = 0; j < N; ++j) s = fma(stack_row<SD, ACT, i>(S, c, j), w[j], s);
             u[i] = ((c.st.sbits >> i) & 1u) ? s : 0.0;
-#pragma unroll
-            for (int k = 0; k <= i; ++k) {
+            static_for<0, i + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
                 double acc = (k == i) ? c.lam : 0.0;
 #pragma unroll
-                for (int j = 0; j < N; ++j) acc = fma(c.st.rows[i][j], c.st.rows[k][j], acc);
+                for (int j = 0; j < N; ++j)
+                    acc = fma(stack_row<SD, ACT, i>(S, c, j), stack_row<SD, ACT, k>(S, c, j), acc);
                 L[tri(i, k)] = acc;
-            }
-        }
+            });
+        });
         ldl_factor_s<R>(L, rd);
         ldl_solve_s<R>(L, rd, u);
+        static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
 #pragma unroll
-        for (int k = 0; k < R; ++k)
-#pragma unroll
-            for (int j = 0; j < N; ++j) w[j] = fma(-u[k], c.st.rows[k][j], w[j]);
+            for (int j = 0; j < N; ++j) w[j] = fma(-u[k], stack_row<SD, ACT, k>(S, c, j), w[j]);
+        });
     }
 }
 
-// stack the rows of task TI (`TIMES` times) following the plan
-template <const ShapeDesc& SD, unsigned ACT, int TI, int TIMES>
-__device__ __forceinline__ void push_s(ModeCtx<SD, ACT>& c, const double (&J)[SD.m[TI]][SD.n], const uint32_t srow,
-                                       const int r_now, const bool gram_now)
+// stack the rows of task TI (plan.push_times times) following the plan
+template <const ShapeDesc& SD, unsigned ACT, int TI>
+__device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc, ModeCtx<SD, ACT>& c,
+                                       const uint32_t srow)
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
-    constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
-    constexpr int NT = N * (N + 1) / 2;
-    (void)r_now; (void)gram_now;
+    constexpr ModePlan MP = Plan<SD, ACT>::mode;
+    constexpr TaskPlan P = MP.t[TI];
+    constexpr int TIMES = P.push_times;
     if constexpr (!P.gram_after) {
-        // stays wide: append at compile-time offsets
+        // stays wide: record the activation bits; state-dependent rows get a per-lane copy
         constexpr int r0 = P.r_after - TIMES * M;
-#pragma unroll
-        for (int rep = 0; rep < TIMES; ++rep)
+        if constexpr (!P.const_j) {
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int j = 0; j < N; ++j) c.st.rows[r0 + rep * M + i][j] = J[i][j];
-        uint32_t bits = srow & ((1u << M) - 1u);
+                for (int j = 0; j < N; ++j) c.st.rows[MP.wide_store[r0 + i]][j] = jac<SD, TI>(S, tc, i, j);
+        }
+        const uint32_t bits = srow & ((1u << M) - 1u);
 #pragma unroll
         for (int rep = 0; rep < TIMES; ++rep) c.st.sbits |= bits << (r0 + rep * M);
     } else {
         constexpr int r_prev = P.r_after - TIMES * M;       // rows before this push
-        constexpr bool was_gram = (TIMES == P.push_times) ? P.gram_before
-                                                          : (P.gram_before || false);
+        constexpr bool was_gram = P.gram_before;
         // one Gram entry at a time (no temporaries of matrix size): old rows
         // (when converting from the wide form), then the new rows
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
+        static_for<0, N>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = decltype(ac)::value;
+            static_for<0, a + 1>([&](auto bc) __attribute__((always_inline)) {
+                constexpr int b = decltype(bc)::value;
                 double g, cc = 0.0;
                 if constexpr (!was_gram) {
                     g = (a == b) ? c.lam : 0.0;
-#pragma unroll
-                    for (int k = 0; k < r_prev; ++k) {
-                        const double pr = c.st.rows[k][a] * c.st.rows[k][b];
+                    static_for<0, r_prev>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        const double pr = stack_row<SD, ACT, k>(S, c, a) * stack_row<SD, ACT, k>(S, c, b);
                         g += pr;
                         if constexpr (!P.c_is_g_before) cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
-                    }
+                    });
                 } else {
                     g = c.st.G[tri(a, b)];
                     if constexpr (!P.c_is_g_before) cc = c.st.C[tri(a, b)];
                 }
                 if constexpr (P.c_is_g_before && !P.c_is_g_after)
                     cc = (a == b) ? g - c.lam : g;      // C starts to differ from G - lam I here
-                double acc = 0.0, accs = 0.0;
+                double acc, accs = 0.0;
+                if constexpr (P.const_j) {
+                    acc = S->cjtj[TI][tri(a, b)];       // J^T J of a constant Jacobian: host-precomputed
+                    if constexpr (P.set_rows) {
 #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    const double pr = J[i][a] * J[i][b];
-                    acc += pr;
-                    if constexpr (P.set_rows) accs += ((srow >> i) & 1u) ? pr : 0.0;
+                        for (int i = 0; i < M; ++i)
+                            accs += ((srow >> i) & 1u) ? jac<SD, TI>(S, tc, i, a) * jac<SD, TI>(S, tc, i, b) : 0.0;
+                    }
+                } else {
+                    acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        const double pr = jac<SD, TI>(S, tc, i, a) * jac<SD, TI>(S, tc, i, b);
+                        acc += pr;
+                        if constexpr (P.set_rows) accs += ((srow >> i) & 1u) ? pr : 0.0;
+                    }
                 }
                 c.st.G[tri(a, b)] = fma((double)TIMES, acc, g);
                 if constexpr (!P.c_is_g_after) c.st.C[tri(a, b)] = fma((double)TIMES, P.set_rows ? accs : acc, cc);
-            }
+            });
+        });
     }
 }
 
@@ -635,8 +754,8 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (!P.skip) {
         const clik_task& t = S->tasks[TI];
-        double e[M], J[M][N], Jt[M];
-        task_eval_s<SD, TI>(S, tk, K, z, ys, lane, e, J, Jt);
+        double e[M], Jt[M];
+        task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
         uint32_t srow = 0xffffffffu;
         if constexpr (P.set_rows) {
             srow = 0u;
@@ -645,7 +764,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
         }
         if constexpr (!P.contributes) {
-            if constexpr (P.push_times > 0) push_s<SD, ACT, TI, P.push_times>(c, J, srow, 0, false);
+            if constexpr (P.push_times > 0) push_s<SD, ACT, TI>(S, tc, c, srow);
         } else {
             double des[M];
             if constexpr (SD.cls[TI] == CLIK_CLS_EQ) {
@@ -685,7 +804,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                     for (int k = 0; k <= i; ++k) {
                         double acc = (k == i) ? c.lam : 0.0;
 #pragma unroll
-                        for (int j = 0; j < N; ++j) acc = fma(J[i][j], J[k][j], acc);
+                        for (int j = 0; j < N; ++j) acc = fma(jac<SD, TI>(S, tc, i, j), jac<SD, TI>(S, tc, k, j), acc);
                         L[tri(i, k)] = acc;
                     }
                 ldl_factor_s<M>(L, rd);
@@ -694,7 +813,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 for (int j = 0; j < N; ++j) {
                     double s = 0.0;
 #pragma unroll
-                    for (int i = 0; i < M; ++i) s = fma(J[i][j], des[i], s);
+                    for (int i = 0; i < M; ++i) s = fma(jac<SD, TI>(S, tc, i, j), des[i], s);
                     w[j] = s;
                 }
             } else {
@@ -703,13 +822,13 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 for (int a = 0; a < N; ++a) {
                     double s = 0.0;
 #pragma unroll
-                    for (int i = 0; i < M; ++i) s = fma(J[i][a], des[i], s);
+                    for (int i = 0; i < M; ++i) s = fma(jac<SD, TI>(S, tc, i, a), des[i], s);
                     w[a] = s;
 #pragma unroll
                     for (int b = 0; b <= a; ++b) {
                         double acc = (a == b) ? c.lam : 0.0;
 #pragma unroll
-                        for (int i = 0; i < M; ++i) acc = fma(J[i][a], J[i][b], acc);
+                        for (int i = 0; i < M; ++i) acc = fma(jac<SD, TI>(S, tc, i, a), jac<SD, TI>(S, tc, i, b), acc);
                         Lg[tri(a, b)] = acc;
                     }
                 }
@@ -728,7 +847,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 for (int i = 0; i < M; ++i) {
                     double s = 0.0;
 #pragma unroll
-                    for (int j = 0; j < N; ++j) s = fma(J[i][j], w[j], s);
+                    for (int j = 0; j < N; ++j) s = fma(jac<SD, TI>(S, tc, i, j), w[j], s);
                     u[i] = s;
                 }
                 ldl_solve_s<M>(L, rd, u);
@@ -736,25 +855,26 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 for (int j = 0; j < N; ++j) {
                     double s = w[j];
 #pragma unroll
-                    for (int i = 0; i < M; ++i) s = fma(-J[i][j], u[i], s);
+                    for (int i = 0; i < M; ++i) s = fma(-jac<SD, TI>(S, tc, i, j), u[i], s);
                     c.v[j] += s;
                 }
-                if constexpr (P.push_times > 0) push_s<SD, ACT, TI, P.push_times>(c, J, 0xffffffffu, 0, false);
+                if constexpr (P.push_times > 0) push_s<SD, ACT, TI>(S, tc, c, 0xffffffffu);
             } else if constexpr (P.quirk) {
                 static_assert(!P.quirk || own_factor, "static shapes need a wide, state-dependent first EqualityConstraint");
             } else {
                 if constexpr (!P.first) {
-                    project_s<SD, ACT, TI>(c, w);
+                    project_s<SD, ACT, TI>(S, c, w);
 #pragma unroll
                     for (int j = 0; j < N; ++j) c.v[j] += w[j];
                 }
                 if constexpr (P.push_times > 0)
-                    push_s<SD, ACT, TI, P.push_times>(c, J, (P.conv && SD.multidim) ? srow : 0xffffffffu, 0, false);
+                    push_s<SD, ACT, TI>(S, tc, c, (P.conv && SD.multidim) ? srow : 0xffffffffu);
             }
         }
     }
 }
 
+// in-tangent-cone test of the inactive SetConstraint TI (pseudo_inverse.py:162-185, :222-252)
 template <const ShapeDesc& SD, unsigned ACT, int TI>
 __device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
 {
@@ -762,9 +882,47 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
     constexpr int M = SD.m[TI];
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (P.cone) {
-        double e[M], J[M][N], Jt[M];
-        task_eval_s<SD, TI>(S, tk, K, z, ys, lane, e, J, Jt);
-        c.ok = c.ok && in_tangent_cone_s<N, M>(S->tasks[TI], e, J, Jt, c.v);
+        const clik_task& t = S->tasks[TI];
+        double e[M], Jt[M], de[M];
+        task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double s = Jt[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) s = fma(jac<SD, TI>(S, tc, i, j), c.v[j], s);
+            de[i] = s;
+        }
+        bool in_tc;
+        if constexpr (M == 1) {
+            const double ev = e[0];
+            if (t.set_min[0] - ev < 1e-12) in_tc = (ev - t.set_max[0] < 1e-12) ? true : (de[0] < 0.0);
+            else in_tc = de[0] > 0.0;
+        } else {
+            bool inside = true, corner = true;
+            double od = 0.0, nde = 0.0, nout = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double le = e[i] - t.set_min[i];
+                const double ue = e[i] - t.set_max[i];
+                if (!(le >= 1e-12) || !(ue <= 1e-12)) inside = false;
+                const double sl = (le > 0.0) - (le < 0.0);
+                const double su = (ue > 0.0) - (ue < 0.0);
+                if (sl != su) corner = false;
+                const double out = 0.5 * (sl + su);
+                od = fma(out, de[i], od);
+                nde = fma(de[i], de[i], nde);
+                nout = fma(out, out, nout);
+            }
+            bool going_in;
+            if (corner) {
+                const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+                going_in = (od < 0.0) ? (fabs(od) / dists < 0.70710678118654757) : false;
+            } else {
+                going_in = od < 0.0;
+            }
+            in_tc = inside ? true : going_in;
+        }
+        c.ok = c.ok && in_tc;
     }
 }
 
@@ -790,7 +948,7 @@ __device__ __forceinline__ void cones_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
 // inactive sets are in their tangent cone
 template <const ShapeDesc& SD, unsigned ACT>
 __device__ __forceinline__ bool pinv_mode_static(const Img<SD>* __restrict__ S, const TickArgs& tk,
-                                                 const Kin<SD.n>& K, const double (&z)[SD.n],
+                                                 const TaskCache<SD>& tc, const double (&z)[SD.n],
                                                  const double* ys, int lane, double (&v)[SD.n])
 {
     constexpr int N = SD.n;

@@ -180,6 +180,11 @@ const char* clik_pinv_kernel_name(const clik_pinv* h);
  * this skill maps to into buf; returns 1 if the skill is eligible for an AOT
  * shape-specialised kernel, 0 if not, <0 on error (tools/gen_shapes.py).      */
 int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts, char* buf, int cap);
+/* attach a shape-specialised kernel that was instantiated at run time from the
+ * library's kernel templates for exactly this skill structure (the analogue of
+ * CasADi's JIT at setup_problem_functions, pseudo_inverse.py:476-483).  The
+ * function pointers come from a shared object built by casclik_amd/jit.py.     */
+int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn, const char* name);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)

@@ -73,7 +73,27 @@ def test_standard_pinv_single_task(iiwa_fk):
     spec = skills.position_skill(iiwa_fk)
     Q, Y = skills.synthetic_inputs(iiwa_fk, 120, seed=4)
     c = _check(spec, {"pinv_method": "standard"}, Q, Y[:, :3], tol=1e-8)
-    assert c.kernel_name == "dynamic"
+    assert c.kernel_name.startswith("jit_")      # no AOT shape: instantiated at setup
+
+
+def test_jit_and_dynamic_kernels_agree(iiwa_fk, monkeypatch):
+    """A skill without an AOT shape gets a kernel instantiated at setup
+    (casclik_amd/jit.py); with CLIK_JIT=0 the dynamic kernel serves it.  Same answers."""
+    t, q, T = _iiwa_syms(iiwa_fk)
+    pos = cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.4, 0.1, 0.6]), gain=5.0, priority=0)
+    elbow = cc.SetConstraint("elbow", q[3], set_min=-1.0, set_max=1.0, gain=2.0, priority=5)
+    spec = cc.SkillSpecification("conv", t, q, constraints=[pos, elbow])
+    opts = {"converge_final_set_to_max": True}
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 300, seed=12, distribution="mixed")
+    fast = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
+    fast.setup_problem_functions()
+    monkeypatch.setenv("CLIK_JIT", "0")
+    slow = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
+    slow.setup_problem_functions()
+    assert fast.kernel_name.startswith("jit_") and slow.kernel_name == "dynamic"
+    a, _, ma = fast.solve_batch(0.0, Q)
+    b, _, mb = slow.solve_batch(0.0, Q)
+    assert np.array_equal(ma, mb) and _rel(a, b).max() < PINV_RTOL
 
 
 def test_feedforward_off_and_tiny_damping(ur5_fk):
