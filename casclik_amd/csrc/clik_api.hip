@@ -217,6 +217,7 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
                 if (t.out_kind[i] == CLIK_OUT_AFFINE && d->rows[t.out_row0[i]].n_y > nyt)
                     nyt = d->rows[t.out_row0[i]].n_y;
             S->shape.ny_terms[ti] = nyt;
+            S->shape.has_t[ti] = (fl & CLIK_ROW_HAS_T) ? 1 : 0;
         }
         if (fl & CLIK_ROW_HAS_T) S->shape.all_affine = S->shape.all_affine;  // (time slots are run-time data)
     }
@@ -408,7 +409,10 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     arr(h.gain_matrix, clik::SHAPE_MAX_TASKS, nt);
     o += "{";
     for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.ny_terms[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
-    o += "}, " + std::to_string(h.n_y) + "}";
+    o += "}, " + std::to_string(h.n_y) + ", ";
+    o += "{";
+    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.has_t[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
+    o += "}}";
     bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
     // the static plan handles the doubly processed first EqualityConstraint only when
     // it owns a wide, state-dependent factor (clik_pinv_static.hpp)
@@ -494,8 +498,11 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         }
     }
     {
+        // CLIK_FORCE_DYNAMIC=1: dynamic kernel only; CLIK_NO_AOT=1: skip the AOT table
+        // (the Python layer may still attach a run-time instantiated kernel)
         const char* force = getenv("CLIK_FORCE_DYNAMIC");
-        h->kernel = clik::pinv_pick_kernel(S, (force && force[0] == '1') ? 0 : 1);
+        const char* noaot = getenv("CLIK_NO_AOT");
+        h->kernel = clik::pinv_pick_kernel(S, ((force && force[0] == '1') || (noaot && noaot[0] == '1')) ? 0 : 1);
     }
     if (h->kernel < 0) {
         delete h;

@@ -45,6 +45,7 @@ struct ShapeDesc {
     int gain_matrix[SHAPE_MAX_TASKS];
     int ny_terms[SHAPE_MAX_TASKS];  // max input_var terms of a row of the task
     int n_y;                        // input_var width
+    int has_t[SHAPE_MAX_TASKS];     // some row of the task carries a time slot
 };
 
 constexpr int shape_rows(const ShapeDesc& sd)

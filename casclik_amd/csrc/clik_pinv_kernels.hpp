@@ -626,6 +626,23 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_kernel(
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
+// ---- diagnostic time stamps (only in builds with -DCLIK_STAMPS, never in the shipped
+// library): s_memtime at phase boundaries of the static kernel, one record per block,
+// written to a buffer no other code reads.
+#ifdef CLIK_STAMPS
+__device__ unsigned long long g_clik_stamps[8 * 4096];
+#define CLIK_STAMP(k)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_clik_stamps[blockIdx.x * 8 + (k)] = t_;  \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define CLIK_STAMP(k)
+#endif
+
 // ---- shape-specialised kernels ---------------------------------------------------
 // LDS layout: [skill image | zs (N slots) | ys (ny slots)], slot = 64 doubles.
 template <const ShapeDesc& SD>
@@ -664,6 +681,7 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
         }
         cache_task<SD, 0>(S, tk, K, z, ys, lane, tc);
     }
+    CLIK_STAMP(2);
     bool done = !valid;
     acc_mode = -1;
 #pragma unroll
@@ -678,6 +696,7 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
             for (int j = 0; j < N; ++j) vout[j] = v[j];
         }
     }
+    CLIK_STAMP(3);
     if constexpr (StaticLayout<SD>::n_sets == 1) {
         if (__ballot(!done) != 0ull) {
             double v[N];
@@ -705,6 +724,7 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     const long long left = B - b0;
     const int rows_valid = left < WAVE ? (int)left : WAVE;
     const bool valid = lane < rows_valid;
+    CLIK_STAMP(0);
     double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
     double* ys = zs + N * WAVE;
     // constants, joint state and inputs travel together: every global load is
@@ -735,6 +755,7 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     stage_store<N>(qv, N, rows_valid, zs, lane);
     if constexpr (SD.n_y > 0) stage_store<SD.n_y>(yv, SD.n_y, rows_valid, ys, lane);
     __syncthreads();
+    CLIK_STAMP(1);
 
     double z[N];
 #pragma unroll
@@ -742,6 +763,7 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     double vout[N];
     int acc_mode;
     pinv_tick_static<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
+    CLIK_STAMP(4);
 
     __syncthreads();
 #pragma unroll
@@ -749,6 +771,7 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     __syncthreads();
     stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
+    CLIK_STAMP(5);
 }
 
 // Mode-parallel variant for small batches (fewer wavefronts than SIMDs): a

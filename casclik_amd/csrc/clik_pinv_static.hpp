@@ -31,6 +31,8 @@ struct TaskPlan {
     int  r_after;
     bool c_is_g_before; // all stacked rows so far have activation 1 (C = G - lam I)
     bool c_is_g_after;
+    int  wide_const_task; // >= 0: the explicit stack before the task is exactly the rows of this ONE
+                          // constant-Jacobian task (pushed once): pinv(Ja) is the host-precomputed cpinv
 };
 
 struct ModePlan {
@@ -78,6 +80,13 @@ constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
         p.r_before = r;
         p.gram_before = gram;
         p.wide_before = gram ? 0 : r;
+        p.wide_const_task = -1;
+        if (!gram && r > 0) {
+            const int t0 = mp.wide_task[0];
+            bool single = sd.const_j[t0] != 0 && r == sd.m[t0];
+            for (int k = 0; k < r && single; ++k) single = mp.wide_task[k] == t0 && mp.wide_local[k] == k;
+            if (single) p.wide_const_task = t0;
+        }
         p.c_is_g_before = c_is_g;
         p.const_j = sd.const_j[ti] != 0;
         if (cls == CLIK_CLS_VELSET) { p.skip = true; p.r_after = r; p.gram_after = gram; p.c_is_g_after = c_is_g; continue; }
@@ -144,6 +153,7 @@ using Img = SkillImage<SD.nj, SD.n_tasks, shape_rows(SD)>;
 // the per-joint axis / origin frames stay in registers.
 template <const ShapeDesc& SD, int J>
 __device__ __forceinline__ void fk_joint_s(const Img<SD>* __restrict__ S, const double (&z)[SD.n],
+                                           const double (&sns)[SD.n], const double (&css)[SD.n],
                                            double (&R)[9], double (&p)[3], double (&ax)[SD.n][3],
                                            double (&org)[SD.n][3])
 {
@@ -183,8 +193,7 @@ __device__ __forceinline__ void fk_joint_s(const Img<SD>* __restrict__ S, const 
             for (int i = 0; i < 3; ++i) org[qi][i] = p[i];
             const double ang = z[qi];
             if constexpr (type == CLIK_JOINT_REVOLUTE) {
-                double sn, cs;
-                sincos_joint(ang, sn, cs);
+                const double sn = sns[qi], cs = css[qi];
                 if constexpr (ak >= 0) {
                     // rotation about a local coordinate axis mixes the two other columns
                     const double s = asign * sn;
@@ -215,7 +224,7 @@ __device__ __forceinline__ void fk_joint_s(const Img<SD>* __restrict__ S, const 
                 for (int i = 0; i < 3; ++i) p[i] = fma(ax[qi][i], ang, p[i]);
             }
         }
-        fk_joint_s<SD, J + 1>(S, z, R, p, ax, org);
+        fk_joint_s<SD, J + 1>(S, z, sns, css, R, p, ax, org);
     }
 }
 
@@ -238,7 +247,16 @@ __device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__
     for (int j = 0; j < N; ++j)
 #pragma unroll
         for (int i = 0; i < 3; ++i) ax[j][i] = org[j][i] = 0.0;
-    fk_joint_s<SD, 0>(S, z, R, p, ax, org);
+    // all sines / cosines first: n independent polynomial chains the scheduler can
+    // interleave; inside the chain recursion they would serialise behind the
+    // frame products (measured: FK was latency-, not issue-bound)
+    double sns[N], css[N];
+    static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) sincos_joint(z[j], sns[j], css[j]);
+        else sns[j] = css[j] = 0.0;
+    });
+    fk_joint_s<SD, 0>(S, z, sns, css, R, p, ax, org);
 #pragma unroll
     for (int i = 0; i < 9; ++i) K.R[i] = R[i];
 #pragma unroll
@@ -304,7 +322,7 @@ __device__ __forceinline__ void orientation_feature_s(const Img<SD>* __restrict_
 
 // value, state gradient and time derivative of one affine row; feature flags
 // and the number of input_var terms are compile-time
-template <int N, int FLAGS, int NY>
+template <int N, int FLAGS, int NY, bool HAS_T>
 __device__ __forceinline__ double row_eval_s(const clik_row& r, const int n_tslots, const TickArgs& tk,
                                              const Kin<N>& K, const double (&z)[N], const double* ys,
                                              const int lane, double (&g)[N], double& dt)
@@ -366,7 +384,8 @@ __device__ __forceinline__ double row_eval_s(const clik_row& r, const int n_tslo
 #pragma unroll
         for (int k = 0; k < NY; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
     }
-    {
+    if constexpr (HAS_T) {
+        // (only tasks with time terms pay for this data-dependent branch)
         const int slot = r.t_slot;
         if (slot >= 0) {
             v += tk.tv[slot];
@@ -432,7 +451,8 @@ __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         double g[N], dt;
-        e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI]>(S->rows[row0 + i], nts, tk, K, z, ys, lane, g, dt);
+        e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI], SD.has_t[TI] != 0>(S->rows[row0 + i], nts, tk, K, z, ys,
+                                                                                lane, g, dt);
         Jt[i] = dt;
 #pragma unroll
         for (int j = 0; j < N; ++j) J[i][j] = g[j];
@@ -606,7 +626,7 @@ __device__ __forceinline__ void task_values(const Img<SD>* __restrict__ S, const
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             double g[N], dt;
-            e[i] = row_eval_s<N, SD.flags[TI] & (CLIK_ROW_HAS_Q | CLIK_ROW_HAS_Y), SD.ny_terms[TI]>(
+            e[i] = row_eval_s<N, SD.flags[TI] & (CLIK_ROW_HAS_Q | CLIK_ROW_HAS_Y), SD.ny_terms[TI], SD.has_t[TI] != 0>(
                 S->rows[row0 + i], nts, tk, nokin, z, ys, lane, g, dt);
             Jt[i] = dt;
         }
@@ -650,6 +670,25 @@ __device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx
     } else {
         constexpr int R = P.wide_before;
         static_assert(R > 0, "projection with an empty stack");
+        if constexpr (P.wide_const_task >= 0) {
+            // stack = rows of one constant-Jacobian task: pinv(Ja) was formed on the host,
+            //   w -= pinv(Ja) * (s o (Ja w))      (no Gram matrix, no factorisation)
+            constexpr int T0 = P.wide_const_task;
+            const double* Pm = S->cpinv[T0];
+            double u[R];
+            static_for<0, R>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                double sacc = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) sacc = fma(stack_row<SD, ACT, i>(S, c, j), w[j], sacc);
+                u[i] = ((c.st.sbits >> i) & 1u) ? sacc : 0.0;
+            });
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+#pragma unroll
+                for (int i = 0; i < R; ++i) w[j] = fma(-Pm[j * CLIK_MAX_M + i], u[i], w[j]);
+            return;
+        }
         double u[R], L[R * (R + 1) / 2], rd[R];
         static_for<0, R>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
@@ -710,12 +749,25 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
                 double g, cc = 0.0;
                 if constexpr (!was_gram) {
                     g = (a == b) ? c.lam : 0.0;
-                    static_for<0, r_prev>([&](auto kc) __attribute__((always_inline)) {
-                        constexpr int k = decltype(kc)::value;
-                        const double pr = stack_row<SD, ACT, k>(S, c, a) * stack_row<SD, ACT, k>(S, c, b);
-                        g += pr;
-                        if constexpr (!P.c_is_g_before) cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
-                    });
+                    if constexpr (P.wide_const_task >= 0) {
+                        // the explicit rows are one constant-Jacobian task: its J^T J is host-precomputed;
+                        // only the activation-weighted sum needs the rows
+                        g += S->cjtj[P.wide_const_task][tri(a, b)];
+                        if constexpr (!P.c_is_g_before) {
+                            static_for<0, r_prev>([&](auto kc) __attribute__((always_inline)) {
+                                constexpr int k = decltype(kc)::value;
+                                const double pr = stack_row<SD, ACT, k>(S, c, a) * stack_row<SD, ACT, k>(S, c, b);
+                                cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
+                            });
+                        }
+                    } else {
+                        static_for<0, r_prev>([&](auto kc) __attribute__((always_inline)) {
+                            constexpr int k = decltype(kc)::value;
+                            const double pr = stack_row<SD, ACT, k>(S, c, a) * stack_row<SD, ACT, k>(S, c, b);
+                            g += pr;
+                            if constexpr (!P.c_is_g_before) cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
+                        });
+                    }
                 } else {
                     g = c.st.G[tri(a, b)];
                     if constexpr (!P.c_is_g_before) cc = c.st.C[tri(a, b)];
