@@ -909,9 +909,13 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     int acc_mode = -1;
 #pragma unroll
     for (int j = 0; j < N; ++j) vout[j] = 0.0;
+#pragma unroll 1
     for (int tick = 0; tick < n_ticks; ++tick) {
-        TickArgs tk;
-        for (int k = 0; k < 2 * nts; ++k) tk.tv[k] = tterms[(size_t)tick * 2 * nts + k];
+        // the skill image is loop invariant: without this fence its LDS reads are all hoisted out of the
+        // tick loop and the live constants spill (2.8 KB of scratch per lane)
+        asm volatile("" ::: "memory");
+        // time terms are read in place ([values | derivatives], 2*nts doubles per tick, never past them)
+        const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
         pinv_tick_static<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
 #pragma unroll
         for (int j = 0; j < N; ++j) {

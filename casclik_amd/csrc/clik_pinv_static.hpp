@@ -598,8 +598,15 @@ template <const ShapeDesc& SD, int TI>
 __device__ __forceinline__ double jac(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc, const int i,
                                       const int j)
 {
-    if constexpr (SD.const_j[TI] != 0) return S->rows[shape_row_base(SD, TI) + i].a[j];
-    else return tc.J[shape_cache_base(SD, TI) + i][j];
+    // the bases must be constant expressions here: evaluated at run time they turn every access into a
+    // dynamically indexed one, which pins the whole cache in scratch
+    if constexpr (SD.const_j[TI] != 0) {
+        constexpr int row0 = shape_row_base(SD, TI);
+        return S->rows[row0 + i].a[j];
+    } else {
+        constexpr int cb = shape_cache_base(SD, TI);
+        return tc.J[cb + i][j];
+    }
 }
 
 // element j of explicit stack row R (compile-time R)
@@ -607,8 +614,13 @@ template <const ShapeDesc& SD, unsigned ACT, int R>
 __device__ __forceinline__ double stack_row(const Img<SD>* __restrict__ S, const ModeCtx<SD, ACT>& c, const int j)
 {
     constexpr ModePlan MP = Plan<SD, ACT>::mode;
-    if constexpr (MP.wide_store[R] >= 0) return c.st.rows[MP.wide_store[R]][j];
-    else return S->rows[shape_row_base(SD, MP.wide_task[R]) + MP.wide_local[R]].a[j];
+    if constexpr (MP.wide_store[R] >= 0) {
+        constexpr int sr = MP.wide_store[R];
+        return c.st.rows[sr][j];
+    } else {
+        constexpr int gr = shape_row_base(SD, MP.wide_task[R]) + MP.wide_local[R];
+        return S->rows[gr].a[j];
+    }
 }
 
 // e (and d e/d t) of task TI without materialising a Jacobian
@@ -729,10 +741,12 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
         // stays wide: record the activation bits; state-dependent rows get a per-lane copy
         constexpr int r0 = P.r_after - TIMES * M;
         if constexpr (!P.const_j) {
+            static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int sr = MP.wide_store[r0 + i];
 #pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) c.st.rows[MP.wide_store[r0 + i]][j] = jac<SD, TI>(S, tc, i, j);
+                for (int j = 0; j < N; ++j) c.st.rows[sr][j] = jac<SD, TI>(S, tc, i, j);
+            });
         }
         const uint32_t bits = srow & ((1u << M) - 1u);
 #pragma unroll
