@@ -218,6 +218,22 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
                     nyt = d->rows[t.out_row0[i]].n_y;
             S->shape.ny_terms[ti] = nyt;
             S->shape.has_t[ti] = (fl & CLIK_ROW_HAS_T) ? 1 : 0;
+            // joint-space task: rows are distinct unit vectors (clik_device.hpp, ShapeDesc::ucol)
+            bool unit = S->task_const_j[ti] != 0 && t.m > 0 && t.m <= CLIK_MAX_M;
+            int cols[CLIK_MAX_M] = {0};
+            unsigned seen = 0;
+            for (int i = 0; i < t.m && unit; ++i) {
+                const clik_row& r = d->rows[t.out_row0[i]];
+                int col = -1;
+                for (int j = 0; j < n; ++j) {
+                    if (r.a[j] == 0.0) continue;
+                    if (r.a[j] != 1.0 || col >= 0) { unit = false; break; }
+                    col = j;
+                }
+                if (col < 0 || (seen >> col) & 1u) unit = false;
+                else { seen |= 1u << col; cols[i] = col + 1; }
+            }
+            for (int i = 0; i < CLIK_MAX_M; ++i) S->shape.ucol[ti][i] = (unit && i < t.m) ? cols[i] : 0;
         }
         if (fl & CLIK_ROW_HAS_T) S->shape.all_affine = S->shape.all_affine;  // (time slots are run-time data)
     }
@@ -412,6 +428,12 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     o += "}, " + std::to_string(h.n_y) + ", ";
     o += "{";
     for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.has_t[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
+    o += "}, {";
+    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) {
+        o += "{";
+        for (int k = 0; k < CLIK_MAX_M; ++k) { o += std::to_string(i < nt ? h.ucol[i][k] : 0); if (k + 1 < CLIK_MAX_M) o += ", "; }
+        o += (i + 1 < clik::SHAPE_MAX_TASKS) ? "}, " : "}";
+    }
     o += "}}";
     bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
     // the static plan handles the doubly processed first EqualityConstraint only when

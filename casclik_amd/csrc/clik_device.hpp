@@ -46,7 +46,20 @@ struct ShapeDesc {
     int ny_terms[SHAPE_MAX_TASKS];  // max input_var terms of a row of the task
     int n_y;                        // input_var width
     int has_t[SHAPE_MAX_TASKS];     // some row of the task carries a time slot
+    // joint-space tasks (joint limits, joint centering): every row of the constant Jacobian is a unit
+    // vector e_col with distinct columns.  ucol[ti][i] = col + 1 of row i, 0 when the task is not of
+    // that form (then all of its entries are 0).
+    int ucol[SHAPE_MAX_TASKS][CLIK_MAX_M];
 };
+
+constexpr bool shape_unit(const ShapeDesc& sd, int ti) { return sd.const_j[ti] != 0 && sd.m[ti] > 0 && sd.ucol[ti][0] > 0; }
+// row of unit task ti whose 1 sits in column col, or -1
+constexpr int shape_unit_row(const ShapeDesc& sd, int ti, int col)
+{
+    for (int i = 0; i < sd.m[ti]; ++i)
+        if (sd.ucol[ti][i] == col + 1) return i;
+    return -1;
+}
 
 constexpr int shape_rows(const ShapeDesc& sd)
 {

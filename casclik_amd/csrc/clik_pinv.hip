@@ -52,6 +52,9 @@ static bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
         if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i] ||
             a.gain_matrix[i] != b.gain_matrix[i] || a.ny_terms[i] != b.ny_terms[i] || a.has_t[i] != b.has_t[i])
             return false;
+    for (int i = 0; i < a.n_tasks; ++i)
+        for (int k = 0; k < CLIK_MAX_M; ++k)
+            if (a.ucol[i][k] != b.ucol[i][k]) return false;
     for (int j = 0; j < a.nj; ++j)
         if (a.jtype[j] != b.jtype[j] || a.jq[j] != b.jq[j] || a.jflags[j] != b.jflags[j]) return false;
     return true;

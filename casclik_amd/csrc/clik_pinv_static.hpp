@@ -631,7 +631,30 @@ __device__ __forceinline__ void task_values(const Img<SD>* __restrict__ S, const
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
-    if constexpr (SD.const_j[TI] != 0) {
+    if constexpr (shape_unit(SD, TI)) {
+        // joint-space rows: e_i = z[col_i] + c_i (+ input / time terms); the zero coefficients are never read
+        constexpr int row0 = shape_row_base(SD, TI);
+        const int nts = S->n_tslots;
+        static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int col = SD.ucol[TI][i] - 1;
+            const clik_row& r = S->rows[row0 + i];
+            double v = r.c + z[col], dt = 0.0;
+            if constexpr ((SD.flags[TI] & CLIK_ROW_HAS_Y) != 0) {
+#pragma unroll
+                for (int k = 0; k < SD.ny_terms[TI]; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
+            }
+            if constexpr (SD.has_t[TI] != 0) {
+                const int slot = r.t_slot;
+                if (slot >= 0) {
+                    v += tk.tv[slot];
+                    dt = tk.tv[nts + slot];
+                }
+            }
+            e[i] = v;
+            Jt[i] = dt;
+        });
+    } else if constexpr (SD.const_j[TI] != 0) {
         constexpr int row0 = shape_row_base(SD, TI);
         const int nts = S->n_tslots;
         Kin<N> nokin;       // constant-Jacobian rows use no kinematic feature (flags exclude P/R/O)
@@ -687,6 +710,16 @@ __device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx
             //   w -= pinv(Ja) * (s o (Ja w))      (no Gram matrix, no factorisation)
             constexpr int T0 = P.wide_const_task;
             const double* Pm = S->cpinv[T0];
+            if constexpr (shape_unit(SD, T0)) {
+                // joint-space stack: Ja w picks components, pinv(Ja) has one entry per row
+                static_for<0, R>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int col = SD.ucol[T0][i] - 1;
+                    const double u = ((c.st.sbits >> i) & 1u) ? w[col] : 0.0;
+                    w[col] = fma(-Pm[col * CLIK_MAX_M + i], u, w[col]);
+                });
+                return;
+            }
             double u[R];
             static_for<0, R>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
@@ -763,7 +796,14 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
                 double g, cc = 0.0;
                 if constexpr (!was_gram) {
                     g = (a == b) ? c.lam : 0.0;
-                    if constexpr (P.wide_const_task >= 0) {
+                    if constexpr (P.wide_const_task >= 0 && shape_unit(SD, P.wide_const_task)) {
+                        // joint-space rows: J^T J and J^T diag(s) J are diagonal 0/1 matrices
+                        constexpr int k = (a == b) ? shape_unit_row(SD, P.wide_const_task, a) : -1;
+                        if constexpr (k >= 0) {
+                            g += 1.0;
+                            if constexpr (!P.c_is_g_before) cc = ((c.st.sbits >> k) & 1u) ? 1.0 : 0.0;
+                        }
+                    } else if constexpr (P.wide_const_task >= 0) {
                         // the explicit rows are one constant-Jacobian task: its J^T J is host-precomputed;
                         // only the activation-weighted sum needs the rows
                         g += S->cjtj[P.wide_const_task][tri(a, b)];
@@ -789,7 +829,11 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
                 if constexpr (P.c_is_g_before && !P.c_is_g_after)
                     cc = (a == b) ? g - c.lam : g;      // C starts to differ from G - lam I here
                 double acc, accs = 0.0;
-                if constexpr (P.const_j) {
+                if constexpr (shape_unit(SD, TI)) {
+                    constexpr int k = (a == b) ? shape_unit_row(SD, TI, a) : -1;
+                    acc = (k >= 0) ? 1.0 : 0.0;
+                    if constexpr (P.set_rows && k >= 0) accs = ((srow >> k) & 1u) ? 1.0 : 0.0;
+                } else if constexpr (P.const_j) {
                     acc = S->cjtj[TI][tri(a, b)];       // J^T J of a constant Jacobian: host-precomputed
                     if constexpr (P.set_rows) {
 #pragma unroll
@@ -854,7 +898,16 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
             double w[N];
             constexpr bool own_factor = !P.const_j && P.wide_self;
             double L[own_factor ? M * (M + 1) / 2 : 1], rd[own_factor ? M : 1];
-            if constexpr (P.const_j) {
+            if constexpr (shape_unit(SD, TI)) {
+                const double* Pm = S->cpinv[TI];
+#pragma unroll
+                for (int j = 0; j < N; ++j) w[j] = 0.0;
+                static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int col = SD.ucol[TI][i] - 1;
+                    w[col] = Pm[col * CLIK_MAX_M + i] * des[i];
+                });
+            } else if constexpr (P.const_j) {
                 const double* Pm = S->cpinv[TI];
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
@@ -951,12 +1004,20 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
         const clik_task& t = S->tasks[TI];
         double e[M], Jt[M], de[M];
         task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
+        if constexpr (shape_unit(SD, TI)) {
+            static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int col = SD.ucol[TI][i] - 1;
+                de[i] = Jt[i] + c.v[col];
+            });
+        } else {
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            double s = Jt[i];
+            for (int i = 0; i < M; ++i) {
+                double s = Jt[i];
 #pragma unroll
-            for (int j = 0; j < N; ++j) s = fma(jac<SD, TI>(S, tc, i, j), c.v[j], s);
-            de[i] = s;
+                for (int j = 0; j < N; ++j) s = fma(jac<SD, TI>(S, tc, i, j), c.v[j], s);
+                de[i] = s;
+            }
         }
         bool in_tc;
         if constexpr (M == 1) {
