@@ -64,7 +64,7 @@ struct clik_pinv {
     DevSkill* dev;
     clik::WarmArgs warm;
     void*     d_img;        // static kernels: device copy of the compact skill image
-    int       mode_parallel; // CLIK_MODE_PARALLEL=1 enables the speculative two-wave kernel
+    int       mode_parallel; // speculative two-wave kernel for small batches (CLIK_MODE_PARALLEL=0 disables)
     // shape-specialised kernel attached at run time (clik_pinv_attach_kernel)
     clik_jit_solve_fn   jit_solve;
     clik_jit_rollout_fn jit_rollout;
@@ -558,11 +558,12 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         }
     }
     {
-        // opt-in: speculative two-wave evaluation of both modes pays only when most
-        // instances sit on a set boundary (measured: 17.5 -> 16.5 us "mixed", but
-        // 11.0 -> 16.4 us when mode 0 would have sufficed)
+        // Speculative two-wave evaluation of both modes (pinv_solve_static_mp_kernel) for
+        // batches that leave SIMDs idle: the tick costs max(mode 0, mode 1) instead of
+        // mode 0 [+ mode 1].  Measured on the config-3 stack at 16384 instances: 8.74 ->
+        // 7.76 us ("mixed") and 7.86 -> 7.64 us ("interior").  CLIK_MODE_PARALLEL=0 disables it.
         const char* mp = getenv("CLIK_MODE_PARALLEL");
-        h->mode_parallel = (mp && mp[0] == '1') ? 1 : 0;
+        h->mode_parallel = (mp && mp[0] == '0') ? 0 : 1;
     }
     h->d_tterms = nullptr;
     h->d_tterms_cap = 0;

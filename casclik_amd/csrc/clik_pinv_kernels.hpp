@@ -639,9 +639,41 @@ __device__ unsigned long long g_clik_stamps[8 * 4096];
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_clik_stamps[blockIdx.x * 8 + (k)] = t_;  \
         __builtin_amdgcn_sched_barrier(0);                                                    \
     } while (0)
+// stamp after everything in flight has landed (perturbs the schedule: shares only)
+#define CLIK_STAMP_DRAINED(k)                                                                 \
+    do {                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+        CLIK_STAMP(k);                                                                        \
+    } while (0)
 #else
 #define CLIK_STAMP(k)
+#define CLIK_STAMP_DRAINED(k)
 #endif
+
+// ---- row-major staging of the shape-specialised kernels --------------------------------
+// The wave's [64][W] block keeps its global (row-major) layout in LDS: the coalesced
+// chunk i of lane l lands at double i*64 + l (a straight copy, no index arithmetic),
+// and lane l then reads its own row at doubles l*W .. l*W+W-1.  For odd W the row
+// stride is an odd number of 8-byte words, so the 64-bit row reads are bank-conflict
+// free; even W costs a 2- to 8-way conflict on W reads, still far below the
+// divide-by-W address arithmetic of a transposing store.
+template <int W>
+__device__ __forceinline__ void rows_to_lds(const double (&v)[W], double* lds, const int lane)
+{
+#pragma unroll
+    for (int i = 0; i < W; ++i) lds[i * WAVE + lane] = v[i];
+}
+template <int W>
+__device__ __forceinline__ void rows_from_lds(double* __restrict__ g, const int rows_valid, const double* lds,
+                                              const int lane)
+{
+    const int total = rows_valid * W;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int k = i * WAVE + lane;
+        if (k < total) g[k] = lds[k];
+    }
+}
 
 // ---- shape-specialised kernels ---------------------------------------------------
 // LDS layout: [skill image | zs (N slots) | ys (ny slots)], slot = 64 doubles.
@@ -713,18 +745,21 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 
 template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
-    const void* __restrict__ img_g, const TickArgs tk, const long long B, const int nq, const int nx, const int ny,
-    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ dx, int32_t* __restrict__ mode_out)
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
     extern __shared__ double lds[];
+    CLIK_STAMP(0);
     constexpr int N = SD.n;
     const int lane = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * WAVE;
     const long long left = B - b0;
     const int rows_valid = left < WAVE ? (int)left : WAVE;
     const bool valid = lane < rows_valid;
-    CLIK_STAMP(0);
+#ifdef CLIK_STAMPS
+    if (rows_valid < 0) return;  // (never taken: makes the next stamp wait for the kernel arguments)
+#endif
+    CLIK_STAMP_DRAINED(6);      // kernel arguments have arrived
     double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
     double* ys = zs + N * WAVE;
     // constants, joint state and inputs travel together: every global load is
@@ -740,36 +775,33 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
     double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
     stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
     if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+    CLIK_STAMP_DRAINED(7);      // image, q and y are in registers
     {
         d2* dst = (d2*)lds;
 #pragma unroll
         for (int k = 0; k < StaticLayout<SD>::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
     }
     const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
-    if (rows_valid < WAVE) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-        for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
-        __syncthreads();
-    }
-    stage_store<N>(qv, N, rows_valid, zs, lane);
-    if constexpr (SD.n_y > 0) stage_store<SD.n_y>(yv, SD.n_y, rows_valid, ys, lane);
+    // (tail block: the clamped loads filled the rows past rows_valid with copies of
+    // the last element - finite values whose results are never stored)
+    rows_to_lds<N>(qv, zs, lane);
+    if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     __syncthreads();
     CLIK_STAMP(1);
 
     double z[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
+    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
     double vout[N];
     int acc_mode;
-    pinv_tick_static<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
+    pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
     CLIK_STAMP(4);
 
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = vout[j];
+    for (int j = 0; j < N; ++j) zs[lane * N + j] = vout[j];
     __syncthreads();
-    stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
+    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
     CLIK_STAMP(5);
 }
@@ -783,9 +815,8 @@ __global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
 // sum; the redundant FK of wave 1 runs on an otherwise idle SIMD.
 template <const ShapeDesc& SD>
 __global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
-    const void* __restrict__ img_g, const TickArgs tk, const long long B, const int nq, const int nx, const int ny,
-    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ dx, int32_t* __restrict__ mode_out)
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
     extern __shared__ double lds[];
     constexpr int N = SD.n;
@@ -814,11 +845,7 @@ __global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
             stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
 #pragma unroll
             for (int k = 0; k < H0; ++k) dst[k * WAVE + lane] = img[k];
-            if (rows_valid < WAVE) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-            }
-            stage_store<N>(qv, N, rows_valid, zs, lane);
+            rows_to_lds<N>(qv, zs, lane);
         } else {
             d2 img[CH - H0 > 0 ? CH - H0 : 1];
 #pragma unroll
@@ -827,35 +854,30 @@ __global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
             if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
 #pragma unroll
             for (int k = H0; k < CH; ++k) dst[k * WAVE + lane] = img[k - H0];
-            if constexpr (SD.n_y > 0) {
-                if (rows_valid < WAVE) {
-#pragma unroll
-                    for (int k = 0; k < SD.n_y; ++k) ys[k * WAVE + lane] = 0.0;
-                }
-                stage_store<SD.n_y>(yv, SD.n_y, rows_valid, ys, lane);
-            }
+            if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
         }
     }
     __syncthreads();
     const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
+    const double* ysl = ys + lane * SD.n_y;
     double z[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
+    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
     TaskCache<SD> tc;
     {
         Kin<N> K;
         if constexpr (SD.uses_fk != 0) {
             forward_kinematics_s<SD>(S, z, K);
-            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ysl, lane, K);
         }
-        cache_task<SD, 0>(S, tk, K, z, ys, lane, tc);
+        cache_task<SD, 0>(S, tk, K, z, ysl, lane, tc);
     }
     double v[N];
     bool ok;
     if (wave == 0) {
-        ok = pinv_mode_static<SD, 0u>(S, tk, tc, z, ys, lane, v);
+        ok = pinv_mode_static<SD, 0u>(S, tk, tc, z, ysl, lane, v);
     } else {
-        ok = pinv_mode_static<SD, 1u>(S, tk, tc, z, ys, lane, v);
+        ok = pinv_mode_static<SD, 1u>(S, tk, tc, z, ysl, lane, v);
 #pragma unroll
         for (int j = 0; j < N; ++j) xs[j * WAVE + lane] = v[j];
         xs[N * WAVE + lane] = ok ? 1.0 : 0.0;
@@ -870,19 +892,19 @@ __global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
             for (int j = 0; j < N; ++j) v[j] = ok1 ? xs[j * WAVE + lane] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = v[j];
+        for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j];
         // (single wave from here on: LDS writes above are read back by the same wave)
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
-        stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
+        rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
         if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
     }
 }
 
 template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
-    const void* __restrict__ img_g, const double* __restrict__ tterms, const int n_ticks, const double dt,
-    const double max_speed, const long long B, const int nq, const int ny,
-    double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq, int32_t* __restrict__ mode_out)
+    const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B,
+    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed)
 {
     extern __shared__ double lds[];
     constexpr int N = SD.n;
@@ -894,17 +916,18 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
     double* ys = zs + N * WAVE;
     const Img<SD>* __restrict__ S = load_image<SD>(img_g, lds, lane);
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
-    __syncthreads();
-    stage_in<N>(q + b0 * N, N, rows_valid, zs, lane);
-    if constexpr (SD.n_y > 0) stage_in<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, ys, lane);
+    {
+        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+        rows_to_lds<N>(qv, zs, lane);
+        if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
+    }
     __syncthreads();
     const int nts = S->n_tslots;
     double z[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[j * WAVE + lane];
+    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
     double vout[N];
     int acc_mode = -1;
 #pragma unroll
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
         asm volatile("" ::: "memory");
         // time terms are read in place ([values | derivatives], 2*nts doubles per tick, never past them)
         const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
-        pinv_tick_static<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
+        pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             double d = vout[j];
@@ -927,14 +950,14 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = z[j];
+    for (int j = 0; j < N; ++j) zs[lane * N + j] = z[j];
     __syncthreads();
-    stage_out<N>(q + b0 * N, N, rows_valid, zs, lane);
+    rows_from_lds<N>(q + b0 * N, rows_valid, zs, lane);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = vout[j];
+    for (int j = 0; j < N; ++j) zs[lane * N + j] = vout[j];
     __syncthreads();
-    stage_out<N>(dq + b0 * N, N, rows_valid, zs, lane);
+    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
@@ -994,12 +1017,12 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
         if (B <= kModeParallelMaxBatch && a.mode_parallel) {
             const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)(SD.n + 1) * WAVE * sizeof(double);
             hipLaunchKernelGGL((pinv_solve_static_mp_kernel<SD>), dim3(grid), dim3(2 * WAVE), shmem, stream,
-                               a.dImg, tk, B, a.nq, a.nx, a.ny, q, x, y, dq, dx, mode);
+                               a.dImg, q, y, dq, mode, B, tk);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((pinv_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
-                       a.dImg, tk, B, a.nq, a.nx, a.ny, q, x, y, dq, dx, mode);
+                       a.dImg, q, y, dq, mode, B, tk);
     return hipGetLastError();
 }
 
@@ -1010,7 +1033,7 @@ inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tte
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL((pinv_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
-                       a.dImg, d_tterms, n_ticks, dt, max_speed, B, a.nq, a.ny, q, y, dq, mode);
+                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
     return hipGetLastError();
 }
 

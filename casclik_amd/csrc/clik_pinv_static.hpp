@@ -290,7 +290,7 @@ __device__ __forceinline__ void orientation_feature_s(const Img<SD>* __restrict_
     double q[4];
     if constexpr (SD.quat_src == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = ys[S->quat_yi[i] * WAVE + lane];
+        for (int i = 0; i < 4; ++i) q[i] = ys[S->quat_yi[i]];
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = S->quat[i];
@@ -382,7 +382,7 @@ __device__ __forceinline__ double row_eval_s(const clik_row& r, const int n_tslo
     if constexpr ((FLAGS & CLIK_ROW_HAS_Y) != 0) {
         // unused terms carry a zero coefficient and index 0
 #pragma unroll
-        for (int k = 0; k < NY; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
+        for (int k = 0; k < NY; ++k) v = fma(r.yc[k], ys[r.yi[k]], v);
     }
     if constexpr (HAS_T) {
         // (only tasks with time terms pay for this data-dependent branch)
@@ -642,7 +642,7 @@ __device__ __forceinline__ void task_values(const Img<SD>* __restrict__ S, const
             double v = r.c + z[col], dt = 0.0;
             if constexpr ((SD.flags[TI] & CLIK_ROW_HAS_Y) != 0) {
 #pragma unroll
-                for (int k = 0; k < SD.ny_terms[TI]; ++k) v = fma(r.yc[k], ys[r.yi[k] * WAVE + lane], v);
+                for (int k = 0; k < SD.ny_terms[TI]; ++k) v = fma(r.yc[k], ys[r.yi[k]], v);
             }
             if constexpr (SD.has_t[TI] != 0) {
                 const int slot = r.t_slot;
