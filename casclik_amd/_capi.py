@@ -176,6 +176,7 @@ _SYMBOLS = [
     "clik_pinv_create", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_shape_describe", "clik_pinv_attach_kernel",
     "clik_pinv_solve_batch", "clik_pinv_rollout_batch",
     "clik_qp_create", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
+    "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel",
     "clik_qp_solve_batch", "clik_qp_data_batch",
 ]
 
@@ -258,6 +259,12 @@ def load_library(path=None):
                                    C.POINTER(C.c_void_p)]
     lib.clik_qp_destroy.restype = C.c_int
     lib.clik_qp_destroy.argtypes = [vp]
+    lib.clik_qp_kernel_name.restype = C.c_char_p
+    lib.clik_qp_kernel_name.argtypes = [vp]
+    lib.clik_qp_shape_describe.restype = C.c_int
+    lib.clik_qp_shape_describe.argtypes = [C.POINTER(clik_skill_desc), C.c_char_p, C.c_int]
+    lib.clik_qp_attach_kernel.restype = C.c_int
+    lib.clik_qp_attach_kernel.argtypes = [vp, C.c_void_p, C.c_char_p]
     lib.clik_qp_n_vars.restype = C.c_int
     lib.clik_qp_n_vars.argtypes = [vp]
     lib.clik_qp_n_rows.restype = C.c_int

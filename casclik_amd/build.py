@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libclik_hip.so")
 SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_pinv_dyn.hip", "clik_qp.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("clik_device.hpp", "clik_pinv_static.hpp", "clik_pinv_kernels.hpp",
-                                          "clik_shapes_gen.hpp")] \
+                                          "clik_qp_static.hpp", "clik_shapes_gen.hpp")] \
     + [os.path.join(ROOT, "include", "clik.h")]
 ARCH = "gfx950"
 # kernarg preload: the first 14 dwords of the kernel arguments (the buffer pointers and the

@@ -160,6 +160,19 @@ class ReactiveQPController(BaseController):
         self._handle = handle
         self.n_qp_vars = self._lib.clik_qp_n_vars(handle)
         self.n_qp_rows = self._lib.clik_qp_n_rows(handle)
+        self.kernel_name = self._lib.clik_qp_kernel_name(handle).decode()
+        # no AOT shape for this skill: instantiate the shape-specialised QP kernel for
+        # it (the reference JIT-compiles its H/A/lbA/ubA functions here, reactive_qp.py:283-298)
+        import os
+        fopts = self.options.get("function_opts") or {}
+        want_jit = fopts.get("jit", True) and os.environ.get("CLIK_JIT", "1") != "0" \
+            and os.environ.get("CLIK_FORCE_DYNAMIC", "0") != "1"
+        if self.kernel_name == "dynamic" and want_jit:
+            from .. import jit
+            with torch.cuda.device(self._device):
+                name = jit.attach_qp(self._lib, handle, cdesc)
+            if name:
+                self.kernel_name = name
 
     def setup_solver(self):
         """The solver lives inside the kernel; make sure the handle exists

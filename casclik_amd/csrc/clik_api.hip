@@ -48,6 +48,10 @@ hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const T
                           double* ub, hipStream_t stream);
 int qp_pick_variant(int n, int nv, int nc);
 size_t qp_variant_lds(int k, int ny);
+int qp_pick_static(const ShapeDesc& sd);
+const char* qp_static_name(int k);
+hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
+                            const double* y, double* dq, double* slack, int32_t* status, hipStream_t stream);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -74,11 +78,18 @@ struct clik_pinv {
     size_t    d_tterms_cap;
 };
 
+typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*, double*,
+                                     double*, int32_t*, hipStream_t);
+
 struct clik_qp {
     DevSkill  host;
     DevSkill* dev;
     clik::WarmArgs warm;
-    int       variant;
+    int       variant;      // dynamic kernel variant (always valid: qp_data and the fallback use it)
+    void*     d_img;        // shape-specialised kernels: skill image + QP options
+    int       static_k;     // AOT shape-specialised kernel, -1 none
+    clik_jit_qp_fn jit_solve;
+    char      jit_name[64];
 };
 
 static thread_local char g_err[512] = "";
@@ -316,7 +327,8 @@ static bool host_const_pinv(const clik_pinv_opts& o, int m, int n, const double*
 // Compact skill image for the shape-specialised kernels; layout =
 // clik::SkillImage<nj, nt, nr> (clik_device.hpp), padded to a multiple of 1 KiB.
 // Static shapes require contiguous, all-affine rows in task order.
-static bool build_skill_image(const DevSkill& S, std::vector<char>& out)
+static bool build_skill_image(const DevSkill& S, std::vector<char>& out, size_t* image_bytes = nullptr,
+                              size_t extra = 0)
 {
     const int nj = S.d.n_joints, nt = S.d.n_tasks;
     int nr = 0;
@@ -334,7 +346,8 @@ static bool build_skill_image(const DevSkill& S, std::vector<char>& out)
     constexpr size_t GT = CLIK_MAX_DOF * (CLIK_MAX_DOF + 1) / 2;
     const size_t o_tail = o_g + sizeof(double) * GT * (size_t)nt;
     const size_t total = o_tail + sizeof(double) * 5 + sizeof(int32_t) * 6;
-    out.assign((total + 1023) / 1024 * 1024, 0);
+    if (image_bytes) *image_bytes = total;
+    out.assign((((total + 15) & ~(size_t)15) + extra + 1023) / 1024 * 1024, 0);
     memcpy(&out[o_j], S.d.joints, sizeof(clik_joint) * (size_t)nj);
     memcpy(&out[o_t], S.d.tasks, sizeof(clik_task) * (size_t)nt);
     memcpy(&out[o_r], S.d.rows, sizeof(clik_row) * (size_t)nr);
@@ -394,19 +407,63 @@ static void finish_pinv_shape(DevSkill& S, const clik_pinv_opts* opts)
     S.shape.multidim = opts->multidim_sets ? 1 : 0;
     S.shape.conv_last = opts->converge_final_set_to_max ? 1 : 0;
     S.shape.standard = opts->pinv_method == CLIK_PINV_STANDARD ? 1 : 0;
+    S.shape.qp = 0;
+    for (int ti = 0; ti < clik::SHAPE_MAX_TASKS; ++ti) S.shape.soft[ti] = 0;
 }
 
-// C++ initialiser of the ShapeDesc a skill + options map to (host only, no HIP
-// call): the input of tools/gen_shapes.py, which writes clik_shapes_gen.hpp.
-extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts, char* buf, int cap)
+// shape of a ReactiveQPController: no pinv options, per-task soft flags
+static void finish_qp_shape(DevSkill& S)
 {
-    if (!opts || !buf || cap <= 0) return fail(CLIK_EINVAL, "bad arguments");
-    DevSkill* S = new (std::nothrow) DevSkill();
-    if (!S) return fail(CLIK_ENOMEM, "out of host memory");
-    int rc = validate_and_derive(desc, S);
-    if (rc) { delete S; return rc; }
-    finish_pinv_shape(*S, opts);
-    const clik::ShapeDesc& h = S->shape;
+    S.shape.feedforward = S.shape.multidim = S.shape.conv_last = S.shape.standard = 0;
+    S.shape.qp = 1;
+    for (int ti = 0; ti < clik::SHAPE_MAX_TASKS; ++ti)
+        S.shape.soft[ti] = (ti < S.d.n_tasks && S.d.tasks[ti].soft) ? 1 : 0;
+}
+
+// rows handed to the active-set solver by the shape-specialised QP kernel (clik_qp_static.hpp,
+// make_qp_plan): everything but the soft equalities
+static int qp_static_rows(const DevSkill& S)
+{
+    int nr = 0;
+    for (int ti = 0; ti < S.d.n_tasks; ++ti) {
+        const clik_task& t = S.d.tasks[ti];
+        const bool folded = t.soft && (t.cls == CLIK_CLS_EQ || t.cls == CLIK_CLS_VELEQ);
+        if (!folded) nr += t.m;
+    }
+    return nr;
+}
+
+// can a shape-specialised QP kernel serve the skill?  (image layout, row budget, LDS)
+static bool qp_static_eligible(const DevSkill& S)
+{
+    if (S.d.n_tasks > clik::SHAPE_MAX_TASKS || S.d.n_x != 0 || !S.shape.all_affine) return false;
+    std::vector<char> img;
+    size_t image_bytes = 0;
+    if (!build_skill_image(S, img, &image_bytes, sizeof(clik::QpTail))) return false;
+    const int nr = qp_static_rows(S);
+    if (nr > 16) return false;
+    const int nra = nr > 0 ? nr : 1, nsa = S.n_slack > 0 ? S.n_slack : 1;
+    const size_t slots = (size_t)S.n + S.d.n_y + nra * (nra + 1) / 2 + 3 * nra + (size_t)nra * S.n + nsa;
+    return img.size() + slots * 64 * sizeof(double) <= 160u * 1024u;
+}
+
+static bool build_qp_image(const DevSkill& S, std::vector<char>& out)
+{
+    size_t image_bytes = 0;
+    if (!build_skill_image(S, out, &image_bytes, sizeof(clik::QpTail))) return false;
+    clik::QpTail t;
+    memset(&t, 0, sizeof(t));
+    t.mu = S.qo.weight_shifter;
+    for (int j = 0; j < CLIK_MAX_DOF; ++j) t.state_w[j] = S.qo.state_weights[j];
+    for (int k = 0; k < CLIK_MAX_QPROWS; ++k) t.slack_w[k] = S.qo.slack_weights[k];
+    t.max_iter = S.qo.max_iter;
+    memcpy(&out[(image_bytes + 15) & ~(size_t)15], &t, sizeof(t));
+    return true;
+}
+
+// C++ aggregate initialiser of a ShapeDesc (field order of clik_device.hpp)
+static std::string shape_to_string(const clik::ShapeDesc& h)
+{
     std::string o = "{";
     auto num = [&](int v) { o += std::to_string(v); o += ", "; };
     auto arr = [&](const int* a, int nn, int used) {
@@ -423,18 +480,35 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     num(h.nj);
     arr(h.jtype, CLIK_MAX_JOINTS, h.nj); arr(h.jq, CLIK_MAX_JOINTS, h.nj); arr(h.jflags, CLIK_MAX_JOINTS, h.nj);
     arr(h.gain_matrix, clik::SHAPE_MAX_TASKS, nt);
+    arr(h.ny_terms, clik::SHAPE_MAX_TASKS, nt);
+    num(h.n_y);
+    arr(h.has_t, clik::SHAPE_MAX_TASKS, nt);
     o += "{";
-    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.ny_terms[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
-    o += "}, " + std::to_string(h.n_y) + ", ";
-    o += "{";
-    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.has_t[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
-    o += "}, {";
     for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) {
         o += "{";
         for (int k = 0; k < CLIK_MAX_M; ++k) { o += std::to_string(i < nt ? h.ucol[i][k] : 0); if (k + 1 < CLIK_MAX_M) o += ", "; }
         o += (i + 1 < clik::SHAPE_MAX_TASKS) ? "}, " : "}";
     }
+    o += "}, ";
+    num(h.qp);
+    o += "{";
+    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.soft[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
     o += "}}";
+    return o;
+}
+
+// C++ initialiser of the ShapeDesc a skill + options map to (host only, no HIP
+// call): the input of tools/gen_shapes.py, which writes clik_shapes_gen.hpp.
+extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts, char* buf, int cap)
+{
+    if (!opts || !buf || cap <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    DevSkill* S = new (std::nothrow) DevSkill();
+    if (!S) return fail(CLIK_ENOMEM, "out of host memory");
+    int rc = validate_and_derive(desc, S);
+    if (rc) { delete S; return rc; }
+    finish_pinv_shape(*S, opts);
+    const clik::ShapeDesc& h = S->shape;
+    const std::string o = shape_to_string(h);
     bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
     // the static plan handles the doubly processed first EqualityConstraint only when
     // it owns a wide, state-dependent factor (clik_pinv_static.hpp)
@@ -683,6 +757,22 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
 }
 
 // ---------------------------------------------------------------------------- QP
+static int qp_upload_image(clik_qp* h)
+{
+    if (h->d_img) return CLIK_OK;
+    std::vector<char> img;
+    if (!build_qp_image(h->host, img))
+        return fail(CLIK_EUNSUPPORTED, "skill rows are not contiguous: no static kernel possible");
+    hipError_t e = hipMalloc(&h->d_img, img.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->d_img) hipFree(h->d_img);
+        h->d_img = nullptr;
+        return hipfail(e, "QP skill image upload");
+    }
+    return CLIK_OK;
+}
+
 extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* opts, clik_qp** out)
 {
     if (!out) return fail(CLIK_EINVAL, "null out pointer");
@@ -728,17 +818,77 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     compute_warm(S, S.lds_slots, h->warm);
     S.zero_token = 0;
     S.lds_slots = 0;
+    finish_qp_shape(S);
+    h->d_img = nullptr;
+    h->static_k = -1;
+    h->jit_solve = nullptr;
+    h->jit_name[0] = 0;
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    {
+        // shape-specialised kernel from the AOT table (CLIK_FORCE_DYNAMIC=1 / CLIK_NO_AOT=1 skip it)
+        const char* force = getenv("CLIK_FORCE_DYNAMIC");
+        const char* noaot = getenv("CLIK_NO_AOT");
+        const bool allow = !((force && force[0] == '1') || (noaot && noaot[0] == '1'));
+        if (allow && qp_static_eligible(S)) {
+            const int k = clik::qp_pick_static(S.shape);
+            if (k >= 0) {
+                int rc2 = qp_upload_image(h);
+                if (rc2) { hipFree(h->dev); delete h; return rc2; }
+                h->static_k = k;
+            }
+        }
+    }
     *out = h;
     return CLIK_OK;
+}
+
+// ShapeDesc initialiser of a QP skill (see clik_shape_describe); returns 1 when a
+// shape-specialised QP kernel can serve it, 0 when not, negative on error.
+extern "C" int clik_qp_shape_describe(const clik_skill_desc* desc, char* buf, int cap)
+{
+    if (!buf || cap <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    DevSkill* S = new (std::nothrow) DevSkill();
+    if (!S) return fail(CLIK_ENOMEM, "out of host memory");
+    int rc = validate_and_derive(desc, S);
+    if (rc) { delete S; return rc; }
+    finish_qp_shape(*S);
+    const std::string o = shape_to_string(S->shape);
+    const bool eligible = qp_static_eligible(*S);
+    delete S;
+    if ((int)o.size() + 1 > cap) return fail(CLIK_EINVAL, "buffer too small");
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return eligible ? 1 : 0;
+}
+
+// Attach a shape-specialised QP kernel compiled at run time (casclik_amd/jit.py instantiates
+// clik_qp_static.hpp for the ShapeDesc that clik_qp_shape_describe printed).
+extern "C" int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, const char* name)
+{
+    if (!h || !solve_fn) return fail(CLIK_EINVAL, "null argument");
+    if (!qp_static_eligible(h->host))
+        return fail(CLIK_EUNSUPPORTED, "skill is outside the shape-specialised QP family");
+    int rc = qp_upload_image(h);
+    if (rc) return rc;
+    h->jit_solve = (clik_jit_qp_fn)solve_fn;
+    snprintf(h->jit_name, sizeof(h->jit_name), "%s", name ? name : "jit");
+    return CLIK_OK;
+}
+
+extern "C" const char* clik_qp_kernel_name(const clik_qp* h)
+{
+    if (!h) return "none";
+    if (h->jit_solve) return h->jit_name;
+    if (h->static_k >= 0) return clik::qp_static_name(h->static_k);
+    return "dynamic";
 }
 
 extern "C" int clik_qp_destroy(clik_qp* h)
 {
     if (!h) return CLIK_OK;
+    if (h->d_img) hipFree(h->d_img);
     if (h->dev) hipFree(h->dev);
     delete h;
     return CLIK_OK;
@@ -769,8 +919,15 @@ extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tt
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
-    hipError_t e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,
-                                         slack, status, (hipStream_t)stream);
+    hipError_t e;
+    if (h->jit_solve)
+        e = h->jit_solve(h->d_img, &tk, (long long)B, q, y, dq, slack, status, (hipStream_t)stream);
+    else if (h->static_k >= 0)
+        e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, y, dq, slack, status,
+                                   (hipStream_t)stream);
+    else
+        e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,
+                                  slack, status, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_solve_kernel launch");
     return CLIK_OK;
 }

@@ -50,6 +50,9 @@ struct ShapeDesc {
     // vector e_col with distinct columns.  ucol[ti][i] = col + 1 of row i, 0 when the task is not of
     // that form (then all of its entries are 0).
     int ucol[SHAPE_MAX_TASKS][CLIK_MAX_M];
+    // ReactiveQPController shapes (0 in pseudo-inverse shapes)
+    int qp;                         // 1: shape of a QP controller (the pinv option fields are 0)
+    int soft[SHAPE_MAX_TASKS];      // constraint_type "soft": the rows carry slack variables
 };
 
 constexpr bool shape_unit(const ShapeDesc& sd, int ti) { return sd.const_j[ti] != 0 && sd.m[ti] > 0 && sd.ucol[ti][0] > 0; }
@@ -92,6 +95,35 @@ struct SkillImage {
     int32_t    n_tslots;
     int32_t    pad;
 };
+
+// options of the QP controller, appended to the skill image of QP shapes at the next
+// 16-byte boundary (host: build_qp_image in clik_api.hip, device: clik_qp_static.hpp)
+struct QpTail {
+    double  mu;                                   // weight_shifter
+    double  state_w[CLIK_MAX_DOF];
+    double  slack_w[CLIK_MAX_QPROWS];
+    int32_t max_iter;
+    int32_t pad;
+};
+
+inline bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
+{
+    if (a.n != b.n || a.n_tasks != b.n_tasks || a.all_affine != b.all_affine || a.uses_fk != b.uses_fk ||
+        a.quat_src != b.quat_src || a.feedforward != b.feedforward || a.multidim != b.multidim ||
+        a.conv_last != b.conv_last || a.standard != b.standard || a.nj != b.nj || a.n_y != b.n_y || a.qp != b.qp)
+        return false;
+    for (int i = 0; i < a.n_tasks; ++i)
+        if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i] ||
+            a.gain_matrix[i] != b.gain_matrix[i] || a.ny_terms[i] != b.ny_terms[i] || a.has_t[i] != b.has_t[i] ||
+            a.soft[i] != b.soft[i])
+            return false;
+    for (int i = 0; i < a.n_tasks; ++i)
+        for (int k = 0; k < CLIK_MAX_M; ++k)
+            if (a.ucol[i][k] != b.ucol[i][k]) return false;
+    for (int j = 0; j < a.nj; ++j)
+        if (a.jtype[j] != b.jtype[j] || a.jq[j] != b.jq[j] || a.jflags[j] != b.jflags[j]) return false;
+    return true;
+}
 
 // Device-resident skill: descriptor + controller options + derived tables.
 struct DevSkill {

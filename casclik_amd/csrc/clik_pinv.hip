@@ -42,24 +42,6 @@ static const ShapeEntry kShapes[] = {
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
-static bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
-{
-    if (a.n != b.n || a.n_tasks != b.n_tasks || a.all_affine != b.all_affine || a.uses_fk != b.uses_fk ||
-        a.quat_src != b.quat_src || a.feedforward != b.feedforward || a.multidim != b.multidim ||
-        a.conv_last != b.conv_last || a.standard != b.standard || a.nj != b.nj || a.n_y != b.n_y)
-        return false;
-    for (int i = 0; i < a.n_tasks; ++i)
-        if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i] ||
-            a.gain_matrix[i] != b.gain_matrix[i] || a.ny_terms[i] != b.ny_terms[i] || a.has_t[i] != b.has_t[i])
-            return false;
-    for (int i = 0; i < a.n_tasks; ++i)
-        for (int k = 0; k < CLIK_MAX_M; ++k)
-            if (a.ucol[i][k] != b.ucol[i][k]) return false;
-    for (int j = 0; j < a.nj; ++j)
-        if (a.jtype[j] != b.jtype[j] || a.jq[j] != b.jq[j] || a.jflags[j] != b.jflags[j]) return false;
-    return true;
-}
-
 // Index into kShapes for a skill: the matching static shape, else the dynamic
 // kernel of the smallest sufficient width.  `allow_static` = 0 forces dynamic.
 int pinv_pick_kernel(const DevSkill& S, int allow_static)

@@ -544,13 +544,14 @@ struct TaskCache {
     double J[ROWS][SD.n];
 };
 
-template <const ShapeDesc& SD, int TI>
+// ALL: also VelocitySetConstraints (the QP controller uses them, the pseudo-inverse one ignores them)
+template <const ShapeDesc& SD, int TI, bool ALL = false>
 __device__ __forceinline__ void cache_task(const Img<SD>* __restrict__ S, const TickArgs& tk, const Kin<SD.n>& K,
                                            const double (&z)[SD.n], const double* ys, const int lane,
                                            TaskCache<SD>& tc)
 {
     if constexpr (TI < SD.n_tasks) {
-        if constexpr (!SD.const_j[TI] && SD.cls[TI] != CLIK_CLS_VELSET) {
+        if constexpr (!SD.const_j[TI] && (ALL || SD.cls[TI] != CLIK_CLS_VELSET)) {
             constexpr int N = SD.n;
             constexpr int M = SD.m[TI];
             constexpr int cb = shape_cache_base(SD, TI);
@@ -564,7 +565,7 @@ __device__ __forceinline__ void cache_task(const Img<SD>* __restrict__ S, const 
                 for (int j = 0; j < N; ++j) tc.J[cb + i][j] = J[i][j];
             }
         }
-        cache_task<SD, TI + 1>(S, tk, K, z, ys, lane, tc);
+        cache_task<SD, TI + 1, ALL>(S, tk, K, z, ys, lane, tc);
     }
 }
 

@@ -20,9 +20,13 @@
 //     multiplier is sign-free
 //   - infeasible problems (hard rows only) are reported per instance, like the
 //     reference's RuntimeError from qpOASES
-#include "clik_device.hpp"
+#include "clik_qp_static.hpp"
 
 namespace clik {
+
+namespace shapes {
+#include "clik_shapes_gen.hpp"
+}  // namespace shapes
 
 // LDS slots per lane: [zs N][ys ny][A rows NC*N (FK frames alias)][Q NC(NC+1)/2][lb NC][ub NC][hinv NC]
 template <int N, int NC>
@@ -92,215 +96,6 @@ __device__ __forceinline__ int qp_rows(const DevSkill* __restrict__ S, const Tic
         row += m;
     }
     return row;
-}
-
-// ---- small LDL^T with a compile-time or run-time size -------------------------------
-template <int NC, bool EXACT>
-__device__ __forceinline__ void qp_ldl_factor(double (&A)[NC * (NC + 1) / 2], double (&rd)[NC], const int r)
-{
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        if (EXACT || k < r) {
-            double t[NC];
-            double d = A[tri(k, k)];
-#pragma unroll
-            for (int j = 0; j < k; ++j) {
-                t[j] = A[tri(k, j)] * A[tri(j, j)];
-                d = fma(-A[tri(k, j)], t[j], d);
-            }
-            A[tri(k, k)] = d;
-            const double inv = recip(d);
-            rd[k] = inv;
-#pragma unroll
-            for (int i = k + 1; i < NC; ++i) {
-                if (EXACT || i < r) {
-                    double s = A[tri(i, k)];
-#pragma unroll
-                    for (int j = 0; j < k; ++j) s = fma(-A[tri(i, j)], t[j], s);
-                    A[tri(i, k)] = s * inv;
-                }
-            }
-        }
-    }
-}
-
-template <int NC, bool EXACT>
-__device__ __forceinline__ void qp_ldl_solve(const double (&A)[NC * (NC + 1) / 2], const double (&rd)[NC],
-                                             double (&x)[NC], const int r)
-{
-#pragma unroll
-    for (int i = 1; i < NC; ++i)
-        if (EXACT || i < r) {
-#pragma unroll
-            for (int j = 0; j < i; ++j) x[i] = fma(-A[tri(i, j)], x[j], x[i]);
-        }
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-        if (EXACT || i < r) x[i] *= rd[i];
-#pragma unroll
-    for (int i = NC - 2; i >= 0; --i)
-        if (EXACT || i < r) {
-#pragma unroll
-            for (int j = i + 1; j < NC; ++j)
-                if (EXACT || j < r) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
-        }
-}
-
-// ---- dual active set in constraint space -------------------------------------------
-// Qs: packed lower triangle of Q per lane (slot tri(i,j)*WAVE + lane), lbs / ubs: bounds,
-// softeq: rows that are soft equalities (their Schur block is SPD, so they all start
-// active: one solve instead of one iteration each).  On return nu holds the signed
-// multipliers of the optimum.  Returns the status (0 optimal, 1 iteration cap,
-// 2 infeasible).  EXACT: nc == NC at compile time (no size guards).
-template <int NC, bool EXACT>
-__device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs,
-                                        const uint32_t softeq, const int lane, const int nc_rt,
-                                        const int max_iter, const bool lane_valid, double (&nu)[NC])
-{
-    constexpr int NT = NC * (NC + 1) / 2;
-    const int nc = EXACT ? NC : nc_rt;
-    // bounds stay in LDS (read once per iteration in the selection scan): keeping
-    // them in registers next to the 13x13 factor spills to scratch
-    uint32_t W = softeq, up = 0u, eq = 0u;
-    double c[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        nu[i] = 0.0;
-        c[i] = 0.0;
-        if ((EXACT || i < nc) && !(ubs[i * WAVE + lane] - lbs[i * WAVE + lane] > 0.0)) eq |= 1u << i;
-    }
-    int status = 0;
-    bool done = !lane_valid;
-    bool need_p = true;
-    bool init = softeq != 0u;            // wave-uniform
-    int p = 0;
-    double sp = 1.0, bp = 0.0;
-    for (int it = 0; it < max_iter; ++it) {
-        if (__ballot(!done) == 0ull) break;
-        // (1) one pass over Q:  c = Q nu  and the masked Schur matrix  D Q_WW D.
-        //     Masks are applied arithmetically (a_i = +-1 for active rows, 0 otherwise):
-        //     per-lane bit tests as control flow would serialise the wave.
-        double L[NT], rd[NC], r[NC], rhs[NC], a[NC];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            c[i] = 0.0;
-            const double wi = (double)((W >> i) & 1u);
-            a[i] = wi - 2.0 * wi * (double)((up >> i) & 1u);
-        }
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                const double q = (EXACT || i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
-                c[i] = fma(q, nu[j], c[i]);
-                if (j != i) c[j] = fma(q, nu[i], c[j]);
-                L[tri(i, j)] = (a[i] * a[j]) * q;
-            }
-            L[tri(i, i)] += 1.0 - a[i] * a[i];          // identity on inactive rows
-        }
-        if (init) {
-            // block start: all soft equalities active at once, nu_E = Q_EE^-1 b_E
-            qp_ldl_factor<NC, EXACT>(L, rd, nc);
-#pragma unroll
-            for (int i = 0; i < NC; ++i) r[i] = ((W >> i) & 1u) ? lbs[i * WAVE + lane] : 0.0;
-            qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
-#pragma unroll
-            for (int i = 0; i < NC; ++i) nu[i] = ((W >> i) & 1u) ? r[i] : 0.0;
-            init = false;
-            continue;
-        }
-        // (2) pick the next constraint to enforce: unsatisfied equalities first,
-        //     then the most violated inequality
-        if (need_p && !done) {
-            double best = 1e-11;
-            int pick = -1;
-            bool pick_up = false;
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                if ((EXACT || i < nc) && !((W >> i) & 1u)) {
-                    const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                    const double iscale = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
-                    const double vlo = (lbi - c[i]) * iscale, vhi = (c[i] - ubi) * iscale;
-                    double v = fmax(vlo, vhi);
-                    if (((eq >> i) & 1u) && v > 1e-11) v += 1e30;       // equalities take precedence
-                    if (v > best) {
-                        best = v;
-                        pick = i;
-                        pick_up = vhi > vlo;
-                        bp = pick_up ? -ubi : lbi;
-                    }
-                }
-            }
-            if (pick < 0) {
-                done = true;
-            } else {
-                p = pick;
-                sp = pick_up ? -1.0 : 1.0;
-            }
-        }
-        if (__ballot(!done) == 0ull) break;
-        // (3) step direction:  r = S_W^-1 (D Q_Wp sp),   zn = n_p' H^-1 (n_p - N_W r)
-        double qpp = 0.0, cp = 0.0;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            // column p of Q (dynamic per lane): packed index of (max(i,p), min(i,p))
-            const int hi_ = i > p ? i : p, lo_ = i > p ? p : i;
-            const double qip = (EXACT || i < nc) ? Qs[(hi_ * (hi_ + 1) / 2 + lo_) * WAVE + lane] : 0.0;
-            rhs[i] = (a[i] * sp) * qip;
-            const double isp = (i == p) ? 1.0 : 0.0;
-            qpp = fma(isp, qip, qpp);
-            cp = fma(isp, c[i], cp);
-        }
-        qp_ldl_factor<NC, EXACT>(L, rd, nc);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) r[i] = rhs[i];
-        qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
-        double zn = qpp;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) zn = fma(-rhs[i], r[i], zn);
-        // (4) step lengths
-        double t1 = 1e300;
-        int l = -1;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            // candidate only for active inequality rows with r_i > 0 (a_i = 0 on inactive rows)
-            const bool cand_ok = (a[i] != 0.0) && !((eq >> i) & 1u) && r[i] > 1e-14;
-            const double mu_i = a[i] * nu[i];
-            const double cand = cand_ok ? fmax(mu_i, 0.0) / r[i] : 1e300;
-            const bool better = cand < t1;
-            t1 = better ? cand : t1;
-            l = better ? i : l;
-        }
-        const double gap = bp - sp * cp;
-        const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
-        const double t2 = has_primal ? gap / zn : 1e300;
-        const double t = fmin(t1, t2);
-        if (!done) {
-            if (!(t < 1e299)) {
-                status = 2;                 // constraint p cannot be satisfied
-                done = true;
-            } else {
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    nu[i] = fma(-t * a[i], r[i], nu[i]);
-                    nu[i] = fma((i == p) ? t : 0.0, sp, nu[i]);
-                }
-                if (t2 <= t1) {
-                    W |= 1u << p;
-                    if (sp < 0.0) up |= 1u << p;
-                    need_p = true;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NC; ++i) nu[i] = (i == l) ? 0.0 : nu[i];
-                    W &= ~(1u << l);
-                    up &= ~(1u << l);
-                    need_p = false;
-                }
-            }
-        }
-    }
-    if (!done) status = 1;
-    return status;
 }
 
 template <int N, int NC, bool EXACT>
@@ -379,7 +174,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
         }
     }
     double nu[NC];
-    const int status = gi_solve<NC, EXACT>(Qs, lbs, ubs, softeq, lane, nc, S->qo.max_iter, valid, nu);
+    const int status = gi_solve<NC, EXACT>(Qs, lbs, ubs, nullptr, softeq, lane, nc, S->qo.max_iter, valid, nu);
 
     // v = H^-1 A' nu
     double u[N];
@@ -574,6 +369,35 @@ hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const T
 {
     if (k < 0 || k >= kNumQpVariants) return hipErrorInvalidValue;
     return kQpVariants[k].data(dS, wa, tk, B, ny, q, x, y, Hd, A, lb, ub, stream);
+}
+
+// ---- shape-specialised QP kernels (clik_qp_static.hpp): AOT table -------------------------
+struct QpStaticEntry {
+    const char* name;
+    const ShapeDesc* sd;
+    qp_static_fn solve;
+};
+#define CLIK_QP_STATIC_ENTRY(S) {"qp_static_" #S, &shapes::S, &launch_qp_static<shapes::S>},
+static const QpStaticEntry kQpShapes[] = {
+#ifdef CLIK_GENERATED_QP_SHAPES
+    CLIK_GENERATED_QP_SHAPES(CLIK_QP_STATIC_ENTRY)
+#endif
+    {nullptr, nullptr, nullptr}
+};
+constexpr int kNumQpShapes = (int)(sizeof(kQpShapes) / sizeof(kQpShapes[0])) - 1;
+
+int qp_pick_static(const ShapeDesc& sd)
+{
+    for (int k = 0; k < kNumQpShapes; ++k)
+        if (shape_equal(*kQpShapes[k].sd, sd)) return k;
+    return -1;
+}
+const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
+hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
+                            const double* y, double* dq, double* slack, int32_t* status, hipStream_t stream)
+{
+    if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
+    return kQpShapes[k].solve(d_img, tk, B, q, y, dq, slack, status, stream);
 }
 
 }  // namespace clik

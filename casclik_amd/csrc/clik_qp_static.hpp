@@ -1,0 +1,594 @@
+// Shape-specialised ReactiveQPController tick (reactive_qp.py:461-528) on gfx950.
+//
+// Same problem as clik_qp.hip,
+//     min 1/2 v'Hv   s.t.  lbA <= A v <= ubA,   v = [robot_vel; slack],  H = diag(h) > 0,
+// with the structure of the skill known at compile time (ShapeDesc, as for the
+// pseudo-inverse kernels) and an algebraically reduced formulation:
+//
+//   * SOFT EQUALITY rows  J v - s = b  (cost 1/2 h_s s^2) are eliminated exactly:
+//         s = J v - b,      P = H_v + J' diag(h_s) J,      g = J' diag(h_s) b,
+//     so the unconstrained minimiser v0 = P^-1 g already satisfies them optimally
+//     (n x n LDL^T, n <= 8) and they never enter the active-set iteration.
+//   * the remaining rows (hard rows, soft inequality rows) run the dual active-set
+//     method of clik_qp.hip in constraint space with
+//         Q = A_r P^-1 A_r' (+ 1/h_s on soft inequality rows),   c = A_r v0 + Q nu,
+//         v = v0 + P^-1 A_r' nu.
+//     For the config-4 skill (6 soft pose rows + 7 joint-speed rows) the masked
+//     refactorisation per iteration is 7x7 instead of 13x13.
+//
+// The minimiser of a strictly convex QP is unique, so this returns the same v and
+// slack as the reference's qpOASES call (parity: tests/test_gpu_qp.py against the
+// oracle, tolerance QP_RTOL).
+#pragma once
+#include "clik_pinv_kernels.hpp"
+
+namespace clik {
+
+// ---- small LDL^T with a compile-time or run-time size -------------------------------
+template <int NC, bool EXACT>
+__device__ __forceinline__ void qp_ldl_factor(double (&A)[NC * (NC + 1) / 2], double (&rd)[NC], const int r)
+{
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (EXACT || k < r) {
+            double t[NC];
+            double d = A[tri(k, k)];
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                t[j] = A[tri(k, j)] * A[tri(j, j)];
+                d = fma(-A[tri(k, j)], t[j], d);
+            }
+            A[tri(k, k)] = d;
+            const double inv = recip(d);
+            rd[k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < NC; ++i) {
+                if (EXACT || i < r) {
+                    double s = A[tri(i, k)];
+#pragma unroll
+                    for (int j = 0; j < k; ++j) s = fma(-A[tri(i, j)], t[j], s);
+                    A[tri(i, k)] = s * inv;
+                }
+            }
+        }
+    }
+}
+
+template <int NC, bool EXACT>
+__device__ __forceinline__ void qp_ldl_solve(const double (&A)[NC * (NC + 1) / 2], const double (&rd)[NC],
+                                             double (&x)[NC], const int r)
+{
+#pragma unroll
+    for (int i = 1; i < NC; ++i)
+        if (EXACT || i < r) {
+#pragma unroll
+            for (int j = 0; j < i; ++j) x[i] = fma(-A[tri(i, j)], x[j], x[i]);
+        }
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+        if (EXACT || i < r) x[i] *= rd[i];
+#pragma unroll
+    for (int i = NC - 2; i >= 0; --i)
+        if (EXACT || i < r) {
+#pragma unroll
+            for (int j = i + 1; j < NC; ++j)
+                if (EXACT || j < r) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
+        }
+}
+
+// ---- dual active set in constraint space -------------------------------------------
+// Qs: packed lower triangle of Q per lane (slot tri(i,j)*WAVE + lane), lbs / ubs: bounds,
+// c0s: constraint values at the unconstrained minimiser (nullptr: zero),
+// softeq: rows that are soft equalities (their Schur block is SPD, so they all start
+// active: one solve instead of one iteration each).  On return nu holds the signed
+// multipliers of the optimum.  Returns the status (0 optimal, 1 iteration cap,
+// 2 infeasible).  EXACT: nc == NC at compile time (no size guards).
+template <int NC, bool EXACT>
+__device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs, const double* c0s,
+                                        const uint32_t softeq, const int lane, const int nc_rt,
+                                        const int max_iter, const bool lane_valid, double (&nu)[NC])
+{
+    constexpr int NT = NC * (NC + 1) / 2;
+    const int nc = EXACT ? NC : nc_rt;
+    // bounds stay in LDS (read once per iteration in the selection scan): keeping
+    // them in registers next to the factor spills to scratch
+    uint32_t W = softeq, up = 0u, eq = 0u;
+    double c[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        nu[i] = 0.0;
+        c[i] = 0.0;
+        if ((EXACT || i < nc) && !(ubs[i * WAVE + lane] - lbs[i * WAVE + lane] > 0.0)) eq |= 1u << i;
+    }
+    int status = 0;
+    bool done = !lane_valid;
+    bool need_p = true;
+    bool init = softeq != 0u;            // wave-uniform
+    int p = 0;
+    double sp = 1.0, bp = 0.0;
+    for (int it = 0; it < max_iter; ++it) {
+        if (__ballot(!done) == 0ull) break;
+        // (1) one pass over Q:  c = c0 + Q nu  and the masked Schur matrix  D Q_WW D.
+        //     Masks are applied arithmetically (a_i = +-1 for active rows, 0 otherwise):
+        //     per-lane bit tests as control flow would serialise the wave.
+        double L[NT], rd[NC], r[NC], rhs[NC], a[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            c[i] = (c0s != nullptr && (EXACT || i < nc)) ? c0s[i * WAVE + lane] : 0.0;
+            const double wi = (double)((W >> i) & 1u);
+            a[i] = wi - 2.0 * wi * (double)((up >> i) & 1u);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double q = (EXACT || i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
+                c[i] = fma(q, nu[j], c[i]);
+                if (j != i) c[j] = fma(q, nu[i], c[j]);
+                L[tri(i, j)] = (a[i] * a[j]) * q;
+            }
+            L[tri(i, i)] += 1.0 - a[i] * a[i];          // identity on inactive rows
+        }
+        if (init) {
+            // block start: all soft equalities active at once, nu_E = Q_EE^-1 b_E
+            qp_ldl_factor<NC, EXACT>(L, rd, nc);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) r[i] = ((W >> i) & 1u) ? lbs[i * WAVE + lane] : 0.0;
+            qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) nu[i] = ((W >> i) & 1u) ? r[i] : 0.0;
+            init = false;
+            continue;
+        }
+        // (2) pick the next constraint to enforce: unsatisfied equalities first,
+        //     then the most violated inequality
+        if (need_p && !done) {
+            double best = 1e-11;
+            int pick = -1;
+            bool pick_up = false;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if ((EXACT || i < nc) && !((W >> i) & 1u)) {
+                    const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
+                    const double iscale = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+                    const double vlo = (lbi - c[i]) * iscale, vhi = (c[i] - ubi) * iscale;
+                    double v = fmax(vlo, vhi);
+                    if (((eq >> i) & 1u) && v > 1e-11) v += 1e30;       // equalities take precedence
+                    if (v > best) {
+                        best = v;
+                        pick = i;
+                        pick_up = vhi > vlo;
+                        bp = pick_up ? -ubi : lbi;
+                    }
+                }
+            }
+            if (pick < 0) {
+                done = true;
+            } else {
+                p = pick;
+                sp = pick_up ? -1.0 : 1.0;
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+        // (3) step direction:  r = S_W^-1 (D Q_Wp sp),   zn = n_p' H^-1 (n_p - N_W r)
+        double qpp = 0.0, cp = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            // column p of Q (dynamic per lane): packed index of (max(i,p), min(i,p))
+            const int hi_ = i > p ? i : p, lo_ = i > p ? p : i;
+            const double qip = (EXACT || i < nc) ? Qs[(hi_ * (hi_ + 1) / 2 + lo_) * WAVE + lane] : 0.0;
+            rhs[i] = (a[i] * sp) * qip;
+            const double isp = (i == p) ? 1.0 : 0.0;
+            qpp = fma(isp, qip, qpp);
+            cp = fma(isp, c[i], cp);
+        }
+        qp_ldl_factor<NC, EXACT>(L, rd, nc);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) r[i] = rhs[i];
+        qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
+        double zn = qpp;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) zn = fma(-rhs[i], r[i], zn);
+        // (4) step lengths
+        double t1 = 1e300;
+        int l = -1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            // candidate only for active inequality rows with r_i > 0 (a_i = 0 on inactive rows)
+            const bool cand_ok = (a[i] != 0.0) && !((eq >> i) & 1u) && r[i] > 1e-14;
+            const double mu_i = a[i] * nu[i];
+            const double cand = cand_ok ? fmax(mu_i, 0.0) / r[i] : 1e300;
+            const bool better = cand < t1;
+            t1 = better ? cand : t1;
+            l = better ? i : l;
+        }
+        const double gap = bp - sp * cp;
+        const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
+        const double t2 = has_primal ? gap / zn : 1e300;
+        const double t = fmin(t1, t2);
+        if (!done) {
+            if (!(t < 1e299)) {
+                status = 2;                 // constraint p cannot be satisfied
+                done = true;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    nu[i] = fma(-t * a[i], r[i], nu[i]);
+                    nu[i] = fma((i == p) ? t : 0.0, sp, nu[i]);
+                }
+                if (t2 <= t1) {
+                    W |= 1u << p;
+                    if (sp < 0.0) up |= 1u << p;
+                    need_p = true;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) nu[i] = (i == l) ? 0.0 : nu[i];
+                    W &= ~(1u << l);
+                    up &= ~(1u << l);
+                    need_p = false;
+                }
+            }
+        }
+    }
+    if (!done) status = 1;
+    return status;
+}
+
+// ---- compile-time plan of the reduced QP ---------------------------------------------
+constexpr int QPS_MAX_ROWS = 16;       // active-set rows a static QP kernel carries in registers
+
+struct QpPlanS {
+    int  nr;                               // rows handed to the active-set solver
+    int  row_task[CLIK_MAX_QPROWS];
+    int  row_local[CLIK_MAX_QPROWS];
+    int  ns;                               // slack variables (= soft rows, in row order)
+    int  slack_base[SHAPE_MAX_TASKS];      // first slack of a soft task
+    bool folded[SHAPE_MAX_TASKS];          // soft equality: eliminated into P, g
+    int  row_base[SHAPE_MAX_TASKS];        // first active-set row of a task that is not folded
+};
+
+constexpr QpPlanS make_qp_plan(const ShapeDesc& sd)
+{
+    QpPlanS p{};
+    for (int ti = 0; ti < sd.n_tasks; ++ti) {
+        const int cls = sd.cls[ti];
+        const bool soft = sd.soft[ti] != 0;
+        p.slack_base[ti] = p.ns;
+        if (soft) p.ns += sd.m[ti];
+        p.folded[ti] = soft && (cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ);
+        p.row_base[ti] = p.nr;
+        if (!p.folded[ti]) {
+            for (int i = 0; i < sd.m[ti]; ++i) {
+                if (p.nr < CLIK_MAX_QPROWS) {
+                    p.row_task[p.nr] = ti;
+                    p.row_local[p.nr] = i;
+                }
+                ++p.nr;
+            }
+        }
+    }
+    return p;
+}
+
+template <const ShapeDesc& SD>
+struct QpLayout {
+    static constexpr QpPlanS P = make_qp_plan(SD);
+    static constexpr int N = SD.n;
+    static constexpr int NY = SD.n_y > 0 ? SD.n_y : 0;
+    static constexpr int NR = P.nr;
+    static constexpr int NRA = NR > 0 ? NR : 1;
+    static constexpr int NT = NRA * (NRA + 1) / 2;
+    static constexpr int NS = P.ns;
+    static constexpr int NSA = NS > 0 ? NS : 1;
+    static constexpr size_t TAIL_OFF = (sizeof(Img<SD>) + 15) & ~(size_t)15;
+    static constexpr int IMG_CHUNKS = (int)((TAIL_OFF + sizeof(QpTail) + 1023) / 1024);
+    static constexpr int IMG_DOUBLES = IMG_CHUNKS * 128;
+    // 64-double slots behind the image
+    static constexpr int O_Z = 0;
+    static constexpr int O_Y = O_Z + N;
+    static constexpr int O_Q = O_Y + NY;
+    static constexpr int O_LB = O_Q + NT;
+    static constexpr int O_UB = O_LB + NRA;
+    static constexpr int O_C0 = O_UB + NRA;
+    static constexpr int O_YS = O_C0 + NRA;          // P^-1 a_r'  (NR x N)
+    static constexpr int O_SL = O_YS + NRA * N;      // folded right-hand sides, then the slack output rows
+    static constexpr int SLOTS = O_SL + NSA;
+    static constexpr size_t LDS_BYTES = ((size_t)IMG_DOUBLES + (size_t)SLOTS * WAVE) * sizeof(double);
+};
+
+// bounds  lbA, ubA  of the rows of task TI (reactive_qp.py:191-246)
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ void qp_bounds_s(const clik_task& t, const double (&e)[SD.m[TI]],
+                                            const double (&Jt)[SD.m[TI]], double (&lo)[SD.m[TI]],
+                                            double (&hi)[SD.m[TI]])
+{
+    constexpr int M = SD.m[TI];
+    constexpr int cls = SD.cls[TI];
+    if constexpr (cls == CLIK_CLS_EQ) {
+        double ke[M];
+        gain_apply_s<M, SD.gain_matrix[TI] != 0>(t, e, ke);
+#pragma unroll
+        for (int i = 0; i < M; ++i) lo[i] = hi[i] = -Jt[i] - ke[i];
+    } else if constexpr (cls == CLIK_CLS_SET) {
+        double d0[M], g[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) d0[i] = t.set_min[i] - e[i];
+        gain_apply_s<M, SD.gain_matrix[TI] != 0>(t, d0, g);
+#pragma unroll
+        for (int i = 0; i < M; ++i) lo[i] = -Jt[i] + g[i];
+#pragma unroll
+        for (int i = 0; i < M; ++i) d0[i] = t.set_max[i] - e[i];
+        gain_apply_s<M, SD.gain_matrix[TI] != 0>(t, d0, g);
+#pragma unroll
+        for (int i = 0; i < M; ++i) hi[i] = -Jt[i] + g[i];
+    } else if constexpr (cls == CLIK_CLS_VELEQ) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) lo[i] = hi[i] = t.target[i] - Jt[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            lo[i] = t.set_min[i] - Jt[i];
+            hi[i] = t.set_max[i] - Jt[i];
+        }
+    }
+}
+
+// per-task pass 1: bounds; folded tasks accumulate into P and g, the others publish their bounds
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
+                                            const TickArgs& tk, const TaskCache<SD>& tc, const double (&z)[SD.n],
+                                            const double* ys, const int lane,
+                                            double (&Pm)[SD.n * (SD.n + 1) / 2], double (&g)[SD.n], double* slots)
+{
+    if constexpr (TI < SD.n_tasks) {
+        using LY = QpLayout<SD>;
+        constexpr int N = SD.n;
+        constexpr int M = SD.m[TI];
+        constexpr QpPlanS P = LY::P;
+        const clik_task& t = S->tasks[TI];
+        double e[M], Jt[M], lo[M], hi[M];
+        task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
+        qp_bounds_s<SD, TI>(t, e, Jt, lo, hi);
+        if constexpr (P.folded[TI]) {
+            constexpr int sb = P.slack_base[TI];
+            static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const double hs = T->mu + T->slack_w[sb + i];
+                const double hb = hs * lo[i];
+                slots[(LY::O_SL + sb + i) * WAVE + lane] = lo[i];
+                if constexpr (shape_unit(SD, TI)) {
+                    constexpr int col = SD.ucol[TI][i] - 1;
+                    Pm[tri(col, col)] += hs;
+                    g[col] += hb;
+                } else {
+                    double hj[N];
+#pragma unroll
+                    for (int a = 0; a < N; ++a) {
+                        const double ja = jac<SD, TI>(S, tc, i, a);
+                        hj[a] = hs * ja;
+                        g[a] = fma(hb, ja, g[a]);
+                    }
+#pragma unroll
+                    for (int a = 0; a < N; ++a)
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) Pm[tri(a, b)] = fma(hj[a], jac<SD, TI>(S, tc, i, b), Pm[tri(a, b)]);
+                }
+            });
+        } else {
+            constexpr int rb = P.row_base[TI];
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                slots[(LY::O_LB + rb + i) * WAVE + lane] = lo[i];
+                slots[(LY::O_UB + rb + i) * WAVE + lane] = hi[i];
+            }
+        }
+        qp_gather_s<SD, TI + 1>(S, T, tk, tc, z, ys, lane, Pm, g, slots);
+    }
+}
+
+// element j of active-set row R
+template <const ShapeDesc& SD, int R>
+__device__ __forceinline__ double qp_row_s(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc, const int j)
+{
+    constexpr QpPlanS P = QpLayout<SD>::P;
+    constexpr int TI = P.row_task[R];
+    constexpr int i = P.row_local[R];
+    return jac<SD, TI>(S, tc, i, j);
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const TickArgs tk)
+{
+    extern __shared__ double lds[];
+    using LY = QpLayout<SD>;
+    constexpr int N = SD.n;
+    constexpr int NR = LY::NR, NRA = LY::NRA, NS = LY::NS;
+    constexpr QpPlanS P = LY::P;
+    constexpr int NTN = N * (N + 1) / 2;
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    double* slots = lds + LY::IMG_DOUBLES;
+    double* zs = slots + LY::O_Z * WAVE;
+    double* ys = slots + LY::O_Y * WAVE;
+    // one memory round trip: image + options, joint state and inputs (see pinv_solve_static_kernel)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    {
+        d2 img[LY::IMG_CHUNKS];
+        const d2* src = (const d2*)img_g;
+#pragma unroll
+        for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
+        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+        d2* dst = (d2*)lds;
+#pragma unroll
+        for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
+        rows_to_lds<N>(qv, zs, lane);
+        if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
+    }
+    __syncthreads();
+    const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
+    const QpTail* __restrict__ T = (const QpTail*)((const char*)lds + LY::TAIL_OFF);
+    const double* ysl = ys + lane * SD.n_y;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+
+    // FK and the state-dependent rows, once
+    TaskCache<SD> tc;
+    {
+        Kin<N> K;
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ysl, lane, K);
+        }
+        cache_task<SD, 0, true>(S, tk, K, z, ysl, lane, tc);
+    }
+
+    // P = H_v + sum_soft-eq J' diag(h_s) J,  g = sum J' diag(h_s) b;  bounds of the other rows -> LDS
+    double L[NTN], rd[N], v[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        v[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) L[tri(a, b)] = (a == b) ? T->mu * T->state_w[a] : 0.0;
+    }
+    qp_gather_s<SD, 0>(S, T, tk, tc, z, ysl, lane, L, v, slots);
+    ldl_factor_s<N>(L, rd);
+    ldl_solve_s<N>(L, rd, v);          // v0 = P^-1 g
+
+    int status = 0;
+    if constexpr (NR > 0) {
+        static_assert(NR <= QPS_MAX_ROWS, "too many active-set rows for a static QP kernel");
+        double* Qs = slots + LY::O_Q * WAVE;
+        double* lbs = slots + LY::O_LB * WAVE;
+        double* ubs = slots + LY::O_UB * WAVE;
+        double* c0s = slots + LY::O_C0 * WAVE;
+        double* Ys = slots + LY::O_YS * WAVE;
+        // Y_r = P^-1 a_r',  c0_r = a_r v0,  Q_rs = a_r Y_s (+ slack curvature on the diagonal)
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int TI = P.row_task[r];
+            double yr[N];
+            double c0 = 0.0;
+            if constexpr (shape_unit(SD, TI)) {
+                constexpr int col = SD.ucol[TI][P.row_local[r]] - 1;
+#pragma unroll
+                for (int j = 0; j < N; ++j) yr[j] = (j == col) ? 1.0 : 0.0;
+                c0 = v[col];
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    yr[j] = qp_row_s<SD, r>(S, tc, j);
+                    c0 = fma(yr[j], v[j], c0);
+                }
+            }
+            ldl_solve_s<N>(L, rd, yr);
+            c0s[r * WAVE + lane] = c0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) Ys[(r * N + j) * WAVE + lane] = yr[j];
+            // row r of Q: a_s . Y_r for s >= r  (symmetric; stored at tri(s, r))
+            static_for<r, NR>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int TS = P.row_task[s];
+                double acc;
+                if constexpr (shape_unit(SD, TS)) {
+                    constexpr int col = SD.ucol[TS][P.row_local[s]] - 1;
+                    acc = yr[col];
+                } else {
+                    acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc = fma(qp_row_s<SD, s>(S, tc, j), yr[j], acc);
+                }
+                if constexpr (s == r && SD.soft[TI] != 0) {
+                    constexpr int sk = P.slack_base[TI] + P.row_local[r];
+                    acc += 1.0 / (T->mu + T->slack_w[sk]);
+                }
+                Qs[tri(s, r) * WAVE + lane] = acc;
+            });
+        });
+        double nu[NRA];
+        status = gi_solve<NRA, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu);
+        // v = v0 + Y nu;  slack of soft inequality rows = -nu / h_s
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = fma(nu[r], Ys[(r * N + j) * WAVE + lane], v[j]);
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int TI = P.row_task[r];
+            if constexpr (SD.soft[TI] != 0) {
+                constexpr int sk = P.slack_base[TI] + P.row_local[r];
+                slots[(LY::O_SL + sk) * WAVE + lane] = -nu[r] / (T->mu + T->slack_w[sk]);
+            }
+        });
+    }
+    const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+    // slack of the folded rows: s = J v - b
+    double sl[LY::NSA];
+#pragma unroll
+    for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * WAVE + lane] : 0.0;
+    static_for<0, SD.n_tasks>([&](auto tc_) __attribute__((always_inline)) {
+        constexpr int TI = decltype(tc_)::value;
+        if constexpr (P.folded[TI]) {
+            constexpr int sb = P.slack_base[TI];
+            static_for<0, SD.m[TI]>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                double acc = -sl[sb + i];
+                if constexpr (shape_unit(SD, TI)) {
+                    constexpr int col = SD.ucol[TI][i] - 1;
+                    acc += v[col];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc = fma(jac<SD, TI>(S, tc, i, j), v[j], acc);
+                }
+                sl[sb + i] = acc;
+            });
+        }
+    });
+    // outputs through LDS (row-major rows, coalesced stores)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j] + bad;
+    if constexpr (NS > 0) {
+        double* so = slots + LY::O_SL * WAVE;
+        if (slack_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) so[lane * NS + k] = sl[k] + bad;
+        }
+    }
+    __syncthreads();
+    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+    if constexpr (NS > 0) {
+        if (slack_out != nullptr) rows_from_lds<NS>(slack_out + b0 * NS, rows_valid, slots + LY::O_SL * WAVE, lane);
+    }
+    if (status_out != nullptr && valid) status_out[b0 + lane] = status;
+}
+
+typedef hipError_t (*qp_static_fn)(const void*, const TickArgs&, long long, const double*, const double*, double*,
+                                   double*, int32_t*, hipStream_t);
+
+template <const ShapeDesc& SD>
+inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long long B, const double* q,
+                                   const double* y, double* dq, double* slack, int32_t* status, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
+    static_assert(shmem <= 160u * 1024u, "static QP kernel needs more LDS than a CU has");
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)qp_solve_static_kernel<SD>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((qp_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
+                       status, B, tk);
+    return hipGetLastError();
+}
+
+}  // namespace clik

@@ -211,6 +211,14 @@ int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* opts,
 int clik_qp_destroy(clik_qp* h);
 int clik_qp_n_vars(const clik_qp* h);   /* n_state + n_slack                     */
 int clik_qp_n_rows(const clik_qp* h);
+/* kernel serving the skill: an AOT shape name, "jit_<hash>" or "dynamic"       */
+const char* clik_qp_kernel_name(const clik_qp* h);
+/* as clik_shape_describe / clik_pinv_attach_kernel, for the QP controller: the
+ * shape-specialised QP kernel (soft equalities eliminated, active set over the
+ * remaining rows) is instantiated per skill structure; reactive_qp.py:283-298
+ * JIT-compiles its H/A/lbA/ubA functions at the same point.                   */
+int clik_qp_shape_describe(const clik_skill_desc* desc, char* buf, int cap);
+int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, const char* name);
 
 /* replaces solve() (reactive_qp.py:461-528).
  *   dq [B][n_q], dx [B][n_x] or NULL, slack [B][n_slack] or NULL  (device, out)

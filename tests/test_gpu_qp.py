@@ -141,3 +141,64 @@ def test_qp_custom_weights(iiwa_fk):
     rdq, _, rslack, _ = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y, weights=w)
     assert (status == 0).all()
     assert _rel(dq, rdq).max() < QP_RTOL and _rel(slack, rslack).max() < QP_RTOL
+
+
+@pytest.mark.parametrize("variant", ["aot", "jit", "dynamic"])
+def test_qp_kernel_variants_agree_with_oracle(iiwa_fk, variant, monkeypatch):
+    """The shape-specialised kernel (soft equalities eliminated, 7-row active set) from
+    the AOT table, the same template instantiated at run time, and the dynamic-shape
+    13-row kernel must all return the reference's minimiser."""
+    from oracle import clik_oracle
+    if variant == "jit":
+        monkeypatch.setenv("CLIK_NO_AOT", "1")
+    elif variant == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    if variant == "aot":
+        assert ctrl.kernel_name.startswith("qp_static_")
+    elif variant == "jit":
+        assert ctrl.kernel_name.startswith("jit_")
+    else:
+        assert ctrl.kernel_name == "dynamic"
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 130, seed=21, distribution="mixed")     # ragged last wave
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y)
+    assert (status == 0).all() and (rstatus == 0).all()
+    assert _rel(dq, rdq).max() < QP_RTOL and _rel(slack, rslack).max() < QP_RTOL
+
+
+def test_qp_soft_set_hard_equality_mix(ur5_fk):
+    """Rows of every kind in one QP: a hard VelocityEqualityConstraint (stays in the
+    active set as an equality), a soft 2-D SetConstraint on the tool position (active-set
+    rows with slack curvature), a soft joint-space EqualityConstraint (eliminated, unit
+    rows) and a soft tool-height equality with a matrix-free gain (eliminated, FK rows)."""
+    from oracle import clik_oracle
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    p_home = fk["chain"].fk_numeric(home)[:3, 3]
+    cons = [
+        cc.VelocityEqualityConstraint("wrist_rate", q[5], target=0.05, priority=0),
+        cc.SetConstraint("xy_box", p[:2], set_min=p_home[:2] - 0.02, set_max=p_home[:2] + 0.02, gain=2.0,
+                         priority=1, constraint_type="soft"),
+        cc.EqualityConstraint("posture", q[1:4] - home[1:4], gain=0.5, priority=2, constraint_type="soft"),
+        cc.EqualityConstraint("height", p[2] - (p_home[2] + 0.05), gain=1.5, priority=3, constraint_type="soft"),
+        cc.VelocitySetConstraint("speed", q, set_min=-np.full(6, 0.4), set_max=np.full(6, 0.4), priority=4),
+    ]
+    spec = cc.SkillSpecification("mix", t, q, constraints=cons)
+    ctrl = _controller(spec)
+    assert ctrl.kernel_name != "dynamic"
+    rng = np.random.default_rng(11)
+    Q = home + rng.normal(scale=0.08, size=(100, 6))
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q)
+    assert (status == 0).all() and (rstatus == 0).all()
+    assert np.abs(dq[:, 5] - 0.05).max() < 1e-12
+    assert _rel(dq, rdq).max() < QP_RTOL and _rel(slack, rslack).max() < QP_RTOL
+    hd, A, lb, ub = clik_oracle.qp_data_batch(spec, 0.0, Q)
+    for b in range(len(Q)):
+        prim, stat, sign = clik_oracle.kkt_residuals(hd[b], A[b], lb[b], ub[b], np.concatenate([dq[b], slack[b]]))
+        assert prim < KKT_TOL and stat < KKT_TOL and sign < KKT_TOL
