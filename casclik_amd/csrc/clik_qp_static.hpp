@@ -83,22 +83,30 @@ __device__ __forceinline__ void qp_ldl_solve(const double (&A)[NC * (NC + 1) / 2
 // active: one solve instead of one iteration each).  On return nu holds the signed
 // multipliers of the optimum.  Returns the status (0 optimal, 1 iteration cap,
 // 2 infeasible).  EXACT: nc == NC at compile time (no size guards).
-template <int NC, bool EXACT>
+// WARM: start from the rows violated at the unconstrained minimiser instead of the empty
+// working set (see the block below); n_vars bounds the size of that initial set.
+template <int NC, bool EXACT, bool WARM = false>
 __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs, const double* c0s,
                                         const uint32_t softeq, const int lane, const int nc_rt,
-                                        const int max_iter, const bool lane_valid, double (&nu)[NC])
+                                        const int max_iter, const bool lane_valid, double (&nu)[NC],
+                                        const int n_vars = NC)
 {
     constexpr int NT = NC * (NC + 1) / 2;
     const int nc = EXACT ? NC : nc_rt;
     // bounds stay in LDS (read once per iteration in the selection scan): keeping
     // them in registers next to the factor spills to scratch
     uint32_t W = softeq, up = 0u, eq = 0u;
-    double c[NC];
+    double c[NC], isc[NC];              // isc: violations are measured relative to max(1, |bounds|)
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         nu[i] = 0.0;
         c[i] = 0.0;
-        if ((EXACT || i < nc) && !(ubs[i * WAVE + lane] - lbs[i * WAVE + lane] > 0.0)) eq |= 1u << i;
+        isc[i] = 1.0;
+        if (EXACT || i < nc) {
+            const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
+            if (!(ubi - lbi > 0.0)) eq |= 1u << i;
+            isc[i] = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+        }
     }
     int status = 0;
     bool done = !lane_valid;
@@ -106,8 +114,92 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
     bool init = softeq != 0u;            // wave-uniform
     int p = 0;
     double sp = 1.0, bp = 0.0;
+#ifdef CLIK_QP_DIAG
+    int g_qp_diag_warm = 0;
+#endif
+    if constexpr (WARM) {
+        // Warm start.  The dual method may start from any S-pair (W, nu): rows of W linearly
+        // independent, the point optimal on {a_i v = b_i, i in W}, multipliers of the right
+        // sign.  Take W0 = rows violated at the unconstrained minimiser (each at the bound it
+        // violates), solve  Q_WW nu_W = b_W - c0_W,  drop the rows whose multiplier has the
+        // wrong sign and repeat until none does: a saturated instance (most joint-speed rows
+        // active) then needs one or two factorisations instead of one iteration per row.
+        // Lanes whose W0 is too large or numerically dependent fall back to the cold start.
+        uint32_t W0 = 0u, up0 = 0u;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (EXACT || i < nc) {
+                const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
+                const double c0 = (c0s != nullptr) ? c0s[i * WAVE + lane] : 0.0;
+                const double vlo = (lbi - c0) * isc[i], vhi = (c0 - ubi) * isc[i];
+                if (fmax(vlo, vhi) > 1e-11) {
+                    W0 |= 1u << i;
+                    if (vhi > vlo) up0 |= 1u << i;
+                    ++cnt;
+                }
+            }
+        }
+        if (cnt > n_vars || !lane_valid) W0 = 0u;
+        for (int pass = 0; pass <= NC; ++pass) {
+            if (__ballot(W0 != 0u) == 0ull) break;
+#ifdef CLIK_QP_DIAG
+            if (W0 != 0u) ++g_qp_diag_warm;
+#endif
+            double L[NT], rd[NC], r[NC], a[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const double wi = (double)((W0 >> i) & 1u);
+                a[i] = wi - 2.0 * wi * (double)((up0 >> i) & 1u);
+                const double bi = ((up0 >> i) & 1u) ? ubs[i * WAVE + lane] : lbs[i * WAVE + lane];
+                const double c0 = (c0s != nullptr && (EXACT || i < nc)) ? c0s[i * WAVE + lane] : 0.0;
+                r[i] = a[i] * (bi - c0);
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const double q = (EXACT || i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
+                    L[tri(i, j)] = (a[i] * a[j]) * q;
+                }
+                L[tri(i, i)] += 1.0 - a[i] * a[i];
+            }
+            // pivots must stay well above rounding: a (near-)dependent W0 shows up as a tiny pivot
+            double dmin = 1e300;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) dmin = fmin(dmin, L[tri(i, i)]);    // diagonal scale before ...
+            const double dscale = dmin;
+            qp_ldl_factor<NC, EXACT>(L, rd, nc);
+            bool sound = dscale > 0.0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) sound = sound && (L[tri(i, i)] > 1e-9 * dscale);                // ... and after
+            qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
+            uint32_t drop = 0u;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (((W0 >> i) & 1u) && !((eq >> i) & 1u) && !(r[i] >= 0.0)) drop |= 1u << i;
+            if (!sound) {
+                W0 = 0u;                    // cold start for this lane
+            } else if (drop != 0u) {
+                W0 &= ~drop;
+                up0 &= ~drop;
+            } else if (W0 != 0u) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) nu[i] = a[i] * r[i];
+                W = W0;
+                up = up0;
+                W0 = 0u;                    // settled
+            }
+        }
+    }
+#ifdef CLIK_QP_DIAG
+    int g_qp_diag_iters = 0;
+#endif
     for (int it = 0; it < max_iter; ++it) {
         if (__ballot(!done) == 0ull) break;
+#ifdef CLIK_QP_DIAG
+        if (!done) ++g_qp_diag_iters;
+#endif
         // (1) one pass over Q:  c = c0 + Q nu  and the masked Schur matrix  D Q_WW D.
         //     Masks are applied arithmetically (a_i = +-1 for active rows, 0 otherwise):
         //     per-lane bit tests as control flow would serialise the wave.
@@ -150,7 +242,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             for (int i = 0; i < NC; ++i) {
                 if ((EXACT || i < nc) && !((W >> i) & 1u)) {
                     const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                    const double iscale = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+                    const double iscale = isc[i];
                     const double vlo = (lbi - c[i]) * iscale, vhi = (c[i] - ubi) * iscale;
                     double v = fmax(vlo, vhi);
                     if (((eq >> i) & 1u) && v > 1e-11) v += 1e30;       // equalities take precedence
@@ -189,19 +281,22 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         double zn = qpp;
 #pragma unroll
         for (int i = 0; i < NC; ++i) zn = fma(-rhs[i], r[i], zn);
-        // (4) step lengths
-        double t1 = 1e300;
+        // (4) step lengths.  The ratio test keeps the best candidate as a fraction
+        //     (num / den, den > 0; first minimum wins) and divides once.
+        double t1n = 1.0, t1d = 0.0;        // den = 0: no candidate yet
         int l = -1;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             // candidate only for active inequality rows with r_i > 0 (a_i = 0 on inactive rows)
             const bool cand_ok = (a[i] != 0.0) && !((eq >> i) & 1u) && r[i] > 1e-14;
-            const double mu_i = a[i] * nu[i];
-            const double cand = cand_ok ? fmax(mu_i, 0.0) / r[i] : 1e300;
-            const bool better = cand < t1;
-            t1 = better ? cand : t1;
+            const double num = fmax(a[i] * nu[i], 0.0);
+            // num / r_i < t1n / t1d   <=>   num * t1d < t1n * r_i      (both denominators positive)
+            const bool better = cand_ok && (t1d == 0.0 || num * t1d < t1n * r[i]);
+            t1n = better ? num : t1n;
+            t1d = better ? r[i] : t1d;
             l = better ? i : l;
         }
+        const double t1 = (l >= 0) ? t1n / t1d : 1e300;
         const double gap = bp - sp * cp;
         const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
         const double t2 = has_primal ? gap / zn : 1e300;
@@ -231,6 +326,9 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         }
     }
     if (!done) status = 1;
+#ifdef CLIK_QP_DIAG
+    status |= (g_qp_diag_iters << 8) | (g_qp_diag_warm << 16);
+#endif
     return status;
 }
 
@@ -514,7 +612,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
             });
         });
         double nu[NRA];
-        status = gi_solve<NRA, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu);
+        status = gi_solve<NRA, true, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu, N);
         // v = v0 + Y nu;  slack of soft inequality rows = -nu / h_s
 #pragma unroll
         for (int r = 0; r < NR; ++r)
