@@ -509,15 +509,20 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     finish_pinv_shape(*S, opts);
     const clik::ShapeDesc& h = S->shape;
     const std::string o = shape_to_string(h);
-    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 1;
+    // (kStaticMaxSets of clik_pinv_kernels.hpp: 2^3 mode bodies per kernel)
+    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 3;
     // the static plan handles the doubly processed first EqualityConstraint only when
     // it owns a wide, state-dependent factor (clik_pinv_static.hpp)
-    for (unsigned act = 0; act < 2u && eligible; ++act) {
-        int r = 0;
+    for (unsigned act = 0; eligible && act < (1u << S->n_sets); ++act) {
+        int r = 0, set_idx = 0;
         for (int ti = 0; ti < h.n_tasks; ++ti) {
             const int cls = h.cls[ti];
             if (cls == CLIK_CLS_VELSET) continue;
-            if (cls == CLIK_CLS_SET && !(act & 1u)) continue;       // (at most one set: bit 0)
+            if (cls == CLIK_CLS_SET) {
+                const bool active = (act >> set_idx) & 1u;
+                ++set_idx;
+                if (!active) continue;
+            }
             const bool conv = cls == CLIK_CLS_SET && ti == h.n_tasks - 1 && h.conv_last;
             const bool contributes = cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ || conv;
             if (contributes && r == 0 && cls == CLIK_CLS_EQ) {
@@ -526,7 +531,6 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
             }
             r += h.m[ti];
         }
-        if (S->n_sets == 0) break;
     }
     delete S;
     if ((int)o.size() + 1 > cap) return fail(CLIK_EINVAL, "buffer too small");

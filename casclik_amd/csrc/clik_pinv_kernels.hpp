@@ -470,6 +470,25 @@ constexpr int shape_n_sets(const ShapeDesc& sd)
     return k;
 }
 
+// activation mask of the k-th mode in the reference's scan order (pseudo_inverse.py:107-130:
+// sorted by number of active sets, then by value; set 0 = bit 0) - same table as the host's
+constexpr unsigned shape_mode_act(const ShapeDesc& sd, int k)
+{
+    const int ns = shape_n_sets(sd);
+    int idx = 0;
+    for (int pc = 0; pc <= ns; ++pc)
+        for (unsigned v = 0; v < (1u << ns); ++v) {
+            int c = 0;
+            for (int b = 0; b < ns; ++b) c += (v >> b) & 1u;
+            if (c == pc) {
+                if (idx == k) return v;
+                ++idx;
+            }
+        }
+    return 0u;
+}
+constexpr int kStaticMaxSets = 3;       // 8 mode bodies per kernel
+
 // ---- one controller tick: FK once, then the mode scan (pseudo_inverse.py:530-555)
 template <int N, class SH>
 __device__ __forceinline__ void pinv_tick(const DevSkill* __restrict__ S, const TickArgs& tk,
@@ -702,7 +721,7 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
                                                  const bool valid, double (&vout)[SD.n], int& acc_mode)
 {
     constexpr int N = SD.n;
-    static_assert(StaticLayout<SD>::n_sets <= 1, "static shapes support at most one SetConstraint");
+    static_assert(StaticLayout<SD>::n_sets <= kStaticMaxSets, "too many SetConstraints for a static shape");
     // FK and the state-dependent task rows once per tick; the FK state dies here
     TaskCache<SD> tc;
     {
@@ -718,29 +737,22 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     acc_mode = -1;
 #pragma unroll
     for (int j = 0; j < N; ++j) vout[j] = 0.0;
-    {
-        double v[N];
-        const bool ok = pinv_mode_static<SD, 0u>(S, tk, tc, z, ys, lane, v);
-        if (!done && ok) {
-            done = true;
-            acc_mode = 0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) vout[j] = v[j];
-        }
-    }
-    CLIK_STAMP(3);
-    if constexpr (StaticLayout<SD>::n_sets == 1) {
-        if (__ballot(!done) != 0ull) {
+    // mode scan in the reference's order; a later mode runs only while some lane still has none
+    static_for<0, (1 << StaticLayout<SD>::n_sets)>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr unsigned ACT = shape_mode_act(SD, k);
+        if (k == 0 || __ballot(!done) != 0ull) {
             double v[N];
-            const bool ok = pinv_mode_static<SD, 1u>(S, tk, tc, z, ys, lane, v);
+            const bool ok = pinv_mode_static<SD, ACT>(S, tk, tc, z, ys, lane, v);
             if (!done && ok) {
                 done = true;
-                acc_mode = 1;
+                acc_mode = k;
 #pragma unroll
                 for (int j = 0; j < N; ++j) vout[j] = v[j];
             }
         }
-    }
+        if constexpr (k == 0) { CLIK_STAMP(3); }
+    });
 }
 
 template <const ShapeDesc& SD>

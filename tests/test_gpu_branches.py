@@ -156,3 +156,28 @@ def test_multidim_set_without_option_is_refused(iiwa_fk):
     ctrl = cc.PseudoInverseController(skill_spec=spec)          # multidim_sets defaults to False
     with pytest.raises(NotImplementedError, match="multidim_sets"):
         ctrl.setup_problem_functions()
+
+
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_three_sets_eight_modes(ur5_fk, kernel, monkeypatch):
+    """Three 1-D SetConstraints between two equality tasks: 8 modes scanned in the
+    reference's order (pseudo_inverse.py:107-130), by the shape-specialised kernel
+    (run-time instantiated, 8 mode bodies) and by the dynamic-shape kernel."""
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    cons = [cc.EqualityConstraint("pos", p - np.array([0.35, 0.2, 0.45]), gain=4.0, priority=1)]
+    for k, i in enumerate((0, 1, 3)):
+        cons.append(cc.SetConstraint("lim_%d" % i, q[i], set_min=0.25 * lo[i], set_max=0.25 * hi[i], gain=1.0 + k,
+                                     priority=2 + k))
+    cons.append(cc.EqualityConstraint("posture", q[2] - 0.3, gain=0.7, priority=9))
+    spec = cc.SkillSpecification("three_sets", t, q, constraints=cons)
+    rng = np.random.default_rng(17)
+    Q = rng.uniform(0.4 * lo, 0.4 * hi, size=(300, 6))       # all 8 modes occur (oracle: 168/19/46/37/8/4/13/5)
+    ctrl = _check(spec, None, Q, min_modes=8)
+    assert ctrl.n_modes == 8
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
