@@ -248,6 +248,29 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
         }
         if (fl & CLIK_ROW_HAS_T) S->shape.all_affine = S->shape.all_affine;  // (time slots are run-time data)
     }
+    // feature-coefficient patterns of the rows in task order (what the static kernels index:
+    // rows of static shapes are contiguous); skills with other row layouts never match a static shape
+    for (int r = 0; r < clik::SHAPE_MAX_ROWS; ++r) S->shape.row_nz[r] = S->shape.row_one[r] = 0u;
+    {
+        int r = 0;
+        for (int ti = 0; ti < d->n_tasks && ti < clik::SHAPE_MAX_TASKS; ++ti) {
+            const clik_task& t = d->tasks[ti];
+            for (int i = 0; i < t.m && r < clik::SHAPE_MAX_ROWS; ++i, ++r) {
+                if (t.out_kind[i] != CLIK_OUT_AFFINE) continue;
+                const clik_row& row = d->rows[t.out_row0[i]];
+                unsigned nz = 0u, one = 0u;
+                auto mark = [&](double v, int bit) {
+                    if (v != 0.0) nz |= 1u << bit;
+                    if (v == 1.0) one |= 1u << bit;
+                };
+                if (row.flags & CLIK_ROW_HAS_P) for (int k = 0; k < 3; ++k) mark(row.b[k], k);
+                if (row.flags & CLIK_ROW_HAS_R) for (int k = 0; k < 9; ++k) mark(row.g[k], 3 + k);
+                if (row.flags & CLIK_ROW_HAS_O) for (int k = 0; k < 3; ++k) mark(row.h[k], 12 + k);
+                S->shape.row_nz[r] = nz;
+                S->shape.row_one[r] = one;
+            }
+        }
+    }
     S->shape.uses_fk = any_fk ? 1 : 0;
     S->shape.quat_src = any_o ? d->quat_src : 0;
     S->lds_slots = last_row;   // (temporarily) number of used affine rows, for the warm-up ranges
@@ -491,9 +514,15 @@ static std::string shape_to_string(const clik::ShapeDesc& h)
     }
     o += "}, ";
     num(h.qp);
-    o += "{";
-    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.soft[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
-    o += "}}";
+    arr(h.soft, clik::SHAPE_MAX_TASKS, nt);
+    auto uarr = [&](const unsigned* a, int nn, bool last) {
+        o += "{";
+        for (int i = 0; i < nn; ++i) { o += std::to_string(a[i]) + "u"; if (i + 1 < nn) o += ", "; }
+        o += last ? "}" : "}, ";
+    };
+    uarr(h.row_nz, clik::SHAPE_MAX_ROWS, false);
+    uarr(h.row_one, clik::SHAPE_MAX_ROWS, true);
+    o += "}";
     return o;
 }
 

@@ -27,6 +27,7 @@ constexpr int WAVE = 64;
 // still come from the descriptor.  The dynamic fallback reads the same fields
 // from DevSkill at run time.
 constexpr int SHAPE_MAX_TASKS = 6;
+constexpr int SHAPE_MAX_ROWS = SHAPE_MAX_TASKS * CLIK_MAX_M;
 struct ShapeDesc {
     int n;                          // n_q + n_x
     int n_tasks;
@@ -53,6 +54,10 @@ struct ShapeDesc {
     // ReactiveQPController shapes (0 in pseudo-inverse shapes)
     int qp;                         // 1: shape of a QP controller (the pinv option fields are 0)
     int soft[SHAPE_MAX_TASKS];      // constraint_type "soft": the rows carry slack variables
+    // sparsity pattern of the tool-frame feature coefficients [b0..b2 | g0..g8 | h0..h2] of every row
+    // (rows in task order): bit k set = coefficient k is non-zero / is exactly 1.0
+    unsigned row_nz[SHAPE_MAX_ROWS];
+    unsigned row_one[SHAPE_MAX_ROWS];
 };
 
 constexpr bool shape_unit(const ShapeDesc& sd, int ti) { return sd.const_j[ti] != 0 && sd.m[ti] > 0 && sd.ucol[ti][0] > 0; }
@@ -122,6 +127,8 @@ inline bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
             if (a.ucol[i][k] != b.ucol[i][k]) return false;
     for (int j = 0; j < a.nj; ++j)
         if (a.jtype[j] != b.jtype[j] || a.jq[j] != b.jq[j] || a.jflags[j] != b.jflags[j]) return false;
+    for (int r = 0; r < SHAPE_MAX_ROWS; ++r)
+        if (a.row_nz[r] != b.row_nz[r] || a.row_one[r] != b.row_one[r]) return false;
     return true;
 }
 

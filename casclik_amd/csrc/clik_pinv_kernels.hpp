@@ -755,8 +755,14 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     });
 }
 
+// (experiment switch: -DCLIK_OCC2 caps the one-wave kernel at 256 VGPRs = two waves per SIMD)
+#ifdef CLIK_OCC2
+#define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define CLIK_OCC_ATTR
+#endif
 template <const ShapeDesc& SD>
-__global__ __launch_bounds__(WAVE) void pinv_solve_static_kernel(
+__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {

@@ -320,9 +320,20 @@ __device__ __forceinline__ void orientation_feature_s(const Img<SD>* __restrict_
             K.M[3 * i + k] = R[3 * i] * Rd[3 * k] + R[3 * i + 1] * Rd[3 * k + 1] + R[3 * i + 2] * Rd[3 * k + 2];
 }
 
-// value, state gradient and time derivative of one affine row; feature flags
-// and the number of input_var terms are compile-time
-template <int N, int FLAGS, int NY, bool HAS_T>
+// value, state gradient and time derivative of one affine row; feature flags,
+// the number of input_var terms and the sparsity pattern of the feature
+// coefficients are compile-time.  NZ / ONE: bit k set = coefficient k of
+// [b0..b2 | g0..g8 | h0..h2] is non-zero / exactly 1 (ShapeDesc::row_nz, row_one):
+// a pose task's rows pick single components (b = e_i or h = e_i), so most
+// products and most coefficient reads disappear.
+template <unsigned NZ, unsigned ONE, int K>
+__device__ __forceinline__ double row_coef(const double& stored)
+{
+    if constexpr (((ONE >> K) & 1u) != 0) return 1.0;
+    else return stored;
+}
+
+template <int N, int FLAGS, int NY, bool HAS_T, unsigned NZ = 0x7fffu, unsigned ONE = 0u>
 __device__ __forceinline__ double row_eval_s(const clik_row& r, const int n_tslots, const TickArgs& tk,
                                              const Kin<N>& K, const double (&z)[N], const double* ys,
                                              const int lane, double (&g)[N], double& dt)
@@ -339,43 +350,65 @@ __device__ __forceinline__ double row_eval_s(const clik_row& r, const int n_tslo
             v = fma(a, z[j], v);
         }
     }
-    constexpr bool fk = (FLAGS & (CLIK_ROW_HAS_P | CLIK_ROW_HAS_R | CLIK_ROW_HAS_O)) != 0;
+    constexpr bool has_p = (FLAGS & CLIK_ROW_HAS_P) != 0 && (NZ & 0x7u) != 0;
+    constexpr bool has_r = (FLAGS & CLIK_ROW_HAS_R) != 0 && (NZ & 0xff8u) != 0;
+    constexpr bool has_o = (FLAGS & CLIK_ROW_HAS_O) != 0 && (NZ & 0x7000u) != 0;
     double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
-    if constexpr ((FLAGS & CLIK_ROW_HAS_P) != 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            lin[i] = r.b[i];
-            v = fma(r.b[i], K.p[i], v);
-        }
-    }
-    if constexpr ((FLAGS & CLIK_ROW_HAS_R) != 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double rc[3] = {K.R[c], K.R[3 + c], K.R[6 + c]};
-            const double gc[3] = {r.g[c], r.g[3 + c], r.g[6 + c]};
-            double u[3];
-            cross3(rc, gc, u);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                ang[i] += u[i];
-                v = fma(gc[i], rc[i], v);
+    if constexpr (has_p) {
+        static_for<0, 3>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (((NZ >> i) & 1u) != 0) {
+                lin[i] = row_coef<NZ, ONE, i>(r.b[i]);
+                v = fma(lin[i], K.p[i], v);
             }
-        }
+        });
     }
-    if constexpr ((FLAGS & CLIK_ROW_HAS_O) != 0) {
+    if constexpr (has_r) {
+        static_for<0, 3>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            constexpr unsigned colmask = (1u << (3 + c)) | (1u << (6 + c)) | (1u << (9 + c));
+            if constexpr ((NZ & colmask) != 0) {
+                const double rc[3] = {K.R[c], K.R[3 + c], K.R[6 + c]};
+                const double gc[3] = {r.g[c], r.g[3 + c], r.g[6 + c]};
+                double u[3];
+                cross3(rc, gc, u);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double mh = K.M[i] * r.h[0] + K.M[3 + i] * r.h[1] + K.M[6 + i] * r.h[2];
-            ang[i] += -0.5 * (K.tr * r.h[i] - mh);
-            v = fma(r.h[i], K.o[i], v);
-        }
+                for (int i = 0; i < 3; ++i) {
+                    ang[i] += u[i];
+                    v = fma(gc[i], rc[i], v);
+                }
+            }
+        });
     }
-    if constexpr (fk) {
+    if constexpr (has_o) {
+        double hh[3] = {0, 0, 0};
+        static_for<0, 3>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (((NZ >> (12 + i)) & 1u) != 0) {
+                hh[i] = row_coef<NZ, ONE, 12 + i>(r.h[i]);
+                v = fma(hh[i], K.o[i], v);
+            }
+        });
+        static_for<0, 3>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            double mh = 0.0;
+            static_for<0, 3>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (((NZ >> (12 + k)) & 1u) != 0) mh = fma(K.M[3 * k + i], hh[k], mh);
+            });
+            if constexpr (((NZ >> (12 + i)) & 1u) != 0) ang[i] += -0.5 * (K.tr * hh[i] - mh);
+            else ang[i] += 0.5 * mh;
+        });
+    }
+    if constexpr (has_p || has_r || has_o) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             double s = g[j];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s = fma(K.Jv[i][j], lin[i], fma(K.Jw[i][j], ang[i], s));
+            static_for<0, 3>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (has_p && ((NZ >> i) & 1u) != 0) s = fma(K.Jv[i][j], lin[i], s);
+                if constexpr (has_r || has_o) s = fma(K.Jw[i][j], ang[i], s);
+            });
             g[j] = s;
         }
     }
@@ -448,15 +481,16 @@ __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const
     constexpr int M = SD.m[TI];
     constexpr int row0 = shape_row_base(SD, TI);
     const int nts = S->n_tslots;
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
+    static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr unsigned NZ = SD.row_nz[row0 + i], ONE = SD.row_one[row0 + i];
         double g[N], dt;
-        e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI], SD.has_t[TI] != 0>(S->rows[row0 + i], nts, tk, K, z, ys,
-                                                                                lane, g, dt);
+        e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI], SD.has_t[TI] != 0, NZ, ONE>(S->rows[row0 + i], nts, tk, K,
+                                                                                         z, ys, lane, g, dt);
         Jt[i] = dt;
 #pragma unroll
         for (int j = 0; j < N; ++j) J[i][j] = g[j];
-    }
+    });
 }
 
 template <int M, bool MATRIX>

@@ -47,5 +47,3 @@ for k, nm in enumerate(names):
     print("  %-40s %8.0f  %5.1f %%" % (nm, np.median(d[:, k]), 100 * np.median(d[:, k]) / np.median(tot)))
 print("  prologue split: kernel args %.0f | global loads %.0f | LDS transpose + barrier %.0f" % (
     np.median(st[:, 6] - st[:, 0]), np.median(st[:, 7] - st[:, 6]), np.median(st[:, 1] - st[:, 7])))
-print("  launch span (first block start -> last block end): %.0f cycles; block start skew p50 %.0f / max %.0f" % (
-    st[:, 5].max() - st[:, 0].min(), np.median(st[:, 0] - st[:, 0].min()), (st[:, 0] - st[:, 0].min()).max()))
