@@ -758,6 +758,8 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 // (experiment switch: -DCLIK_OCC2 caps the one-wave kernel at 256 VGPRs = two waves per SIMD)
 #ifdef CLIK_OCC2
 #define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#elif defined(CLIK_OCC1)
+#define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
 #define CLIK_OCC_ATTR
 #endif
@@ -812,7 +814,12 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
     double vout[N];
     int acc_mode;
-    pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+    // Register copy of the skill image: scalar replacement keeps exactly the fields the tick
+    // reads, and the scheduling barrier keeps their LDS reads together here (one wait) instead
+    // of next to each use (measured: ~40 separate ~100-cycle LDS stalls per tick otherwise).
+    const Img<SD> Sreg = *S;
+    __builtin_amdgcn_sched_barrier(0);
+    pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
     CLIK_STAMP(4);
 
     __syncthreads();
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
 // if admissible, else -1.  The tick costs max(mode 0, mode 1) instead of their
 // sum; the redundant FK of wave 1 runs on an otherwise idle SIMD.
 template <const ShapeDesc& SD>
-__global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
+__global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
@@ -876,11 +883,13 @@ __global__ __launch_bounds__(2 * WAVE) void pinv_solve_static_mp_kernel(
         }
     }
     __syncthreads();
-    const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
+    const Img<SD> Sreg = *(const Img<SD>*)lds;       // register copy, see pinv_solve_static_kernel
+    const Img<SD>* __restrict__ S = &Sreg;
     const double* ysl = ys + lane * SD.n_y;
     double z[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    __builtin_amdgcn_sched_barrier(0);
     TaskCache<SD> tc;
     {
         Kin<N> K;
@@ -946,6 +955,8 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     double z[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    const Img<SD> Sreg = *S;                         // register copy, see pinv_solve_static_kernel
+    __builtin_amdgcn_sched_barrier(0);
     double vout[N];
     int acc_mode = -1;
 #pragma unroll
@@ -957,7 +968,7 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
         asm volatile("" ::: "memory");
         // time terms are read in place ([values | derivatives], 2*nts doubles per tick, never past them)
         const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
-        pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+        pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             double d = vout[j];

@@ -531,12 +531,16 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
         if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     }
     __syncthreads();
-    const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
-    const QpTail* __restrict__ T = (const QpTail*)((const char*)lds + LY::TAIL_OFF);
+    // register copies of the skill image and the QP options (see pinv_solve_static_kernel)
+    const Img<SD> Sreg = *(const Img<SD>*)lds;
+    const QpTail Treg = *(const QpTail*)((const char*)lds + LY::TAIL_OFF);
+    const Img<SD>* __restrict__ S = &Sreg;
+    const QpTail* __restrict__ T = &Treg;
     const double* ysl = ys + lane * SD.n_y;
     double z[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    __builtin_amdgcn_sched_barrier(0);
 
     // FK and the state-dependent rows, once
     TaskCache<SD> tc;
