@@ -49,6 +49,9 @@ def parse():
                     help="replay the K ticks from one hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--allgather", type=int, default=0,
                     help="also all-gather dq over RCCL every tick (reported separately)")
+    ap.add_argument("--ticks-per-launch", type=int, default=1,
+                    help="K > 1: the on-device rollout (K ticks of solve -> clamp -> Euler per launch, "
+                         "SURVEY.md 8(d) 'launch-amortised'); steps must be a multiple of K")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -146,7 +149,20 @@ def main():
     if args.allgather and world > 1:
         gathered = torch.empty((world * B, Q.shape[1]), dtype=torch.float64, device=dev)
 
-    tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ)
+    TPL = args.ticks_per_launch
+    if TPL > 1:
+        if args.workload == "qp" or args.steps % TPL or args.warmup % TPL:
+            raise SystemExit("--ticks-per-launch needs a pinv workload and steps/warmup divisible by it")
+        times = [0.0] * TPL
+        state = {"q": Qd}
+
+        def tick():         # one launch = TPL ticks; the state is carried from launch to launch
+            state["q"], _, _ = ctrl.rollout_batch(times, state["q"], input_var=Yd, dt=1e-3, max_speed=2.0)
+        args.graph = 0
+        args.steps //= TPL
+        args.warmup //= TPL
+    else:
+        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ)
 
     def step():
         tick()
@@ -191,6 +207,7 @@ def main():
         wall, dev_ms = float(tt[0]), float(tt[1])
 
     if rank == 0:
+        K, W = K * TPL, W * TPL          # report in ticks
         total_steps = world * B * K
         value = total_steps / wall
         kern_us = dev_ms * 1e3 / K
@@ -209,7 +226,8 @@ def main():
                              "pose": "BASELINE config 2: %d x iiwa, single 6-D pose task" % B,
                              "qp": "BASELINE config 4: %d x iiwa ReactiveQPController" % B}[args.workload],
                 "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
-                "launch": "hipGraph of K ticks" if graph is not None else "eager, one launch per tick",
+                "launch": ("hipGraph of K ticks" if graph is not None else "eager, one launch per tick") if TPL == 1
+                          else "on-device rollout, %d ticks per launch (solve -> clamp -> Euler)" % TPL,
                 "ticks_per_s": K / wall, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

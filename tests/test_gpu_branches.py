@@ -181,3 +181,58 @@ def test_three_sets_eight_modes(ur5_fk, kernel, monkeypatch):
     ctrl = _check(spec, None, Q, min_modes=8)
     assert ctrl.n_modes == 8
     assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
+
+
+def _path_following_skill(fk):
+    """Path following with a virtual variable (cart_on_track_1D notebook
+    cells 56,75): the tool follows the line p0 + d*s, the path parameter s is a virtual
+    state advanced by a VelocityEqualityConstraint and kept in [0, 1] by a SetConstraint."""
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    s = cs.MX.sym("s", 1)
+    p = fk["T_fk"](q)[:3, 3]
+    p0, d = np.array([0.3, 0.1, 0.4]), np.array([0.2, -0.1, 0.05])
+    cons = [cc.EqualityConstraint("follow", p - (p0 + d * s), gain=2.0, priority=1, constraint_type="soft"),
+            cc.VelocityEqualityConstraint("progress", s, target=0.05, priority=0),
+            cc.SetConstraint("s_range", s, set_min=0.0, set_max=1.0, priority=2)]
+    return cc.SkillSpecification("path", t, q, virtual_var=s, constraints=cons)
+
+
+def test_virtual_variable_pinv(ur5_fk):
+    from oracle import clik_oracle
+    spec = _path_following_skill(ur5_fk)
+    rng = np.random.default_rng(3)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.2, size=(150, 6))
+    X = rng.uniform(-0.1, 1.1, size=(150, 1))
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    assert ctrl.kernel_name == "dynamic"            # virtual variables run the dynamic-shape kernel
+    dq, dx, mode = ctrl.solve_batch(0.0, Q, virtual_var=X)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
+    assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
+    assert dx.shape == (150, 1)
+    assert _rel(np.hstack([dq, dx]), ref).max() < PINV_RTOL
+    # single-instance API returns the virtual velocity as the second result (pseudo_inverse.py:553-555)
+    rob, virt, _ = ctrl.solve(0.0, Q[0], virtual_var=X[0])
+    assert np.allclose(rob.toarray()[:, 0], ref[0, :6], atol=1e-9) and np.allclose(virt.toarray()[:, 0], ref[0, 6:], atol=1e-9)
+
+
+def test_virtual_variable_qp(ur5_fk):
+    from oracle import clik_oracle
+    spec = _path_following_skill(ur5_fk)
+    rng = np.random.default_rng(4)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.2, size=(150, 6))
+    X = rng.uniform(-0.1, 1.1, size=(150, 1))
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    assert ctrl.kernel_name == "dynamic"
+    dq, dx, slack, status = ctrl.solve_batch(0.0, Q, virtual_var=X)
+    rdq, rdx, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, X=X)
+    # s beyond 1 with the hard progress rate contradicts the hard range set: infeasible on both sides
+    assert np.array_equal(status == 2, rstatus == 2) and (rstatus == 2).sum() > 0
+    ok = rstatus == 0
+    assert _rel(dq[ok], rdq[ok]).max() < 1e-8 and _rel(dx[ok], rdx[ok]).max() < 1e-8
+    assert _rel(slack[ok], rslack[ok]).max() < 1e-8
