@@ -665,12 +665,17 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         }
     }
     {
-        // Speculative two-wave evaluation of both modes (pinv_solve_static_mp_kernel) for
-        // batches that leave SIMDs idle: the tick costs max(mode 0, mode 1) instead of
-        // mode 0 [+ mode 1].  Measured on the config-3 stack at 16384 instances: 8.74 ->
-        // 7.76 us ("mixed") and 7.86 -> 7.64 us ("interior").  CLIK_MODE_PARALLEL=0 disables it.
+        // Small batches (fewer wavefronts than SIMDs) put more than one wave on the same 64
+        // instances.  mode_parallel bit 0: speculative two-wave evaluation of both modes
+        // (pinv_solve_static_mp_kernel; measured 8.0 -> 7.2 us on the config-3 stack, "mixed").
+        // Bit 1: role split (pinv_solve_static_split_kernel: main + helper wave per mode, 4 waves);
+        // it shortens the critical wave by 11 % in cycles but measures the same wall time as the
+        // two-wave kernel (6.42 vs 6.47 us), so it is opt-in: CLIK_ROLE_SPLIT=1.
+        // CLIK_MODE_PARALLEL=0 disables both.
         const char* mp = getenv("CLIK_MODE_PARALLEL");
+        const char* rs = getenv("CLIK_ROLE_SPLIT");
         h->mode_parallel = (mp && mp[0] == '0') ? 0 : 1;
+        if (h->mode_parallel && rs && rs[0] == '1') h->mode_parallel |= 2;
     }
     h->d_tterms = nullptr;
     h->d_tterms_cap = 0;

@@ -658,6 +658,15 @@ __device__ unsigned long long g_clik_stamps[8 * 4096];
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_clik_stamps[blockIdx.x * 8 + (k)] = t_;  \
         __builtin_amdgcn_sched_barrier(0);                                                    \
     } while (0)
+// stamp taken by wave w of a multi-wave block (threadIdx.x == 64 w writes)
+#define CLIK_STAMP_W(w, k)                                                                    \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        if (threadIdx.x == 64 * (w) && blockIdx.x < 4096) g_clik_stamps[blockIdx.x * 8 + (k)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
 // stamp after everything in flight has landed (perturbs the schedule: shares only)
 #define CLIK_STAMP_DRAINED(k)                                                                 \
     do {                                                                                      \
@@ -666,6 +675,7 @@ __device__ unsigned long long g_clik_stamps[8 * 4096];
     } while (0)
 #else
 #define CLIK_STAMP(k)
+#define CLIK_STAMP_W(w, k)
 #define CLIK_STAMP_DRAINED(k)
 #endif
 
@@ -927,6 +937,153 @@ __global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_k
     }
 }
 
+// ---- role-split kernel for small batches -----------------------------------------------------
+// With fewer wavefronts than SIMDs (<= 16384 instances on 1024 SIMDs) a tick is the serial fp64
+// chain of ONE wave.  This variant spends the idle SIMDs of the CU on the same 64 instances:
+// per mode a MAIN wave (task solves) and a HELPER wave (builds and factors the Gram-form stack
+// lam I + Ja'Ja that the last task projects through, which depends only on the Jacobians), and
+// with one SetConstraint both modes speculatively (as pinv_solve_static_mp_kernel): 2 or 4 waves
+// per block.  Eligible when every mode has exactly one Gram consumer (ModePlan::helper_ok).
+template <const ShapeDesc& SD, int K = 0>
+constexpr bool shape_split_ok()
+{
+    constexpr int ns = shape_n_sets(SD);
+    if constexpr (ns > 1) return false;
+    else if constexpr (K >= (1 << ns)) return true;
+    else return Plan<SD, shape_mode_act(SD, K)>::mode.helper_ok && shape_split_ok<SD, K + 1>();
+}
+
+template <const ShapeDesc& SD>
+struct SplitLayout {
+    static constexpr int N = SD.n;
+    static constexpr int NM = 1 << shape_n_sets(SD);          // modes (1 or 2)
+    static constexpr int NW = 2 * NM;                          // waves per block
+    static constexpr int XCH = N * (N + 1) / 2 + N;            // slots of one published factor
+    static constexpr int SLOTS = N + (SD.n_y > 0 ? SD.n_y : 0) + NM * XCH + (NM > 1 ? N + 1 : 0);
+    static constexpr size_t LDS_BYTES = ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)SLOTS * WAVE) * sizeof(double);
+};
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(SplitLayout<SD>::NW * WAVE) void pinv_solve_static_split_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
+{
+    extern __shared__ double lds[];
+    CLIK_STAMP_W(0, 0);
+    using LY = SplitLayout<SD>;
+    constexpr int N = SD.n;
+    constexpr int NM = LY::NM, NW = LY::NW;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
+    double* ys = zs + N * WAVE;
+    double* xch = ys + (SD.n_y > 0 ? SD.n_y : 0) * WAVE;      // NM published factors
+    double* res = xch + NM * LY::XCH * WAVE;                  // mode 1 result: v (N slots) + ok (1 slot)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    {
+        // the waves share the prologue loads: image chunks round-robin, q by wave 0, y by the last wave
+        constexpr int CH = StaticLayout<SD>::IMG_CHUNKS;
+        constexpr int PER = (CH + NW - 1) / NW;
+        const d2* src = (const d2*)img_g;
+        d2* dst = (d2*)lds;
+        d2 img[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int ck = k * NW + wave;
+            img[k] = src[(ck < CH ? ck : CH - 1) * WAVE + lane];
+        }
+        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
+        if (wave == 0) stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        if constexpr (SD.n_y > 0) {
+            if (wave == NW - 1) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int ck = k * NW + wave;
+            if (ck < CH) dst[ck * WAVE + lane] = img[k];
+        }
+        if (wave == 0) rows_to_lds<N>(qv, zs, lane);
+        if constexpr (SD.n_y > 0) {
+            if (wave == NW - 1) rows_to_lds<SD.n_y>(yv, ys, lane);
+        }
+    }
+    __syncthreads();
+    CLIK_STAMP_W(0, 1);
+    const Img<SD> Sreg = *(const Img<SD>*)lds;       // register copy, see pinv_solve_static_kernel
+    const Img<SD>* __restrict__ S = &Sreg;
+    const double* ysl = ys + lane * SD.n_y;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    __builtin_amdgcn_sched_barrier(0);
+    TaskCache<SD> tc;
+    {
+        Kin<N> K;
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ysl, lane, K);
+        }
+        cache_task<SD, 0>(S, tk, K, z, ysl, lane, tc);
+    }
+    CLIK_STAMP_W(0, 2);
+    CLIK_STAMP_W(1, 6);
+    double v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = 0.0;
+    bool ok = false;
+    const int my_mode = wave >> 1;
+    const bool helper = (wave & 1) != 0;
+    static_for<0, NM>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr unsigned ACT = shape_mode_act(SD, m);
+        if (my_mode == m) {
+            double* mx = xch + m * LY::XCH * WAVE;
+            if (helper) {
+                helper_mode_static<SD, ACT>(S, tk, tc, z, ysl, lane, mx);
+                CLIK_STAMP_W(1, 7);
+                __syncthreads();                    // (matches the barrier inside the main wave's projection)
+            } else {
+                ok = pinv_mode_static<SD, ACT, ROLE_MAIN>(S, tk, tc, z, ysl, lane, v, mx);
+            }
+        }
+    });
+    CLIK_STAMP_W(0, 3);
+    if constexpr (NM > 1) {
+        if (wave == 2) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) res[j * WAVE + lane] = v[j];
+            res[N * WAVE + lane] = ok ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        int acc_mode = 0;
+        if (!ok) {
+            if constexpr (NM > 1) {
+                const bool ok1 = res[N * WAVE + lane] != 0.0;
+                acc_mode = ok1 ? 1 : -1;
+#pragma unroll
+                for (int j = 0; j < N; ++j) v[j] = ok1 ? res[j * WAVE + lane] : 0.0;
+            } else {
+                acc_mode = -1;
+#pragma unroll
+                for (int j = 0; j < N; ++j) v[j] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j];
+        // (single wave from here on: LDS writes above are read back by the same wave)
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+        if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
+    }
+    CLIK_STAMP_W(0, 5);
+}
+
 template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
@@ -996,7 +1153,7 @@ struct LaunchArgs {
     const void*     dImg;      // static kernels: device copy of the skill image
     const WarmArgs* warm;
     int nq, nx, ny;
-    int mode_parallel;         // allow the speculative two-wave kernel for small batches
+    int mode_parallel;         // small batches: bit 0 two-wave mode scan, bit 1 role-split kernel
 };
 typedef hipError_t (*solve_fn)(const LaunchArgs&, const TickArgs&, long long, const double*, const double*,
                                const double*, double*, double*, int32_t*, hipStream_t);
@@ -1035,6 +1192,8 @@ inline size_t static_lds_bytes(int ny)
 
 // batches up to this many instances leave SIMDs idle (1024 SIMDs x 64 lanes / 2 waves per block)
 constexpr long long kModeParallelMaxBatch = 32768;
+// the role-split kernel runs 2-4 waves per 64 instances: up to one block per CU
+constexpr long long kRoleSplitMaxBatch = 16384;
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
@@ -1042,8 +1201,22 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
                                       hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if constexpr (shape_split_ok<SD>()) {
+        // one block per 64 instances, 2 or 4 waves each: worth it while blocks <= CUs-ish
+        if (B <= kRoleSplitMaxBatch && (a.mode_parallel & 2)) {
+            constexpr size_t shmem = SplitLayout<SD>::LDS_BYTES;
+            if (shmem > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)pinv_solve_static_split_kernel<SD>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL((pinv_solve_static_split_kernel<SD>), dim3(grid), dim3(SplitLayout<SD>::NW * WAVE),
+                               shmem, stream, a.dImg, q, y, dq, mode, B, tk);
+            return hipGetLastError();
+        }
+    }
     if constexpr (StaticLayout<SD>::n_sets == 1) {
-        if (B <= kModeParallelMaxBatch && a.mode_parallel) {
+        if (B <= kModeParallelMaxBatch && (a.mode_parallel & 1)) {
             const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)(SD.n + 1) * WAVE * sizeof(double);
             hipLaunchKernelGGL((pinv_solve_static_mp_kernel<SD>), dim3(grid), dim3(2 * WAVE), shmem, stream,
                                a.dImg, q, y, dq, mode, B, tk);

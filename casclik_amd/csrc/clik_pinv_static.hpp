@@ -45,6 +45,11 @@ struct ModePlan {
     int wide_local[CLIK_MAX_DOF];
     int wide_store[CLIK_MAX_DOF];
     int n_store;        // per-lane row slots needed
+    // role split (pinv_solve_static_split_kernel): the ONE consumer that projects through a Gram-form
+    // stack, or -1.  helper_ok: there is exactly one and it is the last consumer, so a helper wave can
+    // build and factor that stack while the main wave runs the solves that precede it.
+    int gram_consumer;
+    bool helper_ok;
 };
 
 constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
@@ -133,6 +138,19 @@ constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
         p.r_after = r;
         p.gram_after = gram;
         p.c_is_g_after = c_is_g;
+    }
+    {
+        int n_gram = 0;
+        mp.gram_consumer = -1;
+        for (int ti = 0; ti < sd.n_tasks; ++ti) {
+            const TaskPlan& p = mp.t[ti];
+            // consumers of the stack: contributing tasks that project (not the first, not the
+            // double processing that owns its factor)
+            const bool projects = !p.skip && p.contributes && !p.first;
+            if (projects && p.gram_before) { ++n_gram; mp.gram_consumer = ti; }
+        }
+        mp.helper_ok = n_gram == 1 && mp.gram_consumer == last_consumer;
+        if (!mp.helper_ok) mp.gram_consumer = -1;
     }
     return mp;
 }
@@ -614,13 +632,18 @@ struct StackS {
 
 // mutable per-mode state: plain arrays only (no pointers / references) so that
 // scalar replacement keeps every element in a register
-template <const ShapeDesc& SD, unsigned ACT>
+// ROLE: 0 = one wave evaluates the whole mode; ROLE_MAIN = the Gram-form stack is built and
+// factored by a helper wave (helper_mode_static) and received through LDS (xch)
+constexpr int ROLE_SOLO = 0, ROLE_MAIN = 1;
+template <const ShapeDesc& SD, unsigned ACT, int ROLE = 0>
 struct ModeCtx {
     static constexpr int N = SD.n;
     double lam;
     double v[N];
     StackS<N, Plan<SD, ACT>::mode.n_store> st;
     bool ok;
+    uint32_t srows[SHAPE_MAX_TASKS];     // ROLE_MAIN: activation bits of the tasks pushed in Gram form
+    const double* xch;                   // ROLE_MAIN: factor published by the helper wave ([slot][lane])
 };
 
 // read-only inputs of a mode evaluation, passed as separate parameters
@@ -645,8 +668,8 @@ __device__ __forceinline__ double jac(const Img<SD>* __restrict__ S, const TaskC
 }
 
 // element j of explicit stack row R (compile-time R)
-template <const ShapeDesc& SD, unsigned ACT, int R>
-__device__ __forceinline__ double stack_row(const Img<SD>* __restrict__ S, const ModeCtx<SD, ACT>& c, const int j)
+template <const ShapeDesc& SD, unsigned ACT, int R, int ROLE = 0>
+__device__ __forceinline__ double stack_row(const Img<SD>* __restrict__ S, const ModeCtx<SD, ACT, ROLE>& c, const int j)
 {
     constexpr ModePlan MP = Plan<SD, ACT>::mode;
     if constexpr (MP.wide_store[R] >= 0) {
@@ -711,13 +734,55 @@ __device__ __forceinline__ void task_values(const Img<SD>* __restrict__ S, const
 }
 
 // w <- w - pinv(stack) * rJa * w  for the stack state BEFORE task TI
-template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx<SD, ACT>& c, double (&w)[SD.n])
+template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
+__device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc,
+                                          ModeCtx<SD, ACT, ROLE>& c, double (&w)[SD.n])
 {
     constexpr int N = SD.n;
-    constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
+    constexpr ModePlan MPL = Plan<SD, ACT>::mode;
+    constexpr TaskPlan P = MPL.t[TI];
     constexpr int NT = N * (N + 1) / 2;
-    if constexpr (P.gram_before) {
+    if constexpr (P.gram_before && ROLE == ROLE_MAIN) {
+        // The Gram matrix lam I + Ja'Ja is built and factored by the helper wave.  Here:
+        //   u = Ja' diag(s) Ja w  straight from the Jacobians of the stacked tasks,
+        //   then  w -= (lam I + Ja'Ja)^-1 u  with the factor received through LDS.
+        static_assert(MPL.helper_ok && MPL.gram_consumer == TI, "role split needs the unique Gram consumer");
+        double u[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) u[a] = 0.0;
+        static_for<0, TI>([&](auto tn) __attribute__((always_inline)) {
+            constexpr int T = decltype(tn)::value;
+            constexpr TaskPlan PT = MPL.t[T];
+            if constexpr (!PT.skip && PT.push_times > 0) {
+                constexpr int MT = SD.m[T];
+                constexpr double times = (double)PT.push_times;
+                const uint32_t sr = c.srows[T];
+                static_for<0, MT>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (shape_unit(SD, T)) {
+                        constexpr int col = SD.ucol[T][i] - 1;
+                        u[col] = fma(times, ((sr >> i) & 1u) ? w[col] : 0.0, u[col]);
+                    } else {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) sacc = fma(jac<SD, T>(S, tc, i, j), w[j], sacc);
+                        sacc = ((sr >> i) & 1u) ? times * sacc : 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) u[j] = fma(jac<SD, T>(S, tc, i, j), sacc, u[j]);
+                    }
+                });
+            }
+        });
+        __syncthreads();            // the helper wave has published L and 1/d
+        double L[NT], rd[N];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) L[a] = c.xch[a * WAVE];
+#pragma unroll
+        for (int a = 0; a < N; ++a) rd[a] = c.xch[(NT + a) * WAVE];
+        ldl_solve_s<N>(L, rd, u);
+#pragma unroll
+        for (int a = 0; a < N; ++a) w[a] -= u[a];
+    } else if constexpr (P.gram_before) {
         double u[N], L[NT], rd[N];
 #pragma unroll
         for (int a = 0; a < N; ++a) u[a] = 0.0;
@@ -760,7 +825,7 @@ __device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx
                 constexpr int i = decltype(ic)::value;
                 double sacc = 0.0;
 #pragma unroll
-                for (int j = 0; j < N; ++j) sacc = fma(stack_row<SD, ACT, i>(S, c, j), w[j], sacc);
+                for (int j = 0; j < N; ++j) sacc = fma(stack_row<SD, ACT, i, ROLE>(S, c, j), w[j], sacc);
                 u[i] = ((c.st.sbits >> i) & 1u) ? sacc : 0.0;
             });
 #pragma unroll
@@ -774,14 +839,14 @@ __device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx
             constexpr int i = decltype(ic)::value;
             double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) s = fma(stack_row<SD, ACT, i>(S, c, j), w[j], s);
+            for (int j = 0; j < N; ++j) s = fma(stack_row<SD, ACT, i, ROLE>(S, c, j), w[j], s);
             u[i] = ((c.st.sbits >> i) & 1u) ? s : 0.0;
             static_for<0, i + 1>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
                 double acc = (k == i) ? c.lam : 0.0;
 #pragma unroll
                 for (int j = 0; j < N; ++j)
-                    acc = fma(stack_row<SD, ACT, i>(S, c, j), stack_row<SD, ACT, k>(S, c, j), acc);
+                    acc = fma(stack_row<SD, ACT, i, ROLE>(S, c, j), stack_row<SD, ACT, k, ROLE>(S, c, j), acc);
                 L[tri(i, k)] = acc;
             });
         });
@@ -790,14 +855,14 @@ __device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, ModeCtx
         static_for<0, R>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
 #pragma unroll
-            for (int j = 0; j < N; ++j) w[j] = fma(-u[k], stack_row<SD, ACT, k>(S, c, j), w[j]);
+            for (int j = 0; j < N; ++j) w[j] = fma(-u[k], stack_row<SD, ACT, k, ROLE>(S, c, j), w[j]);
         });
     }
 }
 
 // stack the rows of task TI (plan.push_times times) following the plan
-template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc, ModeCtx<SD, ACT>& c,
+template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
+__device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc, ModeCtx<SD, ACT, ROLE>& c,
                                        const uint32_t srow)
 {
     constexpr int N = SD.n;
@@ -805,6 +870,10 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
     constexpr ModePlan MP = Plan<SD, ACT>::mode;
     constexpr TaskPlan P = MP.t[TI];
     constexpr int TIMES = P.push_times;
+    if constexpr (ROLE == ROLE_MAIN) {
+        c.srows[TI] = srow;
+        if constexpr (P.gram_after) return;        // Gram form: the helper wave's job
+    }
     if constexpr (!P.gram_after) {
         // stays wide: record the activation bits; state-dependent rows get a per-lane copy
         constexpr int r0 = P.r_after - TIMES * M;
@@ -845,14 +914,14 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
                         if constexpr (!P.c_is_g_before) {
                             static_for<0, r_prev>([&](auto kc) __attribute__((always_inline)) {
                                 constexpr int k = decltype(kc)::value;
-                                const double pr = stack_row<SD, ACT, k>(S, c, a) * stack_row<SD, ACT, k>(S, c, b);
+                                const double pr = stack_row<SD, ACT, k, ROLE>(S, c, a) * stack_row<SD, ACT, k, ROLE>(S, c, b);
                                 cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
                             });
                         }
                     } else {
                         static_for<0, r_prev>([&](auto kc) __attribute__((always_inline)) {
                             constexpr int k = decltype(kc)::value;
-                            const double pr = stack_row<SD, ACT, k>(S, c, a) * stack_row<SD, ACT, k>(S, c, b);
+                            const double pr = stack_row<SD, ACT, k, ROLE>(S, c, a) * stack_row<SD, ACT, k, ROLE>(S, c, b);
                             g += pr;
                             if constexpr (!P.c_is_g_before) cc += ((c.st.sbits >> k) & 1u) ? pr : 0.0;
                         });
@@ -891,8 +960,8 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
     }
 }
 
-template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
+__device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
@@ -909,7 +978,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                 if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
         }
         if constexpr (!P.contributes) {
-            if constexpr (P.push_times > 0) push_s<SD, ACT, TI>(S, tc, c, srow);
+            if constexpr (P.push_times > 0) push_s<SD, ACT, TI, ROLE>(S, tc, c, srow);
         } else {
             double des[M];
             if constexpr (SD.cls[TI] == CLIK_CLS_EQ) {
@@ -1012,25 +1081,25 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
                     for (int i = 0; i < M; ++i) s = fma(-jac<SD, TI>(S, tc, i, j), u[i], s);
                     c.v[j] += s;
                 }
-                if constexpr (P.push_times > 0) push_s<SD, ACT, TI>(S, tc, c, 0xffffffffu);
+                if constexpr (P.push_times > 0) push_s<SD, ACT, TI, ROLE>(S, tc, c, 0xffffffffu);
             } else if constexpr (P.quirk) {
                 static_assert(!P.quirk || own_factor, "static shapes need a wide, state-dependent first EqualityConstraint");
             } else {
                 if constexpr (!P.first) {
-                    project_s<SD, ACT, TI>(S, c, w);
+                    project_s<SD, ACT, TI, ROLE>(S, tc, c, w);
 #pragma unroll
                     for (int j = 0; j < N; ++j) c.v[j] += w[j];
                 }
                 if constexpr (P.push_times > 0)
-                    push_s<SD, ACT, TI>(S, tc, c, (P.conv && SD.multidim) ? srow : 0xffffffffu);
+                    push_s<SD, ACT, TI, ROLE>(S, tc, c, (P.conv && SD.multidim) ? srow : 0xffffffffu);
             }
         }
     }
 }
 
 // in-tangent-cone test of the inactive SetConstraint TI (pseudo_inverse.py:162-185, :222-252)
-template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
+__device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
@@ -1088,43 +1157,91 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
     }
 }
 
-template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void steps_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
+__device__ __forceinline__ void steps_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
 {
     if constexpr (TI < SD.n_tasks) {
-        step_s<SD, ACT, TI>(CLIK_MODE_ARGS, c);
-        steps_s<SD, ACT, TI + 1>(CLIK_MODE_ARGS, c);
+        step_s<SD, ACT, TI, ROLE>(CLIK_MODE_ARGS, c);
+        steps_s<SD, ACT, TI + 1, ROLE>(CLIK_MODE_ARGS, c);
     }
 }
 
-template <const ShapeDesc& SD, unsigned ACT, int TI>
-__device__ __forceinline__ void cones_s(CLIK_MODE_IN, ModeCtx<SD, ACT>& c)
+template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
+__device__ __forceinline__ void cones_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
 {
     if constexpr (TI < SD.n_tasks) {
-        cone_s<SD, ACT, TI>(CLIK_MODE_ARGS, c);
-        cones_s<SD, ACT, TI + 1>(CLIK_MODE_ARGS, c);
+        cone_s<SD, ACT, TI, ROLE>(CLIK_MODE_ARGS, c);
+        cones_s<SD, ACT, TI + 1, ROLE>(CLIK_MODE_ARGS, c);
     }
 }
 
 // candidate velocity of the mode with activation mask ACT; returns whether all
 // inactive sets are in their tangent cone
-template <const ShapeDesc& SD, unsigned ACT>
+template <const ShapeDesc& SD, unsigned ACT, int ROLE = 0>
 __device__ __forceinline__ bool pinv_mode_static(const Img<SD>* __restrict__ S, const TickArgs& tk,
                                                  const TaskCache<SD>& tc, const double (&z)[SD.n],
-                                                 const double* ys, int lane, double (&v)[SD.n])
+                                                 const double* ys, int lane, double (&v)[SD.n],
+                                                 const double* xch = nullptr)
 {
     constexpr int N = SD.n;
-    ModeCtx<SD, ACT> c;
+    ModeCtx<SD, ACT, ROLE> c;
+    c.xch = xch + lane;
     c.lam = SD.standard ? 0.0 : S->lam;
 #pragma unroll
     for (int j = 0; j < N; ++j) c.v[j] = 0.0;
     c.st.sbits = 0u;
     c.ok = true;
-    steps_s<SD, ACT, 0>(CLIK_MODE_ARGS, c);
-    cones_s<SD, ACT, 0>(CLIK_MODE_ARGS, c);
+    steps_s<SD, ACT, 0, ROLE>(CLIK_MODE_ARGS, c);
+    cones_s<SD, ACT, 0, ROLE>(CLIK_MODE_ARGS, c);
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] = c.v[j];
     return c.ok;
+}
+
+// Helper wave of the role split: builds the stack of mode ACT exactly as the main evaluation
+// would (same activation bits, same push order) up to the unique Gram consumer, factors
+// lam I + Ja'Ja and publishes L (packed) and 1/d through LDS ([slot][lane]).
+template <const ShapeDesc& SD, unsigned ACT>
+__device__ __forceinline__ void helper_mode_static(const Img<SD>* __restrict__ S, const TickArgs& tk,
+                                                   const TaskCache<SD>& tc, const double (&z)[SD.n],
+                                                   const double* ys, int lane, double* xch)
+{
+    constexpr int N = SD.n;
+    constexpr int NT = N * (N + 1) / 2;
+    constexpr ModePlan MP = Plan<SD, ACT>::mode;
+    static_assert(MP.helper_ok, "mode has no unique Gram consumer");
+    ModeCtx<SD, ACT, ROLE_SOLO> c;
+    c.lam = SD.standard ? 0.0 : S->lam;
+    c.st.sbits = 0u;
+    static_for<0, MP.gram_consumer>([&](auto tn) __attribute__((always_inline)) {
+        constexpr int TI = decltype(tn)::value;
+        constexpr TaskPlan P = MP.t[TI];
+        if constexpr (!P.skip && P.push_times > 0) {
+            constexpr int M = SD.m[TI];
+            uint32_t srow = 0xffffffffu;
+            if constexpr (P.set_rows) {
+                const clik_task& t = S->tasks[TI];
+                double e[M], Jt[M];
+                task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
+                srow = 0u;
+#pragma unroll
+                for (int i = 0; i < M; ++i)
+                    if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
+            }
+            // the same argument step_s passes for this kind of task
+            if constexpr (!P.contributes) push_s<SD, ACT, TI>(S, tc, c, srow);
+            else if constexpr (P.quirk) push_s<SD, ACT, TI>(S, tc, c, 0xffffffffu);
+            else push_s<SD, ACT, TI>(S, tc, c, (P.conv && SD.multidim) ? srow : 0xffffffffu);
+        }
+    });
+    double L[NT], rd[N];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) L[a] = c.st.G[a];
+    ldl_factor_s<N>(L, rd);
+#pragma unroll
+    for (int a = 0; a < NT; ++a) xch[a * WAVE + lane] = L[a];
+#pragma unroll
+    for (int a = 0; a < N; ++a) xch[(NT + a) * WAVE + lane] = rd[a];
 }
 
 }  // namespace clik

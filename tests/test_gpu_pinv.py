@@ -155,3 +155,18 @@ def test_single_solve_api(iiwa_fk):
         ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q[b:b + 1], Y=Y[b:b + 1])
         assert ctrl.current_mode == int(ref_mode[0])
         assert _rel(dq[None], ref).max() < PINV_RTOL
+
+
+def test_role_split_kernel_matches_oracle(iiwa_fk, monkeypatch):
+    """Opt-in four-wave kernel (main + helper wave per mode, CLIK_ROLE_SPLIT=1): the helper
+    builds and factors the Gram-form stack, the main wave projects through it."""
+    from oracle import clik_oracle
+    monkeypatch.setenv("CLIK_ROLE_SPLIT", "1")
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 200, seed=31, distribution="mixed")
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, dict(skills.STACK_OPTIONS), 0.0, Q, Y=Y)
+    assert np.array_equal(mode, rmode) and len(np.unique(mode)) >= 2
+    assert _rel(dq, ref).max() < PINV_RTOL
