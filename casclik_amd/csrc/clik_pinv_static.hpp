@@ -269,11 +269,29 @@ __device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__
     // interleave; inside the chain recursion they would serialise behind the
     // frame products (measured: FK was latency-, not issue-bound)
     double sns[N], css[N];
+    bool huge = false;
     static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) sincos_joint(z[j], sns[j], css[j]);
-        else sns[j] = css[j] = 0.0;
+        if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+            sincos_fast(z[j], sns[j], css[j]);
+            huge = huge || fabs(z[j]) > kSinCosFastMax;
+        } else {
+            sns[j] = css[j] = 0.0;
+        }
     });
+    if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+        // some lane has a joint angle beyond the fast path's range: redo those (cold)
+        static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+                if (fabs(z[j]) > kSinCosFastMax) {
+                    const SinCos r = sincos_slow(z[j]);
+                    sns[j] = r.s;
+                    css[j] = r.c;
+                }
+            }
+        });
+    }
     fk_joint_s<SD, 0>(S, z, sns, css, R, p, ax, org);
 #pragma unroll
     for (int i = 0; i < 9; ++i) K.R[i] = R[i];
