@@ -170,3 +170,25 @@ def test_role_split_kernel_matches_oracle(iiwa_fk, monkeypatch):
     ref, rmode = clik_oracle.pinv_solve_batch(spec, dict(skills.STACK_OPTIONS), 0.0, Q, Y=Y)
     assert np.array_equal(mode, rmode) and len(np.unique(mode)) >= 2
     assert _rel(dq, ref).max() < PINV_RTOL
+
+
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_huge_joint_angles_take_the_accurate_sincos_path(iiwa_fk, kernel, monkeypatch):
+    """Joint angles beyond the fast range reduction (|q| > 1e5 rad, a few lanes per wave)
+    go through the library-accurate sin/cos in one cold block; results still match the
+    oracle (which uses libm for every angle)."""
+    from oracle import clik_oracle
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    spec = skills.pose_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 130, seed=5)
+    rng = np.random.default_rng(6)
+    rows = rng.choice(130, size=12, replace=False)
+    Q[rows, rng.integers(0, 7, size=12)] += rng.choice([-1.0, 1.0], size=12) * 2 * np.pi * rng.integers(2e4, 3e6, size=12)
+    assert (np.abs(Q) > 1e5).any()
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, Y=Y)
+    assert np.array_equal(mode, rmode)
+    assert _rel(dq, ref).max() < PINV_RTOL
