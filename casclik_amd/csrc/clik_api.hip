@@ -224,9 +224,11 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
             S->shape.const_j[ti] = S->task_const_j[ti];
             S->shape.gain_matrix[ti] = t.gain_is_matrix ? 1 : 0;
             int nyt = 0;
-            for (int i = 0; i < t.m; ++i)
-                if (t.out_kind[i] == CLIK_OUT_AFFINE && d->rows[t.out_row0[i]].n_y > nyt)
-                    nyt = d->rows[t.out_row0[i]].n_y;
+            for (int i = 0; i < t.m; ++i) {
+                const int nrw = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+                for (int k = 0; k < nrw; ++k)
+                    if (d->rows[t.out_row0[i] + k].n_y > nyt) nyt = d->rows[t.out_row0[i] + k].n_y;
+            }
             S->shape.ny_terms[ti] = nyt;
             S->shape.has_t[ti] = (fl & CLIK_ROW_HAS_T) ? 1 : 0;
             // joint-space task: rows are distinct unit vectors (clik_device.hpp, ShapeDesc::ucol)
@@ -255,19 +257,23 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
         int r = 0;
         for (int ti = 0; ti < d->n_tasks && ti < clik::SHAPE_MAX_TASKS; ++ti) {
             const clik_task& t = d->tasks[ti];
-            for (int i = 0; i < t.m && r < clik::SHAPE_MAX_ROWS; ++i, ++r) {
-                if (t.out_kind[i] != CLIK_OUT_AFFINE) continue;
-                const clik_row& row = d->rows[t.out_row0[i]];
-                unsigned nz = 0u, one = 0u;
-                auto mark = [&](double v, int bit) {
-                    if (v != 0.0) nz |= 1u << bit;
-                    if (v == 1.0) one |= 1u << bit;
-                };
-                if (row.flags & CLIK_ROW_HAS_P) for (int k = 0; k < 3; ++k) mark(row.b[k], k);
-                if (row.flags & CLIK_ROW_HAS_R) for (int k = 0; k < 9; ++k) mark(row.g[k], 3 + k);
-                if (row.flags & CLIK_ROW_HAS_O) for (int k = 0; k < 3; ++k) mark(row.h[k], 12 + k);
-                S->shape.row_nz[r] = nz;
-                S->shape.row_one[r] = one;
+            for (int i = 0; i < t.m; ++i) {
+                const int nrw = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+                S->shape.out_nrows[ti][i] = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 0 : t.out_nrows[i];
+                for (int k2 = 0; k2 < nrw; ++k2, ++r) {
+                    if (r >= clik::SHAPE_MAX_ROWS) continue;
+                    const clik_row& row = d->rows[t.out_row0[i] + k2];
+                    unsigned nz = 0u, one = 0u;
+                    auto mark = [&](double v, int bit) {
+                        if (v != 0.0) nz |= 1u << bit;
+                        if (v == 1.0) one |= 1u << bit;
+                    };
+                    if (row.flags & CLIK_ROW_HAS_P) for (int k = 0; k < 3; ++k) mark(row.b[k], k);
+                    if (row.flags & CLIK_ROW_HAS_R) for (int k = 0; k < 9; ++k) mark(row.g[k], 3 + k);
+                    if (row.flags & CLIK_ROW_HAS_O) for (int k = 0; k < 3; ++k) mark(row.h[k], 12 + k);
+                    S->shape.row_nz[r] = nz;
+                    S->shape.row_one[r] = one;
+                }
             }
         }
     }
@@ -349,7 +355,7 @@ static bool host_const_pinv(const clik_pinv_opts& o, int m, int n, const double*
 
 // Compact skill image for the shape-specialised kernels; layout =
 // clik::SkillImage<nj, nt, nr> (clik_device.hpp), padded to a multiple of 1 KiB.
-// Static shapes require contiguous, all-affine rows in task order.
+// Static shapes require the rows contiguous in task / output order.
 static bool build_skill_image(const DevSkill& S, std::vector<char>& out, size_t* image_bytes = nullptr,
                               size_t extra = 0)
 {
@@ -357,10 +363,13 @@ static bool build_skill_image(const DevSkill& S, std::vector<char>& out, size_t*
     int nr = 0;
     for (int ti = 0; ti < nt; ++ti) {
         const clik_task& t = S.d.tasks[ti];
-        for (int i = 0; i < t.m; ++i)
-            if (t.out_kind[i] != CLIK_OUT_AFFINE || t.out_row0[i] != nr + i) return false;
-        nr += t.m;
+        for (int i = 0; i < t.m; ++i) {
+            // rows in task order, output order; a 2-norm output owns a group of consecutive rows
+            if (t.out_row0[i] != nr) return false;
+            nr += (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+        }
     }
+    if (nr > clik::SHAPE_MAX_ROWS) return false;
     const size_t o_j = 0;
     const size_t o_t = o_j + sizeof(clik_joint) * (size_t)(nj > 0 ? nj : 1);
     const size_t o_r = o_t + sizeof(clik_task) * (size_t)nt;
@@ -459,7 +468,7 @@ static int qp_static_rows(const DevSkill& S)
 // can a shape-specialised QP kernel serve the skill?  (image layout, row budget, LDS)
 static bool qp_static_eligible(const DevSkill& S)
 {
-    if (S.d.n_tasks > clik::SHAPE_MAX_TASKS || S.d.n_x != 0 || !S.shape.all_affine) return false;
+    if (S.d.n_tasks > clik::SHAPE_MAX_TASKS || S.d.n_x != 0) return false;
     std::vector<char> img;
     size_t image_bytes = 0;
     if (!build_skill_image(S, img, &image_bytes, sizeof(clik::QpTail))) return false;
@@ -521,8 +530,14 @@ static std::string shape_to_string(const clik::ShapeDesc& h)
         o += last ? "}" : "}, ";
     };
     uarr(h.row_nz, clik::SHAPE_MAX_ROWS, false);
-    uarr(h.row_one, clik::SHAPE_MAX_ROWS, true);
-    o += "}";
+    uarr(h.row_one, clik::SHAPE_MAX_ROWS, false);
+    o += "{";
+    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) {
+        o += "{";
+        for (int k = 0; k < CLIK_MAX_M; ++k) { o += std::to_string(i < nt ? h.out_nrows[i][k] : 0); if (k + 1 < CLIK_MAX_M) o += ", "; }
+        o += (i + 1 < clik::SHAPE_MAX_TASKS) ? "}, " : "}";
+    }
+    o += "}}";
     return o;
 }
 
@@ -539,7 +554,11 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     const clik::ShapeDesc& h = S->shape;
     const std::string o = shape_to_string(h);
     // (kStaticMaxSets of clik_pinv_kernels.hpp: 2^3 mode bodies per kernel)
-    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && h.all_affine && S->n_sets <= 3;
+    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && S->n_sets <= 3;
+    {
+        std::vector<char> img;
+        if (!build_skill_image(*S, img)) eligible = false;      // rows not in task order / too many rows
+    }
     // the static plan handles the doubly processed first EqualityConstraint only when
     // it owns a wide, state-dependent factor (clik_pinv_static.hpp)
     for (unsigned act = 0; eligible && act < (1u << S->n_sets); ++act) {

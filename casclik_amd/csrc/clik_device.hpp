@@ -58,6 +58,9 @@ struct ShapeDesc {
     // (rows in task order): bit k set = coefficient k is non-zero / is exactly 1.0
     unsigned row_nz[SHAPE_MAX_ROWS];
     unsigned row_one[SHAPE_MAX_ROWS];
+    // output i of task ti: 0 = one affine row; k >= 1 = 2-norm of k consecutive affine rows
+    // (cs.norm_2 / cs.norm_fro constraint expressions)
+    int out_nrows[SHAPE_MAX_TASKS][CLIK_MAX_M];
 };
 
 constexpr bool shape_unit(const ShapeDesc& sd, int ti) { return sd.const_j[ti] != 0 && sd.m[ti] > 0 && sd.ucol[ti][0] > 0; }
@@ -69,16 +72,31 @@ constexpr int shape_unit_row(const ShapeDesc& sd, int ti, int col)
     return -1;
 }
 
+// affine rows behind output i of task ti, and the row layout of static shapes (rows are
+// stored in task order, output order, group order)
+constexpr int shape_out_rows(const ShapeDesc& sd, int ti, int i) { return sd.out_nrows[ti][i] > 0 ? sd.out_nrows[ti][i] : 1; }
+constexpr int shape_task_rows(const ShapeDesc& sd, int ti)
+{
+    int r = 0;
+    for (int i = 0; i < sd.m[ti]; ++i) r += shape_out_rows(sd, ti, i);
+    return r;
+}
 constexpr int shape_rows(const ShapeDesc& sd)
 {
     int r = 0;
-    for (int i = 0; i < sd.n_tasks; ++i) r += sd.m[i];
+    for (int i = 0; i < sd.n_tasks; ++i) r += shape_task_rows(sd, i);
     return r;
 }
 constexpr int shape_row_base(const ShapeDesc& sd, int ti)
 {
     int r = 0;
-    for (int i = 0; i < ti; ++i) r += sd.m[i];
+    for (int i = 0; i < ti; ++i) r += shape_task_rows(sd, i);
+    return r;
+}
+constexpr int shape_out_row0(const ShapeDesc& sd, int ti, int i)
+{
+    int r = shape_row_base(sd, ti);
+    for (int k = 0; k < i; ++k) r += shape_out_rows(sd, ti, k);
     return r;
 }
 
@@ -129,6 +147,9 @@ inline bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
         if (a.jtype[j] != b.jtype[j] || a.jq[j] != b.jq[j] || a.jflags[j] != b.jflags[j]) return false;
     for (int r = 0; r < SHAPE_MAX_ROWS; ++r)
         if (a.row_nz[r] != b.row_nz[r] || a.row_one[r] != b.row_one[r]) return false;
+    for (int i = 0; i < a.n_tasks; ++i)
+        for (int k = 0; k < CLIK_MAX_M; ++k)
+            if (a.out_nrows[i][k] != b.out_nrows[i][k]) return false;
     return true;
 }
 

@@ -515,17 +515,43 @@ __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
-    constexpr int row0 = shape_row_base(SD, TI);
     const int nts = S->n_tslots;
     static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        constexpr unsigned NZ = SD.row_nz[row0 + i], ONE = SD.row_one[row0 + i];
-        double g[N], dt;
-        e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI], SD.has_t[TI] != 0, NZ, ONE>(S->rows[row0 + i], nts, tk, K,
-                                                                                         z, ys, lane, g, dt);
-        Jt[i] = dt;
+        constexpr int r0 = shape_out_row0(SD, TI, i);
+        if constexpr (SD.out_nrows[TI][i] == 0) {
+            constexpr unsigned NZ = SD.row_nz[r0], ONE = SD.row_one[r0];
+            double g[N], dt;
+            e[i] = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI], SD.has_t[TI] != 0, NZ, ONE>(S->rows[r0], nts, tk, K, z,
+                                                                                             ys, lane, g, dt);
+            Jt[i] = dt;
 #pragma unroll
-        for (int j = 0; j < N; ++j) J[i][j] = g[j];
+            for (int j = 0; j < N; ++j) J[i][j] = g[j];
+        } else {
+            // 2-norm of a group of affine rows (cs.norm_2 / cs.norm_fro): e = |r|, J = r'G / |r|
+            // (0/0 at r = 0, as the reference's symbolic derivative)
+            constexpr int NRW = SD.out_nrows[TI][i];
+            double ss = 0.0, tacc = 0.0, acc[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] = 0.0;
+            static_for<0, NRW>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr unsigned NZ = SD.row_nz[r0 + k], ONE = SD.row_one[r0 + k];
+                double g[N], dt;
+                const double v = row_eval_s<N, SD.flags[TI], SD.ny_terms[TI], SD.has_t[TI] != 0, NZ, ONE>(
+                    S->rows[r0 + k], nts, tk, K, z, ys, lane, g, dt);
+                ss = fma(v, v, ss);
+                tacc = fma(v, dt, tacc);
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc[j] = fma(v, g[j], acc[j]);
+            });
+            const double nrm = sqrt(ss);
+            const double inv = 1.0 / nrm;
+            e[i] = nrm;
+            Jt[i] = tacc * inv;
+#pragma unroll
+            for (int j = 0; j < N; ++j) J[i][j] = acc[j] * inv;
+        }
     });
 }
 

@@ -236,3 +236,31 @@ def test_virtual_variable_qp(ur5_fk):
     ok = rstatus == 0
     assert _rel(dq[ok], rdq[ok]).max() < 1e-8 and _rel(dx[ok], rdx[ok]).max() < 1e-8
     assert _rel(slack[ok], rslack[ok]).max() < 1e-8
+
+
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_norm_rows_in_static_shapes(ur5_fk, kernel, monkeypatch):
+    """cs.norm_2 distance constraint (ur5_moe2016_example2 cell 7) and a Frobenius-norm
+    rotation constraint, with two 1-D sets: 2-norm output rows are part of the
+    shape-specialised family (e = |r|, J = r'G/|r|)."""
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    T = fk["T_fk"](q)
+    p = T[:3, 3]
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    R_des = fk["chain"].fk_numeric(home + 0.3)[:3, :3]
+    cons = [cc.EqualityConstraint("dist", cs.norm_2(np.array([0.5, 0.5, 0.5]) - p), gain=5.0, priority=6),
+            cc.EqualityConstraint("rot", cs.norm_fro(T[:3, :3] - R_des), gain=2.0, priority=7),
+            cc.SetConstraint("lim0", q[0], set_min=0.3 * lo[0], set_max=0.3 * hi[0], priority=0),
+            cc.SetConstraint("lim1", q[1], set_min=0.3 * lo[1], set_max=0.3 * hi[1], priority=1)]
+    spec = cc.SkillSpecification("norms", t, q, constraints=cons)
+    rng = np.random.default_rng(23)
+    Q = home + rng.uniform(-0.6, 0.6, size=(200, 6))
+    Q[:, :2] = rng.uniform(0.5 * lo[:2], 0.5 * hi[:2], size=(200, 2))
+    ctrl = _check(spec, None, Q, min_modes=4)
+    assert ctrl.n_modes == 4
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
