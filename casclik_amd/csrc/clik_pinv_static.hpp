@@ -50,6 +50,13 @@ struct ModePlan {
     // build and factor that stack while the main wave runs the solves that precede it.
     int gram_consumer;
     bool helper_ok;
+    // Duplicated-row stack: the unique Gram consumer projects through c copies of the rows of ONE
+    // state-dependent task (the doubly processed first EqualityConstraint, c = 2) with m < n rows.
+    // Then  (c J'J + lam I)^-1 c J'J w  =  c J' (c J J' + lam I)^-1 J w   (push-through identity,
+    // exact for the damped inverse): an m x m factorisation of the matrix the task already formed
+    // instead of building and factoring the n x n Gram matrix.
+    int dup_task;       // the stacked task, -1: not this form
+    int dup_times;      // c
 };
 
 constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
@@ -151,6 +158,21 @@ constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
         }
         mp.helper_ok = n_gram == 1 && mp.gram_consumer == last_consumer;
         if (!mp.helper_ok) mp.gram_consumer = -1;
+        mp.dup_task = -1;
+        mp.dup_times = 0;
+        if (mp.helper_ok && !sd.standard) {
+            int pushed = 0, src = -1;
+            for (int ti = 0; ti < mp.gram_consumer; ++ti)
+                if (!mp.t[ti].skip && mp.t[ti].push_times > 0) { ++pushed; src = ti; }
+            if (pushed == 1) {
+                const TaskPlan& p = mp.t[src];
+                // (quirk && wide_self && !const_j: the task forms J J' + lam I itself; no rows with activation 0)
+                if (p.quirk && p.wide_self && !p.const_j && !p.set_rows && sd.m[src] < n && mp.t[mp.gram_consumer].c_is_g_before) {
+                    mp.dup_task = src;
+                    mp.dup_times = p.push_times;
+                }
+            }
+        }
     }
     return mp;
 }
@@ -678,7 +700,7 @@ struct StackS {
 // scalar replacement keeps every element in a register
 // ROLE: 0 = one wave evaluates the whole mode; ROLE_MAIN = the Gram-form stack is built and
 // factored by a helper wave (helper_mode_static) and received through LDS (xch)
-constexpr int ROLE_SOLO = 0, ROLE_MAIN = 1;
+constexpr int ROLE_SOLO = 0, ROLE_MAIN = 1, ROLE_HELPER = 2;   // helper: builds the stack only, always in full
 template <const ShapeDesc& SD, unsigned ACT, int ROLE = 0>
 struct ModeCtx {
     static constexpr int N = SD.n;
@@ -688,6 +710,9 @@ struct ModeCtx {
     bool ok;
     uint32_t srows[SHAPE_MAX_TASKS];     // ROLE_MAIN: activation bits of the tasks pushed in Gram form
     const double* xch;                   // ROLE_MAIN: factor published by the helper wave ([slot][lane])
+    // duplicated-row stack (ModePlan::dup_task): J J' + lam I of that task, before factorisation
+    static constexpr int DM = Plan<SD, ACT>::mode.dup_task >= 0 ? SD.m[Plan<SD, ACT>::mode.dup_task > 0 ? Plan<SD, ACT>::mode.dup_task : 0] : 1;
+    double dupM[DM * (DM + 1) / 2];
 };
 
 // read-only inputs of a mode evaluation, passed as separate parameters
@@ -786,7 +811,37 @@ __device__ __forceinline__ void project_s(const Img<SD>* __restrict__ S, const T
     constexpr ModePlan MPL = Plan<SD, ACT>::mode;
     constexpr TaskPlan P = MPL.t[TI];
     constexpr int NT = N * (N + 1) / 2;
-    if constexpr (P.gram_before && ROLE == ROLE_MAIN) {
+    if constexpr (P.gram_before && ROLE == ROLE_SOLO && MPL.dup_task >= 0) {
+        static_assert(MPL.gram_consumer == TI, "duplicated-row projection belongs to the unique Gram consumer");
+        constexpr int T0 = MPL.dup_task;
+        constexpr int M0 = SD.m[T0];
+        constexpr double cd = (double)MPL.dup_times;
+        double L[M0 * (M0 + 1) / 2], rd[M0], t[M0];
+        // c (J J' + lam I) - (c - 1) lam I  =  c J J' + lam I
+#pragma unroll
+        for (int i = 0; i < M0; ++i)
+#pragma unroll
+            for (int k = 0; k <= i; ++k)
+                L[tri(i, k)] = (i == k) ? fma(cd, c.dupM[tri(i, k)], -(cd - 1.0) * c.lam) : cd * c.dupM[tri(i, k)];
+#pragma unroll
+        for (int i = 0; i < M0; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) sacc = fma(jac<SD, T0>(S, tc, i, j), w[j], sacc);
+            t[i] = sacc;
+        }
+        ldl_factor_s<M0>(L, rd);
+        ldl_solve_s<M0>(L, rd, t);
+#pragma unroll
+        for (int i = 0; i < M0; ++i) t[i] *= cd;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double sacc = w[j];
+#pragma unroll
+            for (int i = 0; i < M0; ++i) sacc = fma(-jac<SD, T0>(S, tc, i, j), t[i], sacc);
+            w[j] = sacc;
+        }
+    } else if constexpr (P.gram_before && ROLE == ROLE_MAIN) {
         // The Gram matrix lam I + Ja'Ja is built and factored by the helper wave.  Here:
         //   u = Ja' diag(s) Ja w  straight from the Jacobians of the stacked tasks,
         //   then  w -= (lam I + Ja'Ja)^-1 u  with the factor received through LDS.
@@ -918,6 +973,7 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
         c.srows[TI] = srow;
         if constexpr (P.gram_after) return;        // Gram form: the helper wave's job
     }
+    if constexpr (ROLE == ROLE_SOLO && MP.dup_task >= 0 && P.gram_after) return;   // consumer uses the m x m form
     if constexpr (!P.gram_after) {
         // stays wide: record the activation bits; state-dependent rows get a per-lane copy
         constexpr int r0 = P.r_after - TIMES * M;
@@ -1074,6 +1130,10 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
                         for (int j = 0; j < N; ++j) acc = fma(jac<SD, TI>(S, tc, i, j), jac<SD, TI>(S, tc, k, j), acc);
                         L[tri(i, k)] = acc;
                     }
+                if constexpr (ROLE == ROLE_SOLO && Plan<SD, ACT>::mode.dup_task == TI) {
+#pragma unroll
+                    for (int a = 0; a < M * (M + 1) / 2; ++a) c.dupM[a] = L[a];
+                }
                 ldl_factor_s<M>(L, rd);
                 ldl_solve_s<M>(L, rd, des);
 #pragma unroll
@@ -1254,7 +1314,7 @@ __device__ __forceinline__ void helper_mode_static(const Img<SD>* __restrict__ S
     constexpr int NT = N * (N + 1) / 2;
     constexpr ModePlan MP = Plan<SD, ACT>::mode;
     static_assert(MP.helper_ok, "mode has no unique Gram consumer");
-    ModeCtx<SD, ACT, ROLE_SOLO> c;
+    ModeCtx<SD, ACT, ROLE_HELPER> c;
     c.lam = SD.standard ? 0.0 : S->lam;
     c.st.sbits = 0u;
     static_for<0, MP.gram_consumer>([&](auto tn) __attribute__((always_inline)) {
@@ -1273,9 +1333,9 @@ __device__ __forceinline__ void helper_mode_static(const Img<SD>* __restrict__ S
                     if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
             }
             // the same argument step_s passes for this kind of task
-            if constexpr (!P.contributes) push_s<SD, ACT, TI>(S, tc, c, srow);
-            else if constexpr (P.quirk) push_s<SD, ACT, TI>(S, tc, c, 0xffffffffu);
-            else push_s<SD, ACT, TI>(S, tc, c, (P.conv && SD.multidim) ? srow : 0xffffffffu);
+            if constexpr (!P.contributes) push_s<SD, ACT, TI, ROLE_HELPER>(S, tc, c, srow);
+            else if constexpr (P.quirk) push_s<SD, ACT, TI, ROLE_HELPER>(S, tc, c, 0xffffffffu);
+            else push_s<SD, ACT, TI, ROLE_HELPER>(S, tc, c, (P.conv && SD.multidim) ? srow : 0xffffffffu);
         }
     });
     double L[NT], rd[N];
