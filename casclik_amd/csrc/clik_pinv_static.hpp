@@ -1136,6 +1136,20 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
                 }
                 ldl_factor_s<M>(L, rd);
                 ldl_solve_s<M>(L, rd, des);
+                if constexpr (P.quirk) {
+                    // Both passes of the doubly processed first EqualityConstraint at once.  With
+                    // y = M^-1 d, M = J J' + lam I:  pass 1 gives w = J'y, pass 2 (stack [J], :382-396)
+                    // gives w - J'M^-1 J w = w - J'M^-1 (M - lam I) y = lam J' M^-1 y, so the sum is
+                    //     J' (y + lam M^-1 y)
+                    // : one more m x m solve, one J' product, and none of the cancellation of the
+                    // literal form (same value up to its rounding error).
+                    double y2[M];
+#pragma unroll
+                    for (int i = 0; i < M; ++i) y2[i] = des[i];
+                    ldl_solve_s<M>(L, rd, y2);
+#pragma unroll
+                    for (int i = 0; i < M; ++i) des[i] = fma(c.lam, y2[i], des[i]);
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     double s = 0.0;
@@ -1167,24 +1181,8 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
                 for (int j = 0; j < N; ++j) c.v[j] += w[j];
             }
             if constexpr (P.quirk && own_factor) {
-                // second processing of the first EqualityConstraint (:382-396) with
-                // the stack [J]: the factor of J J^T + lam I is reused
-                double u[M];
-#pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) s = fma(jac<SD, TI>(S, tc, i, j), w[j], s);
-                    u[i] = s;
-                }
-                ldl_solve_s<M>(L, rd, u);
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    double s = w[j];
-#pragma unroll
-                    for (int i = 0; i < M; ++i) s = fma(-jac<SD, TI>(S, tc, i, j), u[i], s);
-                    c.v[j] += s;
-                }
+                // (w already holds the sum of both passes, see above; it was added as the first task)
+                static_assert(P.first, "the doubly processed EqualityConstraint is the first contribution");
                 if constexpr (P.push_times > 0) push_s<SD, ACT, TI, ROLE>(S, tc, c, 0xffffffffu);
             } else if constexpr (P.quirk) {
                 static_assert(!P.quirk || own_factor, "static shapes need a wide, state-dependent first EqualityConstraint");

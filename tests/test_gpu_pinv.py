@@ -192,3 +192,27 @@ def test_huge_joint_angles_take_the_accurate_sincos_path(iiwa_fk, kernel, monkey
     ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, Y=Y)
     assert np.array_equal(mode, rmode)
     assert _rel(dq, ref).max() < PINV_RTOL
+
+
+@pytest.mark.parametrize("skill", ["pose", "stack"])
+def test_near_singular_configurations(iiwa_fk, skill):
+    """Stretched-arm configurations (q ~ 0: the iiwa's elbow/wrist singularity) where the damped
+    inverse is doing real work (smallest singular value^2 comparable to lam = 1e-7 or a few
+    orders above): the fused double processing of the first equality and the push-through
+    projection must still agree with the literal algorithm within PINV_RTOL."""
+    from oracle import clik_oracle
+    if skill == "pose":
+        spec, opts = skills.pose_skill(iiwa_fk), None
+    else:
+        spec, opts = skills.stack_skill(iiwa_fk), dict(skills.STACK_OPTIONS)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=opts)
+    ctrl.setup_problem_functions()
+    rng = np.random.default_rng(41)
+    _, Y = skills.synthetic_inputs(iiwa_fk, 192, seed=42)
+    scales = np.repeat([1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 0.0], 32)[:, None]
+    Q = scales * rng.normal(size=(192, 7))
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, 0.0, Q, Y=Y)
+    assert np.isfinite(dq).all()
+    assert np.array_equal(mode, rmode)
+    assert _rel(dq, ref).max() < PINV_RTOL, _rel(dq, ref).max()
