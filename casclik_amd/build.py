@@ -5,7 +5,9 @@ casclik_amd/csrc/_obj and rebuilt when a source or header is newer.
 """
 from __future__ import annotations
 
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -24,6 +26,7 @@ ARCH = "gfx950"
 # a scalar load from the kernarg segment - one memory round trip less at kernel start
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-mllvm", "-amdgpu-kernarg-preload-count=14",
+         "-Rpass-analysis=kernel-resource-usage",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
@@ -32,6 +35,35 @@ def _hipcc():
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     return "hipcc"
+
+
+RESOURCES = os.path.join(OBJ, "kernel_resources.json")
+
+
+def parse_resource_remarks(text):
+    """{kernel symbol: {"VGPRs", "AGPRs", "ScratchSize", "Occupancy", ...}} from the
+    -Rpass-analysis=kernel-resource-usage remarks of one hipcc run."""
+    res, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z ]+?)( \[[^\]]*\])?:\s+(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(3)
+        if key == "Function Name":
+            cur = res.setdefault(val, {})
+        elif cur is not None:
+            try:
+                cur[key.replace(" ", "")] = int(val)
+            except ValueError:
+                cur[key.replace(" ", "")] = val
+    return res
+
+
+def kernel_resources():
+    """The merged report written by the last build (tests assert on it: no scratch in the
+    shape-specialised kernels)."""
+    with open(RESOURCES) as f:
+        return json.load(f)
 
 
 def build_hip(force=False, verbose=False, extra_flags=()):
@@ -55,6 +87,18 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         out, _ = proc.communicate()
         if proc.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode("utf-8", "replace")))
+        # per-kernel register / scratch report of this translation unit (compiler remarks)
+        with open(os.path.join(OBJ, src.replace(".hip", ".resources.json")), "w") as f:
+            json.dump(parse_resource_remarks(out.decode("utf-8", "replace")), f, indent=1, sort_keys=True)
+    if jobs or not os.path.exists(RESOURCES):
+        merged = {}
+        for src in SOURCES:
+            rp = os.path.join(OBJ, src.replace(".hip", ".resources.json"))
+            if os.path.exists(rp):
+                with open(rp) as f:
+                    merged.update(json.load(f))
+        with open(RESOURCES, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
     if jobs or not os.path.exists(LIB) or force:
         # -no-hip-rt: leave the HIP runtime symbols undefined so the library
         # binds to the ONE libamdhip64 the host process already uses (torch
