@@ -20,6 +20,27 @@ namespace shapes {
 #include "clik_shapes_gen.hpp"
 }  // namespace shapes
 
+// ---- compile-time checks of the plans the AOT shapes get (regression guards) ----------------
+#if defined(CLIK_GENERATED_SHAPES) && !defined(CLIK_DEV_SINGLE)
+namespace plan_checks {
+using shapes::kStackIiwa;
+// config 3, mode 0 (set inactive): [pose (twice); centering] -> the centering task projects through the
+// duplicated pose rows (6x6 push-through form), no Gram build
+static_assert(Plan<kStackIiwa, 0u>::mode.t[0].skip && Plan<kStackIiwa, 0u>::mode.t[0].cone, "mode 0: set is a cone test");
+static_assert(Plan<kStackIiwa, 0u>::mode.t[1].quirk && Plan<kStackIiwa, 0u>::mode.t[1].push_times == 2, "first equality twice");
+static_assert(Plan<kStackIiwa, 0u>::mode.dup_task == 1 && Plan<kStackIiwa, 0u>::mode.dup_times == 2, "duplicated-row stack");
+// mode 1 (set active): set rows stay explicit (7 <= 7), the pose projects through them with the
+// host-side pinv of the unit rows, then the stack turns Gram (13 rows) for the centering task
+static_assert(Plan<kStackIiwa, 1u>::mode.t[0].push_times == 1 && !Plan<kStackIiwa, 1u>::mode.t[0].gram_after, "set rows explicit");
+static_assert(!Plan<kStackIiwa, 1u>::mode.t[1].quirk && Plan<kStackIiwa, 1u>::mode.t[1].wide_const_task == 0, "pose behind the set");
+static_assert(Plan<kStackIiwa, 1u>::mode.t[2].gram_before && Plan<kStackIiwa, 1u>::mode.dup_task == -1, "Gram consumer");
+static_assert(Plan<kStackIiwa, 1u>::mode.helper_ok && shape_split_ok<kStackIiwa>(), "role split applies");
+static_assert(shape_unit(kStackIiwa, 0) && !shape_unit(kStackIiwa, 1) && shape_unit(kStackIiwa, 2), "joint-space tasks");
+// mode order of pseudo_inverse.py:107-130 for two sets: 00, 10, 01, 11 with set 0 = bit 0
+static_assert(shape_mode_act(shapes::kStackUr5, 0) == 0u && shape_mode_act(shapes::kStackUr5, 1) == 1u, "one set: 0, 1");
+}  // namespace plan_checks
+#endif
+
 struct ShapeEntry {
     const ShapeDesc* sd;       // nullptr: dynamic kernel of width N
     int N;
