@@ -51,7 +51,8 @@ size_t qp_variant_lds(int k, int ny);
 int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
-                            const double* y, double* dq, double* slack, int32_t* status, hipStream_t stream);
+                            const double* x, const double* y, double* dq, double* dx, double* slack,
+                            int32_t* status, hipStream_t stream);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -78,8 +79,8 @@ struct clik_pinv {
     size_t    d_tterms_cap;
 };
 
-typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*, double*,
-                                     double*, int32_t*, hipStream_t);
+typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
+                                     const double*, double*, double*, double*, int32_t*, hipStream_t);
 
 struct clik_qp {
     DevSkill  host;
@@ -199,6 +200,7 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
     // per-task feature flags, constant-Jacobian detection, shape descriptor
     S->shape.n = n;
     S->shape.n_y = d->n_y;
+    S->shape.n_x = d->n_x;
     S->shape.nj = d->n_joints;
     S->shape.n_tasks = d->n_tasks;
     S->shape.all_affine = 1;
@@ -468,7 +470,7 @@ static int qp_static_rows(const DevSkill& S)
 // can a shape-specialised QP kernel serve the skill?  (image layout, row budget, LDS)
 static bool qp_static_eligible(const DevSkill& S)
 {
-    if (S.d.n_tasks > clik::SHAPE_MAX_TASKS || S.d.n_x != 0) return false;
+    if (S.d.n_tasks > clik::SHAPE_MAX_TASKS) return false;
     std::vector<char> img;
     size_t image_bytes = 0;
     if (!build_skill_image(S, img, &image_bytes, sizeof(clik::QpTail))) return false;
@@ -537,7 +539,7 @@ static std::string shape_to_string(const clik::ShapeDesc& h)
         for (int k = 0; k < CLIK_MAX_M; ++k) { o += std::to_string(i < nt ? h.out_nrows[i][k] : 0); if (k + 1 < CLIK_MAX_M) o += ", "; }
         o += (i + 1 < clik::SHAPE_MAX_TASKS) ? "}, " : "}";
     }
-    o += "}}";
+    o += "}, " + std::to_string(h.n_x) + "}";
     return o;
 }
 
@@ -554,7 +556,7 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     const clik::ShapeDesc& h = S->shape;
     const std::string o = shape_to_string(h);
     // (kStaticMaxSets of clik_pinv_kernels.hpp: 2^3 mode bodies per kernel)
-    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->d.n_x == 0 && S->n_sets <= 3;
+    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->n_sets <= 3;
     {
         std::vector<char> img;
         if (!build_skill_image(*S, img)) eligible = false;      // rows not in task order / too many rows
@@ -978,9 +980,9 @@ extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tt
     if (rc) return rc;
     hipError_t e;
     if (h->jit_solve)
-        e = h->jit_solve(h->d_img, &tk, (long long)B, q, y, dq, slack, status, (hipStream_t)stream);
+        e = h->jit_solve(h->d_img, &tk, (long long)B, q, x, y, dq, dx, slack, status, (hipStream_t)stream);
     else if (h->static_k >= 0)
-        e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, y, dq, slack, status,
+        e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, x, y, dq, dx, slack, status,
                                    (hipStream_t)stream);
     else
         e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,

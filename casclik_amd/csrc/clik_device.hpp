@@ -61,6 +61,7 @@ struct ShapeDesc {
     // output i of task ti: 0 = one affine row; k >= 1 = 2-norm of k consecutive affine rows
     // (cs.norm_2 / cs.norm_fro constraint expressions)
     int out_nrows[SHAPE_MAX_TASKS][CLIK_MAX_M];
+    int n_x;                        // virtual variables: state = [robot_var (n - n_x); virtual_var (n_x)]
 };
 
 constexpr bool shape_unit(const ShapeDesc& sd, int ti) { return sd.const_j[ti] != 0 && sd.m[ti] > 0 && sd.ucol[ti][0] > 0; }
@@ -133,7 +134,8 @@ inline bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
 {
     if (a.n != b.n || a.n_tasks != b.n_tasks || a.all_affine != b.all_affine || a.uses_fk != b.uses_fk ||
         a.quat_src != b.quat_src || a.feedforward != b.feedforward || a.multidim != b.multidim ||
-        a.conv_last != b.conv_last || a.standard != b.standard || a.nj != b.nj || a.n_y != b.n_y || a.qp != b.qp)
+        a.conv_last != b.conv_last || a.standard != b.standard || a.nj != b.nj || a.n_y != b.n_y || a.qp != b.qp ||
+        a.n_x != b.n_x)
         return false;
     for (int i = 0; i < a.n_tasks; ++i)
         if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i] ||

@@ -704,6 +704,28 @@ __device__ __forceinline__ void rows_from_lds(double* __restrict__ g, const int 
     }
 }
 
+// state of the lane's instance: z = [robot_var (NQ); virtual_var (NX)], each staged row-major
+template <int NQ, int NX>
+__device__ __forceinline__ void state_from_lds(const double* zs, const double* xs, const int lane, double (&z)[NQ + NX])
+{
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = zs[lane * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = xs[lane * NX + j];
+    }
+}
+template <int NQ, int NX>
+__device__ __forceinline__ void state_to_lds(const double (&v)[NQ + NX], double* zs, double* xs, const int lane)
+{
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) zs[lane * NQ + j] = v[j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xs[lane * NX + j] = v[NQ + j];
+    }
+}
+
 // ---- shape-specialised kernels ---------------------------------------------------
 // LDS layout: [skill image | zs (N slots) | ys (ny slots)], slot = 64 doubles.
 template <const ShapeDesc& SD>
@@ -776,7 +798,8 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
-    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const double* __restrict__ x,
+    double* __restrict__ dx, const TickArgs tk)
 {
     extern __shared__ double lds[];
     CLIK_STAMP(0);
@@ -790,7 +813,9 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     if (rows_valid < 0) return;  // (never taken: makes the next stamp wait for the kernel arguments)
 #endif
     CLIK_STAMP_DRAINED(6);      // kernel arguments have arrived
-    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
+    constexpr int NX = SD.n_x, NQ = SD.n - SD.n_x;
+    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;       // [64][NQ] robot_var, then [64][NX] virtual_var
+    double* xs = zs + NQ * WAVE;
     double* ys = zs + N * WAVE;
     // constants, joint state and inputs travel together: every global load is
     // issued (index-clamped, branch-free) before the first LDS write, so the
@@ -802,8 +827,9 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
 #pragma unroll
         for (int k = 0; k < StaticLayout<SD>::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
     }
-    double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
-    stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+    double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
+    stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
+    if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
     if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
     CLIK_STAMP_DRAINED(7);      // image, q and y are in registers
     {
@@ -814,14 +840,14 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
     // (tail block: the clamped loads filled the rows past rows_valid with copies of
     // the last element - finite values whose results are never stored)
-    rows_to_lds<N>(qv, zs, lane);
+    rows_to_lds<NQ>(qv, zs, lane);
+    if constexpr (NX > 0) rows_to_lds<NX>(xv, xs, lane);
     if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     __syncthreads();
     CLIK_STAMP(1);
 
     double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    state_from_lds<NQ, NX>(zs, xs, lane, z);
     double vout[N];
     int acc_mode;
     // Register copy of the skill image: scalar replacement keeps exactly the fields the tick
@@ -833,10 +859,10 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     CLIK_STAMP(4);
 
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[lane * N + j] = vout[j];
+    state_to_lds<NQ, NX>(vout, zs, xs, lane);
     __syncthreads();
-    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+    rows_from_lds<NQ>(dq + b0 * NQ, rows_valid, zs, lane);
+    if constexpr (NX > 0) rows_from_lds<NX>(dx + b0 * NX, rows_valid, xs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
     CLIK_STAMP(5);
 }
@@ -1210,7 +1236,7 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
                                       hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    if constexpr (shape_split_ok<SD>()) {
+    if constexpr (shape_split_ok<SD>() && SD.n_x == 0) {
         // one block per 64 instances, 2 or 4 waves each: worth it while blocks <= CUs-ish
         if (B <= kRoleSplitMaxBatch && (a.mode_parallel & 2)) {
             constexpr size_t shmem = SplitLayout<SD>::LDS_BYTES;
@@ -1224,7 +1250,7 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
             return hipGetLastError();
         }
     }
-    if constexpr (StaticLayout<SD>::n_sets == 1) {
+    if constexpr (StaticLayout<SD>::n_sets == 1 && SD.n_x == 0) {      // (the multi-wave kernels stage robot_var only)
         if (B <= kModeParallelMaxBatch && (a.mode_parallel & 1)) {
             const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)(SD.n + 1) * WAVE * sizeof(double);
             hipLaunchKernelGGL((pinv_solve_static_mp_kernel<SD>), dim3(grid), dim3(2 * WAVE), shmem, stream,
@@ -1233,7 +1259,7 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
         }
     }
     hipLaunchKernelGGL((pinv_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
-                       a.dImg, q, y, dq, mode, B, tk);
+                       a.dImg, q, y, dq, mode, B, x, dx, tk);
     return hipGetLastError();
 }
 

@@ -394,10 +394,11 @@ int qp_pick_static(const ShapeDesc& sd)
 }
 const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
-                            const double* y, double* dq, double* slack, int32_t* status, hipStream_t stream)
+                            const double* x, const double* y, double* dq, double* dx, double* slack,
+                            int32_t* status, hipStream_t stream)
 {
     if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
-    return kQpShapes[k].solve(d_img, tk, B, q, y, dq, slack, status, stream);
+    return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, stream);
 }
 
 }  // namespace clik

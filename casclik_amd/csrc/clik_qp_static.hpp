@@ -498,7 +498,7 @@ template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const TickArgs tk)
+    const double* __restrict__ x, double* __restrict__ dx, const TickArgs tk)
 {
     extern __shared__ double lds[];
     using LY = QpLayout<SD>;
@@ -511,8 +511,10 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     const long long left = B - b0;
     const int rows_valid = left < WAVE ? (int)left : WAVE;
     const bool valid = lane < rows_valid;
+    constexpr int NX = SD.n_x, NQ = SD.n - SD.n_x;
     double* slots = lds + LY::IMG_DOUBLES;
-    double* zs = slots + LY::O_Z * WAVE;
+    double* zs = slots + LY::O_Z * WAVE;                 // [64][NQ] robot_var, then [64][NX] virtual_var
+    double* xs = zs + NQ * WAVE;
     double* ys = slots + LY::O_Y * WAVE;
     // one memory round trip: image + options, joint state and inputs (see pinv_solve_static_kernel)
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -521,13 +523,15 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
         const d2* src = (const d2*)img_g;
 #pragma unroll
         for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
-        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
-        stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
+        if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
         if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
         d2* dst = (d2*)lds;
 #pragma unroll
         for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
-        rows_to_lds<N>(qv, zs, lane);
+        rows_to_lds<NQ>(qv, zs, lane);
+        if constexpr (NX > 0) rows_to_lds<NX>(xv, xs, lane);
         if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     }
     __syncthreads();
@@ -538,8 +542,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     const QpTail* __restrict__ T = &Treg;
     const double* ysl = ys + lane * SD.n_y;
     double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    state_from_lds<NQ, NX>(zs, xs, lane, z);
     __builtin_amdgcn_sched_barrier(0);
 
     // FK and the state-dependent rows, once
@@ -657,7 +660,8 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     // outputs through LDS (row-major rows, coalesced stores)
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j] + bad;
+    for (int j = 0; j < N; ++j) v[j] += bad;
+    state_to_lds<NQ, NX>(v, zs, xs, lane);
     if constexpr (NS > 0) {
         double* so = slots + LY::O_SL * WAVE;
         if (slack_out != nullptr) {
@@ -666,19 +670,23 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
         }
     }
     __syncthreads();
-    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+    rows_from_lds<NQ>(dq + b0 * NQ, rows_valid, zs, lane);
+    if constexpr (NX > 0) {
+        if (dx != nullptr) rows_from_lds<NX>(dx + b0 * NX, rows_valid, xs, lane);
+    }
     if constexpr (NS > 0) {
         if (slack_out != nullptr) rows_from_lds<NS>(slack_out + b0 * NS, rows_valid, slots + LY::O_SL * WAVE, lane);
     }
     if (status_out != nullptr && valid) status_out[b0 + lane] = status;
 }
 
-typedef hipError_t (*qp_static_fn)(const void*, const TickArgs&, long long, const double*, const double*, double*,
-                                   double*, int32_t*, hipStream_t);
+typedef hipError_t (*qp_static_fn)(const void*, const TickArgs&, long long, const double*, const double*,
+                                   const double*, double*, double*, double*, int32_t*, hipStream_t);
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long long B, const double* q,
-                                   const double* y, double* dq, double* slack, int32_t* status, hipStream_t stream)
+                                   const double* x, const double* y, double* dq, double* dx, double* slack,
+                                   int32_t* status, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
@@ -689,7 +697,7 @@ inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long l
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((qp_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
-                       status, B, tk);
+                       status, B, x, dx, tk);
     return hipGetLastError();
 }
 

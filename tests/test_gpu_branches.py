@@ -198,8 +198,11 @@ def _path_following_skill(fk):
     return cc.SkillSpecification("path", t, q, virtual_var=s, constraints=cons)
 
 
-def test_virtual_variable_pinv(ur5_fk):
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_virtual_variable_pinv(ur5_fk, kernel, monkeypatch):
     from oracle import clik_oracle
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
     spec = _path_following_skill(ur5_fk)
     rng = np.random.default_rng(3)
     home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
@@ -207,7 +210,7 @@ def test_virtual_variable_pinv(ur5_fk):
     X = rng.uniform(-0.1, 1.1, size=(150, 1))
     ctrl = cc.PseudoInverseController(skill_spec=spec)
     ctrl.setup_problem_functions()
-    assert ctrl.kernel_name == "dynamic"            # virtual variables run the dynamic-shape kernel
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
     dq, dx, mode = ctrl.solve_batch(0.0, Q, virtual_var=X)
     ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
     assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
@@ -218,8 +221,11 @@ def test_virtual_variable_pinv(ur5_fk):
     assert np.allclose(rob.toarray()[:, 0], ref[0, :6], atol=1e-9) and np.allclose(virt.toarray()[:, 0], ref[0, 6:], atol=1e-9)
 
 
-def test_virtual_variable_qp(ur5_fk):
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_virtual_variable_qp(ur5_fk, kernel, monkeypatch):
     from oracle import clik_oracle
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
     spec = _path_following_skill(ur5_fk)
     rng = np.random.default_rng(4)
     home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
@@ -228,7 +234,7 @@ def test_virtual_variable_qp(ur5_fk):
     ctrl = cc.ReactiveQPController(skill_spec=spec)
     ctrl.setup_problem_functions()
     ctrl.setup_solver()
-    assert ctrl.kernel_name == "dynamic"
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
     dq, dx, slack, status = ctrl.solve_batch(0.0, Q, virtual_var=X)
     rdq, rdx, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, X=X)
     # s beyond 1 with the hard progress rate contradicts the hard range set: infeasible on both sides
