@@ -234,32 +234,33 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         }
         // (2) pick the next constraint to enforce: unsatisfied equalities first,
         //     then the most violated inequality
-        if (need_p && !done) {
-            double best = 1e-11;
+        //     (written with selects, not per-lane branches: every divergent `if` costs
+        //     exec-mask bookkeeping on the scalar unit, which a lone wave pays in full)
+        {
+            const bool sel = need_p && !done;
+            double best = 1e-11, bpn = bp;
             int pick = -1;
             bool pick_up = false;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                if ((EXACT || i < nc) && !((W >> i) & 1u)) {
+                if (EXACT || i < nc) {
                     const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                    const double iscale = isc[i];
-                    const double vlo = (lbi - c[i]) * iscale, vhi = (c[i] - ubi) * iscale;
+                    const double vlo = (lbi - c[i]) * isc[i], vhi = (c[i] - ubi) * isc[i];
                     double v = fmax(vlo, vhi);
-                    if (((eq >> i) & 1u) && v > 1e-11) v += 1e30;       // equalities take precedence
-                    if (v > best) {
-                        best = v;
-                        pick = i;
-                        pick_up = vhi > vlo;
-                        bp = pick_up ? -ubi : lbi;
-                    }
+                    v += (((eq >> i) & 1u) && v > 1e-11) ? 1e30 : 0.0;      // equalities take precedence
+                    const bool better = !((W >> i) & 1u) && v > best;
+                    const bool upper = vhi > vlo;
+                    best = better ? v : best;
+                    pick = better ? i : pick;
+                    pick_up = better ? upper : pick_up;
+                    bpn = better ? (upper ? -ubi : lbi) : bpn;
                 }
             }
-            if (pick < 0) {
-                done = true;
-            } else {
-                p = pick;
-                sp = pick_up ? -1.0 : 1.0;
-            }
+            const bool take = sel && pick >= 0;
+            done = done || (sel && pick < 0);
+            p = take ? pick : p;
+            sp = take ? (pick_up ? -1.0 : 1.0) : sp;
+            bp = take ? bpn : bp;
         }
         if (__ballot(!done) == 0ull) break;
         // (3) step direction:  r = S_W^-1 (D Q_Wp sp),   zn = n_p' H^-1 (n_p - N_W r)
@@ -301,28 +302,25 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
         const double t2 = has_primal ? gap / zn : 1e300;
         const double t = fmin(t1, t2);
-        if (!done) {
-            if (!(t < 1e299)) {
-                status = 2;                 // constraint p cannot be satisfied
-                done = true;
-            } else {
+        {
+            const bool live = !done;
+            const bool stuck = live && !(t < 1e299);        // constraint p cannot be satisfied
+            const bool step = live && !stuck;
+            const bool full = step && (t2 <= t1);           // p enters the working set
+            const bool part = step && !full;                // l leaves it
+            status = stuck ? 2 : status;
+            done = done || stuck;
+            const double ts = step ? t : 0.0;
 #pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    nu[i] = fma(-t * a[i], r[i], nu[i]);
-                    nu[i] = fma((i == p) ? t : 0.0, sp, nu[i]);
-                }
-                if (t2 <= t1) {
-                    W |= 1u << p;
-                    if (sp < 0.0) up |= 1u << p;
-                    need_p = true;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NC; ++i) nu[i] = (i == l) ? 0.0 : nu[i];
-                    W &= ~(1u << l);
-                    up &= ~(1u << l);
-                    need_p = false;
-                }
+            for (int i = 0; i < NC; ++i) {
+                double ni = fma(-ts * a[i], r[i], nu[i]);
+                ni = fma((i == p) ? ts : 0.0, sp, ni);
+                nu[i] = (part && i == l) ? 0.0 : ni;
             }
+            const uint32_t pbit = 1u << (p & 31), lbit = part ? (1u << (l & 31)) : 0u;
+            W = (full ? (W | pbit) : W) & ~lbit;
+            up = ((full && sp < 0.0) ? (up | pbit) : up) & ~lbit;
+            need_p = step ? full : need_p;
         }
     }
     if (!done) status = 1;

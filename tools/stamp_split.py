@@ -1,5 +1,7 @@
+"""Diagnostic: per-wave cycle stamps of the opt-in role-split kernel (CLIK_ROLE_SPLIT=1):
+main wave of mode 0 (wave 0) and its helper (wave 1).  Separate JIT build with stamps."""
 import ctypes as C, os, sys
-os.environ["CLIK_NO_AOT"]="1"; os.environ["CLIK_JIT_STAMPS"]="1"
+os.environ["CLIK_NO_AOT"]="1"; os.environ["CLIK_JIT_STAMPS"]="1"; os.environ["CLIK_ROLE_SPLIT"]="1"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT","/root/repo"))
 import numpy as np, torch
 import casclik_amd as cc
