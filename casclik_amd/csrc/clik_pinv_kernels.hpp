@@ -919,11 +919,11 @@ __global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_k
         }
     }
     __syncthreads();
-    // Register copies of the skill image (see pinv_solve_static_kernel), one per phase here: each
-    // keeps only the fields its phase reads, so the constants of the mode evaluation are not live
-    // (or parked in AGPRs) during the kinematics.  Pays at small batches (-2.4 % on the config-3
-    // tick); with four busy SIMDs per CU the extra LDS reads cost more than they save, so the
-    // one-wave kernel copies once.
+    // Register copies of the skill image (see pinv_solve_static_kernel), one per phase here (the
+    // kinematics, then every task step): each keeps only the fields its phase reads, so later
+    // constants are not live (or parked in AGPRs) earlier.  Pays at small batches (-4 % on the
+    // config-3 tick); with four busy SIMDs per CU the extra LDS reads cost more than they save,
+    // so the one-wave kernel copies once.
     const Img<SD>* __restrict__ Slds = (const Img<SD>*)lds;
     const double* ysl = ys + lane * SD.n_y;
     double z[N];
@@ -943,13 +943,9 @@ __global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_k
     double v[N];
     bool ok;
     if (wave == 0) {
-        const Img<SD> S0 = *Slds;
-        __builtin_amdgcn_sched_barrier(0);
-        ok = pinv_mode_static<SD, 0u>(&S0, tk, tc, z, ysl, lane, v);
+        ok = pinv_mode_static<SD, 0u>(Slds, tk, tc, z, ysl, lane, v);       // (per-task copies inside)
     } else {
-        const Img<SD> S1 = *Slds;
-        __builtin_amdgcn_sched_barrier(0);
-        ok = pinv_mode_static<SD, 1u>(&S1, tk, tc, z, ysl, lane, v);
+        ok = pinv_mode_static<SD, 1u>(Slds, tk, tc, z, ysl, lane, v);
 #pragma unroll
         for (int j = 0; j < N; ++j) xs[j * WAVE + lane] = v[j];
         xs[N * WAVE + lane] = ok ? 1.0 : 0.0;

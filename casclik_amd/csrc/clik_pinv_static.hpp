@@ -719,6 +719,15 @@ struct ModeCtx {
 #define CLIK_MODE_IN const Img<SD>* __restrict__ S, const TickArgs& tk, const TaskCache<SD>& tc, \
                      const double (&z)[SD.n], const double* ys, const int lane
 #define CLIK_MODE_ARGS S, tk, tc, z, ys, lane
+// step_s / cone_s take their own register copy of the image fields they read (S_in may point
+// into LDS - the two-wave kernel passes the LDS image so that only the current task's constants
+// occupy registers - or to a caller's register copy, in which case this copy is free)
+#define CLIK_MODE_IN_RAW const Img<SD>* __restrict__ S_in, const TickArgs& tk, const TaskCache<SD>& tc, \
+                         const double (&z)[SD.n], const double* ys, const int lane
+#define CLIK_TASK_IMAGE(S, S_in)            \
+    const Img<SD> S##_copy = *S_in;         \
+    __builtin_amdgcn_sched_barrier(0);      \
+    const Img<SD>* __restrict__ S = &S##_copy
 
 // J[i][j] of task TI: cached per-lane value or image coefficient
 template <const ShapeDesc& SD, int TI>
@@ -1061,12 +1070,13 @@ __device__ __forceinline__ void push_s(const Img<SD>* __restrict__ S, const Task
 }
 
 template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
-__device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
+__device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>& c)
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (!P.skip) {
+        CLIK_TASK_IMAGE(S, S_in);
         const clik_task& t = S->tasks[TI];
         double e[M], Jt[M];
         task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
@@ -1201,12 +1211,13 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
 
 // in-tangent-cone test of the inactive SetConstraint TI (pseudo_inverse.py:162-185, :222-252)
 template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
-__device__ __forceinline__ void cone_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
+__device__ __forceinline__ void cone_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>& c)
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (P.cone) {
+        CLIK_TASK_IMAGE(S, S_in);
         const clik_task& t = S->tasks[TI];
         double e[M], Jt[M], de[M];
         task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
