@@ -668,7 +668,7 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
     if (clik::pinv_kernel_is_static(h->kernel)) {
         std::vector<char> img;
         if (!build_skill_image(S, img)) {
@@ -678,8 +678,8 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
             e = hipMalloc(&h->d_img, img.size());
             if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
-                if (h->d_img) hipFree(h->d_img);
-                hipFree(h->dev);
+                if (h->d_img) (void)hipFree(h->d_img);
+                (void)hipFree(h->dev);
                 delete h;
                 return hipfail(e, "skill image upload");
             }
@@ -718,7 +718,7 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
         hipError_t e = hipMalloc(&h->d_img, img.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            if (h->d_img) hipFree(h->d_img);
+            if (h->d_img) (void)hipFree(h->d_img);
             h->d_img = nullptr;
             return hipfail(e, "skill image upload");
         }
@@ -732,9 +732,9 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
 extern "C" int clik_pinv_destroy(clik_pinv* h)
 {
     if (!h) return CLIK_OK;
-    if (h->d_tterms) hipFree(h->d_tterms);
-    if (h->d_img) hipFree(h->d_img);
-    if (h->dev) hipFree(h->dev);
+    if (h->d_tterms) (void)hipFree(h->d_tterms);
+    if (h->d_img) (void)hipFree(h->d_img);
+    if (h->dev) (void)hipFree(h->dev);
     delete h;
     return CLIK_OK;
 }
@@ -796,7 +796,7 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
     if (need > 0) {
         if (!tterms) return fail(CLIK_EINVAL, "tterms required");
         if (need > h->d_tterms_cap) {
-            if (h->d_tterms) hipFree(h->d_tterms);
+            if (h->d_tterms) (void)hipFree(h->d_tterms);
             hipError_t e = hipMalloc((void**)&h->d_tterms, need * sizeof(double));
             if (e != hipSuccess) { h->d_tterms = nullptr; h->d_tterms_cap = 0; return hipfail(e, "hipMalloc(tterms)"); }
             h->d_tterms_cap = need;
@@ -825,7 +825,7 @@ static int qp_upload_image(clik_qp* h)
     hipError_t e = hipMalloc(&h->d_img, img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (h->d_img) hipFree(h->d_img);
+        if (h->d_img) (void)hipFree(h->d_img);
         h->d_img = nullptr;
         return hipfail(e, "QP skill image upload");
     }
@@ -885,7 +885,7 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
     {
         // shape-specialised kernel from the AOT table (CLIK_FORCE_DYNAMIC=1 / CLIK_NO_AOT=1 skip it)
         const char* force = getenv("CLIK_FORCE_DYNAMIC");
@@ -895,7 +895,7 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
             const int k = clik::qp_pick_static(S.shape);
             if (k >= 0) {
                 int rc2 = qp_upload_image(h);
-                if (rc2) { hipFree(h->dev); delete h; return rc2; }
+                if (rc2) { (void)hipFree(h->dev); delete h; return rc2; }
                 h->static_k = k;
             }
         }
@@ -947,8 +947,8 @@ extern "C" const char* clik_qp_kernel_name(const clik_qp* h)
 extern "C" int clik_qp_destroy(clik_qp* h)
 {
     if (!h) return CLIK_OK;
-    if (h->d_img) hipFree(h->d_img);
-    if (h->dev) hipFree(h->dev);
+    if (h->d_img) (void)hipFree(h->d_img);
+    if (h->dev) (void)hipFree(h->dev);
     delete h;
     return CLIK_OK;
 }
