@@ -226,6 +226,7 @@ def main():
                              "pose": "BASELINE config 2: %d x iiwa, single 6-D pose task" % B,
                              "qp": "BASELINE config 4: %d x iiwa ReactiveQPController" % B}[args.workload],
                 "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
+                "kernel": getattr(ctrl, "kernel_name", None),
                 "launch": ("hipGraph of K ticks" if graph is not None else "eager, one launch per tick") if TPL == 1
                           else "on-device rollout, %d ticks per launch (solve -> clamp -> Euler)" % TPL,
                 "ticks_per_s": K / wall, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
