@@ -853,9 +853,13 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     // Register copy of the skill image: scalar replacement keeps exactly the fields the tick
     // reads, and the scheduling barrier keeps their LDS reads together here (one wait) instead
     // of next to each use (measured: ~40 separate ~100-cycle LDS stalls per tick otherwise).
+#ifdef CLIK_NO_REGIMG
+    pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+#else
     const Img<SD> Sreg = *S;
     __builtin_amdgcn_sched_barrier(0);
     pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+#endif
     CLIK_STAMP(4);
 
     __syncthreads();
