@@ -270,3 +270,43 @@ def test_norm_rows_in_static_shapes(ur5_fk, kernel, monkeypatch):
     ctrl = _check(spec, None, Q, min_modes=4)
     assert ctrl.n_modes == 4
     assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
+
+
+def _cart_skill():
+    """cart_on_track_1D notebook (cells 3-6, 56): a 1-DoF cart q follows the path parameter s
+    (virtual variable) inside track limits - no kinematic chain at all, n_state = 2."""
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 1)
+    s = cs.MX.sym("s", 1)
+    cons = [cc.EqualityConstraint("follow", q - 2.0 * s, gain=3.0, priority=2, constraint_type="soft"),
+            cc.VelocityEqualityConstraint("advance", s, target=0.25, priority=1),
+            cc.SetConstraint("track", q, set_min=-1.0, set_max=1.0, gain=5.0, priority=0)]
+    return cc.SkillSpecification("cart", t, q, virtual_var=s, constraints=cons)
+
+
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_chainless_one_dof_skill(kernel, monkeypatch):
+    """Smallest possible problem (n_state = 2, no FK) through both controllers and both kernel
+    families."""
+    from oracle import clik_oracle
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    spec = _cart_skill()
+    rng = np.random.default_rng(2)
+    Q = rng.uniform(-1.3, 1.3, size=(200, 1))
+    X = rng.uniform(-0.2, 0.8, size=(200, 1))
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
+    dq, dx, mode = ctrl.solve_batch(0.0, Q, virtual_var=X)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
+    assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
+    assert _rel(np.hstack([dq, dx]), ref).max() < PINV_RTOL
+    qp = cc.ReactiveQPController(skill_spec=spec)
+    qp.setup_problem_functions()
+    qp.setup_solver()
+    assert (qp.kernel_name == "dynamic") == (kernel == "dynamic")
+    dq, dx, slack, status = qp.solve_batch(0.0, Q, virtual_var=X)
+    rdq, rdx, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, X=X)
+    assert np.array_equal(status, rstatus) and (status == 0).all()
+    assert _rel(np.hstack([dq, dx, slack]), np.hstack([rdq, rdx, rslack])).max() < 1e-8
