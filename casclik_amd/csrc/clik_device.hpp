@@ -758,12 +758,11 @@ __device__ __forceinline__ void gain_apply(const clik_task& t, const int m, cons
     }
 }
 
-// Cooperative, fully coalesced load of the wave's [64][w] row-major block into
-// LDS transposed to [w][64] (lane l then owns row l).  rows_valid <= 64.
-// All loads are issued before the first LDS write (one memory round trip);
-// WMAX bounds the unrolled issue (w <= WMAX).
-// The two halves of stage_in: unconditional (index-clamped) loads so that the
-// caller can put several blocks in flight before the first LDS write.
+// Cooperative, fully coalesced load of the wave's [64][w] row-major block into registers
+// (chunk i of lane l = element i*64 + l of the block).  rows_valid <= 64; the loads are
+// unconditional with clamped indices, so a caller can put several blocks in flight before
+// the first LDS write (one memory round trip).  WMAX bounds the unrolled issue (w <= WMAX).
+// The shape-specialised kernels then copy the chunks to LDS unchanged (rows_to_lds).
 template <int WMAX>
 __device__ __forceinline__ void stage_load(const double* __restrict__ g, const int w, const int rows_valid,
                                            const int lane, double (&v)[WMAX])
@@ -774,45 +773,6 @@ __device__ __forceinline__ void stage_load(const double* __restrict__ g, const i
         int k = (i < w ? i : 0) * WAVE + lane;
         k = k < last ? k : last;
         v[i] = g[k];
-    }
-}
-
-template <int WMAX>
-__device__ __forceinline__ void stage_store(const double (&v)[WMAX], const int w, const int rows_valid,
-                                            double* lds, const int lane)
-{
-    const int total = rows_valid * w;
-#pragma unroll
-    for (int i = 0; i < WMAX; ++i) {
-        const int k = i * WAVE + lane;
-        if (i < w && k < total) {
-            const int r = k / w, c = k - r * w;
-            lds[c * WAVE + r] = v[i];
-        }
-    }
-}
-
-template <int WMAX>
-__device__ __forceinline__ void stage_in(const double* __restrict__ g, const int w, const int rows_valid,
-                                         double* lds, const int lane)
-{
-    double v[WMAX];
-    stage_load<WMAX>(g, w, rows_valid, lane, v);
-    stage_store<WMAX>(v, w, rows_valid, lds, lane);
-}
-
-template <int WMAX>
-__device__ __forceinline__ void stage_out(double* __restrict__ g, const int w, const int rows_valid,
-                                          const double* lds, const int lane)
-{
-    const int total = rows_valid * w;
-#pragma unroll
-    for (int i = 0; i < WMAX; ++i) {
-        const int k = i * WAVE + lane;
-        if (i < w && k < total) {
-            const int r = k / w, c = k - r * w;
-            g[k] = lds[c * WAVE + r];
-        }
     }
 }
 
