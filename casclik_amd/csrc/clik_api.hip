@@ -555,8 +555,8 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     finish_pinv_shape(*S, opts);
     const clik::ShapeDesc& h = S->shape;
     const std::string o = shape_to_string(h);
-    // (kStaticMaxSets of clik_pinv_kernels.hpp: 2^3 mode bodies per kernel)
-    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->n_sets <= 3;
+    // (kStaticMaxSets of clik_pinv_kernels.hpp: up to 2^5 mode bodies per kernel)
+    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->n_sets <= 5;
     {
         std::vector<char> img;
         if (!build_skill_image(*S, img)) eligible = false;      // rows not in task order / too many rows

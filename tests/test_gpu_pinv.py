@@ -89,12 +89,16 @@ def test_static_and_dynamic_kernels_agree(iiwa_fk, monkeypatch):
     assert _rel(a, b).max() < PINV_RTOL
 
 
-def test_generic_skills_on_dynamic_kernel(ur5_fk):
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_skills_without_aot_shape(ur5_fk, kernel, monkeypatch):
     """Skills with no AOT shape: 1-D sets with a 32-mode scan + scalar distance
     task (ur5_transformation_matrix... cell 27) and a time-trajectory tracking
-    task with feed-forward (ur5_moe2016_example2 cell 7)."""
+    task with feed-forward (ur5_moe2016_example2 cell 7); served by run-time
+    instantiated kernels (32 mode bodies) or by the dynamic-shape kernels."""
     from oracle import clik_oracle
     from casclik_amd import sym as cs
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
     fk = ur5_fk
     t = cs.MX.sym("t")
     q = cs.MX.sym("q", 6)
@@ -106,7 +110,7 @@ def test_generic_skills_on_dynamic_kernel(ur5_fk):
         cons.append(cc.SetConstraint("limit_q_%d" % i, q[i], set_min=0.3 * lo[i], set_max=0.3 * hi[i], priority=i))
     spec = cc.SkillSpecification("point", t, q, constraints=cons)
     ctrl = _controller(spec)
-    assert ctrl.kernel_name == "dynamic" and ctrl.n_modes == 32
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic") and ctrl.n_modes == 32
     rng = np.random.default_rng(4)
     Q = rng.uniform(0.35 * lo, 0.35 * hi, size=(130, 6))
     dq, _, mode = ctrl.solve_batch(0.0, Q)
