@@ -555,8 +555,8 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     finish_pinv_shape(*S, opts);
     const clik::ShapeDesc& h = S->shape;
     const std::string o = shape_to_string(h);
-    // (kStaticMaxSets of clik_pinv_kernels.hpp: up to 2^5 mode bodies per kernel)
-    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->n_sets <= 5;
+    // (kStaticMaxSets of clik_pinv_kernels.hpp: up to 2^6 mode bodies per kernel)
+    bool eligible = S->d.n_tasks <= clik::SHAPE_MAX_TASKS && S->n_sets <= 6;
     {
         std::vector<char> img;
         if (!build_skill_image(*S, img)) eligible = false;      // rows not in task order / too many rows
@@ -710,7 +710,8 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
 // setup_problem_functions (pseudo_inverse.py:476-483).
 extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn, const char* name)
 {
-    if (!h || !solve_fn || !rollout_fn) return fail(CLIK_EINVAL, "null argument");
+    // (rollout_fn may be NULL: the rollout then keeps the kernel chosen at creation)
+    if (!h || !solve_fn) return fail(CLIK_EINVAL, "null argument");
     if (!h->d_img) {
         std::vector<char> img;
         if (!build_skill_image(h->host, img))

@@ -26,7 +26,7 @@ constexpr int WAVE = 64;
 // left; numeric values (gains, bounds, chain constants, row coefficients)
 // still come from the descriptor.  The dynamic fallback reads the same fields
 // from DevSkill at run time.
-constexpr int SHAPE_MAX_TASKS = 6;
+constexpr int SHAPE_MAX_TASKS = 8;
 constexpr int SHAPE_MAX_ROWS = SHAPE_MAX_TASKS * CLIK_MAX_M;
 struct ShapeDesc {
     int n;                          // n_q + n_x

@@ -487,7 +487,7 @@ constexpr unsigned shape_mode_act(const ShapeDesc& sd, int k)
         }
     return 0u;
 }
-constexpr int kStaticMaxSets = 5;       // up to 32 mode bodies per kernel (instantiated in scan order)
+constexpr int kStaticMaxSets = 6;       // up to 64 mode bodies per kernel (instantiated in scan order)
 
 // ---- one controller tick: FK once, then the mode scan (pseudo_inverse.py:530-555)
 template <int N, class SH>

@@ -183,7 +183,8 @@ int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts,
 /* attach a shape-specialised kernel that was instantiated at run time from the
  * library's kernel templates for exactly this skill structure (the analogue of
  * CasADi's JIT at setup_problem_functions, pseudo_inverse.py:476-483).  The
- * function pointers come from a shared object built by casclik_amd/jit.py.     */
+ * function pointers come from a shared object built by casclik_amd/jit.py.
+ * rollout_fn may be NULL (the rollout then keeps the kernel chosen at creation). */
 int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn, const char* name);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.

@@ -310,3 +310,29 @@ def test_chainless_one_dof_skill(kernel, monkeypatch):
     rdq, rdx, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, X=X)
     assert np.array_equal(status, rstatus) and (status == 0).all()
     assert _rel(np.hstack([dq, dx, slack]), np.hstack([rdq, rdx, rslack])).max() < 1e-8
+
+
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_all_joint_limits_as_sets_64_modes(ur5_fk, kernel, monkeypatch):
+    """Every UR5 joint limit as its own 1-D SetConstraint (the Moe-2016 way) above a position
+    task and a posture task: 8 constraints, 64 modes - the largest skill of the static family
+    (64 mode bodies in scan order; the build takes tens of seconds, once per skill structure)."""
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    # (the posture task drives q5: the tool position does not depend on it, and a set on a joint no task
+    # moves would have its tangent-cone test decided by rounding noise)
+    cons = [cc.EqualityConstraint("pos", p - np.array([0.4, 0.2, 0.3]), gain=5.0, priority=10),
+            cc.EqualityConstraint("posture", q[5] - 0.3, gain=1.0, priority=11)]
+    for i in range(6):
+        cons.append(cc.SetConstraint("limit_q_%d" % i, q[i], set_min=0.3 * lo[i], set_max=0.3 * hi[i], priority=i))
+    spec = cc.SkillSpecification("all_limits", t, q, constraints=cons)
+    rng = np.random.default_rng(29)
+    Q = rng.uniform(0.36 * lo, 0.36 * hi, size=(256, 6))
+    ctrl = _check(spec, None, Q, min_modes=10)
+    assert ctrl.n_modes == 64
+    assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
