@@ -220,3 +220,27 @@ def test_near_singular_configurations(iiwa_fk, skill):
     assert np.isfinite(dq).all()
     assert np.array_equal(mode, rmode)
     assert _rel(dq, ref).max() < PINV_RTOL, _rel(dq, ref).max()
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 129])
+def test_ragged_batch_sizes(iiwa_fk, B):
+    """Tail blocks (rows_valid < 64) of the two-wave kernel, the one-wave kernel and the
+    shape-specialised QP kernel: results identical to the same rows of a larger batch."""
+    from oracle import clik_oracle
+    Qall, Yall = skills.synthetic_inputs(iiwa_fk, 192, seed=77, distribution="mixed")
+    Q, Y = Qall[:B], Yall[:B]
+    for spec, opts in ((skills.stack_skill(iiwa_fk), dict(skills.STACK_OPTIONS)), (skills.pose_skill(iiwa_fk), None)):
+        ctrl = cc.PseudoInverseController(skill_spec=spec, options=opts)
+        ctrl.setup_problem_functions()
+        dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+        ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, 0.0, Q, Y=Y)
+        assert dq.shape == (B, 7) and np.array_equal(mode, rmode)
+        assert _rel(dq, ref).max() < PINV_RTOL
+    qspec = skills.qp_skill(iiwa_fk)
+    qctrl = cc.ReactiveQPController(skill_spec=qspec)
+    qctrl.setup_problem_functions()
+    qctrl.setup_solver()
+    dq, _, slack, status = qctrl.solve_batch(0.0, Q, input_var=Y)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(qspec, 0.0, Q, Y=Y)
+    assert (status == 0).all() and (rstatus == 0).all() and slack.shape == (B, 6)
+    assert _rel(dq, rdq).max() < 1e-8 and _rel(slack, rslack).max() < 1e-8
