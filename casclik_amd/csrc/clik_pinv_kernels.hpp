@@ -871,21 +871,21 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     CLIK_STAMP(5);
 }
 
-// Mode-parallel variant for small batches (fewer wavefronts than SIMDs): a
-// 128-thread block = two wavefronts on two SIMDs of one CU working on the SAME 64
-// instances; wave 0 evaluates mode 0 (set inactive), wave 1 speculatively
-// evaluates mode 1 (set active).  The mode scan of reference
-// pseudo_inverse.py:530-550 becomes a select: mode 0 if admissible, else mode 1
-// if admissible, else -1.  The tick costs max(mode 0, mode 1) instead of their
-// sum; the redundant FK of wave 1 runs on an otherwise idle SIMD.
+// Mode-parallel variant for small batches (fewer wavefronts than SIMDs) and skills with one or
+// two SetConstraints: a block = 2 or 4 wavefronts on different SIMDs of one CU working on the
+// SAME 64 instances; wave m speculatively evaluates the m-th mode of the reference's scan order.
+// The mode scan of pseudo_inverse.py:530-550 becomes a select: the first admissible mode, else
+// -1.  The tick costs the longest mode instead of the sum of the modes some lane needs; the
+// redundant FK of the extra waves runs on otherwise idle SIMDs.
 template <const ShapeDesc& SD>
-__global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_kernel(
+__global__ __launch_bounds__((1 << shape_n_sets(SD)) * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
     extern __shared__ double lds[];
     constexpr int N = SD.n;
-    static_assert(StaticLayout<SD>::n_sets == 1, "mode-parallel kernel is for shapes with one SetConstraint");
+    constexpr int NM = 1 << StaticLayout<SD>::n_sets;       // modes = waves per block (2 or 4)
+    static_assert(NM == 2 || NM == 4, "mode-parallel kernel is for shapes with one or two SetConstraints");
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long b0 = (long long)blockIdx.x * WAVE;
@@ -894,32 +894,33 @@ __global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_k
     const bool valid = lane < rows_valid;
     double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
     double* ys = zs + N * WAVE;
-    double* xs = ys + (SD.n_y > 0 ? SD.n_y : 0) * WAVE;      // exchange: v of mode 1 (N slots) + ok flag (1 slot)
+    double* xs = ys + (SD.n_y > 0 ? SD.n_y : 0) * WAVE;      // exchange: per later mode v (N slots) + ok flag (1 slot)
     typedef double d2 __attribute__((ext_vector_type(2)));
-    // the two waves split the prologue loads: wave 0 image + q, wave 1 image tail + y
     {
+        // the waves share the prologue loads: image chunks round-robin, q by wave 0, y by the last wave
         constexpr int CH = StaticLayout<SD>::IMG_CHUNKS;
-        constexpr int H0 = (CH + 1) / 2;
+        constexpr int PER = (CH + NM - 1) / NM;
         const d2* src = (const d2*)img_g;
         d2* dst = (d2*)lds;
-        if (wave == 0) {
-            d2 img[H0];
+        d2 img[PER];
 #pragma unroll
-            for (int k = 0; k < H0; ++k) img[k] = src[k * WAVE + lane];
-            double qv[N];
-            stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        for (int k = 0; k < PER; ++k) {
+            const int ck = k * NM + wave;
+            img[k] = src[(ck < CH ? ck : CH - 1) * WAVE + lane];
+        }
+        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
+        if (wave == 0) stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        if constexpr (SD.n_y > 0) {
+            if (wave == NM - 1) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+        }
 #pragma unroll
-            for (int k = 0; k < H0; ++k) dst[k * WAVE + lane] = img[k];
-            rows_to_lds<N>(qv, zs, lane);
-        } else {
-            d2 img[CH - H0 > 0 ? CH - H0 : 1];
-#pragma unroll
-            for (int k = H0; k < CH; ++k) img[k - H0] = src[k * WAVE + lane];
-            double yv[SD.n_y > 0 ? SD.n_y : 1];
-            if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
-#pragma unroll
-            for (int k = H0; k < CH; ++k) dst[k * WAVE + lane] = img[k - H0];
-            if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
+        for (int k = 0; k < PER; ++k) {
+            const int ck = k * NM + wave;
+            if (ck < CH) dst[ck * WAVE + lane] = img[k];
+        }
+        if (wave == 0) rows_to_lds<N>(qv, zs, lane);
+        if constexpr (SD.n_y > 0) {
+            if (wave == NM - 1) rows_to_lds<SD.n_y>(yv, ys, lane);
         }
     }
     __syncthreads();
@@ -945,26 +946,39 @@ __global__ __launch_bounds__(2 * WAVE) CLIK_OCC_ATTR void pinv_solve_static_mp_k
         cache_task<SD, 0>(&Sfk, tk, K, z, ysl, lane, tc);
     }
     double v[N];
-    bool ok;
-    if (wave == 0) {
-        ok = pinv_mode_static<SD, 0u>(Slds, tk, tc, z, ysl, lane, v);       // (per-task copies inside)
-    } else {
-        ok = pinv_mode_static<SD, 1u>(Slds, tk, tc, z, ysl, lane, v);
 #pragma unroll
-        for (int j = 0; j < N; ++j) xs[j * WAVE + lane] = v[j];
-        xs[N * WAVE + lane] = ok ? 1.0 : 0.0;
-    }
+    for (int j = 0; j < N; ++j) v[j] = 0.0;
+    bool ok = false;
+    // wave m evaluates the m-th mode of the reference's scan order (per-task image copies inside)
+    static_for<0, NM>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr unsigned ACT = shape_mode_act(SD, m);
+        if (wave == m) {
+            ok = pinv_mode_static<SD, ACT>(Slds, tk, tc, z, ysl, lane, v);
+            if constexpr (m > 0) {
+                double* xm = xs + (m - 1) * (N + 1) * WAVE;
+#pragma unroll
+                for (int j = 0; j < N; ++j) xm[j * WAVE + lane] = v[j];
+                xm[N * WAVE + lane] = ok ? 1.0 : 0.0;
+            }
+        }
+    });
     __syncthreads();
     if (wave == 0) {
-        int acc_mode = 0;
-        if (!ok) {
-            const bool ok1 = xs[N * WAVE + lane] != 0.0;
-            acc_mode = ok1 ? 1 : -1;
+        // the scan of pseudo_inverse.py:530-550 as a select: first admissible mode in scan order
+        int acc_mode = ok ? 0 : -1;
+        bool done = ok;
+        static_for<1, NM>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            const double* xm = xs + (m - 1) * (N + 1) * WAVE;
+            const bool take = !done && xm[N * WAVE + lane] != 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) v[j] = ok1 ? xs[j * WAVE + lane] : 0.0;
-        }
+            for (int j = 0; j < N; ++j) v[j] = take ? xm[j * WAVE + lane] : v[j];
+            acc_mode = take ? m : acc_mode;
+            done = done || take;
+        });
 #pragma unroll
-        for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j];
+        for (int j = 0; j < N; ++j) zs[lane * N + j] = done ? v[j] : 0.0;
         // (single wave from here on: LDS writes above are read back by the same wave)
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
@@ -1250,10 +1264,12 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
             return hipGetLastError();
         }
     }
-    if constexpr (StaticLayout<SD>::n_sets == 1 && SD.n_x == 0) {      // (the multi-wave kernels stage robot_var only)
-        if (B <= kModeParallelMaxBatch && (a.mode_parallel & 1)) {
-            const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)(SD.n + 1) * WAVE * sizeof(double);
-            hipLaunchKernelGGL((pinv_solve_static_mp_kernel<SD>), dim3(grid), dim3(2 * WAVE), shmem, stream,
+    if constexpr ((StaticLayout<SD>::n_sets == 1 || StaticLayout<SD>::n_sets == 2) && SD.n_x == 0) {
+        // one wave per mode (2 or 4) on the same 64 instances (the multi-wave kernels stage robot_var only)
+        constexpr int NM = 1 << StaticLayout<SD>::n_sets;
+        if (B <= kModeParallelMaxBatch / (NM / 2) && (a.mode_parallel & 1)) {
+            const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)(NM - 1) * (SD.n + 1) * WAVE * sizeof(double);
+            hipLaunchKernelGGL((pinv_solve_static_mp_kernel<SD>), dim3(grid), dim3(NM * WAVE), shmem, stream,
                                a.dImg, q, y, dq, mode, B, tk);
             return hipGetLastError();
         }
