@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--ticks-per-launch", type=int, default=1,
                     help="K > 1: the on-device rollout (K ticks of solve -> clamp -> Euler per launch, "
                          "SURVEY.md 8(d) 'launch-amortised'); steps must be a multiple of K")
+    ap.add_argument("--qp-hot", type=int, default=0,
+                    help="qp workload: carry each instance's working set from tick to tick (hot start)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -161,6 +163,8 @@ def main():
         args.graph = 0
         args.steps //= TPL
         args.warmup //= TPL
+    elif args.workload == "qp":
+        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ, hot_start=bool(args.qp_hot))
     else:
         tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ)
 
@@ -224,7 +228,8 @@ def main():
                                       "[multidim joint-limit set; 6-D pose; joint centering], "
                                       "PseudoInverseController" % B,
                              "pose": "BASELINE config 2: %d x iiwa, single 6-D pose task" % B,
-                             "qp": "BASELINE config 4: %d x iiwa ReactiveQPController" % B}[args.workload],
+                             "qp": "BASELINE config 4: %d x iiwa ReactiveQPController%s" % (
+                                 B, " (hot-started from the previous tick's working set)" if args.qp_hot else "")}[args.workload],
                 "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
                 "kernel": getattr(ctrl, "kernel_name", None),
                 "launch": ("hipGraph of K ticks" if graph is not None else "eager, one launch per tick") if TPL == 1

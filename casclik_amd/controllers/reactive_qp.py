@@ -206,10 +206,16 @@ class ReactiveQPController(BaseController):
 
     # -- per tick -----------------------------------------------------------------
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
-                    return_status=True):
+                    return_status=True, hot_set=None, use_hot=True):
         """One QP tick for a batch: returns (robot_vel [B,n_q], virtual_vel |
         None, slack [B,n_slack] | None, status [B]) - status 0 optimal,
-        1 iteration cap, 2 infeasible (then the velocities are NaN)."""
+        1 iteration cap, 2 infeasible (then the velocities are NaN).
+
+        ``hot_set``: optional int32 device tensor [B] carrying every instance's
+        working set from tick to tick (the reference's qpOASES instance hot-starts
+        the same way, reactive_qp.py:491-513).  It is read when ``use_hot`` and
+        always overwritten with the final working set; the minimiser is the same
+        with or without it."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -231,10 +237,13 @@ class ReactiveQPController(BaseController):
         SL = torch.empty((B, ns), dtype=torch.float64, device=dev) if ns else None
         status = torch.empty((B,), dtype=torch.int32, device=dev) if return_status else None
         tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
+        if hot_set is not None and (hot_set.dtype != torch.int32 or hot_set.numel() != B or not hot_set.is_cuda):
+            raise ValueError("hot_set must be an int32 device tensor with one entry per instance")
         with torch.cuda.device(dev):
-            rc = self._lib.clik_qp_solve_batch(
+            rc = self._lib.clik_qp_solve_batch_hot(
                 self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
-                ptr(SL), ptr(status), current_stream(dev))
+                ptr(SL), ptr(status), ptr(hot_set), 1 if (hot_set is not None and use_hot) else 0,
+                current_stream(dev))
         _capi.check(self._lib, rc)
         if was_np:
             return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),
@@ -242,9 +251,10 @@ class ReactiveQPController(BaseController):
                     None if status is None else status.cpu().numpy())
         return dQ, dX, SL, status
 
-    def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None):
+    def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None, hot_start=False):
         """Pre-bind device tensors and return ``tick(time_var=0.0)``: one kernel
-        launch per call (lean path for control loops, graph capture, benchmarks)."""
+        launch per call (lean path for control loops, graph capture, benchmarks).
+        ``hot_start``: keep each instance's working set between ticks (see solve_batch)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -260,18 +270,22 @@ class ReactiveQPController(BaseController):
         dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
         SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None
         status = torch.empty((B,), dtype=torch.int32, device=dev)
-        fn, handle, lib = self._lib.clik_qp_solve_batch, self._handle, self._lib
-        args = (ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(SL), ptr(status))
+        fn, handle, lib = self._lib.clik_qp_solve_batch_hot, self._handle, self._lib
+        hot = torch.zeros((B,), dtype=torch.int32, device=dev) if hot_start else None
+        args = (ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(SL), ptr(status), ptr(hot))
         static_tt = _capi.tterms_arg(np.zeros(0)) if d.n_tslots == 0 else None
+        state = {"ticks": 0}
 
         def tick(time_var=0.0, stream_handle=None):
             tt, ttp = static_tt if static_tt is not None else _capi.tterms_arg(d.time_terms(time_var))
             sh = stream_handle if stream_handle is not None else current_stream(dev)
-            rc = fn(handle, B, ttp, *args, sh)
+            rc = fn(handle, B, ttp, *args, 1 if (hot is not None and state["ticks"] > 0) else 0, sh)
+            state["ticks"] += 1
             if rc != 0:
                 _capi.check(lib, rc)
 
-        tick.tensors = (Q, X, Y, dQ, dX, SL, status)
+        tick.tensors = (Q, X, Y, dQ, dX, SL, status, hot)
+        tick.hot_set = hot
         tick.out, tick.slack, tick.status = dQ, SL, status
         return tick
 

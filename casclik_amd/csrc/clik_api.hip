@@ -52,7 +52,7 @@ int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
-                            int32_t* status, hipStream_t stream);
+                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -80,7 +80,7 @@ struct clik_pinv {
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
-                                     const double*, double*, double*, double*, int32_t*, hipStream_t);
+                                     const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
 
 struct clik_qp {
     DevSkill  host;
@@ -972,6 +972,13 @@ extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tt
                                    const double* x, const double* y, double* dq, double* dx, double* slack,
                                    int32_t* status, void* stream)
 {
+    return clik_qp_solve_batch_hot(h, B, tterms, q, x, y, dq, dx, slack, status, nullptr, 0, stream);
+}
+
+extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms, const double* q,
+                                       const double* x, const double* y, double* dq, double* dx, double* slack,
+                                       int32_t* status, int32_t* hot_set, int32_t use_hot, void* stream)
+{
     int rc = qp_check_args(h, B, q, x, y);
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
@@ -981,10 +988,11 @@ extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tt
     if (rc) return rc;
     hipError_t e;
     if (h->jit_solve)
-        e = h->jit_solve(h->d_img, &tk, (long long)B, q, x, y, dq, dx, slack, status, (hipStream_t)stream);
+        e = h->jit_solve(h->d_img, &tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set, use_hot,
+                         (hipStream_t)stream);
     else if (h->static_k >= 0)
-        e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, x, y, dq, dx, slack, status,
-                                   (hipStream_t)stream);
+        e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set,
+                                   use_hot, (hipStream_t)stream);
     else
         e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,
                                   slack, status, (hipStream_t)stream);

@@ -395,10 +395,10 @@ int qp_pick_static(const ShapeDesc& sd)
 const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
-                            int32_t* status, hipStream_t stream)
+                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream)
 {
     if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
-    return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, stream);
+    return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream);
 }
 
 }  // namespace clik

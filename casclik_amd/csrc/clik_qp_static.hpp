@@ -89,7 +89,7 @@ template <int NC, bool EXACT, bool WARM = false>
 __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, const double* ubs, const double* c0s,
                                         const uint32_t softeq, const int lane, const int nc_rt,
                                         const int max_iter, const bool lane_valid, double (&nu)[NC],
-                                        const int n_vars = NC)
+                                        const int n_vars = NC, int32_t* hot = nullptr, const bool use_hot = false)
 {
     constexpr int NT = NC * (NC + 1) / 2;
     const int nc = EXACT ? NC : nc_rt;
@@ -147,6 +147,16 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                     ++cnt;
                 }
             }
+        }
+        if (use_hot && hot != nullptr) {
+            // hot start: the working set of the previous tick of this instance (bits 0..15 rows,
+            // bits 16..31 "at the upper bound"), like the reference's qpOASES hot start
+            // (reactive_qp.py:491-513).  Any set is only a guess: the passes below repair it.
+            const uint32_t bits = (uint32_t)*hot;
+            const uint32_t rowmask = (NC >= 16) ? 0xffffu : ((1u << NC) - 1u);
+            W0 = bits & rowmask;
+            up0 = (bits >> 16) & W0;
+            cnt = __builtin_popcount(W0);
         }
         if (cnt > n_vars || !lane_valid) W0 = 0u;
         int pd_left = kPdPasses;
@@ -370,6 +380,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         }
     }
     if (!done) status = 1;
+    if (hot != nullptr && lane_valid) *hot = (int32_t)((W & 0xffffu) | ((up & 0xffffu) << 16));
 #ifdef CLIK_QP_DIAG
     status |= (g_qp_diag_iters << 8) | (g_qp_diag_warm << 16) | (g_qp_diag_cold << 24);
 #endif
@@ -542,7 +553,8 @@ template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const double* __restrict__ x, double* __restrict__ dx, const TickArgs tk)
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
 {
     extern __shared__ double lds[];
     using LY = QpLayout<SD>;
@@ -663,7 +675,8 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
             });
         });
         double nu[NRA];
-        status = gi_solve<NRA, true, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu, N);
+        status = gi_solve<NRA, true, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu, N,
+                                           hot_set != nullptr ? hot_set + (b0 + lane) : nullptr, use_hot != 0);
         // v = v0 + Y nu;  slack of soft inequality rows = -nu / h_s
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -725,12 +738,12 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
 }
 
 typedef hipError_t (*qp_static_fn)(const void*, const TickArgs&, long long, const double*, const double*,
-                                   const double*, double*, double*, double*, int32_t*, hipStream_t);
+                                   const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long long B, const double* q,
                                    const double* x, const double* y, double* dq, double* dx, double* slack,
-                                   int32_t* status, hipStream_t stream)
+                                   int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
@@ -741,7 +754,7 @@ inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long l
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((qp_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
-                       status, B, x, dx, tk);
+                       status, B, x, dx, hot_set, use_hot, tk);
     return hipGetLastError();
 }
 

@@ -229,6 +229,17 @@ int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tterms,
                         double* dq, double* dx, double* slack, int32_t* status,
                         void* stream);
 
+/* The same with a hot start (the reference's qpOASES instance hot-starts from the previous
+ * call, reactive_qp.py:491-513): hot_set [B] int32 (device, in/out) carries each instance's
+ * working set from tick to tick.  use_hot = 0: cold guess, the final set is only written (first
+ * tick); use_hot = 1: the stored set seeds the active-set iteration, then is overwritten.  The
+ * set is a guess that the solver repairs; the result is the same minimiser.  Only the
+ * shape-specialised kernels use it (the dynamic fallback ignores it and leaves it unchanged).  */
+int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms,
+                            const double* q, const double* x, const double* y,
+                            double* dq, double* dx, double* slack, int32_t* status,
+                            int32_t* hot_set, int32_t use_hot, void* stream);
+
 /* QP data only (H diag, A, lbA, ubA as the reference's H_func/A_func/Blb/Bub,
  * reactive_qp.py:283-298) for inspection and parity tests:
  *   Hdiag [B][nv], A [B][nc][nv] row-major, lbA [B][nc], ubA [B][nc]          */

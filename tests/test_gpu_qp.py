@@ -202,3 +202,29 @@ def test_qp_soft_set_hard_equality_mix(ur5_fk):
     for b in range(len(Q)):
         prim, stat, sign = clik_oracle.kkt_residuals(hd[b], A[b], lb[b], ub[b], np.concatenate([dq[b], slack[b]]))
         assert prim < KKT_TOL and stat < KKT_TOL and sign < KKT_TOL
+
+
+def test_qp_hot_start_gives_the_same_minimiser(iiwa_fk):
+    """Hot start (working set carried between ticks, like the reference's qpOASES instance):
+    exact hint, stale hint from a different state and garbage hint all end at the cold result."""
+    import torch
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 300, seed=33, distribution="mixed")
+    Q2, _ = skills.synthetic_inputs(iiwa_fk, 300, seed=34, distribution="mixed")
+    cold = ctrl.solve_batch(0.0, Q, input_var=Y)
+    hot = torch.zeros(300, dtype=torch.int32, device="cuda")
+    first = ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot, use_hot=False)       # writes the set
+    sets = hot.cpu().numpy().copy()
+    assert (sets != 0).any()
+    again = ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot)                      # exact hint
+    assert np.array_equal(hot.cpu().numpy(), sets)
+    ctrl.solve_batch(0.0, Q2, input_var=Y, hot_set=hot)                             # another state
+    stale = ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot)                      # stale hint
+    junk_t = torch.from_numpy(np.random.default_rng(1).integers(-2**31, 2**31 - 1, size=300).astype(np.int32)).cuda()
+    junk = ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=junk_t)                    # garbage hint
+    rdq, _, rslack, _ = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y)
+    for res in (cold, first, again, stale, junk):
+        assert (res[3] == 0).all()
+        assert _rel(res[0], rdq).max() < QP_RTOL and _rel(res[2], rslack).max() < QP_RTOL
