@@ -153,13 +153,13 @@ def main():
 
     TPL = args.ticks_per_launch
     if TPL > 1:
-        if args.workload == "qp" or args.steps % TPL or args.warmup % TPL:
-            raise SystemExit("--ticks-per-launch needs a pinv workload and steps/warmup divisible by it")
+        if args.steps % TPL or args.warmup % TPL:
+            raise SystemExit("--ticks-per-launch needs steps and warmup divisible by it")
         times = [0.0] * TPL
         state = {"q": Qd}
 
         def tick():         # one launch = TPL ticks; the state is carried from launch to launch
-            state["q"], _, _ = ctrl.rollout_batch(times, state["q"], input_var=Yd, dt=1e-3, max_speed=2.0)
+            state["q"] = ctrl.rollout_batch(times, state["q"], input_var=Yd, dt=1e-3, max_speed=2.0)[0]
         args.graph = 0
         args.steps //= TPL
         args.warmup //= TPL

@@ -251,6 +251,38 @@ class ReactiveQPController(BaseController):
                     None if status is None else status.cpu().numpy())
         return dQ, dX, SL, status
 
+    def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008, max_speed=0.0):
+        """``len(time_vars)`` ticks of QP solve -> clamp(+-max_speed) -> Euler ``q += dq*dt`` in
+        one launch, the working set hot-started from tick to tick (the host loop of
+        ur5_moe2016_example2.ipynb:537-545 for this controller).  Returns
+        (q_final, dq_last, slack_last | None, status [B] = worst status met)."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        if not was_np:
+            Q = Q.clone()
+        B = Q.shape[0]
+        Y = None
+        if d.n_y > 0:
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        times = np.asarray(time_vars, dtype=float).reshape(-1)
+        tt = np.concatenate([d.time_terms(t) for t in times]) if d.n_tslots else np.zeros(0)
+        tt, ttp = _capi.tterms_arg(tt)
+        dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_qp_rollout_batch(
+                self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
+                ptr(Q), ptr(Y), ptr(dQ), ptr(SL), ptr(status), current_stream(dev))
+        _capi.check(self._lib, rc)
+        if was_np:
+            return (Q.cpu().numpy(), dQ.cpu().numpy(), None if SL is None else SL.cpu().numpy(),
+                    status.cpu().numpy())
+        return Q, dQ, SL, status
+
     def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None, hot_start=False):
         """Pre-bind device tensors and return ``tick(time_var=0.0)``: one kernel
         launch per call (lean path for control loops, graph capture, benchmarks).

@@ -53,6 +53,9 @@ const char* qp_static_name(int k);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream);
+hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
+                                    double max_speed, long long B, double* q, const double* y, double* dq,
+                                    double* slack, int32_t* status, hipStream_t stream);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -82,6 +85,9 @@ struct clik_pinv {
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
                                      const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
 
+typedef hipError_t (*clik_jit_qp_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
+                                             const double*, double*, double*, int32_t*, hipStream_t);
+
 struct clik_qp {
     DevSkill  host;
     DevSkill* dev;
@@ -90,7 +96,10 @@ struct clik_qp {
     void*     d_img;        // shape-specialised kernels: skill image + QP options
     int       static_k;     // AOT shape-specialised kernel, -1 none
     clik_jit_qp_fn jit_solve;
+    clik_jit_qp_rollout_fn jit_rollout;
     char      jit_name[64];
+    double*   d_tterms;     // rollout workspace
+    size_t    d_tterms_cap;
 };
 
 static thread_local char g_err[512] = "";
@@ -882,7 +891,10 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     h->d_img = nullptr;
     h->static_k = -1;
     h->jit_solve = nullptr;
+    h->jit_rollout = nullptr;
     h->jit_name[0] = 0;
+    h->d_tterms = nullptr;
+    h->d_tterms_cap = 0;
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
@@ -925,15 +937,55 @@ extern "C" int clik_qp_shape_describe(const clik_skill_desc* desc, char* buf, in
 
 // Attach a shape-specialised QP kernel compiled at run time (casclik_amd/jit.py instantiates
 // clik_qp_static.hpp for the ShapeDesc that clik_qp_shape_describe printed).
-extern "C" int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, const char* name)
+extern "C" int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, void* rollout_fn, const char* name)
 {
+    // (rollout_fn may be NULL: clik_qp_rollout_batch then needs an AOT kernel)
     if (!h || !solve_fn) return fail(CLIK_EINVAL, "null argument");
     if (!qp_static_eligible(h->host))
         return fail(CLIK_EUNSUPPORTED, "skill is outside the shape-specialised QP family");
     int rc = qp_upload_image(h);
     if (rc) return rc;
     h->jit_solve = (clik_jit_qp_fn)solve_fn;
+    h->jit_rollout = (clik_jit_qp_rollout_fn)rollout_fn;
     snprintf(h->jit_name, sizeof(h->jit_name), "%s", name ? name : "jit");
+    return CLIK_OK;
+}
+
+// n_ticks of QP solve -> clamp -> Euler in one launch (SURVEY.md 8(f).1 for the QP controller); the
+// working set is carried from tick to tick inside the kernel.  Needs a shape-specialised kernel.
+extern "C" int clik_qp_rollout_batch(const clik_qp* hc, int64_t B, int32_t n_ticks, double dt, double max_speed,
+                                     const double* tterms, double* q, const double* y, double* dq,
+                                     double* slack, int32_t* status, void* stream)
+{
+    clik_qp* h = const_cast<clik_qp*>(hc);
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
+    if (B == 0 || n_ticks == 0) return CLIK_OK;
+    const DevSkill& S = h->host;
+    if (S.d.n_x > 0) return fail(CLIK_EUNSUPPORTED, "rollout with virtual_var is not supported");
+    if (!h->jit_rollout && h->static_k < 0)
+        return fail(CLIK_EUNSUPPORTED, "the QP rollout needs a shape-specialised kernel (none attached for this skill)");
+    if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
+    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    const size_t need = (size_t)n_ticks * 2 * (size_t)S.d.n_tslots;
+    if (need > 0) {
+        if (!tterms) return fail(CLIK_EINVAL, "tterms required");
+        if (need > h->d_tterms_cap) {
+            if (h->d_tterms) (void)hipFree(h->d_tterms);
+            hipError_t e = hipMalloc((void**)&h->d_tterms, need * sizeof(double));
+            if (e != hipSuccess) { h->d_tterms = nullptr; h->d_tterms_cap = 0; return hipfail(e, "hipMalloc(tterms)"); }
+            h->d_tterms_cap = need;
+        }
+        hipError_t e = hipMemcpyAsync(h->d_tterms, tterms, need * sizeof(double), hipMemcpyHostToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
+    }
+    hipError_t e = h->jit_rollout
+                       ? h->jit_rollout(h->d_img, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack,
+                                        status, (hipStream_t)stream)
+                       : clik::qp_launch_rollout_static(h->static_k, h->d_img, h->d_tterms, n_ticks, dt, max_speed,
+                                                        (long long)B, q, y, dq, slack, status, (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "qp_rollout_kernel launch");
     return CLIK_OK;
 }
 
@@ -948,6 +1000,7 @@ extern "C" const char* clik_qp_kernel_name(const clik_qp* h)
 extern "C" int clik_qp_destroy(clik_qp* h)
 {
     if (!h) return CLIK_OK;
+    if (h->d_tterms) (void)hipFree(h->d_tterms);
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->dev) (void)hipFree(h->dev);
     delete h;

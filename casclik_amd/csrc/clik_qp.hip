@@ -376,13 +376,14 @@ struct QpStaticEntry {
     const char* name;
     const ShapeDesc* sd;
     qp_static_fn solve;
+    qp_static_rollout_fn rollout;
 };
-#define CLIK_QP_STATIC_ENTRY(S) {"qp_static_" #S, &shapes::S, &launch_qp_static<shapes::S>},
+#define CLIK_QP_STATIC_ENTRY(S) {"qp_static_" #S, &shapes::S, &launch_qp_static<shapes::S>, &launch_qp_rollout_static<shapes::S>},
 static const QpStaticEntry kQpShapes[] = {
 #ifdef CLIK_GENERATED_QP_SHAPES
     CLIK_GENERATED_QP_SHAPES(CLIK_QP_STATIC_ENTRY)
 #endif
-    {nullptr, nullptr, nullptr}
+    {nullptr, nullptr, nullptr, nullptr}
 };
 constexpr int kNumQpShapes = (int)(sizeof(kQpShapes) / sizeof(kQpShapes[0])) - 1;
 
@@ -399,6 +400,14 @@ hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long l
 {
     if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
     return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream);
+}
+
+hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
+                                    double max_speed, long long B, double* q, const double* y, double* dq,
+                                    double* slack, int32_t* status, hipStream_t stream)
+{
+    if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
+    return kQpShapes[k].rollout(d_img, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, slack, status, stream);
 }
 
 }  // namespace clik

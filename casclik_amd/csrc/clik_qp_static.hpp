@@ -549,58 +549,21 @@ __device__ __forceinline__ double qp_row_s(const Img<SD>* __restrict__ S, const 
     return jac<SD, TI>(S, tc, i, j);
 }
 
+// One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
+// v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
+// slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
 template <const ShapeDesc& SD>
-__global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
-    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
-    const TickArgs tk)
+__device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
+                                              const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
+                                              const int lane, const bool valid, double* slots,
+                                              double (&v)[SD.n], double (&sl)[QpLayout<SD>::NSA],
+                                              int32_t* hot, const bool use_hot)
 {
-    extern __shared__ double lds[];
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
     constexpr int NR = LY::NR, NRA = LY::NRA, NS = LY::NS;
     constexpr QpPlanS P = LY::P;
     constexpr int NTN = N * (N + 1) / 2;
-    const int lane = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
-    constexpr int NX = SD.n_x, NQ = SD.n - SD.n_x;
-    double* slots = lds + LY::IMG_DOUBLES;
-    double* zs = slots + LY::O_Z * WAVE;                 // [64][NQ] robot_var, then [64][NX] virtual_var
-    double* xs = zs + NQ * WAVE;
-    double* ys = slots + LY::O_Y * WAVE;
-    // one memory round trip: image + options, joint state and inputs (see pinv_solve_static_kernel)
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    {
-        d2 img[LY::IMG_CHUNKS];
-        const d2* src = (const d2*)img_g;
-#pragma unroll
-        for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
-        double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
-        stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
-        if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
-        if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
-        d2* dst = (d2*)lds;
-#pragma unroll
-        for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
-        rows_to_lds<NQ>(qv, zs, lane);
-        if constexpr (NX > 0) rows_to_lds<NX>(xv, xs, lane);
-        if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
-    }
-    __syncthreads();
-    // register copies of the skill image and the QP options (see pinv_solve_static_kernel)
-    const Img<SD> Sreg = *(const Img<SD>*)lds;
-    const QpTail Treg = *(const QpTail*)((const char*)lds + LY::TAIL_OFF);
-    const Img<SD>* __restrict__ S = &Sreg;
-    const QpTail* __restrict__ T = &Treg;
-    const double* ysl = ys + lane * SD.n_y;
-    double z[N];
-    state_from_lds<NQ, NX>(zs, xs, lane, z);
-    __builtin_amdgcn_sched_barrier(0);
-
     // FK and the state-dependent rows, once
     TaskCache<SD> tc;
     {
@@ -613,7 +576,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     }
 
     // P = H_v + sum_soft-eq J' diag(h_s) J,  g = sum J' diag(h_s) b;  bounds of the other rows -> LDS
-    double L[NTN], rd[N], v[N];
+    double L[NTN], rd[N];
 #pragma unroll
     for (int a = 0; a < N; ++a) {
         v[a] = 0.0;
@@ -675,8 +638,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
             });
         });
         double nu[NRA];
-        status = gi_solve<NRA, true, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu, N,
-                                           hot_set != nullptr ? hot_set + (b0 + lane) : nullptr, use_hot != 0);
+        status = gi_solve<NRA, true, true>(Qs, lbs, ubs, c0s, 0u, lane, NR, T->max_iter, valid, nu, N, hot, use_hot);
         // v = v0 + Y nu;  slack of soft inequality rows = -nu / h_s
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -691,9 +653,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
             }
         });
     }
-    const double bad = (status == 2) ? __builtin_nan("") : 0.0;
     // slack of the folded rows: s = J v - b
-    double sl[LY::NSA];
 #pragma unroll
     for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * WAVE + lane] : 0.0;
     static_for<0, SD.n_tasks>([&](auto tc_) __attribute__((always_inline)) {
@@ -714,6 +674,65 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
             });
         }
     });
+    return status;
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    extern __shared__ double lds[];
+    using LY = QpLayout<SD>;
+    constexpr int N = SD.n;
+    constexpr int NR = LY::NR, NRA = LY::NRA, NS = LY::NS;
+    constexpr QpPlanS P = LY::P;
+    constexpr int NTN = N * (N + 1) / 2;
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    constexpr int NX = SD.n_x, NQ = SD.n - SD.n_x;
+    double* slots = lds + LY::IMG_DOUBLES;
+    double* zs = slots + LY::O_Z * WAVE;                 // [64][NQ] robot_var, then [64][NX] virtual_var
+    double* xs = zs + NQ * WAVE;
+    double* ys = slots + LY::O_Y * WAVE;
+    // one memory round trip: image + options, joint state and inputs (see pinv_solve_static_kernel)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    {
+        d2 img[LY::IMG_CHUNKS];
+        const d2* src = (const d2*)img_g;
+#pragma unroll
+        for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
+        double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
+        if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
+        if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+        d2* dst = (d2*)lds;
+#pragma unroll
+        for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
+        rows_to_lds<NQ>(qv, zs, lane);
+        if constexpr (NX > 0) rows_to_lds<NX>(xv, xs, lane);
+        if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
+    }
+    __syncthreads();
+    // register copies of the skill image and the QP options (see pinv_solve_static_kernel)
+    const Img<SD> Sreg = *(const Img<SD>*)lds;
+    const QpTail Treg = *(const QpTail*)((const char*)lds + LY::TAIL_OFF);
+    const Img<SD>* __restrict__ S = &Sreg;
+    const QpTail* __restrict__ T = &Treg;
+    const double* ysl = ys + lane * SD.n_y;
+    double z[N];
+    state_from_lds<NQ, NX>(zs, xs, lane, z);
+    __builtin_amdgcn_sched_barrier(0);
+
+    double v[N], sl[LY::NSA];
+    const int status = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl,
+                                          hot_set != nullptr ? hot_set + (b0 + lane) : nullptr, use_hot != 0);
+    const double bad = (status == 2) ? __builtin_nan("") : 0.0;
     // outputs through LDS (row-major rows, coalesced stores)
     __syncthreads();
 #pragma unroll
@@ -735,6 +754,122 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
         if (slack_out != nullptr) rows_from_lds<NS>(slack_out + b0 * NS, rows_valid, slots + LY::O_SL * WAVE, lane);
     }
     if (status_out != nullptr && valid) status_out[b0 + lane] = status;
+}
+
+// n_ticks of (QP tick -> clamp(+-max_speed) -> explicit Euler q += dq dt) in one launch: the host
+// loop of the notebooks (ur5_moe2016_example2.ipynb:537-545) for the QP controller.  The working
+// set stays in a register from tick to tick (hot start), the skill image and the targets in LDS.
+// q is updated in place; dq / slack receive the last tick, status the worst status met.
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
+    const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed)
+{
+    extern __shared__ double lds[];
+    using LY = QpLayout<SD>;
+    constexpr int N = SD.n;
+    constexpr int NS = LY::NS;
+    static_assert(SD.n_x == 0, "the rollout integrates robot variables only");
+    const int lane = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
+    double* slots = lds + LY::IMG_DOUBLES;
+    double* zs = slots + LY::O_Z * WAVE;
+    double* ys = slots + LY::O_Y * WAVE;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    {
+        d2 img[LY::IMG_CHUNKS];
+        const d2* src = (const d2*)img_g;
+#pragma unroll
+        for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
+        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
+        d2* dst = (d2*)lds;
+#pragma unroll
+        for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
+        rows_to_lds<N>(qv, zs, lane);
+        if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
+    }
+    __syncthreads();
+    const Img<SD>* __restrict__ S = (const Img<SD>*)lds;
+    const QpTail* __restrict__ T = (const QpTail*)((const char*)lds + LY::TAIL_OFF);
+    const int nts = S->n_tslots;
+    const double* ysl = ys + lane * SD.n_y;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    double v[N], sl[LY::NSA];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < LY::NSA; ++k) sl[k] = 0.0;
+    int32_t hot = 0;
+    int worst = 0;
+#pragma unroll 1
+    for (int tick = 0; tick < n_ticks; ++tick) {
+        asm volatile("" ::: "memory");      // (keeps the image reads inside the loop, see pinv_rollout_static_kernel)
+        const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
+        const int st = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl, &hot, tick > 0);
+        worst = st > worst ? st : worst;
+        const bool okl = st != 2;           // an infeasible tick leaves the state where it is
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double d = v[j];
+            if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+            v[j] = d;
+            z[j] = okl ? fma(d, dt, z[j]) : z[j];
+        }
+    }
+    const double bad = (worst == 2) ? __builtin_nan("") : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[lane * N + j] = z[j];
+    __syncthreads();
+    rows_from_lds<N>(q + b0 * N, rows_valid, zs, lane);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j] + bad;
+    if constexpr (NS > 0) {
+        double* so = slots + LY::O_SL * WAVE;
+        if (slack_out != nullptr) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) so[lane * NS + k] = sl[k] + bad;
+        }
+    }
+    __syncthreads();
+    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+    if constexpr (NS > 0) {
+        if (slack_out != nullptr) rows_from_lds<NS>(slack_out + b0 * NS, rows_valid, slots + LY::O_SL * WAVE, lane);
+    }
+    if (status_out != nullptr && valid) status_out[b0 + lane] = worst;
+}
+
+typedef hipError_t (*qp_static_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
+                                           const double*, double*, double*, int32_t*, hipStream_t);
+
+template <const ShapeDesc& SD>
+inline hipError_t launch_qp_rollout_static(const void* d_img, const double* d_tterms, int n_ticks, double dt,
+                                           double max_speed, long long B, double* q, const double* y, double* dq,
+                                           double* slack, int32_t* status, hipStream_t stream)
+{
+    if constexpr (SD.n_x != 0) {
+        return hipErrorNotSupported;
+    } else {
+        const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+        constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
+        if (shmem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)qp_rollout_static_kernel<SD>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((qp_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
+                           status, B, d_tterms, n_ticks, dt, max_speed);
+        return hipGetLastError();
+    }
 }
 
 typedef hipError_t (*qp_static_fn)(const void*, const TickArgs&, long long, const double*, const double*,

@@ -219,7 +219,7 @@ const char* clik_qp_kernel_name(const clik_qp* h);
  * remaining rows) is instantiated per skill structure; reactive_qp.py:283-298
  * JIT-compiles its H/A/lbA/ubA functions at the same point.                   */
 int clik_qp_shape_describe(const clik_skill_desc* desc, char* buf, int cap);
-int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, const char* name);
+int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, void* rollout_fn, const char* name);
 
 /* replaces solve() (reactive_qp.py:461-528).
  *   dq [B][n_q], dx [B][n_x] or NULL, slack [B][n_slack] or NULL  (device, out)
@@ -239,6 +239,14 @@ int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms,
                             const double* q, const double* x, const double* y,
                             double* dq, double* dx, double* slack, int32_t* status,
                             int32_t* hot_set, int32_t use_hot, void* stream);
+
+/* "next" row for the QP controller: n_ticks of solve -> clamp(+-max_speed) ->
+ * explicit Euler q += dq*dt inside one launch, the working set hot-started from tick to tick.
+ * q is updated in place; dq / slack receive the last tick, status the worst status met (an
+ * infeasible tick leaves q where it is).  Needs a shape-specialised kernel for the skill.     */
+int clik_qp_rollout_batch(const clik_qp* h, int64_t B, int32_t n_ticks, double dt,
+                          double max_speed, const double* tterms, double* q, const double* y,
+                          double* dq, double* slack, int32_t* status, void* stream);
 
 /* QP data only (H diag, A, lbA, ubA as the reference's H_func/A_func/Blb/Bub,
  * reactive_qp.py:283-298) for inspection and parity tests:

@@ -228,3 +228,34 @@ def test_qp_hot_start_gives_the_same_minimiser(iiwa_fk):
     for res in (cold, first, again, stale, junk):
         assert (res[3] == 0).all()
         assert _rel(res[0], rdq).max() < QP_RTOL and _rel(res[2], rslack).max() < QP_RTOL
+
+
+@pytest.mark.parametrize("variant", ["aot", "jit"])
+def test_qp_rollout_matches_host_loop(iiwa_fk, variant, monkeypatch):
+    """n ticks of QP solve -> clamp -> Euler in one launch (working set hot-started inside the
+    kernel) == the host loop of ur5_moe2016_example2.ipynb:537-545 driven tick by tick with
+    cold solves."""
+    if variant == "jit":
+        monkeypatch.setenv("CLIK_NO_AOT", "1")
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 100, seed=14, distribution="mixed")
+    dt, vmax, n_ticks = 0.008, 1.0, 10
+    q = Q.copy()
+    for _ in range(n_ticks):
+        dq, _, slack, status = ctrl.solve_batch(0.0, q, input_var=Y)
+        assert (status == 0).all()
+        dq = np.clip(dq, -vmax, vmax)
+        q = q + dq * dt
+    q_dev, dq_dev, slack_dev, status_dev = ctrl.rollout_batch(np.zeros(n_ticks), Q, input_var=Y, dt=dt, max_speed=vmax)
+    assert (status_dev == 0).all()
+    assert np.abs(q_dev - q).max() < 1e-9 and np.abs(dq_dev - dq).max() < 1e-7
+    assert np.abs(slack_dev - slack).max() < 1e-7
+
+
+def test_qp_rollout_needs_a_static_kernel(iiwa_fk, monkeypatch):
+    monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    ctrl = _controller(skills.qp_skill(iiwa_fk))
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 8, seed=15)
+    with pytest.raises(Exception, match="shape-specialised"):
+        ctrl.rollout_batch(np.zeros(3), Q, input_var=Y)
