@@ -1,3 +1,5 @@
+"""Tick time of the UR5 distance skill with 1..5 joint-limit SetConstraints (2..32 modes):
+run-time instantiated static kernels vs the dynamic kernel (CLIK_FORCE_DYNAMIC=1).  GPU box only."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT","/root/repo"))
 import numpy as np, torch
