@@ -74,3 +74,43 @@ def ptr(t):
 def current_stream(device):
     torch = _torch()
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class SingleSlot(object):
+    """Persistent staging for the single-instance ``solve()`` call (B = 1): one pinned host
+    buffer and one device buffer each way, so a call is one H2D copy, one launch, one D2H copy
+    and one stream synchronisation instead of fresh tensors per argument."""
+
+    def __init__(self, device, n_in, n_out, n_int):
+        torch = _torch()
+        self.device = device
+        self.h_in = torch.empty((max(n_in, 1),), dtype=torch.float64).pin_memory()
+        self.d_in = torch.empty((max(n_in, 1),), dtype=torch.float64, device=device)
+        # outputs: n_out doubles followed by n_int int32 (padded to 8 bytes)
+        self.n_out, self.n_int = n_out, n_int
+        nbytes = 8 * n_out + 8 * ((n_int + 1) // 2)
+        self.d_out = torch.zeros((max(nbytes, 8),), dtype=torch.uint8, device=device)
+        self.h_out = torch.zeros((max(nbytes, 8),), dtype=torch.uint8).pin_memory()
+        self.in_np = self.h_in.numpy()
+        out_np = self.h_out.numpy()
+        self.out_f = out_np[:8 * n_out].view(np.float64)
+        self.out_i = out_np[8 * n_out:8 * n_out + 4 * n_int].view(np.int32)
+        self.d_in_ptr = self.d_in.data_ptr()
+        self.d_out_ptr = self.d_out.data_ptr()
+
+    def in_ptr(self, offset_doubles):
+        return C.c_void_p(self.d_in_ptr + 8 * offset_doubles)
+
+    def out_ptr(self, offset_doubles):
+        return C.c_void_p(self.d_out_ptr + 8 * offset_doubles)
+
+    def int_ptr(self, index=0):
+        return C.c_void_p(self.d_out_ptr + 8 * self.n_out + 4 * index)
+
+    def upload(self):
+        self.d_in.copy_(self.h_in, non_blocking=True)
+
+    def download(self):
+        torch = _torch()
+        self.h_out.copy_(self.d_out, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()

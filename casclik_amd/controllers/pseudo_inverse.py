@@ -17,7 +17,7 @@ import numpy as np
 from .. import _capi
 from .. import sym as cs
 from ..lowering import lower_skill
-from .base_controller import (BaseController, current_stream, device_of, ptr,
+from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
                               to_device_matrix, _torch)
 
 
@@ -52,6 +52,7 @@ class PseudoInverseController(BaseController):
             except Exception:
                 pass
             self._handle = None
+        self._slot = None
 
     # -- options (pseudo_inverse.py:42-66) --------------------------------
     @property
@@ -296,15 +297,33 @@ class PseudoInverseController(BaseController):
         if spec.n_input_var > 0:
             y = _flat(input_var if input_var is not None
                       else np.zeros(spec.n_input_var), spec.n_input_var, "input_var")
-        dq, dx, mode = self.solve_batch(
-            float(_scalar(time_var)), q.reshape(1, -1),
-            None if x is None else x.reshape(1, -1),
-            None if y is None else y.reshape(1, -1))
-        self.current_mode = int(mode[0])
-        cntrl_rob = cs.DM(dq[0])
+        # B = 1 through persistent pinned / device staging (one copy each way)
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        nq, nx, ny = d.n_q, d.n_x, d.n_y
+        slot = getattr(self, "_slot", None)
+        if slot is None:
+            slot = self._slot = SingleSlot(self._device, nq + nx + ny, nq + nx, 1)
+        slot.in_np[:nq] = q
+        if nx:
+            slot.in_np[nq:nq + nx] = x
+        if ny:
+            slot.in_np[nq + nx:nq + nx + ny] = y
+        tt, ttp = _capi.tterms_arg(d.time_terms(float(_scalar(time_var))))
+        with torch.cuda.device(self._device):
+            slot.upload()
+            rc = self._lib.clik_pinv_solve_batch(
+                self._handle, 1, ttp, slot.in_ptr(0), slot.in_ptr(nq) if nx else None,
+                slot.in_ptr(nq + nx) if ny else None, slot.out_ptr(0), slot.out_ptr(nq) if nx else None,
+                slot.int_ptr(0), current_stream(self._device))
+            _capi.check(self._lib, rc)
+            slot.download()
+        self.current_mode = int(slot.out_i[0])
+        cntrl_rob = cs.DM(slot.out_f[:nq].copy())
         cntrl_virt = None
         if spec.n_virtual_var > 0 and virtual_var is not None and spec._has_virtual:
-            cntrl_virt = cs.DM(dx[0])
+            cntrl_virt = cs.DM(slot.out_f[nq:nq + nx].copy())
         return cntrl_rob, cntrl_virt, None
 
 

@@ -20,7 +20,7 @@ import numpy as np
 from .. import _capi
 from .. import sym as cs
 from ..lowering import lower_skill
-from .base_controller import (BaseController, current_stream, device_of, ptr,
+from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
                               to_device_matrix, _torch)
 from .pseudo_inverse import _flat, _scalar
 
@@ -81,6 +81,7 @@ class ReactiveQPController(BaseController):
             except Exception:
                 pass
             self._handle = None
+        self._slot = None
 
     # -- weights ------------------------------------------------------------
     @property
@@ -366,18 +367,39 @@ class ReactiveQPController(BaseController):
         if spec.n_input_var > 0:
             y = _flat(input_var if input_var is not None
                       else np.zeros(spec.n_input_var), spec.n_input_var, "input_var")
-        dq, dx, slack, status = self.solve_batch(
-            float(_scalar(time_var)), q.reshape(1, -1),
-            None if x is None else x.reshape(1, -1),
-            None if y is None else y.reshape(1, -1))
-        if int(status[0]) != 0:
+        # B = 1 through persistent pinned / device staging (one copy each way); the working set of
+        # the previous call hot-starts this one, like the reference's stateful qpOASES instance
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        nq, nx, ny, ns = d.n_q, d.n_x, d.n_y, d.n_slack
+        slot = getattr(self, "_slot", None)
+        if slot is None:
+            slot = self._slot = SingleSlot(self._device, nq + nx + ny, nq + nx + ns, 2)
+            self._slot_calls = 0
+        slot.in_np[:nq] = q
+        if nx:
+            slot.in_np[nq:nq + nx] = x
+        if ny:
+            slot.in_np[nq + nx:nq + nx + ny] = y
+        tt, ttp = _capi.tterms_arg(d.time_terms(float(_scalar(time_var))))
+        with torch.cuda.device(self._device):
+            slot.upload()
+            rc = self._lib.clik_qp_solve_batch_hot(
+                self._handle, 1, ttp, slot.in_ptr(0), slot.in_ptr(nq) if nx else None,
+                slot.in_ptr(nq + nx) if ny else None, slot.out_ptr(0), slot.out_ptr(nq) if nx else None,
+                slot.out_ptr(nq + nx) if ns else None, slot.int_ptr(0), slot.int_ptr(1),
+                1 if self._slot_calls > 0 else 0, current_stream(self._device))
+            _capi.check(self._lib, rc)
+            slot.download()
+        self._slot_calls += 1
+        status = int(slot.out_i[0])
+        if status != 0:
             raise RuntimeError("ReactiveQPController: QP %s"
-                               % ("infeasible" if int(status[0]) == 2
-                                  else "hit the iteration cap"))
-        res_robot_vel = cs.DM(dq[0])
-        res_virtual_vel = cs.DM(dx[0]) if (dx is not None and spec._has_virtual) else None
-        res_slack = cs.DM(slack[0]) if slack is not None else None
-        self.res = {"x": cs.DM(np.concatenate(
-            [dq[0]] + ([dx[0]] if dx is not None else [])
-            + ([slack[0]] if slack is not None else [])))}
+                               % ("infeasible" if status == 2 else "hit the iteration cap"))
+        out = slot.out_f.copy()
+        res_robot_vel = cs.DM(out[:nq])
+        res_virtual_vel = cs.DM(out[nq:nq + nx]) if (nx and spec._has_virtual) else None
+        res_slack = cs.DM(out[nq + nx:nq + nx + ns]) if ns else None
+        self.res = {"x": cs.DM(out[:nq + nx + ns])}
         return res_robot_vel, res_virtual_vel, res_slack
