@@ -1270,12 +1270,18 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
     }
 }
 
+// Task steps in order.  The image fields of step TI+1 are requested from LDS before step TI
+// computes (cur = register copy for step TI), so their latency hides behind that step's
+// arithmetic - a lone wave has nothing else to hide it behind.  (When S already points to a
+// register copy, as in the one-wave kernel, these copies are free.)
 template <const ShapeDesc& SD, unsigned ACT, int TI, int ROLE = 0>
-__device__ __forceinline__ void steps_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c)
+__device__ __forceinline__ void steps_s(CLIK_MODE_IN, ModeCtx<SD, ACT, ROLE>& c, const Img<SD>* cur)
 {
     if constexpr (TI < SD.n_tasks) {
-        step_s<SD, ACT, TI, ROLE>(CLIK_MODE_ARGS, c);
-        steps_s<SD, ACT, TI + 1, ROLE>(CLIK_MODE_ARGS, c);
+        const Img<SD> nxt = *S;
+        __builtin_amdgcn_sched_barrier(0);
+        step_s<SD, ACT, TI, ROLE>(cur, tk, tc, z, ys, lane, c);
+        steps_s<SD, ACT, TI + 1, ROLE>(CLIK_MODE_ARGS, c, &nxt);
     }
 }
 
@@ -1304,7 +1310,11 @@ __device__ __forceinline__ bool pinv_mode_static(const Img<SD>* __restrict__ S, 
     for (int j = 0; j < N; ++j) c.v[j] = 0.0;
     c.st.sbits = 0u;
     c.ok = true;
-    steps_s<SD, ACT, 0, ROLE>(CLIK_MODE_ARGS, c);
+    {
+        const Img<SD> first = *S;
+        __builtin_amdgcn_sched_barrier(0);
+        steps_s<SD, ACT, 0, ROLE>(CLIK_MODE_ARGS, c, &first);
+    }
     cones_s<SD, ACT, 0, ROLE>(CLIK_MODE_ARGS, c);
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] = c.v[j];
