@@ -244,3 +244,31 @@ def test_ragged_batch_sizes(iiwa_fk, B):
     rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(qspec, 0.0, Q, Y=Y)
     assert (status == 0).all() and (rstatus == 0).all() and slack.shape == (B, 6)
     assert _rel(dq, rdq).max() < 1e-8 and _rel(slack, rslack).max() < 1e-8
+
+
+def test_rollout_with_time_trajectory(ur5_fk):
+    """Rollout of a tracking skill whose target moves with time (ur5_moe2016_example2 cell 7):
+    the per-tick time terms (values and exact derivatives for the feed-forward) are read in
+    place from the device buffer; must equal the host loop with the same time stamps."""
+    from casclik_amd import sym as cs
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    path = cs.vertcat(0.5 * cs.sin(0.1 * t) * cs.sin(0.1 * t) + 0.2, 0.5 * cs.cos(0.1 * t) + 0.25 * cs.sin(0.1 * t),
+                      0.5 * cs.sin(0.1 * t) * cs.cos(0.1 * t) + 0.1)
+    spec = cc.SkillSpecification("track", t, q, constraints=[
+        cc.EqualityConstraint("move_point", p - path, gain=0.5, constraint_type="soft")])
+    ctrl = _controller(spec)
+    assert ctrl.kernel_name != "dynamic"
+    rng = np.random.default_rng(8)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.1, size=(70, 6))
+    dt, n_ticks = 0.05, 9
+    times = 3.0 + dt * np.arange(n_ticks)
+    qh = Q.copy()
+    for tv in times:
+        dq, _, _ = ctrl.solve_batch(float(tv), qh)
+        qh = qh + dq * dt
+    q_dev, dq_dev, _ = ctrl.rollout_batch(times, Q, dt=dt)
+    assert np.abs(q_dev - qh).max() < 1e-10 and np.abs(dq_dev - dq).max() < 1e-9
