@@ -259,3 +259,33 @@ def test_qp_rollout_needs_a_static_kernel(iiwa_fk, monkeypatch):
     Q, Y = skills.synthetic_inputs(iiwa_fk, 8, seed=15)
     with pytest.raises(Exception, match="shape-specialised"):
         ctrl.rollout_batch(np.zeros(3), Q, input_var=Y)
+
+
+def test_qp_rollout_with_time_trajectory(ur5_fk):
+    """QP rollout of a soft tracking task whose target moves with time under joint-speed limits:
+    per-tick time terms read in place, working set hot-started; equals the host loop of cold solves."""
+    fk = ur5_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    path = cs.vertcat(0.5 * cs.sin(0.1 * t) * cs.sin(0.1 * t) + 0.2, 0.5 * cs.cos(0.1 * t) + 0.25 * cs.sin(0.1 * t),
+                      0.5 * cs.sin(0.1 * t) * cs.cos(0.1 * t) + 0.1)
+    cons = [cc.EqualityConstraint("move_point", p - path, gain=2.0, constraint_type="soft", priority=1),
+            cc.VelocitySetConstraint("speed", q, set_min=-np.full(6, 0.3), set_max=np.full(6, 0.3), priority=0)]
+    spec = cc.SkillSpecification("track_qp", t, q, constraints=cons)
+    ctrl = _controller(spec)
+    assert ctrl.kernel_name != "dynamic"
+    rng = np.random.default_rng(18)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.1, size=(70, 6))
+    dt, n_ticks = 0.05, 8
+    times = 3.0 + dt * np.arange(n_ticks)
+    qh = Q.copy()
+    for tv in times:
+        dq, _, slack, status = ctrl.solve_batch(float(tv), qh)
+        assert (status == 0).all()
+        qh = qh + dq * dt
+    assert (np.abs(np.abs(dq) - 0.3) < 1e-12).any()          # the speed limits are active somewhere
+    q_dev, dq_dev, slack_dev, status_dev = ctrl.rollout_batch(times, Q, dt=dt)
+    assert (status_dev == 0).all()
+    assert np.abs(q_dev - qh).max() < 1e-9 and np.abs(dq_dev - dq).max() < 1e-7 and np.abs(slack_dev - slack).max() < 1e-7
