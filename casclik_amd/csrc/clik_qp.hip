@@ -188,9 +188,30 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
                 if (j < n) u[j] = fma(nu[i], As[(i * N + j) * WAVE + lane], u[j]);
         }
     }
-    const double bad = (status == 2) ? __builtin_nan("") : 0.0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) u[j] = u[j] * hinv[j] + bad;
+    for (int j = 0; j < N; ++j) u[j] = u[j] * hinv[j];
+    // safety net in the space of the answer: every row  lbA <= A_u v - s <= ubA  must hold for the
+    // returned v (s = -nu h_s^-1 on soft rows); see the shape-specialised kernel
+    int status_v = status;
+    if (status == 0) {
+        double worst = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (i < nc) {
+                double cv = nu[i] * hsi[i * WAVE + lane];
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (j < n) cv = fma(As[(i * N + j) * WAVE + lane], u[j], cv);
+                const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
+                const double sc = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+                worst = fmax(worst, fmax(lbi - cv, cv - ubi) * sc);
+            }
+        }
+        if (!(worst <= 1e-8)) status_v = 2;
+    }
+    const double bad = (status_v == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] += bad;
     if (slack_out != nullptr && valid) {
         const int ns = S->n_slack;
         int k = 0;
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
     __syncthreads();
     stage_out_dyn(dq + b0 * nq, nq, rows_valid, zs, lane);
     if (nx > 0 && dx != nullptr) stage_out_dyn(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (status_out != nullptr && valid) status_out[b0 + lane] = status;
+    if (status_out != nullptr && valid) status_out[b0 + lane] = status_v;
 }
 
 // H diagonal, A, lbA, ubA exactly as the reference's H_func / A_func / Blb_func /

@@ -24,6 +24,10 @@
 
 namespace clik {
 
+#ifdef CLIK_QP_DIAG
+__device__ double g_qp_dbg[64 * 40];       // diagnostic dump of block 0 (tools only)
+#endif
+
 // ---- small LDL^T with a compile-time or run-time size -------------------------------
 template <int NC, bool EXACT>
 __device__ __forceinline__ void qp_ldl_factor(double (&A)[NC * (NC + 1) / 2], double (&rd)[NC], const int r)
@@ -109,13 +113,16 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         }
     }
     int status = 0;
+#ifdef CLIK_QP_DIAG
+    int g_qp_diag_cold = 0;
+#endif
     bool done = !lane_valid;
     bool need_p = true;
     bool init = softeq != 0u;            // wave-uniform
     int p = 0;
     double sp = 1.0, bp = 0.0;
 #ifdef CLIK_QP_DIAG
-    int g_qp_diag_warm = 0, g_qp_diag_cold = 0;
+    int g_qp_diag_warm = 0;
 #endif
     if constexpr (WARM) {
         // Warm start.  The dual method may start from any S-pair (W, nu): rows of W linearly
@@ -355,7 +362,10 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         }
         const double t1 = (l >= 0) ? t1n / t1d : 1e300;
         const double gap = bp - sp * cp;
-        const bool has_primal = zn > 1e-13 * fmax(1.0, qpp);
+        // zn = |n_p|^2 sin^2(angle between n_p and the span of the working set) in the H^-1 metric;
+        // a row within ~1e-5 rad of that span counts as dependent (then only a dual step is possible).
+        // A tighter test lets rounding noise through and the working set goes singular.
+        const bool has_primal = zn > 1e-10 * qpp;
         const double t2 = has_primal ? gap / zn : 1e300;
         const double t = fmin(t1, t2);
         {
@@ -380,6 +390,42 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         }
     }
     if (!done) status = 1;
+    // Safety net (the oracle and qpOASES have the same): the point must satisfy every row.  An
+    // infeasible problem whose working set became numerically dependent can leave the loop
+    // "optimal" with violated rows; that is status 2, never a silent wrong answer.
+    if (__ballot(status == 0 && lane_valid) != 0ull) {
+        double cc[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) cc[i] = (c0s != nullptr && (EXACT || i < nc)) ? c0s[i * WAVE + lane] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double q = (EXACT || i < nc) ? Qs[tri(i, j) * WAVE + lane] : 0.0;
+                cc[i] = fma(q, nu[j], cc[i]);
+                if (j != i) cc[j] = fma(q, nu[i], cc[j]);
+            }
+        }
+        double worst = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (EXACT || i < nc) {
+                const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
+                worst = fmax(worst, fmax(lbi - cc[i], cc[i] - ubi) * isc[i]);
+            }
+        }
+        if (status == 0 && !(worst <= 1e-8)) status = 2;
+#ifdef CLIK_QP_DIAG
+        if (blockIdx.x == 0) {
+            double* o = g_qp_dbg + lane * 40;
+#pragma unroll
+            for (int i = 0; i < NC && i < 12; ++i) { o[i] = cc[i]; o[12 + i] = nu[i]; }
+            o[24] = worst; o[25] = (double)W; o[26] = (double)up; o[27] = (double)status;
+        }
+        g_qp_diag_cold |= (worst > 1e-8) ? 8 : 0;
+        g_qp_diag_cold |= 16;       // the check ran
+#endif
+    }
     if (hot != nullptr && lane_valid) *hot = (int32_t)((W & 0xffffu) | ((up & 0xffffu) << 16));
 #ifdef CLIK_QP_DIAG
     status |= (g_qp_diag_iters << 8) | (g_qp_diag_warm << 16) | (g_qp_diag_cold << 24);
@@ -652,6 +698,32 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
                 slots[(LY::O_SL + sk) * WAVE + lane] = -nu[r] / (T->mu + T->slack_w[sk]);
             }
         });
+        // Safety net in the space of the answer (the oracle and qpOASES check the same): every row
+        // must hold for the v that is returned.  (The multiplier-space test inside gi_solve can be
+        // fooled when a numerically dependent working set blows the multipliers up.)
+        if (status == 0) {
+            double worst = 0.0;
+            static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int TI = P.row_task[r];
+                double cv;
+                if constexpr (shape_unit(SD, TI)) {
+                    cv = v[SD.ucol[TI][P.row_local[r]] - 1];
+                } else {
+                    cv = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) cv = fma(qp_row_s<SD, r>(S, tc, j), v[j], cv);
+                }
+                if constexpr (SD.soft[TI] != 0) {
+                    constexpr int sk = P.slack_base[TI] + P.row_local[r];
+                    cv -= slots[(LY::O_SL + sk) * WAVE + lane];         // row is  a v - s
+                }
+                const double lbi = lbs[r * WAVE + lane], ubi = ubs[r * WAVE + lane];
+                const double sc = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+                worst = fmax(worst, fmax(lbi - cv, cv - ubi) * sc);
+            });
+            if (!(worst <= 1e-8)) status = 2;
+        }
     }
     // slack of the folded rows: s = J v - b
 #pragma unroll

@@ -289,3 +289,32 @@ def test_qp_rollout_with_time_trajectory(ur5_fk):
     q_dev, dq_dev, slack_dev, status_dev = ctrl.rollout_batch(times, Q, dt=dt)
     assert (status_dev == 0).all()
     assert np.abs(q_dev - qh).max() < 1e-9 and np.abs(dq_dev - dq).max() < 1e-7 and np.abs(slack_dev - slack).max() < 1e-7
+
+
+@pytest.mark.parametrize("kernel", ["static", "dynamic"])
+def test_qp_infeasible_by_a_dependent_row_is_reported(iiwa_fk, kernel, monkeypatch):
+    """Found by tools/fuzz_parity.py: hard joint-speed limits + a hard tool-height set whose
+    Jacobian row lies in the span of five speed rows.  Where the limits cannot deliver the
+    required height rate the QP is infeasible; an active-set iteration that lets the
+    (numerically) dependent row into the working set ends 'optimal' with violated rows.  Every
+    such instance must come back as status 2, the feasible ones must match the oracle."""
+    from oracle import clik_oracle
+    if kernel == "dynamic":
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    fk = iiwa_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 7)
+    p = fk["T_fk"](q)[:3, 3]
+    cons = [cc.VelocitySetConstraint("speed", q, set_min=-np.ones(7), set_max=np.ones(7), priority=0),
+            cc.SetConstraint("height", p[2], set_min=0.2, set_max=0.6, gain=0.8, priority=1)]
+    spec = cc.SkillSpecification("dep", t, q, constraints=cons)
+    ctrl = _controller(spec)
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    Q = np.random.default_rng(12).uniform(0.32 * lo, 0.32 * hi, size=(256, 7))
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q)
+    rdq, _, _, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q)
+    assert (rstatus == 2).sum() > 50 and (rstatus == 0).sum() > 20
+    assert np.array_equal(status == 2, rstatus == 2)
+    ok = rstatus == 0
+    assert (status[ok] == 0).all() and np.isnan(dq[~ok]).all()
+    assert _rel(dq[ok], rdq[ok]).max() < QP_RTOL

@@ -61,11 +61,17 @@ def random_skill(rng, fk, n):
     picks = rng.choice(len(pool), size=nt, replace=False)
     prios = rng.permutation(nt)
     cons = [pool[i](int(prios[a])) for a, i in enumerate(picks)]
+    # a weak rest-posture task over all joints at the lowest priority: without it the joints no
+    # task moves have an exactly zero velocity and the tangent-cone test of a set on such a joint
+    # compares structural zeros (decided by +-1e-20 of rounding in a factorisation-based evaluation)
+    rest = rng.random() < 0.75
+    if rest:
+        cons.append(cc.EqualityConstraint("rest", q - home, gain=0.05, priority=99))
     opts = {"feedforward": bool(rng.random() < 0.8), "multidim_sets": bool(multi),
             "converge_final_set_to_max": bool(rng.random() < 0.3),
             "pinv_method": "damped" if rng.random() < 0.85 else "standard",
             "damping_factor": float(10 ** rng.uniform(-9, -5))}
-    return cc.SkillSpecification("fuzz", t, q, constraints=cons), opts
+    return cc.SkillSpecification("fuzz", t, q, constraints=cons), opts, rest
 
 
 def main():
@@ -74,11 +80,12 @@ def main():
     rng = np.random.default_rng(seed)
     worst = 0.0
     checked = skipped = 0
+    qp_worst, qp_checked = [0.0], [0]
     for s in range(n_skills):
         robot = "ur5" if rng.random() < 0.5 else "iiwa"
         fk = skills.ur5() if robot == "ur5" else skills.iiwa()
         n = len(fk["joint_names"])
-        spec, opts = random_skill(rng, fk, n)
+        spec, opts, rest = random_skill(rng, fk, n)
         lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
         Q = rng.uniform(0.32 * lo, 0.32 * hi, size=(128, n))
         try:
@@ -108,12 +115,64 @@ def main():
             worst = max(worst, err)
             checked += int(ok.sum())
             skipped += int((~sane).sum())
-            flag = "" if (bad_modes == 0 and err < PINV_RTOL) else "   <-- MISMATCH"
+            flag = "" if ((bad_modes == 0 or not rest) and err < PINV_RTOL) else "   <-- MISMATCH"
+            if bad_modes and not rest:
+                flag = "   (mode ties possible: no rest task)"
             print("skill %2d %-4s tasks %s opts ff=%d md=%d conv=%d %s  kernel %-12s modes %s bad_modes %d err %.2e%s" % (
                 s, robot, [type(c).__name__[:6] + str(c.expression.size()[0] if hasattr(c.expression, "size") else "") for c in spec.constraints],
                 opts["feedforward"], opts["multidim_sets"], opts["converge_final_set_to_max"], opts["pinv_method"][:4],
                 names[-1], np.bincount(rmode + 1).tolist(), bad_modes, err, flag))
         os.environ.pop("CLIK_FORCE_DYNAMIC", None)
+        # the same skill through the QP controller (equalities and sets made soft at random)
+        for c in spec.constraints:
+            if isinstance(c, (cc.EqualityConstraint, cc.SetConstraint)):
+                c.constraint_type = "soft" if rng.random() < 0.7 else "hard"
+        spec = cc.SkillSpecification("fuzz_qp", spec.time_var, spec.robot_var, constraints=list(spec.constraints))
+        try:
+            rdq, _, rsl, rst = clik_oracle.qp_solve_batch(spec, 0.0, Q)
+        except Exception as exc:
+            print("skill %2d %-4s qp oracle refused: %s" % (s, robot, str(exc)[:60]))
+            continue
+        for env in ({}, {"CLIK_FORCE_DYNAMIC": "1"}):
+            os.environ.pop("CLIK_FORCE_DYNAMIC", None)
+            os.environ.update(env)
+            try:
+                qc = cc.ReactiveQPController(skill_spec=spec)
+                qc.setup_problem_functions()
+                qc.setup_solver()
+            except NotImplementedError as exc:
+                print("skill %2d %-4s qp refused by the device limits: %s" % (s, robot, str(exc)[:60]))
+                break
+            dq, _, sl, st = qc.solve_batch(0.0, Q)
+            ok = (rst == 0) & (st == 0)
+            rel = np.abs(dq - rdq).max(axis=1) / (1.0 + np.abs(rdq).max(axis=1))
+            if sl is not None and rsl is not None:
+                rel = np.maximum(rel, np.abs(sl - rsl).max(axis=1) / (1.0 + np.abs(rsl).max(axis=1)))
+            err = float(rel[ok].max()) if ok.any() else 0.0
+            qp_worst[0] = max(qp_worst[0], err)
+            qp_checked[0] += int(ok.sum())
+            # lanes the numpy active-set oracle gave up on (it reports those as infeasible) but the device
+            # solved: the device answer must then pass the solver-independent KKT check
+            disputed = np.where((rst == 2) & (st == 0))[0]
+            kkt_ok = True
+            if disputed.size:
+                hd, A, lb, ub = clik_oracle.qp_data_batch(spec, 0.0, Q[disputed])
+                for k, b in enumerate(disputed):
+                    vfull = np.concatenate([dq[b]] + ([sl[b]] if sl is not None else []))
+                    prim, stat, sign = clik_oracle.kkt_residuals(hd[k], A[k], lb[k], ub[k], vfull)
+                    kkt_ok = kkt_ok and max(prim, stat, sign) < 1e-7
+            same_status = np.array_equal((st == 2) | np.isin(np.arange(len(st)), disputed), rst == 2) and kkt_ok
+            flag = "" if (same_status and err < 1e-8 and (st[rst == 0] == 0).all()) else "   <-- QP MISMATCH"
+            if disputed.size and kkt_ok:
+                flag += "   (%d lanes: oracle gave up, device answer passes KKT)" % disputed.size
+            odd = np.where((rst == 2) & (st != 2))[0]
+            if odd.size and "MISMATCH" in flag:
+                flag += "   device status of those lanes: %s, KKT ok: %s" % (st[odd].tolist(), kkt_ok)
+            print("skill %2d %-4s qp rows %d  kernel %-12s infeasible %d err %.2e  status oracle!=2&gpu==2: %d, oracle==2&gpu!=2: %d, gpu cap: %d%s" % (
+                s, robot, qc.n_qp_rows, qc.kernel_name[:12], int((rst == 2).sum()), err,
+                int(((rst != 2) & (st == 2)).sum()), int(((rst == 2) & (st != 2)).sum()), int((st == 1).sum()), flag))
+        os.environ.pop("CLIK_FORCE_DYNAMIC", None)
+    print("QP: checked %d instance-results, worst relative error %.3e (tolerance 1e-08)" % (qp_checked[0], qp_worst[0]))
     print("checked %d instance-results (%d skipped as degenerate), worst relative error %.3e (tolerance %.0e)" % (
         checked, skipped, worst, PINV_RTOL))
 
