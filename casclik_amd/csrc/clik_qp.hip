@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
                 worst = fmax(worst, fmax(lbi - cv, cv - ubi) * sc);
             }
         }
-        if (!(worst <= 1e-6)) status_v = 2;      // (a net for garbage, not a precision test)
+        if (!(worst <= 1e-7)) status_v = 2;      // (a net for garbage, not a precision test)
     }
     const double bad = (status_v == 2) ? __builtin_nan("") : 0.0;
 #pragma unroll

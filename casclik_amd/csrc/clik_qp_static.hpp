@@ -414,7 +414,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                 worst = fmax(worst, fmax(lbi - cc[i], cc[i] - ubi) * isc[i]);
             }
         }
-        if (status == 0 && !(worst <= 1e-8)) status = 2;
+        if (status == 0 && !(worst <= 1e-7)) status = 2;      // (a net for garbage, not a precision test)
 #ifdef CLIK_QP_DIAG
         if (blockIdx.x == 0) {
             double* o = g_qp_dbg + lane * 40;
@@ -422,7 +422,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             for (int i = 0; i < NC && i < 12; ++i) { o[i] = cc[i]; o[12 + i] = nu[i]; }
             o[24] = worst; o[25] = (double)W; o[26] = (double)up; o[27] = (double)status;
         }
-        g_qp_diag_cold |= (worst > 1e-8) ? 8 : 0;
+        g_qp_diag_cold |= (worst > 1e-7) ? 8 : 0;
         g_qp_diag_cold |= 16;       // the check ran
 #endif
     }
@@ -722,7 +722,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
                 const double sc = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
                 worst = fmax(worst, fmax(lbi - cv, cv - ubi) * sc);
             });
-            if (!(worst <= 1e-6)) status = 2;       // (a net for garbage, not a precision test)
+            if (!(worst <= 1e-7)) status = 2;       // (a net for garbage, not a precision test)
         }
     }
     // slack of the folded rows: s = J v - b

@@ -81,6 +81,20 @@ def random_skill(rng, fk, n):
     return cc.SkillSpecification("fuzz", t, q, input_var=y if uses_y else None, constraints=cons), opts, rest
 
 
+def lp_margin(A, lb, ub):
+    """Largest t (capped at 1) with lb + t <= A v <= ub - t for some v: > 0 strictly feasible, 0 feasible
+    with an empty interior (hard equalities), < 0 infeasible by that much."""
+    from scipy.optimize import linprog
+    nv = A.shape[1]
+    Aub = np.hstack([np.vstack([A, -A]), np.ones((2 * A.shape[0], 1))])
+    bub = np.concatenate([ub, -lb])
+    fin = np.isfinite(bub)
+    c = np.zeros(nv + 1)
+    c[-1] = -1.0
+    r = linprog(c, A_ub=Aub[fin], b_ub=bub[fin], bounds=[(None, None)] * nv + [(None, 1.0)], method="highs")
+    return float(r.x[-1]) if r.status == 0 else float("-inf")
+
+
 def main():
     n_skills = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -169,28 +183,37 @@ def main():
             err = float(rel[ok].max()) if ok.any() else 0.0
             qp_worst[0] = max(qp_worst[0], err)
             qp_checked[0] += int(ok.sum())
-            # lanes the numpy active-set oracle gave up on (it reports those as infeasible) but the device
-            # solved: the device answer must then pass the solver-independent KKT check
-            disputed = np.where((rst == 2) & (st == 0))[0]
-            kkt_ok = True
-            if disputed.size:
-                hd, A, lb, ub = clik_oracle.qp_data_batch(spec, tval, Q[disputed], Y=None if Y is None else Y[disputed])
-                for k, b in enumerate(disputed):
-                    vfull = np.concatenate([dq[b]] + ([sl[b]] if sl is not None else []))
-                    prim, stat, sign = clik_oracle.kkt_residuals(hd[k], A[k], lb[k], ub[k], vfull)
-                    kkt_ok = kkt_ok and max(prim, stat, sign) < 1e-7
-            same_status = np.array_equal((st == 2) | np.isin(np.arange(len(st)), disputed), rst == 2) and kkt_ok
-            flag = "" if (same_status and err < 1e-7 and (st[rst == 0] == 0).all()) else "   <-- QP MISMATCH"
-            if disputed.size and kkt_ok:
-                flag += "   (%d lanes: oracle gave up, device answer passes KKT)" % disputed.size
-            odd = np.where((rst == 2) & (st != 2))[0]
-            if odd.size and "MISMATCH" in flag:
-                flag += "   device status of those lanes: %s, KKT ok: %s" % (st[odd].tolist(), kkt_ok)
+            # lanes where the status verdicts differ.  Two kinds are not bugs: (a) the numpy active-set oracle
+            # gave up (it reports those as infeasible) and the device answer passes the solver-independent KKT
+            # check; (b) the feasible set has measure zero or is empty by a hair (hard equalities on dependent
+            # rows: LP margin within 1e-6 of zero), where "infeasible" and "solved to tolerance" are both
+            # defensible in floating point.  Anything else is a mismatch.
+            differ = np.where((rst == 2) != (st == 2))[0]
+            kkt_pass = border = 0
+            real = []
+            if differ.size:
+                hd, A, lb, ub = clik_oracle.qp_data_batch(spec, tval, Q[differ], Y=None if Y is None else Y[differ])
+                for k, b in enumerate(differ):
+                    if st[b] == 0:
+                        vfull = np.concatenate([dq[b]] + ([sl[b]] if sl is not None else []))
+                        if max(clik_oracle.kkt_residuals(hd[k], A[k], lb[k], ub[k], vfull)) < 1e-7:
+                            kkt_pass += 1
+                            continue
+                    if abs(lp_margin(A[k], lb[k], ub[k])) < 1e-6:
+                        border += 1
+                        continue
+                    real.append(int(b))
+            flag = "" if (not real and err < 1e-7 and (st[rst == 0] != 1).all()) else "   <-- QP MISMATCH"
+            if kkt_pass or border:
+                flag += "   (status differs on %d lanes: %d device answers pass KKT, %d borderline by LP margin)" % (
+                    differ.size, kkt_pass, border)
+            if real:
+                flag += "   lanes %s device status %s" % (real[:8], st[real[:8]].tolist())
             print("skill %2d %-4s qp rows %d  kernel %-12s infeasible %d err %.2e  status oracle!=2&gpu==2: %d, oracle==2&gpu!=2: %d, gpu cap: %d%s" % (
                 s, robot, qc.n_qp_rows, qc.kernel_name[:12], int((rst == 2).sum()), err,
                 int(((rst != 2) & (st == 2)).sum()), int(((rst == 2) & (st != 2)).sum()), int((st == 1).sum()), flag))
         os.environ.pop("CLIK_FORCE_DYNAMIC", None)
-    print("QP: checked %d instance-results, worst relative error %.3e (tolerance 1e-08)" % (qp_checked[0], qp_worst[0]))
+    print("QP: checked %d instance-results, worst relative error %.3e (flag threshold 1e-07)" % (qp_checked[0], qp_worst[0]))
     print("checked %d instance-results (%d skipped as degenerate), worst relative error %.3e (tolerance %.0e)" % (
         checked, skipped, worst, PINV_RTOL))
 
