@@ -141,9 +141,17 @@ class PseudoInverseController(BaseController):
         if self.kernel_name == "dynamic" and want_jit:
             from .. import jit
             with torch.cuda.device(self._device):
-                name = jit.attach(self._lib, handle, cdesc, copts)
+                name = jit.attach(self._lib, handle, cdesc, copts, extern=self.descriptor.extern_source())
             if name:
                 self.kernel_name = name
+        if self.descriptor.extern_code and not self.kernel_name.startswith("jit_"):
+            # constraints outside the row-table family exist only as generated code inside a
+            # run-time instantiated kernel; there is no other path (and no CPU fallback)
+            raise NotImplementedError(
+                "the skill has constraint expressions that need generated device code (%s), but no "
+                "kernel could be instantiated for it (jit disabled, hipcc missing, or the skill is "
+                "outside the shape-specialised family)" % ", ".join(
+                    repr(self.descriptor.tasks[k]["label"]) for k in sorted(self.descriptor.extern_code)))
 
     def setup_solver(self):
         """Reference parity: re-runs the problem setup (pseudo_inverse.py:506-510)."""

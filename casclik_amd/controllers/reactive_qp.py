@@ -171,9 +171,17 @@ class ReactiveQPController(BaseController):
         if self.kernel_name == "dynamic" and want_jit:
             from .. import jit
             with torch.cuda.device(self._device):
-                name = jit.attach_qp(self._lib, handle, cdesc)
+                name = jit.attach_qp(self._lib, handle, cdesc, extern=d.extern_source())
             if name:
                 self.kernel_name = name
+        if d.extern_code and not self.kernel_name.startswith("jit_"):
+            # constraints outside the row-table family exist only as generated code inside a
+            # run-time instantiated kernel; there is no other path (and no CPU fallback)
+            raise NotImplementedError(
+                "the skill has constraint expressions that need generated device code (%s), but no "
+                "kernel could be instantiated for it (jit disabled, hipcc missing, or the skill is "
+                "outside the shape-specialised family)" % ", ".join(
+                    repr(d.tasks[k]["label"]) for k in sorted(d.extern_code)))
 
     def setup_solver(self):
         """The solver lives inside the kernel; make sure the handle exists

@@ -187,9 +187,15 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
             return fail(CLIK_EUNSUPPORTED, "task %d: %d rows (limit %d)", ti, t.m, CLIK_MAX_M);
         for (int i = 0; i < t.m; ++i) {
             const int r0 = t.out_row0[i];
-            const int nr = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
-            if (t.out_kind[i] != CLIK_OUT_AFFINE && t.out_kind[i] != CLIK_OUT_NORM2)
+            const int nr = (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 1;
+            if (t.out_kind[i] != CLIK_OUT_AFFINE && t.out_kind[i] != CLIK_OUT_NORM2 &&
+                t.out_kind[i] != CLIK_OUT_EXTERN)
                 return fail(CLIK_EINVAL, "task %d row %d: bad out_kind", ti, i);
+            if ((t.out_kind[i] == CLIK_OUT_EXTERN) != (t.out_kind[0] == CLIK_OUT_EXTERN))
+                return fail(CLIK_EINVAL, "task %d: EXTERN outputs cannot be mixed with table rows", ti);
+            if (t.out_kind[i] == CLIK_OUT_EXTERN && ti >= clik::SHAPE_MAX_TASKS)
+                return fail(CLIK_EUNSUPPORTED, "code-generated constraints need a shape-specialised kernel "
+                                               "(at most %d constraints)", clik::SHAPE_MAX_TASKS);
             if (nr < 0 || r0 < 0 || r0 + nr > d->n_rows) return fail(CLIK_EINVAL, "task %d row %d: row range", ti, i);
             for (int k = r0; k < r0 + nr; ++k) {
                 const clik_row& r = d->rows[k];
@@ -218,7 +224,7 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
         const clik_task& t = d->tasks[ti];
         int fl = 0, affine = 1;
         for (int i = 0; i < t.m; ++i) {
-            const int nr = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+            const int nr = (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 1;
             if (t.out_kind[i] != CLIK_OUT_AFFINE) affine = 0;
             for (int k = t.out_row0[i]; k < t.out_row0[i] + nr; ++k) fl |= d->rows[k].flags;
             if (t.out_row0[i] + nr > last_row) last_row = t.out_row0[i] + nr;
@@ -234,9 +240,10 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
             S->shape.flags[ti] = fl & ~CLIK_ROW_HAS_T;
             S->shape.const_j[ti] = S->task_const_j[ti];
             S->shape.gain_matrix[ti] = t.gain_is_matrix ? 1 : 0;
+            S->shape.ext[ti] = (t.out_kind[0] == CLIK_OUT_EXTERN) ? 1 : 0;
             int nyt = 0;
             for (int i = 0; i < t.m; ++i) {
-                const int nrw = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+                const int nrw = (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 1;
                 for (int k = 0; k < nrw; ++k)
                     if (d->rows[t.out_row0[i] + k].n_y > nyt) nyt = d->rows[t.out_row0[i] + k].n_y;
             }
@@ -269,8 +276,8 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
         for (int ti = 0; ti < d->n_tasks && ti < clik::SHAPE_MAX_TASKS; ++ti) {
             const clik_task& t = d->tasks[ti];
             for (int i = 0; i < t.m; ++i) {
-                const int nrw = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
-                S->shape.out_nrows[ti][i] = (t.out_kind[i] == CLIK_OUT_AFFINE) ? 0 : t.out_nrows[i];
+                const int nrw = (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 1;
+                S->shape.out_nrows[ti][i] = (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 0;
                 for (int k2 = 0; k2 < nrw; ++k2, ++r) {
                     if (r >= clik::SHAPE_MAX_ROWS) continue;
                     const clik_row& row = d->rows[t.out_row0[i] + k2];
@@ -377,7 +384,7 @@ static bool build_skill_image(const DevSkill& S, std::vector<char>& out, size_t*
         for (int i = 0; i < t.m; ++i) {
             // rows in task order, output order; a 2-norm output owns a group of consecutive rows
             if (t.out_row0[i] != nr) return false;
-            nr += (t.out_kind[i] == CLIK_OUT_AFFINE) ? 1 : t.out_nrows[i];
+            nr += (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 1;
         }
     }
     if (nr > clik::SHAPE_MAX_ROWS) return false;
@@ -548,7 +555,10 @@ static std::string shape_to_string(const clik::ShapeDesc& h)
         for (int k = 0; k < CLIK_MAX_M; ++k) { o += std::to_string(i < nt ? h.out_nrows[i][k] : 0); if (k + 1 < CLIK_MAX_M) o += ", "; }
         o += (i + 1 < clik::SHAPE_MAX_TASKS) ? "}, " : "}";
     }
-    o += "}, " + std::to_string(h.n_x) + "}";
+    o += "}, " + std::to_string(h.n_x) + ", ";
+    o += "{";
+    for (int i = 0; i < clik::SHAPE_MAX_TASKS; ++i) { o += std::to_string(i < nt ? h.ext[i] : 0); if (i + 1 < clik::SHAPE_MAX_TASKS) o += ", "; }
+    o += "}}";
     return o;
 }
 
@@ -756,6 +766,20 @@ extern "C" const char* clik_pinv_kernel_name(const clik_pinv* h)
     return h ? clik::pinv_kernel_name(h->kernel) : "none";
 }
 
+// constraints whose rows are code generated from the caller's expression graph (CLIK_OUT_EXTERN)
+// exist only inside the kernel instantiated for them
+static bool skill_has_extern(const DevSkill& S)
+{
+    for (int ti = 0; ti < S.d.n_tasks; ++ti)
+        if (S.d.tasks[ti].out_kind[0] == CLIK_OUT_EXTERN) return true;
+    return false;
+}
+static int extern_needs_kernel(const char* what)
+{
+    return fail(CLIK_EUNSUPPORTED, "%s: the skill has code-generated constraint rows and no kernel instantiated "
+                                   "for them is attached (casclik_amd.jit needs hipcc)", what);
+}
+
 static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk)
 {
     memset(tk, 0, sizeof(*tk));
@@ -778,6 +802,7 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_x > 0 && (!x || !dx)) return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    if (!h->jit_solve && skill_has_extern(S)) return extern_needs_kernel("clik_pinv_solve_batch");
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
@@ -800,6 +825,7 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
     if (B == 0 || n_ticks == 0) return CLIK_OK;
     const DevSkill& S = h->host;
     if (S.d.n_x > 0) return fail(CLIK_EUNSUPPORTED, "rollout with virtual_var is not supported");
+    if (!h->jit_rollout && skill_has_extern(S)) return extern_needs_kernel("clik_pinv_rollout_batch");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     const size_t need = (size_t)n_ticks * 2 * (size_t)S.d.n_tslots;
@@ -1036,6 +1062,7 @@ extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
     if (!dq) return fail(CLIK_EINVAL, "dq must be a device pointer");
+    if (!h->jit_solve && skill_has_extern(h->host)) return extern_needs_kernel("clik_qp_solve_batch");
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
@@ -1061,6 +1088,8 @@ extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tte
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
     if (!Hdiag || !A || !lbA || !ubA) return fail(CLIK_EINVAL, "output pointers required");
+    if (skill_has_extern(h->host))
+        return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: not available for skills with code-generated rows");
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;

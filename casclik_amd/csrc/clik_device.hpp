@@ -62,6 +62,9 @@ struct ShapeDesc {
     // (cs.norm_2 / cs.norm_fro constraint expressions)
     int out_nrows[SHAPE_MAX_TASKS][CLIK_MAX_M];
     int n_x;                        // virtual variables: state = [robot_var (n - n_x); virtual_var (n_x)]
+    // 1: e, J, d e/d t of the task come from ExternTask<ti> (code generated from the caller's expression
+    // graph, CLIK_OUT_EXTERN); only run-time instantiated kernels can carry such a task
+    int ext[SHAPE_MAX_TASKS];
 };
 
 constexpr bool shape_unit(const ShapeDesc& sd, int ti) { return sd.const_j[ti] != 0 && sd.m[ti] > 0 && sd.ucol[ti][0] > 0; }
@@ -140,7 +143,7 @@ inline bool shape_equal(const ShapeDesc& a, const ShapeDesc& b)
     for (int i = 0; i < a.n_tasks; ++i)
         if (a.cls[i] != b.cls[i] || a.m[i] != b.m[i] || a.flags[i] != b.flags[i] || a.const_j[i] != b.const_j[i] ||
             a.gain_matrix[i] != b.gain_matrix[i] || a.ny_terms[i] != b.ny_terms[i] || a.has_t[i] != b.has_t[i] ||
-            a.soft[i] != b.soft[i])
+            a.soft[i] != b.soft[i] || a.ext[i] != b.ext[i])
             return false;
     for (int i = 0; i < a.n_tasks; ++i)
         for (int k = 0; k < CLIK_MAX_M; ++k)

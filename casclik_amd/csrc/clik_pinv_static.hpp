@@ -528,6 +528,21 @@ __device__ __forceinline__ void ldl_solve_s(const double (&A)[K * (K + 1) / 2], 
         for (int j = i + 1; j < K; ++j) x[i] = fma(-A[tri(j, i)], x[j], x[i]);
 }
 
+// Constraints written outside the affine-in-features family (CLIK_OUT_EXTERN, ShapeDesc::ext): the
+// run-time instantiated translation unit specialises ExternTask<TI> with straight-line code generated from
+// the caller's expression graph and its symbolic derivatives (casclik_amd/codegen.py) - what the reference
+// gets from cs.jacobian + the CasADi JIT (constraints.py:67-73, pseudo_inverse.py:476-483).
+// tv: the tick's time-slot values (TickArgs::tv), K: tool frame and its Jacobians.
+template <int TI>
+struct ExternTask {
+    template <int N, int M>
+    __device__ static void eval(const double (&)[N], const double*, const double*, const Kin<N>&, double (&)[M],
+                                double (&)[M][N], double (&)[M])
+    {
+        static_assert(TI < 0, "ShapeDesc::ext is set for a task without generated code");
+    }
+};
+
 // e, J, d e/d t of task TI: rows are contiguous and all affine in static shapes
 template <const ShapeDesc& SD, int TI>
 __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const TickArgs& tk,
@@ -537,6 +552,10 @@ __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
+    if constexpr (SD.ext[TI] != 0) {
+        ExternTask<TI>::template eval<N, M>(z, ys, tk.tv, K, e, J, Jt);
+        return;
+    }
     const int nts = S->n_tslots;
     static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;

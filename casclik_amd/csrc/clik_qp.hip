@@ -203,8 +203,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
                 for (int j = 0; j < N; ++j)
                     if (j < n) cv = fma(As[(i * N + j) * WAVE + lane], u[j], cv);
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                const double sc = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
-                worst = fmax(worst, fmax(lbi - cv, cv - ubi) * sc);
+                worst = fmax(worst, fmax((lbi - cv) / fmax(1.0, fabs(lbi)), (cv - ubi) / fmax(1.0, fabs(ubi))));
             }
         }
         if (!(worst <= 1e-7)) status_v = 2;      // (a net for garbage, not a precision test)

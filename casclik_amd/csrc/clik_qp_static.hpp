@@ -100,16 +100,20 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
     // bounds stay in LDS (read once per iteration in the selection scan): keeping
     // them in registers next to the factor spills to scratch
     uint32_t W = softeq, up = 0u, eq = 0u;
-    double c[NC], isc[NC];              // isc: violations are measured relative to max(1, |bounds|)
+    // violations are measured relative to max(1, |bound|) of the bound in question (a one-sided
+    // SetConstraint carries the reference's default 1e10 on its other side, constraints.py:199-206:
+    // a common scale per row would hide the violation of the real bound)
+    double c[NC], isl[NC], ish[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         nu[i] = 0.0;
         c[i] = 0.0;
-        isc[i] = 1.0;
+        isl[i] = ish[i] = 1.0;
         if (EXACT || i < nc) {
             const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
             if (!(ubi - lbi > 0.0)) eq |= 1u << i;
-            isc[i] = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
+            isl[i] = 1.0 / fmax(1.0, fabs(lbi));
+            ish[i] = 1.0 / fmax(1.0, fabs(ubi));
         }
     }
     int status = 0;
@@ -147,7 +151,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             if (EXACT || i < nc) {
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                 const double c0 = (c0s != nullptr) ? c0s[i * WAVE + lane] : 0.0;
-                const double vlo = (lbi - c0) * isc[i], vhi = (c0 - ubi) * isc[i];
+                const double vlo = (lbi - c0) * isl[i], vhi = (c0 - ubi) * ish[i];
                 if (fmax(vlo, vhi) > 1e-11) {
                     W0 |= 1u << i;
                     if (vhi > vlo) up0 |= 1u << i;
@@ -224,7 +228,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                 for (int i = 0; i < NC; ++i) {
                     if (EXACT || i < nc) {
                         const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                        const double vlo = (lbi - cc[i]) * isc[i], vhi = (cc[i] - ubi) * isc[i];
+                        const double vlo = (lbi - cc[i]) * isl[i], vhi = (cc[i] - ubi) * ish[i];
                         if (pd && !((W0 >> i) & 1u) && fmax(vlo, vhi) > 1e-11) {
                             add |= 1u << i;
                             if (vhi > vlo) addup |= 1u << i;
@@ -308,7 +312,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             for (int i = 0; i < NC; ++i) {
                 if (EXACT || i < nc) {
                     const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                    const double vlo = (lbi - c[i]) * isc[i], vhi = (c[i] - ubi) * isc[i];
+                    const double vlo = (lbi - c[i]) * isl[i], vhi = (c[i] - ubi) * ish[i];
                     double v = fmax(vlo, vhi);
                     v += (((eq >> i) & 1u) && v > 1e-11) ? 1e30 : 0.0;      // equalities take precedence
                     const bool better = !((W >> i) & 1u) && v > best;
@@ -411,7 +415,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         for (int i = 0; i < NC; ++i) {
             if (EXACT || i < nc) {
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                worst = fmax(worst, fmax(lbi - cc[i], cc[i] - ubi) * isc[i]);
+                worst = fmax(worst, fmax((lbi - cc[i]) * isl[i], (cc[i] - ubi) * ish[i]));
             }
         }
         if (status == 0 && !(worst <= 1e-7)) status = 2;      // (a net for garbage, not a precision test)
@@ -719,8 +723,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
                     cv -= slots[(LY::O_SL + sk) * WAVE + lane];         // row is  a v - s
                 }
                 const double lbi = lbs[r * WAVE + lane], ubi = ubs[r * WAVE + lane];
-                const double sc = 1.0 / fmax(1.0, fmax(fabs(lbi), fabs(ubi)));
-                worst = fmax(worst, fmax(lbi - cv, cv - ubi) * sc);
+                worst = fmax(worst, fmax((lbi - cv) / fmax(1.0, fabs(lbi)), (cv - ubi) / fmax(1.0, fabs(ubi))));
             });
             if (!(worst <= 1e-7)) status = 2;       // (a net for garbage, not a precision test)
         }

@@ -38,9 +38,10 @@ MAX_TSLOTS = 32
 MAX_YTERMS = 4
 MAX_QPVARS = 24
 MAX_QPROWS = 32
+MAX_STATIC_TASKS = 8   # SHAPE_MAX_TASKS of csrc/clik_device.hpp
 
 ROW_HAS_Q, ROW_HAS_P, ROW_HAS_R, ROW_HAS_O, ROW_HAS_Y, ROW_HAS_T = 1, 2, 4, 8, 16, 32
-OUT_AFFINE, OUT_NORM2 = 0, 1
+OUT_AFFINE, OUT_NORM2, OUT_EXTERN = 0, 1, 2
 CLS_EQ, CLS_SET, CLS_VELEQ, CLS_VELSET = 0, 1, 2, 3
 
 
@@ -122,6 +123,7 @@ class SkillDescriptor(object):
         self.quat_yi = [0, 0, 0, 0]
         self.quat = [0.0, 0.0, 0.0, 1.0]
         self.time_family = None
+        self.extern_code = {}  # task index -> C++ source of its ExternTask specialisation (codegen.py)
 
     @property
     def n_state(self):
@@ -138,6 +140,11 @@ class SkillDescriptor(object):
     @property
     def n_slack(self):
         return sum(t["m"] for t in self.tasks if t["soft"])
+
+    def extern_source(self):
+        """Generated device code of the constraints outside the row-table family
+        ('' when there is none); part of the run-time instantiated kernel."""
+        return "".join(self.extern_code[k] for k in sorted(self.extern_code))
 
     def time_terms(self, t):
         """Host-side per-tick evaluation of the time slots:
@@ -447,39 +454,71 @@ class _Lowerer(object):
             else:
                 raise ValueError("gain shape %s does not fit '%s'" % (g.shape, cnstr.label))
         if cls in (CLS_SET, CLS_VELSET):
-            task["set_min"][:m] = self._const_vector(cnstr.set_min, m, "set_min", cnstr.label)
-            task["set_max"][:m] = self._const_vector(cnstr.set_max, m, "set_max", cnstr.label)
+            # an infinite bound (set_max=cs.inf, double_pendulum_2D...ipynb cell 10) becomes the value the
+            # reference itself uses for "no bound" (constraints.py:199-206): the device arithmetic stays finite
+            for key, val in (("set_min", cnstr.set_min), ("set_max", cnstr.set_max)):
+                v = self._const_vector(val, m, key, cnstr.label)
+                task[key][:m] = np.where(np.isinf(v), np.sign(v) * 1e10, v)
         if cls == CLS_VELEQ:
             task["target"][:m] = self._const_vector(cnstr.target, m, "target", cnstr.label)
         arr = cs._as_array(expr)
         memo = {}
-        for i in range(m):
-            node = arr[i, 0]
-            try:
-                form = self.affine(node, memo)
-                task["out_kind"][i] = OUT_AFFINE
-                task["out_row0"][i] = self._emit_row(form)
-                task["out_nrows"][i] = 1
-            except NotAffine as why:
-                if node.op != "norm2":
-                    raise NotImplementedError(
-                        "row %d of constraint '%s' is outside the device task "
-                        "family (%s)" % (i, cnstr.label, why))
+        mark = (len(self.desc.rows), len(self.desc.tslots))
+        try:
+            for i in range(m):
+                node = arr[i, 0]
                 try:
+                    form = self.affine(node, memo)
+                    task["out_kind"][i] = OUT_AFFINE
+                    task["out_row0"][i] = self._emit_row(form)
+                    task["out_nrows"][i] = 1
+                except NotAffine:
+                    if node.op != "norm2":
+                        raise
                     forms = [self.affine(a, memo) for a in node.args]
-                except NotAffine as why2:
-                    raise NotImplementedError(
-                        "row %d of constraint '%s': norm of a non-affine "
-                        "expression (%s)" % (i, cnstr.label, why2))
-                forms = [f for f in forms if not (f.is_const() and f.c == 0.0)]
-                first = None
-                for f in forms:
-                    r = self._emit_row(f)
-                    first = r if first is None else first
-                task["out_kind"][i] = OUT_NORM2
-                task["out_row0"][i] = first if first is not None else 0
-                task["out_nrows"][i] = len(forms)
+                    forms = [f for f in forms if not (f.is_const() and f.c == 0.0)]
+                    first = None
+                    for f in forms:
+                        r = self._emit_row(f)
+                        first = r if first is None else first
+                    task["out_kind"][i] = OUT_NORM2
+                    task["out_row0"][i] = first if first is not None else 0
+                    task["out_nrows"][i] = len(forms)
+        except NotAffine:
+            # outside the row table: the whole constraint becomes generated code (codegen.py)
+            self._rollback(mark)
+            self._lower_extern(task, [arr[i, 0] for i in range(m)], cnstr.label)
         return task
+
+    def _rollback(self, mark):
+        n_rows, n_ts = mark
+        del self.desc.rows[n_rows:]
+        del self.desc.tslots[n_ts:]
+        self._tslot_index = {k: v for k, v in self._tslot_index.items() if v < n_ts}
+
+    def _lower_extern(self, task, nodes, label):
+        from . import codegen
+        ti = len(self.desc.tasks)
+        if ti >= MAX_STATIC_TASKS:
+            raise NotImplementedError(
+                "constraint '%s' needs generated device code, which only the shape-specialised "
+                "kernels carry (at most %d constraints)" % (label, MAX_STATIC_TASKS))
+        em = codegen.TaskEmitter(self)
+        try:
+            self.desc.extern_code[ti] = em.emit_task(ti, nodes)
+        except NotImplementedError as why:
+            raise NotImplementedError("constraint '%s': %s" % (label, why))
+        self._extern_keep = getattr(self, "_extern_keep", []) + [em]
+        for i in range(len(nodes)):
+            # placeholder row per output (keeps the row layout of the kernels); HAS_P: uses the tool frame
+            form = _Affine()
+            r = self._emit_row(form)
+            if em.uses_fk:
+                self.desc.rows[r]["flags"] |= ROW_HAS_P
+                self.desc.uses_fk = True
+            task["out_kind"][i] = OUT_EXTERN
+            task["out_row0"][i] = r
+            task["out_nrows"][i] = 1
 
     def run(self):
         spec = self.spec

@@ -100,6 +100,14 @@ typedef struct clik_row {
 /* how output row i of a constraint is formed from affine rows */
 #define CLIK_OUT_AFFINE 0     /* e_i = r[row0]                                    */
 #define CLIK_OUT_NORM2  1     /* e_i = || r[row0 .. row0+nrows) ||_2              */
+/* e_i, its state gradient and d e_i/d t come from a device function generated from the
+ * caller's expression graph and compiled into the kernel attached with
+ * clik_pinv_attach_kernel / clik_qp_attach_kernel (the CasADi-generated function of
+ * pseudo_inverse.py:476-483 / reactive_qp.py:262-298).  All outputs of such a constraint
+ * are EXTERN; each owns one placeholder row (zero coefficients; HAS_P flags a use of the
+ * chain's tool frame).  Without an attached kernel every solve entry returns
+ * CLIK_EUNSUPPORTED: the built-in kernels cannot evaluate it. */
+#define CLIK_OUT_EXTERN 2
 
 /* constraint classes (casclik/constraints.py:88,148,299,336) */
 #define CLIK_CLS_EQ     0

@@ -588,8 +588,12 @@ def qp_solve_dense(hdiag, A, lb, ub, max_iter=200, eq_tol=0.0):
         if ub[i] - lb[i] <= eq_tol:
             eq_rows.append(i)
         else:
-            cons.append((i, +1.0, lb[i]))
-            cons.append((i, -1.0, -ub[i]))
+            # (an infinite bound is no constraint: notebooks pass set_max=cs.inf,
+            # double_pendulum_2D_comparison_of_controllers.ipynb cell 10)
+            if np.isfinite(lb[i]):
+                cons.append((i, +1.0, lb[i]))
+            if np.isfinite(ub[i]):
+                cons.append((i, -1.0, -ub[i]))
     x = np.zeros(nv)
     act = []     # entries (normal vector, rhs, is_eq, tag)
     u = np.zeros(0)
@@ -670,8 +674,9 @@ def qp_solve_dense(hdiag, A, lb, ub, max_iter=200, eq_tol=0.0):
             # never hand out a point that is not primal feasible: on an
             # infeasible problem the scan above can run out of candidates
             Ax = A.dot(x)
-            scl = np.maximum(1.0, np.maximum(np.abs(lb), np.abs(ub)))
-            if np.any((lb - Ax) / scl > 1e-8) or np.any((Ax - ub) / scl > 1e-8):
+            lo_s = np.where(np.isfinite(lb), (lb - Ax) / np.maximum(1.0, np.abs(np.where(np.isfinite(lb), lb, 0.0))), -1.0)
+            hi_s = np.where(np.isfinite(ub), (Ax - ub) / np.maximum(1.0, np.abs(np.where(np.isfinite(ub), ub, 0.0))), -1.0)
+            if np.any(lo_s > 1e-8) or np.any(hi_s > 1e-8):
                 raise QPInfeasible("no feasible point found")
             return x
         i, sgn, rhs = pick

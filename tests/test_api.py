@@ -165,9 +165,10 @@ def test_lowering_norm_and_time_terms(ur5_fk):
 def test_lowering_rejects_what_the_device_cannot_do(iiwa_fk):
     t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("dq", 7)
     T = iiwa_fk["T_fk"](q)
-    with pytest.raises(NotImplementedError, match="outside the device task family"):
-        lower_skill(cc.SkillSpecification("s", t, q, constraints=[
-            cc.EqualityConstraint("sq", T[0, 3] * T[1, 3])]))
+    # a product of state-dependent terms is outside the row table: it becomes generated code
+    # (tests/test_codegen.py), not a refusal
+    d = lower_skill(cc.SkillSpecification("s", t, q, constraints=[cc.EqualityConstraint("sq", T[0, 3] * T[1, 3])]))
+    assert 0 in d.extern_code and d.uses_fk
     with pytest.raises(NotImplementedError, match="velocity variables"):
         lower_skill(cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint("v", dq[0])]))
     with pytest.raises(NotImplementedError, match="rows"):

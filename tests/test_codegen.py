@@ -1,0 +1,149 @@
+"""Generated constraint code (casclik_amd/codegen.py) against the oracle's forward-mode
+dual numbers - on the CPU: the generated ``ExternTask<TI>::eval`` bodies are plain C++
+once ``__device__`` is defined away, so g++ compiles them and ctypes calls them.
+The oracle differentiates the same expression trees with dual numbers
+(oracle/clik_oracle.py ExprEvaluator), the generator with symbolic derivatives
+(casclik_amd/autodiff.py): two independent routes to ``cs.jacobian``
+(reference: casclik/constraints.py:67-73)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import casclik_amd as cc
+from casclik_amd import sym as cs, skills
+from casclik_amd.lowering import lower_skill, OUT_EXTERN, OUT_AFFINE
+from oracle import clik_oracle
+from extern_skills import double_pendulum_skill, mixed_frame_skill
+
+HARNESS = r"""
+#include <cmath>
+#define __device__
+#define __forceinline__ inline
+template <int N> struct Kin { double p[3]; double R[9]; double Jv[3][N]; double Jw[3][N]; double o[3]; double M[9]; double tr; };
+template <int TI> struct ExternTask;
+%(extern)s
+template <int TI, int N, int M>
+static void run(const double* z, const double* ys, const double* tv, const double* kin, double* e, double* J, double* Jt)
+{
+    double zz[N], ee[M], JJ[M][N], tt[M];
+    Kin<N> K;
+    for (int i = 0; i < N; ++i) zz[i] = z[i];
+    for (int i = 0; i < 3; ++i) K.p[i] = kin[i];
+    for (int i = 0; i < 9; ++i) K.R[i] = kin[3 + i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < N; ++j) { K.Jv[i][j] = kin[12 + i * N + j]; K.Jw[i][j] = kin[12 + 3 * N + i * N + j]; }
+    ExternTask<TI>::template eval<N, M>(zz, ys, tv, K, ee, JJ, tt);
+    for (int i = 0; i < M; ++i) { e[i] = ee[i]; Jt[i] = tt[i]; for (int j = 0; j < N; ++j) J[i * N + j] = JJ[i][j]; }
+}
+extern "C" void run_task(int ti, const double* z, const double* ys, const double* tv, const double* kin, double* e, double* J, double* Jt)
+{
+    switch (ti) {
+%(cases)s
+    }
+}
+"""
+
+
+def _compile(desc, tmp_path):
+    cases = "".join("    case %d: run<%d, %d, %d>(z, ys, tv, kin, e, J, Jt); break;\n"
+                    % (ti, ti, desc.n_state, desc.tasks[ti]["m"]) for ti in sorted(desc.extern_code))
+    _compile.count += 1               # (a fresh name per build: dlopen caches by path)
+    src = tmp_path / ("gen%d.cpp" % _compile.count)
+    src.write_text(HARNESS % {"extern": desc.extern_source(), "cases": cases})
+    so = tmp_path / ("gen%d.so" % _compile.count)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", str(src), "-o", str(so)])
+    lib = C.CDLL(str(so))
+    dp = C.POINTER(C.c_double)
+    lib.run_task.argtypes = [C.c_int] + [dp] * 7
+    return lib
+
+
+_compile.count = 0
+
+
+def _kin_numeric(fk, q, n_state):
+    """p, R, Jv, Jw of the tool frame at q (finite differences are not needed: the angular columns
+    follow from dR/dq_s R^T = skew(w_s)); Jacobian columns padded to the state width."""
+    n = len(q)
+    qs = cs.MX.sym("qk", n)
+    T = fk["T_fk"](qs)
+    spec = cc.SkillSpecification("k", cs.MX.sym("tk"), qs, constraints=[cc.EqualityConstraint("p", T[:3, 3])])
+    ev = clik_oracle.ExprEvaluator(spec, 0.0, np.asarray(q, dtype=float)[None, :], None)
+    p, _, Jv = ev.vector(T[:3, 3])
+    cols, dcols = [], []
+    for c in range(3):
+        v, _, d = ev.vector(T[:3, c])
+        cols.append(v[0])
+        dcols.append(d[0])
+    R = np.stack(cols, axis=1)                      # R[:, c]
+    Jw = np.zeros((3, n))
+    for s in range(n):
+        dR = np.stack([dcols[c][:, s] for c in range(3)], axis=1)
+        W = dR @ R.T
+        Jw[:, s] = [W[2, 1], W[0, 2], W[1, 0]]
+    pad = np.zeros((3, n_state - n))
+    return np.concatenate([p[0], R.reshape(-1), np.hstack([Jv[0], pad]).reshape(-1), np.hstack([Jw, pad]).reshape(-1)])
+
+
+def _check(spec, desc, lib, t, Z, Y, fk=None, tol=1e-12):
+    tv = np.ascontiguousarray(desc.time_terms(t)) if desc.n_tslots else np.zeros(1)
+    dp = C.POINTER(C.c_double)
+    n = desc.n_state
+    ev = clik_oracle.ExprEvaluator(spec, t, Z, Y)
+    for ti in sorted(desc.extern_code):
+        cn = spec.constraints[ti]
+        m = desc.tasks[ti]["m"]
+        e_ref, jt_ref, j_ref = ev.vector(cn.expression)
+        for b in range(Z.shape[0]):
+            kin = _kin_numeric(fk, Z[b, :desc.n_q], n) if fk is not None else np.zeros(12 + 6 * n)
+            z = np.ascontiguousarray(Z[b])
+            ys = np.ascontiguousarray(Y[b]) if Y is not None else np.zeros(1)
+            e, J, Jt = np.zeros(m), np.zeros(m * n), np.zeros(m)
+            lib.run_task(ti, *[a.ctypes.data_as(dp) for a in (z, ys, tv, kin, e, J, Jt)])
+            scale = 1.0 + np.abs(j_ref[b]).max()
+            assert np.abs(e - e_ref[b]).max() <= tol * (1 + np.abs(e_ref[b]).max()), (cn.label, "value")
+            assert np.abs(J.reshape(m, n) - j_ref[b]).max() <= tol * scale, (cn.label, "jacobian")
+            assert np.abs(Jt - jt_ref[b]).max() <= tol * (1 + np.abs(jt_ref[b]).max()), (cn.label, "time derivative")
+
+
+def test_double_pendulum_constraints_become_generated_code(tmp_path):
+    rng = np.random.default_rng(0)
+    for track in (False, True):
+        spec = double_pendulum_skill(track)
+        d = lower_skill(spec)
+        kinds = [t["out_kind"][0] for t in d.tasks]
+        assert kinds == [OUT_EXTERN, OUT_AFFINE, OUT_EXTERN, OUT_EXTERN]
+        assert d.n_tslots == (4 if track else 0)          # target value and rate, per coordinate
+        assert not d.uses_fk and not d.joints
+        lib = _compile(d, tmp_path)
+        _check(spec, d, lib, 1.7, rng.uniform(-3.0, 3.0, size=(16, 2)), None)
+
+
+def test_generated_code_with_tool_frame_time_input_and_virtual_terms(tmp_path):
+    fk = skills.iiwa()
+    spec = mixed_frame_skill(fk)
+    d = lower_skill(spec)
+    assert [tk["out_kind"][0] for tk in d.tasks] == [OUT_EXTERN, OUT_EXTERN, OUT_AFFINE]
+    assert d.uses_fk and len(d.joints) > 0
+    lib = _compile(d, tmp_path)
+    rng = np.random.default_rng(1)
+    Z = np.concatenate([rng.uniform(-1.5, 1.5, size=(8, 7)), rng.uniform(-1, 1, size=(8, 1))], axis=1)
+    _check(spec, d, lib, 0.8, Z, rng.uniform(-1, 1, size=(8, 3)), fk=fk, tol=1e-11)
+
+
+def test_what_generated_code_cannot_express_is_refused():
+    fk = skills.iiwa()
+    t, q, dq, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("dq", 7), cs.MX.sym("y", 4)
+    T = fk["T_fk"](q)
+    with pytest.raises(NotImplementedError, match="orientation_error inside a non-affine"):
+        lower_skill(cc.SkillSpecification("s", t, q, input_var=y, constraints=[
+            cc.EqualityConstraint("o", cs.orientation_error(T[:3, :3], y)[0] * q[0])]))
+    with pytest.raises(NotImplementedError, match="velocity variables"):
+        lower_skill(cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint("v", dq[0] * q[0])]))
+    # more constraints than a shape-specialised kernel carries: generated code has nowhere to live
+    many = [cc.EqualityConstraint("a%d" % i, q[i % 7] + 0.1 * i, priority=i) for i in range(8)]
+    many.append(cc.EqualityConstraint("prod", q[0] * q[1], priority=9))
+    with pytest.raises(NotImplementedError, match="generated device code"):
+        lower_skill(cc.SkillSpecification("s", t, q, constraints=many))

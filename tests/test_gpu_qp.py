@@ -318,3 +318,42 @@ def test_qp_infeasible_by_a_dependent_row_is_reported(iiwa_fk, kernel, monkeypat
     ok = rstatus == 0
     assert (status[ok] == 0).all() and np.isnan(dq[~ok]).all()
     assert _rel(dq[ok], rdq[ok]).max() < QP_RTOL
+
+
+@pytest.mark.parametrize("force_dynamic", [False, True])
+def test_qp_one_sided_set_with_the_default_other_bound(iiwa_fk, monkeypatch, force_dynamic):
+    """A SetConstraint with only set_min given keeps the reference's default set_max = 1e10
+    (constraints.py:199-206).  The violation of the real bound must not be measured relative to that
+    1e10 (it was: the active-set scan then never saw it and the floor was not enforced); an infinite
+    bound (double_pendulum_2D...ipynb cell 10, set_max=cs.inf) must behave the same."""
+    from oracle import clik_oracle
+    if force_dynamic:
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 7)
+    T = iiwa_fk["T_fk"](q)
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 300, seed=11)
+    ref = None
+    for set_max in (None, cs.inf):
+        kw = {} if set_max is None else {"set_max": set_max}
+        floor = cc.SetConstraint("floor", T[2, 3], set_min=0.75, gain=2.0, priority=0, **kw)
+        reach = cc.EqualityConstraint("reach", T[:3, 3] - np.array([0.5, 0.1, 0.3]), gain=3.0, priority=1,
+                                      constraint_type="soft")
+        speed = cc.VelocitySetConstraint("speed", q, set_min=-1.0, set_max=1.0, priority=2)
+        spec = cc.SkillSpecification("floor", t, q, constraints=[floor, reach, speed])
+        ctrl = _controller(spec)
+        assert (ctrl.kernel_name == "dynamic") == force_dynamic
+        dq, _, slack, status = ctrl.solve_batch(0.0, Q)
+        rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q)
+        assert np.array_equal(status, rstatus)
+        ok = rstatus == 0
+        assert ok.sum() > 250
+        assert _rel(dq[ok], rdq[ok]).max() < QP_RTOL
+        # the floor row is active on the instances that start below it: it really is enforced
+        hd, A, lb, ub = clik_oracle.qp_data_batch(spec, 0.0, Q)
+        row = (A[:, 0, :7] * dq).sum(axis=1)
+        below = ok & (lb[:, 0] > 0.0)
+        assert below.sum() > 30 and (row[below] >= lb[below, 0] - 1e-8).all()
+        if ref is None:
+            ref = dq
+        else:
+            assert np.array_equal(np.isnan(ref), np.isnan(dq)) and np.nanmax(np.abs(ref - dq)) < 1e-9
