@@ -168,7 +168,7 @@ class ReactiveQPController(BaseController):
         fopts = self.options.get("function_opts") or {}
         want_jit = fopts.get("jit", True) and os.environ.get("CLIK_JIT", "1") != "0" \
             and os.environ.get("CLIK_FORCE_DYNAMIC", "0") != "1"
-        if self.kernel_name == "dynamic" and want_jit:
+        if self.kernel_name in ("dynamic", "none") and want_jit:
             from .. import jit
             with torch.cuda.device(self._device):
                 name = jit.attach_qp(self._lib, handle, cdesc, extern=d.extern_source())
@@ -182,6 +182,11 @@ class ReactiveQPController(BaseController):
                 "kernel could be instantiated for it (jit disabled, hipcc missing, or the skill is "
                 "outside the shape-specialised family)" % ", ".join(
                     repr(d.tasks[k]["label"]) for k in sorted(d.extern_code)))
+        if self.kernel_name == "none":
+            raise NotImplementedError(
+                "the QP of this skill (%d variables x %d rows) exceeds the built-in kernel and no "
+                "shape-specialised kernel could be instantiated for it (jit disabled or hipcc missing)"
+                % (self.n_qp_vars, self.n_qp_rows))
 
     def setup_solver(self):
         """The solver lives inside the kernel; make sure the handle exists

@@ -92,7 +92,8 @@ struct clik_qp {
     DevSkill  host;
     DevSkill* dev;
     clik::WarmArgs warm;
-    int       variant;      // dynamic kernel variant (always valid: qp_data and the fallback use it)
+    int       variant;      // dynamic kernel variant (qp_data and the fallback use it); -1: the skill only fits
+                            // the shape-specialised kernels
     void*     d_img;        // shape-specialised kernels: skill image + QP options
     int       static_k;     // AOT shape-specialised kernel, -1 none
     clik_jit_qp_fn jit_solve;
@@ -901,19 +902,29 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
             if (S.d.tasks[ti].m > need) need = S.d.tasks[ti].m;
         h->variant = clik::qp_pick_variant(need, S.n_qp_vars, S.n_qp_rows);
     }
-    if (h->variant < 0) {
-        delete h;
-        return fail(CLIK_EUNSUPPORTED, "no QP kernel variant for %d variables x %d rows (device limit: 16 rows)",
-                    S.n_qp_vars, S.n_qp_rows);
-    }
-    if (clik::qp_variant_lds(h->variant, S.d.n_y) > 160u * 1024u) {
-        delete h;
-        return fail(CLIK_EUNSUPPORTED, "QP needs more LDS than a CU has (input_var too large)");
+    finish_qp_shape(S);
+    {
+        // The built-in (dynamic) kernel keeps every row, soft equalities included, in its active set;
+        // the shape-specialised kernels eliminate those and fit larger skills.  A skill only they can
+        // serve gets a handle without a built-in kernel (variant -1): it solves once a kernel is
+        // attached (clik_qp_attach_kernel) or the AOT table has one.
+        const bool dyn_rows = h->variant >= 0;
+        const bool dyn_lds = dyn_rows && clik::qp_variant_lds(h->variant, S.d.n_y) <= 160u * 1024u;
+        if (!dyn_lds) {
+            if (!qp_static_eligible(S)) {
+                delete h;
+                if (!dyn_rows)
+                    return fail(CLIK_EUNSUPPORTED,
+                                "no QP kernel variant for %d variables x %d rows (device limit: 16 rows)",
+                                S.n_qp_vars, S.n_qp_rows);
+                return fail(CLIK_EUNSUPPORTED, "QP needs more LDS than a CU has (input_var too large)");
+            }
+            h->variant = -1;
+        }
     }
     compute_warm(S, S.lds_slots, h->warm);
     S.zero_token = 0;
     S.lds_slots = 0;
-    finish_qp_shape(S);
     h->d_img = nullptr;
     h->static_k = -1;
     h->jit_solve = nullptr;
@@ -1020,7 +1031,7 @@ extern "C" const char* clik_qp_kernel_name(const clik_qp* h)
     if (!h) return "none";
     if (h->jit_solve) return h->jit_name;
     if (h->static_k >= 0) return clik::qp_static_name(h->static_k);
-    return "dynamic";
+    return h->variant >= 0 ? "dynamic" : "none";
 }
 
 extern "C" int clik_qp_destroy(clik_qp* h)
@@ -1073,6 +1084,9 @@ extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double
     else if (h->static_k >= 0)
         e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set,
                                    use_hot, (hipStream_t)stream);
+    else if (h->variant < 0)
+        return fail(CLIK_EUNSUPPORTED, "clik_qp_solve_batch: this skill needs a shape-specialised kernel and none "
+                                       "is attached (casclik_amd.jit needs hipcc)");
     else
         e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,
                                   slack, status, (hipStream_t)stream);
@@ -1090,6 +1104,8 @@ extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tte
     if (!Hdiag || !A || !lbA || !ubA) return fail(CLIK_EINVAL, "output pointers required");
     if (skill_has_extern(h->host))
         return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: not available for skills with code-generated rows");
+    if (h->variant < 0)
+        return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: the skill exceeds the built-in kernel's limits");
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
