@@ -24,7 +24,7 @@ import math
 
 from . import autodiff
 
-_UNARY_C = {"sin": "sin", "cos": "cos", "tan": "tan", "sqrt": "sqrt", "exp": "exp", "log": "log",
+_UNARY_C = {"tan": "tan", "sqrt": "sqrt", "exp": "exp", "log": "log",
             "fabs": "fabs"}
 _INFIX = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
 
@@ -115,6 +115,15 @@ class TaskEmitter(object):
         if op == "ori_err":
             raise NotImplementedError("orientation_error inside a non-affine constraint expression")
         args = [self.ref(a) for a in node.args]
+        if op in ("sin", "cos"):
+            # one evaluation serves both (a Jacobian needs the other one anyway); sincos_joint is the
+            # kernels' own routine (straight-line up to 1e5 rad, library fallback beyond)
+            key = ("sincos", args[0])
+            if key not in self._by_key:
+                k = len(self.lines)
+                self.lines.append("double s%d, c%d; sincos_joint(%s, s%d, c%d);" % (k, k, args[0], k, k))
+                self._by_key[key] = ("s%d" % k, "c%d" % k)
+            return self._by_key[key][0 if op == "sin" else 1]
         if op in _INFIX:
             expr = "%s %s %s" % (args[0], _INFIX[op], args[1])
         elif op == "neg":

@@ -72,6 +72,10 @@ class CPinvOracle(object):
     def __init__(self, spec, options=None):
         self.lib = load()
         self.desc = lower_skill(spec)
+        if self.desc.extern_code:
+            # (this restatement reads the lowered row table; expression-graph constraints are
+            # covered by the numpy oracle only)
+            raise NotImplementedError("the C oracle has no rows for constraints outside the row table")
         self.cdesc = _capi.desc_to_c(self.desc)
         self.copts = _capi.pinv_opts_to_c(_full_pinv_options(options))
 

@@ -24,6 +24,7 @@ HARNESS = r"""
 #define __forceinline__ inline
 template <int N> struct Kin { double p[3]; double R[9]; double Jv[3][N]; double Jw[3][N]; double o[3]; double M[9]; double tr; };
 template <int TI> struct ExternTask;
+static inline void sincos_joint(double x, double& s, double& c) { s = std::sin(x); c = std::cos(x); }
 %(extern)s
 template <int TI, int N, int M>
 static void run(const double* z, const double* ys, const double* tv, const double* kin, double* e, double* J, double* Jt)

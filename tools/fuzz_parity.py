@@ -63,6 +63,17 @@ def random_skill(rng, fk, n):
     pool.append(lambda pr: cc.EqualityConstraint("pos_y", p - y[:3], gain=gain(3), priority=pr))
     path = cs.vertcat(0.3 + 0.1 * cs.sin(0.7 * t), 0.2 * cs.cos(0.4 * t), 0.45 + 0.05 * cs.sin(t))
     pool.append(lambda pr: cc.EqualityConstraint("track_t", p - path, gain=gain(3), priority=pr))
+    # one-sided set (the other bound stays at the reference's default 1e10) and constraints outside the
+    # affine row table (generated device code: products / trigonometric functions of the state)
+    pool.append(lambda pr: cc.SetConstraint("floor", p[2], set_min=float(rng.uniform(0.2, 0.5)), gain=gain(1), priority=pr))
+    ctr = rng.uniform(0.2, 0.5, size=3)
+    pool.append(lambda pr: cc.SetConstraint("keepout", cs.dot(p - ctr, p - ctr), set_min=float(rng.uniform(0.01, 0.06)),
+                                            gain=gain(1), priority=pr))
+    ja, jb = rng.choice(n - 1, size=2, replace=False).tolist()
+    pool.append(lambda pr: cc.EqualityConstraint("trig", cs.sin(q[ja]) * cs.cos(q[jb]) + 0.3 * q[ja] - 0.2 + 0.1 * cs.sin(t),
+                                                 gain=gain(1), priority=pr))
+    pool.append(lambda pr: cc.EqualityConstraint("xy_prod", cs.vertcat(p[0] * p[1] - 0.05, T[2, 2] * q[jb] - 0.1),
+                                                 gain=gain(2), priority=pr))
     nt = int(rng.integers(2, 6))
     picks = rng.choice(len(pool), size=nt, replace=False)
     prios = rng.permutation(nt)
@@ -116,14 +127,27 @@ def main():
         except Exception as exc:                      # (e.g. standard pinv on a singular stack)
             print("skill %2d %-4s oracle refused: %s" % (s, robot, str(exc)[:60]))
             continue
-        out = c_oracle.CPinvOracle(spec, opts).solve_batch(tval, Q, Y=Y)
-        sane = (out[-1] == rmode) & np.isfinite(ref).all(axis=1)
-        # yardstick for ill-conditioned stacks (deep priority stacks, undamped inverse of a rank-deficient
-        # stack): how far the two CPU evaluations of the same algorithm are from each other
-        cdq = np.hstack([out[0]] + ([out[1]] if out[1] is not None and np.ndim(out[1]) == 2 else []))
-        lane_gap = np.abs(cdq - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
-        sane &= lane_gap < 1e-8          # lanes where even the CPU evaluations part ways are no parity evidence
-        cpu_gap = float(lane_gap[sane].max()) if sane.any() else 0.0
+        sane = np.isfinite(ref).all(axis=1)
+        cpu_gap = 0.0
+        try:
+            out = c_oracle.CPinvOracle(spec, opts).solve_batch(tval, Q, Y=Y)
+        except NotImplementedError:
+            out = None        # generated constraints: the C restatement reads the row table only
+        if out is not None:
+            sane &= out[-1] == rmode
+            # yardstick for ill-conditioned stacks (deep priority stacks, undamped inverse of a rank-deficient
+            # stack): how far the two CPU evaluations of the same algorithm are from each other
+            cdq = np.hstack([out[0]] + ([out[1]] if out[1] is not None and np.ndim(out[1]) == 2 else []))
+            lane_gap = np.abs(cdq - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+            sane &= lane_gap < 1e-8          # lanes where even the CPU evaluations part ways are no parity evidence
+            cpu_gap = float(lane_gap[sane].max()) if sane.any() else 0.0
+        else:
+            # second CPU evaluation = the numpy oracle with q moved by a few ulps: how far its own answer
+            # moves under rounding-level noise is the yardstick (same thresholds as above)
+            ref_p, _ = clik_oracle.pinv_solve_batch(spec, opts, tval, Q * (1.0 + 1e-15), Y=Y)
+            lane_gap = np.abs(ref_p - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+            sane &= lane_gap < 1e-8
+            cpu_gap = float(lane_gap[sane].max()) if sane.any() else 0.0
         tol = max(PINV_RTOL, 20.0 * cpu_gap)
         # a mode that flips under a 1e-12 perturbation of q is decided by rounding (e.g. a set on a
         # joint that no task moves): not a parity question
@@ -135,7 +159,12 @@ def main():
             os.environ.pop("CLIK_FORCE_DYNAMIC", None)
             os.environ.update(env)
             ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
-            ctrl.setup_problem_functions()
+            try:
+                ctrl.setup_problem_functions()
+            except NotImplementedError as exc:
+                # (generated constraints live only in the instantiated kernel: no dynamic run for them)
+                print("skill %2d %-4s pinv %s refused: %s" % (s, robot, "dynamic" if env else "static", str(exc)[:70]))
+                continue
             names.append(ctrl.kernel_name[:12])
             dq, _, mode = ctrl.solve_batch(tval, Q, input_var=Y)
             ok = sane & (mode == rmode)
@@ -173,8 +202,8 @@ def main():
                 qc.setup_problem_functions()
                 qc.setup_solver()
             except NotImplementedError as exc:
-                print("skill %2d %-4s qp refused by the device limits: %s" % (s, robot, str(exc)[:60]))
-                break
+                print("skill %2d %-4s qp %s refused: %s" % (s, robot, "dynamic" if env else "static", str(exc)[:70]))
+                continue
             dq, _, sl, st = qc.solve_batch(tval, Q, input_var=Y)
             ok = (rst == 0) & (st == 0)
             rel = np.abs(dq - rdq).max(axis=1) / (1.0 + np.abs(rdq).max(axis=1))
