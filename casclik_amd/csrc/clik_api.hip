@@ -582,7 +582,8 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
         if (!build_skill_image(*S, img)) eligible = false;      // rows not in task order / too many rows
     }
     // the static plan handles the doubly processed first EqualityConstraint only when
-    // it owns a wide, state-dependent factor (clik_pinv_static.hpp)
+    // it owns a state-dependent factor (clik_pinv_static.hpp); "standard" keeps the wide-only rule
+    // (its tall branch has no damping to carry the closed form)
     for (unsigned act = 0; eligible && act < (1u << S->n_sets); ++act) {
         int r = 0, set_idx = 0;
         for (int ti = 0; ti < h.n_tasks; ++ti) {
@@ -597,7 +598,7 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
             const bool contributes = cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ || conv;
             if (contributes && r == 0 && cls == CLIK_CLS_EQ) {
                 const bool wide = h.standard ? (h.m[ti] < h.n) : (h.n >= h.m[ti]);
-                if (h.const_j[ti] || !wide) eligible = false;
+                if (h.const_j[ti] || (!wide && h.standard)) eligible = false;
             }
             r += h.m[ti];
         }

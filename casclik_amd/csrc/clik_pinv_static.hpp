@@ -118,10 +118,9 @@ constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
         const bool consumed = ti < last_consumer || (p.quirk && ti <= last_consumer);
         // a quirk task consumes its own first push even if nothing follows
         p.push_times = (ti < last_consumer) ? times : 0;
-        if (p.quirk && !(p.wide_self && !p.const_j)) {
-            // generic quirk route needs the first push for its own projection
-            if (p.push_times == 0) p.push_times = 1;
-        }
+        // (the doubly processed first EqualityConstraint evaluates both of its passes in closed form from
+        // its own factor - wide or tall - and needs no push of its own; constant-Jacobian first
+        // equalities are not served by static shapes, see step_s)
         (void)consumed;
         if (p.push_times > 0) {
             const int r_new = r + p.push_times * m;
@@ -1204,17 +1203,27 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
                 }
                 ldl_factor_s<N>(Lg, rg);
                 ldl_solve_s<N>(Lg, rg, w);
+                if constexpr (P.quirk) {
+                    // Tall first EqualityConstraint (more rows than states, e.g. an 8-row dual-quaternion
+                    // error on a 6-DoF arm): pass 1 gives w = G^-1 J'd with G = J'J + lam I; pass 2 projects
+                    // through the stack [J] (:382-396): N = I - G^-1 J'J = lam G^-1, so it adds lam G^-1 w.
+                    double w2[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) w2[j] = w[j];
+                    ldl_solve_s<N>(Lg, rg, w2);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) w[j] = fma(c.lam, w2[j], w[j]);
+                }
             }
             if constexpr (P.first) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) c.v[j] += w[j];
             }
-            if constexpr (P.quirk && own_factor) {
+            if constexpr (P.quirk) {
                 // (w already holds the sum of both passes, see above; it was added as the first task)
                 static_assert(P.first, "the doubly processed EqualityConstraint is the first contribution");
+                static_assert(!P.const_j, "static shapes need a state-dependent first EqualityConstraint");
                 if constexpr (P.push_times > 0) push_s<SD, ACT, TI, ROLE>(S, tc, c, 0xffffffffu);
-            } else if constexpr (P.quirk) {
-                static_assert(!P.quirk || own_factor, "static shapes need a wide, state-dependent first EqualityConstraint");
             } else {
                 if constexpr (!P.first) {
                     project_s<SD, ACT, TI, ROLE>(S, tc, c, w);

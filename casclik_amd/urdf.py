@@ -49,7 +49,7 @@ def axis_angle_matrix(axis, angle):
 
 class Joint(object):
     __slots__ = ("name", "type", "R", "p", "axis", "lower", "upper",
-                 "velocity", "q_index")
+                 "velocity", "q_index", "rpy")
 
     def __init__(self, name, jtype, R, p, axis, lower, upper, velocity):
         self.name = name
@@ -61,6 +61,7 @@ class Joint(object):
         self.upper = upper
         self.velocity = velocity
         self.q_index = -1
+        self.rpy = None       # origin roll-pitch-yaw as written in the URDF (quaternion sign of geom.py)
 
 
 class Chain(object):
@@ -193,6 +194,7 @@ def load_chain(filename, root, tip):
             raise NotImplementedError("joint type '%s'" % jtype)
         joints.append(Joint(j.attrib["name"], t, rpy_matrix(rpy), xyz, axis,
                             lower, upper, velocity))
+        joints[-1].rpy = [float(v) for v in rpy]
     return Chain(joints, root, tip)
 
 
@@ -205,7 +207,9 @@ class converter(object):
         act = chain.actuated
         q = _sym.MX.sym("q", chain.n_actuated)
         T = chain(q)
+        from . import geom
         return {
+            "dual_quaternion_fk": _sym.Function("dual_quaternion_fk", [q], [geom.dual_quaternion_fk(chain, q)]),
             "joint_names": [j.name for j in act],
             "upper": [j.upper for j in act],
             "lower": [j.lower for j in act],

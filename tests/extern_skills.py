@@ -41,3 +41,50 @@ def mixed_frame_skill(fk):
                                 gain=2.0, priority=1, constraint_type="soft"),
           cc.EqualityConstraint("rest", q - 0.1, gain=0.5, priority=2, constraint_type="soft")]
     return cc.SkillSpecification("mixed", t, q, virtual_var=x, input_var=y, constraints=cn)
+
+
+def dual_quaternion_skill(fk, which="Q_dist2", for_pinv=False):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 3, 14-18 (and the comparison notebook's
+    cells 37-38): the tool frame as a dual quaternion Q_fk(q), its deviation from a desired frame as an
+    8-row soft EqualityConstraint, joint limits and a joint speed limit."""
+    import numpy as np
+    from casclik_amd import numpy_geom, casadi_geom
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    Q_fk = fk["dual_quaternion_fk"]
+    quat1 = cs.SX.sym("quat1", 8)
+    q1, q2 = cs.SX.sym("q1", 8), cs.SX.sym("q2", 8)
+    dual_quaternion_product = cs.Function("dualquatprod", [q1, q2], [casadi_geom.dual_quaternion_product(q1, q2)])
+    dual_quaternion_conj = cs.Function("dualquatconj", [q1], [casadi_geom.dual_quaternion_conj(q1)])
+    dual_hamilton_operator_minus = cs.Function("dH_minus", [quat1], [cs.vertcat(
+        cs.horzcat(quat1[3], quat1[2], -quat1[1], quat1[0], 0, 0, 0, 0),
+        cs.horzcat(-quat1[2], quat1[3], quat1[0], quat1[1], 0, 0, 0, 0),
+        cs.horzcat(quat1[1], -quat1[0], quat1[3], quat1[2], 0, 0, 0, 0),
+        cs.horzcat(-quat1[0], -quat1[1], -quat1[2], quat1[3], 0, 0, 0, 0),
+        cs.horzcat(quat1[7], quat1[6], -quat1[5], quat1[4], quat1[3], quat1[2], -quat1[1], quat1[0]),
+        cs.horzcat(-quat1[6], quat1[7], quat1[4], quat1[5], -quat1[2], quat1[3], quat1[0], quat1[1]),
+        cs.horzcat(quat1[5], -quat1[4], quat1[7], quat1[6], quat1[1], -quat1[0], quat1[3], quat1[2]),
+        cs.horzcat(-quat1[4], -quat1[5], -quat1[6], quat1[7], -quat1[0], -quat1[1], -quat1[2], quat1[3]))])
+    rpy = [5.0 * (np.pi / 180.0), 0.0, 0.0]
+    xyz = [0.5, 0.0, 0.5]
+    Q_des = numpy_geom.dual_quaternion_revolute(xyz, rpy, [1, 0, 0], 0.0)
+    Q_id = numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0)
+    if which == "Q_dist1":
+        expr = dual_quaternion_product(Q_fk(q), dual_quaternion_conj(Q_des)) - Q_id
+    else:
+        Hm = dual_hamilton_operator_minus(Q_des)
+        Cconj = cs.diag([-1, -1, -1, 1, -1, -1, -1, 1])
+        expr = cs.mtimes(Hm, cs.mtimes(Cconj, Q_des - Q_fk(q)))
+    dist = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=10.0,
+                                 priority=301)
+    q_min, q_max = np.array(fk["lower"]), np.array(fk["upper"])
+    max_speed = np.pi / 5
+    if for_pinv:
+        limits = [cc.SetConstraint(label="limit_q_" + str(i), expression=q[i], set_min=q_min[i], set_max=q_max[i],
+                                   priority=i) for i in range(6)]
+        cn = [dist] + limits
+    else:
+        cn = [dist,
+              cc.SetConstraint(label="Joint_Limits", expression=q, set_min=q_min, set_max=q_max),
+              cc.VelocitySetConstraint(label="Joint_speed_limits", expression=q,
+                                       set_min=-cs.vertcat([max_speed] * 6), set_max=cs.vertcat([max_speed] * 6))]
+    return cc.SkillSpecification(label=which, time_var=t, robot_var=q, robot_vel_var=dq, constraints=cn)

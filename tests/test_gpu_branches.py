@@ -336,3 +336,24 @@ def test_all_joint_limits_as_sets_64_modes(ur5_fk, kernel, monkeypatch):
     ctrl = _check(spec, None, Q, min_modes=10)
     assert ctrl.n_modes == 64
     assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
+
+
+@pytest.mark.parametrize("force_dynamic", [False, True])
+def test_tall_first_equality_is_processed_twice(ur5_fk, monkeypatch, force_dynamic):
+    """First EqualityConstraint with more rows than joints (8 x 6): pinv takes the Gram branch
+    (pseudo_inverse.py:97-100) and the double processing (:317-326, :382-396) projects through
+    [J]: N = lam (J'J + lam I)^-1.  A lower-priority task then projects through [J; J]."""
+    if force_dynamic:
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    T = ur5_fk["T_fk"](q)
+    frame = cc.EqualityConstraint("frame", cs.vertcat(T[:3, 3] - np.array([0.4, 0.1, 0.4]),
+                                                      T[:3, 0] - np.array([0.0, 1.0, 0.0]),
+                                                      T[:2, 1] - np.array([1.0, 0.0])), gain=4.0, priority=0)
+    rest = cc.EqualityConstraint("rest", q - np.array([0.0, -1.2, 1.0, -1.0, 0.3, 0.0]), gain=0.3, priority=1)
+    for cons in ([frame], [frame, rest]):
+        spec = cc.SkillSpecification("tall", t, q, constraints=cons)
+        Q, _ = skills.synthetic_inputs(ur5_fk, 300, seed=6)
+        ctrl = _check(spec, {"damping_factor": 1e-4}, 0.3 * Q, tol=1e-8)
+        assert (ctrl.kernel_name == "dynamic") == force_dynamic

@@ -11,7 +11,7 @@ import pytest
 import casclik_amd as cc
 from casclik_amd import skills
 from casclik_amd import sym as cs
-from extern_skills import double_pendulum_skill, mixed_frame_skill
+from extern_skills import double_pendulum_skill, mixed_frame_skill, dual_quaternion_skill
 from tolerances import PINV_RTOL, QP_RTOL
 
 pytestmark = pytest.mark.gpu
@@ -150,3 +150,54 @@ def test_generated_constraints_need_the_instantiated_kernel(monkeypatch):
     rc = lib.clik_pinv_solve_batch(h, 64, None, q.data_ptr(), None, None, dq.data_ptr(), None, mode.data_ptr(), None)
     assert rc == -2 and b"code-generated" in lib.clik_last_error()
     lib.clik_pinv_destroy(h)
+
+
+@pytest.mark.parametrize("which", ["Q_dist1", "Q_dist2"])
+def test_dual_quaternion_pose_error_reactive_qp(ur5_fk, which):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 16-18, 24: the dual-quaternion pose
+    errors (8 rows built from Q_fk(q), generated code) with joint limits and the speed limit through
+    ReactiveQPController, and the notebook's loop (cell 39: solve -> clamp -> Euler) as a rollout."""
+    from oracle import clik_oracle
+    spec = dual_quaternion_skill(ur5_fk, which)
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    assert ctrl.kernel_name.startswith("jit_")
+    rng = np.random.default_rng(8)
+    home = np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0])
+    Q = home + rng.uniform(-1.0, 1.0, size=(512, 6))
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q)
+    rdq, _, rsl, rst = clik_oracle.qp_solve_batch(spec, 0.0, Q)
+    assert np.array_equal(status, rst) and (rst == 0).all()
+    assert _rel(dq, rdq).max() < QP_RTOL and _rel(slack, rsl).max() < QP_RTOL
+    assert np.abs(dq).max() <= np.pi / 5 + 1e-9
+    # 100 ticks of the simulation loop from UR5_home
+    dt, n_ticks, vmax = 0.01, 100, np.pi / 5
+    ts = dt * np.arange(n_ticks)
+    q0 = np.stack([home, home + 0.2])
+    qf, dq_last, _, st = ctrl.rollout_batch(ts, q0, dt=dt, max_speed=vmax)
+    q = q0.copy()
+    for k in range(n_ticks):
+        rdq, _, _, rst = clik_oracle.qp_solve_batch(spec, ts[k], q)
+        q = q + np.clip(rdq, -vmax, vmax) * dt
+    assert (st == 0).all() and np.abs(qf - q).max() < 1e-7
+
+
+def test_dual_quaternion_pose_error_pseudo_inverse(ur5_fk):
+    """The comparison notebook's pinv skill (cells 37-38): six 1-D joint-limit sets (64 modes) in front of
+    the 8-row dual-quaternion error, which is the first EqualityConstraint and TALL (8 rows, 6 joints): its
+    double processing (pseudo_inverse.py:317-326, :382-396) runs in the Gram form."""
+    from oracle import clik_oracle
+    spec = dual_quaternion_skill(ur5_fk, "Q_dist2", for_pinv=True)
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    assert ctrl.kernel_name.startswith("jit_")
+    rng = np.random.default_rng(9)
+    home = np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0])
+    Q = home + rng.uniform(-1.0, 1.0, size=(1024, 6))
+    Q[::7, 2] = rng.choice([-1.0, 1.0], size=Q[::7].shape[0]) * rng.uniform(3.0, 3.4, size=Q[::7].shape[0])  # elbow limit
+    dq, _, mode = ctrl.solve_batch(0.0, Q)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q)
+    assert np.array_equal(mode, rmode)
+    assert len(np.unique(mode)) >= 2
+    assert _rel(dq, ref).max() < PINV_RTOL, _rel(dq, ref).max()

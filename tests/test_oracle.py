@@ -319,3 +319,30 @@ def test_oracle_reproduces_golden(iiwa_fk, ur5_fk):
     dq, _, slack, status = orc.qp_solve_batch(skills.qp_skill(iiwa_fk), 0.0, g["iiwa_qp_Q"], Y=g["iiwa_qp_Y"])
     assert (status == 0).all()
     assert _rel(dq, g["iiwa_qp_dq"]).max() < 1e-11 and _rel(slack, g["iiwa_qp_slack"]).max() < 1e-11
+
+
+def test_dual_quaternion_fk_matches_the_notebook_outputs(ur5_fk):
+    """Known answers the reference notebooks print for urdf2casadi's dual-quaternion kinematics
+    (ur5_dual_quaternion_comparison_of_controllers.ipynb cell 7: Q_fk(UR5_home); cell 33:
+    dual_quaternion_revolute of the desired frame and the identity) - they pin layout, sign and the
+    1/2 t (x) r convention of casclik_amd/geom.py - and agreement with the matrix kinematics."""
+    from casclik_amd import numpy_geom
+    home = [0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0]
+    Q0 = ur5_fk["dual_quaternion_fk"](home).toarray().ravel()
+    printed = np.array([-0.707107, -3.46237e-12, -3.46237e-12, 0.707107, -3.40946e-13, -0.28624, 0.421616, 3.21923e-13])
+    assert np.abs(Q0 - printed).max() < 5e-7                      # printed with 6 significant digits
+    T0 = numpy_geom.dual_quaternion_to_transformation_matrix(Q0)
+    assert abs(np.linalg.norm(T0[:3, 3]) - 1.0192) < 5e-5         # "Distance to UR5_pome pos: 1.0192"
+    assert np.allclose(numpy_geom.dual_quaternion_revolute([0.2, 0.2, 0.75], [0.0, 0.0, 0.0], [1, 0, 0], 0.0),
+                       [0.0, 0.0, 0.0, 1.0, 0.1, 0.1, 0.375, 0.0], atol=1e-15)
+    assert np.allclose(numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0),
+                       [0, 0, 0, 1, 0, 0, 0, 0], atol=0)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        qq = rng.uniform(-3.0, 3.0, 6)
+        Q = ur5_fk["dual_quaternion_fk"](qq).toarray().ravel()
+        assert abs(Q[:4].dot(Q[:4]) - 1.0) < 1e-14 and abs(Q[:4].dot(Q[4:])) < 1e-14       # unit dual quaternion
+        assert np.abs(numpy_geom.dual_quaternion_to_transformation_matrix(Q) - ur5_fk["T_fk"](qq).toarray()).max() < 1e-14
+        Qi = numpy_geom.dual_quaternion_inv(Q)
+        assert np.abs(numpy_geom.dual_quaternion_product(Q, Qi) - [0, 0, 0, 1, 0, 0, 0, 0]).max() < 1e-14
+        assert np.abs(numpy_geom.dual_quaternion_to_pos(Q) - ur5_fk["T_fk"](qq).toarray()[:3, 3]).max() < 1e-14
