@@ -100,20 +100,25 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
     // bounds stay in LDS (read once per iteration in the selection scan): keeping
     // them in registers next to the factor spills to scratch
     uint32_t W = softeq, up = 0u, eq = 0u;
-    // violations are measured relative to max(1, |bound|) of the bound in question (a one-sided
-    // SetConstraint carries the reference's default 1e10 on its other side, constraints.py:199-206:
-    // a common scale per row would hide the violation of the real bound)
-    double c[NC], isl[NC], ish[NC];
+    // A row counts as violated when it misses a bound by more than kVtol * max(1, |that bound|): relative to
+    // the bound in question, not to the row (a one-sided SetConstraint carries the reference's default 1e10
+    // on its other side, constraints.py:199-206 - a common scale would hide the violation of the real
+    // bound).  The scan works with the excess over that tolerance; the scales are recomputed from the
+    // bounds it reads anyway (two more instructions per row, no registers).
+    constexpr double kVtol = 1e-11;
+    auto excess = [](const double lbi, const double ubi, const double cv, const double tol, double& xlo,
+                     double& xhi) __attribute__((always_inline)) {
+        xlo = fma(-tol, fmax(1.0, fabs(lbi)), lbi - cv);
+        xhi = fma(-tol, fmax(1.0, fabs(ubi)), cv - ubi);
+    };
+    double c[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         nu[i] = 0.0;
         c[i] = 0.0;
-        isl[i] = ish[i] = 1.0;
         if (EXACT || i < nc) {
             const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
             if (!(ubi - lbi > 0.0)) eq |= 1u << i;
-            isl[i] = 1.0 / fmax(1.0, fabs(lbi));
-            ish[i] = 1.0 / fmax(1.0, fabs(ubi));
         }
     }
     int status = 0;
@@ -151,8 +156,9 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             if (EXACT || i < nc) {
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                 const double c0 = (c0s != nullptr) ? c0s[i * WAVE + lane] : 0.0;
-                const double vlo = (lbi - c0) * isl[i], vhi = (c0 - ubi) * ish[i];
-                if (fmax(vlo, vhi) > 1e-11) {
+                double vlo, vhi;
+                excess(lbi, ubi, c0, kVtol, vlo, vhi);
+                if (fmax(vlo, vhi) > 0.0) {
                     W0 |= 1u << i;
                     if (vhi > vlo) up0 |= 1u << i;
                     ++cnt;
@@ -228,8 +234,9 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                 for (int i = 0; i < NC; ++i) {
                     if (EXACT || i < nc) {
                         const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                        const double vlo = (lbi - cc[i]) * isl[i], vhi = (cc[i] - ubi) * ish[i];
-                        if (pd && !((W0 >> i) & 1u) && fmax(vlo, vhi) > 1e-11) {
+                        double vlo, vhi;
+                        excess(lbi, ubi, cc[i], kVtol, vlo, vhi);
+                        if (pd && !((W0 >> i) & 1u) && fmax(vlo, vhi) > 0.0) {
                             add |= 1u << i;
                             if (vhi > vlo) addup |= 1u << i;
                         }
@@ -305,16 +312,17 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         //     exec-mask bookkeeping on the scalar unit, which a lone wave pays in full)
         {
             const bool sel = need_p && !done;
-            double best = 1e-11, bpn = bp;
+            double best = 0.0, bpn = bp;
             int pick = -1;
             bool pick_up = false;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 if (EXACT || i < nc) {
                     const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                    const double vlo = (lbi - c[i]) * isl[i], vhi = (c[i] - ubi) * ish[i];
+                    double vlo, vhi;
+                    excess(lbi, ubi, c[i], kVtol, vlo, vhi);
                     double v = fmax(vlo, vhi);
-                    v += (((eq >> i) & 1u) && v > 1e-11) ? 1e30 : 0.0;      // equalities take precedence
+                    v += (((eq >> i) & 1u) && v > 0.0) ? 1e30 : 0.0;        // equalities take precedence
                     const bool better = !((W >> i) & 1u) && v > best;
                     const bool upper = vhi > vlo;
                     best = better ? v : best;
@@ -415,10 +423,12 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         for (int i = 0; i < NC; ++i) {
             if (EXACT || i < nc) {
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                worst = fmax(worst, fmax((lbi - cc[i]) * isl[i], (cc[i] - ubi) * ish[i]));
+                double vlo, vhi;
+                excess(lbi, ubi, cc[i], 1e-7, vlo, vhi);
+                worst = fmax(worst, fmax(vlo, vhi));
             }
         }
-        if (status == 0 && !(worst <= 1e-7)) status = 2;      // (a net for garbage, not a precision test)
+        if (status == 0 && !(worst <= 0.0)) status = 2;       // (a net for garbage, not a precision test)
 #ifdef CLIK_QP_DIAG
         if (blockIdx.x == 0) {
             double* o = g_qp_dbg + lane * 40;
@@ -426,7 +436,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             for (int i = 0; i < NC && i < 12; ++i) { o[i] = cc[i]; o[12 + i] = nu[i]; }
             o[24] = worst; o[25] = (double)W; o[26] = (double)up; o[27] = (double)status;
         }
-        g_qp_diag_cold |= (worst > 1e-7) ? 8 : 0;
+        g_qp_diag_cold |= (worst > 0.0) ? 8 : 0;
         g_qp_diag_cold |= 16;       // the check ran
 #endif
     }
@@ -447,7 +457,13 @@ struct QpPlanS {
     int  ns;                               // slack variables (= soft rows, in row order)
     int  slack_base[SHAPE_MAX_TASKS];      // first slack of a soft task
     bool folded[SHAPE_MAX_TASKS];          // soft equality: eliminated into P, g
-    int  row_base[SHAPE_MAX_TASKS];        // first active-set row of a task that is not folded
+    // active-set row of output i of a task that is not folded, and whether it shares that row with an
+    // earlier constraint: two hard joint-space rows on the same state (joint limits  lb <= dq_i <= ub  from a
+    // SetConstraint on q and the speed limit  -v <= dq_i <= v  of a VelocitySetConstraint on q - the pair
+    // every UR5 notebook stacks, e.g. ur5_dual_quaternion_vs_transformation_matrix.ipynb cell 14) are ONE
+    // row  max(lb) <= dq_i <= min(ub): same feasible set, same minimiser, half the active-set size.
+    int  row_of[SHAPE_MAX_TASKS][CLIK_MAX_M];
+    bool merged[SHAPE_MAX_TASKS][CLIK_MAX_M];
 };
 
 constexpr QpPlanS make_qp_plan(const ShapeDesc& sd)
@@ -459,9 +475,23 @@ constexpr QpPlanS make_qp_plan(const ShapeDesc& sd)
         p.slack_base[ti] = p.ns;
         if (soft) p.ns += sd.m[ti];
         p.folded[ti] = soft && (cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ);
-        p.row_base[ti] = p.nr;
         if (!p.folded[ti]) {
+            const bool box = !soft && shape_unit(sd, ti) && (cls == CLIK_CLS_SET || cls == CLIK_CLS_VELSET);
             for (int i = 0; i < sd.m[ti]; ++i) {
+                int same = -1;
+                if (box)
+                    for (int r = 0; r < p.nr && r < CLIK_MAX_QPROWS && same < 0; ++r) {
+                        const int t2 = p.row_task[r];
+                        const bool box2 = sd.soft[t2] == 0 && shape_unit(sd, t2) &&
+                                          (sd.cls[t2] == CLIK_CLS_SET || sd.cls[t2] == CLIK_CLS_VELSET);
+                        if (box2 && sd.ucol[t2][p.row_local[r]] == sd.ucol[ti][i]) same = r;
+                    }
+                if (same >= 0) {
+                    p.row_of[ti][i] = same;
+                    p.merged[ti][i] = true;
+                    continue;
+                }
+                p.row_of[ti][i] = p.nr;
                 if (p.nr < CLIK_MAX_QPROWS) {
                     p.row_task[p.nr] = ti;
                     p.row_local[p.nr] = i;
@@ -578,12 +608,20 @@ __device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const
                 }
             });
         } else {
-            constexpr int rb = P.row_base[TI];
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                slots[(LY::O_LB + rb + i) * WAVE + lane] = lo[i];
-                slots[(LY::O_UB + rb + i) * WAVE + lane] = hi[i];
-            }
+            static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int row = P.row_of[TI][i];
+                double* lbp = slots + (LY::O_LB + row) * WAVE + lane;
+                double* ubp = slots + (LY::O_UB + row) * WAVE + lane;
+                if constexpr (P.merged[TI][i]) {
+                    // (the row was written by the earlier constraint of the pair: tasks are gathered in order)
+                    *lbp = fmax(*lbp, lo[i]);
+                    *ubp = fmin(*ubp, hi[i]);
+                } else {
+                    *lbp = lo[i];
+                    *ubp = hi[i];
+                }
+            });
         }
         qp_gather_s<SD, TI + 1>(S, T, tk, tc, z, ys, lane, Pm, g, slots);
     }

@@ -68,14 +68,29 @@ def dual_quaternion_skill(fk, which="Q_dist2", for_pinv=False):
     xyz = [0.5, 0.0, 0.5]
     Q_des = numpy_geom.dual_quaternion_revolute(xyz, rpy, [1, 0, 0], 0.0)
     Q_id = numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0)
-    if which == "Q_dist1":
+    gain, prio = 10.0, 301
+    if which in ("cart_dist", "quat_dist"):
+        # ur5_dual_quaternion_comparison_of_controllers.ipynb cell 12: position read off the dual
+        # quaternion, and the "improper" quaternion distance to p_des
+        p1, p2 = cs.SX.sym("p1", 4), cs.SX.sym("p2", 4)
+        quaternion_product = cs.Function("quatprod", [p1, p2], [casadi_geom.quaternion_product(p1, p2)])
+        quaternion_conj = cs.Function("quatconj", [p1], [casadi_geom.quaternion_conj(p1)])
+        p_des_a = np.hstack([np.array([0.5, 0.5, 0.5]), 0.0])
+        Q_r = Q_fk(q)[:4]
+        Q_d = Q_fk(q)[4:8]
+        if which == "cart_dist":
+            expr = 2 * quaternion_product(Q_d, quaternion_conj(Q_r))[:3]
+        else:
+            expr = Q_d[:3] - 0.5 * quaternion_product(p_des_a, Q_r)[:3]
+        gain, prio = 1.0, 300
+    elif which == "Q_dist1":
         expr = dual_quaternion_product(Q_fk(q), dual_quaternion_conj(Q_des)) - Q_id
     else:
         Hm = dual_hamilton_operator_minus(Q_des)
         Cconj = cs.diag([-1, -1, -1, 1, -1, -1, -1, 1])
         expr = cs.mtimes(Hm, cs.mtimes(Cconj, Q_des - Q_fk(q)))
-    dist = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=10.0,
-                                 priority=301)
+    dist = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=gain,
+                                 priority=prio)
     q_min, q_max = np.array(fk["lower"]), np.array(fk["upper"])
     max_speed = np.pi / 5
     if for_pinv:

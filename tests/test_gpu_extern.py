@@ -152,7 +152,7 @@ def test_generated_constraints_need_the_instantiated_kernel(monkeypatch):
     lib.clik_pinv_destroy(h)
 
 
-@pytest.mark.parametrize("which", ["Q_dist1", "Q_dist2"])
+@pytest.mark.parametrize("which", ["Q_dist1", "Q_dist2", "cart_dist", "quat_dist"])
 def test_dual_quaternion_pose_error_reactive_qp(ur5_fk, which):
     """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 16-18, 24: the dual-quaternion pose
     errors (8 rows built from Q_fk(q), generated code) with joint limits and the speed limit through
@@ -183,12 +183,13 @@ def test_dual_quaternion_pose_error_reactive_qp(ur5_fk, which):
     assert (st == 0).all() and np.abs(qf - q).max() < 1e-7
 
 
-def test_dual_quaternion_pose_error_pseudo_inverse(ur5_fk):
+@pytest.mark.parametrize("which", ["Q_dist2", "quat_dist"])
+def test_dual_quaternion_pose_error_pseudo_inverse(ur5_fk, which):
     """The comparison notebook's pinv skill (cells 37-38): six 1-D joint-limit sets (64 modes) in front of
     the 8-row dual-quaternion error, which is the first EqualityConstraint and TALL (8 rows, 6 joints): its
     double processing (pseudo_inverse.py:317-326, :382-396) runs in the Gram form."""
     from oracle import clik_oracle
-    spec = dual_quaternion_skill(ur5_fk, "Q_dist2", for_pinv=True)
+    spec = dual_quaternion_skill(ur5_fk, which, for_pinv=True)
     ctrl = cc.PseudoInverseController(skill_spec=spec)
     ctrl.setup_problem_functions()
     assert ctrl.kernel_name.startswith("jit_")
