@@ -100,25 +100,40 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
     // bounds stay in LDS (read once per iteration in the selection scan): keeping
     // them in registers next to the factor spills to scratch
     uint32_t W = softeq, up = 0u, eq = 0u;
-    // A row counts as violated when it misses a bound by more than kVtol * max(1, |that bound|): relative to
-    // the bound in question, not to the row (a one-sided SetConstraint carries the reference's default 1e10
-    // on its other side, constraints.py:199-206 - a common scale would hide the violation of the real
-    // bound).  The scan works with the excess over that tolerance; the scales are recomputed from the
-    // bounds it reads anyway (two more instructions per row, no registers).
+    // Violations are measured relative to max(1, |bound|) of the bound in question, not of the row (a
+    // one-sided SetConstraint carries the reference's default 1e10 on its other side, constraints.py:199-206:
+    // a common scale per row would hide the violation of the real bound).  Up to 8 rows the two scales per
+    // row live in registers; larger working sets need those registers for the factor and recompute the
+    // scale from the bound they read anyway (v_rcp_f64: ranking and a 1e-11 threshold do not need more).
     constexpr double kVtol = 1e-11;
-    auto excess = [](const double lbi, const double ubi, const double cv, const double tol, double& xlo,
-                     double& xhi) __attribute__((always_inline)) {
-        xlo = fma(-tol, fmax(1.0, fabs(lbi)), lbi - cv);
-        xhi = fma(-tol, fmax(1.0, fabs(ubi)), cv - ubi);
+#ifndef CLIK_QP_SCALE_REGS_MAX
+#define CLIK_QP_SCALE_REGS_MAX 8
+#endif
+    constexpr bool kScaleRegs = NC <= CLIK_QP_SCALE_REGS_MAX;
+    double isl[kScaleRegs ? NC : 1], ish[kScaleRegs ? NC : 1];
+    auto excess = [&](const int i, const double lbi, const double ubi, const double cv, double& xlo,
+                      double& xhi) __attribute__((always_inline)) {
+        if constexpr (kScaleRegs) {
+            xlo = (lbi - cv) * isl[i];
+            xhi = (cv - ubi) * ish[i];
+        } else {
+            xlo = (lbi - cv) * __builtin_amdgcn_rcp(fmax(1.0, fabs(lbi)));
+            xhi = (cv - ubi) * __builtin_amdgcn_rcp(fmax(1.0, fabs(ubi)));
+        }
     };
     double c[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         nu[i] = 0.0;
         c[i] = 0.0;
+        if constexpr (kScaleRegs) isl[i] = ish[i] = 1.0;
         if (EXACT || i < nc) {
             const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
             if (!(ubi - lbi > 0.0)) eq |= 1u << i;
+            if constexpr (kScaleRegs) {
+                isl[i] = 1.0 / fmax(1.0, fabs(lbi));
+                ish[i] = 1.0 / fmax(1.0, fabs(ubi));
+            }
         }
     }
     int status = 0;
@@ -157,8 +172,8 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                 const double c0 = (c0s != nullptr) ? c0s[i * WAVE + lane] : 0.0;
                 double vlo, vhi;
-                excess(lbi, ubi, c0, kVtol, vlo, vhi);
-                if (fmax(vlo, vhi) > 0.0) {
+                excess(i, lbi, ubi, c0, vlo, vhi);
+                if (fmax(vlo, vhi) > kVtol) {
                     W0 |= 1u << i;
                     if (vhi > vlo) up0 |= 1u << i;
                     ++cnt;
@@ -235,8 +250,8 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                     if (EXACT || i < nc) {
                         const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                         double vlo, vhi;
-                        excess(lbi, ubi, cc[i], kVtol, vlo, vhi);
-                        if (pd && !((W0 >> i) & 1u) && fmax(vlo, vhi) > 0.0) {
+                        excess(i, lbi, ubi, cc[i], vlo, vhi);
+                        if (pd && !((W0 >> i) & 1u) && fmax(vlo, vhi) > kVtol) {
                             add |= 1u << i;
                             if (vhi > vlo) addup |= 1u << i;
                         }
@@ -312,7 +327,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         //     exec-mask bookkeeping on the scalar unit, which a lone wave pays in full)
         {
             const bool sel = need_p && !done;
-            double best = 0.0, bpn = bp;
+            double best = kVtol, bpn = bp;
             int pick = -1;
             bool pick_up = false;
 #pragma unroll
@@ -320,9 +335,9 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                 if (EXACT || i < nc) {
                     const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                     double vlo, vhi;
-                    excess(lbi, ubi, c[i], kVtol, vlo, vhi);
+                    excess(i, lbi, ubi, c[i], vlo, vhi);
                     double v = fmax(vlo, vhi);
-                    v += (((eq >> i) & 1u) && v > 0.0) ? 1e30 : 0.0;        // equalities take precedence
+                    v += (((eq >> i) & 1u) && v > kVtol) ? 1e30 : 0.0;      // equalities take precedence
                     const bool better = !((W >> i) & 1u) && v > best;
                     const bool upper = vhi > vlo;
                     best = better ? v : best;
@@ -424,11 +439,11 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             if (EXACT || i < nc) {
                 const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                 double vlo, vhi;
-                excess(lbi, ubi, cc[i], 1e-7, vlo, vhi);
+                excess(i, lbi, ubi, cc[i], vlo, vhi);
                 worst = fmax(worst, fmax(vlo, vhi));
             }
         }
-        if (status == 0 && !(worst <= 0.0)) status = 2;       // (a net for garbage, not a precision test)
+        if (status == 0 && !(worst <= 1e-7)) status = 2;      // (a net for garbage, not a precision test)
 #ifdef CLIK_QP_DIAG
         if (blockIdx.x == 0) {
             double* o = g_qp_dbg + lane * 40;
@@ -436,7 +451,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             for (int i = 0; i < NC && i < 12; ++i) { o[i] = cc[i]; o[12 + i] = nu[i]; }
             o[24] = worst; o[25] = (double)W; o[26] = (double)up; o[27] = (double)status;
         }
-        g_qp_diag_cold |= (worst > 0.0) ? 8 : 0;
+        g_qp_diag_cold |= (worst > 1e-7) ? 8 : 0;
         g_qp_diag_cold |= 16;       // the check ran
 #endif
     }
