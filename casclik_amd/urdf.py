@@ -198,23 +198,66 @@ def load_chain(filename, root, tip):
     return Chain(joints, root, tip)
 
 
+def chain_from_denavit_hartenberg(joint_angles, link_lengths, link_offsets, link_twists, joint_names=None,
+                                  upper_limits=None, lower_limits=None):
+    """Serial chain from a classic (distal) Denavit-Hartenberg table,
+    ``T_i = Rot_z(theta_i) Trans_z(d_i) Trans_x(a_i) Rot_x(alpha_i)``: ``joint_angles[i]`` is ``"s"`` for an
+    actuated (symbolic) revolute joint or a fixed angle (call site: ur5_moe2016_example2.ipynb cell 2, the
+    classic DH table of the UR5).  The link transform behind joint i is the origin of joint i+1; the last one
+    becomes a fixed joint."""
+    n = len(link_lengths)
+    if not (len(joint_angles) == len(link_offsets) == len(link_twists) == n):
+        raise ValueError("Denavit-Hartenberg lists must have equal length")
+    joints = []
+    R_prev, p_prev = np.eye(3), np.zeros(3)          # fixed transform accumulated in front of the next joint
+    k = 0
+    for i in range(n):
+        ang = joint_angles[i]
+        ca, sa = math.cos(link_twists[i]), math.sin(link_twists[i])
+        R_link = np.array([[1.0, 0.0, 0.0], [0.0, ca, -sa], [0.0, sa, ca]])
+        p_link = np.array([float(link_lengths[i]), 0.0, float(link_offsets[i])])
+        if isinstance(ang, str):
+            name = joint_names[k] if joint_names is not None else "joint_%d" % k
+            lo = float(lower_limits[k]) if lower_limits is not None else -math.inf
+            hi = float(upper_limits[k]) if upper_limits is not None else math.inf
+            joints.append(Joint(name, JOINT_REVOLUTE, R_prev, p_prev, [0.0, 0.0, 1.0], lo, hi, None))
+            k += 1
+            R_prev, p_prev = R_link, p_link
+        else:
+            Rz = axis_angle_matrix(np.array([0.0, 0.0, 1.0]), float(ang))
+            # fold  [R_prev p_prev] Rz [R_link p_link]  into the pending fixed transform
+            p_prev = p_prev + R_prev.dot(Rz).dot(p_link)
+            R_prev = R_prev.dot(Rz).dot(R_link)
+    joints.append(Joint("dh_tip", JOINT_FIXED, R_prev, p_prev, [1.0, 0.0, 0.0], None, None, None))
+    return Chain(joints, "dh_base", "dh_tip")
+
+
+def _fk_dict(chain):
+    act = chain.actuated
+    q = _sym.MX.sym("q", chain.n_actuated)
+    T = chain(q)
+    from . import geom
+    return {
+        "dual_quaternion_fk": _sym.Function("dual_quaternion_fk", [q], [geom.dual_quaternion_fk(chain, q)]),
+        "joint_names": [j.name for j in act],
+        "upper": [j.upper for j in act],
+        "lower": [j.lower for j in act],
+        "velocity": [j.velocity for j in act],
+        "q": q,
+        "T_fk": _sym.Function("T_fk", [q], [T]),
+        "chain": chain,
+    }
+
+
 class converter(object):
     """Namespace mirroring ``urdf2casadi.converter``."""
 
     @staticmethod
+    def from_denavit_hartenberg(joint_angles, link_lengths, link_offsets, link_twists, joint_names=None,
+                                upper_limits=None, lower_limits=None):
+        return _fk_dict(chain_from_denavit_hartenberg(joint_angles, link_lengths, link_offsets, link_twists,
+                                                      joint_names, upper_limits, lower_limits))
+
+    @staticmethod
     def from_file(root, tip, filename):
-        chain = load_chain(filename, root, tip)
-        act = chain.actuated
-        q = _sym.MX.sym("q", chain.n_actuated)
-        T = chain(q)
-        from . import geom
-        return {
-            "dual_quaternion_fk": _sym.Function("dual_quaternion_fk", [q], [geom.dual_quaternion_fk(chain, q)]),
-            "joint_names": [j.name for j in act],
-            "upper": [j.upper for j in act],
-            "lower": [j.lower for j in act],
-            "velocity": [j.velocity for j in act],
-            "q": q,
-            "T_fk": _sym.Function("T_fk", [q], [T]),
-            "chain": chain,
-        }
+        return _fk_dict(load_chain(filename, root, tip))

@@ -272,3 +272,71 @@ def test_rollout_with_time_trajectory(ur5_fk):
         qh = qh + dq * dt
     q_dev, dq_dev, _ = ctrl.rollout_batch(times, Q, dt=dt)
     assert np.abs(q_dev - qh).max() < 1e-10 and np.abs(dq_dev - dq).max() < 1e-9
+
+
+@pytest.mark.parametrize("multidim", [False, True])
+def test_moe2016_box_skill_on_the_denavit_hartenberg_chain(ur5_fk, multidim):
+    """ur5_moe2016_example2.ipynb cells 2-11 as written: the UR5 from its classic DH table
+    (converter.from_denavit_hartenberg), wall avoidance as three 1-D sets (8 modes) or one 3-D set
+    (multidim_sets), the moving tracking target, through both controllers; the notebook's loop
+    (:537-545) as an on-device rollout from its UR5_home."""
+    from oracle import clik_oracle
+    from casclik_amd import converter
+    pi = np.pi
+    fk = converter.from_denavit_hartenberg(
+        joint_angles=["s" for _ in range(6)], link_lengths=[0., -0.425, -0.392, 0., 0., 0.],
+        link_offsets=[0.089, 0., 0., 0.109, 0.095, 0.082], link_twists=[pi / 2, 0., 0., pi / 2, -pi / 2, 0.],
+        joint_names=ur5_fk["joint_names"], upper_limits=ur5_fk["upper"], lower_limits=ur5_fk["lower"])
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    T_fk = fk["T_fk"]
+    p_fk = cs.Function("p_fk", [t, q], [T_fk(q)[:3, 3]])
+    x_min, x_max, y_min, y_max, z_min, z_max = 0.1, 0.6, -0.5, 0.4, -0.3, 0.25
+    omega = 0.1
+    path_des = cs.vertcat(0.5 * cs.sin(omega * t) * cs.sin(omega * t) + 0.2,
+                          0.5 * cs.cos(omega * t) + 0.25 * cs.sin(omega * t),
+                          0.5 * cs.sin(omega * t) * cs.cos(omega * t) + 0.1)
+    path_cnstr = cc.EqualityConstraint(label="move_point2", expression=p_fk(t, q) - path_des, priority=10,
+                                       constraint_type="soft", gain=0.15)
+    if multidim:
+        cons = [cc.SetConstraint(label="colav_box", expression=p_fk(t, q), set_min=np.array([x_min, y_min, z_min]),
+                                 set_max=np.array([x_max, y_max, z_max]), priority=7, constraint_type="hard", gain=5e2),
+                path_cnstr]
+        opts = {"multidim_sets": True}
+    else:
+        cons = [cc.SetConstraint(label="colav_x", expression=p_fk(t, q)[0], set_min=x_min, set_max=x_max, priority=8,
+                                 constraint_type="hard", gain=5e2),
+                cc.SetConstraint(label="colav_y", expression=p_fk(t, q)[1], set_min=y_min, set_max=y_max, priority=7,
+                                 constraint_type="hard", gain=5e2),
+                cc.SetConstraint(label="colav_z", expression=p_fk(t, q)[2], set_min=z_min, set_max=z_max, priority=9,
+                                 constraint_type="hard", gain=5e2),
+                path_cnstr]
+        opts = None
+    spec = cc.SkillSpecification(label="box_move", time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons)
+    assert [c.label for c in spec.constraints][:2] == (["colav_box", "move_point2"] if multidim else ["colav_y", "colav_x"])
+    home = np.array([-(50.0 / 180.0) * pi, -(160.0 / 180.0) * pi, -(110.0 / 180.0) * pi, -(90.0 / 180.0) * pi,
+                     -(90.0 / 180.0) * pi, 0.0])
+    rng = np.random.default_rng(12)
+    Q = home + rng.uniform(-0.5, 0.5, size=(400, 6))
+    ctrl = _controller(spec, opts)
+    for tval in (0.0, 11.0):
+        dqs, _, mode = ctrl.solve_batch(tval, Q)
+        ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, tval, Q)
+        assert np.array_equal(mode, rmode) and len(np.unique(mode)) >= 2
+        assert _rel(dqs, ref).max() < PINV_RTOL
+    # the simulation loop of the notebook, 150 ticks from UR5_home
+    dt, vmax, n_ticks = 0.008, pi / 5, 150
+    ts = dt * np.arange(n_ticks)
+    q_dev, _, mode_dev = ctrl.rollout_batch(ts, home[None, :].repeat(2, axis=0), dt=dt, max_speed=vmax)
+    qh = home[None, :].copy()
+    for k in range(n_ticks):
+        r, rm = clik_oracle.pinv_solve_batch(spec, opts, ts[k], qh)
+        qh = qh + np.clip(r, -vmax, vmax) * dt
+    assert np.abs(q_dev[0] - qh[0]).max() < 1e-8 and mode_dev[0] == rm[0]
+    qp = cc.ReactiveQPController(skill_spec=spec)
+    qp.setup_problem_functions()
+    qp.setup_solver()
+    qdq, _, qsl, st = qp.solve_batch(3.0, Q)
+    rdq, _, rsl, rst = clik_oracle.qp_solve_batch(spec, 3.0, Q)
+    assert np.array_equal(st, rst)
+    ok = rst == 0
+    assert ok.sum() > 100 and _rel(qdq[ok], rdq[ok]).max() < 1e-8

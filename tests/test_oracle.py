@@ -346,3 +346,31 @@ def test_dual_quaternion_fk_matches_the_notebook_outputs(ur5_fk):
         Qi = numpy_geom.dual_quaternion_inv(Q)
         assert np.abs(numpy_geom.dual_quaternion_product(Q, Qi) - [0, 0, 0, 1, 0, 0, 0, 0]).max() < 1e-14
         assert np.abs(numpy_geom.dual_quaternion_to_pos(Q) - ur5_fk["T_fk"](qq).toarray()[:3, 3]).max() < 1e-14
+
+
+def test_denavit_hartenberg_chain_of_the_moe2016_notebook(ur5_fk):
+    """converter.from_denavit_hartenberg with the notebook's classic UR5 DH table
+    (ur5_moe2016_example2.ipynb cell 2).  Pins: the notebook starts "in the box" (cell 5: UR5_home, cell 7:
+    box limits) - true for the classic DH frames, false for the URDF frames at the same joint angles - and
+    the DH chain equals the URDF chain up to the UR5's known base rotation Rz(pi) and the rounding of the
+    table (3 decimals)."""
+    from casclik_amd import converter
+    pi = np.pi
+    fk = converter.from_denavit_hartenberg(
+        joint_angles=["s" for _ in range(6)], link_lengths=[0., -0.425, -0.392, 0., 0., 0.],
+        link_offsets=[0.089, 0., 0., 0.109, 0.095, 0.082], link_twists=[pi / 2, 0., 0., pi / 2, -pi / 2, 0.],
+        joint_names=ur5_fk["joint_names"], upper_limits=ur5_fk["upper"], lower_limits=ur5_fk["lower"])
+    assert fk["joint_names"] == ur5_fk["joint_names"] and fk["upper"] == ur5_fk["upper"]
+    home = np.array([-(50.0 / 180.0) * pi, -(160.0 / 180.0) * pi, -(110.0 / 180.0) * pi, -(90.0 / 180.0) * pi,
+                     -(90.0 / 180.0) * pi, 0.0])
+    p = fk["T_fk"](home).toarray()[:3, 3]
+    box_lo, box_hi = np.array([0.1, -0.5, -0.3]), np.array([0.6, 0.4, 0.25])
+    assert (p > box_lo).all() and (p < box_hi).all()
+    pu = ur5_fk["T_fk"](home).toarray()[:3, 3]
+    assert not ((pu > box_lo).all() and (pu < box_hi).all())
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        qq = rng.uniform(-3.0, 3.0, 6)
+        T, Tu = fk["T_fk"](qq).toarray(), ur5_fk["T_fk"](qq).toarray()
+        assert np.abs(T[:3, 3] - np.array([-1.0, -1.0, 1.0]) * Tu[:3, 3]).max() < 2e-3
+        assert abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-12
