@@ -5,6 +5,7 @@ import pytest
 
 import casclik_amd as cc
 from casclik_amd import skills
+from casclik_amd import sym as cs
 from tolerances import PINV_RTOL, PINV_RTOL_TIGHT
 
 pytestmark = pytest.mark.gpu
