@@ -317,13 +317,16 @@ def test_moe2016_box_skill_on_the_denavit_hartenberg_chain(ur5_fk, multidim):
     home = np.array([-(50.0 / 180.0) * pi, -(160.0 / 180.0) * pi, -(110.0 / 180.0) * pi, -(90.0 / 180.0) * pi,
                      -(90.0 / 180.0) * pi, 0.0])
     rng = np.random.default_rng(12)
-    Q = home + rng.uniform(-0.5, 0.5, size=(400, 6))
+    Q = home + rng.uniform(-1.0, 1.0, size=(400, 6))
     ctrl = _controller(spec, opts)
-    for tval in (0.0, 11.0):
+    seen = set()
+    for tval in (0.0, 25.0):
         dqs, _, mode = ctrl.solve_batch(tval, Q)
         ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, tval, Q)
-        assert np.array_equal(mode, rmode) and len(np.unique(mode)) >= 2
+        assert np.array_equal(mode, rmode)
         assert _rel(dqs, ref).max() < PINV_RTOL
+        seen |= set(mode.tolist())
+    assert len(seen) >= 2
     # the simulation loop of the notebook, 150 ticks from UR5_home
     dt, vmax, n_ticks = 0.008, pi / 5, 150
     ts = dt * np.arange(n_ticks)
