@@ -114,6 +114,48 @@ def quaternion_rpy(roll, pitch, yaw):
                      cr * cp * cy + sr * sp * sy])
 
 
+def _trig(v):
+    """(sin, cos) of a number or an expression."""
+    if isinstance(v, _sym.MX):
+        return _sym.sin(v), _sym.cos(v)
+    return math.sin(float(v)), math.cos(float(v))
+
+
+def dual_quaternion_rpy(rpy):
+    """Pure rotation Rz(yaw) Ry(pitch) Rx(roll); the angles may be expressions."""
+    a, sym = _entries(rpy, 3)
+    (sr, cr), (sp, cp), (sy, cy) = _trig(0.5 * a[0]), _trig(0.5 * a[1]), _trig(0.5 * a[2])
+    r = [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+         cr * cp * cy + sr * sp * sy]
+    return _pack(r + [0.0, 0.0, 0.0, 0.0], sym)
+
+
+def dual_quaternion_translation(xyz):
+    a, sym = _entries(xyz, 3)
+    return _pack([0.0, 0.0, 0.0, 1.0, 0.5 * a[0], 0.5 * a[1], 0.5 * a[2], 0.0], sym)
+
+
+def dual_quaternion_axis_translation(axis, ang):
+    a, s1 = _entries(axis, 3)
+    g, s2 = _entries(ang, 1)
+    return _pack([0.0, 0.0, 0.0, 1.0, 0.5 * a[0] * g[0], 0.5 * a[1] * g[0], 0.5 * a[2] * g[0], 0.0], s1 or s2)
+
+
+def dual_quaternion_axis_rotation(axis, ang):
+    a, s1 = _entries(axis, 3)
+    g, s2 = _entries(ang, 1)
+    sn, cn = _trig(0.5 * g[0])
+    return _pack([a[0] * sn, a[1] * sn, a[2] * sn, cn, 0.0, 0.0, 0.0, 0.0], s1 or s2)
+
+
+def T_rpy(displacement, roll, pitch, yaw):
+    """Homogeneous transform with translation ``displacement`` and rotation RPY."""
+    T = np.eye(4)
+    T[:3, :3] = rotation_rpy(roll, pitch, yaw)
+    T[:3, 3] = np.asarray(displacement, dtype=float).reshape(-1)
+    return T
+
+
 def rotation_rpy(roll, pitch, yaw):
     cr, sr = math.cos(roll), math.sin(roll)
     cp, sp = math.cos(pitch), math.sin(pitch)
@@ -226,6 +268,9 @@ _COMMON = dict(quaternion_product=quaternion_product, quaternion_conj=quaternion
                dual_quaternion_revolute=dual_quaternion_revolute,
                dual_quaternion_prismatic=dual_quaternion_prismatic,
                dual_quaternion_to_transformation_matrix=dual_quaternion_to_transformation_matrix,
-               quaternion_rpy=quaternion_rpy, rotation_rpy=rotation_rpy)
+               quaternion_rpy=quaternion_rpy, rotation_rpy=rotation_rpy, T_rpy=T_rpy,
+               dual_quaternion_rpy=dual_quaternion_rpy, dual_quaternion_translation=dual_quaternion_translation,
+               dual_quaternion_axis_translation=dual_quaternion_axis_translation,
+               dual_quaternion_axis_rotation=dual_quaternion_axis_rotation)
 casadi_geom = _Namespace("casadi_geom", **_COMMON)
 numpy_geom = _Namespace("numpy_geom", **_COMMON)

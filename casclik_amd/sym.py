@@ -1037,3 +1037,10 @@ def depends_on(expr, var):
         return any(rec(a) for a in s.args)
 
     return any(rec(s) for s in _as_array(expr).flat)
+
+
+def jacobian(expr, var):
+    """``cs.jacobian`` (reference use: constraints.py:67-73; ur5_moe2016_example2.ipynb cell 4):
+    symbolic m x n matrix of partial derivatives."""
+    from . import autodiff
+    return autodiff.jacobian(expr, var)

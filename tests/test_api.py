@@ -189,3 +189,31 @@ def test_controller_needs_the_hip_library_or_gpu():
         c.setup_problem_functions()
     with pytest.raises(RuntimeError, match="setup"):
         c.solve(0.0, np.zeros(7), input_var=np.zeros(7))
+
+
+def test_geometry_helpers_compose_like_the_joint_transforms():
+    """casadi_geom / numpy_geom look-alikes (urdf2casadi call surface of the dual-quaternion notebooks,
+    ur5_dual_quaternion_comparison_of_controllers.ipynb cell 4): the elementary dual quaternions compose to
+    the joint transforms, numbers and expressions agree, and cs.jacobian differentiates FK expressions."""
+    from casclik_amd import casadi_geom as g, numpy_geom as ng, skills
+    xyz, rpy, ax = [0.3, -0.2, 0.5], [0.4, -0.3, 1.1], np.array([0.0, 0.0, 1.0])
+    base = ng.dual_quaternion_revolute(xyz, rpy, [1, 0, 0], 0.0)
+    assert np.abs(ng.dual_quaternion_product(ng.dual_quaternion_translation(xyz), ng.dual_quaternion_rpy(rpy)) - base).max() < 1e-15
+    assert np.abs(ng.dual_quaternion_to_transformation_matrix(base) - ng.T_rpy(xyz, *rpy)).max() < 1e-15
+    assert np.abs(ng.dual_quaternion_product(base, ng.dual_quaternion_axis_rotation(ax, 0.7))
+                  - ng.dual_quaternion_revolute(xyz, rpy, ax, 0.7)).max() < 1e-15
+    assert np.abs(ng.dual_quaternion_product(base, ng.dual_quaternion_axis_translation(ax, 0.7))
+                  - ng.dual_quaternion_prismatic(xyz, rpy, ax, 0.7)).max() < 1e-15
+    r = cs.SX.sym("rpy", 3)
+    f = cs.Function("dqrpy", [r], [g.dual_quaternion_rpy(r)])
+    assert np.abs(f(rpy).toarray().ravel() - ng.dual_quaternion_rpy(rpy)).max() < 1e-15
+    fk = skills.ur5()
+    q = cs.MX.sym("q", 6)
+    J = cs.Function("J", [q], [cs.jacobian(fk["T_fk"](q)[:3, 3], q)])
+    q0 = np.array([0.3, -1.2, 1.0, -0.5, 0.4, 0.1])
+    num = np.zeros((3, 6))
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = 1e-6
+        num[:, k] = (fk["T_fk"](q0 + d).toarray()[:3, 3] - fk["T_fk"](q0 - d).toarray()[:3, 3]) / 2e-6
+    assert np.abs(J(q0).toarray() - num).max() < 1e-8
