@@ -51,19 +51,9 @@ def dual_quaternion_skill(fk, which="Q_dist2", for_pinv=False):
     from casclik_amd import numpy_geom, casadi_geom
     t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
     Q_fk = fk["dual_quaternion_fk"]
-    quat1 = cs.SX.sym("quat1", 8)
     q1, q2 = cs.SX.sym("q1", 8), cs.SX.sym("q2", 8)
     dual_quaternion_product = cs.Function("dualquatprod", [q1, q2], [casadi_geom.dual_quaternion_product(q1, q2)])
     dual_quaternion_conj = cs.Function("dualquatconj", [q1], [casadi_geom.dual_quaternion_conj(q1)])
-    dual_hamilton_operator_minus = cs.Function("dH_minus", [quat1], [cs.vertcat(
-        cs.horzcat(quat1[3], quat1[2], -quat1[1], quat1[0], 0, 0, 0, 0),
-        cs.horzcat(-quat1[2], quat1[3], quat1[0], quat1[1], 0, 0, 0, 0),
-        cs.horzcat(quat1[1], -quat1[0], quat1[3], quat1[2], 0, 0, 0, 0),
-        cs.horzcat(-quat1[0], -quat1[1], -quat1[2], quat1[3], 0, 0, 0, 0),
-        cs.horzcat(quat1[7], quat1[6], -quat1[5], quat1[4], quat1[3], quat1[2], -quat1[1], quat1[0]),
-        cs.horzcat(-quat1[6], quat1[7], quat1[4], quat1[5], -quat1[2], quat1[3], quat1[0], quat1[1]),
-        cs.horzcat(quat1[5], -quat1[4], quat1[7], quat1[6], quat1[1], -quat1[0], quat1[3], quat1[2]),
-        cs.horzcat(-quat1[4], -quat1[5], -quat1[6], quat1[7], -quat1[0], -quat1[1], -quat1[2], quat1[3]))])
     rpy = [5.0 * (np.pi / 180.0), 0.0, 0.0]
     xyz = [0.5, 0.0, 0.5]
     Q_des = numpy_geom.dual_quaternion_revolute(xyz, rpy, [1, 0, 0], 0.0)
@@ -86,9 +76,10 @@ def dual_quaternion_skill(fk, which="Q_dist2", for_pinv=False):
     elif which == "Q_dist1":
         expr = dual_quaternion_product(Q_fk(q), dual_quaternion_conj(Q_des)) - Q_id
     else:
-        Hm = dual_hamilton_operator_minus(Q_des)
-        Cconj = cs.diag([-1, -1, -1, 1, -1, -1, -1, 1])
-        expr = cs.mtimes(Hm, cs.mtimes(Cconj, Q_des - Q_fk(q)))
+        # conj(Q_des - Q_fk(q)) (x) Q_des: the comparison notebook writes it with the product (cell 34), the
+        # other one with the right-multiplication matrix of Q_des and diag(-1,-1,-1,1,-1,-1,-1,1) (cell 18) -
+        # the same eight expressions
+        expr = dual_quaternion_product(dual_quaternion_conj(Q_des - Q_fk(q)), Q_des)
     dist = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=gain,
                                  priority=prio)
     q_min, q_max = np.array(fk["lower"]), np.array(fk["upper"])
