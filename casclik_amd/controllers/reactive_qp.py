@@ -19,6 +19,8 @@ import numpy as np
 
 from .. import _capi
 from .. import sym as cs
+from ..constraints import (EqualityConstraint, SetConstraint, VelocityEqualityConstraint,
+                           VelocitySetConstraint)
 from ..lowering import lower_skill
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
                               to_device_matrix, _torch)
@@ -199,24 +201,88 @@ class ReactiveQPController(BaseController):
             raise RuntimeError("call setup_problem_functions() / setup_solver() first")
 
     def setup_initial_problem_solver(self):
-        """The reference solves a second QP over (virtual_vel, slack) with the
-        robot velocity fixed (reactive_qp.py:300-424); its result is only used
-        as a warm start, which an exact solver does not need.  Kept for call
-        compatibility."""
+        """The reference builds a second QP over (virtual_vel, slack) with the robot velocity
+        fixed (reactive_qp.py:300-424); its result is only used as a warm start.  Nothing to
+        compile here: see solve_initial_problem."""
         spec = self.skill_spec
         self._has_initial = (spec.n_slack_var > 0) or (spec.n_virtual_var > 0
                                                       and spec._has_virtual)
 
     def solve_initial_problem(self, time_var0, robot_var0, virtual_var0=None,
                               robot_vel_var0=None, input_var0=None):  # noqa: D401
-        """Returns (virtual_vel0, slack0) like reactive_qp.py:426-459.  The
-        values come from the full QP at the initial state (the reference fixes
-        robot_vel to ``robot_vel_var0`` and re-optimises the rest); callers
-        use them only as ``warmstart_*`` arguments."""
-        if not self._has_initial:
+        """(virtual_vel0, slack0) of reactive_qp.py:426-459: the minimiser of
+        ``mu w_virt |dx|^2 + (1+mu) w_slack |s|^2`` over the rows that involve virtual or slack
+        variables, with the robot velocity fixed to ``robot_vel_var0`` (zeros by default).
+
+        Without virtual variables (every UR5 notebook) the rows decouple, ``-s_i in [lb_i, ub_i]``,
+        and the minimiser is each slack clamped to its interval nearest zero - evaluated here from
+        the expression graph at the one initial state (setup-time host arithmetic, like the
+        lowering; no solver involved).  With virtual variables the values come from the full QP at
+        the initial state on the device (the reference re-optimises virtual_vel and slack with the
+        robot held still); callers use either only as ``warmstart_*`` arguments, which an exact
+        solver does not need."""
+        if not getattr(self, "_has_initial", True):
             return None, None
-        res = self.solve(time_var0, robot_var0, virtual_var0, input_var0)
-        return res[1], res[2]
+        spec = self.skill_spec
+        if spec.n_slack_var == 0 and not (spec.n_virtual_var > 0 and spec._has_virtual):
+            return None, None
+        if spec.n_virtual_var > 0 and spec._has_virtual:
+            res = self.solve(time_var0, robot_var0, virtual_var0, input_var0)
+            return res[1], res[2]
+        from .. import autodiff
+        env = {}
+
+        def bind(var, val):
+            if var is None or var.numel() == 0:
+                return
+            flat = np.asarray(val.toarray() if hasattr(val, "toarray") else val, dtype=float).reshape(-1)
+            fam = cs._families_of(var)[0]
+            env[id(fam)] = {k: float(flat[k]) for k in range(flat.size)}
+
+        nq = spec.n_robot_var
+        bind(spec.time_var, [time_var0])
+        bind(spec.robot_var, robot_var0)
+        if spec.n_input_var > 0:
+            bind(spec.input_var, np.zeros(spec.n_input_var) if input_var0 is None else input_var0)
+        dq0 = np.zeros(nq) if robot_vel_var0 is None else \
+            np.asarray(robot_vel_var0.toarray() if hasattr(robot_vel_var0, "toarray") else robot_vel_var0,
+                       dtype=float).reshape(-1)
+        slack = []
+        for cn in spec.constraints:
+            if cn.constraint_type != "soft":
+                continue
+            expr = cn.expression
+            m = expr.size()[0]
+            e = cs.evaluate(expr, env).reshape(-1)
+            base = -cs.evaluate(autodiff.jacobian(expr, spec.time_var), env).reshape(-1)
+            if dq0.any():
+                base = base - cs.evaluate(autodiff.jacobian(expr, spec.robot_var), env).dot(dq0)
+
+            def gained(v, g=cn.gain):
+                if isinstance(g, cs.MX):
+                    g = cs.evaluate(g, {})
+                if isinstance(g, cs.DM):
+                    g = g.toarray()
+                g = np.asarray(g, dtype=float)
+                return float(g) * v if g.size == 1 else g.reshape(m, m).dot(v)
+
+            def vec(val):
+                if isinstance(val, cs.MX):
+                    val = cs.evaluate(val, {})
+                a = np.asarray(val.toarray() if isinstance(val, cs.DM) else val, dtype=float).reshape(-1)
+                return np.full(m, a[0]) if a.size == 1 and m > 1 else a
+
+            if isinstance(cn, EqualityConstraint):
+                lb = ub = base - gained(e)
+            elif isinstance(cn, SetConstraint):
+                lb, ub = base + gained(vec(cn.set_min) - e), base + gained(vec(cn.set_max) - e)
+            elif isinstance(cn, VelocityEqualityConstraint):
+                lb = ub = base + vec(cn.target)
+            else:
+                lb, ub = base + vec(cn.set_min), base + vec(cn.set_max)
+            # -s in [lb, ub]:  s in [-ub, -lb], the point nearest zero
+            slack.append(np.clip(0.0, -ub, -lb))
+        return None, cs.DM(np.concatenate(slack).reshape(-1, 1))
 
     # -- per tick -----------------------------------------------------------------
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,

@@ -732,3 +732,67 @@ def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
     dx = xs[:, nq:nq + nvirt] if nvirt > 0 else None
     slack = xs[:, nq + nvirt:nq + nvirt + ns] if ns > 0 else None
     return dq, dx, slack, status
+
+
+def qp_initial_problem(spec, t0, q0, x0=None, dq0=None, y0=None, weights=None, mu=0.001):
+    """Literal ReactiveQPController.solve_initial_problem (reactive_qp.py:300-459): the QP over
+    (virtual_vel, slack) with the robot velocity fixed to ``dq0`` (zeros when not given, :437-438):
+
+        H = diag(mu w_virt, (1 + mu) w_slack)                                   (:321-331)
+        rows of every constraint that depends on virtual_var or is soft         (:339-391):
+            [J_virt | -I_slack] [dx; s]  in  [lb, ub] - d e/d t - J_q dq0       (:353-372)
+
+    Returns (virtual_vel | None, slack | None); (None, None) without virtual and slack variables."""
+    from casclik_amd import sym as cs
+    nq = spec.n_robot_var
+    nvirt = spec.n_virtual_var if spec.virtual_var is not None else 0
+    nslack = spec.n_slack_var
+    if nvirt == 0 and nslack == 0:
+        return None, None
+    q0 = np.asarray(q0, dtype=float).reshape(1, -1)
+    Z = q0 if nvirt == 0 else np.hstack([q0, (np.zeros((1, nvirt)) if x0 is None
+                                              else np.asarray(x0, dtype=float).reshape(1, -1))])
+    Yb = None
+    if spec.n_input_var > 0:
+        Yb = np.zeros((1, spec.n_input_var)) if y0 is None else np.asarray(y0, dtype=float).reshape(1, -1)
+    dq0 = np.zeros(nq) if dq0 is None else np.asarray(dq0, dtype=float).reshape(-1)
+    evaluator = ExprEvaluator(spec, t0, Z, Yb)
+    _, wv, ws = weights if weights is not None else qp_weights(spec)
+    hd = np.concatenate(([mu * wv] if nvirt > 0 else []) + ([(1.0 + mu) * ws] if nslack > 0 else []))
+    A_rows, lbs, ubs = [], [], []
+    slack_ind = 0
+    for c in spec.constraints:
+        e, Jt, Jz = evaluator.vector(c.expression)
+        e, Jt, Jz = e[0], Jt[0], Jz[0]
+        m = e.size
+        found_virt = nvirt > 0 and cs.depends_on(c.expression, spec.virtual_var)     # structural, as J_virt.nnz()
+        blk = np.zeros((m, nvirt + nslack))
+        if found_virt:
+            blk[:, :nvirt] = Jz[:, nq:nq + nvirt]
+        lb = -Jt - Jz[:, :nq].dot(dq0)
+        ub = lb.copy()
+        kind = _cls(c)
+        if kind == "EqualityConstraint":
+            ke = _gain_apply(c.gain, e)
+            lb, ub = lb - ke, ub - ke
+        elif kind == "SetConstraint":
+            lb = lb + _gain_apply(c.gain, _num(c.set_min, m) - e)
+            ub = ub + _gain_apply(c.gain, _num(c.set_max, m) - e)
+        elif kind == "VelocityEqualityConstraint":
+            lb, ub = lb + _num(c.target, m), ub + _num(c.target, m)
+        elif kind == "VelocitySetConstraint":
+            lb, ub = lb + _num(c.set_min, m), ub + _num(c.set_max, m)
+        found_slack = False
+        if nslack > 0 and c.constraint_type == "soft":
+            for i in range(m):
+                blk[i, nvirt + slack_ind + i] = -1.0
+            slack_ind += m
+            found_slack = True
+        if found_virt or found_slack:
+            A_rows.append(blk)
+            lbs.append(lb)
+            ubs.append(ub)
+    if not A_rows:
+        return None, None
+    x = qp_solve_dense(hd, np.vstack(A_rows), np.concatenate(lbs), np.concatenate(ubs))
+    return (x[:nvirt] if nvirt > 0 else None), (x[nvirt:nvirt + nslack] if nslack > 0 else None)

@@ -217,3 +217,34 @@ def test_geometry_helpers_compose_like_the_joint_transforms():
         d[k] = 1e-6
         num[:, k] = (fk["T_fk"](q0 + d).toarray()[:3, 3] - fk["T_fk"](q0 - d).toarray()[:3, 3]) / 2e-6
     assert np.abs(J(q0).toarray() - num).max() < 1e-8
+
+
+def test_initial_problem_slack_matches_the_reference_formulation(ur5_fk):
+    """solve_initial_problem (reactive_qp.py:300-459) without virtual variables: the controller's
+    closed form (each slack clamped to its interval nearest zero) against the oracle's literal QP over
+    the slack variables, for the notebooks' call ``solve_initial_problem(0, UR5_home)[-1]``
+    (ur5_dual_quaternion_comparison_of_controllers.ipynb cell 17) and with a robot velocity given."""
+    from oracle import clik_oracle
+    from extern_skills import dual_quaternion_skill
+    home = np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0])
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
+    T = ur5_fk["T_fk"](q)
+    soft_set = cc.SkillSpecification("soft_set", t, q, constraints=[
+        cc.SetConstraint("band", T[:2, 3], set_min=np.array([0.3, -0.1]), set_max=np.array([0.5, 0.1]), gain=2.0,
+                         constraint_type="soft", priority=1),
+        cc.EqualityConstraint("track", T[:3, 3] - cs.vertcat(0.4 + 0.1 * cs.sin(t), 0.0, 0.5), gain=np.diag([1.0, 2.0, 3.0]),
+                              constraint_type="soft", priority=2, slack_weight=4.0),
+        cc.VelocitySetConstraint("speed", q, set_min=-np.ones(6), set_max=np.ones(6), priority=0)])
+    for spec in (dual_quaternion_skill(ur5_fk, "Q_dist2"), dual_quaternion_skill(ur5_fk, "cart_dist"), soft_set):
+        ctrl = cc.ReactiveQPController(skill_spec=spec)
+        ctrl.setup_initial_problem_solver()
+        for dq0 in (None, np.array([0.1, -0.2, 0.3, 0.0, 0.05, -0.1])):
+            virt, slack = ctrl.solve_initial_problem(0.7, home, robot_vel_var0=dq0)
+            rvirt, rslack = clik_oracle.qp_initial_problem(spec, 0.7, home, dq0=dq0)
+            assert virt is None and rvirt is None
+            assert slack.toarray().shape == (spec.n_slack_var, 1)
+            assert np.abs(slack.toarray()[:, 0] - rslack).max() < 1e-10
+    hard = cc.SkillSpecification("hard", t, q, constraints=[cc.EqualityConstraint("p", T[:3, 3], constraint_type="hard")])
+    ctrl = cc.ReactiveQPController(skill_spec=hard)
+    ctrl.setup_initial_problem_solver()
+    assert ctrl.solve_initial_problem(0.0, home) == (None, None)
