@@ -16,7 +16,7 @@ import numpy as np
 
 from .. import _capi
 from .. import sym as cs
-from ..lowering import lower_skill
+from ..lowering import lower_skill, DYN_MAX_M
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
                               to_device_matrix, _torch)
 
@@ -138,12 +138,17 @@ class PseudoInverseController(BaseController):
         import os
         want_jit = self.options["function_opts"].get("jit", True) and os.environ.get("CLIK_JIT", "1") != "0" \
             and os.environ.get("CLIK_FORCE_DYNAMIC", "0") != "1"
-        if self.kernel_name == "dynamic" and want_jit:
+        if self.kernel_name in ("dynamic", "none") and want_jit:
             from .. import jit
             with torch.cuda.device(self._device):
                 name = jit.attach(self._lib, handle, cdesc, copts, extern=self.descriptor.extern_source())
             if name:
                 self.kernel_name = name
+        if self.kernel_name == "none":
+            raise NotImplementedError(
+                "a constraint of this skill has more rows than the built-in kernels are wide (%d) and no "
+                "shape-specialised kernel could be instantiated for it (jit disabled, hipcc missing, or the "
+                "skill is outside the shape-specialised family)" % DYN_MAX_M)
         if self.descriptor.extern_code and not self.kernel_name.startswith("jit_"):
             # constraints outside the row-table family exist only as generated code inside a
             # run-time instantiated kernel; there is no other path (and no CPU fallback)

@@ -512,6 +512,29 @@ static bool build_qp_image(const DevSkill& S, std::vector<char>& out)
     return true;
 }
 
+// constraints whose rows are code generated from the caller's expression graph (CLIK_OUT_EXTERN)
+// exist only inside the kernel instantiated for them
+static bool skill_has_extern(const DevSkill& S)
+{
+    for (int ti = 0; ti < S.d.n_tasks; ++ti)
+        if (S.d.tasks[ti].out_kind[0] == CLIK_OUT_EXTERN) return true;
+    return false;
+}
+// ... and so do constraints with more rows than the built-in kernels are wide (CLIK_DYN_MAX_M)
+static bool skill_has_wide_task(const DevSkill& S)
+{
+    for (int ti = 0; ti < S.d.n_tasks; ++ti)
+        if (S.d.tasks[ti].m > CLIK_DYN_MAX_M) return true;
+    return false;
+}
+static bool skill_needs_static(const DevSkill& S) { return skill_has_extern(S) || skill_has_wide_task(S); }
+static int extern_needs_kernel(const char* what)
+{
+    return fail(CLIK_EUNSUPPORTED, "%s: the skill has code-generated constraint rows or a constraint with more "
+                                   "than %d rows, and no kernel instantiated for it is attached "
+                                   "(casclik_amd.jit needs hipcc)", what, CLIK_DYN_MAX_M);
+}
+
 // C++ aggregate initialiser of a ShapeDesc (field order of clik_device.hpp)
 static std::string shape_to_string(const clik::ShapeDesc& h)
 {
@@ -675,10 +698,12 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         const char* noaot = getenv("CLIK_NO_AOT");
         h->kernel = clik::pinv_pick_kernel(S, ((force && force[0] == '1') || (noaot && noaot[0] == '1')) ? 0 : 1);
     }
-    if (h->kernel < 0) {
+    if (h->kernel < 0 && !skill_has_wide_task(S)) {
         delete h;
         return fail(CLIK_EUNSUPPORTED, "no kernel variant for n = %d", S.n);
     }
+    // (kernel < 0 with a wide constraint: no built-in kernel is wide enough; the handle solves once a
+    // kernel instantiated for the skill is attached)
     compute_warm(S, S.lds_slots, h->warm);
     S.zero_token = 0;
     S.lds_slots = clik::pinv_lds_slots_host(clik::pinv_kernel_width(h->kernel), S.d.n_y);
@@ -768,20 +793,6 @@ extern "C" const char* clik_pinv_kernel_name(const clik_pinv* h)
     return h ? clik::pinv_kernel_name(h->kernel) : "none";
 }
 
-// constraints whose rows are code generated from the caller's expression graph (CLIK_OUT_EXTERN)
-// exist only inside the kernel instantiated for them
-static bool skill_has_extern(const DevSkill& S)
-{
-    for (int ti = 0; ti < S.d.n_tasks; ++ti)
-        if (S.d.tasks[ti].out_kind[0] == CLIK_OUT_EXTERN) return true;
-    return false;
-}
-static int extern_needs_kernel(const char* what)
-{
-    return fail(CLIK_EUNSUPPORTED, "%s: the skill has code-generated constraint rows and no kernel instantiated "
-                                   "for them is attached (casclik_amd.jit needs hipcc)", what);
-}
-
 static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk)
 {
     memset(tk, 0, sizeof(*tk));
@@ -804,7 +815,8 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_x > 0 && (!x || !dx)) return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
-    if (!h->jit_solve && skill_has_extern(S)) return extern_needs_kernel("clik_pinv_solve_batch");
+    if (!h->jit_solve && (h->kernel < 0 || !clik::pinv_kernel_is_static(h->kernel)) && skill_needs_static(S))
+        return extern_needs_kernel("clik_pinv_solve_batch");
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
@@ -827,7 +839,8 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
     if (B == 0 || n_ticks == 0) return CLIK_OK;
     const DevSkill& S = h->host;
     if (S.d.n_x > 0) return fail(CLIK_EUNSUPPORTED, "rollout with virtual_var is not supported");
-    if (!h->jit_rollout && skill_has_extern(S)) return extern_needs_kernel("clik_pinv_rollout_batch");
+    if (!h->jit_rollout && (h->kernel < 0 || !clik::pinv_kernel_is_static(h->kernel)) && skill_needs_static(S))
+        return extern_needs_kernel("clik_pinv_rollout_batch");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     const size_t need = (size_t)n_ticks * 2 * (size_t)S.d.n_tslots;
@@ -1074,7 +1087,7 @@ extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
     if (!dq) return fail(CLIK_EINVAL, "dq must be a device pointer");
-    if (!h->jit_solve && skill_has_extern(h->host)) return extern_needs_kernel("clik_qp_solve_batch");
+    if (!h->jit_solve && h->static_k < 0 && skill_needs_static(h->host)) return extern_needs_kernel("clik_qp_solve_batch");
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
@@ -1103,8 +1116,9 @@ extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tte
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
     if (!Hdiag || !A || !lbA || !ubA) return fail(CLIK_EINVAL, "output pointers required");
-    if (skill_has_extern(h->host))
-        return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: not available for skills with code-generated rows");
+    if (skill_needs_static(h->host))
+        return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: not available for skills that only the "
+                                       "shape-specialised kernels serve (generated rows, > 8 rows per constraint)");
     if (h->variant < 0)
         return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: the skill exceeds the built-in kernel's limits");
     TickArgs tk;

@@ -31,7 +31,8 @@ from .urdf import JOINT_FIXED
 MAX_DOF = 8
 MAX_JOINTS = 12
 MAX_TASKS = 16
-MAX_M = 8
+MAX_M = 12              # > DYN_MAX_M rows only in the shape-specialised kernels
+DYN_MAX_M = 8
 MAX_ROWS = 96
 MAX_SETS = 6
 MAX_TSLOTS = 32

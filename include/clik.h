@@ -37,12 +37,15 @@
 extern "C" {
 #endif
 
-#define CLIK_ABI_VERSION 1
+#define CLIK_ABI_VERSION 2
 
 #define CLIK_MAX_DOF      8   /* n_state = n_robot_var + n_virtual_var            */
 #define CLIK_MAX_JOINTS  12   /* chain joints, fixed ones included                */
 #define CLIK_MAX_TASKS   16   /* constraints per skill                            */
-#define CLIK_MAX_M        8   /* rows of one constraint expression                */
+#define CLIK_MAX_M       12   /* rows of one constraint expression; more than
+                                 CLIK_DYN_MAX_M only in the shape-specialised kernels
+                                 (attached or AOT): the built-in kernels refuse them  */
+#define CLIK_DYN_MAX_M    8
 #define CLIK_MAX_ROWS    96   /* affine rows over all constraints                 */
 #define CLIK_MAX_SETS     6   /* SetConstraints -> 2^6 modes                      */
 #define CLIK_MAX_TSLOTS  32   /* time-only sub-expressions evaluated by the host  */

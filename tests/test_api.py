@@ -173,7 +173,12 @@ def test_lowering_rejects_what_the_device_cannot_do(iiwa_fk):
         lower_skill(cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint("v", dq[0])]))
     with pytest.raises(NotImplementedError, match="rows"):
         lower_skill(cc.SkillSpecification("s", t, q, constraints=[
-            cc.EqualityConstraint("nine", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2]))]))
+            cc.EqualityConstraint("thirteen", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3], q[0]))]))
+    # nine rows (the "three point" pose error of ur5_dual_quaternion_vs_transformation_matrix.ipynb cell 20)
+    # fit the ABI; only the shape-specialised kernels are wide enough for them
+    nine = lower_skill(cc.SkillSpecification("s", t, q, constraints=[
+        cc.EqualityConstraint("nine", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2]))]))
+    assert nine.tasks[0]["m"] == 9
     seven_sets = [cc.SetConstraint("s%d" % i, q[i], set_min=-1.0, set_max=1.0, priority=i) for i in range(7)]
     with pytest.raises(NotImplementedError, match="modes"):
         lower_skill(cc.SkillSpecification("s", t, q, constraints=seven_sets))

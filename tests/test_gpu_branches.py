@@ -357,3 +357,50 @@ def test_tall_first_equality_is_processed_twice(ur5_fk, monkeypatch, force_dynam
         Q, _ = skills.synthetic_inputs(ur5_fk, 300, seed=6)
         ctrl = _check(spec, {"damping_factor": 1e-4}, 0.3 * Q, tol=1e-8)
         assert (ctrl.kernel_name == "dynamic") == force_dynamic
+
+
+def test_nine_row_three_point_pose_error(ur5_fk, monkeypatch):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cell 20, T_dist3: the "three point" pose error,
+    9 rows on a 6-DoF arm - more rows than the built-in kernels are wide (CLIK_DYN_MAX_M = 8), so only the
+    instantiated kernels serve it: as the tall, doubly processed first equality of the pinv controller
+    behind 1-D joint-limit sets, and as 9 soft rows of the QP controller."""
+    from oracle import clik_oracle
+    from casclik_amd import numpy_geom
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    T_fk = ur5_fk["T_fk"]
+    T_des = np.eye(4)
+    T_des[:3, :3] = numpy_geom.rotation_rpy(5.0 * (np.pi / 180.0), 0.0, 0.0)
+    T_des[:3, 3] = [0.5, 0.0, 0.5]
+    expr = cs.vertcat(T_fk(q)[0, :3].T + T_fk(q)[:3, 3] - T_des[0, :3] - T_des[:3, 3],
+                      T_fk(q)[1, :3].T + T_fk(q)[:3, 3] - T_des[1, :3] - T_des[:3, 3],
+                      T_fk(q)[2, :3].T + T_fk(q)[:3, 3] - T_des[2, :3] - T_des[:3, 3])
+    dist = cc.EqualityConstraint(label="T_dist3", expression=expr, gain=10.0, constraint_type="soft", priority=300)
+    q_min, q_max = np.array(ur5_fk["lower"]), np.array(ur5_fk["upper"])
+    home = np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0])
+    rng = np.random.default_rng(21)
+    Q = home + rng.uniform(-1.0, 1.0, size=(300, 6))
+    Q[::5, 2] = rng.choice([-1.0, 1.0], size=Q[::5].shape[0]) * rng.uniform(3.0, 3.4, size=Q[::5].shape[0])
+    limits = [cc.SetConstraint(label="limit_q_%d" % i, expression=q[i], set_min=q_min[i], set_max=q_max[i], priority=i)
+              for i in (1, 2)]
+    spec = cc.SkillSpecification("T_dist3_pinv", t, q, dq, constraints=[dist] + limits)
+    ctrl = _check(spec, None, Q, min_modes=2)
+    assert ctrl.kernel_name.startswith("jit_")
+    qspec = cc.SkillSpecification("T_dist3_qp", t, q, dq, constraints=[
+        dist, cc.SetConstraint(label="Joint_Limits", expression=q, set_min=q_min, set_max=q_max),
+        cc.VelocitySetConstraint(label="Joint_speed_limits", expression=q, set_min=-np.full(6, np.pi / 5),
+                                 set_max=np.full(6, np.pi / 5))])
+    qc = cc.ReactiveQPController(skill_spec=qspec)
+    qc.setup_problem_functions()
+    qc.setup_solver()
+    assert qc.kernel_name.startswith("jit_")
+    qdq, _, qsl, st = qc.solve_batch(0.0, Q)
+    rdq, _, rsl, rst = clik_oracle.qp_solve_batch(qspec, 0.0, Q)
+    assert np.array_equal(st, rst)
+    ok = rst == 0
+    assert ok.sum() > 200 and _rel(qdq[ok], rdq[ok]).max() < 1e-8 and _rel(qsl[ok], rsl[ok]).max() < 1e-8
+    # no built-in kernel is that wide: without the instantiation the controllers refuse, loudly
+    monkeypatch.setenv("CLIK_JIT", "0")
+    with pytest.raises(NotImplementedError, match="more rows than the built-in kernels"):
+        cc.PseudoInverseController(skill_spec=spec).setup_problem_functions()
+    with pytest.raises(NotImplementedError, match="exceeds the built-in kernel"):
+        cc.ReactiveQPController(skill_spec=qspec).setup_problem_functions()
