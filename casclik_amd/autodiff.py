@@ -92,7 +92,13 @@ def diff_scalar(node, key, memo):
                 acc = _s_add(acc, _s_mul(_fk_d(node, k), da))
         r = acc
     else:
-        raise NotImplementedError("symbolic derivative of op '%s'" % op)
+        # opaque nodes (orientation error, FK derivative entries): zero when no argument depends on the
+        # symbol (e.g. d/dt of a pose error whose target is not a function of time)
+        ds = [diff_scalar(a, key, memo) for a in node.args]
+        if all(d.is_const() and d.value == 0.0 for d in ds):
+            r = _ZERO
+        else:
+            raise NotImplementedError("symbolic derivative of op '%s'" % op)
     memo[nid] = r
     return r
 

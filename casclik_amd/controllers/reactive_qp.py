@@ -256,7 +256,19 @@ class ReactiveQPController(BaseController):
             e = cs.evaluate(expr, env).reshape(-1)
             base = -cs.evaluate(autodiff.jacobian(expr, spec.time_var), env).reshape(-1)
             if dq0.any():
-                base = base - cs.evaluate(autodiff.jacobian(expr, spec.robot_var), env).dot(dq0)
+                try:
+                    base = base - cs.evaluate(autodiff.jacobian(expr, spec.robot_var), env).dot(dq0)
+                except NotImplementedError:
+                    # (opaque orientation-error nodes have no symbolic q-derivative: directional difference)
+                    fam = id(cs._families_of(spec.robot_var)[0])
+                    q_at = dict(env[fam])
+                    h = 1e-6
+                    env[fam] = {k: q_at[k] + h * dq0[k] for k in q_at}
+                    ep = cs.evaluate(expr, env).reshape(-1)
+                    env[fam] = {k: q_at[k] - h * dq0[k] for k in q_at}
+                    em = cs.evaluate(expr, env).reshape(-1)
+                    env[fam] = q_at
+                    base = base - (ep - em) / (2.0 * h)
 
             def gained(v, g=cn.gain):
                 if isinstance(g, cs.MX):
