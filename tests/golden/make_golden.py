@@ -54,6 +54,38 @@ def main():
     out["iiwa_qp_dq"], out["iiwa_qp_slack"] = dq, slack
     np.savez_compressed(os.path.join(HERE, "clik_golden.npz"), **out)
     print("wrote clik_golden.npz with", sorted(out))
+    notebook_cases()
+
+
+def notebook_inputs():
+    """Seeded states for the reference notebooks' own skills (tests/extern_skills.py)."""
+    rng = np.random.default_rng(77)
+    home = np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0])
+    Qp = np.stack([rng.uniform(0.1, np.pi - 0.1, 32), rng.uniform(-1.5, 1.5, 32)], axis=1)
+    Qu = home + rng.uniform(-1.0, 1.0, size=(32, 6))
+    Qu[::4, 2] = np.array([3.2, -3.3, 3.05, -3.15, 3.35, -3.0, 3.1, -3.25])
+    return Qp, Qu
+
+
+def notebook_cases():
+    """double_pendulum_2D_comparison_of_controllers.ipynb (tracking skill, QP) and the dual-quaternion
+    notebooks (Q_dist2 through QP and - behind six 1-D limit sets - through the pseudo-inverse controller)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from extern_skills import double_pendulum_skill, dual_quaternion_skill
+    Qp, Qu = notebook_inputs()
+    out = {"pendulum_Q": Qp, "ur5_Q": Qu}
+    spec = double_pendulum_skill(True)
+    dq, _, slack, status = clik_oracle.qp_solve_batch(spec, 1.3, Qp, weights=clik_oracle.qp_weights(spec, [1.0, 1.0]))
+    out["pendulum_qp_dq"], out["pendulum_qp_slack"], out["pendulum_qp_status"] = dq, slack, status
+    fk = skills.ur5()
+    dq, _, slack, status = clik_oracle.qp_solve_batch(dual_quaternion_skill(fk, "Q_dist2"), 0.0, Qu)
+    assert (status == 0).all()
+    out["dq_qp_dq"], out["dq_qp_slack"] = dq, slack
+    dq, mode = clik_oracle.pinv_solve_batch(dual_quaternion_skill(fk, "Q_dist2", for_pinv=True), None, 0.0, Qu)
+    out["dq_pinv_dq"], out["dq_pinv_mode"] = dq, mode
+    np.savez_compressed(os.path.join(HERE, "notebook_golden.npz"), **out)
+    print("wrote notebook_golden.npz with", sorted(out), "modes", np.bincount(mode + 1).tolist(),
+          "pendulum status", np.bincount(status * 0 + out["pendulum_qp_status"]).tolist())
 
 
 if __name__ == "__main__":

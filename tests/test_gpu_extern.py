@@ -202,3 +202,26 @@ def test_dual_quaternion_pose_error_pseudo_inverse(ur5_fk, which):
     assert np.array_equal(mode, rmode)
     assert len(np.unique(mode)) >= 2
     assert _rel(dq, ref).max() < PINV_RTOL, _rel(dq, ref).max()
+
+
+def test_notebook_golden_vectors(ur5_fk):
+    """Committed fixtures (tests/golden/notebook_golden.npz, oracle-of-record, see make_golden.py): the
+    notebooks' skills on the device without importing the oracle."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "notebook_golden.npz"))
+    ctrl = cc.ReactiveQPController(skill_spec=double_pendulum_skill(True), robot_var_weights=[1.0, 1.0])
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    dq, _, slack, status = ctrl.solve_batch(1.3, g["pendulum_Q"])
+    assert np.array_equal(status, g["pendulum_qp_status"])
+    ok = status == 0
+    assert _rel(dq[ok], g["pendulum_qp_dq"][ok]).max() < QP_RTOL and _rel(slack[ok], g["pendulum_qp_slack"][ok]).max() < QP_RTOL
+    qc = cc.ReactiveQPController(skill_spec=dual_quaternion_skill(ur5_fk, "Q_dist2"))
+    qc.setup_problem_functions()
+    qc.setup_solver()
+    dq, _, slack, status = qc.solve_batch(0.0, g["ur5_Q"])
+    assert (status == 0).all()
+    assert _rel(dq, g["dq_qp_dq"]).max() < QP_RTOL and _rel(slack, g["dq_qp_slack"]).max() < QP_RTOL
+    pc = cc.PseudoInverseController(skill_spec=dual_quaternion_skill(ur5_fk, "Q_dist2", for_pinv=True))
+    pc.setup_problem_functions()
+    dq, _, mode = pc.solve_batch(0.0, g["ur5_Q"])
+    assert np.array_equal(mode, g["dq_pinv_mode"]) and _rel(dq, g["dq_pinv_dq"]).max() < PINV_RTOL
