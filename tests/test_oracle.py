@@ -382,9 +382,9 @@ def test_notebook_golden_vectors_are_the_oracles_answers(ur5_fk):
     from extern_skills import double_pendulum_skill, dual_quaternion_skill
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "notebook_golden.npz"))
     spec = double_pendulum_skill(True)
-    dq, _, slack, status = clik_oracle.qp_solve_batch(spec, 1.3, g["pendulum_Q"], weights=clik_oracle.qp_weights(spec, [1.0, 1.0]))
+    dq, _, slack, status = orc.qp_solve_batch(spec, 1.3, g["pendulum_Q"], weights=orc.qp_weights(spec, [1.0, 1.0]))
     assert np.array_equal(status, g["pendulum_qp_status"])
     ok = status == 0
     assert np.abs(dq[ok] - g["pendulum_qp_dq"][ok]).max() < 1e-12 and np.abs(slack[ok] - g["pendulum_qp_slack"][ok]).max() < 1e-12
-    dq, mode = clik_oracle.pinv_solve_batch(dual_quaternion_skill(ur5_fk, "Q_dist2", for_pinv=True), None, 0.0, g["ur5_Q"])
+    dq, mode = orc.pinv_solve_batch(dual_quaternion_skill(ur5_fk, "Q_dist2", for_pinv=True), None, 0.0, g["ur5_Q"])
     assert np.array_equal(mode, g["dq_pinv_mode"]) and np.abs(dq - g["dq_pinv_dq"]).max() < 1e-12
