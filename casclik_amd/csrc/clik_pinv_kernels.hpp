@@ -929,7 +929,13 @@ __global__ __launch_bounds__((1 << shape_n_sets(SD)) * WAVE) CLIK_OCC_ATTR void 
     // constants are not live (or parked in AGPRs) earlier.  Pays at small batches (-4 % on the
     // config-3 tick); with four busy SIMDs per CU the extra LDS reads cost more than they save,
     // so the one-wave kernel copies once.
+#ifdef CLIK_IMG_GLOBAL
+    // (experiment: read the skill image through the scalar cache straight from global memory instead of
+    // the LDS copy - see DESIGN.md "measured options")
+    const Img<SD>* __restrict__ Slds = (const Img<SD>*)img_g;
+#else
     const Img<SD>* __restrict__ Slds = (const Img<SD>*)lds;
+#endif
     const double* ysl = ys + lane * SD.n_y;
     double z[N];
 #pragma unroll
