@@ -74,6 +74,17 @@ def random_skill(rng, fk, n):
                                                  gain=gain(1), priority=pr))
     pool.append(lambda pr: cc.EqualityConstraint("xy_prod", cs.vertcat(p[0] * p[1] - 0.05, T[2, 2] * q[jb] - 0.1),
                                                  gain=gain(2), priority=pr))
+    # constraints wider than the built-in kernels (9-12 rows: shape-specialised kernels only)
+    xa = rng.normal(size=3)
+    xa /= np.linalg.norm(xa)
+    pool.append(lambda pr: cc.EqualityConstraint("wide9", cs.vertcat(p - rng.uniform(0.2, 0.5, size=3), T[:3, 0] - xa,
+                                                                      T[:3, 2] - np.array([0.0, 0.0, 1.0])),
+                                                 gain=gain(9), priority=pr))
+    jw = sorted(rng.choice(n, size=min(n, 5), replace=False).tolist())
+    pool.append(lambda pr: cc.SetConstraint("wide_box", cs.vertcat(p, T[:3, 1], *[q[j] for j in jw]),
+                                            set_min=np.concatenate([[0.1, -0.4, 0.1], -0.9 * np.ones(3), 0.28 * lo[jw]]),
+                                            set_max=np.concatenate([[0.6, 0.4, 0.7], 0.9 * np.ones(3), 0.28 * hi[jw]]),
+                                            gain=gain(6 + len(jw)), priority=pr))
     nt = int(rng.integers(2, 6))
     picks = rng.choice(len(pool), size=nt, replace=False)
     prios = rng.permutation(nt)
@@ -88,6 +99,8 @@ def random_skill(rng, fk, n):
             "converge_final_set_to_max": bool(rng.random() < 0.3),
             "pinv_method": "damped" if rng.random() < 0.85 else "standard",
             "damping_factor": float(10 ** rng.uniform(-9, -5))}
+    if any(c.label == "wide_box" for c in cons):
+        opts["multidim_sets"] = True
     uses_y = any(c.label in ("pose_y", "pos_y") for c in cons)
     return cc.SkillSpecification("fuzz", t, q, input_var=y if uses_y else None, constraints=cons), opts, rest
 
