@@ -78,12 +78,16 @@ def current_stream(device):
 
 class SingleSlot(object):
     """Persistent staging for the single-instance ``solve()`` call (B = 1): one pinned host
-    buffer and one device buffer each way, so a call is one H2D copy, one launch, one D2H copy
-    and one stream synchronisation instead of fresh tensors per argument."""
+    buffer each way that the kernel reads and writes in place (pinned host memory is mapped into
+    the device's address space on ROCm, same pointer), so a call is one launch and one stream
+    synchronisation - no copy commands.  ``CLIK_SOLVE_STAGED=1`` restores the staged variant
+    (pinned -> device copy, launch, device -> pinned copy)."""
 
     def __init__(self, device, n_in, n_out, n_int):
+        import os
         torch = _torch()
         self.device = device
+        self.zero_copy = os.environ.get("CLIK_SOLVE_STAGED", "0") != "1"
         self.h_in = torch.empty((max(n_in, 1),), dtype=torch.float64).pin_memory()
         self.d_in = torch.empty((max(n_in, 1),), dtype=torch.float64, device=device)
         # outputs: n_out doubles followed by n_int int32 (padded to 8 bytes)
@@ -95,8 +99,13 @@ class SingleSlot(object):
         out_np = self.h_out.numpy()
         self.out_f = out_np[:8 * n_out].view(np.float64)
         self.out_i = out_np[8 * n_out:8 * n_out + 4 * n_int].view(np.int32)
-        self.d_in_ptr = self.d_in.data_ptr()
-        self.d_out_ptr = self.d_out.data_ptr()
+        # one device in the process: no device-guard context around the call (it costs ~3 us)
+        import contextlib
+        self._single_device = torch.cuda.device_count() == 1
+        self._no_guard = contextlib.nullcontext()
+        self._stream = None
+        self.d_in_ptr = self.h_in.data_ptr() if self.zero_copy else self.d_in.data_ptr()
+        self.d_out_ptr = self.h_out.data_ptr() if self.zero_copy else self.d_out.data_ptr()
 
     def in_ptr(self, offset_doubles):
         return C.c_void_p(self.d_in_ptr + 8 * offset_doubles)
@@ -107,10 +116,25 @@ class SingleSlot(object):
     def int_ptr(self, index=0):
         return C.c_void_p(self.d_out_ptr + 8 * self.n_out + 4 * index)
 
+    def guard(self):
+        """Device context for the call (a no-op when the process has one device)."""
+        return self._no_guard if self._single_device else _torch().cuda.device(self.device)
+
+    def begin(self):
+        """Stream of this call (torch's current stream, looked up once) as a launch argument."""
+        self._stream = _torch().cuda.current_stream(self.device)
+        if not self.zero_copy:
+            self.d_in.copy_(self.h_in, non_blocking=True)
+        return C.c_void_p(self._stream.cuda_stream)
+
     def upload(self):
-        self.d_in.copy_(self.h_in, non_blocking=True)
+        if not self.zero_copy:
+            self.d_in.copy_(self.h_in, non_blocking=True)
 
     def download(self):
         torch = _torch()
-        self.h_out.copy_(self.d_out, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        if not self.zero_copy:
+            self.h_out.copy_(self.d_out, non_blocking=True)
+        st = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+        self._stream = None
+        st.synchronize()

@@ -324,12 +324,12 @@ class PseudoInverseController(BaseController):
         if ny:
             slot.in_np[nq + nx:nq + nx + ny] = y
         tt, ttp = _capi.tterms_arg(d.time_terms(float(_scalar(time_var))))
-        with torch.cuda.device(self._device):
-            slot.upload()
+        with slot.guard():
+            stream = slot.begin()
             rc = self._lib.clik_pinv_solve_batch(
                 self._handle, 1, ttp, slot.in_ptr(0), slot.in_ptr(nq) if nx else None,
                 slot.in_ptr(nq + nx) if ny else None, slot.out_ptr(0), slot.out_ptr(nq) if nx else None,
-                slot.int_ptr(0), current_stream(self._device))
+                slot.int_ptr(0), stream)
             _capi.check(self._lib, rc)
             slot.download()
         self.current_mode = int(slot.out_i[0])

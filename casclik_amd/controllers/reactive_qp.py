@@ -474,13 +474,13 @@ class ReactiveQPController(BaseController):
         if ny:
             slot.in_np[nq + nx:nq + nx + ny] = y
         tt, ttp = _capi.tterms_arg(d.time_terms(float(_scalar(time_var))))
-        with torch.cuda.device(self._device):
-            slot.upload()
+        with slot.guard():
+            stream = slot.begin()
             rc = self._lib.clik_qp_solve_batch_hot(
                 self._handle, 1, ttp, slot.in_ptr(0), slot.in_ptr(nq) if nx else None,
                 slot.in_ptr(nq + nx) if ny else None, slot.out_ptr(0), slot.out_ptr(nq) if nx else None,
                 slot.out_ptr(nq + nx) if ns else None, slot.int_ptr(0), slot.int_ptr(1),
-                1 if self._slot_calls > 0 else 0, current_stream(self._device))
+                1 if self._slot_calls > 0 else 0, stream)
             _capi.check(self._lib, rc)
             slot.download()
         self._slot_calls += 1
