@@ -357,3 +357,27 @@ def test_qp_one_sided_set_with_the_default_other_bound(iiwa_fk, monkeypatch, for
             ref = dq
         else:
             assert np.array_equal(np.isnan(ref), np.isnan(dq)) and np.nanmax(np.abs(ref - dq)) < 1e-9
+
+
+def test_qp_baseline_full_size(iiwa_fk):
+    """BASELINE.json config 4 at its full size (16384 instances): every answer passes the
+    solver-independent KKT check on a 1024-instance sample and matches the oracle there; permuting the
+    batch permutes the answers bit for bit; no instance is reported infeasible or capped."""
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = _controller(spec)
+    B = 16384
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=0, distribution="mixed")
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+    assert (status == 0).all()
+    idx = np.random.default_rng(2).choice(B, size=1024, replace=False)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[idx], Y=Y[idx])
+    assert (rstatus == 0).all()
+    assert _rel(dq[idx], rdq).max() < QP_RTOL and _rel(slack[idx], rslack).max() < QP_RTOL
+    hd, A, lb, ub = clik_oracle.qp_data_batch(spec, 0.0, Q[idx], Y=Y[idx])
+    for k, b in enumerate(idx):
+        prim, stat, sign = clik_oracle.kkt_residuals(hd[k], A[k], lb[k], ub[k], np.concatenate([dq[b], slack[b]]))
+        assert max(prim, stat, sign) < KKT_TOL
+    perm = np.random.default_rng(3).permutation(B)
+    dq_p, _, slack_p, status_p = ctrl.solve_batch(0.0, Q[perm], input_var=Y[perm])
+    assert np.array_equal(dq_p, dq[perm]) and np.array_equal(slack_p, slack[perm])
