@@ -263,10 +263,13 @@ class PseudoInverseController(BaseController):
         return tick
 
     def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008,
-                      max_speed=0.0):
+                      max_speed=0.0, virtual_var=None):
         """``len(time_vars)`` ticks of solve -> clamp(+-max_speed) -> Euler
         ``q += dq*dt`` in one launch (the host loop of
-        ur5_moe2016_example2.ipynb:537-545).  Returns (q_final, dq_last, mode_last)."""
+        ur5_moe2016_example2.ipynb:537-545).  Returns (q_final, dq_last, mode_last); for a
+        skill with virtual variables (path following, cart_on_track_1D...ipynb cell 60: pass
+        ``virtual_var``) the path parameters are integrated alongside, unclamped, and the result
+        is (q_final, x_final, dq_last, dx_last, mode_last)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -275,6 +278,28 @@ class PseudoInverseController(BaseController):
         if not was_np:
             Q = Q.clone()
         B = Q.shape[0]
+        if d.n_x > 0:
+            if virtual_var is None:
+                raise ValueError("skill has virtual_var: pass virtual_var")
+            X, x_np = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+            if not x_np:
+                X = X.clone()
+            Y = None
+            if d.n_y > 0:
+                Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+            times = np.asarray(time_vars, dtype=float).reshape(-1)
+            tt = np.concatenate([d.time_terms(t) for t in times]) if d.n_tslots else np.zeros(0)
+            tt, ttp = _capi.tterms_arg(tt)
+            dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+            dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev)
+            mode = torch.empty((B,), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                rc = self._lib.clik_pinv_rollout_batch_x(
+                    self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
+                    ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(mode), current_stream(dev))
+            _capi.check(self._lib, rc)
+            outs = (Q, X, dQ, dX, mode)
+            return tuple(o.cpu().numpy() for o in outs) if was_np else outs
         Y = None
         if d.n_y > 0:
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)

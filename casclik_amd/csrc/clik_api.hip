@@ -28,6 +28,8 @@ struct LaunchArgs {
     const WarmArgs* warm;
     int nq, nx, ny;
     int mode_parallel;
+    double* roll_x;         // (mirror of clik_pinv_kernels.hpp)
+    double* roll_dx;
 };
 int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
@@ -820,7 +822,7 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel};
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr};
     hipError_t e = h->jit_solve
                        ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
                        : clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
@@ -833,12 +835,24 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
                                        double max_speed, const double* tterms, double* q, const double* y,
                                        double* dq, int32_t* mode, void* stream)
 {
+    return clik_pinv_rollout_batch_x(hc, B, n_ticks, dt, max_speed, tterms, q, nullptr, y, dq, nullptr, mode, stream);
+}
+
+extern "C" int clik_pinv_rollout_batch_x(const clik_pinv* hc, int64_t B, int32_t n_ticks, double dt,
+                                         double max_speed, const double* tterms, double* q, double* x,
+                                         const double* y, double* dq, double* dx, int32_t* mode, void* stream)
+{
     clik_pinv* h = const_cast<clik_pinv*>(hc);
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
     if (B == 0 || n_ticks == 0) return CLIK_OK;
     const DevSkill& S = h->host;
-    if (S.d.n_x > 0) return fail(CLIK_EUNSUPPORTED, "rollout with virtual_var is not supported");
+    if (S.d.n_x > 0) {
+        if (!x || !dx) return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required (clik_pinv_rollout_batch_x)");
+        if (!h->jit_rollout && !(h->kernel >= 0 && clik::pinv_kernel_is_static(h->kernel)))
+            return fail(CLIK_EUNSUPPORTED, "the rollout of a skill with virtual_var needs a shape-specialised kernel "
+                                           "(none attached for this skill)");
+    }
     if (!h->jit_rollout && (h->kernel < 0 || !clik::pinv_kernel_is_static(h->kernel)) && skill_needs_static(S))
         return extern_needs_kernel("clik_pinv_rollout_batch");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
@@ -856,7 +870,7 @@ extern "C" int clik_pinv_rollout_batch(const clik_pinv* hc, int64_t B, int32_t n
                                       (hipStream_t)stream);
         if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
     }
-    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel};
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx};
     hipError_t e = h->jit_rollout
                        ? h->jit_rollout(&la, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
                                         (hipStream_t)stream)

@@ -1143,30 +1143,36 @@ template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B,
-    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed)
+    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed,
+    double* __restrict__ x, double* __restrict__ dx)
 {
+    // x / dx: virtual variables (path parameters, cart_on_track_1D...ipynb cells 56-60): integrated like the
+    // robot variables, never clamped; unused (null) in skills without them
     extern __shared__ double lds[];
     constexpr int N = SD.n;
+    constexpr int NX = SD.n_x, NQ = N - NX;
     const int lane = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * WAVE;
     const long long left = B - b0;
     const int rows_valid = left < WAVE ? (int)left : WAVE;
     const bool valid = lane < rows_valid;
     double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;
+    double* xs = zs + NQ * WAVE;
     double* ys = zs + N * WAVE;
     const Img<SD>* __restrict__ S = load_image<SD>(img_g, lds, lane);
     {
-        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
-        stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
+        if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
         if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
-        rows_to_lds<N>(qv, zs, lane);
+        rows_to_lds<NQ>(qv, zs, lane);
+        if constexpr (NX > 0) rows_to_lds<NX>(xv, xs, lane);
         if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     }
     __syncthreads();
     const int nts = S->n_tslots;
     double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    state_from_lds<NQ, NX>(zs, xs, lane, z);
     const Img<SD> Sreg = *S;                         // register copy, see pinv_solve_static_kernel
     __builtin_amdgcn_sched_barrier(0);
     double vout[N];
@@ -1184,21 +1190,21 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             double d = vout[j];
-            if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+            if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
             vout[j] = d;
             z[j] = fma(d, dt, z[j]);
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[lane * N + j] = z[j];
+    state_to_lds<NQ, NX>(z, zs, xs, lane);
     __syncthreads();
-    rows_from_lds<N>(q + b0 * N, rows_valid, zs, lane);
+    rows_from_lds<NQ>(q + b0 * NQ, rows_valid, zs, lane);
+    if constexpr (NX > 0) rows_from_lds<NX>(x + b0 * NX, rows_valid, xs, lane);
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[lane * N + j] = vout[j];
+    state_to_lds<NQ, NX>(vout, zs, xs, lane);
     __syncthreads();
-    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+    rows_from_lds<NQ>(dq + b0 * NQ, rows_valid, zs, lane);
+    if constexpr (NX > 0) rows_from_lds<NX>(dx + b0 * NX, rows_valid, xs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
@@ -1209,6 +1215,8 @@ struct LaunchArgs {
     const WarmArgs* warm;
     int nq, nx, ny;
     int mode_parallel;         // small batches: bit 0 two-wave mode scan, bit 1 role-split kernel
+    double* roll_x;            // rollout of a skill with virtual variables: their state (in/out) and last rates
+    double* roll_dx;
 };
 typedef hipError_t (*solve_fn)(const LaunchArgs&, const TickArgs&, long long, const double*, const double*,
                                const double*, double*, double*, int32_t*, hipStream_t);
@@ -1292,7 +1300,7 @@ inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tte
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL((pinv_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
-                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
+                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx);
     return hipGetLastError();
 }
 

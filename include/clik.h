@@ -215,6 +215,15 @@ int clik_pinv_rollout_batch(const clik_pinv* h, int64_t B, int32_t n_ticks,
                             double dt, double max_speed, const double* tterms,
                             double* q, const double* y, double* dq,
                             int32_t* mode, void* stream);
+/* The same for skills with virtual variables (path following: the loop of
+ * cart_on_track_1D_comparison_of_controllers.ipynb cell 60 integrates the path
+ * parameter next to the robot state): x [B][n_x] is updated in place like q,
+ * dx receives the last tick; the clamp applies to the robot velocities only.
+ * Needs a shape-specialised kernel (attached or AOT).                          */
+int clik_pinv_rollout_batch_x(const clik_pinv* h, int64_t B, int32_t n_ticks,
+                              double dt, double max_speed, const double* tterms,
+                              double* q, double* x, const double* y, double* dq,
+                              double* dx, int32_t* mode, void* stream);
 
 /* ---- ReactiveQPController path ----------------------------------------- */
 /* replaces setup_problem_functions()+setup_solver() (reactive_qp.py:248-298) */

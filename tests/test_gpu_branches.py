@@ -404,3 +404,34 @@ def test_nine_row_three_point_pose_error(ur5_fk, monkeypatch):
         cc.PseudoInverseController(skill_spec=spec).setup_problem_functions()
     with pytest.raises(NotImplementedError, match="exceeds the built-in kernel"):
         cc.ReactiveQPController(skill_spec=qspec).setup_problem_functions()
+
+
+def test_rollout_with_virtual_variable_matches_the_host_loop(ur5_fk, monkeypatch):
+    """Path following on the device (cart_on_track_1D...ipynb cell 60 integrates the path parameter next to
+    the robot state): n ticks of solve -> clamp(robot velocities) -> Euler on [q; s] in one launch against the
+    same loop over the oracle.  The built-in dynamic kernel cannot (loud refusal)."""
+    from oracle import clik_oracle
+    spec = _path_following_skill(ur5_fk)
+    rng = np.random.default_rng(5)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.2, size=(70, 6))
+    X = rng.uniform(0.0, 0.9, size=(70, 1))
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    dt, vmax, n_ticks = 0.01, 0.4, 40
+    ts = dt * np.arange(n_ticks)
+    qf, xf, dq_last, dx_last, mode = ctrl.rollout_batch(ts, Q, dt=dt, max_speed=vmax, virtual_var=X)
+    q, x = Q.copy(), X.copy()
+    for k in range(n_ticks):
+        r, rmode = clik_oracle.pinv_solve_batch(spec, None, ts[k], q, X=x)
+        dq, dx = np.clip(r[:, :6], -vmax, vmax), r[:, 6:]
+        q, x = q + dq * dt, x + dx * dt
+    assert np.array_equal(mode, rmode)
+    assert np.abs(qf - q).max() < 1e-8 and np.abs(xf - x).max() < 1e-8
+    assert np.abs(dq_last - dq).max() < 1e-7 and np.abs(dx_last - dx).max() < 1e-7
+    assert np.abs(xf - X - 0.05 * dt * n_ticks).max() < 1e-6        # the path parameter advanced at its set rate
+    monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    dyn = cc.PseudoInverseController(skill_spec=spec)
+    dyn.setup_problem_functions()
+    with pytest.raises(NotImplementedError, match="shape-specialised kernel"):
+        dyn.rollout_batch(ts, Q, dt=dt, max_speed=vmax, virtual_var=X)
