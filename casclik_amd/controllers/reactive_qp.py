@@ -343,11 +343,13 @@ class ReactiveQPController(BaseController):
                     None if status is None else status.cpu().numpy())
         return dQ, dX, SL, status
 
-    def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008, max_speed=0.0):
+    def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008, max_speed=0.0, virtual_var=None):
         """``len(time_vars)`` ticks of QP solve -> clamp(+-max_speed) -> Euler ``q += dq*dt`` in
         one launch, the working set hot-started from tick to tick (the host loop of
         ur5_moe2016_example2.ipynb:537-545 for this controller).  Returns
-        (q_final, dq_last, slack_last | None, status [B] = worst status met)."""
+        (q_final, dq_last, slack_last | None, status [B] = worst status met); for a skill with
+        virtual variables (pass ``virtual_var``; cart_on_track_1D...ipynb cell 60) they are integrated
+        alongside, unclamped: (q_final, x_final, dq_last, dx_last, slack_last | None, status)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -356,6 +358,14 @@ class ReactiveQPController(BaseController):
         if not was_np:
             Q = Q.clone()
         B = Q.shape[0]
+        X = dX = None
+        if d.n_x > 0:
+            if virtual_var is None:
+                raise ValueError("skill has virtual_var: pass virtual_var")
+            X, x_np = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
+            if not x_np:
+                X = X.clone()
+            dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev)
         Y = None
         if d.n_y > 0:
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
@@ -366,14 +376,14 @@ class ReactiveQPController(BaseController):
         SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            rc = self._lib.clik_qp_rollout_batch(
+            rc = self._lib.clik_qp_rollout_batch_x(
                 self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
-                ptr(Q), ptr(Y), ptr(dQ), ptr(SL), ptr(status), current_stream(dev))
+                ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(SL), ptr(status), current_stream(dev))
         _capi.check(self._lib, rc)
+        outs = (Q, dQ, SL, status) if X is None else (Q, X, dQ, dX, SL, status)
         if was_np:
-            return (Q.cpu().numpy(), dQ.cpu().numpy(), None if SL is None else SL.cpu().numpy(),
-                    status.cpu().numpy())
-        return Q, dQ, SL, status
+            return tuple(None if o is None else o.cpu().numpy() for o in outs)
+        return outs
 
     def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None, hot_start=False):
         """Pre-bind device tensors and return ``tick(time_var=0.0)``: one kernel

@@ -57,7 +57,7 @@ hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long l
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream);
 hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
                                     double max_speed, long long B, double* q, const double* y, double* dq,
-                                    double* slack, int32_t* status, hipStream_t stream);
+                                    double* slack, int32_t* status, double* x, double* dx, hipStream_t stream);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -88,7 +88,8 @@ typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, co
                                      const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
 
 typedef hipError_t (*clik_jit_qp_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
-                                             const double*, double*, double*, int32_t*, hipStream_t);
+                                             const double*, double*, double*, int32_t*, double*, double*,
+                                             hipStream_t);
 
 struct clik_qp {
     DevSkill  host;
@@ -1022,12 +1023,21 @@ extern "C" int clik_qp_rollout_batch(const clik_qp* hc, int64_t B, int32_t n_tic
                                      const double* tterms, double* q, const double* y, double* dq,
                                      double* slack, int32_t* status, void* stream)
 {
+    return clik_qp_rollout_batch_x(hc, B, n_ticks, dt, max_speed, tterms, q, nullptr, y, dq, nullptr, slack, status,
+                                   stream);
+}
+
+extern "C" int clik_qp_rollout_batch_x(const clik_qp* hc, int64_t B, int32_t n_ticks, double dt, double max_speed,
+                                       const double* tterms, double* q, double* x, const double* y, double* dq,
+                                       double* dx, double* slack, int32_t* status, void* stream)
+{
     clik_qp* h = const_cast<clik_qp*>(hc);
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
     if (B == 0 || n_ticks == 0) return CLIK_OK;
     const DevSkill& S = h->host;
-    if (S.d.n_x > 0) return fail(CLIK_EUNSUPPORTED, "rollout with virtual_var is not supported");
+    if (S.d.n_x > 0 && (!x || !dx))
+        return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required (clik_qp_rollout_batch_x)");
     if (!h->jit_rollout && h->static_k < 0)
         return fail(CLIK_EUNSUPPORTED, "the QP rollout needs a shape-specialised kernel (none attached for this skill)");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
@@ -1047,9 +1057,10 @@ extern "C" int clik_qp_rollout_batch(const clik_qp* hc, int64_t B, int32_t n_tic
     }
     hipError_t e = h->jit_rollout
                        ? h->jit_rollout(h->d_img, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack,
-                                        status, (hipStream_t)stream)
+                                        status, x, dx, (hipStream_t)stream)
                        : clik::qp_launch_rollout_static(h->static_k, h->d_img, h->d_tterms, n_ticks, dt, max_speed,
-                                                        (long long)B, q, y, dq, slack, status, (hipStream_t)stream);
+                                                        (long long)B, q, y, dq, slack, status, x, dx,
+                                                        (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_rollout_kernel launch");
     return CLIK_OK;
 }

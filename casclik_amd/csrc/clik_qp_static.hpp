@@ -892,13 +892,15 @@ template <const ShapeDesc& SD>
 __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed)
+    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed,
+    double* __restrict__ x, double* __restrict__ dx)
 {
+    // x / dx: virtual variables, integrated like the robot variables and never clamped (null without them)
     extern __shared__ double lds[];
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
+    constexpr int NX = SD.n_x, NQ = N - NX;
     constexpr int NS = LY::NS;
-    static_assert(SD.n_x == 0, "the rollout integrates robot variables only");
     const int lane = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * WAVE;
     const long long left = B - b0;
@@ -913,13 +915,15 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
         const d2* src = (const d2*)img_g;
 #pragma unroll
         for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
-        double qv[N], yv[SD.n_y > 0 ? SD.n_y : 1];
-        stage_load<N>(q + b0 * N, N, rows_valid, lane, qv);
+        double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
+        stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
+        if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
         if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
         d2* dst = (d2*)lds;
 #pragma unroll
         for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
-        rows_to_lds<N>(qv, zs, lane);
+        rows_to_lds<NQ>(qv, zs, lane);
+        if constexpr (NX > 0) rows_to_lds<NX>(xv, zs + NQ * WAVE, lane);
         if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     }
     __syncthreads();
@@ -927,9 +931,9 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
     const QpTail* __restrict__ T = (const QpTail*)((const char*)lds + LY::TAIL_OFF);
     const int nts = S->n_tslots;
     const double* ysl = ys + lane * SD.n_y;
+    double* xs = zs + NQ * WAVE;
     double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[lane * N + j];
+    state_from_lds<NQ, NX>(zs, xs, lane, z);
     double v[N], sl[LY::NSA];
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] = 0.0;
@@ -947,20 +951,24 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             double d = v[j];
-            if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+            if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
             v[j] = d;
             z[j] = okl ? fma(d, dt, z[j]) : z[j];
         }
     }
     const double bad = (worst == 2) ? __builtin_nan("") : 0.0;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[lane * N + j] = z[j];
+    state_to_lds<NQ, NX>(z, zs, xs, lane);
     __syncthreads();
-    rows_from_lds<N>(q + b0 * N, rows_valid, zs, lane);
+    rows_from_lds<NQ>(q + b0 * NQ, rows_valid, zs, lane);
+    if constexpr (NX > 0) rows_from_lds<NX>(x + b0 * NX, rows_valid, xs, lane);
     __syncthreads();
+    {
+        double vb[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) zs[lane * N + j] = v[j] + bad;
+        for (int j = 0; j < N; ++j) vb[j] = v[j] + bad;
+        state_to_lds<NQ, NX>(vb, zs, xs, lane);
+    }
     if constexpr (NS > 0) {
         double* so = slots + LY::O_SL * WAVE;
         if (slack_out != nullptr) {
@@ -969,7 +977,8 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
         }
     }
     __syncthreads();
-    rows_from_lds<N>(dq + b0 * N, rows_valid, zs, lane);
+    rows_from_lds<NQ>(dq + b0 * NQ, rows_valid, zs, lane);
+    if constexpr (NX > 0) rows_from_lds<NX>(dx + b0 * NX, rows_valid, xs, lane);
     if constexpr (NS > 0) {
         if (slack_out != nullptr) rows_from_lds<NS>(slack_out + b0 * NS, rows_valid, slots + LY::O_SL * WAVE, lane);
     }
@@ -977,16 +986,16 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
 }
 
 typedef hipError_t (*qp_static_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
-                                           const double*, double*, double*, int32_t*, hipStream_t);
+                                           const double*, double*, double*, int32_t*, double*, double*, hipStream_t);
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_qp_rollout_static(const void* d_img, const double* d_tterms, int n_ticks, double dt,
                                            double max_speed, long long B, double* q, const double* y, double* dq,
-                                           double* slack, int32_t* status, hipStream_t stream)
+                                           double* slack, int32_t* status, double* x, double* dx,
+                                           hipStream_t stream)
 {
-    if constexpr (SD.n_x != 0) {
-        return hipErrorNotSupported;
-    } else {
+    if (SD.n_x != 0 && (x == nullptr || dx == nullptr)) return hipErrorInvalidValue;
+    {
         const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
         constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
         if (shmem > 64 * 1024) {
@@ -995,7 +1004,7 @@ inline hipError_t launch_qp_rollout_static(const void* d_img, const double* d_tt
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL((qp_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
-                           status, B, d_tterms, n_ticks, dt, max_speed);
+                           status, B, d_tterms, n_ticks, dt, max_speed, x, dx);
         return hipGetLastError();
     }
 }

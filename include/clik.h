@@ -267,6 +267,11 @@ int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms,
 int clik_qp_rollout_batch(const clik_qp* h, int64_t B, int32_t n_ticks, double dt,
                           double max_speed, const double* tterms, double* q, const double* y,
                           double* dq, double* slack, int32_t* status, void* stream);
+/* ... and for skills with virtual variables (see clik_pinv_rollout_batch_x).      */
+int clik_qp_rollout_batch_x(const clik_qp* h, int64_t B, int32_t n_ticks,
+                            double dt, double max_speed, const double* tterms,
+                            double* q, double* x, const double* y, double* dq,
+                            double* dx, double* slack, int32_t* status, void* stream);
 
 /* QP data only (H diag, A, lbA, ubA as the reference's H_func/A_func/Blb/Bub,
  * reactive_qp.py:283-298) for inspection and parity tests:

@@ -435,3 +435,28 @@ def test_rollout_with_virtual_variable_matches_the_host_loop(ur5_fk, monkeypatch
     dyn.setup_problem_functions()
     with pytest.raises(NotImplementedError, match="shape-specialised kernel"):
         dyn.rollout_batch(ts, Q, dt=dt, max_speed=vmax, virtual_var=X)
+
+
+def test_qp_rollout_with_virtual_variable_matches_the_host_loop(ur5_fk):
+    """The same path-following loop through ReactiveQPController (clik_qp_rollout_batch_x): robot state and
+    path parameter integrated on the device, working set carried between ticks."""
+    from oracle import clik_oracle
+    spec = _path_following_skill(ur5_fk)
+    rng = np.random.default_rng(6)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.2, size=(40, 6))
+    X = rng.uniform(0.1, 0.8, size=(40, 1))
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    dt, vmax, n_ticks = 0.01, 0.4, 30
+    ts = dt * np.arange(n_ticks)
+    qf, xf, dq_last, dx_last, slack, status = ctrl.rollout_batch(ts, Q, dt=dt, max_speed=vmax, virtual_var=X)
+    q, x = Q.copy(), X.copy()
+    for k in range(n_ticks):
+        rdq, rdx, rsl, rst = clik_oracle.qp_solve_batch(spec, ts[k], q, X=x)
+        assert (rst == 0).all()
+        q, x = q + np.clip(rdq, -vmax, vmax) * dt, x + rdx * dt
+    assert (status == 0).all()
+    assert np.abs(qf - q).max() < 1e-7 and np.abs(xf - x).max() < 1e-7
+    assert np.abs(dx_last - rdx).max() < 1e-7 and np.abs(slack - rsl).max() < 1e-6
