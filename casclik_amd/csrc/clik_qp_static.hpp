@@ -102,12 +102,13 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
     uint32_t W = softeq, up = 0u, eq = 0u;
     // Violations are measured relative to max(1, |bound|) of the bound in question, not of the row (a
     // one-sided SetConstraint carries the reference's default 1e10 on its other side, constraints.py:199-206:
-    // a common scale per row would hide the violation of the real bound).  Up to 8 rows the two scales per
-    // row live in registers; larger working sets need those registers for the factor and recompute the
-    // scale from the bound they read anyway (v_rcp_f64: ranking and a 1e-11 threshold do not need more).
+    // a common scale per row would hide the violation of the real bound).  The scale is recomputed from the
+    // bound the scan reads anyway (v_rcp_f64: ranking and a 1e-11 threshold do not need more); keeping the two
+    // scales per row in registers instead (CLIK_QP_SCALE_REGS_MAX = rows up to which to do so) measured
+    // 0.3-0.5 us slower per tick on config 4 (cold, hot and rollout) and spills beyond 8 rows.
     constexpr double kVtol = 1e-11;
 #ifndef CLIK_QP_SCALE_REGS_MAX
-#define CLIK_QP_SCALE_REGS_MAX 8
+#define CLIK_QP_SCALE_REGS_MAX 0
 #endif
     constexpr bool kScaleRegs = NC <= CLIK_QP_SCALE_REGS_MAX;
     double isl[kScaleRegs ? NC : 1], ish[kScaleRegs ? NC : 1];
