@@ -173,7 +173,16 @@ class ReactiveQPController(BaseController):
         if self.kernel_name in ("dynamic", "none") and want_jit:
             from .. import jit
             with torch.cuda.device(self._device):
-                name = jit.attach_qp(self._lib, handle, cdesc, extern=d.extern_source())
+                try:
+                    name = jit.attach_qp(self._lib, handle, cdesc, extern=d.extern_source())
+                except RuntimeError as exc:
+                    # (a failed instantiation is not fatal when a built-in kernel serves the skill: say so
+                    # and run that one - still the GPU path; skills only instantiated kernels can serve
+                    # fail below)
+                    import warnings
+                    warnings.warn("run-time kernel instantiation failed, using the built-in dynamic-shape "
+                                  "kernel: %s" % str(exc)[:400])
+                    name = None
             if name:
                 self.kernel_name = name
         if d.extern_code and not self.kernel_name.startswith("jit_"):
