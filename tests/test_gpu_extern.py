@@ -225,3 +225,26 @@ def test_notebook_golden_vectors(ur5_fk):
     pc.setup_problem_functions()
     dq, _, mode = pc.solve_batch(0.0, g["ur5_Q"])
     assert np.array_equal(mode, g["dq_pinv_mode"]) and _rel(dq, g["dq_pinv_dq"]).max() < PINV_RTOL
+
+
+def test_failed_instantiation_is_loud_and_falls_back_only_where_a_builtin_kernel_can_serve(ur5_fk, monkeypatch):
+    """A broken hipcc invocation at setup: a row-table skill runs on the built-in dynamic kernel (with a
+    warning) and still matches the oracle; a skill with generated constraints has no other kernel and fails."""
+    from oracle import clik_oracle
+    monkeypatch.setenv("CLIK_JIT_DEFINES", "-fthis-flag-does-not-exist-%d" % os.getpid())
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
+    T = ur5_fk["T_fk"](q)
+    spec = cc.SkillSpecification("plain", t, q, constraints=[
+        cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.35, 0.15, 0.45]), gain=1.7, priority=1),
+        cc.SetConstraint("wrist", q[4], set_min=-0.3, set_max=0.3, priority=0)])
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    with pytest.warns(UserWarning, match="instantiation failed"):
+        ctrl.setup_problem_functions()
+    assert ctrl.kernel_name == "dynamic"
+    Q, _ = skills.synthetic_inputs(ur5_fk, 100, seed=3)
+    dq, _, mode = ctrl.solve_batch(0.0, 0.3 * Q)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, 0.3 * Q)
+    assert np.array_equal(mode, rmode) and _rel(dq, ref).max() < PINV_RTOL
+    with pytest.warns(UserWarning, match="instantiation failed"):
+        with pytest.raises(NotImplementedError, match="generated device code"):
+            cc.ReactiveQPController(skill_spec=double_pendulum_skill(False)).setup_problem_functions()
