@@ -421,7 +421,10 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
     // Safety net (the oracle and qpOASES have the same): the point must satisfy every row.  An
     // infeasible problem whose working set became numerically dependent can leave the loop
     // "optimal" with violated rows; that is status 2, never a silent wrong answer.
-    if (__ballot(status == 0 && lane_valid) != 0ull) {
+#ifndef CLIK_QP_NU_NET
+#define CLIK_QP_NU_NET 1
+#endif
+    if (CLIK_QP_NU_NET && __ballot(status == 0 && lane_valid) != 0ull) {
         double cc[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) cc[i] = (c0s != nullptr && (EXACT || i < nc)) ? c0s[i * WAVE + lane] : 0.0;
