@@ -148,3 +148,53 @@ def test_what_generated_code_cannot_express_is_refused():
     many.append(cc.EqualityConstraint("prod", q[0] * q[1], priority=9))
     with pytest.raises(NotImplementedError, match="generated device code"):
         lower_skill(cc.SkillSpecification("s", t, q, constraints=many))
+
+
+def _random_expression(rng, leaves, depth):
+    """Random smooth expression over the leaves (division and sqrt guarded away from singularities)."""
+    if depth == 0 or rng.random() < 0.15:
+        leaf = leaves[int(rng.integers(len(leaves)))]
+        return leaf if rng.random() < 0.8 else leaf * float(rng.uniform(-2.0, 2.0))
+    op = int(rng.integers(10))
+    a = _random_expression(rng, leaves, depth - 1)
+    if op <= 3:
+        b = _random_expression(rng, leaves, depth - 1)
+        return [a + b, a - b, a * b, a / (2.5 + cs.sin(b))][op]
+    if op == 4:
+        return cs.sin(a)
+    if op == 5:
+        return cs.cos(a)
+    if op == 6:
+        return cs.sqrt(1.0 + a * a)
+    if op == 7:
+        return cs.exp(-(a * a) / (1.0 + a * a))
+    if op == 8:
+        return a ** int(rng.integers(2, 4))
+    return cs.norm_2(cs.vertcat(a, 0.7, _random_expression(rng, leaves, depth - 1)))
+
+
+def test_random_expression_trees(tmp_path):
+    """Property test of the generator: random expression trees over robot, virtual, input and time
+    variables (and tool-frame entries), generated code against the oracle's dual numbers."""
+    fk = skills.ur5()
+    rng = np.random.default_rng(2024)
+    for trial in range(16):
+        t, q, x, y = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("x", 2), cs.MX.sym("y", 2)
+        T = fk["T_fk"](q)
+        leaves = [q[i] for i in range(6)] + [x[0], x[1], y[0], y[1], t, cs.sin(0.3 * t)]
+        if trial % 2 == 0:
+            leaves += [T[0, 3], T[1, 3], T[2, 3], T[0, 0], T[1, 2], T[2, 1]]
+        rows = []
+        while len(rows) < 3:
+            e = _random_expression(rng, leaves, 4)
+            if isinstance(e, cs.MX) and not e.is_constant():
+                rows.append(e)
+        cn = [cc.EqualityConstraint("rand", cs.vertcat(*rows), gain=1.0),
+              cc.EqualityConstraint("anchor", q - 0.1, priority=5)]
+        spec = cc.SkillSpecification("rand%d" % trial, t, q, virtual_var=x, input_var=y, constraints=cn)
+        d = lower_skill(spec)
+        if 0 not in d.extern_code:
+            continue                                   # (the draw happened to be affine)
+        lib = _compile(d, tmp_path)
+        Z = np.concatenate([rng.uniform(-1.2, 1.2, size=(6, 6)), rng.uniform(-1, 1, size=(6, 2))], axis=1)
+        _check(spec, d, lib, 0.9, Z, rng.uniform(-1, 1, size=(6, 2)), fk=fk if d.uses_fk else None, tol=1e-10)
