@@ -94,3 +94,28 @@ def dual_quaternion_skill(fk, which="Q_dist2", for_pinv=False):
               cc.VelocitySetConstraint(label="Joint_speed_limits", expression=q,
                                        set_min=-cs.vertcat([max_speed] * 6), set_max=cs.vertcat([max_speed] * 6))]
     return cc.SkillSpecification(label=which, time_var=t, robot_var=q, robot_vel_var=dq, constraints=cn)
+
+
+def random_expression(rng, leaves, depth):
+    """Random smooth expression over the leaves (division and sqrt guarded away from singularities)."""
+    if depth == 0 or rng.random() < 0.15:
+        leaf = leaves[int(rng.integers(len(leaves)))]
+        return leaf if rng.random() < 0.8 else leaf * float(rng.uniform(-2.0, 2.0))
+    op = int(rng.integers(10))
+    a = random_expression(rng, leaves, depth - 1)
+    if op <= 3:
+        b = random_expression(rng, leaves, depth - 1)
+        return [a + b, a - b, a * b, a / (2.5 + cs.sin(b))][op]
+    if op == 4:
+        return cs.sin(a)
+    if op == 5:
+        return cs.cos(a)
+    if op == 6:
+        return cs.sqrt(1.0 + a * a)
+    if op == 7:
+        return cs.exp(-(a * a) / (1.0 + a * a))
+    if op == 8:
+        return a ** int(rng.integers(2, 4))
+    return cs.norm_2(cs.vertcat(a, 0.7, random_expression(rng, leaves, depth - 1)))
+
+

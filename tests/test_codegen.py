@@ -16,7 +16,7 @@ import casclik_amd as cc
 from casclik_amd import sym as cs, skills
 from casclik_amd.lowering import lower_skill, OUT_EXTERN, OUT_AFFINE
 from oracle import clik_oracle
-from extern_skills import double_pendulum_skill, mixed_frame_skill
+from extern_skills import double_pendulum_skill, mixed_frame_skill, random_expression as _random_expression
 
 HARNESS = r"""
 #include <cmath>
@@ -148,29 +148,6 @@ def test_what_generated_code_cannot_express_is_refused():
     many.append(cc.EqualityConstraint("prod", q[0] * q[1], priority=9))
     with pytest.raises(NotImplementedError, match="generated device code"):
         lower_skill(cc.SkillSpecification("s", t, q, constraints=many))
-
-
-def _random_expression(rng, leaves, depth):
-    """Random smooth expression over the leaves (division and sqrt guarded away from singularities)."""
-    if depth == 0 or rng.random() < 0.15:
-        leaf = leaves[int(rng.integers(len(leaves)))]
-        return leaf if rng.random() < 0.8 else leaf * float(rng.uniform(-2.0, 2.0))
-    op = int(rng.integers(10))
-    a = _random_expression(rng, leaves, depth - 1)
-    if op <= 3:
-        b = _random_expression(rng, leaves, depth - 1)
-        return [a + b, a - b, a * b, a / (2.5 + cs.sin(b))][op]
-    if op == 4:
-        return cs.sin(a)
-    if op == 5:
-        return cs.cos(a)
-    if op == 6:
-        return cs.sqrt(1.0 + a * a)
-    if op == 7:
-        return cs.exp(-(a * a) / (1.0 + a * a))
-    if op == 8:
-        return a ** int(rng.integers(2, 4))
-    return cs.norm_2(cs.vertcat(a, 0.7, _random_expression(rng, leaves, depth - 1)))
 
 
 def test_random_expression_trees(tmp_path):

@@ -22,6 +22,7 @@ import casclik_amd as cc                             # noqa: E402
 from casclik_amd import skills, sym as cs            # noqa: E402
 from oracle import clik_oracle, c_oracle             # noqa: E402
 from tolerances import PINV_RTOL                     # noqa: E402
+from extern_skills import random_expression         # noqa: E402
 
 
 def random_skill(rng, fk, n):
@@ -85,6 +86,10 @@ def random_skill(rng, fk, n):
                                             set_min=np.concatenate([[0.1, -0.4, 0.1], -0.9 * np.ones(3), 0.28 * lo[jw]]),
                                             set_max=np.concatenate([[0.6, 0.4, 0.7], 0.9 * np.ones(3), 0.28 * hi[jw]]),
                                             gain=gain(6 + len(jw)), priority=pr))
+    # random smooth expression trees of the joints, the tool position and time (generated code)
+    leaves = [q[j] for j in range(n)] + [p[0], p[1], p[2], T[2, 2], cs.sin(0.5 * t)]
+    rexpr = cs.vertcat(random_expression(rng, leaves, 3), random_expression(rng, leaves, 3))
+    pool.append(lambda pr: cc.EqualityConstraint("tree", rexpr - np.array([0.3, -0.2]), gain=gain(2), priority=pr))
     nt = int(rng.integers(2, 6))
     picks = rng.choice(len(pool), size=nt, replace=False)
     prios = rng.permutation(nt)
