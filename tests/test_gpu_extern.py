@@ -248,3 +248,45 @@ def test_failed_instantiation_is_loud_and_falls_back_only_where_a_builtin_kernel
     with pytest.warns(UserWarning, match="instantiation failed"):
         with pytest.raises(NotImplementedError, match="generated device code"):
             cc.ReactiveQPController(skill_spec=double_pendulum_skill(False)).setup_problem_functions()
+
+
+def test_generated_constraints_in_every_constraint_class(iiwa_fk):
+    """Generated rows as a multidimensional SetConstraint (activation matrix S, pseudo_inverse.py:289-298),
+    as the converging final set (:337-379), as a VelocityEqualityConstraint and as a VelocitySetConstraint
+    (QP only: the pinv controller skips it), next to table rows."""
+    from oracle import clik_oracle
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 7)
+    T = iiwa_fk["T_fk"](q)
+    p = T[:3, 3]
+    reach = cc.SetConstraint("reach", cs.vertcat(cs.dot(p, p), cs.sin(q[0]) * q[1]), set_min=np.array([0.15, -0.2]),
+                             set_max=np.array([0.45, 0.2]), gain=1.5, priority=0)
+    swirl = cc.VelocityEqualityConstraint("swirl", cs.cos(q[2]) * q[3] + 0.1 * cs.sin(t), target=0.05, priority=1)
+    pos = cc.EqualityConstraint("pos", p - np.array([0.4, 0.1, 0.5]), gain=2.0, priority=2, constraint_type="soft")
+    rest = cc.EqualityConstraint("rest", q - 0.2, gain=0.2, priority=3, constraint_type="soft")
+    rate = cc.VelocitySetConstraint("rate", cs.vertcat(p[0] * p[1], q[5] * q[6]), set_min=-0.1 * np.ones(2),
+                                    set_max=0.1 * np.ones(2), priority=4)
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 600, seed=15)
+    Q = 0.6 * Q
+    for cons, opts in (([reach, swirl, pos, rest, rate], {"multidim_sets": True}),
+                       ([swirl, pos, rest, reach], {"multidim_sets": True, "converge_final_set_to_max": True})):
+        reach.priority = 0 if cons[0] is reach else 9
+        spec = cc.SkillSpecification("classes", t, q, constraints=cons)
+        ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
+        ctrl.setup_problem_functions()
+        assert ctrl.kernel_name.startswith("jit_")
+        dq, _, mode = ctrl.solve_batch(0.6, Q)
+        ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, 0.6, Q)
+        assert np.array_equal(mode, rmode) and len(np.unique(mode)) >= 2
+        assert _rel(dq, ref).max() < PINV_RTOL, _rel(dq, ref).max()
+    reach.priority = 0
+    reach.constraint_type = "soft"
+    qspec = cc.SkillSpecification("classes_qp", t, q, constraints=[reach, swirl, pos, rest, rate])
+    qc = cc.ReactiveQPController(skill_spec=qspec)
+    qc.setup_problem_functions()
+    qc.setup_solver()
+    assert qc.kernel_name.startswith("jit_")
+    qdq, _, qsl, st = qc.solve_batch(0.6, Q)
+    rdq, _, rsl, rst = clik_oracle.qp_solve_batch(qspec, 0.6, Q)
+    assert np.array_equal(st, rst)
+    ok = rst == 0
+    assert ok.sum() > 300 and _rel(qdq[ok], rdq[ok]).max() < 1e-7
