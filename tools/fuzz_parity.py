@@ -157,6 +157,11 @@ def main():
             # stack): how far the two CPU evaluations of the same algorithm are from each other
             cdq = np.hstack([out[0]] + ([out[1]] if out[1] is not None and np.ndim(out[1]) == 2 else []))
             lane_gap = np.abs(cdq - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+            # ... and how far the numpy oracle's own answer moves when q moves by a few ulps (the two CPU
+            # oracles share their arithmetic - pivoted elimination - so their distance alone underestimates
+            # the noise floor of an ill-conditioned stack; the kernels factor without pivoting)
+            ref_p, _ = clik_oracle.pinv_solve_batch(spec, opts, tval, Q * (1.0 + 1e-15), Y=Y)
+            lane_gap = np.maximum(lane_gap, np.abs(ref_p - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1)))
             sane &= lane_gap < 1e-8          # lanes where even the CPU evaluations part ways are no parity evidence
             cpu_gap = float(lane_gap[sane].max()) if sane.any() else 0.0
         else:
