@@ -160,8 +160,9 @@ def main():
             # ... and how far the numpy oracle's own answer moves when q moves by a few ulps (the two CPU
             # oracles share their arithmetic - pivoted elimination - so their distance alone underestimates
             # the noise floor of an ill-conditioned stack; the kernels factor without pivoting)
-            ref_p, _ = clik_oracle.pinv_solve_batch(spec, opts, tval, Q * (1.0 + 1e-15), Y=Y)
-            lane_gap = np.maximum(lane_gap, np.abs(ref_p - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1)))
+            for eps in (1e-15, -1e-15, 3e-15):      # (one sample is a noisy estimate of a lane's sensitivity)
+                ref_p, _ = clik_oracle.pinv_solve_batch(spec, opts, tval, Q * (1.0 + eps), Y=Y)
+                lane_gap = np.maximum(lane_gap, np.abs(ref_p - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1)))
             sane &= lane_gap < 1e-8          # lanes where even the CPU evaluations part ways are no parity evidence
             cpu_gap = float(lane_gap[sane].max()) if sane.any() else 0.0
         else:
