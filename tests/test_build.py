@@ -62,3 +62,32 @@ def test_shape_of_the_config3_stack():
     cons.append(cc.EqualityConstraint("c", q - 0.1, priority=9))
     rc4, _ = _describe(lib, cc.SkillSpecification("many", t, q, constraints=cons), dict(opts, multidim_sets=False))
     assert rc4 == 0
+
+
+def test_instantiated_notebook_qp_kernel_has_no_scratch(tmp_path):
+    """The kernel instantiated for the dual-quaternion notebook QP (generated 8-row error, joint limits and
+    speed limits merged into six box rows) must stay in registers: 12 separate rows spilled 784 B per lane."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from extern_skills import dual_quaternion_skill
+    from casclik_amd import jit
+    from casclik_amd.build import parse_resource_remarks, FLAGS
+    hipcc = jit._hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    lib = _capi.load_library()
+    d = lower_skill(dual_quaternion_skill(skills.ur5(), "Q_dist2"))
+    cdesc = _capi.desc_to_c(d)
+    buf = C.create_string_buffer(16384)
+    assert lib.clik_qp_shape_describe(C.byref(cdesc), buf, len(buf)) == 1
+    src = tmp_path / "dq_qp.hip"
+    src.write_text(jit._QP_TEMPLATE % {"init": buf.value.decode(), "extern": d.extern_source()})
+    out = subprocess.run([hipcc] + FLAGS + ["-c", str(src), "-o", str(tmp_path / "dq_qp.o")],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()[-2000:]
+    res = parse_resource_remarks(out.stdout.decode())
+    kernels = {k: v for k, v in res.items() if "qp_solve_static_kernel" in k or "qp_rollout_static_kernel" in k}
+    assert len(kernels) == 2
+    for name, r in kernels.items():
+        assert r["ScratchSize"] == 0, (name, r)
