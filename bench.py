@@ -5,22 +5,37 @@
 
 A *step* is one controller tick over the whole batch resident in HBM (one
 kernel launch per tick per GPU).  `value` = instance-steps per second =
-(N * batch * K) / time, the BASELINE.json metric "CLIK steps/sec (whole
+(N * batch * steps timed) / time, the BASELINE.json metric "CLIK steps/sec (whole
 node), 7-DoF 3-task priority stack, batch 16384" (batch is per GPU: weak
 scaling, as in BASELINE config 5 = 131072 instances over 8 GPUs).
 
 The JSON line also carries
   roofline      algorithmic HBM bytes (q 56 B + target 56 B +
-                dq 56 B + mode 4 B per instance-step) over the mean kernel
+                dq 56 B + mode 4 B per instance-step) over the kernel
                 duration from HIP events on the launch stream, vs 8 TB/s
   cpu_baseline  the C restatement of the reference algorithm (oracle/, kind
                 "port") timed on this host's cores on a bounded sample
+
+Timing protocol: W untimed warm-up steps, then an untimed, time-based clock ramp
+(--ramp-ms of replays: a fresh GPU needs ~100 ms of work before its clocks
+settle, which a 20-step run never reaches), then R back-to-back replays of the
+K-step hipGraph inside ONE barrier + synchronize bracket.  `ms_per_step` =
+bracket wall time / (R*K) (max over ranks), `value` = instances * R * K / wall;
+`roofline.kernel_us` = median over the R replays of (HIP-event time of one
+replay / K).  R is chosen so that the bracket holds >= --min-timed-ms of work
+and >= 50 replays; R and R*K are stated in `config`.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (torch.distributed.run on 127.0.0.1) BEFORE anything touches a GPU and
+relays rank 0's JSON line; with fewer than N visible devices it exits non-zero.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TF = 78.6       # half of the 157.3 TF fp32 vector peak
-ALG_FLOP_PER_STEP = {"stack": 7.5e3, "pose": 2.9e3, "qp": 6.0e3}
+PROFILE_FILES = ("r2_counters.json", "r1_traffic.json")     # newest first
 
 
 def parse():
@@ -54,9 +66,35 @@ def parse():
                          "SURVEY.md 8(d) 'launch-amortised'); steps must be a multiple of K")
     ap.add_argument("--qp-hot", type=int, default=0,
                     help="qp workload: carry each instance's working set from tick to tick (hot start)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="lanes per robot instance of the pinv kernel: 0 = the library's choice, 1 = "
+                         "lane-per-instance kernels only, 4 / 8 / 16 = the multi-lane kernel (CLIK_LANES)")
+    ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp before the timed region")
+    ap.add_argument("--min-timed-ms", type=float, default=60.0, help="least work inside the timed bracket")
+    ap.add_argument("--replays", type=int, default=0, help="R (0: from --min-timed-ms, at least 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a launcher: become the launcher.  Nothing here initialises a GPU
+    (torch.cuda.device_count() only counts), and the ranks are fresh child processes."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; not running fewer ranks "
+                         "under that label\n" % (args.gpus, n))
+        sys.exit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def make_workload(name, fk):
@@ -77,16 +115,32 @@ def make_workload(name, fk):
 
 
 def cpu_baseline(workload, spec, opts, Q, Y, seconds):
-    """Time the C restatement (oracle/clik_oracle_c.c) on the host cores this
-    process may use; the thread count with the best throughput is reported."""
-    from oracle import c_oracle
-    if workload == "qp":
-        return None
-    co = c_oracle.CPinvOracle(spec, opts)
+    """Time the CPU restatement on the host cores this process may use.  Pseudo-inverse
+    workloads: the C restatement (oracle/clik_oracle_c.c, OpenMP over instances; the thread
+    count with the best throughput is reported).  QP: the numpy restatement (one core)."""
+    import numpy as np
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    if workload == "qp":
+        from oracle import clik_oracle
+        n = min(len(Q), 256)
+        t0 = time.perf_counter()
+        clik_oracle.qp_solve_batch(spec, 0.0, Q[:n], Y=Y[:n])
+        one = time.perf_counter() - t0
+        reps = max(1, min(50, int(seconds / max(one, 1e-6)) - 1))
+        t0 = time.perf_counter()
+        for k in range(reps):
+            lo = (k * n) % max(1, len(Q) - n + 1)
+            clik_oracle.qp_solve_batch(spec, 0.0, Q[lo:lo + n], Y=Y[lo:lo + n])
+        el = time.perf_counter() - t0
+        return {"value": n * reps / el, "unit": "instance-steps/s", "cores": 1, "kind": "port",
+                "host_cores_available": avail,
+                "sample": "%d x %d instances of the bench batch, numpy restatement of reactive_qp.py:175-246 + dense "
+                          "Goldfarb-Idnani (oracle/clik_oracle.py), one core" % (reps, n)}
+    from oracle import c_oracle
+    co = c_oracle.CPinvOracle(spec, opts)
     # enough rows per thread to amortise the OpenMP fork/join
     reps_rows = max(1, (8 * 16384) // len(Q))
     Qs, Ys = np.tile(Q, (reps_rows, 1)), np.tile(Y, (reps_rows, 1))
@@ -112,24 +166,43 @@ def cpu_baseline(workload, spec, opts, Q, Y, seconds):
                       "{1,8,32,64,all} threads" % (reps, sample, reps_rows)}
 
 
-def measured_traffic(workload, dist_name, batch):
-    """HBM bytes per launch from the PMC passes recorded under profiles/ (they
-    cannot be collected from inside this process); None when no profile matches."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            prof = json.load(f)
-        return prof["%s_%s_B%d" % (workload, dist_name, batch)]["traffic_bytes"]
-    except Exception:
-        return None
+def profiled(workload, dist_name, batch, kernel):
+    """Per-launch PMC figures of this configuration recorded under profiles/ (they cannot be collected
+    from inside this process: separate rocprofv3 --pmc passes, tools/rocprof_counters.py).  Returns
+    (entry, source) or (None, None): a configuration that was not profiled gets no traffic figure."""
+    keys = ["%s_%s_B%d_%s" % (workload, dist_name, batch, kernel), "%s_%s_B%d" % (workload, dist_name, batch)]
+    for fn in PROFILE_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                prof = json.load(f)
+        except Exception:
+            continue
+        for k in keys:
+            ent = prof.get(k)
+            if isinstance(ent, dict) and ("traffic_bytes" in ent or "fp64_flops_per_launch" in ent):
+                want = ent.get("kernel")
+                if want is not None and want != kernel:
+                    continue
+                return ent, "profiles/" + fn + "#" + k
+    return None, None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.lanes:
+        os.environ["CLIK_LANES"] = str(args.lanes)
+
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -187,41 +260,83 @@ def main():
                     tick()
             graph.replay()          # untimed first replay (upload)
             stream.synchronize()
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
+
+        def replay():               # K steps
+            if graph is not None:
+                graph.replay()
+            else:
+                for _ in range(K):
+                    step()
+
+        # untimed clock ramp; its rate also sizes R
+        t_r = time.perf_counter()
+        n_ramp = 0
+        while True:
+            replay()
+            n_ramp += 1
+            if n_ramp % 4 == 0 or K >= 500:
+                stream.synchronize()
+                if (time.perf_counter() - t_r) * 1e3 >= args.ramp_ms:
+                    break
+        stream.synchronize()
+        est_ms = (time.perf_counter() - t_r) * 1e3 / n_ramp          # one replay, host-inclusive (upper bound)
+        R = args.replays if args.replays > 0 else max(50, int(args.min_timed_ms / max(est_ms, 1e-3)) + 1)
+        R = min(R, 20000)
+        if dist is not None:
+            rr = torch.tensor([R], dtype=torch.int64, device=dev)
+            dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+            R = int(rr.item())
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ev0.record(stream)
-        if graph is not None:
-            graph.replay()
-        else:
-            for _ in range(K):
-                step()
-        ev1.record(stream)
+        evs[0].record(stream)
+        for r in range(R):
+            replay()
+            evs[r + 1].record(stream)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    per_replay_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(R))
+    med_ms = per_replay_ms[R // 2]
+    dev_ms = evs[0].elapsed_time(evs[R])
     if dist is not None:
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, dev_ms, med_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(tt[0]), float(tt[1])
+        wall, dev_ms, med_ms = float(tt[0]), float(tt[1]), float(tt[2])
 
     if rank == 0:
         K, W = K * TPL, W * TPL          # report in ticks
-        total_steps = world * B * K
+        timed_steps = R * K
+        total_steps = world * B * timed_steps
         value = total_steps / wall
-        kern_us = dev_ms * 1e3 / K
+        kern_us = med_ms * 1e3 / K
         bytes_per_inst = 8 * (Q.shape[1] + Y.shape[1] + Q.shape[1]) + (0 if args.workload == "qp" else 4)
         alg_bytes = bytes_per_inst * B
         achieved = alg_bytes / (kern_us * 1e-6) / 1e9
+        kernel = getattr(ctrl, "kernel_name", None)
+        variant = getattr(ctrl, "kernel_variant", None)
+        if callable(variant):
+            kernel = variant(B)
+        prof, prof_src = profiled(args.workload, args.dist, B, kernel)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": prof.get("traffic_bytes") if prof else None,
+                "traffic_source": prof_src if (prof and "traffic_bytes" in prof) else None,
+                "kernel_us": kern_us, "kernel_us_mean": dev_ms * 1e3 / timed_steps,
+                "algorithmic_bytes_per_launch": alg_bytes}
+        if prof and "fp64_flops_per_launch" in prof:
+            # executed fp64 flops (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes, FMA = 2) over the measured
+            # kernel time: what the VALUs did, not what the literal algorithm would need
+            roof["fp64_valu_frac_executed"] = (prof["fp64_flops_per_launch"] / (kern_us * 1e-6)
+                                               / (FP64_VALU_PEAK_TF * 1e12))
+            roof["fp64_source"] = prof_src
         out = {
             "metric": "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384",
             "value": value, "unit": "instance-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall * 1e3 / timed_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": {"stack": "BASELINE config 3: %d x KUKA iiwa 7-DoF per GPU, priority stack "
@@ -231,17 +346,16 @@ def main():
                              "qp": "BASELINE config 4: %d x iiwa ReactiveQPController%s" % (
                                  B, " (hot-started from the previous tick's working set)" if args.qp_hot else "")}[args.workload],
                 "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
-                "kernel": getattr(ctrl, "kernel_name", None),
+                "kernel": kernel,
                 "launch": ("hipGraph of K ticks" if graph is not None else "eager, one launch per tick") if TPL == 1
                           else "on-device rollout, %d ticks per launch (solve -> clamp -> Euler)" % TPL,
-                "ticks_per_s": K / wall, "parallelism": "dp%d (independent shards, no data-path collective)" % world,
+                "replays": R, "timed_steps": timed_steps, "clock_ramp_ms": args.ramp_ms,
+                "timing": "R back-to-back replays of the K-step graph in one barrier+synchronize bracket; "
+                          "ms_per_step = wall / (R*K), max over ranks",
+                "ticks_per_s": timed_steps / wall,
+                "parallelism": "dp%d (independent shards, no data-path collective)" % world,
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.workload, args.dist, B),
-                         "kernel_us": kern_us, "algorithmic_bytes_per_launch": alg_bytes,
-                         "fp64_valu_frac_algorithmic": (ALG_FLOP_PER_STEP[args.workload] * B / (kern_us * 1e-6))
-                                                       / (FP64_VALU_PEAK_TF * 1e12)},
+            "roofline": roof,
         }
         if args.cpu_baseline and world == 1:
             try:
@@ -251,6 +365,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 
