@@ -18,12 +18,14 @@ The JSON line also carries
 
 Timing protocol: W untimed warm-up steps, then an untimed, time-based clock ramp
 (--ramp-ms of replays: a fresh GPU needs ~100 ms of work before its clocks
-settle, which a 20-step run never reaches), then R back-to-back replays of the
-K-step hipGraph inside ONE barrier + synchronize bracket.  `ms_per_step` =
-bracket wall time / (R*K) (max over ranks), `value` = instances * R * K / wall;
+settle, which a 20-step run never reaches), then R back-to-back replays of a
+hipGraph inside ONE barrier + synchronize bracket.  The graph holds the K steps
+repeated to >= 1024 ticks (a graph launch opens with a ~10 us device bubble that
+a 20-tick graph would pay every 20 ticks).  `ms_per_step` = bracket wall time /
+timed steps (max over ranks), `value` = instances * timed steps / wall;
 `roofline.kernel_us` = median over the R replays of (HIP-event time of one
-replay / K).  R is chosen so that the bracket holds >= --min-timed-ms of work
-and >= 50 replays; R and R*K are stated in `config`.
+replay / its ticks).  R is chosen so that the bracket holds >= --min-timed-ms of
+work and >= 50 replays; R and the timed steps are stated in `config`.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
 itself (torch.distributed.run on 127.0.0.1) BEFORE anything touches a GPU and
@@ -253,19 +255,24 @@ def main():
             step()
         stream.synchronize()
         graph = None
+        # a replay = GK steps = the K steps repeated until the graph holds >= 1024 ticks: every graph launch
+        # starts with a ~10 us bubble on the device (measured: 6.26 us per step from a 20-tick graph against
+        # 5.74 us from a 2000-tick graph of the same kernel), which a control loop that enqueues ticks
+        # continuously never sees
+        GK = K * max(1, -(-1024 // K)) if (args.graph and gathered is None and TPL == 1) else K
         if args.graph and gathered is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                for _ in range(K):
+                for _ in range(GK):
                     tick()
             graph.replay()          # untimed first replay (upload)
             stream.synchronize()
 
-        def replay():               # K steps
+        def replay():               # GK steps
             if graph is not None:
                 graph.replay()
             else:
-                for _ in range(K):
+                for _ in range(GK):
                     step()
 
         # untimed clock ramp; its rate also sizes R
@@ -274,7 +281,7 @@ def main():
         while True:
             replay()
             n_ramp += 1
-            if n_ramp % 4 == 0 or K >= 500:
+            if n_ramp % 4 == 0 or GK >= 500:
                 stream.synchronize()
                 if (time.perf_counter() - t_r) * 1e3 >= args.ramp_ms:
                     break
@@ -308,11 +315,11 @@ def main():
         wall, dev_ms, med_ms = float(tt[0]), float(tt[1]), float(tt[2])
 
     if rank == 0:
-        K, W = K * TPL, W * TPL          # report in ticks
-        timed_steps = R * K
+        K, W, GK = K * TPL, W * TPL, GK * TPL          # report in ticks
+        timed_steps = R * GK
         total_steps = world * B * timed_steps
         value = total_steps / wall
-        kern_us = med_ms * 1e3 / K
+        kern_us = med_ms * 1e3 / GK
         bytes_per_inst = 8 * (Q.shape[1] + Y.shape[1] + Q.shape[1]) + (0 if args.workload == "qp" else 4)
         alg_bytes = bytes_per_inst * B
         achieved = alg_bytes / (kern_us * 1e-6) / 1e9
@@ -347,11 +354,12 @@ def main():
                                  B, " (hot-started from the previous tick's working set)" if args.qp_hot else "")}[args.workload],
                 "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
                 "kernel": kernel,
-                "launch": ("hipGraph of K ticks" if graph is not None else "eager, one launch per tick") if TPL == 1
+                "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
+                           else "eager, one launch per tick") if TPL == 1
                           else "on-device rollout, %d ticks per launch (solve -> clamp -> Euler)" % TPL,
                 "replays": R, "timed_steps": timed_steps, "clock_ramp_ms": args.ramp_ms,
-                "timing": "R back-to-back replays of the K-step graph in one barrier+synchronize bracket; "
-                          "ms_per_step = wall / (R*K), max over ranks",
+                "timing": "R back-to-back replays in one barrier+synchronize bracket; "
+                          "ms_per_step = wall / timed_steps, max over ranks",
                 "ticks_per_s": timed_steps / wall,
                 "parallelism": "dp%d (independent shards, no data-path collective)" % world,
             },
