@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libclik_hip.so")
 SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_pinv_dyn.hip", "clik_qp.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("clik_device.hpp", "clik_pinv_static.hpp", "clik_pinv_kernels.hpp",
+HEADERS = [os.path.join(CSRC, h) for h in ("clik_device.hpp", "clik_pinv_static.hpp", "clik_pinv_kernels.hpp", "clik_pinv_team.hpp",
                                           "clik_qp_static.hpp", "clik_shapes_gen.hpp")] \
     + [os.path.join(ROOT, "include", "clik.h")]
 ARCH = "gfx950"

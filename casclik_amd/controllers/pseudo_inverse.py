@@ -167,6 +167,11 @@ class PseudoInverseController(BaseController):
                 "outside the shape-specialised family)" % ", ".join(
                     repr(self.descriptor.tasks[k]["label"]) for k in sorted(self.descriptor.extern_code)))
 
+    def kernel_variant(self, batch):
+        """``<kernel>/<variant>`` serving a batch of that many instances: ``team4`` (four lanes per
+        instance), ``mp2`` / ``mp4`` (one wave per mode), ``split``, ``lane`` (one instance per lane)."""
+        return "%s/%s" % (self.kernel_name, self._lib.clik_pinv_kernel_variant(self._handle, int(batch)).decode())
+
     def setup_solver(self):
         """Reference parity: re-runs the problem setup (pseudo_inverse.py:506-510)."""
         self.setup_problem_functions()

@@ -33,6 +33,7 @@ struct LaunchArgs {
 };
 int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
+const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B);
 int pinv_kernel_width(int k);
 int pinv_kernel_is_static(int k);
 hipError_t pinv_launch_solve(int k, const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
@@ -746,6 +747,13 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         const char* rs = getenv("CLIK_ROLE_SPLIT");
         h->mode_parallel = (mp && mp[0] == '0') ? 0 : 1;
         if (h->mode_parallel && rs && rs[0] == '1') h->mode_parallel |= 2;
+        // Bit 2: team kernel, four lanes per instance (pinv_solve_static_team_kernel) for the config-3
+        // family up to kTeamMaxBatch instances; bit 3: at any batch size.  CLIK_LANES=1 keeps the
+        // lane-per-instance kernels, CLIK_LANES=4 forces the team kernel (head-to-head runs), unset / 0 =
+        // the library's choice.
+        const char* ln = getenv("CLIK_LANES");
+        if (!ln || ln[0] == '0' || ln[0] == '\0') h->mode_parallel |= 4;
+        else if (ln[0] == '4') h->mode_parallel |= 4 | 8;
     }
     h->d_tterms = nullptr;
     h->d_tterms_cap = 0;
@@ -794,6 +802,13 @@ extern "C" const char* clik_pinv_kernel_name(const clik_pinv* h)
 {
     if (h && h->jit_solve) return h->jit_name;
     return h ? clik::pinv_kernel_name(h->kernel) : "none";
+}
+
+extern "C" const char* clik_pinv_kernel_variant(const clik_pinv* h, int64_t B)
+{
+    if (!h) return "none";
+    if (!h->jit_solve && !(h->kernel >= 0 && clik::pinv_kernel_is_static(h->kernel))) return "dynamic";
+    return clik::pinv_static_variant(h->host.shape, h->mode_parallel, (long long)B);
 }
 
 static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk)

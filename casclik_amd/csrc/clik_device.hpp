@@ -578,24 +578,16 @@ __device__ __forceinline__ void orientation_feature(const DevSkill* __restrict__
                           2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
                           2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
     const double* R = K.R;
-    K.o[0] = K.o[1] = K.o[2] = 0.0;
-    double tr = 0.0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double rc[3] = {R[c], R[3 + c], R[6 + c]};
-        const double dc[3] = {Rd[c], Rd[3 + c], Rd[6 + c]};
-        double v[3];
-        cross3(rc, dc, v);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) K.o[i] = fma(0.5, v[i], K.o[i]);
-        tr += rc[0] * dc[0] + rc[1] * dc[1] + rc[2] * dc[2];
-    }
-    K.tr = tr;
+    // M = R Rd^T carries everything:  sum_c r_c x rd_c = vee(M^T - M)  and  tr(Rd^T R) = tr M
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             K.M[3 * i + k] = R[3 * i] * Rd[3 * k] + R[3 * i + 1] * Rd[3 * k + 1] + R[3 * i + 2] * Rd[3 * k + 2];
+    K.o[0] = 0.5 * (K.M[5] - K.M[7]);
+    K.o[1] = 0.5 * (K.M[6] - K.M[2]);
+    K.o[2] = 0.5 * (K.M[1] - K.M[3]);
+    K.tr = K.M[0] + K.M[4] + K.M[8];
 }
 
 // Value, state gradient and time derivative of one affine row (clik_row).

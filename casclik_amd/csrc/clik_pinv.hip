@@ -79,6 +79,7 @@ int pinv_pick_kernel(const DevSkill& S, int allow_static)
 }
 
 const char* pinv_kernel_name(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].name : "none"; }
+const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B) { return static_variant(sd, mode_parallel, B); }
 int pinv_kernel_width(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].N : 0; }
 int pinv_kernel_is_static(int k) { return (k >= 0 && k < kNumShapes && kShapes[k].sd) ? 1 : 0; }
 

@@ -1208,13 +1208,18 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
+}  // namespace clik
+#include "clik_pinv_team.hpp"   // four lanes per instance (needs StaticLayout)
+namespace clik {
+
 // common launcher signature of the kernel table
 struct LaunchArgs {
     const DevSkill* dS;        // dynamic kernels
     const void*     dImg;      // static kernels: device copy of the skill image
     const WarmArgs* warm;
     int nq, nx, ny;
-    int mode_parallel;         // small batches: bit 0 two-wave mode scan, bit 1 role-split kernel
+    int mode_parallel;         // small batches: bit 0 two-wave mode scan, bit 1 role-split kernel,
+                               // bit 2 team kernel (four lanes per instance) where the shape allows, bit 3 ... at any batch
     double* roll_x;            // rollout of a skill with virtual variables: their state (in/out) and last rates
     double* roll_dx;
 };
@@ -1257,6 +1262,26 @@ inline size_t static_lds_bytes(int ny)
 constexpr long long kModeParallelMaxBatch = 32768;
 // the role-split kernel runs 2-4 waves per 64 instances: up to one block per CU
 constexpr long long kRoleSplitMaxBatch = 16384;
+// the team kernel runs four lanes per instance: up to 16384 instances its waves have a SIMD each; beyond,
+// two of them share a SIMD's fp64 pipe and the tick doubles (measured: 5.1 us at 16384, 9.2 us at 32768 against
+// 6.0 us of the two-wave kernel, profiles/r2_lanes_head_to_head.md)
+constexpr long long kTeamMaxBatch = 16384;
+
+// Which kernel variant serves a batch of B instances of a static shape (the label bench.py and the
+// tests report): the same conditions launch_solve_static evaluates, on the run-time copy of the shape.
+inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long long B)
+{
+    if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch))) return "team4";
+    const int ns = shape_n_sets(sd);
+    if (sd.n_x == 0 && ns <= 1 && B <= kRoleSplitMaxBatch && (mode_parallel & 2)) {
+        bool ok = true;
+        for (int k = 0; k < (1 << ns); ++k) ok = ok && make_plan(sd, shape_mode_act(sd, k)).helper_ok;
+        if (ok) return "split";
+    }
+    if ((ns == 1 || ns == 2) && sd.n_x == 0 && B <= kModeParallelMaxBatch / ((1 << ns) / 2) && (mode_parallel & 1))
+        return ns == 1 ? "mp2" : "mp4";
+    return "lane";
+}
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
@@ -1264,6 +1289,14 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
                                       hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if constexpr (shape_team_ok(SD)) {
+        // four lanes per instance, a block of four waves = 64 instances (same grid)
+        if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch)) {
+            hipLaunchKernelGGL((pinv_solve_static_team_kernel<SD>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                               team_lds_bytes<SD>(), stream, a.dImg, q, y, dq, mode, B, tk);
+            return hipGetLastError();
+        }
+    }
     if constexpr (shape_split_ok<SD>() && SD.n_x == 0) {
         // one block per 64 instances, 2 or 4 waves each: worth it while blocks <= CUs-ish
         if (B <= kRoleSplitMaxBatch && (a.mode_parallel & 2)) {

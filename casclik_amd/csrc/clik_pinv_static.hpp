@@ -274,22 +274,15 @@ constexpr int shape_state_type(const ShapeDesc& sd, int qi)
     return CLIK_JOINT_FIXED;     // state variable not driven by the chain
 }
 
+// sin / cos of every revolute state variable (the caller may produce them differently: the team kernel
+// splits them over the lanes of an instance, clik_pinv_team.hpp)
 template <const ShapeDesc& SD>
-__device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__ S, const double (&z)[SD.n],
-                                                     Kin<SD.n>& K)
+__device__ __forceinline__ void fk_sincos_all(const double (&z)[SD.n], double (&sns)[SD.n], double (&css)[SD.n])
 {
     constexpr int N = SD.n;
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    double p[3] = {0, 0, 0};
-    double ax[N][3], org[N][3];
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ax[j][i] = org[j][i] = 0.0;
     // all sines / cosines first: n independent polynomial chains the scheduler can
     // interleave; inside the chain recursion they would serialise behind the
     // frame products (measured: FK was latency-, not issue-bound)
-    double sns[N], css[N];
     bool huge = false;
     static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
@@ -313,6 +306,21 @@ __device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__
             }
         });
     }
+}
+
+template <const ShapeDesc& SD>
+__device__ __forceinline__ void forward_kinematics_sc(const Img<SD>* __restrict__ S, const double (&z)[SD.n],
+                                                      const double (&sns)[SD.n], const double (&css)[SD.n],
+                                                      Kin<SD.n>& K)
+{
+    constexpr int N = SD.n;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double p[3] = {0, 0, 0};
+    double ax[N][3], org[N][3];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ax[j][i] = org[j][i] = 0.0;
     fk_joint_s<SD, 0>(S, z, sns, css, R, p, ax, org);
 #pragma unroll
     for (int i = 0; i < 9; ++i) K.R[i] = R[i];
@@ -341,6 +349,15 @@ __device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__
 }
 
 template <const ShapeDesc& SD>
+__device__ __forceinline__ void forward_kinematics_s(const Img<SD>* __restrict__ S, const double (&z)[SD.n],
+                                                     Kin<SD.n>& K)
+{
+    double sns[SD.n], css[SD.n];
+    fk_sincos_all<SD>(z, sns, css);
+    forward_kinematics_sc<SD>(S, z, sns, css, K);
+}
+
+template <const ShapeDesc& SD>
 __device__ __forceinline__ void orientation_feature_s(const Img<SD>* __restrict__ S, const double* ys,
                                                       const int lane, Kin<SD.n>& K)
 {
@@ -357,24 +374,16 @@ __device__ __forceinline__ void orientation_feature_s(const Img<SD>* __restrict_
                           2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
                           2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
     const double* R = K.R;
-    K.o[0] = K.o[1] = K.o[2] = 0.0;
-    double tr = 0.0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double rc[3] = {R[c], R[3 + c], R[6 + c]};
-        const double dc[3] = {Rd[c], Rd[3 + c], Rd[6 + c]};
-        double v[3];
-        cross3(rc, dc, v);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) K.o[i] = fma(0.5, v[i], K.o[i]);
-        tr += rc[0] * dc[0] + rc[1] * dc[1] + rc[2] * dc[2];
-    }
-    K.tr = tr;
+    // M = R Rd^T carries everything:  sum_c r_c x rd_c = vee(M^T - M)  and  tr(Rd^T R) = tr M
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             K.M[3 * i + k] = R[3 * i] * Rd[3 * k] + R[3 * i + 1] * Rd[3 * k + 1] + R[3 * i + 2] * Rd[3 * k + 2];
+    K.o[0] = 0.5 * (K.M[5] - K.M[7]);
+    K.o[1] = 0.5 * (K.M[6] - K.M[2]);
+    K.o[2] = 0.5 * (K.M[1] - K.M[3]);
+    K.tr = K.M[0] + K.M[4] + K.M[8];
 }
 
 // value, state gradient and time derivative of one affine row; feature flags,

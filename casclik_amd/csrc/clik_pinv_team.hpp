@@ -1,0 +1,397 @@
+// Team kernel: FOUR LANES PER ROBOT INSTANCE for the priority-stack family of BASELINE config 3
+//
+//     [ SetConstraint on every joint (multidim, unit rows) ;  state-dependent EqualityConstraint
+//       with m <= n rows (the pose) ;  joint-space EqualityConstraint (unit rows, e.g. centering) ]
+//
+// (reference: pseudo_inverse.py:259-451 evaluated for both modes of the one-set table :107-130,
+// mode scan :530-550).  At <= 32768 instances the lane-per-instance kernels leave 3/4 of the SIMDs
+// idle and a tick is the serial instruction stream of one wave; here the four lanes of a DPP quad
+// share one instance, so 16384 instances are 1024 waves (one per SIMD) and each wave issues fewer
+// instructions.
+//
+// What the lanes split is NOT the entries of the <= 8x8 matrices (moving an fp64 between lanes costs
+// 1-2 instructions, a Gram entry costs 7 FMAs: entry-level splits are communication-bound, see
+// DESIGN.md) but the INDEPENDENT SOLVES of the two speculated modes.  Both modes of the family need
+// only damped solves with shifted copies of ONE Gram matrix  Gm = J J'  of the pose task:
+//
+//   A0 = Gm + lam I        y  = A0^-1 d1,  y2 = A0^-1 y                       (both modes)
+//        mode 0: the doubly processed first equality (:317-326 + :382-396) sums to J'(y + lam y2)
+//        mode 1: the pose behind the active set:  N_set J' y
+//   A1 = 2 Gm + lam I      mode 0: the centering task projects through [J; J]:
+//                              (2J'J + lam I)^-1 2J'J w  =  2 J' A1^-1 (J w)       (push-through)
+//   A2 = Gm + (1+lam) I    mode 1: the centering task projects through [I; J] with activations S:
+//                              G = (1+lam) I + J'J,  C = S + J'J,
+//                              G^-1 u = (u - J' A2^-1 (J u)) / (1+lam),  u = C w   (Woodbury)
+//
+// so lane r of the quad factors  A_r = alpha_r Gm + beta_r I  and back-substitutes ITS right-hand
+// side with the SAME instruction stream (only data differ): three 6x6 LDL' factorisations, four
+// solves and four J' products cost one of each.  Lane 3 repeats lane 0's first solve without the
+// second pass (mode 1 needs J'y alone).  The results meet through DPP quad_perm moves (no LDS
+// round trip); FK, the task rows and Gm are evaluated redundantly by the four lanes.
+//
+// The identities are exact for the damped inverse; the values differ from the literal Gram-form
+// evaluation by rounding only (A1, A2 are the better conditioned forms), inside PINV_RTOL.
+#pragma once
+#include "clik_pinv_static.hpp"
+
+namespace clik {
+
+// -DCLIK_TEAM_ABLATE=<bits>: timing experiments only (tools/ablate_team.py; wrong results by design, never
+// in the shipped library): 1 no cone test, 2 no second solve, 4 no factorisation / solves, 8 no Gram build,
+// 16 no FK / task rows (the state stands in for the rows)
+#ifndef CLIK_TEAM_ABLATE
+#define CLIK_TEAM_ABLATE 0
+#endif
+
+constexpr int TEAM = 4;                     // lanes per instance = one DPP quad
+constexpr int TEAM_WAVES = 4;               // waves per block: 64 instances, one wave per SIMD of a CU
+constexpr int TEAM_INST = TEAM_WAVES * WAVE / TEAM;
+
+constexpr bool shape_team_ok(const ShapeDesc& sd)
+{
+    if (sd.qp || sd.n_tasks != 3 || sd.n_x != 0 || sd.standard || sd.conv_last || !sd.multidim) return false;
+    if (sd.cls[0] != CLIK_CLS_SET || sd.cls[1] != CLIK_CLS_EQ || sd.cls[2] != CLIK_CLS_EQ) return false;
+    // the set covers every state variable exactly once (then  lam I + Jset'Jset = (1+lam) I)
+    if (!shape_unit(sd, 0) || sd.m[0] != sd.n || sd.n < 2) return false;
+    for (int c = 0; c < sd.n; ++c)
+        if (shape_unit_row(sd, 0, c) < 0) return false;
+    if (sd.const_j[1] || sd.m[1] > sd.n || sd.m[1] < 1) return false;
+    if (!shape_unit(sd, 2)) return false;
+    return true;
+}
+
+// value of lane SRC_EVEN / SRC_ODD of each lane pair of the quad (pairs (0,1) and (2,3))
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(const double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int QUAD_LANE0 = 0x00;    // quad_perm:[0,0,0,0]
+
+template <const ShapeDesc& SD>
+inline size_t team_lds_bytes()
+{
+    return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n + (SD.n_y > 0 ? SD.n_y : 0)) * TEAM_INST) * sizeof(double);
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
+{
+    static_assert(shape_team_ok(SD), "shape outside the team kernel's family");
+    extern __shared__ double lds[];
+    constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2], NY = SD.n_y > 0 ? SD.n_y : 0;
+    constexpr int NT = M * (M + 1) / 2;
+    constexpr int NTHREADS = TEAM_WAVES * WAVE;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = tid & (TEAM - 1);                 // role in the team
+    const int inst = tid >> 2;                      // instance within the block
+    const long long b0 = (long long)blockIdx.x * TEAM_INST;
+    const long long left = B - b0;
+    const int rows_valid = left < TEAM_INST ? (int)left : TEAM_INST;
+    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;       // [64][N] joint state, later the velocities
+    double* ys = zs + N * TEAM_INST;                        // [64][NY]
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    CLIK_STAMP_W(0, 0);
+    {
+        // one memory round trip: image chunks round-robin over the waves, the block's q / y rows
+        // cooperatively (coalesced, index-clamped), all issued before the first LDS write
+        constexpr int CH = StaticLayout<SD>::IMG_CHUNKS;
+        constexpr int PER = (CH + TEAM_WAVES - 1) / TEAM_WAVES;
+        constexpr int QR = (N * TEAM_INST + NTHREADS - 1) / NTHREADS;
+        constexpr int YR = (NY * TEAM_INST + NTHREADS - 1) / NTHREADS;
+        const d2* src = (const d2*)img_g;
+        d2* dst = (d2*)lds;
+        const int lane = tid & (WAVE - 1);
+        d2 img[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int ck = k * TEAM_WAVES + wave;
+            img[k] = src[(ck < CH ? ck : CH - 1) * WAVE + lane];
+        }
+        double qv[QR], yv[YR > 0 ? YR : 1];
+        const double* qg = q + b0 * N;
+        const int qlast = rows_valid * N - 1;
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            const int k = i * NTHREADS + tid;
+            qv[i] = qg[k < qlast ? k : qlast];
+        }
+        if constexpr (NY > 0) {
+            const double* yg = y + b0 * NY;
+            const int ylast = rows_valid * NY - 1;
+#pragma unroll
+            for (int i = 0; i < YR; ++i) {
+                const int k = i * NTHREADS + tid;
+                yv[i] = yg[k < ylast ? k : ylast];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int ck = k * TEAM_WAVES + wave;
+            if (ck < CH) dst[ck * WAVE + lane] = img[k];
+        }
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            const int k = i * NTHREADS + tid;
+            if (k < N * TEAM_INST) zs[k] = qv[i];
+        }
+        if constexpr (NY > 0) {
+#pragma unroll
+            for (int i = 0; i < YR; ++i) {
+                const int k = i * NTHREADS + tid;
+                if (k < NY * TEAM_INST) ys[k] = yv[i];
+            }
+        }
+    }
+    __syncthreads();
+    CLIK_STAMP_W(0, 1);
+    const Img<SD>* __restrict__ Slds = (const Img<SD>*)lds;
+    const double* ysl = ys + inst * NY;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = zs[inst * N + j];
+
+    // ---- front end: sin / cos split over the quad, then FK and the task rows in every lane ----
+    TaskCache<SD> tc;
+    {
+        double sns[N], css[N];
+        if constexpr (SD.uses_fk != 0) {
+            // lane r evaluates state variables 2r and 2r+1 (clamped), the quad exchanges by DPP
+            const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+            const double a0 = zs[inst * N + j0], a1 = zs[inst * N + j1];
+            double sn0, cs0, sn1, cs1;
+            sincos_fast(a0, sn0, cs0);
+            sincos_fast(a1, sn1, cs1);
+            const bool huge = fabs(a0) > kSinCosFastMax || fabs(a1) > kSinCosFastMax;
+            if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+                if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
+                if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
+            }
+            static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+                    constexpr int CTRL = (j / 2) * 0x55;           // quad_perm:[k,k,k,k], k = owner lane
+                    sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
+                    css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
+                } else {
+                    sns[j] = css[j] = 0.0;
+                }
+            });
+        }
+        const Img<SD> Sfk = *Slds;
+        __builtin_amdgcn_sched_barrier(0);
+        Kin<N> K;
+        if constexpr ((CLIK_TEAM_ABLATE & 16) != 0) {
+#pragma unroll
+            for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
+                tc.e[i] = z[i % N] + sns[(i + 1) % N];
+                tc.Jt[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) tc.J[i][j] = z[(i + j) % N] * css[j];
+            }
+        } else {
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_sc<SD>(&Sfk, z, sns, css, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(&Sfk, ysl, inst, K);
+        }
+        cache_task<SD, 0>(&Sfk, tk, K, z, ysl, inst, tc);
+        }
+    }
+    CLIK_STAMP_W(0, 2);
+    const Img<SD> Sb = *Slds;
+    __builtin_amdgcn_sched_barrier(0);
+    const Img<SD>* __restrict__ S = &Sb;
+    const double lam = S->lam;
+    const double one_lam = 1.0 + lam;
+
+    // desired task velocities  d = -K e - de/dt   (pseudo_inverse.py:318-321, :383-386)
+    double des1[M], w2[N];
+    {
+        double e[M], Jt[M], ke[M];
+        task_values<SD, 1>(S, tk, tc, z, ysl, inst, e, Jt);
+        gain_apply_s<M, SD.gain_matrix[1] != 0>(S->tasks[1], e, ke);
+#pragma unroll
+        for (int i = 0; i < M; ++i) des1[i] = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
+    }
+    {
+        // w2 = pinv(J2) d2 of the joint-space task: one entry per row (host-side pinv of the unit rows)
+        double e[M2], Jt[M2], ke[M2];
+        task_values<SD, 2>(S, tk, tc, z, ysl, inst, e, Jt);
+        gain_apply_s<M2, SD.gain_matrix[2] != 0>(S->tasks[2], e, ke);
+#pragma unroll
+        for (int j = 0; j < N; ++j) w2[j] = 0.0;
+        const double* Pm = S->cpinv[2];
+        static_for<0, M2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int col = SD.ucol[2][i] - 1;
+            const double d = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
+            w2[col] = Pm[col * CLIK_MAX_M + i] * d;
+        });
+    }
+    // the set: violated rows (activation S of the multidim set, :289-298) by state column, and the
+    // values its tangent-cone test needs
+    double e0[M0], Jt0[M0];
+    task_values<SD, 0>(S, tk, tc, z, ysl, inst, e0, Jt0);
+    double sact[N], p0[N];          // sact[col] = 1.0 when the set row on that state is violated
+    static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int col = SD.ucol[0][i] - 1;
+        sact[col] = ((e0[i] - S->tasks[0].set_max[i] > 0.0) || (e0[i] - S->tasks[0].set_min[i] < 0.0)) ? 1.0 : 0.0;
+        p0[col] = S->cpinv[0][col * CLIK_MAX_M + i];
+    });
+
+    // Gm = J J'
+    double Gm[NT];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) {
+            double acc = 0.0;
+            if constexpr ((CLIK_TEAM_ABLATE & 8) != 0) {
+                acc = jac<SD, 1>(S, tc, i, k) * jac<SD, 1>(S, tc, k, i);
+            } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
+            }
+            Gm[tri(i, k)] = acc;
+        }
+
+    CLIK_STAMP_W(0, 3);
+    // ---- per-lane role ------------------------------------------------------------------------
+    // The lower-priority task's projected contribution, with the stack matrix G = D + c J'J of the mode
+    // (D = lam I in mode 0 with c = 2; D = (1+lam) I in mode 1 with c = 1) and C = G - (D - S):
+    //     w2 - G^-1 C w2  =  G^-1 (D - S) w2  =  D^-1 (x - c J' A^-1 J x),   x = (D - S) w2,  A = c J J' + D
+    // (Woodbury; S = 0 in mode 0).  So lane 1 solves A1 t = J w2 (then x/D = w2, c = 2), lane 2 solves
+    // A2 t = J x with x = ((1+lam) - s) o w2 (c = 1), lanes 0 / 3 solve A0 y = d1.
+    const bool solo = (r == 0) || (r == 3);
+    const double alpha = (r == 1) ? 2.0 : 1.0;
+    const double beta = (r == 2) ? one_lam : lam;
+    const double hsel = solo ? 1.0 : 0.0;
+    double rhs[M];
+    {
+        double x[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double f = (r == 2) ? one_lam - sact[j] : ((r == 1) ? 1.0 : 0.0);
+            x[j] = w2[j] * f;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double sacc = hsel * des1[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) sacc = fma(jac<SD, 1>(S, tc, i, j), x[j], sacc);
+            rhs[i] = sacc;
+        }
+    }
+    double A[NT], rd[M], s2[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? fma(alpha, Gm[tri(i, k)], beta) : alpha * Gm[tri(i, k)];
+    if constexpr ((CLIK_TEAM_ABLATE & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) rhs[i] *= A[tri(i, i)] + A[tri(M - 1, i)];
+    } else {
+    ldl_factor_s<M>(A, rd);
+    ldl_solve_s<M>(A, rd, rhs);
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) s2[i] = rhs[i];
+    if constexpr ((CLIK_TEAM_ABLATE & (2 | 4)) == 0)
+    ldl_solve_s<M>(A, rd, s2);      // (second pass of the doubly processed equality: lane 0 only)
+    const double lam0 = (r == 0) ? lam : 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) rhs[i] = fma(lam0, s2[i], rhs[i]);
+    double g[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) sacc = fma(jac<SD, 1>(S, tc, i, j), rhs[i], sacc);
+        g[j] = sacc;
+    }
+
+    CLIK_STAMP_W(0, 4);
+    // ---- the quad's results meet: lanes 0/1 form the mode-0 velocity, lanes 2/3 the mode-1 one --
+    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)
+    //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)
+    const bool hi_pair = (r & 2) != 0;
+    const double kap = hi_pair ? 1.0 / one_lam : 1.0;
+    const double eta = hi_pair ? 1.0 : 2.0;
+    double v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double first = quad_perm_f64<0xF0>(g[j]);      // quad_perm:[0,0,3,3]: g0 | g3
+        const double second = quad_perm_f64<0xA5>(g[j]);     // quad_perm:[1,1,2,2]: g1 | g2
+        const double nmul = hi_pair ? fma(-p0[j], sact[j], 1.0) : 1.0;
+        const double xx = hi_pair ? w2[j] * (one_lam - sact[j]) : w2[j];
+        v[j] = fma(first, nmul, kap * fma(-eta, second, xx));
+    }
+    // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; lanes 2/3 evaluate it
+    // on the other candidate, unused)
+    bool in_tc;
+    if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
+        in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
+    } else {
+        double de[M0];
+        static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int col = SD.ucol[0][i] - 1;
+            de[i] = Jt0[i] + v[col];
+        });
+        const clik_task& t = S->tasks[0];
+        bool inside = true, corner = true;
+        double od = 0.0, nde = 0.0, nout = 0.0;
+#pragma unroll
+        for (int i = 0; i < M0; ++i) {
+            const double le = e0[i] - t.set_min[i];
+            const double ue = e0[i] - t.set_max[i];
+            if (!(le >= 1e-12) || !(ue <= 1e-12)) inside = false;
+            const double sl = (le > 0.0) - (le < 0.0);
+            const double su = (ue > 0.0) - (ue < 0.0);
+            if (sl != su) corner = false;
+            const double out = 0.5 * (sl + su);
+            od = fma(out, de[i], od);
+            nde = fma(de[i], de[i], nde);
+            nout = fma(out, out, nout);
+        }
+        bool going_in;
+        if (corner) {
+            const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+            going_in = (od < 0.0) ? (fabs(od) / dists < 0.70710678118654757) : false;
+        } else {
+            going_in = od < 0.0;
+        }
+        in_tc = inside ? true : going_in;
+    }
+    // the scan of :530-550 as a select: mode 0 if its cone test passes, else mode 1 (the active set
+    // has no cone test, so mode 1 is always admissible)
+    CLIK_STAMP_W(0, 6);
+    const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
+    if (r == (ok0 ? 0 : 2)) {
+        // (each team reads and writes only its own row, and a team is inside one wave: no barrier needed)
+#pragma unroll
+        for (int j = 0; j < N; ++j) zs[inst * N + j] = v[j];
+        if (mode_out != nullptr && inst < rows_valid) mode_out[b0 + inst] = ok0 ? 0 : 1;
+    }
+    __syncthreads();
+    {
+        constexpr int QR = (N * TEAM_INST + NTHREADS - 1) / NTHREADS;
+        double* dg = dq + b0 * N;
+        const int total = rows_valid * N;
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            const int k = i * NTHREADS + tid;
+            if (k < total) dg[k] = zs[k];
+        }
+    }
+    CLIK_STAMP_W(0, 5);
+}
+
+}  // namespace clik

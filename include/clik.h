@@ -187,6 +187,10 @@ int clik_pinv_n_modes(const clik_pinv* h);
 /* name of the kernel variant serving this skill: an AOT shape name (guard-free
  * instantiation for the skill's structure) or "dynamic" (run-time guards).   */
 const char* clik_pinv_kernel_name(const clik_pinv* h);
+/* which variant of that kernel a batch of B instances gets: "team4" (four lanes per instance,
+ * small batches of the priority-stack family), "mp2"/"mp4" (one wave per mode), "split", "lane"
+ * (one instance per lane) or "dynamic".                                               */
+const char* clik_pinv_kernel_variant(const clik_pinv* h, int64_t B);
 /* developer aid (host only, no GPU needed): writes the C++ ShapeDesc initialiser
  * this skill maps to into buf; returns 1 if the skill is eligible for an AOT
  * shape-specialised kernel, 0 if not, <0 on error (tools/gen_shapes.py).      */

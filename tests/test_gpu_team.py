@@ -1,0 +1,144 @@
+"""GPU parity of the four-lanes-per-instance ("team") kernel of the config-3 family
+(casclik_amd/csrc/clik_pinv_team.hpp) against the CPU oracles and against the
+lane-per-instance kernels, through the C ABI (CLIK_LANES selects the variant when the
+handle is created)."""
+import numpy as np
+import pytest
+
+import casclik_amd as cc
+from casclik_amd import skills
+from casclik_amd import sym as cs
+from casclik_amd.constraints import EqualityConstraint, SetConstraint
+from casclik_amd.skill_specification import SkillSpecification
+from tolerances import PINV_RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, ref):
+    return np.abs(a - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
+
+
+def _controller(spec, options, lanes, monkeypatch):
+    monkeypatch.setenv("CLIK_LANES", str(lanes))
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(options))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    return ctrl
+
+
+@pytest.mark.parametrize("robot", ["iiwa", "ur5"])
+@pytest.mark.parametrize("dist", ["interior", "mixed"])
+@pytest.mark.parametrize("B", [1, 37, 200, 1024])
+def test_team_kernel_vs_numpy_oracle(iiwa_fk, ur5_fk, robot, dist, B, monkeypatch):
+    from oracle import clik_oracle
+    fk = iiwa_fk if robot == "iiwa" else ur5_fk
+    spec = skills.stack_skill(fk)
+    ctrl = _controller(spec, skills.STACK_OPTIONS, 4, monkeypatch)
+    assert ctrl.kernel_variant(B).endswith("/team4")
+    Q, Y = skills.synthetic_inputs(fk, B, seed=11 + B, distribution=dist)
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q, Y=Y)
+    assert np.array_equal(mode, ref_mode)
+    assert _rel(dq, ref).max() < PINV_RTOL
+    if dist == "mixed" and B >= 200:
+        assert (mode == 0).any() and (mode == 1).any()     # both candidates are exercised
+
+
+def test_team_kernel_vs_c_oracle_and_lane_kernel_full_size(iiwa_fk, monkeypatch):
+    """BASELINE config 3 at its full size: the whole batch against the C oracle, and against the
+    lane-per-instance kernel (same modes; velocities within the rounding of the two evaluation orders)."""
+    from oracle.c_oracle import CPinvOracle
+    spec = skills.stack_skill(iiwa_fk)
+    B = 16384
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=0, distribution="mixed")
+    team = _controller(spec, skills.STACK_OPTIONS, 4, monkeypatch)
+    lane = _controller(spec, skills.STACK_OPTIONS, 1, monkeypatch)
+    assert team.kernel_variant(B).endswith("/team4") and not lane.kernel_variant(B).endswith("/team4")
+    dq_t, _, mode_t = team.solve_batch(0.0, Q, input_var=Y)
+    dq_l, _, mode_l = lane.solve_batch(0.0, Q, input_var=Y)
+    ref, _, ref_mode = CPinvOracle(spec, skills.STACK_OPTIONS).solve_batch(0.0, Q, Y=Y)
+    assert np.array_equal(mode_t, ref_mode) and np.array_equal(mode_l, ref_mode)
+    assert _rel(dq_t, ref).max() < PINV_RTOL
+    assert _rel(dq_t, dq_l).max() < PINV_RTOL
+    # a permuted batch gives the permuted answer bit for bit (no cross-instance coupling, no
+    # dependence on the position inside the quad / wave / block)
+    perm = np.random.default_rng(1).permutation(B)
+    dq_p, _, mode_p = team.solve_batch(0.0, Q[perm], input_var=Y[perm])
+    assert np.array_equal(dq_p, dq_t[perm]) and np.array_equal(mode_p, mode_t[perm])
+
+
+def _custom_stack(fk, gain_matrix, one_sided):
+    n = len(fk["joint_names"])
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", n)
+    dq = cs.MX.sym("dq", n)
+    y = cs.MX.sym("y", 7)
+    T = fk["T_fk"](q)
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    if one_sided:
+        limits = SetConstraint(label="joint_limits", expression=q, set_max=hi, priority=0)
+    else:
+        limits = SetConstraint(label="joint_limits", expression=q, set_min=lo, set_max=hi, priority=0)
+    rng = np.random.default_rng(4)
+    K = 10.0 * np.eye(6) + (rng.uniform(-1, 1, (6, 6)) if gain_matrix else 0.0)
+    pose = EqualityConstraint(label="tool_pose", expression=skills._pose_expression(T, y),
+                              gain=K if gain_matrix else 10.0, constraint_type="soft", priority=1)
+    # joint-space task on a subset of the joints, time-dependent target (feedforward term)
+    sub = cs.vertcat(q[0] - 0.3 * cs.sin(t), q[2] + 0.1, q[n - 1] - 0.2 * t)
+    center = EqualityConstraint(label="some_joints", expression=sub, gain=1.5, constraint_type="soft", priority=2)
+    return SkillSpecification(label="custom_stack", time_var=t, robot_var=q, robot_vel_var=dq, input_var=y,
+                              constraints=[limits, pose, center])
+
+
+@pytest.mark.parametrize("gain_matrix", [False, True])
+@pytest.mark.parametrize("one_sided", [False, True])
+@pytest.mark.parametrize("feedforward", [True, False])
+def test_team_kernel_family_members(iiwa_fk, gain_matrix, one_sided, feedforward, monkeypatch):
+    """Other members of the family through run-time instantiated kernels: matrix gain, one-sided
+    limits, a joint-space task on three joints with time terms, feedforward on / off."""
+    from oracle import clik_oracle
+    spec = _custom_stack(iiwa_fk, gain_matrix, one_sided)
+    opts = dict(skills.STACK_OPTIONS, feedforward=feedforward)
+    ctrl = _controller(spec, opts, 4, monkeypatch)
+    B = 300
+    assert ctrl.kernel_variant(B).endswith("/team4"), ctrl.kernel_variant(B)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=21, distribution="mixed")
+    for t in (0.0, 0.7):
+        dq, _, mode = ctrl.solve_batch(t, Q, input_var=Y)
+        ref, ref_mode = clik_oracle.pinv_solve_batch(spec, opts, t, Q, Y=Y)
+        assert np.array_equal(mode, ref_mode)
+        assert _rel(dq, ref).max() < PINV_RTOL
+
+
+def test_team_kernel_near_singular(iiwa_fk, monkeypatch):
+    """Stretched-out arm (sigma_min^2 of the pose Jacobian below lam): the shifted factorisations
+    A0 = JJ' + lam I, A1 = 2JJ' + lam I stay positive definite and agree with the oracle."""
+    from oracle import clik_oracle
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = _controller(spec, skills.STACK_OPTIONS, 4, monkeypatch)
+    rng = np.random.default_rng(8)
+    B = 128
+    Q = rng.normal(0.0, 1e-5, size=(B, 7))      # all joints near zero: the iiwa is singular there
+    _, Y = skills.synthetic_inputs(iiwa_fk, B, seed=2)
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q, Y=Y)
+    assert np.array_equal(mode, ref_mode)
+    assert np.isfinite(dq).all()
+    # (near the singularity |dq| is ~1e3..1e5 and the problem is ill-conditioned by construction:
+    # relative agreement of the whole vector at the documented level)
+    assert _rel(dq, ref).max() < 1e-5
+
+
+def test_default_selection_by_batch(iiwa_fk, monkeypatch):
+    """Unset CLIK_LANES: the library picks the team kernel for small batches of the family and the
+    lane-per-instance kernels above; a skill outside the family never gets it."""
+    monkeypatch.delenv("CLIK_LANES", raising=False)
+    ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(iiwa_fk), options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    assert ctrl.kernel_variant(16384).endswith("/team4")
+    assert ctrl.kernel_variant(32768).endswith("/mp2")
+    assert ctrl.kernel_variant(1 << 20).endswith("/lane")
+    pose = cc.PseudoInverseController(skill_spec=skills.pose_skill(iiwa_fk))
+    pose.setup_problem_functions()
+    assert pose.kernel_variant(16384).endswith("/lane")
