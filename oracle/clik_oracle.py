@@ -314,10 +314,11 @@ def dpinv(J, opt):
     """pseudo_inverse.py:92-105."""
     rows, cols = J.shape
     if opt["pinv_method"] == "standard":
-        # cs.pinv: solve(J^T J, J^T) for tall, solve(J J^T, J)^T otherwise
-        if rows >= cols:
-            return np.linalg.solve(J.T.dot(J), J.T)
-        return np.linalg.solve(J.dot(J.T), J).T
+        # cs.pinv (CasADi GenericMatrix::pinv): size2 >= size1 -> solve(J J^T, J)^T, else solve(J^T J, J^T);
+        # a square J takes the first form
+        if cols >= rows:
+            return np.linalg.solve(J.dot(J.T), J).T
+        return np.linalg.solve(J.T.dot(J), J.T)
     lam = opt["damping_factor"]
     if cols >= rows:
         inner = J.dot(J.T) + lam * np.eye(rows)

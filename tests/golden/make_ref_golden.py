@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_pins.npz by running the REFERENCE's own Python (casclik from
+/root/reference) over the stand-in casadi module (tests/golden/refshim).  Build container only:
+the reference does not exist on the GPU box, the fixture (inputs + outputs, data only) travels.
+
+    python tests/golden/make_ref_golden.py
+
+What this pins and what it does not (see refshim/casadi/__init__.py): the reference's control flow and
+formulas are the reference's (its files are imported, not restated); the arithmetic under them is numpy,
+not CasADi.  Forward kinematics: the reference gets T_fk from urdf2casadi (not vendored); here the chain
+is read from the reference's own URDF files and multiplied out with cs.sin / cs.cos / cs.mtimes.
+"""
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import casadi as cs          # noqa: E402  (the stand-in)
+import casclik as cc         # noqa: E402  (the reference)
+import pin_skills            # noqa: E402
+
+assert cs.__file__.startswith(HERE) and cc.__file__.startswith(REF), (cs.__file__, cc.__file__)
+
+
+def rpy_matrix(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def load_chain(urdf, root, tip):
+    """joints root -> tip of a URDF: (type, origin R, origin p, axis, lower, upper, velocity)"""
+    tree = ET.parse(urdf).getroot()
+    by_child = {j.find("child").attrib["link"]: j for j in tree.findall("joint")}
+    chain, link = [], tip
+    while link != root:
+        j = by_child[link]
+        org = j.find("origin")
+        xyz = [float(v) for v in (org.attrib.get("xyz", "0 0 0") if org is not None else "0 0 0").split()]
+        rpy = [float(v) for v in (org.attrib.get("rpy", "0 0 0") if org is not None else "0 0 0").split()]
+        ax = j.find("axis")
+        axis = [float(v) for v in (ax.attrib["xyz"] if ax is not None else "1 0 0").split()]
+        lim = j.find("limit")
+        chain.append(dict(type=j.attrib["type"], R=rpy_matrix(*rpy), p=np.array(xyz), axis=np.array(axis),
+                          lower=float(lim.attrib.get("lower", 0)) if lim is not None else 0.0,
+                          upper=float(lim.attrib.get("upper", 0)) if lim is not None else 0.0,
+                          velocity=float(lim.attrib.get("velocity", 0)) if lim is not None else 0.0))
+        link = j.find("parent").attrib["link"]
+    return chain[::-1]
+
+
+def axis_rotation(axis, c, s):
+    """Rodrigues rotation about a unit axis, entries as expressions of c = cos q, s = sin q"""
+    x, y, z = axis
+    C = 1 - c
+    return [[c + x * x * C, x * y * C - z * s, x * z * C + y * s],
+            [y * x * C + z * s, c + y * y * C, y * z * C - x * s],
+            [z * x * C - y * s, z * y * C + x * s, c + z * z * C]]
+
+
+def make_T_fk(chain):
+    def T_fk(q):
+        T = cs.DM.eye(4)
+        k = 0
+        for j in chain:
+            O = np.eye(4)
+            O[:3, :3], O[:3, 3] = j["R"], j["p"]
+            T = cs.mtimes(T, cs.DM(O))
+            if j["type"] in ("revolute", "continuous"):
+                rows = axis_rotation(j["axis"], cs.cos(q[k]), cs.sin(q[k]))
+                Rq = cs.vertcat(*[cs.horzcat(*(list(r) + [0.0])) for r in rows], cs.horzcat(0.0, 0.0, 0.0, 1.0))
+                T = cs.mtimes(T, Rq)
+                k += 1
+            elif j["type"] == "prismatic":
+                Pq = cs.vertcat(*[cs.horzcat(*(list(np.eye(3)[i]) + [j["axis"][i] * q[k]])) for i in range(3)],
+                                cs.horzcat(0.0, 0.0, 0.0, 1.0))
+                T = cs.mtimes(T, Pq)
+                k += 1
+        return T
+    return T_fk
+
+
+def quat_to_rot(qt):
+    x, y, z, w = qt[0], qt[1], qt[2], qt[3]
+    return [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+
+
+def ori_err(R, quat):
+    """e_o = 1/2 sum_c r_c x rd_c  (SURVEY.md 8(d)), columns of R and of the target rotation"""
+    Rd = quat_to_rot(quat)
+    acc = None
+    for c in range(3):
+        r = [R[i, c] for i in range(3)]
+        d = [Rd[i][c] for i in range(3)]
+        cr = [r[1] * d[2] - r[2] * d[1], r[2] * d[0] - r[0] * d[2], r[0] * d[1] - r[1] * d[0]]
+        acc = cr if acc is None else [a + b for a, b in zip(acc, cr)]
+    return cs.vertcat(*[0.5 * a for a in acc])
+
+
+def quat_from_matrix(R):
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        return np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    i = int(np.argmax(np.diag(R)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+    out = np.zeros(4)
+    out[i], out[j], out[k], out[3] = 0.25 * s, (R[j, i] + R[i, j]) / s, (R[k, i] + R[i, k]) / s, (R[k, j] - R[j, k]) / s
+    return out
+
+
+def numeric_fk(T_fk, n, qv):
+    q = cs.MX.sym("q", n)
+    return cs.Function("fk", [q], [T_fk(q)])(qv).full()
+
+
+ROBOTS = {
+    "iiwa": (os.path.join(REF, "examples/notebooks/urdf/lbr_iiwa_14_r820.urdf"), "base_link", "tool0"),
+    "ur5": (os.path.join(REF, "examples/notebooks/urdf/ur5.urdf"), "base_link", "tool0"),
+}
+PLAN = [   # (fixture name, robot, case, B, input distribution, times)
+    ("iiwa_position", "iiwa", "position", 64, "interior", [0.0]),
+    ("iiwa_position_standard", "iiwa", "position_standard", 48, "interior", [0.0]),
+    ("iiwa_pose", "iiwa", "pose", 64, "interior", [0.0]),
+    ("ur5_pose", "ur5", "pose", 48, "interior", [0.0]),
+    ("iiwa_stack_const", "iiwa", "stack_const", 96, "mixed", [0.0]),
+    ("ur5_stack_const", "ur5", "stack_const", 64, "mixed", [0.0]),
+    ("iiwa_stack_const_time", "iiwa", "stack_const_time", 48, "mixed", [0.3, 1.7]),
+    ("iiwa_stack_sets1d", "iiwa", "stack_sets1d", 96, "mixed", [0.0]),
+    ("iiwa_stack_noff", "iiwa", "stack_noff", 48, "mixed", [0.9]),
+    ("iiwa_conv_last", "iiwa", "conv_last", 64, "mixed", [0.0]),
+    ("iiwa_veleq_first", "iiwa", "veleq_first", 48, "interior", [0.0]),
+    ("iiwa_qp_pose", "iiwa", "qp_pose", 64, "interior", [0.0]),
+    ("ur5_qp_limits", "ur5", "qp_limits", 64, "mixed", [0.0]),
+    ("iiwa_qp_path", "iiwa", "qp_path", 48, "interior", [0.0]),
+]
+
+
+def inputs(chain, T_fk, B, dist, seed):
+    act = [j for j in chain if j["type"] != "fixed"]
+    lo, hi = np.array([j["lower"] for j in act]), np.array([j["upper"] for j in act])
+    rng = np.random.default_rng(seed)
+    if dist == "interior":
+        Q = rng.uniform(0.9 * lo, 0.9 * hi, size=(B, len(lo)))
+    else:
+        r = hi - lo
+        Q = rng.uniform(lo - 0.05 * r, hi + 0.05 * r, size=(B, len(lo)))
+    Qd = rng.uniform(0.8 * lo, 0.8 * hi, size=(B, len(lo)))
+    Y = np.zeros((B, 7))
+    for b in range(B):
+        T = numeric_fk(T_fk, len(lo), Qd[b])
+        Y[b, :3], Y[b, 3:] = T[:3, 3], quat_from_matrix(T[:3, :3])
+    return Q, Y
+
+
+def main():
+    out = {}
+    for k, (name, robot, case, B, dist, times) in enumerate(PLAN):
+        urdf, root, tip = ROBOTS[robot]
+        chain = load_chain(urdf, root, tip)
+        act = [j for j in chain if j["type"] != "fixed"]
+        T_fk = make_T_fk(chain)
+        n = len(act)
+        lower, upper = [j["lower"] for j in act], [j["upper"] for j in act]
+        vmax = [j["velocity"] for j in act]
+        Q, Y = inputs(chain, T_fk, B, dist, seed=100 + k)
+        # constant target of the input-free skills: the pose at a fixed interior configuration
+        q_c = 0.35 * np.array(upper) * np.array([1, -1, 1, -1, 1, -1, 1][:n])
+        Tc = numeric_fk(T_fk, n, q_c)
+        consts = {"p_des": Tc[:3, 3], "quat_des": quat_from_matrix(Tc[:3, :3])}
+        env = pin_skills.Env(cs, cc, T_fk, ori_err, lower, upper, vmax, consts)
+        built = pin_skills.CASES[case](env)
+        spec, ny, nx = built["spec"], built["ny"], built.get("nx", 0)
+        rng = np.random.default_rng(900 + k)
+        X = rng.uniform(-0.2, 1.2, size=(B, nx)) if nx else None
+        out[name + "_Q"], out[name + "_t"] = Q, np.array(times)
+        out[name + "_p_des"], out[name + "_quat_des"] = consts["p_des"], consts["quat_des"]
+        if ny:
+            out[name + "_Y"] = Y[:, :ny]
+        if nx:
+            out[name + "_X"] = X
+        if built["controller"] == "pinv":
+            ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(built["options"]))
+            ctrl.setup_problem_functions()
+            dq = np.zeros((len(times), B, n))
+            mode = np.zeros((len(times), B), dtype=np.int32)
+            for ti, t in enumerate(times):
+                for b in range(B):
+                    kw = {"input_var": Y[b, :ny]} if ny else {}
+                    res = ctrl.solve(t, Q[b], **kw)
+                    dq[ti, b] = res[0].full().reshape(-1)
+                    mode[ti, b] = ctrl.current_mode
+            out[name + "_dq"], out[name + "_mode"] = dq, mode
+            print("%-26s modes %s  max|dq| %.3g  (%d constraints, order %s)" % (
+                name, np.bincount(mode.reshape(-1) + 1), np.abs(dq).max(), len(spec.constraints),
+                [c.label for c in spec.constraints]))
+        else:
+            ctrl = cc.ReactiveQPController(skill_spec=spec, options=dict(built["options"]))
+            ctrl.setup_problem_functions()
+            ctrl.setup_solver()
+            ctrl.setup_initial_problem_solver()
+            nv = n + nx + spec.n_slack_var
+            nc = sum(c.expression.size()[0] for c in spec.constraints)
+            H, A = np.zeros((B, nv)), np.zeros((B, nc, nv))
+            lbA, ubA = np.zeros((B, nc)), np.zeros((B, nc))
+            dq, dx, slack = np.zeros((B, n)), np.zeros((B, nx)), np.zeros((B, spec.n_slack_var))
+            ivirt, islack = np.zeros((B, nx)), np.zeros((B, spec.n_slack_var))
+            worst = 0.0
+            for b in range(B):
+                kw = {}
+                if ny:
+                    kw["input_var"] = Y[b, :ny]
+                if nx:
+                    kw["virtual_var"] = X[b]
+                rq, rx, rs = ctrl.solve(times[0], Q[b], **kw)
+                vals = [times[0], Q[b]] + ([X[b]] if nx else []) + ([Y[b, :ny]] if ny else [])
+                Hb = ctrl.H_func(*vals).full()
+                H[b], A[b] = np.diag(Hb), ctrl.A_func(*vals).full()
+                lbA[b], ubA[b] = ctrl.Blb_func(*vals).full().reshape(-1), ctrl.Bub_func(*vals).full().reshape(-1)
+                dq[b] = rq.full().reshape(-1)
+                if nx:
+                    dx[b] = rx.full().reshape(-1)
+                slack[b] = rs.full().reshape(-1)
+                # the stand-in QP solver's answer must satisfy the KKT conditions of the reference's data
+                x = ctrl.res["x"].full().reshape(-1)
+                lam = ctrl.res["lam_a"].full().reshape(-1)
+                ax = A[b] @ x
+                stat = np.abs(Hb @ x + A[b].T @ lam).max()
+                feas = max(0.0, (ax - ubA[b]).max(), (lbA[b] - ax).max())
+                comp = max(np.abs(np.where(lam > 0, lam * (ax - ubA[b]), 0.0)).max(),
+                           np.abs(np.where(lam < 0, lam * (ax - lbA[b]), 0.0)).max())
+                worst = max(worst, stat, feas, comp)
+                iv, isl = ctrl.solve_initial_problem(times[0], Q[b], virtual_var0=(X[b] if nx else None),
+                                                     input_var0=(Y[b, :ny] if ny else None))
+                if nx:
+                    ivirt[b] = iv.full().reshape(-1)
+                islack[b] = isl.full().reshape(-1)
+            assert worst < 1e-8, worst
+            out.update({name + "_H": H, name + "_A": A, name + "_lbA": lbA, name + "_ubA": ubA, name + "_dq": dq,
+                        name + "_dx": dx, name + "_slack": slack, name + "_init_virt": ivirt,
+                        name + "_init_slack": islack})
+            print("%-26s nv %d nc %d  KKT residual of the stand-in QP %.2e  max|dq| %.3g" % (name, nv, nc, worst, np.abs(dq).max()))
+    np.savez_compressed(os.path.join(HERE, "ref_pins.npz"), **out)
+    print("wrote", os.path.join(HERE, "ref_pins.npz"), "%d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+"""Skill scripts of the reference-pinned fixtures (tests/golden/ref_pins.npz), written ONCE against
+the casclik / casadi API surface and instantiated twice:
+
+  * by tests/golden/make_ref_golden.py with the REFERENCE package (`import casclik as cc` from
+    /root/reference) over the stand-in `casadi` module (tests/golden/refshim), forward kinematics
+    spelled out with sin / cos / mtimes from the reference's own URDF files;
+  * by the tests with the product (`casclik_amd`, `casclik_amd.sym`), forward kinematics from its
+    URDF converter.
+
+`env` supplies what differs: cs, cc, T_fk(q) -> 4x4 expression, ori_err(R, quat) -> 3x1 expression,
+joint limits / speed limits, and the constants a fixture stores (`consts`).
+Reference notebooks these follow: ur5_moe2016_example2.ipynb (1-D and multidimensional limit sets in
+front of a pose task), ur5_transformation_matrix...ipynb cell 8 (position task), cart_on_track_1D...
+cells 6, 56 (soft pose + speed limits in the QP controller, path following with a virtual variable).
+"""
+import numpy as np
+
+
+class Env(object):
+    def __init__(self, cs, cc, T_fk, ori_err, lower, upper, vmax, consts=None):
+        self.cs, self.cc, self.T_fk, self.ori_err = cs, cc, T_fk, ori_err
+        self.lower, self.upper, self.vmax = np.asarray(lower, float), np.asarray(upper, float), np.asarray(vmax, float)
+        self.consts = consts or {}
+
+
+def _syms(env, ny=0, nx=0):
+    cs = env.cs
+    n = len(env.lower)
+    out = dict(t=cs.MX.sym("t"), q=cs.MX.sym("q", n), dq=cs.MX.sym("dq", n))
+    if ny:
+        out["y"] = cs.MX.sym("y", ny)
+    if nx:
+        out["x"] = cs.MX.sym("x", nx)
+        out["dx"] = cs.MX.sym("dx", nx)
+    return out
+
+
+def _pose(env, T, p_des, quat_des):
+    cs = env.cs
+    return cs.vertcat(T[:3, 3] - p_des, env.ori_err(T[:3, :3], quat_des))
+
+
+def position(env):
+    """BASELINE config 1: 3-D tool position, target from input_var"""
+    cc, s = env.cc, _syms(env, ny=3)
+    T = env.T_fk(s["q"])
+    pos = cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - s["y"], gain=10.0,
+                                constraint_type="soft", priority=1)
+    spec = cc.SkillSpecification(label="position", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[pos])
+    return dict(spec=spec, controller="pinv", options={}, ny=3)
+
+
+def pose(env):
+    """BASELINE config 2: 6-D pose task, target from input_var"""
+    cc, s = env.cc, _syms(env, ny=7)
+    T = env.T_fk(s["q"])
+    c = cc.EqualityConstraint(label="tool_pose", expression=_pose(env, T, s["y"][:3], s["y"][3:7]), gain=10.0,
+                              constraint_type="soft", priority=1)
+    spec = cc.SkillSpecification(label="pose", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[c])
+    return dict(spec=spec, controller="pinv", options={}, ny=7)
+
+
+def _stack(env, multidim, options, time_target=False):
+    """BASELINE config 3 with a CONSTANT pose target (the reference cannot build the multidimensional
+    tangent-cone function of a skill with an input_var: pseudo_inverse.py:219-221 appends a string to
+    the variable list)"""
+    cs, cc, s = env.cs, env.cc, _syms(env)
+    n = len(env.lower)
+    T = env.T_fk(s["q"])
+    p_des = np.asarray(env.consts["p_des"], float)
+    quat = np.asarray(env.consts["quat_des"], float)
+    if time_target:
+        p_des = p_des + cs.vertcat(0.05 * cs.sin(s["t"]), 0.02 * s["t"], 0.0)
+    mid = 0.5 * (env.lower + env.upper)
+    cns = [cc.EqualityConstraint(label="tool_pose", expression=_pose(env, T, p_des, quat), gain=10.0,
+                                 constraint_type="soft", priority=10),
+           cc.EqualityConstraint(label="joint_centering", expression=s["q"] - mid, gain=1.0,
+                                 constraint_type="soft", priority=20)]
+    if multidim:
+        cns.append(cc.SetConstraint(label="joint_limits", expression=s["q"], set_min=env.lower, set_max=env.upper,
+                                    priority=0))
+    else:
+        # 1-D limit sets on two joints (ur5_moe2016_example2.ipynb cell 6 style), priorities 0 and 1
+        for k, j in enumerate((1, 3)):
+            cns.append(cc.SetConstraint(label="limit_q%d" % j, expression=s["q"][j], set_min=float(env.lower[j]),
+                                        set_max=float(env.upper[j]), priority=k))
+    spec = cc.SkillSpecification(label="stack", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 constraints=cns)
+    return dict(spec=spec, controller="pinv", options=options, ny=0)
+
+
+def stack_const(env):
+    return _stack(env, True, {"multidim_sets": True})
+
+
+def stack_const_time(env):
+    return _stack(env, True, {"multidim_sets": True}, time_target=True)
+
+
+def stack_sets1d(env):
+    return _stack(env, False, {})
+
+
+def stack_noff(env):
+    """feedforward off on a time-dependent target"""
+    return _stack(env, False, {"feedforward": False}, time_target=True)
+
+
+def position_standard(env):
+    """pinv_method standard (cs.pinv: the undamped normal equations) - a single task: with the doubly
+    stacked first equality every later projector of the standard method is singular by construction"""
+    out = position(env)
+    out["options"] = {"pinv_method": "standard"}
+    return out
+
+
+def conv_last(env):
+    """converge_final_set_to_max with the set as the LAST constraint (pseudo_inverse.py:337-379)"""
+    cs, cc, s = env.cs, env.cc, _syms(env, ny=3)
+    T = env.T_fk(s["q"])
+    pos = cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - s["y"], gain=5.0,
+                                constraint_type="soft", priority=0)
+    lim = cc.SetConstraint(label="limit_q2", expression=s["q"][2], set_min=float(env.lower[2]) * 0.5,
+                           set_max=float(env.upper[2]) * 0.5, gain=2.0, priority=5)
+    spec = cc.SkillSpecification(label="conv_last", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[pos, lim])
+    return dict(spec=spec, controller="pinv", options={"converge_final_set_to_max": True}, ny=3)
+
+
+def veleq_first(env):
+    """a VelocityEqualityConstraint as the first constraint (processed once, :327-335), then an equality"""
+    cs, cc, s = env.cs, env.cc, _syms(env, ny=3)
+    T = env.T_fk(s["q"])
+    vel = cc.VelocityEqualityConstraint(label="tool_z_speed", expression=T[2, 3], target=0.1, priority=0,
+                                        constraint_type="soft")
+    pos = cc.EqualityConstraint(label="tool_xy", expression=T[:2, 3] - s["y"][:2], gain=4.0,
+                                constraint_type="soft", priority=1)
+    spec = cc.SkillSpecification(label="veleq_first", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[vel, pos])
+    return dict(spec=spec, controller="pinv", options={}, ny=3)
+
+
+def qp_pose(env):
+    """BASELINE config 4: soft pose equality + hard joint-speed VelocitySetConstraint"""
+    cs, cc, s = env.cs, env.cc, _syms(env, ny=7)
+    T = env.T_fk(s["q"])
+    c = cc.EqualityConstraint(label="tool_pose", expression=_pose(env, T, s["y"][:3], s["y"][3:7]), gain=10.0,
+                              constraint_type="soft", priority=1)
+    speed = cc.VelocitySetConstraint(label="joint_speed_limits", expression=s["q"], set_min=-env.vmax,
+                                     set_max=env.vmax, priority=0)
+    spec = cc.SkillSpecification(label="qp_pose", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[c, speed])
+    return dict(spec=spec, controller="qp", options={}, ny=7)
+
+
+def qp_limits(env):
+    """soft position task + hard joint-limit SetConstraint + hard speed limits (the UR5 notebooks' QP stack)"""
+    cs, cc, s = env.cs, env.cc, _syms(env, ny=3)
+    T = env.T_fk(s["q"])
+    pos = cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - s["y"], gain=3.0,
+                                constraint_type="soft", priority=1, slack_weight=2.0)
+    lim = cc.SetConstraint(label="joint_limits", expression=s["q"], set_min=env.lower, set_max=env.upper, gain=1.0,
+                           priority=0)
+    speed = cc.VelocitySetConstraint(label="joint_speed_limits", expression=s["q"], set_min=-env.vmax,
+                                     set_max=env.vmax, priority=0)
+    spec = cc.SkillSpecification(label="qp_limits", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[pos, lim, speed])
+    return dict(spec=spec, controller="qp", options={}, ny=3)
+
+
+def qp_path(env):
+    """path following with a virtual variable (cart_on_track_1D...ipynb cells 56, 75): the tool follows
+    p(x) = p0 + x d, the path parameter x is a virtual variable driven to x_goal"""
+    cs, cc, s = env.cs, env.cc, _syms(env, nx=1)
+    T = env.T_fk(s["q"])
+    p0 = np.asarray(env.consts["p_des"], float)
+    d = np.array([0.1, -0.05, 0.08])
+    follow = cc.EqualityConstraint(label="follow_path", expression=T[:3, 3] - (p0 + d * s["x"]), gain=5.0,
+                                   constraint_type="soft", priority=1)
+    goal = cc.EqualityConstraint(label="path_goal", expression=s["x"] - 1.0, gain=0.5, constraint_type="soft",
+                                 priority=2)
+    speed = cc.VelocitySetConstraint(label="joint_speed_limits", expression=s["q"], set_min=-env.vmax,
+                                     set_max=env.vmax, priority=0)
+    spec = cc.SkillSpecification(label="qp_path", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 virtual_var=s["x"], virtual_vel_var=s["dx"], constraints=[follow, goal, speed])
+    return dict(spec=spec, controller="qp", options={}, ny=0, nx=1)
+
+
+CASES = {
+    "position": position, "pose": pose, "stack_const": stack_const, "stack_const_time": stack_const_time,
+    "stack_sets1d": stack_sets1d, "stack_noff": stack_noff, "position_standard": position_standard, "conv_last": conv_last,
+    "veleq_first": veleq_first, "qp_pose": qp_pose, "qp_limits": qp_limits, "qp_path": qp_path,
+}

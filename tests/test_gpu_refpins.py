@@ -1,0 +1,64 @@
+"""GPU: the HIP path (through the controller API -> C ABI) against fixtures produced by the REFERENCE's
+own code run over a stand-in casadi (tests/golden/make_ref_golden.py, see tests/test_refpins.py for what
+that pins).  Every BASELINE config and every branch of pseudo_inverse.py:274-443 the fixtures cover."""
+import numpy as np
+import pytest
+
+import casclik_amd as cc
+import refpins
+from tolerances import QP_RTOL, pinv_rtol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", refpins.PINV_NAMES)
+def test_pinv_hip_matches_the_reference_run(name):
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    ctrl = cc.PseudoInverseController(skill_spec=built["spec"], options=dict(built["options"]))
+    ctrl.setup_problem_functions()
+    tol = pinv_rtol(refpins.sigma_min_geometric(refpins.robot_fk(name), Q), stacked="stack" in name)
+    for ti, t in enumerate(times):
+        dq, _, mode = ctrl.solve_batch(float(t), Q, input_var=Y)
+        assert np.array_equal(mode, refpins.PINS[name + "_mode"][ti]), (name, ctrl.kernel_name)
+        err = refpins.rel_err(dq, refpins.PINS[name + "_dq"][ti])
+        assert (err < tol).all(), (name, ctrl.kernel_name, err.max())
+
+
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_stack_kernel_variants_match_the_reference_run(lanes, monkeypatch):
+    """both kernel families of the config-3 structure (lane per instance, four lanes per instance)"""
+    monkeypatch.setenv("CLIK_LANES", str(lanes))
+    for name in ("iiwa_stack_const", "ur5_stack_const"):
+        built = refpins.product_skill(name)
+        Q, Y, X, times = refpins.arrays(name)
+        ctrl = cc.PseudoInverseController(skill_spec=built["spec"], options=dict(built["options"]))
+        ctrl.setup_problem_functions()
+        assert ctrl.kernel_variant(len(Q)).endswith("/team4") == (lanes == 4), ctrl.kernel_variant(len(Q))
+        dq, _, mode = ctrl.solve_batch(float(times[0]), Q)
+        assert np.array_equal(mode, refpins.PINS[name + "_mode"][0])
+        assert refpins.rel_err(dq, refpins.PINS[name + "_dq"][0]).max() < 1e-7
+
+
+@pytest.mark.parametrize("name", refpins.QP_NAMES)
+def test_qp_hip_matches_the_reference_run(name):
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    P = refpins.PINS
+    t = float(times[0])
+    ctrl = cc.ReactiveQPController(skill_spec=built["spec"])
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    H, A, lb, ub = ctrl.qp_data_batch(t, Q, virtual_var=X, input_var=Y)
+    assert np.abs(H - P[name + "_H"]).max() < 1e-14
+    assert np.abs(A - P[name + "_A"]).max() < 1e-10
+    fin = np.abs(P[name + "_lbA"]) < 1e9
+    assert np.abs(lb - P[name + "_lbA"])[fin].max() < 1e-9 and np.array_equal(lb[~fin], P[name + "_lbA"][~fin])
+    fin = np.abs(P[name + "_ubA"]) < 1e9
+    assert np.abs(ub - P[name + "_ubA"])[fin].max() < 1e-9 and np.array_equal(ub[~fin], P[name + "_ubA"][~fin])
+    dq, dx, slack, status = ctrl.solve_batch(t, Q, virtual_var=X, input_var=Y)
+    assert (status == 0).all(), (name, np.bincount(status))
+    assert refpins.rel_err(dq, P[name + "_dq"]).max() < QP_RTOL
+    assert refpins.rel_err(slack, P[name + "_slack"]).max() < QP_RTOL
+    if X is not None:
+        assert refpins.rel_err(dx, P[name + "_dx"]).max() < QP_RTOL

@@ -1,0 +1,66 @@
+"""CPU: the oracle against fixtures produced by the REFERENCE's own code.
+
+tests/golden/ref_pins.npz holds the outputs of /root/reference/casclik (its constraint classes,
+SkillSpecification, PseudoInverseController.get_problem_expressions / solve, ReactiveQPController
+get_cost_expr / get_constraints_expr / setup_initial_problem_solver / solve) executed over a stand-in
+casadi module (tests/golden/refshim: numpy arithmetic, forward-mode derivatives).  This removes the
+risk that oracle/clik_oracle.py restates the reference's control flow wrongly; it does not pin
+CasADi's rounding (the back-end is a stand-in)."""
+import numpy as np
+import pytest
+
+import refpins
+from oracle import clik_oracle
+from tolerances import PINV_RTOL, pinv_rtol
+
+
+@pytest.mark.parametrize("name", refpins.PINV_NAMES)
+def test_numpy_oracle_matches_the_reference_run(name):
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    tol = pinv_rtol(refpins.sigma_min_geometric(refpins.robot_fk(name), Q), stacked="stack" in name)
+    for ti, t in enumerate(times):
+        ref, ref_mode = refpins.PINS[name + "_dq"][ti], refpins.PINS[name + "_mode"][ti]
+        dq, mode = clik_oracle.pinv_solve_batch(built["spec"], built["options"] or None, float(t), Q, Y=Y)
+        assert np.array_equal(mode, ref_mode), name
+        err = refpins.rel_err(dq, ref)
+        assert (err < tol).all(), (name, err.max())
+    # the reference sorted the constraints by priority itself; the product's front-end must agree
+    assert [c.label for c in built["spec"].constraints][0] in ("joint_limits", "limit_q1", "tool_position",
+                                                                  "tool_pose", "tool_z_speed")
+
+
+@pytest.mark.parametrize("name", [n for n in refpins.PINV_NAMES if "stack_const" in n or n.endswith("_pose")
+                                  or n.endswith("_position")])
+def test_c_oracle_matches_the_reference_run(name):
+    from oracle.c_oracle import CPinvOracle
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    co = CPinvOracle(built["spec"], built["options"] or None)
+    for ti, t in enumerate(times):
+        dq, _, mode = co.solve_batch(float(t), Q, Y=Y)
+        assert np.array_equal(mode, refpins.PINS[name + "_mode"][ti])
+        assert refpins.rel_err(dq, refpins.PINS[name + "_dq"][ti]).max() < PINV_RTOL
+
+
+@pytest.mark.parametrize("name", refpins.QP_NAMES)
+def test_qp_data_and_solution_match_the_reference_run(name):
+    """H, A, lbA, ubA as the reference's H_func / A_func / Blb / Bub (reactive_qp.py:175-246) and the
+    minimiser its solve() slices out (:514-528)"""
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    P = refpins.PINS
+    t = float(times[0])
+    H, A, lb, ub = clik_oracle.qp_data_batch(built["spec"], t, Q, X=X, Y=Y)
+    assert np.abs(H - P[name + "_H"]).max() < 1e-14
+    assert np.abs(A - P[name + "_A"]).max() < 1e-11
+    big = np.abs(P[name + "_lbA"]) < 1e9          # one-sided bounds stay +-1e10 on both sides
+    assert np.abs(lb - P[name + "_lbA"])[big].max() < 1e-10 and np.array_equal(lb[~big], P[name + "_lbA"][~big])
+    big = np.abs(P[name + "_ubA"]) < 1e9
+    assert np.abs(ub - P[name + "_ubA"])[big].max() < 1e-10 and np.array_equal(ub[~big], P[name + "_ubA"][~big])
+    dq, dx, slack, status = clik_oracle.qp_solve_batch(built["spec"], t, Q, X=X, Y=Y)
+    assert (status == 0).all()
+    assert refpins.rel_err(dq, P[name + "_dq"]).max() < 1e-9
+    assert refpins.rel_err(slack, P[name + "_slack"]).max() < 1e-9
+    if X is not None:
+        assert refpins.rel_err(dx, P[name + "_dx"]).max() < 1e-9
