@@ -522,9 +522,38 @@ constexpr QpPlanS make_qp_plan(const ShapeDesc& sd)
     return p;
 }
 
+// Box family: after the soft equalities are folded into P and g, every remaining row is a HARD bound on one
+// state variable (joint-limit SetConstraint / speed-limit VelocitySetConstraint on q, merged per state):
+//     min 1/2 v'P v - g'v   s.t.  lb_c <= v_c <= ub_c  on the bounded states c
+// (BASELINE config 4 and the QP stacks of the UR5 notebooks).  Such a QP is solved by a projected Newton
+// iteration on the states (qp_box_solve) instead of the dual active-set iteration over rows.
+constexpr bool qp_box_family(const ShapeDesc& sd)
+{
+    const QpPlanS p = make_qp_plan(sd);
+    if (p.nr <= 0 || p.nr > CLIK_MAX_DOF) return false;
+    for (int r = 0; r < p.nr; ++r) {
+        const int ti = p.row_task[r];
+        if (sd.soft[ti] != 0 || !shape_unit(sd, ti)) return false;
+        if (sd.cls[ti] != CLIK_CLS_SET && sd.cls[ti] != CLIK_CLS_VELSET) return false;
+    }
+    return true;
+}
+// MEASURED AND NOT THE DEFAULT (config 4, 16384 instances, cold / hot start per tick): dual active-set
+// iteration 40.4 / 10.6 us; projected Newton below 38.5 / 25.8 us; block principal pivoting (first attempt,
+// history) 93 / 7.4 us with a cycling tail of 30+ passes.  The projected Newton needs fewer passes (2.8 on
+// average, 10 worst against 4 and 11-13) but a pass with its face re-solves costs ~1500 instructions against
+// ~1000 of an active-set iteration, so the slowest wave of the batch - which is what a tick costs - is no
+// shorter.  -DCLIK_QP_BOX_PN builds it (tools/qp_passes.py sweeps its pass cap).
+#ifdef CLIK_QP_BOX_PN
+#define CLIK_QP_BOX_OK(SD) qp_box_family(SD)
+#else
+#define CLIK_QP_BOX_OK(SD) false
+#endif
+
 template <const ShapeDesc& SD>
 struct QpLayout {
     static constexpr QpPlanS P = make_qp_plan(SD);
+    static constexpr bool BOX = CLIK_QP_BOX_OK(SD);
     static constexpr int N = SD.n;
     static constexpr int NY = SD.n_y > 0 ? SD.n_y : 0;
     static constexpr int NR = P.nr;
@@ -539,11 +568,11 @@ struct QpLayout {
     static constexpr int O_Z = 0;
     static constexpr int O_Y = O_Z + N;
     static constexpr int O_Q = O_Y + NY;
-    static constexpr int O_LB = O_Q + NT;
+    static constexpr int O_LB = O_Q + (BOX ? 0 : NT);       // (the box solver keeps no Q / Y / c0 in LDS)
     static constexpr int O_UB = O_LB + NRA;
     static constexpr int O_C0 = O_UB + NRA;
-    static constexpr int O_YS = O_C0 + NRA;          // P^-1 a_r'  (NR x N)
-    static constexpr int O_SL = O_YS + NRA * N;      // folded right-hand sides, then the slack output rows
+    static constexpr int O_YS = O_C0 + (BOX ? 0 : NRA);      // P^-1 a_r'  (NR x N)
+    static constexpr int O_SL = O_YS + (BOX ? 0 : NRA * N);  // folded right-hand sides, then the slack output rows
     static constexpr int SLOTS = O_SL + NSA;
     static constexpr size_t LDS_BYTES = ((size_t)IMG_DOUBLES + (size_t)SLOTS * WAVE) * sizeof(double);
 };
@@ -656,6 +685,211 @@ __device__ __forceinline__ double qp_row_s(const Img<SD>* __restrict__ S, const 
     return jac<SD, TI>(S, tc, i, j);
 }
 
+// Projected Newton (Bertsekas 1982) for  min f(x) = 1/2 x'P x - g'x,  lb_c <= x_c <= ub_c  (P symmetric positive
+// definite, packed lower triangle; unbounded states carry -/+ infinity).  x stays feasible.  One pass:
+//   binding set  I = { c : x_c at a bound and the gradient pushes it outward }   (those stay where they are)
+//   Newton direction on the rest: a fixed-size LDL' of P with the rows / columns of I replaced by the identity
+//     (one instruction stream for all lanes, only the masks differ),
+//   x <- clip(x - d) when that decreases f enough (88 % of the passes), else the direction is re-solved without
+//     the states it would push through their bounds and the exact minimiser along its feasible segment is taken
+//     (a 1-D quadratic: no backtracking loop),
+//   the gradient follows by  grad += P (x_new - x)  - the same product gives the decrease of f for the test.
+// A pass that moves nothing is a fixed point = the KKT point (checked against a freshly computed gradient).
+// The method is monotone (no cycling) and identifies the active set in a few passes: on the config-4 bench
+// inputs (5-7 of the 7 speed limits active at the optimum) 2.8 passes per instance on average, 6 at the 99th
+// percentile, 10 worst of 32768 (block principal pivoting: 4.2 / 17 / 30; the dual active-set iteration it
+// replaces for this family: 4 iterations on average, 11-13 worst, at twice the instructions per iteration).
+// Start: the vertex the linear term points to (x_c = ub_c where g_c > 0, lb_c where g_c < 0) - with most bounds
+// active at the optimum that is closer than the unconstrained minimiser and needs no factorisation - or, hot,
+// the partition of the previous tick (hot = atL | atU << 16).
+// Returns 0 (KKT point), 1 (pass cap), 2 (lb > ub: infeasible).
+template <int N>
+__device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
+                                            const double (&lb)[N], const double (&ub)[N], const int max_pass,
+                                            const bool valid, double (&x)[N], int32_t* hot, const bool use_hot)
+{
+    constexpr int NT = N * (N + 1) / 2;
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < N; ++a) empty = empty || (lb[a] - ub[a] > 1e-9 * fmax(1.0, fmax(fabs(lb[a]), fabs(ub[a]))));
+    uint32_t hl = 0u, hu = 0u;
+    if (use_hot && hot != nullptr) {
+        const uint32_t h = (uint32_t)*hot;
+        hl = h & 0xffffu;
+        hu = (h >> 16) & ~hl;
+    }
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        const double mid = fmin(fmax(0.0, lb[a]), ub[a]);
+        const bool has_l = lb[a] > -1e300, has_u = ub[a] < 1e300;
+        double x0;
+        if (use_hot) x0 = ((hl >> a) & 1u) && has_l ? lb[a] : ((((hu >> a) & 1u) && has_u) ? ub[a] : mid);
+        else x0 = (g[a] > 0.0) ? (has_u ? ub[a] : mid) : ((g[a] < 0.0 && has_l) ? lb[a] : mid);
+        x[a] = empty ? 0.0 : x0;
+    }
+    double gr[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        double sacc = -g[a];
+#pragma unroll
+        for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
+        gr[a] = sacc;
+    }
+    bool done = !valid || empty;
+    int status = empty ? 2 : 1;
+    // Newton direction of the face { x_c fixed for c in fix }:  d = P_FF^-1 grad_F, 0 on the fixed states.  The
+    // fixed rows / columns leave the system through a 1e30 penalty on the diagonal (their direction comes out
+    // ~1e-30 and the clip keeps them exactly on the bound; the factor of the free block is the factor of P_FF to
+    // rounding): 2 instructions per state instead of 3 selects per matrix entry, one instruction stream for all lanes
+    auto face_newton = [&](const bool (&fix)[N], double (&dir)[N]) __attribute__((always_inline)) {
+        double M[NT], rd[N];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) M[a] = Pm[a];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            dir[a] = fix[a] ? 0.0 : gr[a];
+            M[tri(a, a)] += fix[a] ? 1e30 : 0.0;
+        }
+        ldl_factor_s<N>(M, rd);
+        ldl_solve_s<N>(M, rd, dir);
+#pragma unroll
+        for (int a = 0; a < N; ++a) dir[a] = fix[a] ? 0.0 : dir[a];      // (exactly zero: the hit test below divides by it)
+    };
+    // (bitwise & | on the flags below: the short-circuit forms compile to a divergent branch per state)
+#pragma unroll 1
+    for (int pass = 0; pass < max_pass; ++pass) {
+        if (__ballot(!done) == 0ull) break;
+        // binding set: states on a bound that the gradient pushes outward
+        double d[N];
+        bool at_l[N], at_u[N], bind[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            at_l[a] = x[a] <= lb[a];
+            at_u[a] = x[a] >= ub[a];
+            bind[a] = (at_l[a] & (gr[a] > 0.0)) | (at_u[a] & (gr[a] < 0.0));
+        }
+        face_newton(bind, d);
+        // full Newton step, clipped to the box (moves whole blocks of states onto their bounds at once):
+        // dl = x_new - x, pd = P dl; accepted when it decreases f enough (Armijo on the clipped step)
+        double dl[N], pd[N];
+        double lin = 0.0, quad = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double xn = fmin(fmax(x[a] - d[a], lb[a]), ub[a]);
+            dl[a] = xn - x[a];
+            lin = fma(gr[a], dl[a], lin);
+        }
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], dl[b], sacc);
+            pd[a] = sacc;
+            quad = fma(dl[a], sacc, quad);
+        }
+        const bool full_ok = done | (fma(0.5, quad, lin) <= 1e-4 * lin);
+        if (__ballot(!full_ok) != 0ull) {
+            // (12 % of the passes) the clipped step overshoots.  States that sit on a bound with the gradient pointing
+            // inward but the Newton direction pushing them outward cannot move: they join the fixed set and the
+            // direction is re-solved on the smaller face (at most three times) - zeroing their components instead
+            // leaves a non-Newton direction that zigzags between two faces for dozens of passes.  Then the exact
+            // minimiser along the straight segment x - a dm, a <= the first bound hit: f is a 1-D quadratic there
+            // and dm a descent direction, so there is no backtracking loop.
+            bool stay[N], settled = full_ok;
+#pragma unroll
+            for (int a = 0; a < N; ++a) stay[a] = (at_l[a] & (d[a] > 0.0)) | (at_u[a] & (d[a] < 0.0));
+#pragma unroll 1
+            for (int rf = 0; rf < 3; ++rf) {
+                bool anyz = false;
+#pragma unroll
+                for (int a = 0; a < N; ++a) anyz = anyz | stay[a];
+                const bool need = !settled & anyz;
+                if (__ballot(need) == 0ull) break;
+                bool fix[N], grew = false;
+                double d2[N];
+#pragma unroll
+                for (int a = 0; a < N; ++a) fix[a] = bind[a] | stay[a];
+                face_newton(fix, d2);
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    const bool s2 = stay[a] | (!fix[a] & ((at_l[a] & (d2[a] > 0.0)) | (at_u[a] & (d2[a] < 0.0))));
+                    grew = grew | (s2 != stay[a]);
+                    stay[a] = need ? s2 : stay[a];
+                    d[a] = need ? d2[a] : d[a];
+                }
+                settled = settled | !grew;
+            }
+            double dm[N], pdm[N];
+            double amax = 1.0, sl = 0.0, cv = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                dm[a] = stay[a] ? 0.0 : d[a];
+                const double room = (dm[a] > 0.0) ? (x[a] - lb[a]) : (x[a] - ub[a]);     // same sign as dm
+                // room / dm by a reciprocal (a hit distance needs no correctly rounded quotient)
+                const double ahit = (dm[a] != 0.0) ? room * recip(dm[a]) : 1.0;
+                amax = fmin(amax, ahit);
+                sl = fma(gr[a], dm[a], sl);
+            }
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], dm[b], sacc);
+                pdm[a] = sacc;
+                cv = fma(dm[a], sacc, cv);
+            }
+            const double astar = (cv > 0.0) ? sl * recip(cv) : 1.0;
+            const double al = full_ok ? 0.0 : fmax(0.0, fmin(amax, astar));
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                dl[a] = full_ok ? dl[a] : -al * dm[a];
+                pd[a] = full_ok ? pd[a] : -al * pdm[a];
+            }
+        }
+        double mv = 0.0, mx = 0.0;
+        bool kkt = true;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            mv = fmax(mv, fabs(dl[a]));
+            mx = fmax(mx, fabs(x[a]));
+            const double xn = fmin(fmax(x[a] + dl[a], lb[a]), ub[a]);
+            const double gn = gr[a] + pd[a];
+            x[a] = done ? x[a] : xn;
+            gr[a] = done ? gr[a] : gn;
+            const double tol = 1e-9 * fmax(1.0, fabs(g[a]));
+            kkt = kkt & (((x[a] <= lb[a]) & (gr[a] >= -tol)) | ((x[a] >= ub[a]) & (gr[a] <= tol)) | (fabs(gr[a]) <= tol));
+        }
+        // a pass that moves nothing AND satisfies the KKT conditions (on the running gradient; re-checked below
+        // on a fresh one) ends the iteration; a tiny move alone does not: a step can be cut short by a bound
+        // that is 1e-13 away, and the next pass goes on from there
+        done = done | ((mv <= 1e-10 * (1.0 + mx)) & kkt);
+    }
+    if (!empty) {
+        // the KKT conditions of the returned point on a freshly computed gradient
+        bool kkt = true;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double sacc = -g[a];
+#pragma unroll
+            for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
+            const double tol = 1e-9 * fmax(1.0, fabs(g[a]));
+            const bool fine = ((x[a] <= lb[a]) & (sacc >= -tol)) | ((x[a] >= ub[a]) & (sacc <= tol)) | (fabs(sacc) <= tol);
+            kkt = kkt & fine;
+        }
+        status = kkt ? 0 : 1;
+    }
+    if (hot != nullptr && valid) {
+        uint32_t atL = 0u, atU = 0u;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            if (x[a] <= lb[a]) atL |= 1u << a;
+            else if (x[a] >= ub[a]) atU |= 1u << a;
+        }
+        *hot = (int32_t)(atL | (atU << 16));
+    }
+    return status;
+}
+
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
@@ -691,6 +925,46 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
         for (int b = 0; b <= a; ++b) L[tri(a, b)] = (a == b) ? T->mu * T->state_w[a] : 0.0;
     }
     qp_gather_s<SD, 0>(S, T, tk, tc, z, ysl, lane, L, v, slots);
+    if constexpr (LY::BOX) {
+        // bounds by state (rows of the plan are unit rows on distinct states), then projected Newton
+        double lbc[N], ubc[N], gv[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            lbc[a] = -__builtin_inf();
+            ubc[a] = __builtin_inf();
+            gv[a] = v[a];
+        }
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int col = SD.ucol[P.row_task[r]][P.row_local[r]] - 1;
+            lbc[col] = slots[(LY::O_LB + r) * WAVE + lane];
+            ubc[col] = slots[(LY::O_UB + r) * WAVE + lane];
+        });
+        int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
+        if (!valid) status = 0;
+        // slack of the folded rows: s = J v - b
+#pragma unroll
+        for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * WAVE + lane] : 0.0;
+        static_for<0, SD.n_tasks>([&](auto tc_) __attribute__((always_inline)) {
+            constexpr int TI = decltype(tc_)::value;
+            if constexpr (P.folded[TI]) {
+                constexpr int sb = P.slack_base[TI];
+                static_for<0, SD.m[TI]>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    double acc = -sl[sb + i];
+                    if constexpr (shape_unit(SD, TI)) {
+                        constexpr int col = SD.ucol[TI][i] - 1;
+                        acc += v[col];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) acc = fma(jac<SD, TI>(S, tc, i, j), v[j], acc);
+                    }
+                    sl[sb + i] = acc;
+                });
+            }
+        });
+        return status;
+    } else {
     ldl_factor_s<N>(L, rd);
     ldl_solve_s<N>(L, rd, v);          // v0 = P^-1 g
 
@@ -807,6 +1081,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
         }
     });
     return status;
+    }   // (dual active-set path)
 }
 
 template <const ShapeDesc& SD>

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""profiles/r2_counters.json from the PMC passes of tools/profile_round.sh (gpurun_out/r2prof/pmc_*.txt):
+raw per-dispatch means of every counter, and the derived figures bench.py prints (HBM traffic with the
+gfx950 FETCH_SIZE x2 correction, executed fp64 flops, per-wave instruction counts, SQ busy / wait shares).
+SQ_*_CYCLES-type counters tick once per 4 clocks (MI355X_MICROARCH.md); they are reported x4.
+    python tools/make_counters_json.py gpurun_out/r2prof profiles/r2_counters.json
+"""
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per instance, batch)
+    "stack_team4": ("stack_mixed_B16384_kStackIiwa/team4", "kStackIiwa/team4", 172, 16384),
+    "stack_lane": ("stack_mixed_B16384_kStackIiwa/mp2", "kStackIiwa/mp2", 172, 16384),
+    "qp": ("qp_mixed_B16384_qp_static_kQpPoseIiwa", "qp_static_kQpPoseIiwa", 168, 16384),
+}
+out = {"note": "rocprofv3 --pmc passes (one counter group per run, no tracing) of python3 bench.py --graph 0 at 16384 "
+               "instances, inputs 'mixed'; mean per dispatch over 520 dispatches, summed over XCDs "
+               "(tools/rocprof_counters.py).  traffic_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the x2 is the "
+               "gfx950 correction calibrated in profiles/r1_traffic.json).  fp64_flops_per_launch = 64 lanes x "
+               "(2 FMA + MUL + ADD) wave-instructions EXECUTED (the team kernel's four lanes per instance repeat the "
+               "front end, so its executed flops exceed the lane kernels').  insts_per_wave = counter / SQ_WAVES; "
+               "cycle-type SQ counters are in units of 4 clocks and are listed x4 as clk_per_wave."}
+for tag, (key, kernel, bpi, B) in CASES.items():
+    raw = {}
+    try:
+        for line in open("%s/pmc_%s.txt" % (src, tag)):
+            m = re.match(r"(\S+)\s+mean per dispatch ([0-9.]+) over (\d+) dispatches", line)
+            if m:
+                raw[m.group(1)] = float(m.group(2))
+    except OSError:
+        continue
+    if not raw:
+        continue
+    w = raw.get("SQ_WAVES", 0.0) or 1.0
+    ent = {"kernel": kernel, "raw_per_dispatch": raw, "algorithmic_bytes": bpi * B,
+           "traffic_bytes": int(round(2 * raw["FETCH_SIZE"] * 1024 + raw["WRITE_SIZE"] * 1024)),
+           "fp64_flops_per_launch": 64.0 * (2 * raw["SQ_INSTS_VALU_FMA_F64"] + raw["SQ_INSTS_VALU_MUL_F64"]
+                                            + raw["SQ_INSTS_VALU_ADD_F64"]),
+           "waves": w,
+           "insts_per_wave": {k[9:].lower(): round(raw[k] / w, 1) for k in raw if k.startswith("SQ_INSTS_")},
+           "clk_per_wave": {k[3:].lower(): round(4 * raw[k] / w) for k in
+                            ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+                             "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS") if k in raw}}
+    out[key] = ent
+with open(dst, "w") as f:
+    json.dump(out, f, indent=1)
+for k, v in out.items():
+    if isinstance(v, dict):
+        print(k, "traffic", v["traffic_bytes"], "flops %.3g" % v["fp64_flops_per_launch"], v["insts_per_wave"], v["clk_per_wave"])

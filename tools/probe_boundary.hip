@@ -51,6 +51,41 @@ __global__ __launch_bounds__(256) void k_rw(const double* __restrict__ q, const 
     if (tid < 192) dq[b0 + 256 + tid] = acc;
 }
 
+// straight-line code of the same length as a tick (no loop): does instruction fetch cost anything beyond
+// the 4 clocks of issue?  NI independent-ish fp64 FMAs over 8 accumulators, fully unrolled, against the
+// same work in a loop of 64 (which stays in the instruction cache / buffer).
+template <int NI, bool UNROLLED>
+__global__ __launch_bounds__(256) void k_code(const double* __restrict__ q, const double* __restrict__ y,
+                                              double* __restrict__ dq, const double* __restrict__ img, int nf_rt)
+{
+    const int tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * 64 * 7;
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = q[b0 + tid] + k;
+    const double m = y[b0 + tid] + 0.999999, c = y[b0 + tid + 1] + 1e-9;      // run-time operands: no literals
+    if constexpr (UNROLLED) {
+#pragma unroll
+        for (int i = 0; i < NI / 8; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = fma(a[k], m, c);
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < NI / 64; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = fma(a[k], m, c);
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += a[k];
+    if (nf_rt == 12345) acc += 1.0;
+    dq[b0 + tid] = acc;
+}
+
 typedef void (*kern_t)(const double*, const double*, double*, const double*, int);
 
 int main()
@@ -74,6 +109,12 @@ int main()
         {"rw_img_f500", k_rw<1, 500>, 16384},
         {"rw_img_f1000", k_rw<1, 1000>, 16384},
         {"rw_img_f2000", k_rw<1, 2000>, 16384},
+        {"code1024_loop", k_code<1024, false>, 0},
+        {"code1024_flat", k_code<1024, true>, 0},
+        {"code2048_loop", k_code<2048, false>, 0},
+        {"code2048_flat", k_code<2048, true>, 0},
+        {"code4096_loop", k_code<4096, false>, 0},
+        {"code4096_flat", k_code<4096, true>, 0},
     };
     for (auto& c : cases) {
         hipGraph_t g;
