@@ -15,6 +15,7 @@ from casclik_amd.skill_specification import SkillSpecification
 from casclik_amd.controllers import PseudoInverseController, ReactiveQPController
 from casclik_amd.urdf import converter
 from casclik_amd import sym
+from casclik_amd import integration_methods
 from casclik_amd.geom import casadi_geom, numpy_geom
 
 __version__ = "0.1.0"

@@ -95,6 +95,11 @@ class BaseConstraint(object):
         """(d expression / d varA) * varB (reference: constraints.py:75-80)."""
         return cs.mtimes(self.jacobian(varA), varB)
 
+    def nullspace(self, var):
+        """``I - pinv(J) J`` with ``J = d expression / d var`` as an MX (reference: constraints.py:82-85)."""
+        J = self.jacobian(var)
+        return cs.MX.eye(var.size()[0]) - cs.mtimes(cs.pinv(J), J)
+
 
 class EqualityConstraint(BaseConstraint):
     """Drive ``expression`` to zero:  J v = -gain*expression - d expr/dt

@@ -35,6 +35,26 @@ def device_of(device=None):
     return torch.device(device)
 
 
+def check_out_tensor(t, shape, dtype_name, device, what):
+    """An output tensor the kernels write through ``data_ptr()``: it must be exactly what they assume -
+    a contiguous torch tensor of that shape and dtype on the controller's device - or the launch would write
+    out of bounds / garbage instead of raising."""
+    torch = _torch()
+    if t is None:
+        return
+    want = getattr(torch, dtype_name)
+    if not isinstance(t, torch.Tensor):
+        raise ValueError("%s must be a torch tensor on %s" % (what, device))
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (what, tuple(shape), tuple(t.shape)))
+    if t.dtype != want:
+        raise ValueError("%s must be %s, got %s" % (what, want, t.dtype))
+    if t.device != torch.device(device):
+        raise ValueError("%s lives on %s, the controller on %s" % (what, t.device, device))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % what)
+
+
 def to_device_matrix(val, width, device, what, batch=None):
     """numpy / list / DM / torch -> contiguous float64 [B, width] tensor on
     ``device``; returns (tensor, was_numpy)."""

@@ -18,7 +18,7 @@ from .. import _capi
 from .. import sym as cs
 from ..lowering import lower_skill, DYN_MAX_M
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
-                              to_device_matrix, _torch)
+                              to_device_matrix, check_out_tensor, _torch)
 
 
 class PseudoInverseController(BaseController):
@@ -219,6 +219,7 @@ class PseudoInverseController(BaseController):
                 raise ValueError("skill has input_var: pass input_var")
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
         if out is not None:
+            check_out_tensor(out, (B, d.n_q), "float64", dev, "out")
             dQ = out
         else:
             dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
@@ -252,6 +253,8 @@ class PseudoInverseController(BaseController):
             X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
         if d.n_y > 0:
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        check_out_tensor(out, (B, d.n_q), "float64", dev, "out")
+        check_out_tensor(mode_out, (B,), "int32", dev, "mode_out")
         dQ = out if out is not None else torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
         dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
         mode = mode_out if mode_out is not None else torch.empty((B,), dtype=torch.int32, device=dev)
@@ -277,59 +280,51 @@ class PseudoInverseController(BaseController):
         return tick
 
     def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008,
-                      max_speed=0.0, virtual_var=None):
-        """``len(time_vars)`` ticks of solve -> clamp(+-max_speed) -> Euler
-        ``q += dq*dt`` in one launch (the host loop of
-        ur5_moe2016_example2.ipynb:537-545).  Returns (q_final, dq_last, mode_last); for a
-        skill with virtual variables (path following, cart_on_track_1D...ipynb cell 60: pass
-        ``virtual_var``) the path parameters are integrated alongside, unclamped, and the result
-        is (q_final, x_final, dq_last, dx_last, mode_last)."""
+                      max_speed=0.0, virtual_var=None, method="euler"):
+        """``len(time_vars)`` ticks of solve -> clamp(+-max_speed) -> integrate in one launch.
+        ``method="euler"``: ``q += dq*dt``, the host loop of ur5_moe2016_example2.ipynb:537-545;
+        ``method="rk4"``: classical Runge-Kutta with the controller as the right-hand side
+        (casclik/integration_methods.py:17-23: k1..k4 at t, t+dt/2, t+dt/2, t+dt, each clamped).
+        Returns (q_final, dq_last, mode_last); for a skill with virtual variables (path following,
+        cart_on_track_1D...ipynb cell 60: pass ``virtual_var``) the path parameters are integrated
+        alongside, unclamped, and the result is (q_final, x_final, dq_last, dx_last, mode_last)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
         dev = self._device
+        if method not in ("euler", "rk4"):
+            raise ValueError("method must be 'euler' or 'rk4'")
         Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
         if not was_np:
             Q = Q.clone()
         B = Q.shape[0]
+        X = dX = None
         if d.n_x > 0:
             if virtual_var is None:
                 raise ValueError("skill has virtual_var: pass virtual_var")
             X, x_np = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
             if not x_np:
                 X = X.clone()
-            Y = None
-            if d.n_y > 0:
-                Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
-            times = np.asarray(time_vars, dtype=float).reshape(-1)
-            tt = np.concatenate([d.time_terms(t) for t in times]) if d.n_tslots else np.zeros(0)
-            tt, ttp = _capi.tterms_arg(tt)
-            dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
             dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev)
-            mode = torch.empty((B,), dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
-                rc = self._lib.clik_pinv_rollout_batch_x(
-                    self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
-                    ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(mode), current_stream(dev))
-            _capi.check(self._lib, rc)
-            outs = (Q, X, dQ, dX, mode)
-            return tuple(o.cpu().numpy() for o in outs) if was_np else outs
         Y = None
         if d.n_y > 0:
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
         times = np.asarray(time_vars, dtype=float).reshape(-1)
-        tt = np.concatenate([d.time_terms(t) for t in times]) if d.n_tslots else np.zeros(0)
+        if method == "rk4":
+            stage_times = np.stack([times, times + 0.5 * dt, times + 0.5 * dt, times + dt], axis=1).reshape(-1)
+        else:
+            stage_times = times
+        tt = np.concatenate([d.time_terms(t) for t in stage_times]) if d.n_tslots else np.zeros(0)
         tt, ttp = _capi.tterms_arg(tt)
         dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
         mode = torch.empty((B,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            rc = self._lib.clik_pinv_rollout_batch(
-                self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
-                ptr(Q), ptr(Y), ptr(dQ), ptr(mode), current_stream(dev))
+            rc = self._lib.clik_pinv_rollout_batch_m(
+                self._handle, B, int(times.size), 1 if method == "rk4" else 0, float(dt), float(max_speed), ttp,
+                ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(mode), current_stream(dev))
         _capi.check(self._lib, rc)
-        if was_np:
-            return Q.cpu().numpy(), dQ.cpu().numpy(), mode.cpu().numpy()
-        return Q, dQ, mode
+        outs = (Q, X, dQ, dX, mode) if d.n_x > 0 else (Q, dQ, mode)
+        return tuple(o.cpu().numpy() for o in outs) if was_np else outs
 
     def solve(self, time_var, robot_var, virtual_var=None, input_var=None,
               warmstart_robot_vel_var=None, warmstart_virtual_vel_var=None,

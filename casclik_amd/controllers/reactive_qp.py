@@ -23,7 +23,7 @@ from ..constraints import (EqualityConstraint, SetConstraint, VelocityEqualityCo
                            VelocitySetConstraint)
 from ..lowering import lower_skill
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
-                              to_device_matrix, _torch)
+                              to_device_matrix, check_out_tensor, _torch)
 from .pseudo_inverse import _flat, _scalar
 
 
@@ -226,18 +226,15 @@ class ReactiveQPController(BaseController):
         Without virtual variables (every UR5 notebook) the rows decouple, ``-s_i in [lb_i, ub_i]``,
         and the minimiser is each slack clamped to its interval nearest zero - evaluated here from
         the expression graph at the one initial state (setup-time host arithmetic, like the
-        lowering; no solver involved).  With virtual variables the values come from the full QP at
-        the initial state on the device (the reference re-optimises virtual_vel and slack with the
-        robot held still); callers use either only as ``warmstart_*`` arguments, which an exact
-        solver does not need."""
+        lowering; no solver involved).  With virtual variables the reduced QP of :300-424 is solved
+        on the device (``_initial_problem_with_virtual``)."""
         if not getattr(self, "_has_initial", True):
             return None, None
         spec = self.skill_spec
         if spec.n_slack_var == 0 and not (spec.n_virtual_var > 0 and spec._has_virtual):
             return None, None
         if spec.n_virtual_var > 0 and spec._has_virtual:
-            res = self.solve(time_var0, robot_var0, virtual_var0, input_var0)
-            return res[1], res[2]
+            return self._initial_problem_with_virtual(time_var0, robot_var0, virtual_var0, robot_vel_var0, input_var0)
         from .. import autodiff
         env = {}
 
@@ -304,6 +301,70 @@ class ReactiveQPController(BaseController):
             # -s in [lb, ub]:  s in [-ub, -lb], the point nearest zero
             slack.append(np.clip(0.0, -ub, -lb))
         return None, cs.DM(np.concatenate(slack).reshape(-1, 1))
+
+    def _initial_problem_with_virtual(self, time_var0, robot_var0, virtual_var0, robot_vel_var0, input_var0):
+        """The reference's initial problem with virtual variables (reactive_qp.py:300-459), on the device:
+
+            min  mu w_virt |dx|^2 + (1 + mu) w_slack |s|^2                                   (:321-331, D12)
+            s.t. [J_virt | -I_slack] [dx; s]  in  [lbA, ubA] - J_q dq0                       (:339-391)
+
+        over the rows of the constraints that depend on the virtual variables or carry slack, the robot
+        velocity held at ``robot_vel_var0`` (zeros by default, :437-438).  ``A = [J_q | J_virt | -I]``,
+        ``lbA``, ``ubA`` of the full QP come from the device (``qp_data_batch``: the kernels' FK and
+        Jacobians at the initial state); the reduced QP is then a skill of its own - linear
+        velocity-level rows in the ``n_virtual`` unknowns with those numbers as coefficients - and is
+        solved by a second ReactiveQPController, i.e. by the same device kernels."""
+        from .. import sym as cs_
+        from ..skill_specification import SkillSpecification
+        spec = self.skill_spec
+        nq, nx, ns = spec.n_robot_var, spec.n_virtual_var, spec.n_slack_var
+        as1 = lambda v, n: np.zeros((1, n)) if v is None else np.asarray(  # noqa: E731
+            v.toarray() if hasattr(v, "toarray") else v, dtype=float).reshape(1, n)
+        q0, x0 = as1(robot_var0, nq), as1(virtual_var0, nx)
+        y0 = as1(input_var0, spec.n_input_var) if spec.n_input_var > 0 and spec._has_input else None
+        dq0 = as1(robot_vel_var0, nq).reshape(-1)
+        H, A, lb, ub = self.qp_data_batch(time_var0, q0, virtual_var=x0, input_var=y0)
+        H, A, lb, ub = H[0], A[0], lb[0], ub[0]
+        mu = self.weight_shifter
+        w_virt = H[nq:nq + nx] / mu
+        w_slack = H[nq + nx:] - mu                      # main problem: mu + w  (:187)
+        xs = cs_.MX.sym("dx_init", nx)
+        cns, slack_w, row = [], [], 0
+        sl = 0
+        for cn in spec.constraints:
+            m = cn.expression.size()[0]
+            rows = slice(row, row + m)
+            row += m
+            soft = cn.constraint_type == "soft"
+            found_virt = cs_.depends_on(cn.expression, spec.virtual_var)       # structural, as J_virt.nnz() (:346-347)
+            if soft:
+                wk = w_slack[sl:sl + m]
+                sl += m
+            if not (found_virt or soft):
+                continue
+            Jv = A[rows, nq:nq + nx] if found_virt else np.zeros((m, nx))
+            shift = A[rows, :nq].dot(dq0)
+            lo, hi = lb[rows] - shift, ub[rows] - shift
+            kw = dict(label="init_" + cn.label, expression=cs_.mtimes(Jv, xs), priority=len(cns),
+                      constraint_type="soft" if soft else "hard")
+            if np.array_equal(lo, hi):
+                cns.append(VelocityEqualityConstraint(target=lo, **kw))
+            else:
+                cns.append(VelocitySetConstraint(set_min=lo, set_max=hi, **kw))
+            if soft:
+                slack_w.extend(((1.0 + mu) * wk - mu).tolist())               # mu + w' = (1 + mu) w  (:331)
+        if not cns:
+            return None, None
+        t_ = cs_.MX.sym("t_init")
+        sub = SkillSpecification(label=spec.label + "_initial", time_var=t_, robot_var=xs, constraints=cns)
+        ctrl = ReactiveQPController(sub, robot_var_weights=list(w_virt), slack_var_weights=slack_w or None,
+                                    options={"device": self.options.get("device")} if self.options.get("device") is not None else None)
+        ctrl.setup_problem_functions()
+        dx, _, slack, status = ctrl.solve_batch(0.0, np.zeros((1, nx)))
+        if int(status[0]) == 2:
+            raise RuntimeError("initial problem infeasible")
+        res_slack = cs.DM(slack[0].reshape(-1, 1)) if ns > 0 else None
+        return cs.DM(dx[0].reshape(-1, 1)), res_slack
 
     # -- per tick -----------------------------------------------------------------
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
@@ -409,6 +470,7 @@ class ReactiveQPController(BaseController):
             X, _ = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)
         if d.n_y > 0:
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        check_out_tensor(out, (B, d.n_q), "float64", dev, "out")
         dQ = out if out is not None else torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
         dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
         SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None

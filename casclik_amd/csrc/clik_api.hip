@@ -30,6 +30,7 @@ struct LaunchArgs {
     int mode_parallel;
     double* roll_x;         // (mirror of clik_pinv_kernels.hpp)
     double* roll_dx;
+    int roll_stages;
 };
 int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
@@ -81,8 +82,6 @@ struct clik_pinv {
     clik_jit_rollout_fn jit_rollout;
     char      jit_name[64];
     int       kernel;       // index into the kernel table (static shape or dynamic)
-    double*   d_tterms;     // rollout workspace
-    size_t    d_tterms_cap;
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
@@ -103,8 +102,6 @@ struct clik_qp {
     clik_jit_qp_fn jit_solve;
     clik_jit_qp_rollout_fn jit_rollout;
     char      jit_name[64];
-    double*   d_tterms;     // rollout workspace
-    size_t    d_tterms_cap;
 };
 
 static thread_local char g_err[512] = "";
@@ -755,8 +752,6 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         if (!ln || ln[0] == '0' || ln[0] == '\0') h->mode_parallel |= 4;
         else if (ln[0] == '4') h->mode_parallel |= 4 | 8;
     }
-    h->d_tterms = nullptr;
-    h->d_tterms_cap = 0;
     *out = h;
     return CLIK_OK;
 }
@@ -790,7 +785,6 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
 extern "C" int clik_pinv_destroy(clik_pinv* h)
 {
     if (!h) return CLIK_OK;
-    if (h->d_tterms) (void)hipFree(h->d_tterms);
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->dev) (void)hipFree(h->dev);
     delete h;
@@ -838,12 +832,32 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr};
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr, 1};
     hipError_t e = h->jit_solve
                        ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
                        : clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
                                                  (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
+    return CLIK_OK;
+}
+
+// Time-slot records of a rollout (host) -> a device buffer that lives for this call only: allocated, filled and
+// released in stream order (hipMallocAsync / hipFreeAsync), so handles stay immutable and two rollouts on two
+// streams never share it.  The host array is consumed before the call returns (pageable source: the runtime
+// stages it synchronously), so the caller may free it right away.
+static int stage_tterms(const double* tterms, size_t count, hipStream_t stream, double** out)
+{
+    *out = nullptr;
+    if (count == 0) return CLIK_OK;
+    if (!tterms) return fail(CLIK_EINVAL, "tterms required");
+    hipError_t e = hipMallocAsync((void**)out, count * sizeof(double), stream);
+    if (e != hipSuccess) { *out = nullptr; return hipfail(e, "hipMallocAsync(tterms)"); }
+    e = hipMemcpyAsync(*out, tterms, count * sizeof(double), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(*out, stream);
+        *out = nullptr;
+        return hipfail(e, "hipMemcpyAsync(tterms)");
+    }
     return CLIK_OK;
 }
 
@@ -858,40 +872,43 @@ extern "C" int clik_pinv_rollout_batch_x(const clik_pinv* hc, int64_t B, int32_t
                                          double max_speed, const double* tterms, double* q, double* x,
                                          const double* y, double* dq, double* dx, int32_t* mode, void* stream)
 {
-    clik_pinv* h = const_cast<clik_pinv*>(hc);
+    return clik_pinv_rollout_batch_m(hc, B, n_ticks, CLIK_INTEGRATE_EULER, dt, max_speed, tterms, q, x, y, dq, dx, mode,
+                                     stream);
+}
+
+extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t n_ticks, int32_t method, double dt,
+                                         double max_speed, const double* tterms, double* q, double* x,
+                                         const double* y, double* dq, double* dx, int32_t* mode, void* stream)
+{
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
+    if (method != CLIK_INTEGRATE_EULER && method != CLIK_INTEGRATE_RK4) return fail(CLIK_EINVAL, "unknown integration method %d", method);
     if (B == 0 || n_ticks == 0) return CLIK_OK;
     const DevSkill& S = h->host;
+    const bool has_static = h->jit_rollout || (h->kernel >= 0 && clik::pinv_kernel_is_static(h->kernel));
     if (S.d.n_x > 0) {
         if (!x || !dx) return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required (clik_pinv_rollout_batch_x)");
-        if (!h->jit_rollout && !(h->kernel >= 0 && clik::pinv_kernel_is_static(h->kernel)))
+        if (!has_static)
             return fail(CLIK_EUNSUPPORTED, "the rollout of a skill with virtual_var needs a shape-specialised kernel "
                                            "(none attached for this skill)");
     }
+    if (method == CLIK_INTEGRATE_RK4 && !has_static)
+        return fail(CLIK_EUNSUPPORTED, "the Runge-Kutta rollout needs a shape-specialised kernel (none attached for this skill)");
     if (!h->jit_rollout && (h->kernel < 0 || !clik::pinv_kernel_is_static(h->kernel)) && skill_needs_static(S))
         return extern_needs_kernel("clik_pinv_rollout_batch");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
-    const size_t need = (size_t)n_ticks * 2 * (size_t)S.d.n_tslots;
-    if (need > 0) {
-        if (!tterms) return fail(CLIK_EINVAL, "tterms required");
-        if (need > h->d_tterms_cap) {
-            if (h->d_tterms) (void)hipFree(h->d_tterms);
-            hipError_t e = hipMalloc((void**)&h->d_tterms, need * sizeof(double));
-            if (e != hipSuccess) { h->d_tterms = nullptr; h->d_tterms_cap = 0; return hipfail(e, "hipMalloc(tterms)"); }
-            h->d_tterms_cap = need;
-        }
-        hipError_t e = hipMemcpyAsync(h->d_tterms, tterms, need * sizeof(double), hipMemcpyHostToDevice,
-                                      (hipStream_t)stream);
-        if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
-    }
-    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx};
+    const int stages = method == CLIK_INTEGRATE_RK4 ? 4 : 1;
+    double* d_tt = nullptr;
+    int rc = stage_tterms(tterms, (size_t)n_ticks * stages * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
+    if (rc) return rc;
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx, stages};
     hipError_t e = h->jit_rollout
-                       ? h->jit_rollout(&la, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
+                       ? h->jit_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
                                         (hipStream_t)stream)
-                       : clik::pinv_launch_rollout(h->kernel, la, h->d_tterms, n_ticks, dt, max_speed, (long long)B,
+                       : clik::pinv_launch_rollout(h->kernel, la, d_tt, n_ticks, dt, max_speed, (long long)B,
                                                    q, y, dq, mode, (hipStream_t)stream);
+    if (d_tt) (void)hipFreeAsync(d_tt, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_rollout_kernel launch");
     return CLIK_OK;
 }
@@ -974,8 +991,6 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
     h->jit_name[0] = 0;
-    h->d_tterms = nullptr;
-    h->d_tterms_cap = 0;
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
@@ -1046,7 +1061,7 @@ extern "C" int clik_qp_rollout_batch_x(const clik_qp* hc, int64_t B, int32_t n_t
                                        const double* tterms, double* q, double* x, const double* y, double* dq,
                                        double* dx, double* slack, int32_t* status, void* stream)
 {
-    clik_qp* h = const_cast<clik_qp*>(hc);
+    const clik_qp* h = hc;
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
     if (B == 0 || n_ticks == 0) return CLIK_OK;
@@ -1057,25 +1072,16 @@ extern "C" int clik_qp_rollout_batch_x(const clik_qp* hc, int64_t B, int32_t n_t
         return fail(CLIK_EUNSUPPORTED, "the QP rollout needs a shape-specialised kernel (none attached for this skill)");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
-    const size_t need = (size_t)n_ticks * 2 * (size_t)S.d.n_tslots;
-    if (need > 0) {
-        if (!tterms) return fail(CLIK_EINVAL, "tterms required");
-        if (need > h->d_tterms_cap) {
-            if (h->d_tterms) (void)hipFree(h->d_tterms);
-            hipError_t e = hipMalloc((void**)&h->d_tterms, need * sizeof(double));
-            if (e != hipSuccess) { h->d_tterms = nullptr; h->d_tterms_cap = 0; return hipfail(e, "hipMalloc(tterms)"); }
-            h->d_tterms_cap = need;
-        }
-        hipError_t e = hipMemcpyAsync(h->d_tterms, tterms, need * sizeof(double), hipMemcpyHostToDevice,
-                                      (hipStream_t)stream);
-        if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync(tterms)");
-    }
+    double* d_tt = nullptr;
+    int rc = stage_tterms(tterms, (size_t)n_ticks * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
+    if (rc) return rc;
     hipError_t e = h->jit_rollout
-                       ? h->jit_rollout(h->d_img, h->d_tterms, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack,
+                       ? h->jit_rollout(h->d_img, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack,
                                         status, x, dx, (hipStream_t)stream)
-                       : clik::qp_launch_rollout_static(h->static_k, h->d_img, h->d_tterms, n_ticks, dt, max_speed,
+                       : clik::qp_launch_rollout_static(h->static_k, h->d_img, d_tt, n_ticks, dt, max_speed,
                                                         (long long)B, q, y, dq, slack, status, x, dx,
                                                         (hipStream_t)stream);
+    if (d_tt) (void)hipFreeAsync(d_tt, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_rollout_kernel launch");
     return CLIK_OK;
 }
@@ -1091,7 +1097,6 @@ extern "C" const char* clik_qp_kernel_name(const clik_qp* h)
 extern "C" int clik_qp_destroy(clik_qp* h)
 {
     if (!h) return CLIK_OK;
-    if (h->d_tterms) (void)hipFree(h->d_tterms);
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->dev) (void)hipFree(h->dev);
     delete h;

@@ -1144,10 +1144,13 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B,
     const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed,
-    double* __restrict__ x, double* __restrict__ dx)
+    double* __restrict__ x, double* __restrict__ dx, const int stages)
 {
     // x / dx: virtual variables (path parameters, cart_on_track_1D...ipynb cells 56-60): integrated like the
-    // robot variables, never clamped; unused (null) in skills without them
+    // robot variables, never clamped; unused (null) in skills without them.
+    // stages: 1 = explicit Euler (the notebooks' loop), 4 = classical Runge-Kutta with the controller as the
+    // right-hand side (integration_methods.py:17-23): k1..k4 at t, t + dt/2, t + dt/2, t + dt, each stage clamped;
+    // tterms then holds four time-slot records per tick.
     extern __shared__ double lds[];
     constexpr int N = SD.n;
     constexpr int NX = SD.n_x, NQ = N - NX;
@@ -1181,19 +1184,39 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     for (int j = 0; j < N; ++j) vout[j] = 0.0;
 #pragma unroll 1
     for (int tick = 0; tick < n_ticks; ++tick) {
-        // the skill image is loop invariant: without this fence its LDS reads are all hoisted out of the
-        // tick loop and the live constants spill (2.8 KB of scratch per lane)
-        asm volatile("" ::: "memory");
-        // time terms are read in place ([values | derivatives], 2*nts doubles per tick, never past them)
-        const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
-        pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+        double z0[N], ks[N];
+        int mode0 = -1;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            double d = vout[j];
-            if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
-            vout[j] = d;
-            z[j] = fma(d, dt, z[j]);
+            z0[j] = z[j];
+            ks[j] = 0.0;
         }
+#pragma unroll 1
+        for (int st = 0; st < stages; ++st) {
+            // the skill image is loop invariant: without this fence its LDS reads are all hoisted out of the
+            // tick loop and the live constants spill (2.8 KB of scratch per lane)
+            asm volatile("" ::: "memory");
+            // time terms are read in place ([values | derivatives], 2*nts doubles per stage, never past them)
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + st) * 2 * nts);
+            pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+            const double wgt = (stages == 1) ? 1.0 : ((st == 0 || st == 3) ? 1.0 : 2.0);
+            const double cnext = (st == 2) ? dt : 0.5 * dt;          // offset of the next stage's state
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double d = vout[j];
+                if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                ks[j] = fma(wgt, d, ks[j]);
+                z[j] = fma(d, cnext, z0[j]);
+            }
+            mode0 = (st == 0) ? acc_mode : mode0;
+        }
+        const double scale = (stages == 1) ? 1.0 : 1.0 / 6.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            vout[j] = ks[j] * scale;
+            z[j] = fma(vout[j], dt, z0[j]);
+        }
+        acc_mode = mode0;       // (Runge-Kutta: the mode of the first stage)
     }
     __syncthreads();
     state_to_lds<NQ, NX>(z, zs, xs, lane);
@@ -1222,6 +1245,7 @@ struct LaunchArgs {
                                // bit 2 team kernel (four lanes per instance) where the shape allows, bit 3 ... at any batch
     double* roll_x;            // rollout of a skill with virtual variables: their state (in/out) and last rates
     double* roll_dx;
+    int roll_stages;           // rollout: controller evaluations per tick (0 / 1 explicit Euler, 4 Runge-Kutta)
 };
 typedef hipError_t (*solve_fn)(const LaunchArgs&, const TickArgs&, long long, const double*, const double*,
                                const double*, double*, double*, int32_t*, hipStream_t);
@@ -1333,7 +1357,8 @@ inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tte
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL((pinv_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
-                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx);
+                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx,
+                       a.roll_stages == 4 ? 4 : 1);
     return hipGetLastError();
 }
 

@@ -763,6 +763,44 @@ def inv(a):
     return DM(_np.linalg.inv(evaluate(m, {})))
 
 
+def solve(a, b):
+    """``cs.solve(A, B)`` = A^-1 B.  Constant operands: numpy.  Expressions: Gaussian elimination without
+    pivoting written out on the expression graph - meant for the small symmetric positive definite systems the
+    reference forms (``J J' + lam I`` in its pinv, pseudo_inverse.py:92-105; constraints.py:82-85)."""
+    A = a if isinstance(a, MX) else MX(a)
+    B = b if isinstance(b, MX) else MX(b)
+    n = A.size()[0]
+    if A.size()[1] != n or B.size()[0] != n:
+        raise ValueError("solve: dimension mismatch %s \\ %s" % (A.size(), B.size()))
+    if A.is_constant() and B.is_constant():
+        return DM(_np.linalg.solve(evaluate(A, {}), evaluate(B, {})))
+    k = B.size()[1]
+    M = [[A[i, j] for j in range(n)] + [B[i, c] for c in range(k)] for i in range(n)]
+    for p in range(n):
+        piv = M[p][p]
+        for i in range(p + 1, n):
+            f = M[i][p] / piv
+            for j in range(p + 1, n + k):
+                M[i][j] = M[i][j] - f * M[p][j]
+    X = [[None] * k for _ in range(n)]
+    for c in range(k):
+        for i in range(n - 1, -1, -1):
+            acc = M[i][n + c]
+            for j in range(i + 1, n):
+                acc = acc - M[i][j] * X[j][c]
+            X[i][c] = acc / M[i][i]
+    return vertcat(*[horzcat(*row) for row in X])
+
+
+def pinv(a):
+    """``cs.pinv(A)`` as CasADi defines it: ``size2 >= size1``: ``solve(A A', A)'``, else ``solve(A'A, A')``."""
+    A = a if isinstance(a, MX) else MX(a)
+    r, c = A.size()
+    if c >= r:
+        return solve(mtimes(A, A.T), A).T
+    return solve(mtimes(A.T, A), A.T)
+
+
 def if_else(cond, a, b, short_circuit=False):
     c, x = _bcast(_as_array(cond), _as_array(a))
     c, y = _bcast(c, _as_array(b))

@@ -23,8 +23,10 @@
  *   - `tterms` is a HOST pointer to 2*n_tslots doubles (values then time
  *     derivatives of the skill's time-only sub-expressions at this tick); it is
  *     copied into the kernel arguments, so the call stays graph-capturable.
- *   - Handles are immutable after creation: solve calls are re-entrant across
- *     streams.  Calls are asynchronous w.r.t. the host (no hidden sync).
+ *   - Handles are immutable after creation: solve and rollout calls are re-entrant
+ *     across streams.  Calls are asynchronous w.r.t. the host (no hidden sync); the
+ *     rollouts keep their per-call time-slot records in a stream-ordered allocation
+ *     (hipMallocAsync / hipFreeAsync on the caller's stream), not in the handle.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream) so this
  *     header needs no HIP include.
  */
@@ -225,6 +227,19 @@ int clik_pinv_rollout_batch(const clik_pinv* h, int64_t B, int32_t n_ticks,
  * dx receives the last tick; the clamp applies to the robot velocities only.
  * Needs a shape-specialised kernel (attached or AOT).                          */
 int clik_pinv_rollout_batch_x(const clik_pinv* h, int64_t B, int32_t n_ticks,
+                              double dt, double max_speed, const double* tterms,
+                              double* q, double* x, const double* y, double* dq,
+                              double* dx, int32_t* mode, void* stream);
+
+/* The same with a choice of integration scheme (casclik/integration_methods.py:11-23):
+ * CLIK_INTEGRATE_EULER = the calls above; CLIK_INTEGRATE_RK4 = classical Runge-Kutta with the controller
+ * as the right-hand side, four solves per tick at t, t+dt/2, t+dt/2, t+dt (each clamped), state
+ * += dt/6 (k1 + 2 k2 + 2 k3 + k4).  tterms then holds n_ticks*4*2*n_tslots doubles (one record per stage);
+ * dq / dx receive the last tick's combined rate, mode the mode of its first stage.  x / dx may be NULL for
+ * skills without virtual variables.  Runge-Kutta needs a shape-specialised kernel.                  */
+#define CLIK_INTEGRATE_EULER 0
+#define CLIK_INTEGRATE_RK4   1
+int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t n_ticks, int32_t method,
                               double dt, double max_speed, const double* tterms,
                               double* q, double* x, const double* y, double* dq,
                               double* dx, int32_t* mode, void* stream);

@@ -253,3 +253,62 @@ def test_initial_problem_slack_matches_the_reference_formulation(ur5_fk):
     ctrl = cc.ReactiveQPController(skill_spec=hard)
     ctrl.setup_initial_problem_solver()
     assert ctrl.solve_initial_problem(0.0, home) == (None, None)
+
+
+def test_integration_method_factories():
+    """get_euler_function / get_rk4_function with the reference's call shape (integration_methods.py:11-23)"""
+    import numpy as np
+    from casclik_amd import sym as cs
+    from casclik_amd.integration_methods import get_euler_function, get_rk4_function
+    x = cs.MX.sym("x", 2)
+    rate = lambda v: cs.vertcat(v[1], -v[0])        # harmonic oscillator  # noqa: E731
+    dt = 0.01
+    fe, fr = get_euler_function(x, rate, dt), get_rk4_function(x, rate, dt)
+    ve = vr = np.array([1.0, 0.0])
+    for _ in range(100):
+        ve = np.array(fe(ve)).reshape(-1)
+        vr = np.array(fr(vr)).reshape(-1)
+    exact = np.array([np.cos(1.0), -np.sin(1.0)])
+    assert np.abs(vr - exact).max() < 1e-10                 # fourth order
+    assert 1e-3 < np.abs(ve - exact).max() < 1e-2           # first order
+    # one Euler step is exactly x + dx dt
+    assert np.allclose(np.array(fe([2.0, 3.0])).reshape(-1), [2.0 + 3.0 * dt, 3.0 - 2.0 * dt], rtol=0, atol=1e-15)
+    # symbolic call: the step function composes into an expression (as cs.Function does)
+    y = cs.MX.sym("y", 2)
+    two = cs.Function("two", [y], [fr(fr(y))])
+    assert np.abs(np.array(two([1.0, 0.0])).reshape(-1) - [np.cos(2 * dt), -np.sin(2 * dt)]).max() < 1e-11
+
+
+def test_nullspace_and_symbolic_pinv(ur5_fk):
+    """BaseConstraint.nullspace = I - pinv(J) J (constraints.py:82-85) with cs.pinv / cs.solve of the shim"""
+    import numpy as np
+    import casclik_amd as cc
+    from casclik_amd import sym as cs
+    q = cs.MX.sym("q", 6)
+    c = cc.EqualityConstraint("pos", ur5_fk["T_fk"](q)[:3, 3] - np.array([0.3, 0.2, 0.4]), gain=1.0)
+    N = cs.Function("N", [q], [c.nullspace(q)])
+    J = cs.Function("J", [q], [c.jacobian(q)])
+    qv = np.array([0.3, -1.2, 1.0, -0.5, 0.7, 0.2])
+    Nv, Jv = np.array(N(qv)), np.array(J(qv))
+    assert np.abs(Jv @ Nv).max() < 1e-13 and np.abs(Nv @ Nv - Nv).max() < 1e-13
+    assert np.abs(Nv - (np.eye(6) - np.linalg.pinv(Jv) @ Jv)).max() < 1e-12
+    # tall matrices take the other branch of cs.pinv; constants are evaluated on the spot
+    A = np.random.default_rng(0).normal(size=(5, 3))
+    assert np.abs(np.array(cs.pinv(A)) - np.linalg.pinv(A)).max() < 1e-12
+    assert np.abs(np.array(cs.solve(A.T @ A, np.eye(3))) - np.linalg.inv(A.T @ A)).max() < 1e-12
+
+
+def test_out_tensor_validation_helper():
+    """outputs handed to the kernels by pointer are validated (shape, dtype, device, contiguity)"""
+    import pytest
+    import torch
+    from casclik_amd.controllers.base_controller import check_out_tensor
+    dev = torch.device("cpu")
+    check_out_tensor(torch.empty((4, 7), dtype=torch.float64), (4, 7), "float64", dev, "out")
+    check_out_tensor(None, (4, 7), "float64", dev, "out")
+    for bad in (torch.empty((4, 7), dtype=torch.float32), torch.empty((3, 7), dtype=torch.float64),
+                torch.empty((7, 4), dtype=torch.float64).T, [[0.0] * 7] * 4):
+        with pytest.raises(ValueError):
+            check_out_tensor(bad, (4, 7), "float64", dev, "out")
+    with pytest.raises(ValueError):
+        check_out_tensor(torch.empty((4,), dtype=torch.int64), (4,), "int32", dev, "mode_out")

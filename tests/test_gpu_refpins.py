@@ -62,3 +62,26 @@ def test_qp_hip_matches_the_reference_run(name):
     assert refpins.rel_err(slack, P[name + "_slack"]).max() < QP_RTOL
     if X is not None:
         assert refpins.rel_err(dx, P[name + "_dx"]).max() < QP_RTOL
+
+
+@pytest.mark.parametrize("name", refpins.QP_NAMES)
+def test_initial_problem_hip_matches_the_reference_run(name):
+    """ReactiveQPController.solve_initial_problem against the reference's (reactive_qp.py:300-459): without
+    virtual variables the decoupled slack rows, with them the reduced QP solved on the device"""
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    P = refpins.PINS
+    ctrl = cc.ReactiveQPController(skill_spec=built["spec"])
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    ctrl.setup_initial_problem_solver()
+    for b in range(0, len(Q), 11):
+        virt, slack = ctrl.solve_initial_problem(float(times[0]), Q[b], virtual_var0=None if X is None else X[b],
+                                                 input_var0=None if Y is None else Y[b])
+        ref = P[name + "_init_slack"][b]
+        assert np.abs(np.asarray(slack.toarray()).reshape(-1) - ref).max() < 1e-8 * (1 + np.abs(ref).max())
+        if X is not None:
+            refv = P[name + "_init_virt"][b]
+            assert np.abs(np.asarray(virt.toarray()).reshape(-1) - refv).max() < 1e-8 * (1 + np.abs(refv).max())
+        else:
+            assert virt is None

@@ -64,3 +64,19 @@ def test_qp_data_and_solution_match_the_reference_run(name):
     assert refpins.rel_err(slack, P[name + "_slack"]).max() < 1e-9
     if X is not None:
         assert refpins.rel_err(dx, P[name + "_dx"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", refpins.QP_NAMES)
+def test_initial_problem_matches_the_reference_run(name):
+    """solve_initial_problem (reactive_qp.py:300-459): the reduced QP over [virtual_vel; slack] with the robot
+    velocity held at zero, weights mu w_virt and (1 + mu) w_slack (D12) - the oracle's restatement against the
+    reference's own code"""
+    built = refpins.product_skill(name)
+    Q, Y, X, times = refpins.arrays(name)
+    P = refpins.PINS
+    for b in range(0, len(Q), 7):
+        virt, slack = clik_oracle.qp_initial_problem(built["spec"], float(times[0]), Q[b],
+                                                     x0=None if X is None else X[b], y0=None if Y is None else Y[b])
+        assert np.abs(slack - P[name + "_init_slack"][b]).max() < 1e-9 * (1 + np.abs(slack).max())
+        if X is not None:
+            assert np.abs(virt - P[name + "_init_virt"][b]).max() < 1e-9 * (1 + np.abs(virt).max())
