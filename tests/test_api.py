@@ -312,3 +312,41 @@ def test_out_tensor_validation_helper():
             check_out_tensor(bad, (4, 7), "float64", dev, "out")
     with pytest.raises(ValueError):
         check_out_tensor(torch.empty((4,), dtype=torch.int64), (4,), "int32", dev, "mode_out")
+
+
+def test_print_constraints_matches_the_notebooks_stored_output():
+    """SkillSpecification.print_constraints (skill_specification.py:202-217) against the text the reference
+    notebooks STORE in their output cells (tests/golden/notebook_prints.json): stable priority sort, the
+    virtual / input dependence flags and the per-class counts, verbatim."""
+    import io
+    import json
+    import os
+    import sys
+    import casclik_amd as cc
+    from casclik_amd import sym as cs
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "notebook_prints.json")))
+    for fx in data["prints"]:
+        t, p, dp = cs.MX.sym("t"), cs.MX.sym("p"), cs.MX.sym("dp")
+        x, dx = (cs.MX.sym("x"), cs.MX.sym("dx")) if fx["virtual"] else (None, None)
+        sym = {"q": p, "x": x, "t": t}
+        cons = []
+        for c in fx["constraints"]:
+            expr = 0.5
+            for d in c["depends"]:
+                expr = expr + (0.4 * cs.sin(0.3 * sym[d]) if d != "q" else sym[d])
+            kw = dict(label=c["label"], expression=expr, priority=c["priority"], constraint_type=c["constraint_type"])
+            if c["cls"] == "SetConstraint":
+                cons.append(cc.SetConstraint(set_min=0.0, set_max=1.0, **kw))
+            elif c["cls"] == "VelocitySetConstraint":
+                cons.append(cc.VelocitySetConstraint(set_min=-0.275, set_max=0.275, **kw))
+            else:
+                cons.append(cc.EqualityConstraint(gain=1.0, **kw))
+        spec = cc.SkillSpecification(label=fx["label"], time_var=t, robot_var=p, robot_vel_var=dp, virtual_var=x,
+                                     virtual_vel_var=dx, constraints=cons)
+        buf, old = io.StringIO(), sys.stdout
+        sys.stdout = buf
+        try:
+            spec.print_constraints()
+        finally:
+            sys.stdout = old
+        assert buf.getvalue() == fx["stdout"], (fx["notebook"], fx["cell"], buf.getvalue())
