@@ -80,5 +80,7 @@ class ShardedController(object):
         if gather and dist.is_initialized():
             if not isinstance(dq, torch.Tensor):
                 dq = torch.from_numpy(dq)
+            if dq.is_cuda and dist.get_backend(self.group) == "gloo":
+                dq = dq.cpu()           # (a gloo group exchanges host tensors; "nccl" = RCCL takes the device rows)
             return all_gather_rows(dq, n_rows_total, self.group)
         return dq
