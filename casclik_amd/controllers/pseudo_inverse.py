@@ -153,6 +153,21 @@ class PseudoInverseController(BaseController):
                     name = None
             if name:
                 self.kernel_name = name
+        # Skills of the four-lanes-per-instance family get that kernel with their own numbers compiled in (the
+        # reference's JIT compiles its functions with the constants of the skill too); function_opts["jit_values"]
+        # = False or CLIK_JIT_VALUES=0 keeps the kernel that reads the skill image from memory
+        self.value_kernel = None
+        if want_jit and self.options["function_opts"].get("jit_values", True) \
+                and os.environ.get("CLIK_JIT_VALUES", "1") != "0" and not self.descriptor.extern_code \
+                and self._lib.clik_pinv_kernel_variant(handle, 1).decode() == "team4":
+            from .. import jit
+            with torch.cuda.device(self._device):
+                try:
+                    self.value_kernel = jit.attach_values(self._lib, handle, cdesc, copts)
+                except RuntimeError as exc:
+                    import warnings
+                    warnings.warn("value-specialised kernel could not be built, using the image-reading one: %s"
+                                  % str(exc)[:300])
         if self.kernel_name == "none":
             raise NotImplementedError(
                 "a constraint of this skill has more rows than the built-in kernels are wide (%d) and no "

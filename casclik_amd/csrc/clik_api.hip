@@ -35,6 +35,8 @@ struct LaunchArgs {
 int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
 const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B);
+bool shape_team_ok_rt(const ShapeDesc& sd);
+long long pinv_team_max_batch();
 int pinv_kernel_width(int k);
 int pinv_kernel_is_static(int k);
 hipError_t pinv_launch_solve(int k, const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
@@ -71,6 +73,9 @@ typedef hipError_t (*clik_jit_solve_fn)(const clik::LaunchArgs*, const TickArgs*
 typedef hipError_t (*clik_jit_rollout_fn)(const clik::LaunchArgs*, const double*, int, double, double, long long,
                                           double*, const double*, double*, int32_t*, hipStream_t);
 
+typedef hipError_t (*clik_jit_value_fn)(const clik::LaunchArgs*, const TickArgs*, long long, const double*,
+                                        const double*, double*, int32_t*, hipStream_t);
+
 struct clik_pinv {
     DevSkill  host;
     DevSkill* dev;
@@ -82,6 +87,9 @@ struct clik_pinv {
     clik_jit_rollout_fn jit_rollout;
     char      jit_name[64];
     int       kernel;       // index into the kernel table (static shape or dynamic)
+    // team kernel with this skill's numbers compiled in (clik_pinv_attach_value_kernel), used for the batches the
+    // image-reading team kernel would serve
+    clik_jit_value_fn   val_solve;
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
@@ -646,6 +654,7 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     h->d_img = nullptr;
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
+    h->val_solve = nullptr;
     h->jit_name[0] = 0;
     finish_pinv_shape(S, opts);
     if (opts->pinv_method != CLIK_PINV_DAMPED && opts->pinv_method != CLIK_PINV_STANDARD) {
@@ -748,6 +757,11 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         // family up to kTeamMaxBatch instances; bit 3: at any batch size.  CLIK_LANES=1 keeps the
         // lane-per-instance kernels, CLIK_LANES=4 forces the team kernel (head-to-head runs), unset / 0 =
         // the library's choice.
+        // Bit 4: CLIK_LARGE_BATCH=0 keeps the one-wave-per-SIMD lane kernel at every batch size; bit 5 marks
+        // handles served by the ahead-of-time table (the only ones that carry the large-batch build)
+        const char* lb = getenv("CLIK_LARGE_BATCH");
+        if (lb && lb[0] == '0') h->mode_parallel |= 16;
+        if (clik::pinv_kernel_is_static(h->kernel)) h->mode_parallel |= 32;
         const char* ln = getenv("CLIK_LANES");
         if (!ln || ln[0] == '0' || ln[0] == '\0') h->mode_parallel |= 4;
         else if (ln[0] == '4') h->mode_parallel |= 4 | 8;
@@ -780,6 +794,31 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
     h->jit_rollout = (clik_jit_rollout_fn)rollout_fn;
     snprintf(h->jit_name, sizeof(h->jit_name), "%s", name ? name : "jit");
     return CLIK_OK;
+}
+
+extern "C" int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (solve_fn && !clik::shape_team_ok_rt(h->host.shape))
+        return fail(CLIK_EUNSUPPORTED, "value-specialised kernels exist for the four-lanes-per-instance family only");
+    h->val_solve = (clik_jit_value_fn)solve_fn;
+    if (solve_fn) h->mode_parallel |= 64;
+    else h->mode_parallel &= ~64;
+    return CLIK_OK;
+}
+
+// the skill image of this handle (what the static kernels read from memory) as 64-bit words, for
+// casclik_amd/jit.py to compile into a value-specialised kernel; returns the number of words
+extern "C" int clik_pinv_image_words(const clik_pinv* h, uint64_t* buf, int cap)
+{
+    if (!h || !buf || cap <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    std::vector<char> img;
+    size_t bytes = 0;
+    if (!build_skill_image(h->host, img, &bytes)) return fail(CLIK_EUNSUPPORTED, "skill rows are not contiguous");
+    const int words = (int)((bytes + 7) / 8);
+    if (words > cap) return fail(CLIK_EINVAL, "image needs %d words, buffer holds %d", words, cap);
+    memcpy(buf, img.data(), (size_t)words * 8);
+    return words;
 }
 
 extern "C" int clik_pinv_destroy(clik_pinv* h)
@@ -833,7 +872,11 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
     const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr, 1};
-    hipError_t e = h->jit_solve
+    // a value-specialised team kernel serves the batches the image-reading team kernel would serve
+    const bool team_batch = (h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch());
+    hipError_t e = (h->val_solve && team_batch)
+                       ? h->val_solve(&la, &tk, (long long)B, q, y, dq, mode, (hipStream_t)stream)
+                   : h->jit_solve
                        ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
                        : clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
                                                  (hipStream_t)stream);

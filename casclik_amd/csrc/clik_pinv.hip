@@ -1,6 +1,7 @@
 // Kernel table of the PseudoInverseController path: AOT shape-specialised
 // instantiations (this TU, shapes from clik_shapes_gen.hpp) + the dynamic-shape
 // kernels (clik_pinv_dyn.hip).
+#define CLIK_LARGE_BATCH_VARIANT 1      // the ahead-of-time shapes also get the large-batch (occupancy 2) kernel
 #include "clik_pinv_kernels.hpp"
 
 namespace clik {
@@ -80,6 +81,8 @@ int pinv_pick_kernel(const DevSkill& S, int allow_static)
 
 const char* pinv_kernel_name(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].name : "none"; }
 const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B) { return static_variant(sd, mode_parallel, B); }
+bool shape_team_ok_rt(const ShapeDesc& sd) { return shape_team_ok(sd); }
+long long pinv_team_max_batch() { return kTeamMaxBatch; }
 int pinv_kernel_width(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].N : 0; }
 int pinv_kernel_is_static(int k) { return (k >= 0 && k < kNumShapes && kShapes[k].sd) ? 1 : 0; }
 

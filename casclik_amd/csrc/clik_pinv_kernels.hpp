@@ -787,7 +787,7 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     });
 }
 
-// (experiment switch: -DCLIK_OCC2 caps the one-wave kernel at 256 VGPRs = two waves per SIMD)
+// (experiment switches: -DCLIK_OCC2 / -DCLIK_OCC1 pin the occupancy of the kernels below)
 #ifdef CLIK_OCC2
 #define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #elif defined(CLIK_OCC1)
@@ -795,11 +795,14 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 #else
 #define CLIK_OCC_ATTR
 #endif
-template <const ShapeDesc& SD>
-__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
+// body of the lane-per-instance kernel.  REGIMG: keep a register copy of the skill image (one LDS read burst and
+// one wait instead of ~40 separate ~100-cycle LDS stalls: what a lone wave per SIMD wants) or read it from LDS
+// where it is used (fewer live registers: what two waves per SIMD want)
+template <const ShapeDesc& SD, bool REGIMG>
+__device__ __forceinline__ void pinv_solve_static_body(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const double* __restrict__ x,
-    double* __restrict__ dx, const TickArgs tk)
+    double* __restrict__ dx, const TickArgs& tk)
 {
     extern __shared__ double lds[];
     CLIK_STAMP(0);
@@ -853,13 +856,13 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     // Register copy of the skill image: scalar replacement keeps exactly the fields the tick
     // reads, and the scheduling barrier keeps their LDS reads together here (one wait) instead
     // of next to each use (measured: ~40 separate ~100-cycle LDS stalls per tick otherwise).
-#ifdef CLIK_NO_REGIMG
-    pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
-#else
-    const Img<SD> Sreg = *S;
-    __builtin_amdgcn_sched_barrier(0);
-    pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
-#endif
+    if constexpr (!REGIMG) {
+        pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+    } else {
+        const Img<SD> Sreg = *S;
+        __builtin_amdgcn_sched_barrier(0);
+        pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+    }
     CLIK_STAMP(4);
 
     __syncthreads();
@@ -869,6 +872,33 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
     if constexpr (NX > 0) rows_from_lds<NX>(dx + b0 * NX, rows_valid, xs, lane);
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
     CLIK_STAMP(5);
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const double* __restrict__ x,
+    double* __restrict__ dx, const TickArgs tk)
+{
+#ifdef CLIK_NO_REGIMG
+    pinv_solve_static_body<SD, false>(img_g, q, y, dq, mode_out, B, x, dx, tk);
+#else
+    pinv_solve_static_body<SD, true>(img_g, q, y, dq, mode_out, B, x, dx, tk);
+#endif
+}
+
+// Large-batch variant (>= kOcc2MinBatch instances: every SIMD has work queued): capped at 256 registers so that
+// TWO waves share a SIMD and cover each other's LDS / dependency stalls, skill image read from LDS in place.
+// Measured at 1 048 576 instances: 85.7 us against 95.4 us of the kernel above (+11 %); at 131 072 it loses
+// (15.6 vs 14.8 us), hence the threshold.  Costs 64 B per lane of scratch (the only static kernel with any).
+// Built for the ahead-of-time shapes only (-DCLIK_LARGE_BATCH_VARIANT in their translation unit).
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void pinv_solve_static_occ2_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const double* __restrict__ x,
+    double* __restrict__ dx, const TickArgs tk)
+{
+    pinv_solve_static_body<SD, false>(img_g, q, y, dq, mode_out, B, x, dx, tk);
 }
 
 // Mode-parallel variant for small batches (fewer wavefronts than SIMDs) and skills with one or
@@ -1290,12 +1320,16 @@ constexpr long long kRoleSplitMaxBatch = 16384;
 // two of them share a SIMD's fp64 pipe and the tick doubles (measured: 5.1 us at 16384, 9.2 us at 32768 against
 // 6.0 us of the two-wave kernel, profiles/r2_lanes_head_to_head.md)
 constexpr long long kTeamMaxBatch = 16384;
+// from this many instances on every SIMD has several waves queued and the two-waves-per-SIMD build of the
+// lane-per-instance kernel wins (pinv_solve_static_occ2_kernel)
+constexpr long long kOcc2MinBatch = 524288;
 
 // Which kernel variant serves a batch of B instances of a static shape (the label bench.py and the
 // tests report): the same conditions launch_solve_static evaluates, on the run-time copy of the shape.
 inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long long B)
 {
-    if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch))) return "team4";
+    if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch)))
+        return (mode_parallel & 64) ? "team4v" : "team4";       // bit 6: a value-specialised team kernel is attached
     const int ns = shape_n_sets(sd);
     if (sd.n_x == 0 && ns <= 1 && B <= kRoleSplitMaxBatch && (mode_parallel & 2)) {
         bool ok = true;
@@ -1304,6 +1338,7 @@ inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long l
     }
     if ((ns == 1 || ns == 2) && sd.n_x == 0 && B <= kModeParallelMaxBatch / ((1 << ns) / 2) && (mode_parallel & 1))
         return ns == 1 ? "mp2" : "mp4";
+    if (B >= kOcc2MinBatch && (mode_parallel & 32) && !(mode_parallel & 16)) return "lane/occ2";
     return "lane";
 }
 
@@ -1345,8 +1380,29 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
             return hipGetLastError();
         }
     }
+#ifdef CLIK_LARGE_BATCH_VARIANT
+    if (B >= kOcc2MinBatch && !(a.mode_parallel & 16)) {
+        hipLaunchKernelGGL((pinv_solve_static_occ2_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
+                           a.dImg, q, y, dq, mode, B, x, dx, tk);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((pinv_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
                        a.dImg, q, y, dq, mode, B, x, dx, tk);
+    return hipGetLastError();
+}
+
+// the team kernel with the skill's numbers compiled in (IMGV::value, see clik_pinv_team.hpp); the caller
+// (clik_pinv_solve_batch) uses it for the batches the image-reading team kernel would serve
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_solve_team_values(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
+                                           const double* y, double* dq, int32_t* mode, hipStream_t stream)
+{
+    static_assert(shape_team_ok(SD), "value-specialised kernels exist for the team family only");
+    const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
+    hipLaunchKernelGGL((pinv_solve_static_team_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                       team_lds_bytes<SD>(true), stream, nullptr, q, y, dq, mode, B, tk);
+    (void)a;
     return hipGetLastError();
 }
 

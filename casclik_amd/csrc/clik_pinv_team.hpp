@@ -72,17 +72,30 @@ __device__ __forceinline__ double quad_perm_f64(const double x)
 constexpr int QUAD_LANE0 = 0x00;    // quad_perm:[0,0,0,0]
 
 template <const ShapeDesc& SD>
-inline size_t team_lds_bytes()
+inline size_t team_lds_bytes(bool values = false)
 {
-    return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n + (SD.n_y > 0 ? SD.n_y : 0)) * TEAM_INST) * sizeof(double);
+    return ((size_t)(values ? 0 : StaticLayout<SD>::IMG_DOUBLES) + (size_t)(SD.n + (SD.n_y > 0 ? SD.n_y : 0)) * TEAM_INST) * sizeof(double);
 }
 
-template <const ShapeDesc& SD>
+// raw words of a skill image as a literal (value-specialised kernels, see below)
+template <int K>
+struct RawImage {
+    unsigned long long w[K];
+};
+
+// IMGV = void: the skill's numbers (chain, gains, bounds, row coefficients) come from the skill image in memory
+// (global -> LDS -> registers).  IMGV = a type with `static constexpr Img<SD> value`: they are COMPILED IN - the
+// instantiation belongs to one skill, as the functions CasADi generates for the reference do
+// (pseudo_inverse.py:476-483 compiles the expression graph with its constants).  No image traffic, no LDS reads of
+// constants, and every product with a structural 0 / 1 disappears at compile time.  casclik_amd/jit.py builds
+// such an instantiation when the controller is set up (clik_pinv_attach_value_kernel).
+template <const ShapeDesc& SD, class IMGV = void>
 __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kernel(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
     static_assert(shape_team_ok(SD), "shape outside the team kernel's family");
+    constexpr bool VALUES = !std::is_void<IMGV>::value;
     extern __shared__ double lds[];
     constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2], NY = SD.n_y > 0 ? SD.n_y : 0;
     constexpr int NT = M * (M + 1) / 2;
@@ -94,25 +107,27 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     const long long b0 = (long long)blockIdx.x * TEAM_INST;
     const long long left = B - b0;
     const int rows_valid = left < TEAM_INST ? (int)left : TEAM_INST;
-    double* zs = lds + StaticLayout<SD>::IMG_DOUBLES;       // [64][N] joint state, later the velocities
+    double* zs = lds + (VALUES ? 0 : StaticLayout<SD>::IMG_DOUBLES);       // [64][N] joint state, later the velocities
     double* ys = zs + N * TEAM_INST;                        // [64][NY]
     typedef double d2 __attribute__((ext_vector_type(2)));
     CLIK_STAMP_W(0, 0);
     {
         // one memory round trip: image chunks round-robin over the waves, the block's q / y rows
         // cooperatively (coalesced, index-clamped), all issued before the first LDS write
-        constexpr int CH = StaticLayout<SD>::IMG_CHUNKS;
-        constexpr int PER = (CH + TEAM_WAVES - 1) / TEAM_WAVES;
+        constexpr int CH = VALUES ? 0 : StaticLayout<SD>::IMG_CHUNKS;
+        constexpr int PER = VALUES ? 1 : (CH + TEAM_WAVES - 1) / TEAM_WAVES;
         constexpr int QR = (N * TEAM_INST + NTHREADS - 1) / NTHREADS;
         constexpr int YR = (NY * TEAM_INST + NTHREADS - 1) / NTHREADS;
         const d2* src = (const d2*)img_g;
         d2* dst = (d2*)lds;
         const int lane = tid & (WAVE - 1);
         d2 img[PER];
+        if constexpr (!VALUES) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int ck = k * TEAM_WAVES + wave;
-            img[k] = src[(ck < CH ? ck : CH - 1) * WAVE + lane];
+            for (int k = 0; k < PER; ++k) {
+                const int ck = k * TEAM_WAVES + wave;
+                img[k] = src[(ck < CH ? ck : CH - 1) * WAVE + lane];
+            }
         }
         double qv[QR], yv[YR > 0 ? YR : 1];
         const double* qg = q + b0 * N;
@@ -131,10 +146,12 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
                 yv[i] = yg[k < ylast ? k : ylast];
             }
         }
+        if constexpr (!VALUES) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int ck = k * TEAM_WAVES + wave;
-            if (ck < CH) dst[ck * WAVE + lane] = img[k];
+            for (int k = 0; k < PER; ++k) {
+                const int ck = k * TEAM_WAVES + wave;
+                if (ck < CH) dst[ck * WAVE + lane] = img[k];
+            }
         }
 #pragma unroll
         for (int i = 0; i < QR; ++i) {
@@ -151,7 +168,10 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     }
     __syncthreads();
     CLIK_STAMP_W(0, 1);
-    const Img<SD>* __restrict__ Slds = (const Img<SD>*)lds;
+    // (a LOCAL constexpr copy: loads from it fold to immediates; the namespace-scope object itself is emitted
+    // "externally_initialized" on the device and would be read from memory)
+    constexpr Img<SD> Sval = []() constexpr { if constexpr (VALUES) return IMGV::value; else return Img<SD>{}; }();
+    const Img<SD>* __restrict__ Slds = VALUES ? &Sval : (const Img<SD>*)lds;
     const double* ysl = ys + inst * NY;
     double z[N];
 #pragma unroll

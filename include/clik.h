@@ -191,7 +191,8 @@ int clik_pinv_n_modes(const clik_pinv* h);
 const char* clik_pinv_kernel_name(const clik_pinv* h);
 /* which variant of that kernel a batch of B instances gets: "team4" (four lanes per instance,
  * small batches of the priority-stack family), "mp2"/"mp4" (one wave per mode), "split", "lane"
- * (one instance per lane) or "dynamic".                                               */
+ * (one instance per lane), "lane/occ2" (its large-batch build), "team4v" (team4 with the skill's
+ * numbers compiled in) or "dynamic".                                                    */
 const char* clik_pinv_kernel_variant(const clik_pinv* h, int64_t B);
 /* developer aid (host only, no GPU needed): writes the C++ ShapeDesc initialiser
  * this skill maps to into buf; returns 1 if the skill is eligible for an AOT
@@ -203,6 +204,15 @@ int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_opts* opts,
  * function pointers come from a shared object built by casclik_amd/jit.py.
  * rollout_fn may be NULL (the rollout then keeps the kernel chosen at creation). */
 int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn, const char* name);
+
+/* Value-specialised kernel: the four-lanes-per-instance kernel instantiated with THIS skill's numbers (chain
+ * constants, gains, bounds, row coefficients) compiled in, as the functions CasADi generates for the reference
+ * are (pseudo_inverse.py:476-483).  clik_pinv_image_words returns the numbers as the 64-bit words of the skill
+ * image (n words, or a negative error); casclik_amd/jit.py compiles them into the kernel templates and attaches
+ * the result.  It serves the batch sizes the "team4" variant serves (reported as "team4v"); solve_fn = NULL
+ * detaches it.  Only for skills of that kernel's family.                                                  */
+int clik_pinv_image_words(const clik_pinv* h, uint64_t* buf, int cap);
+int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)

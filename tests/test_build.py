@@ -24,6 +24,11 @@ def test_static_kernels_use_no_scratch(resources):
     static = {k: v for k, v in resources.items() if "static" in k}
     assert len(static) >= 12
     for name, r in static.items():
+        if "occ2" in name:
+            # the large-batch build trades a few spilled doubles for two waves per SIMD (measured +11 % at
+            # 1 M instances): bounded, and it must really reach occupancy 2
+            assert r["ScratchSize"] <= 256 and r["VGPRs"] <= 256 and r["Occupancy"] >= 2, (name, r)
+            continue
         assert r["ScratchSize"] == 0, (name, r)
         # (spills may go to AGPRs, which is register space: only memory scratch is forbidden)
         assert r["VGPRs"] + r["AGPRs"] <= 512

@@ -381,3 +381,48 @@ def test_qp_baseline_full_size(iiwa_fk):
     perm = np.random.default_rng(3).permutation(B)
     dq_p, _, slack_p, status_p = ctrl.solve_batch(0.0, Q[perm], input_var=Y[perm])
     assert np.array_equal(dq_p, dq[perm]) and np.array_equal(slack_p, slack[perm])
+
+
+@pytest.mark.parametrize("seed,index", [(1, 1562), (3, 2204)])
+def test_dynamic_qp_infeasible_only_where_the_feasible_set_is_empty_by_a_hair(seed, index, monkeypatch):
+    """Regression seeds of tools/fuzz_qp_dynamic.py (385 k instances of 1500 random skills through the dynamic-shape
+    QP kernel): the two instances where the device reports "infeasible" and the numpy oracle finds a minimiser.
+    Both skills stack HARD equalities on nearly dependent rows (the oracle itself calls 45 - 247 of their 256
+    instances infeasible); the disputed instance must be borderline - LP feasibility margin below 1e-6 - and every
+    instance with a clear margin must agree with the oracle."""
+    import os
+    import sys
+    from oracle import clik_oracle
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    rng = np.random.default_rng(seed)
+    FK = {"iiwa": skills.iiwa(), "ur5": skills.ur5()}
+    for s in range(index + 1):          # replay the generator's stream up to the skill
+        robot = "ur5" if rng.random() < 0.5 else "iiwa"
+        fk = FK[robot]
+        spec, opts, rest = fuzz_parity.random_skill(rng, fk, len(fk["joint_names"]))
+        for c in spec.constraints:
+            if isinstance(c, (cc.EqualityConstraint, cc.SetConstraint)):
+                c.constraint_type = "soft" if rng.random() < 0.7 else "hard"
+        qseed = int(rng.integers(1 << 30))
+        tval = float(rng.uniform(0.0, 3.0))
+    spec = cc.SkillSpecification("fuzz_qp", spec.time_var, spec.robot_var,
+                                 input_var=spec.input_var if spec.n_input_var > 0 else None,
+                                 constraints=list(spec.constraints))
+    Q, Y = skills.synthetic_inputs(fk, 256, seed=qseed, distribution="mixed")
+    Yin = Y if spec.n_input_var > 0 else None
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    assert ctrl.kernel_name == "dynamic"
+    dq, _, sl, st = ctrl.solve_batch(tval, Q, input_var=Yin)
+    rdq, _, rsl, rst = clik_oracle.qp_solve_batch(spec, tval, Q, Y=Yin)
+    differ = np.nonzero((rst == 2) != (st == 2))[0]
+    hd, A, lb, ub = clik_oracle.qp_data_batch(spec, tval, Q[differ], Y=None if Yin is None else Yin[differ])
+    for k in range(len(differ)):
+        assert abs(fuzz_parity.lp_margin(A[k], lb[k], ub[k])) < 1e-6, (differ[k], fuzz_parity.lp_margin(A[k], lb[k], ub[k]))
+    ok = (rst == 0) & (st == 0)
+    assert ok.any() or (rst == 2).sum() > 200
+    if ok.any():
+        assert (np.abs(dq - rdq).max(axis=1) / (1 + np.abs(rdq).max(axis=1)))[ok].max() < 1e-6

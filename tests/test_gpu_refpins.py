@@ -34,7 +34,7 @@ def test_stack_kernel_variants_match_the_reference_run(lanes, monkeypatch):
         Q, Y, X, times = refpins.arrays(name)
         ctrl = cc.PseudoInverseController(skill_spec=built["spec"], options=dict(built["options"]))
         ctrl.setup_problem_functions()
-        assert ctrl.kernel_variant(len(Q)).endswith("/team4") == (lanes == 4), ctrl.kernel_variant(len(Q))
+        assert ("/team4" in ctrl.kernel_variant(len(Q))) == (lanes == 4), ctrl.kernel_variant(len(Q))
         dq, _, mode = ctrl.solve_batch(float(times[0]), Q)
         assert np.array_equal(mode, refpins.PINS[name + "_mode"][0])
         assert refpins.rel_err(dq, refpins.PINS[name + "_dq"][0]).max() < 1e-7
