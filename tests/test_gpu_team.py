@@ -138,7 +138,8 @@ def test_default_selection_by_batch(iiwa_fk, monkeypatch):
     ctrl.setup_problem_functions()
     assert ("/team4" in ctrl.kernel_variant(16384))
     assert ctrl.kernel_variant(32768).endswith("/mp2")
-    assert ctrl.kernel_variant(1 << 20).endswith("/lane")
+    assert ctrl.kernel_variant(131072).endswith("/lane")
+    assert ctrl.kernel_variant(1 << 20).endswith("/lane/occ2")      # (the ahead-of-time shapes' large-batch build)
     pose = cc.PseudoInverseController(skill_spec=skills.pose_skill(iiwa_fk))
     pose.setup_problem_functions()
     assert pose.kernel_variant(16384).endswith("/lane")
@@ -164,5 +165,3 @@ def test_value_specialised_and_image_reading_team_kernels_agree(iiwa_fk, ur5_fk,
     ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q[:400], Y=Y[:400])
     assert np.array_equal(mode_v, mode_i) and np.array_equal(mode_v[:400], ref_mode)
     assert _rel(dq_v, dq_i).max() < PINV_RTOL and _rel(dq_v[:400], ref).max() < PINV_RTOL
-    # beyond the team kernel's batch range the handle falls back to its other kernels
-    assert not ("/team4" in val.kernel_variant(1 << 20))

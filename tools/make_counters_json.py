@@ -11,6 +11,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per instance, batch)
+    "stack_team4v": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
     "stack_team4": ("stack_mixed_B16384_kStackIiwa/team4", "kStackIiwa/team4", 172, 16384),
     "stack_lane": ("stack_mixed_B16384_kStackIiwa/mp2", "kStackIiwa/mp2", 172, 16384),
     "qp": ("qp_mixed_B16384_qp_static_kQpPoseIiwa", "qp_static_kQpPoseIiwa", 168, 16384),

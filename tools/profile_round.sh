@@ -23,8 +23,8 @@ run_pmc () {     # name, "counter list", bench args...
     python3 tools/rocprof_counters.py /tmp/pmc_$name solve_static >> $OUT/pmc_${name}.txt 2>&1
     tail -3 $OUT/pmc_${name}.txt
 }
-for V in team4:0 lane:1; do
-    tag=${V%%:*}; lanes=${V##*:}
+for V in team4v:0:1 team4:0:0 lane:1:1; do
+    tag=${V%%:*}; rest=${V#*:}; lanes=${rest%%:*}; export CLIK_JIT_VALUES=${rest##*:}
     run_stats stack_$tag --lanes $lanes
     rm -f $OUT/pmc_stack_$tag.txt
     for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
@@ -33,6 +33,7 @@ for V in team4:0 lane:1; do
         run_pmc stack_$tag "$C" --lanes $lanes
     done
 done
+unset CLIK_JIT_VALUES
 run_stats qp --workload qp
 rm -f $OUT/pmc_qp.txt
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
