@@ -74,7 +74,8 @@ constexpr int QUAD_LANE0 = 0x00;    // quad_perm:[0,0,0,0]
 template <const ShapeDesc& SD>
 inline size_t team_lds_bytes(bool values = false)
 {
-    return ((size_t)(values ? 0 : StaticLayout<SD>::IMG_DOUBLES) + (size_t)(SD.n + (SD.n_y > 0 ? SD.n_y : 0)) * TEAM_INST) * sizeof(double);
+    if (values) return 0;       // (the value-specialised instantiation reads and writes global memory directly)
+    return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n + (SD.n_y > 0 ? SD.n_y : 0)) * TEAM_INST) * sizeof(double);
 }
 
 // raw words of a skill image as a literal (value-specialised kernels, see below)
@@ -111,7 +112,20 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     double* ys = zs + N * TEAM_INST;                        // [64][NY]
     typedef double d2 __attribute__((ext_vector_type(2)));
     CLIK_STAMP_W(0, 0);
-    {
+    // Value-specialised instantiation: every index into the state / input rows is a literal, so each lane reads its
+    // instance's rows straight from global memory into registers (the four lanes of a quad hit the same addresses,
+    // a wave's 16 rows are contiguous) and the selected lane stores the velocities itself: no LDS, no barrier.
+    const long long binst = (b0 + inst < B) ? (b0 + inst) : (B - 1);
+    double zdir[N], ydir[NY > 0 ? NY : 1];
+    if constexpr (VALUES) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) zdir[j] = q[binst * N + j];
+        if constexpr (NY > 0) {
+#pragma unroll
+            for (int k = 0; k < NY; ++k) ydir[k] = y[binst * NY + k];
+        }
+    }
+    if constexpr (!VALUES) {
         // one memory round trip: image chunks round-robin over the waves, the block's q / y rows
         // cooperatively (coalesced, index-clamped), all issued before the first LDS write
         constexpr int CH = VALUES ? 0 : StaticLayout<SD>::IMG_CHUNKS;
@@ -165,17 +179,17 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
                 if (k < NY * TEAM_INST) ys[k] = yv[i];
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     CLIK_STAMP_W(0, 1);
     // (a LOCAL constexpr copy: loads from it fold to immediates; the namespace-scope object itself is emitted
     // "externally_initialized" on the device and would be read from memory)
     constexpr Img<SD> Sval = []() constexpr { if constexpr (VALUES) return IMGV::value; else return Img<SD>{}; }();
     const Img<SD>* __restrict__ Slds = VALUES ? &Sval : (const Img<SD>*)lds;
-    const double* ysl = ys + inst * NY;
+    const double* ysl = VALUES ? ydir : ys + inst * NY;
     double z[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = zs[inst * N + j];
+    for (int j = 0; j < N; ++j) z[j] = VALUES ? zdir[j] : zs[inst * N + j];
 
     // ---- front end: sin / cos split over the quad, then FK and the task rows in every lane ----
     TaskCache<SD> tc;
@@ -184,7 +198,8 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
         if constexpr (SD.uses_fk != 0) {
             // lane r evaluates state variables 2r and 2r+1 (clamped), the quad exchanges by DPP
             const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-            const double a0 = zs[inst * N + j0], a1 = zs[inst * N + j1];
+            const double a0 = VALUES ? q[binst * N + j0] : zs[inst * N + j0];
+            const double a1 = VALUES ? q[binst * N + j1] : zs[inst * N + j1];
             double sn0, cs0, sn1, cs1;
             sincos_fast(a0, sn0, cs0);
             sincos_fast(a1, sn1, cs1);
@@ -394,14 +409,20 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     // has no cone test, so mode 1 is always admissible)
     CLIK_STAMP_W(0, 6);
     const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
-    if (r == (ok0 ? 0 : 2)) {
-        // (each team reads and writes only its own row, and a team is inside one wave: no barrier needed)
+    if constexpr (VALUES) {
+        if (r == (ok0 ? 0 : 2) && inst < rows_valid) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) zs[inst * N + j] = v[j];
-        if (mode_out != nullptr && inst < rows_valid) mode_out[b0 + inst] = ok0 ? 0 : 1;
-    }
-    __syncthreads();
-    {
+            for (int j = 0; j < N; ++j) dq[(b0 + inst) * N + j] = v[j];
+            if (mode_out != nullptr) mode_out[b0 + inst] = ok0 ? 0 : 1;
+        }
+    } else {
+        if (r == (ok0 ? 0 : 2)) {
+            // (each team reads and writes only its own row, and a team is inside one wave: no barrier needed)
+#pragma unroll
+            for (int j = 0; j < N; ++j) zs[inst * N + j] = v[j];
+            if (mode_out != nullptr && inst < rows_valid) mode_out[b0 + inst] = ok0 ? 0 : 1;
+        }
+        __syncthreads();
         constexpr int QR = (N * TEAM_INST + NTHREADS - 1) / NTHREADS;
         double* dg = dq + b0 * N;
         const int total = rows_valid * N;
