@@ -71,6 +71,13 @@ __device__ __forceinline__ double quad_perm_f64(const double x)
 }
 constexpr int QUAD_LANE0 = 0x00;    // quad_perm:[0,0,0,0]
 
+// sign(x) / 2 as a double: -0.5, 0 or +0.5 (three instructions: the sign bit onto the pattern of 0.5, zero test)
+__device__ __forceinline__ double half_sign(const double x)
+{
+    const int h = (__double2hiint(x) & (int)0x80000000) | 0x3fe00000;
+    return (x != 0.0) ? __hiloint2double(h, 0) : 0.0;
+}
+
 template <const ShapeDesc& SD>
 inline size_t team_lds_bytes(bool values = false)
 {
@@ -374,36 +381,42 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
         in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
     } else {
-        double de[M0];
-        static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int col = SD.ucol[0][i] - 1;
-            de[i] = Jt0[i] + v[col];
-        });
+        // (pseudo_inverse.py:222-252, same values; written for few instructions: half signs by bit operations,
+        // flags combined bitwise - the short-circuit forms compile to a branch per row -, and everything behind
+        // "inside" skipped when every instance of the wave is inside its limits, the normal state of a control loop)
         const clik_task& t = S->tasks[0];
-        bool inside = true, corner = true;
-        double od = 0.0, nde = 0.0, nout = 0.0;
+        double le[M0], ue[M0];
+        bool inside = true;
 #pragma unroll
         for (int i = 0; i < M0; ++i) {
-            const double le = e0[i] - t.set_min[i];
-            const double ue = e0[i] - t.set_max[i];
-            if (!(le >= 1e-12) || !(ue <= 1e-12)) inside = false;
-            const double sl = (le > 0.0) - (le < 0.0);
-            const double su = (ue > 0.0) - (ue < 0.0);
-            if (sl != su) corner = false;
-            const double out = 0.5 * (sl + su);
-            od = fma(out, de[i], od);
-            nde = fma(de[i], de[i], nde);
-            nout = fma(out, out, nout);
+            le[i] = e0[i] - t.set_min[i];
+            ue[i] = e0[i] - t.set_max[i];
+            inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
         }
-        bool going_in;
-        if (corner) {
-            const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
-            going_in = (od < 0.0) ? (fabs(od) / dists < 0.70710678118654757) : false;
-        } else {
-            going_in = od < 0.0;
+        in_tc = true;
+        if (__ballot(!inside) != 0ull) {
+            bool corner = true;
+            double od = 0.0, nde = 0.0, nout = 0.0;
+            static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int col = SD.ucol[0][i] - 1;
+                const double de = Jt0[i] + v[col];
+                const double hl = half_sign(le[i]), hu = half_sign(ue[i]);     // (sign(le) + sign(ue)) / 2 = hl + hu
+                corner = corner & (hl == hu);
+                const double out = hl + hu;
+                od = fma(out, de, od);
+                nde = fma(de, de, nde);
+                nout = fma(out, out, nout);
+            });
+            bool going_in = od < 0.0;
+            if (__ballot(corner & !inside) != 0ull) {
+                // every joint beyond a limit (a corner of the box): inward only within 45 degrees of the diagonal
+                const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+                const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
+                going_in = corner ? steep : going_in;
+            }
+            in_tc = inside | going_in;
         }
-        in_tc = inside ? true : going_in;
     }
     // the scan of :530-550 as a select: mode 0 if its cone test passes, else mode 1 (the active set
     // has no cone test, so mode 1 is always admissible)
