@@ -363,6 +363,13 @@ __device__ __forceinline__ double recip(const double d)
     return r;
 }
 
+// sign(x) / 2 as a double: -0.5, 0 or +0.5 (three instructions: the sign bit onto the pattern of 0.5, zero test)
+__device__ __forceinline__ double half_sign(const double x)
+{
+    const int h = (__double2hiint(x) & (int)0x80000000) | 0x3fe00000;
+    return (x != 0.0) ? __hiloint2double(h, 0) : 0.0;
+}
+
 // argument range of the fast path (3-term Cody-Waite reduction stays exact)
 constexpr double kSinCosFastMax = 1.0e5;
 

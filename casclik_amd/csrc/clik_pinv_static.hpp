@@ -288,7 +288,7 @@ __device__ __forceinline__ void fk_sincos_all(const double (&z)[SD.n], double (&
         constexpr int j = decltype(jc)::value;
         if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
             sincos_fast(z[j], sns[j], css[j]);
-            huge = huge || fabs(z[j]) > kSinCosFastMax;
+            huge = huge | (fabs(z[j]) > kSinCosFastMax);
         } else {
             sns[j] = css[j] = 0.0;
         }
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
             srow = 0u;
 #pragma unroll
             for (int i = 0; i < M; ++i)
-                if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
+                srow |= (uint32_t)((e[i] - t.set_max[i] > 0.0) | (e[i] - t.set_min[i] < 0.0)) << i;     // (bitwise: no branch per row)
         }
         if constexpr (!P.contributes) {
             if constexpr (P.push_times > 0) push_s<SD, ACT, TI, ROLE>(S, tc, c, srow);
@@ -1279,31 +1279,40 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
             if (t.set_min[0] - ev < 1e-12) in_tc = (ev - t.set_max[0] < 1e-12) ? true : (de[0] < 0.0);
             else in_tc = de[0] > 0.0;
         } else {
-            bool inside = true, corner = true;
-            double od = 0.0, nde = 0.0, nout = 0.0;
+            // (flags combined bitwise and half signs by bit operations: the short-circuit / comparison-difference
+            // forms compile to a divergent branch per row; everything behind "inside" is skipped when every
+            // instance of the wave is inside its limits)
+            double le[M], ue[M];
+            bool inside = true;
 #pragma unroll
             for (int i = 0; i < M; ++i) {
-                const double le = e[i] - t.set_min[i];
-                const double ue = e[i] - t.set_max[i];
-                if (!(le >= 1e-12) || !(ue <= 1e-12)) inside = false;
-                const double sl = (le > 0.0) - (le < 0.0);
-                const double su = (ue > 0.0) - (ue < 0.0);
-                if (sl != su) corner = false;
-                const double out = 0.5 * (sl + su);
-                od = fma(out, de[i], od);
-                nde = fma(de[i], de[i], nde);
-                nout = fma(out, out, nout);
+                le[i] = e[i] - t.set_min[i];
+                ue[i] = e[i] - t.set_max[i];
+                inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
             }
-            bool going_in;
-            if (corner) {
-                const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
-                going_in = (od < 0.0) ? (fabs(od) / dists < 0.70710678118654757) : false;
-            } else {
-                going_in = od < 0.0;
+            in_tc = true;
+            if (__ballot(!inside) != 0ull) {
+                bool corner = true;
+                double od = 0.0, nde = 0.0, nout = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const double hl = half_sign(le[i]), hu = half_sign(ue[i]);
+                    corner = corner & (hl == hu);
+                    const double out = hl + hu;
+                    od = fma(out, de[i], od);
+                    nde = fma(de[i], de[i], nde);
+                    nout = fma(out, out, nout);
+                }
+                bool going_in = od < 0.0;
+                if (__ballot(corner & !inside) != 0ull) {
+                    const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+                    const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
+                    going_in = corner ? steep : going_in;
+                }
+                in_tc = inside | going_in;
             }
-            in_tc = inside ? true : going_in;
         }
-        c.ok = c.ok && in_tc;
+        c.ok = c.ok & in_tc;
     }
 }
 
@@ -1386,7 +1395,7 @@ __device__ __forceinline__ void helper_mode_static(const Img<SD>* __restrict__ S
                 srow = 0u;
 #pragma unroll
                 for (int i = 0; i < M; ++i)
-                    if ((e[i] - t.set_max[i] > 0.0) || (e[i] - t.set_min[i] < 0.0)) srow |= 1u << i;
+                    srow |= (uint32_t)((e[i] - t.set_max[i] > 0.0) | (e[i] - t.set_min[i] < 0.0)) << i;     // (bitwise: no branch per row)
             }
             // the same argument step_s passes for this kind of task
             if constexpr (!P.contributes) push_s<SD, ACT, TI, ROLE_HELPER>(S, tc, c, srow);

@@ -71,13 +71,6 @@ __device__ __forceinline__ double quad_perm_f64(const double x)
 }
 constexpr int QUAD_LANE0 = 0x00;    // quad_perm:[0,0,0,0]
 
-// sign(x) / 2 as a double: -0.5, 0 or +0.5 (three instructions: the sign bit onto the pattern of 0.5, zero test)
-__device__ __forceinline__ double half_sign(const double x)
-{
-    const int h = (__double2hiint(x) & (int)0x80000000) | 0x3fe00000;
-    return (x != 0.0) ? __hiloint2double(h, 0) : 0.0;
-}
-
 template <const ShapeDesc& SD>
 inline size_t team_lds_bytes(bool values = false)
 {
@@ -210,7 +203,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
             double sn0, cs0, sn1, cs1;
             sincos_fast(a0, sn0, cs0);
             sincos_fast(a1, sn1, cs1);
-            const bool huge = fabs(a0) > kSinCosFastMax || fabs(a1) > kSinCosFastMax;
+            const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
             if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
                 if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
                 if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
@@ -284,7 +277,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         constexpr int col = SD.ucol[0][i] - 1;
-        sact[col] = ((e0[i] - S->tasks[0].set_max[i] > 0.0) || (e0[i] - S->tasks[0].set_min[i] < 0.0)) ? 1.0 : 0.0;
+        sact[col] = ((e0[i] - S->tasks[0].set_max[i] > 0.0) | (e0[i] - S->tasks[0].set_min[i] < 0.0)) ? 1.0 : 0.0;
         p0[col] = S->cpinv[0][col * CLIK_MAX_M + i];
     });
 

@@ -224,15 +224,15 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
             qp_ldl_factor<NC, EXACT>(L, rd, nc);
             bool sound = dscale > 0.0;
 #pragma unroll
-            for (int i = 0; i < NC; ++i) sound = sound && (L[tri(i, i)] > 1e-9 * dscale);                // ... and after
+            for (int i = 0; i < NC; ++i) sound = sound & (L[tri(i, i)] > 1e-9 * dscale);                // ... and after
             qp_ldl_solve<NC, EXACT>(L, rd, r, nc);
             uint32_t drop = 0u;
 #pragma unroll
             for (int i = 0; i < NC; ++i)
-                if (((W0 >> i) & 1u) && !((eq >> i) & 1u) && !(r[i] >= 0.0)) drop |= 1u << i;
+                if (((W0 >> i) & 1u) & !((eq >> i) & 1u) & !(r[i] >= 0.0)) drop |= 1u << i;
             // primal-dual passes also add the rows violated at the point this W0 gives
             uint32_t add = 0u, addup = 0u;
-            const bool pd = pd_left > 0 && W0 != 0u && sound;
+            const bool pd = pd_left > 0 & W0 != 0u & sound;
             if (__ballot(pd) != 0ull) {
                 double cc[NC];
 #pragma unroll
@@ -252,7 +252,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                         const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
                         double vlo, vhi;
                         excess(i, lbi, ubi, cc[i], vlo, vhi);
-                        if (pd && !((W0 >> i) & 1u) && fmax(vlo, vhi) > kVtol) {
+                        if (pd & !((W0 >> i) & 1u) & fmax(vlo, vhi) > kVtol) {
                             add |= 1u << i;
                             if (vhi > vlo) addup |= 1u << i;
                         }
@@ -264,7 +264,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
 #ifdef CLIK_QP_DIAG
                 g_qp_diag_cold |= 1;
 #endif
-            } else if (drop != 0u || add != 0u) {
+            } else if (drop != 0u | add != 0u) {
                 W0 = (W0 & ~drop) | add;
                 up0 = (up0 & ~drop) | addup;
                 pd_left -= 1;
@@ -327,7 +327,7 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         //     (written with selects, not per-lane branches: every divergent `if` costs
         //     exec-mask bookkeeping on the scalar unit, which a lone wave pays in full)
         {
-            const bool sel = need_p && !done;
+            const bool sel = need_p & !done;
             double best = kVtol, bpn = bp;
             int pick = -1;
             bool pick_up = false;
@@ -338,8 +338,8 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                     double vlo, vhi;
                     excess(i, lbi, ubi, c[i], vlo, vhi);
                     double v = fmax(vlo, vhi);
-                    v += (((eq >> i) & 1u) && v > kVtol) ? 1e30 : 0.0;      // equalities take precedence
-                    const bool better = !((W >> i) & 1u) && v > best;
+                    v += (((eq >> i) & 1u) & v > kVtol) ? 1e30 : 0.0;      // equalities take precedence
+                    const bool better = !((W >> i) & 1u) & v > best;
                     const bool upper = vhi > vlo;
                     best = better ? v : best;
                     pick = better ? i : pick;
@@ -347,8 +347,8 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
                     bpn = better ? (upper ? -ubi : lbi) : bpn;
                 }
             }
-            const bool take = sel && pick >= 0;
-            done = done || (sel && pick < 0);
+            const bool take = sel & pick >= 0;
+            done = done | (sel & pick < 0);
             p = take ? pick : p;
             sp = take ? (pick_up ? -1.0 : 1.0) : sp;
             bp = take ? bpn : bp;
@@ -380,10 +380,10 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             // candidate only for active inequality rows with r_i > 0 (a_i = 0 on inactive rows)
-            const bool cand_ok = (a[i] != 0.0) && !((eq >> i) & 1u) && r[i] > 1e-14;
+            const bool cand_ok = (a[i] != 0.0) & !((eq >> i) & 1u) & r[i] > 1e-14;
             const double num = fmax(a[i] * nu[i], 0.0);
             // num / r_i < t1n / t1d   <=>   num * t1d < t1n * r_i      (both denominators positive)
-            const bool better = cand_ok && (t1d == 0.0 || num * t1d < t1n * r[i]);
+            const bool better = cand_ok & (t1d == 0.0 | num * t1d < t1n * r[i]);
             t1n = better ? num : t1n;
             t1d = better ? r[i] : t1d;
             l = better ? i : l;
@@ -398,22 +398,22 @@ __device__ __forceinline__ int gi_solve(const double* Qs, const double* lbs, con
         const double t = fmin(t1, t2);
         {
             const bool live = !done;
-            const bool stuck = live && !(t < 1e299);        // constraint p cannot be satisfied
-            const bool step = live && !stuck;
-            const bool full = step && (t2 <= t1);           // p enters the working set
-            const bool part = step && !full;                // l leaves it
+            const bool stuck = live & !(t < 1e299);        // constraint p cannot be satisfied
+            const bool step = live & !stuck;
+            const bool full = step & (t2 <= t1);           // p enters the working set
+            const bool part = step & !full;                // l leaves it
             status = stuck ? 2 : status;
-            done = done || stuck;
+            done = done | stuck;
             const double ts = step ? t : 0.0;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 double ni = fma(-ts * a[i], r[i], nu[i]);
                 ni = fma((i == p) ? ts : 0.0, sp, ni);
-                nu[i] = (part && i == l) ? 0.0 : ni;
+                nu[i] = (part & i == l) ? 0.0 : ni;
             }
             const uint32_t pbit = 1u << (p & 31), lbit = part ? (1u << (l & 31)) : 0u;
             W = (full ? (W | pbit) : W) & ~lbit;
-            up = ((full && sp < 0.0) ? (up | pbit) : up) & ~lbit;
+            up = ((full & sp < 0.0) ? (up | pbit) : up) & ~lbit;
             need_p = step ? full : need_p;
         }
     }
