@@ -243,7 +243,7 @@ def load_library(path=None):
     lib.clik_pinv_image_words.restype = C.c_int
     lib.clik_pinv_image_words.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     lib.clik_pinv_attach_value_kernel.restype = C.c_int
-    lib.clik_pinv_attach_value_kernel.argtypes = [vp, C.c_void_p]
+    lib.clik_pinv_attach_value_kernel.argtypes = [vp, C.c_void_p, C.c_void_p]
     lib.clik_pinv_kernel_variant.restype = C.c_char_p
     lib.clik_pinv_kernel_variant.argtypes = [vp, C.c_int64]
     lib.clik_pinv_attach_kernel.restype = C.c_int

@@ -90,6 +90,7 @@ struct clik_pinv {
     // team kernel with this skill's numbers compiled in (clik_pinv_attach_value_kernel), used for the batches the
     // image-reading team kernel would serve
     clik_jit_value_fn   val_solve;
+    clik_jit_rollout_fn val_rollout;
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
@@ -655,6 +656,7 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
     h->val_solve = nullptr;
+    h->val_rollout = nullptr;
     h->jit_name[0] = 0;
     finish_pinv_shape(S, opts);
     if (opts->pinv_method != CLIK_PINV_DAMPED && opts->pinv_method != CLIK_PINV_STANDARD) {
@@ -796,12 +798,13 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
     return CLIK_OK;
 }
 
-extern "C" int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn)
+extern "C" int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (solve_fn && !clik::shape_team_ok_rt(h->host.shape))
         return fail(CLIK_EUNSUPPORTED, "value-specialised kernels exist for the four-lanes-per-instance family only");
     h->val_solve = (clik_jit_value_fn)solve_fn;
+    h->val_rollout = solve_fn ? (clik_jit_rollout_fn)rollout_fn : nullptr;
     if (solve_fn) h->mode_parallel |= 64;
     else h->mode_parallel &= ~64;
     return CLIK_OK;
@@ -946,7 +949,11 @@ extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t 
     int rc = stage_tterms(tterms, (size_t)n_ticks * stages * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
     if (rc) return rc;
     const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx, stages};
-    hipError_t e = h->jit_rollout
+    const bool team_batch = (h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch());
+    hipError_t e = (h->val_rollout && team_batch)
+                       ? h->val_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
+                                        (hipStream_t)stream)
+                   : h->jit_rollout
                        ? h->jit_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
                                         (hipStream_t)stream)
                        : clik::pinv_launch_rollout(h->kernel, la, d_tt, n_ticks, dt, max_speed, (long long)B,

@@ -1406,12 +1406,34 @@ inline hipError_t launch_solve_team_values(const LaunchArgs& a, const TickArgs& 
     return hipGetLastError();
 }
 
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_rollout_team_values(const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
+                                             double max_speed, long long B, double* q, const double* y, double* dq,
+                                             int32_t* mode, hipStream_t stream)
+{
+    static_assert(shape_team_ok(SD), "value-specialised kernels exist for the team family only");
+    const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
+    hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                       team_rollout_lds_bytes<SD>(true), stream, nullptr, q, y, dq, mode, B, d_tterms, n_ticks, dt,
+                       max_speed, a.roll_stages == 4 ? 4 : 1);
+    return hipGetLastError();
+}
+
 template <const ShapeDesc& SD>
 inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
                                         double max_speed, long long B, double* q, const double* y, double* dq,
                                         int32_t* mode, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if constexpr (shape_team_ok(SD)) {
+        // four lanes per instance (same grid: 64 instances per block of four waves)
+        if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch)) {
+            hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                               team_rollout_lds_bytes<SD>(), stream, a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt,
+                               max_speed, a.roll_stages == 4 ? 4 : 1);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((pinv_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
                        a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx,
                        a.roll_stages == 4 ? 4 : 1);

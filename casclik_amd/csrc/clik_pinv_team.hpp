@@ -78,6 +78,234 @@ inline size_t team_lds_bytes(bool values = false)
     return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n + (SD.n_y > 0 ? SD.n_y : 0)) * TEAM_INST) * sizeof(double);
 }
 
+// One tick of the lane's instance in the quad: candidate velocities of both modes and the tangent-cone verdict.
+// Slds: skill image (LDS copy, or the address of a local constexpr object whose loads fold to literals);
+// z: the instance's state in every lane of the quad; a0 / a1: state variables 2r and 2r+1 (clamped to N-1) of lane
+// r; on return lanes 0/1 hold the mode-0 velocity in v, lanes 2/3 the mode-1 one, in_tc the cone test of v.
+template <const ShapeDesc& SD>
+__device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, const TickArgs& tk,
+                                          const double (&z)[SD.n], const double* ysl, const double a0, const double a1,
+                                          const int r, const int inst, double (&v)[SD.n], bool& in_tc)
+{
+    constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2];
+    constexpr int NT = M * (M + 1) / 2;
+    // ---- front end: sin / cos split over the quad, then FK and the task rows in every lane ----
+    TaskCache<SD> tc;
+    {
+        double sns[N], css[N];
+        if constexpr (SD.uses_fk != 0) {
+            // lane r evaluated state variables 2r and 2r+1 (a0, a1), the quad exchanges by DPP
+            double sn0, cs0, sn1, cs1;
+            sincos_fast(a0, sn0, cs0);
+            sincos_fast(a1, sn1, cs1);
+            const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
+            if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+                if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
+                if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
+            }
+            static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+                    constexpr int CTRL = (j / 2) * 0x55;           // quad_perm:[k,k,k,k], k = owner lane
+                    sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
+                    css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
+                } else {
+                    sns[j] = css[j] = 0.0;
+                }
+            });
+        }
+        const Img<SD> Sfk = *Slds;
+        __builtin_amdgcn_sched_barrier(0);
+        Kin<N> K;
+        if constexpr ((CLIK_TEAM_ABLATE & 16) != 0) {
+#pragma unroll
+            for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
+                tc.e[i] = z[i % N] + sns[(i + 1) % N];
+                tc.Jt[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) tc.J[i][j] = z[(i + j) % N] * css[j];
+            }
+        } else {
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_sc<SD>(&Sfk, z, sns, css, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(&Sfk, ysl, inst, K);
+        }
+        cache_task<SD, 0>(&Sfk, tk, K, z, ysl, inst, tc);
+        }
+    }
+    
+    const Img<SD> Sb = *Slds;
+    __builtin_amdgcn_sched_barrier(0);
+    const Img<SD>* __restrict__ S = &Sb;
+    const double lam = S->lam;
+    const double one_lam = 1.0 + lam;
+
+    // desired task velocities  d = -K e - de/dt   (pseudo_inverse.py:318-321, :383-386)
+    double des1[M], w2[N];
+    {
+        double e[M], Jt[M], ke[M];
+        task_values<SD, 1>(S, tk, tc, z, ysl, inst, e, Jt);
+        gain_apply_s<M, SD.gain_matrix[1] != 0>(S->tasks[1], e, ke);
+#pragma unroll
+        for (int i = 0; i < M; ++i) des1[i] = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
+    }
+    {
+        // w2 = pinv(J2) d2 of the joint-space task: one entry per row (host-side pinv of the unit rows)
+        double e[M2], Jt[M2], ke[M2];
+        task_values<SD, 2>(S, tk, tc, z, ysl, inst, e, Jt);
+        gain_apply_s<M2, SD.gain_matrix[2] != 0>(S->tasks[2], e, ke);
+#pragma unroll
+        for (int j = 0; j < N; ++j) w2[j] = 0.0;
+        const double* Pm = S->cpinv[2];
+        static_for<0, M2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int col = SD.ucol[2][i] - 1;
+            const double d = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
+            w2[col] = Pm[col * CLIK_MAX_M + i] * d;
+        });
+    }
+    // the set: violated rows (activation S of the multidim set, :289-298) by state column, and the
+    // values its tangent-cone test needs
+    double e0[M0], Jt0[M0];
+    task_values<SD, 0>(S, tk, tc, z, ysl, inst, e0, Jt0);
+    double sact[N], p0[N];          // sact[col] = 1.0 when the set row on that state is violated
+    static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int col = SD.ucol[0][i] - 1;
+        sact[col] = ((e0[i] - S->tasks[0].set_max[i] > 0.0) | (e0[i] - S->tasks[0].set_min[i] < 0.0)) ? 1.0 : 0.0;
+        p0[col] = S->cpinv[0][col * CLIK_MAX_M + i];
+    });
+
+    // Gm = J J'
+    double Gm[NT];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) {
+            double acc = 0.0;
+            if constexpr ((CLIK_TEAM_ABLATE & 8) != 0) {
+                acc = jac<SD, 1>(S, tc, i, k) * jac<SD, 1>(S, tc, k, i);
+            } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
+            }
+            Gm[tri(i, k)] = acc;
+        }
+
+    
+    // ---- per-lane role ------------------------------------------------------------------------
+    // The lower-priority task's projected contribution, with the stack matrix G = D + c J'J of the mode
+    // (D = lam I in mode 0 with c = 2; D = (1+lam) I in mode 1 with c = 1) and C = G - (D - S):
+    //     w2 - G^-1 C w2  =  G^-1 (D - S) w2  =  D^-1 (x - c J' A^-1 J x),   x = (D - S) w2,  A = c J J' + D
+    // (Woodbury; S = 0 in mode 0).  So lane 1 solves A1 t = J w2 (then x/D = w2, c = 2), lane 2 solves
+    // A2 t = J x with x = ((1+lam) - s) o w2 (c = 1), lanes 0 / 3 solve A0 y = d1.
+    const bool solo = (r == 0) || (r == 3);
+    const double alpha = (r == 1) ? 2.0 : 1.0;
+    const double beta = (r == 2) ? one_lam : lam;
+    const double hsel = solo ? 1.0 : 0.0;
+    double rhs[M];
+    {
+        double x[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double f = (r == 2) ? one_lam - sact[j] : ((r == 1) ? 1.0 : 0.0);
+            x[j] = w2[j] * f;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double sacc = hsel * des1[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) sacc = fma(jac<SD, 1>(S, tc, i, j), x[j], sacc);
+            rhs[i] = sacc;
+        }
+    }
+    double A[NT], rd[M], s2[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? fma(alpha, Gm[tri(i, k)], beta) : alpha * Gm[tri(i, k)];
+    if constexpr ((CLIK_TEAM_ABLATE & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) rhs[i] *= A[tri(i, i)] + A[tri(M - 1, i)];
+    } else {
+    ldl_factor_s<M>(A, rd);
+    ldl_solve_s<M>(A, rd, rhs);
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) s2[i] = rhs[i];
+    if constexpr ((CLIK_TEAM_ABLATE & (2 | 4)) == 0)
+    ldl_solve_s<M>(A, rd, s2);      // (second pass of the doubly processed equality: lane 0 only)
+    const double lam0 = (r == 0) ? lam : 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) rhs[i] = fma(lam0, s2[i], rhs[i]);
+    double g[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) sacc = fma(jac<SD, 1>(S, tc, i, j), rhs[i], sacc);
+        g[j] = sacc;
+    }
+
+    
+    // ---- the quad's results meet: lanes 0/1 form the mode-0 velocity, lanes 2/3 the mode-1 one --
+    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)
+    //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)
+    const bool hi_pair = (r & 2) != 0;
+    const double kap = hi_pair ? 1.0 / one_lam : 1.0;
+    const double eta = hi_pair ? 1.0 : 2.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double first = quad_perm_f64<0xF0>(g[j]);      // quad_perm:[0,0,3,3]: g0 | g3
+        const double second = quad_perm_f64<0xA5>(g[j]);     // quad_perm:[1,1,2,2]: g1 | g2
+        const double nmul = hi_pair ? fma(-p0[j], sact[j], 1.0) : 1.0;
+        const double xx = hi_pair ? w2[j] * (one_lam - sact[j]) : w2[j];
+        v[j] = fma(first, nmul, kap * fma(-eta, second, xx));
+    }
+    // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; lanes 2/3 evaluate it
+    // on the other candidate, unused)
+    if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
+        in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
+    } else {
+        // (pseudo_inverse.py:222-252, same values; written for few instructions: half signs by bit operations,
+        // flags combined bitwise - the short-circuit forms compile to a branch per row -, and everything behind
+        // "inside" skipped when every instance of the wave is inside its limits, the normal state of a control loop)
+        const clik_task& t = S->tasks[0];
+        double le[M0], ue[M0];
+        bool inside = true;
+#pragma unroll
+        for (int i = 0; i < M0; ++i) {
+            le[i] = e0[i] - t.set_min[i];
+            ue[i] = e0[i] - t.set_max[i];
+            inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
+        }
+        in_tc = true;
+        if (__ballot(!inside) != 0ull) {
+            bool corner = true;
+            double od = 0.0, nde = 0.0, nout = 0.0;
+            static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int col = SD.ucol[0][i] - 1;
+                const double de = Jt0[i] + v[col];
+                const double hl = half_sign(le[i]), hu = half_sign(ue[i]);     // (sign(le) + sign(ue)) / 2 = hl + hu
+                corner = corner & (hl == hu);
+                const double out = hl + hu;
+                od = fma(out, de, od);
+                nde = fma(de, de, nde);
+                nout = fma(out, out, nout);
+            });
+            bool going_in = od < 0.0;
+            if (__ballot(corner & !inside) != 0ull) {
+                // every joint beyond a limit (a corner of the box): inward only within 45 degrees of the diagonal
+                const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+                const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
+                going_in = corner ? steep : going_in;
+            }
+            in_tc = inside | going_in;
+        }
+    }
+}
+
 // raw words of a skill image as a literal (value-specialised kernels, see below)
 template <int K>
 struct RawImage {
@@ -191,226 +419,12 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = VALUES ? zdir[j] : zs[inst * N + j];
 
-    // ---- front end: sin / cos split over the quad, then FK and the task rows in every lane ----
-    TaskCache<SD> tc;
-    {
-        double sns[N], css[N];
-        if constexpr (SD.uses_fk != 0) {
-            // lane r evaluates state variables 2r and 2r+1 (clamped), the quad exchanges by DPP
-            const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-            const double a0 = VALUES ? q[binst * N + j0] : zs[inst * N + j0];
-            const double a1 = VALUES ? q[binst * N + j1] : zs[inst * N + j1];
-            double sn0, cs0, sn1, cs1;
-            sincos_fast(a0, sn0, cs0);
-            sincos_fast(a1, sn1, cs1);
-            const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
-            if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
-                if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
-                if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
-            }
-            static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
-                    constexpr int CTRL = (j / 2) * 0x55;           // quad_perm:[k,k,k,k], k = owner lane
-                    sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
-                    css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
-                } else {
-                    sns[j] = css[j] = 0.0;
-                }
-            });
-        }
-        const Img<SD> Sfk = *Slds;
-        __builtin_amdgcn_sched_barrier(0);
-        Kin<N> K;
-        if constexpr ((CLIK_TEAM_ABLATE & 16) != 0) {
-#pragma unroll
-            for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
-                tc.e[i] = z[i % N] + sns[(i + 1) % N];
-                tc.Jt[i] = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) tc.J[i][j] = z[(i + j) % N] * css[j];
-            }
-        } else {
-        if constexpr (SD.uses_fk != 0) {
-            forward_kinematics_sc<SD>(&Sfk, z, sns, css, K);
-            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(&Sfk, ysl, inst, K);
-        }
-        cache_task<SD, 0>(&Sfk, tk, K, z, ysl, inst, tc);
-        }
-    }
-    CLIK_STAMP_W(0, 2);
-    const Img<SD> Sb = *Slds;
-    __builtin_amdgcn_sched_barrier(0);
-    const Img<SD>* __restrict__ S = &Sb;
-    const double lam = S->lam;
-    const double one_lam = 1.0 + lam;
-
-    // desired task velocities  d = -K e - de/dt   (pseudo_inverse.py:318-321, :383-386)
-    double des1[M], w2[N];
-    {
-        double e[M], Jt[M], ke[M];
-        task_values<SD, 1>(S, tk, tc, z, ysl, inst, e, Jt);
-        gain_apply_s<M, SD.gain_matrix[1] != 0>(S->tasks[1], e, ke);
-#pragma unroll
-        for (int i = 0; i < M; ++i) des1[i] = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
-    }
-    {
-        // w2 = pinv(J2) d2 of the joint-space task: one entry per row (host-side pinv of the unit rows)
-        double e[M2], Jt[M2], ke[M2];
-        task_values<SD, 2>(S, tk, tc, z, ysl, inst, e, Jt);
-        gain_apply_s<M2, SD.gain_matrix[2] != 0>(S->tasks[2], e, ke);
-#pragma unroll
-        for (int j = 0; j < N; ++j) w2[j] = 0.0;
-        const double* Pm = S->cpinv[2];
-        static_for<0, M2>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int col = SD.ucol[2][i] - 1;
-            const double d = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
-            w2[col] = Pm[col * CLIK_MAX_M + i] * d;
-        });
-    }
-    // the set: violated rows (activation S of the multidim set, :289-298) by state column, and the
-    // values its tangent-cone test needs
-    double e0[M0], Jt0[M0];
-    task_values<SD, 0>(S, tk, tc, z, ysl, inst, e0, Jt0);
-    double sact[N], p0[N];          // sact[col] = 1.0 when the set row on that state is violated
-    static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int col = SD.ucol[0][i] - 1;
-        sact[col] = ((e0[i] - S->tasks[0].set_max[i] > 0.0) | (e0[i] - S->tasks[0].set_min[i] < 0.0)) ? 1.0 : 0.0;
-        p0[col] = S->cpinv[0][col * CLIK_MAX_M + i];
-    });
-
-    // Gm = J J'
-    double Gm[NT];
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int k = 0; k <= i; ++k) {
-            double acc = 0.0;
-            if constexpr ((CLIK_TEAM_ABLATE & 8) != 0) {
-                acc = jac<SD, 1>(S, tc, i, k) * jac<SD, 1>(S, tc, k, i);
-            } else {
-#pragma unroll
-            for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
-            }
-            Gm[tri(i, k)] = acc;
-        }
-
-    CLIK_STAMP_W(0, 3);
-    // ---- per-lane role ------------------------------------------------------------------------
-    // The lower-priority task's projected contribution, with the stack matrix G = D + c J'J of the mode
-    // (D = lam I in mode 0 with c = 2; D = (1+lam) I in mode 1 with c = 1) and C = G - (D - S):
-    //     w2 - G^-1 C w2  =  G^-1 (D - S) w2  =  D^-1 (x - c J' A^-1 J x),   x = (D - S) w2,  A = c J J' + D
-    // (Woodbury; S = 0 in mode 0).  So lane 1 solves A1 t = J w2 (then x/D = w2, c = 2), lane 2 solves
-    // A2 t = J x with x = ((1+lam) - s) o w2 (c = 1), lanes 0 / 3 solve A0 y = d1.
-    const bool solo = (r == 0) || (r == 3);
-    const double alpha = (r == 1) ? 2.0 : 1.0;
-    const double beta = (r == 2) ? one_lam : lam;
-    const double hsel = solo ? 1.0 : 0.0;
-    double rhs[M];
-    {
-        double x[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double f = (r == 2) ? one_lam - sact[j] : ((r == 1) ? 1.0 : 0.0);
-            x[j] = w2[j] * f;
-        }
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            double sacc = hsel * des1[i];
-#pragma unroll
-            for (int j = 0; j < N; ++j) sacc = fma(jac<SD, 1>(S, tc, i, j), x[j], sacc);
-            rhs[i] = sacc;
-        }
-    }
-    double A[NT], rd[M], s2[M];
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? fma(alpha, Gm[tri(i, k)], beta) : alpha * Gm[tri(i, k)];
-    if constexpr ((CLIK_TEAM_ABLATE & 4) != 0) {
-#pragma unroll
-        for (int i = 0; i < M; ++i) rhs[i] *= A[tri(i, i)] + A[tri(M - 1, i)];
-    } else {
-    ldl_factor_s<M>(A, rd);
-    ldl_solve_s<M>(A, rd, rhs);
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) s2[i] = rhs[i];
-    if constexpr ((CLIK_TEAM_ABLATE & (2 | 4)) == 0)
-    ldl_solve_s<M>(A, rd, s2);      // (second pass of the doubly processed equality: lane 0 only)
-    const double lam0 = (r == 0) ? lam : 0.0;
-#pragma unroll
-    for (int i = 0; i < M; ++i) rhs[i] = fma(lam0, s2[i], rhs[i]);
-    double g[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int i = 0; i < M; ++i) sacc = fma(jac<SD, 1>(S, tc, i, j), rhs[i], sacc);
-        g[j] = sacc;
-    }
-
-    CLIK_STAMP_W(0, 4);
-    // ---- the quad's results meet: lanes 0/1 form the mode-0 velocity, lanes 2/3 the mode-1 one --
-    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)
-    //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)
-    const bool hi_pair = (r & 2) != 0;
-    const double kap = hi_pair ? 1.0 / one_lam : 1.0;
-    const double eta = hi_pair ? 1.0 : 2.0;
+    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+    const double a0 = VALUES ? q[binst * N + j0] : zs[inst * N + j0];
+    const double a1 = VALUES ? q[binst * N + j1] : zs[inst * N + j1];
     double v[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double first = quad_perm_f64<0xF0>(g[j]);      // quad_perm:[0,0,3,3]: g0 | g3
-        const double second = quad_perm_f64<0xA5>(g[j]);     // quad_perm:[1,1,2,2]: g1 | g2
-        const double nmul = hi_pair ? fma(-p0[j], sact[j], 1.0) : 1.0;
-        const double xx = hi_pair ? w2[j] * (one_lam - sact[j]) : w2[j];
-        v[j] = fma(first, nmul, kap * fma(-eta, second, xx));
-    }
-    // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; lanes 2/3 evaluate it
-    // on the other candidate, unused)
     bool in_tc;
-    if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
-        in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
-    } else {
-        // (pseudo_inverse.py:222-252, same values; written for few instructions: half signs by bit operations,
-        // flags combined bitwise - the short-circuit forms compile to a branch per row -, and everything behind
-        // "inside" skipped when every instance of the wave is inside its limits, the normal state of a control loop)
-        const clik_task& t = S->tasks[0];
-        double le[M0], ue[M0];
-        bool inside = true;
-#pragma unroll
-        for (int i = 0; i < M0; ++i) {
-            le[i] = e0[i] - t.set_min[i];
-            ue[i] = e0[i] - t.set_max[i];
-            inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
-        }
-        in_tc = true;
-        if (__ballot(!inside) != 0ull) {
-            bool corner = true;
-            double od = 0.0, nde = 0.0, nout = 0.0;
-            static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int col = SD.ucol[0][i] - 1;
-                const double de = Jt0[i] + v[col];
-                const double hl = half_sign(le[i]), hu = half_sign(ue[i]);     // (sign(le) + sign(ue)) / 2 = hl + hu
-                corner = corner & (hl == hu);
-                const double out = hl + hu;
-                od = fma(out, de, od);
-                nde = fma(de, de, nde);
-                nout = fma(out, out, nout);
-            });
-            bool going_in = od < 0.0;
-            if (__ballot(corner & !inside) != 0ull) {
-                // every joint beyond a limit (a corner of the box): inward only within 45 degrees of the diagonal
-                const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
-                const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
-                going_in = corner ? steep : going_in;
-            }
-            in_tc = inside | going_in;
-        }
-    }
+    team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, v, in_tc);
     // the scan of :530-550 as a select: mode 0 if its cone test passes, else mode 1 (the active set
     // has no cone test, so mode 1 is always admissible)
     CLIK_STAMP_W(0, 6);
@@ -439,6 +453,120 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
         }
     }
     CLIK_STAMP_W(0, 5);
+}
+
+// n_ticks of (tick -> clamp(+-max_speed) -> integrate) in one launch with four lanes per instance: the host loop
+// of the notebooks (ur5_moe2016_example2.ipynb:537-545) without the per-tick launch and HBM round trip, the state
+// in registers (replicated over the quad).  stages = 1: explicit Euler; 4: classical Runge-Kutta with the
+// controller as the right-hand side (see pinv_rollout_static_kernel).  q is updated in place; dq / mode receive
+// the last tick (Runge-Kutta: the combined rate and the mode of the first stage).
+template <const ShapeDesc& SD, class IMGV = void>
+__global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_kernel(
+    const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B,
+    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed, const int stages)
+{
+    static_assert(shape_team_ok(SD), "shape outside the team kernel's family");
+    constexpr bool VALUES = !std::is_void<IMGV>::value;
+    extern __shared__ double lds[];
+    constexpr int N = SD.n, NY = SD.n_y > 0 ? SD.n_y : 0;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = tid & (TEAM - 1);
+    const int inst = tid >> 2;
+    const long long b0 = (long long)blockIdx.x * TEAM_INST;
+    const bool valid = b0 + inst < B;
+    const long long binst = valid ? (b0 + inst) : (B - 1);
+    double* ys = lds + (VALUES ? 0 : StaticLayout<SD>::IMG_DOUBLES);        // [64][NY] (image-reading build only)
+    double z[N], ydir[NY > 0 ? NY : 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = q[binst * N + j];
+    if constexpr (NY > 0) {
+#pragma unroll
+        for (int k = 0; k < NY; ++k) ydir[k] = y[binst * NY + k];
+    }
+    if constexpr (!VALUES) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        constexpr int CH = StaticLayout<SD>::IMG_CHUNKS;
+        const d2* src = (const d2*)img_g;
+        d2* dst = (d2*)lds;
+        const int lane = tid & (WAVE - 1);
+        for (int ck = wave; ck < CH; ck += TEAM_WAVES) dst[ck * WAVE + lane] = src[ck * WAVE + lane];
+        if constexpr (NY > 0) {
+            // (run-time input indices: the rows of the image-reading build live in LDS; the quad writes the same values)
+#pragma unroll
+            for (int k = 0; k < NY; ++k) ys[inst * NY + k] = ydir[k];
+        }
+        __syncthreads();
+    }
+    constexpr Img<SD> Sval = []() constexpr { if constexpr (VALUES) return IMGV::value; else return Img<SD>{}; }();
+    const Img<SD>* __restrict__ Slds = VALUES ? &Sval : (const Img<SD>*)lds;
+    const double* ysl = VALUES ? ydir : ys + inst * NY;
+    const int nts = Slds->n_tslots;
+    double vout[N];
+    int acc_mode = -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vout[j] = 0.0;
+#pragma unroll 1
+    for (int tick = 0; tick < n_ticks; ++tick) {
+        double z0[N], ks[N];
+        int mode0 = -1;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            z0[j] = z[j];
+            ks[j] = 0.0;
+        }
+#pragma unroll 1
+        for (int st = 0; st < stages; ++st) {
+            asm volatile("" ::: "memory");      // (keeps the image reads inside the loop, see pinv_rollout_static_kernel)
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + st) * 2 * nts);
+            // lane r's two sin / cos arguments out of the replicated state (register selects)
+            double a0 = z[N - 1], a1 = z[N - 1];
+            static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (2 * k < N) a0 = (r == k) ? z[2 * k] : a0;
+                if constexpr (2 * k + 1 < N) a1 = (r == k) ? z[2 * k + 1] : a1;
+            });
+            double v[N];
+            bool in_tc;
+            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, v, in_tc);
+            const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
+            const double wgt = (stages == 1) ? 1.0 : ((st == 0 || st == 3) ? 1.0 : 2.0);
+            const double cnext = (st == 2) ? dt : 0.5 * dt;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                // the accepted candidate in every lane of the quad: mode 0 lives in lane 0, mode 1 in lane 2
+                const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xAA>(v[j]);
+                double d = ok0 ? c0 : c1;
+                if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                ks[j] = fma(wgt, d, ks[j]);
+                z[j] = fma(d, cnext, z0[j]);
+            }
+            mode0 = (st == 0) ? (ok0 ? 0 : 1) : mode0;
+        }
+        const double scale = (stages == 1) ? 1.0 : 1.0 / 6.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            vout[j] = ks[j] * scale;
+            z[j] = fma(vout[j], dt, z0[j]);
+        }
+        acc_mode = mode0;
+    }
+    if (r == 0 && valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            q[(b0 + inst) * N + j] = z[j];
+            dq[(b0 + inst) * N + j] = vout[j];
+        }
+        if (mode_out != nullptr) mode_out[b0 + inst] = acc_mode;
+    }
+}
+
+template <const ShapeDesc& SD>
+inline size_t team_rollout_lds_bytes(bool values = false)
+{
+    if (values) return 0;
+    return ((size_t)StaticLayout<SD>::IMG_DOUBLES + (size_t)(SD.n_y > 0 ? SD.n_y : 0) * TEAM_INST) * sizeof(double);
 }
 
 }  // namespace clik

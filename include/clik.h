@@ -209,10 +209,11 @@ int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn, cons
  * constants, gains, bounds, row coefficients) compiled in, as the functions CasADi generates for the reference
  * are (pseudo_inverse.py:476-483).  clik_pinv_image_words returns the numbers as the 64-bit words of the skill
  * image (n words, or a negative error); casclik_amd/jit.py compiles them into the kernel templates and attaches
- * the result.  It serves the batch sizes the "team4" variant serves (reported as "team4v"); solve_fn = NULL
- * detaches it.  Only for skills of that kernel's family.                                                  */
+ * the result (solve_fn: the per-tick kernel; rollout_fn: its on-device rollout, may be NULL).  They serve the
+ * batch sizes the "team4" variant serves (reported as "team4v"); solve_fn = NULL detaches both.  Only for skills
+ * of that kernel's family.                                                                                  */
 int clik_pinv_image_words(const clik_pinv* h, uint64_t* buf, int cap);
-int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn);
+int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)
