@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the four-lanes-per-instance kernels (team4 / team4v and their rollout) on the GPU box:
+random members of the config-3 family - robot, scalar / matrix gains, one- or two-sided limits scaled at random,
+the third task on a random subset of the joints with constant / time-dependent / input-dependent targets, feed-forward
+on / off, damping 1e-9 .. 1e-5, inputs interior / mixed / near-singular - against the numpy oracle.
+    python tools/fuzz_team.py [n_skills] [seed]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np                                   # noqa: E402
+
+import casclik_amd as cc                             # noqa: E402
+from casclik_amd import skills, sym as cs            # noqa: E402
+from oracle import clik_oracle                       # noqa: E402
+
+n_skills = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+FK = {"iiwa": skills.iiwa(), "ur5": skills.ur5()}
+worst = 0.0
+bad = 0
+for s in range(n_skills):
+    robot = "ur5" if rng.random() < 0.4 else "iiwa"
+    fk = FK[robot]
+    n = len(fk["joint_names"])
+    t, q, y = cs.MX.sym("t"), cs.MX.sym("q", n), cs.MX.sym("y", 7 + n)
+    T = fk["T_fk"](q)
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    scale = rng.uniform(0.5, 1.0)
+    kw = dict(label="limits", expression=q, priority=0, set_max=scale * hi)
+    if rng.random() < 0.75:
+        kw["set_min"] = scale * lo
+    limits = cc.SetConstraint(**kw)
+    m = 6 if rng.random() < 0.7 else 3
+    expr = skills._pose_expression(T, y) if m == 6 else T[:3, 3] - y[:3]
+    if rng.random() < 0.3:
+        expr = expr + cs.vertcat(*([0.02 * cs.sin(0.7 * t)] + [0.0] * (m - 1)))
+    K = float(rng.uniform(1.0, 12.0)) if rng.random() < 0.6 else \
+        np.diag(rng.uniform(1.0, 10.0, size=m)) + 0.3 * rng.normal(size=(m, m))
+    pose = cc.EqualityConstraint("task", expr, gain=K, constraint_type="soft", priority=1)
+    k3 = int(rng.integers(1, n + 1))
+    js = sorted(rng.choice(n, size=k3, replace=False).tolist())
+    rows = []
+    for j in js:
+        kind = rng.integers(0, 3)
+        tgt = float(rng.uniform(0.3 * lo[j], 0.3 * hi[j]))
+        rows.append(q[j] - tgt if kind == 0 else (q[j] - tgt - 0.1 * cs.sin(0.5 * t) if kind == 1 else q[j] - y[7 + j]))
+    K3 = float(rng.uniform(0.2, 3.0)) if rng.random() < 0.7 or k3 == 1 else np.diag(rng.uniform(0.2, 3.0, size=k3))
+    third = cc.EqualityConstraint("joints", cs.vertcat(*rows), gain=K3, constraint_type="soft", priority=2)
+    spec = cc.SkillSpecification("fuzz_team", t, q, input_var=y, constraints=[third, limits, pose])
+    opts = {"multidim_sets": True, "feedforward": bool(rng.random() < 0.8), "damping_factor": float(10 ** rng.uniform(-9, -5))}
+    B = 256
+    dist = ["interior", "mixed", "mixed"][int(rng.integers(0, 3))]
+    Q, Y7 = skills.synthetic_inputs(fk, B, seed=int(rng.integers(1 << 30)), distribution=dist)
+    if rng.random() < 0.15:
+        Q[: B // 4] = rng.normal(0.0, 1e-4, size=(B // 4, n))          # near the stretched-out singularity
+    Y = np.hstack([Y7, rng.uniform(0.3 * lo, 0.3 * hi, size=(B, n))])
+    tval = float(rng.uniform(0.0, 3.0))
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, tval, Q, Y=Y)
+    for values in ("1", "0"):
+        os.environ["CLIK_JIT_VALUES"] = values
+        ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
+        ctrl.setup_problem_functions()
+        variant = ctrl.kernel_variant(B)
+        if "/team4" not in variant:
+            print("skill %3d %-4s NOT in the team family: %s" % (s, robot, variant))
+            break
+        dq, _, mode = ctrl.solve_batch(tval, Q, input_var=Y)
+        agree = mode == rmode
+        err = float((np.abs(dq - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1)))[agree].max())
+        # one rollout tick must equal the solve
+        q1, dq1, m1 = ctrl.rollout_batch([tval], Q, input_var=Y, dt=1e-3)
+        rerr = float(np.abs(dq1 - dq).max() / (1.0 + np.abs(dq).max()))
+        worst = max(worst, err)
+        flag = ""
+        if (~agree).any() or err > 1e-7 or rerr > 1e-9 or not np.array_equal(m1, mode):
+            bad += 1
+            flag = "   <-- MISMATCH"
+        print("skill %3d %-4s m=%d third=%d %-9s ff=%d lam=%.0e %-8s modes %s wrong %d err %.2e rollout %.1e%s" % (
+            s, robot, m, k3, variant.split("/")[-1], opts["feedforward"], opts["damping_factor"], dist,
+            np.bincount(rmode + 1).tolist(), int((~agree).sum()), err, rerr, flag))
+print("fuzz_team: %d skills, worst relative error %.3e, mismatching runs %d" % (n_skills, worst, bad))
