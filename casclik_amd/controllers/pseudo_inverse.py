@@ -214,13 +214,17 @@ class PseudoInverseController(BaseController):
 
         robot_var [B, n_q], virtual_var [B, n_x], input_var [B, n_y] as numpy
         arrays or torch tensors (tensors on the controller's device are used
-        in place).  Returns (robot_vel [B,n_q], virtual_vel | None, mode [B])
+        in place).  ``time_var``: one time stamp for the batch, or an array with one per
+        instance (then one launch per distinct time stamp).  Returns (robot_vel [B,n_q], virtual_vel | None, mode [B])
         in the container type of ``robot_var``.  The launch is asynchronous on
         torch's current stream when tensors are passed."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
         dev = self._device
+        if np.ndim(time_var) > 0 and np.size(time_var) > 1:
+            return self._solve_batch_per_instance_time(time_var, robot_var, virtual_var, input_var, out, return_mode)
+        time_var = float(np.asarray(time_var).reshape(-1)[0]) if np.ndim(time_var) > 0 else time_var
         Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
         B = Q.shape[0]
         X = None
@@ -246,6 +250,42 @@ class PseudoInverseController(BaseController):
                 self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
                 ptr(mode), current_stream(dev))
         _capi.check(self._lib, rc)
+        if was_np:
+            return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),
+                    None if mode is None else mode.cpu().numpy())
+        return dQ, dX, mode
+
+    def _solve_batch_per_instance_time(self, times, robot_var, virtual_var, input_var, out, return_mode):
+        """``time_var`` with one entry per instance (robots at different phases of a trajectory).  The kernels take
+        the time slots of ONE time stamp in their arguments, so the batch is grouped by distinct time stamps and
+        each group is one launch on its rows (a batch with k distinct phases costs k launches plus the row
+        gathers; instances that share a clock cost nothing extra)."""
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        times = np.asarray(times, dtype=float).reshape(-1)
+        if times.size != B:
+            raise ValueError("time_var has %d entries, the batch %d instances" % (times.size, B))
+        X = to_device_matrix(virtual_var, d.n_x, dev, "virtual_var", B)[0] if d.n_x > 0 else None
+        Y = to_device_matrix(input_var, d.n_y, dev, "input_var", B)[0] if d.n_y > 0 else None
+        if out is not None:
+            check_out_tensor(out, (B, d.n_q), "float64", dev, "out")
+        dQ = out if out is not None else torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
+        dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
+        mode = torch.empty((B,), dtype=torch.int32, device=dev) if return_mode else None
+        uniq, inverse = np.unique(times, return_inverse=True)
+        for k, tv in enumerate(uniq):
+            rows = torch.from_numpy(np.nonzero(inverse == k)[0]).to(dev)
+            res = self.solve_batch(float(tv), Q.index_select(0, rows),
+                                   virtual_var=None if X is None else X.index_select(0, rows),
+                                   input_var=None if Y is None else Y.index_select(0, rows), return_mode=return_mode)
+            dQ.index_copy_(0, rows, res[0])
+            if dX is not None:
+                dX.index_copy_(0, rows, res[1])
+            if mode is not None:
+                mode.index_copy_(0, rows, res[2])
         if was_np:
             return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),
                     None if mode is None else mode.cpu().numpy())

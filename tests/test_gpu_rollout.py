@@ -104,3 +104,21 @@ def test_rollouts_on_two_streams_do_not_share_state(ur5_fk):
     torch.cuda.synchronize()
     for qa, qb in outs:
         assert np.array_equal(qa.cpu().numpy(), ref_a) and np.array_equal(qb.cpu().numpy(), ref_b)
+
+
+def test_per_instance_time_stamps(ur5_fk):
+    """time_var with one entry per instance: grouped by distinct time stamps, one launch each; equals the
+    per-time-stamp calls"""
+    spec, ctrl = _tracking(ur5_fk, 6)
+    rng = np.random.default_rng(12)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.1, size=(97, 6))
+    phases = np.array([0.0, 1.5, 4.0])
+    times = phases[rng.integers(0, 3, size=97)]
+    dq, _, mode = ctrl.solve_batch(times, Q)
+    for tv in phases:
+        rows = times == tv
+        ref, _, rmode = ctrl.solve_batch(float(tv), Q[rows])
+        assert np.array_equal(dq[rows], ref) and np.array_equal(mode[rows], rmode)
+    with pytest.raises(ValueError):
+        ctrl.solve_batch(times[:5], Q)

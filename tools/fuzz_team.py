@@ -62,6 +62,20 @@ for s in range(n_skills):
     Y = np.hstack([Y7, rng.uniform(0.3 * lo, 0.3 * hi, size=(B, n))])
     tval = float(rng.uniform(0.0, 3.0))
     ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, tval, Q, Y=Y)
+    # degenerate ties: a 3-row position task leaves the last joint (rotation about the tool axis) with an exactly
+    # zero velocity in the oracle and +-1e-20 in a factorisation-based evaluation; the tangent-cone test of that
+    # joint's limit is then decided by rounding.  Lanes whose oracle mode flips under a 1e-12 relative perturbation
+    # of q are skipped (as tools/fuzz_parity.py does).
+    tie = np.zeros(B, dtype=bool)
+    for eps in (1e-12, -1e-12):
+        _, pm = clik_oracle.pinv_solve_batch(spec, opts, tval, Q * (1.0 + eps), Y=Y)
+        tie |= pm != rmode
+    if m == 3:
+        # ... and lanes where that joint is outside its limits (the zero is structural there, not just close)
+        lim_lo = limits.set_min if kw.get("set_min") is not None else -1e10 * np.ones(n)
+        tie |= (Q[:, n - 1] > np.asarray(limits.set_max)[n - 1]) | (Q[:, n - 1] < np.asarray(lim_lo)[n - 1])
+    # the projectors' condition number is ~2 sigma_max^2 / lam: the rounding yardstick scales with 1 / lam
+    tol = max(1e-7, 2e-15 / opts["damping_factor"])       # (2 sigma_max^2 / lam x 1e-16 with sigma_max^2 ~ 10)
     for values in ("1", "0"):
         os.environ["CLIK_JIT_VALUES"] = values
         ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
@@ -71,17 +85,18 @@ for s in range(n_skills):
             print("skill %3d %-4s NOT in the team family: %s" % (s, robot, variant))
             break
         dq, _, mode = ctrl.solve_batch(tval, Q, input_var=Y)
-        agree = mode == rmode
-        err = float((np.abs(dq - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1)))[agree].max())
+        agree = (mode == rmode) | tie
+        cmp_ = (mode == rmode) & ~tie
+        err = float((np.abs(dq - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1)))[cmp_].max()) if cmp_.any() else 0.0
         # one rollout tick must equal the solve
         q1, dq1, m1 = ctrl.rollout_batch([tval], Q, input_var=Y, dt=1e-3)
         rerr = float(np.abs(dq1 - dq).max() / (1.0 + np.abs(dq).max()))
         worst = max(worst, err)
         flag = ""
-        if (~agree).any() or err > 1e-7 or rerr > 1e-9 or not np.array_equal(m1, mode):
+        if (~agree).any() or err > tol or rerr > 1e-9 or not np.array_equal(m1, mode):
             bad += 1
             flag = "   <-- MISMATCH"
-        print("skill %3d %-4s m=%d third=%d %-9s ff=%d lam=%.0e %-8s modes %s wrong %d err %.2e rollout %.1e%s" % (
+        print("skill %3d %-4s m=%d third=%d %-9s ff=%d lam=%.0e %-8s modes %s ties %d wrong %d err %.2e (tol %.0e) rollout %.1e%s" % (
             s, robot, m, k3, variant.split("/")[-1], opts["feedforward"], opts["damping_factor"], dist,
-            np.bincount(rmode + 1).tolist(), int((~agree).sum()), err, rerr, flag))
+            np.bincount(rmode + 1).tolist(), int(tie.sum()), int((~agree).sum()), err, tol, rerr, flag))
 print("fuzz_team: %d skills, worst relative error %.3e, mismatching runs %d" % (n_skills, worst, bad))
