@@ -172,7 +172,9 @@ def profiled(workload, dist_name, batch, kernel):
     """Per-launch PMC figures of this configuration recorded under profiles/ (they cannot be collected
     from inside this process: separate rocprofv3 --pmc passes, tools/rocprof_counters.py).  Returns
     (entry, source) or (None, None): a configuration that was not profiled gets no traffic figure."""
-    keys = ["%s_%s_B%d_%s" % (workload, dist_name, batch, kernel), "%s_%s_B%d" % (workload, dist_name, batch)]
+    keys = ["%s_%s_B%d_%s" % (workload, dist_name, batch, kernel)]
+    if str(kernel).endswith(("/lane", "/mp2")) or "/" not in str(kernel):
+        keys.append("%s_%s_B%d" % (workload, dist_name, batch))       # round-1 entries (recorded before variants had names)
     for fn in PROFILE_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -327,7 +329,8 @@ def main():
         variant = getattr(ctrl, "kernel_variant", None)
         if callable(variant):
             kernel = variant(B)
-        prof, prof_src = profiled(args.workload, args.dist, B, kernel)
+        # (an on-device rollout moves its bytes once per launch of TPL ticks: no per-tick traffic figure was profiled)
+        prof, prof_src = profiled(args.workload, args.dist, B, kernel) if TPL == 1 else (None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof.get("traffic_bytes") if prof else None,
