@@ -122,3 +122,29 @@ def test_per_instance_time_stamps(ur5_fk):
         assert np.array_equal(dq[rows], ref) and np.array_equal(mode[rows], rmode)
     with pytest.raises(ValueError):
         ctrl.solve_batch(times[:5], Q)
+
+
+def test_output_tensors_are_validated(iiwa_fk):
+    """out / mode_out go to the kernels by pointer: a wrong shape, dtype, device or a strided view raises instead
+    of writing out of bounds (solve_batch, bind_batch of both controllers)"""
+    import torch
+    ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(iiwa_fk), options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 10, seed=1)
+    Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+    good = torch.empty((10, 7), dtype=torch.float64, device="cuda")
+    ctrl.solve_batch(0.0, Qd, input_var=Yd, out=good)
+    bad = [torch.empty((10, 7), dtype=torch.float32, device="cuda"), torch.empty((9, 7), dtype=torch.float64, device="cuda"),
+           torch.empty((10, 7), dtype=torch.float64), torch.empty((7, 10), dtype=torch.float64, device="cuda").T]
+    for out in bad:
+        with pytest.raises(ValueError):
+            ctrl.solve_batch(0.0, Qd, input_var=Yd, out=out)
+        with pytest.raises(ValueError):
+            ctrl.bind_batch(Qd, input_var=Yd, out=out)
+    with pytest.raises(ValueError):
+        ctrl.bind_batch(Qd, input_var=Yd, mode_out=torch.empty((10,), dtype=torch.int64, device="cuda"))
+    qp = cc.ReactiveQPController(skill_spec=skills.qp_skill(iiwa_fk))
+    qp.setup_problem_functions()
+    qp.setup_solver()
+    with pytest.raises(ValueError):
+        qp.bind_batch(Qd, input_var=Yd, out=bad[0])
