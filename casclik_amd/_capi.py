@@ -174,10 +174,10 @@ def qp_opts_to_c(mu, state_weights, slack_weights, max_iter=0):
 _SYMBOLS = [
     "clik_last_error", "clik_abi_version",
     "clik_pinv_create", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_shape_describe", "clik_pinv_attach_kernel",
-    "clik_pinv_solve_batch", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
+    "clik_pinv_solve_batch", "clik_pinv_solve_batch_t", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
     "clik_qp_create", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
     "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel",
-    "clik_qp_solve_batch", "clik_qp_solve_batch_hot", "clik_qp_rollout_batch", "clik_qp_rollout_batch_x", "clik_qp_data_batch",
+    "clik_qp_solve_batch", "clik_qp_solve_batch_hot", "clik_qp_solve_batch_t", "clik_qp_rollout_batch", "clik_qp_rollout_batch_x", "clik_qp_data_batch",
 ]
 
 _lib = None
@@ -254,6 +254,8 @@ def load_library(path=None):
     lib.clik_pinv_solve_batch.restype = C.c_int
     lib.clik_pinv_solve_batch.argtypes = [vp, C.c_int64, C.POINTER(C.c_double),
                                           dp, dp, dp, dp, dp, ip, vp]
+    lib.clik_pinv_solve_batch_t.restype = C.c_int
+    lib.clik_pinv_solve_batch_t.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp, ip, vp]
     lib.clik_pinv_rollout_batch.restype = C.c_int
     lib.clik_pinv_rollout_batch.argtypes = [vp, C.c_int64, C.c_int32,
                                             C.c_double, C.c_double,
@@ -293,6 +295,8 @@ def load_library(path=None):
     lib.clik_qp_solve_batch_hot.restype = C.c_int
     lib.clik_qp_solve_batch_hot.argtypes = [vp, C.c_int64, C.POINTER(C.c_double),
                                         dp, dp, dp, dp, dp, dp, ip, ip, C.c_int32, vp]
+    lib.clik_qp_solve_batch_t.restype = C.c_int
+    lib.clik_qp_solve_batch_t.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp, dp, ip, ip, C.c_int32, vp]
     lib.clik_qp_data_batch.restype = C.c_int
     lib.clik_qp_data_batch.argtypes = [vp, C.c_int64, C.POINTER(C.c_double),
                                        dp, dp, dp, dp, dp, dp, dp, vp]
@@ -302,6 +306,9 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+CLIK_OK, CLIK_EINVAL, CLIK_EUNSUPPORTED, CLIK_EHIP, CLIK_ENOMEM = 0, -1, -2, -3, -4     # include/clik.h:59-63
 
 
 def check(lib, rc):

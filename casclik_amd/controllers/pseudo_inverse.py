@@ -256,10 +256,10 @@ class PseudoInverseController(BaseController):
         return dQ, dX, mode
 
     def _solve_batch_per_instance_time(self, times, robot_var, virtual_var, input_var, out, return_mode):
-        """``time_var`` with one entry per instance (robots at different phases of a trajectory).  The kernels take
-        the time slots of ONE time stamp in their arguments, so the batch is grouped by distinct time stamps and
-        each group is one launch on its rows (a batch with k distinct phases costs k launches plus the row
-        gathers; instances that share a clock cost nothing extra)."""
+        """``time_var`` with one entry per instance (robots at different phases of a trajectory): ONE launch of the
+        per-instance-time kernel (clik_pinv_solve_batch_t: the time-only sub-expressions are evaluated on the host
+        per distinct time stamp and travel as a [B, 2 * n_tslots] device array).  A skill served by the dynamic
+        fallback kernel has no such variant: its batch is grouped by distinct time stamps, one launch per group."""
         torch = _torch()
         d = self.descriptor
         dev = self._device
@@ -276,7 +276,16 @@ class PseudoInverseController(BaseController):
         dX = torch.empty((B, d.n_x), dtype=torch.float64, device=dev) if d.n_x else None
         mode = torch.empty((B,), dtype=torch.int32, device=dev) if return_mode else None
         uniq, inverse = np.unique(times, return_inverse=True)
-        for k, tv in enumerate(uniq):
+        terms = np.asarray([np.asarray(d.time_terms(float(tv)), dtype=float).reshape(-1) for tv in uniq])
+        rc = _capi.CLIK_EUNSUPPORTED
+        if terms.shape[1] > 0:
+            T = torch.from_numpy(np.ascontiguousarray(terms[inverse])).to(dev)
+            with torch.cuda.device(dev):
+                rc = self._lib.clik_pinv_solve_batch_t(self._handle, B, ptr(T), ptr(Q), ptr(X), ptr(Y), ptr(dQ),
+                                                       ptr(dX), ptr(mode), current_stream(dev))
+            if rc != _capi.CLIK_EUNSUPPORTED:
+                _capi.check(self._lib, rc)
+        for k, tv in enumerate(uniq if rc == _capi.CLIK_EUNSUPPORTED else ()):
             rows = torch.from_numpy(np.nonzero(inverse == k)[0]).to(dev)
             res = self.solve_batch(float(tv), Q.index_select(0, rows),
                                    virtual_var=None if X is None else X.index_select(0, rows),

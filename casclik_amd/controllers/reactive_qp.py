@@ -377,13 +377,24 @@ class ReactiveQPController(BaseController):
         working set from tick to tick (the reference's qpOASES instance hot-starts
         the same way, reactive_qp.py:491-513).  It is read when ``use_hot`` and
         always overwritten with the final working set; the minimiser is the same
-        with or without it."""
+        with or without it.
+
+        ``time_var`` may hold one time per instance (robots at different phases of their
+        trajectories): one launch of the per-instance-time kernel (clik_qp_solve_batch_t)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
         dev = self._device
         Q, was_np = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
         B = Q.shape[0]
+        times = None
+        if np.ndim(time_var) > 0 and np.size(time_var) > 1:
+            times = np.asarray(time_var, dtype=float).reshape(-1)
+            if times.size != B:
+                raise ValueError("time_var has %d entries, the batch %d instances" % (times.size, B))
+            time_var = float(times[0])
+        elif np.ndim(time_var) > 0:
+            time_var = float(np.asarray(time_var).reshape(-1)[0])
         X = Y = None
         if d.n_x > 0:
             if virtual_var is None:
@@ -401,11 +412,40 @@ class ReactiveQPController(BaseController):
         tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
         if hot_set is not None and (hot_set.dtype != torch.int32 or hot_set.numel() != B or not hot_set.is_cuda):
             raise ValueError("hot_set must be an int32 device tensor with one entry per instance")
+        hot_flag = 1 if (hot_set is not None and use_hot) else 0
+        T = None
+        if times is not None and np.size(tt) > 0:
+            uniq, inverse = np.unique(times, return_inverse=True)
+            terms = np.asarray([np.asarray(d.time_terms(float(tv)), dtype=float).reshape(-1) for tv in uniq])
+            T = torch.from_numpy(np.ascontiguousarray(terms[inverse])).to(dev)
         with torch.cuda.device(dev):
-            rc = self._lib.clik_qp_solve_batch_hot(
-                self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
-                ptr(SL), ptr(status), ptr(hot_set), 1 if (hot_set is not None and use_hot) else 0,
-                current_stream(dev))
+            if T is not None:
+                rc = self._lib.clik_qp_solve_batch_t(
+                    self._handle, B, ptr(T), ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
+                    ptr(SL), ptr(status), ptr(hot_set), hot_flag, current_stream(dev))
+            else:
+                rc = self._lib.clik_qp_solve_batch_hot(
+                    self._handle, B, ttp, ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX),
+                    ptr(SL), ptr(status), ptr(hot_set), hot_flag, current_stream(dev))
+        if T is not None and rc == _capi.CLIK_EUNSUPPORTED:
+            # (a skill on the dynamic fallback kernel: one launch per distinct time stamp)
+            for k, tv in enumerate(uniq):
+                rows = torch.from_numpy(np.nonzero(inverse == k)[0]).to(dev)
+                hs = None if hot_set is None else hot_set.index_select(0, rows)
+                res = self.solve_batch(float(tv), Q.index_select(0, rows),
+                                       virtual_var=None if X is None else X.index_select(0, rows),
+                                       input_var=None if Y is None else Y.index_select(0, rows),
+                                       return_status=return_status, hot_set=hs, use_hot=use_hot)
+                dQ.index_copy_(0, rows, res[0])
+                if dX is not None:
+                    dX.index_copy_(0, rows, res[1])
+                if SL is not None:
+                    SL.index_copy_(0, rows, res[2])
+                if status is not None:
+                    status.index_copy_(0, rows, res[3])
+                if hs is not None:
+                    hot_set.index_copy_(0, rows, hs)
+            rc = 0
         _capi.check(self._lib, rc)
         if was_np:
             return (dQ.cpu().numpy(), None if dX is None else dX.cpu().numpy(),

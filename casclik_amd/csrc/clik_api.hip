@@ -31,6 +31,7 @@ struct LaunchArgs {
     double* roll_x;         // (mirror of clik_pinv_kernels.hpp)
     double* roll_dx;
     int roll_stages;
+    const double* t_inst;
 };
 int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
@@ -58,7 +59,8 @@ int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
-                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream);
+                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,
+                            const double* t_inst);
 hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
                                     double max_speed, long long B, double* q, const double* y, double* dq,
                                     double* slack, int32_t* status, double* x, double* dx, hipStream_t stream);
@@ -94,7 +96,8 @@ struct clik_pinv {
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
-                                     const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
+                                     const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t,
+                                     const double*);
 
 typedef hipError_t (*clik_jit_qp_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
                                              const double*, double*, double*, int32_t*, double*, double*,
@@ -858,9 +861,9 @@ static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk)
     return CLIK_OK;
 }
 
-extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double* tterms, const double* q,
-                                     const double* x, const double* y, double* dq, double* dx,
-                                     int32_t* mode, void* stream)
+static int pinv_solve_common(const clik_pinv* h, int64_t B, const double* tterms, const double* t_inst,
+                             const double* q, const double* x, const double* y, double* dq, double* dx,
+                             int32_t* mode, void* stream)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0) return fail(CLIK_EINVAL, "negative batch size");
@@ -869,15 +872,21 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_x > 0 && (!x || !dx)) return fail(CLIK_EINVAL, "skill has virtual_var: x and dx required");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
-    if (!h->jit_solve && (h->kernel < 0 || !clik::pinv_kernel_is_static(h->kernel)) && skill_needs_static(S))
-        return extern_needs_kernel("clik_pinv_solve_batch");
+    const bool is_static = h->jit_solve || (h->kernel >= 0 && clik::pinv_kernel_is_static(h->kernel));
+    if (!is_static && skill_needs_static(S)) return extern_needs_kernel("clik_pinv_solve_batch");
     TickArgs tk;
-    int rc = fill_tick(S, tterms, &tk);
-    if (rc) return rc;
-    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr, 1};
+    if (t_inst == nullptr) {
+        int rc = fill_tick(S, tterms, &tk);
+        if (rc) return rc;
+    } else if (!is_static) {
+        return fail(CLIK_EUNSUPPORTED, "clik_pinv_solve_batch_t: per-instance time needs a shape-specialised kernel "
+                                       "for the skill (none built in, none attached)");
+    }
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr, 1,
+                                 t_inst};
     // a value-specialised team kernel serves the batches the image-reading team kernel would serve
     const bool team_batch = (h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch());
-    hipError_t e = (h->val_solve && team_batch)
+    hipError_t e = (h->val_solve && team_batch && t_inst == nullptr)
                        ? h->val_solve(&la, &tk, (long long)B, q, y, dq, mode, (hipStream_t)stream)
                    : h->jit_solve
                        ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
@@ -885,6 +894,24 @@ extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double
                                                  (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
     return CLIK_OK;
+}
+
+extern "C" int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double* tterms, const double* q,
+                                     const double* x, const double* y, double* dq, double* dx,
+                                     int32_t* mode, void* stream)
+{
+    return pinv_solve_common(h, B, tterms, nullptr, q, x, y, dq, dx, mode, stream);
+}
+
+extern "C" int clik_pinv_solve_batch_t(const clik_pinv* h, int64_t B, const double* t_inst, const double* q,
+                                       const double* x, const double* y, double* dq, double* dx,
+                                       int32_t* mode, void* stream)
+{
+    if (h && h->host.d.n_tslots > 0 && !t_inst)
+        return fail(CLIK_EINVAL, "clik_pinv_solve_batch_t: t_inst (device, [B][2 * n_tslots]) required");
+    if (h && h->host.d.n_tslots == 0)       // (nothing depends on time)
+        return pinv_solve_common(h, B, nullptr, nullptr, q, x, y, dq, dx, mode, stream);
+    return pinv_solve_common(h, B, nullptr, t_inst, q, x, y, dq, dx, mode, stream);
 }
 
 // Time-slot records of a rollout (host) -> a device buffer that lives for this call only: allocated, filled and
@@ -948,7 +975,7 @@ extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t 
     double* d_tt = nullptr;
     int rc = stage_tterms(tterms, (size_t)n_ticks * stages * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
     if (rc) return rc;
-    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx, stages};
+    const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx, stages, nullptr};
     const bool team_batch = (h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch());
     hipError_t e = (h->val_rollout && team_batch)
                        ? h->val_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
@@ -1174,9 +1201,9 @@ extern "C" int clik_qp_solve_batch(const clik_qp* h, int64_t B, const double* tt
     return clik_qp_solve_batch_hot(h, B, tterms, q, x, y, dq, dx, slack, status, nullptr, 0, stream);
 }
 
-extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms, const double* q,
-                                       const double* x, const double* y, double* dq, double* dx, double* slack,
-                                       int32_t* status, int32_t* hot_set, int32_t use_hot, void* stream)
+static int qp_solve_common(const clik_qp* h, int64_t B, const double* tterms, const double* t_inst, const double* q,
+                           const double* x, const double* y, double* dq, double* dx, double* slack,
+                           int32_t* status, int32_t* hot_set, int32_t use_hot, void* stream)
 {
     int rc = qp_check_args(h, B, q, x, y);
     if (rc) return rc;
@@ -1184,15 +1211,20 @@ extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double
     if (!dq) return fail(CLIK_EINVAL, "dq must be a device pointer");
     if (!h->jit_solve && h->static_k < 0 && skill_needs_static(h->host)) return extern_needs_kernel("clik_qp_solve_batch");
     TickArgs tk;
-    rc = fill_tick(h->host, tterms, &tk);
-    if (rc) return rc;
+    if (t_inst == nullptr) {
+        rc = fill_tick(h->host, tterms, &tk);
+        if (rc) return rc;
+    } else if (!h->jit_solve && h->static_k < 0) {
+        return fail(CLIK_EUNSUPPORTED, "clik_qp_solve_batch_t: per-instance time needs a shape-specialised kernel "
+                                       "for the skill (none built in, none attached)");
+    }
     hipError_t e;
     if (h->jit_solve)
         e = h->jit_solve(h->d_img, &tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set, use_hot,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, t_inst);
     else if (h->static_k >= 0)
         e = clik::qp_launch_static(h->static_k, h->d_img, tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set,
-                                   use_hot, (hipStream_t)stream);
+                                   use_hot, (hipStream_t)stream, t_inst);
     else if (h->variant < 0)
         return fail(CLIK_EUNSUPPORTED, "clik_qp_solve_batch: this skill needs a shape-specialised kernel and none "
                                        "is attached (casclik_amd.jit needs hipcc)");
@@ -1201,6 +1233,24 @@ extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double
                                   slack, status, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_solve_kernel launch");
     return CLIK_OK;
+}
+
+extern "C" int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms, const double* q,
+                                       const double* x, const double* y, double* dq, double* dx, double* slack,
+                                       int32_t* status, int32_t* hot_set, int32_t use_hot, void* stream)
+{
+    return qp_solve_common(h, B, tterms, nullptr, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream);
+}
+
+extern "C" int clik_qp_solve_batch_t(const clik_qp* h, int64_t B, const double* t_inst, const double* q,
+                                     const double* x, const double* y, double* dq, double* dx, double* slack,
+                                     int32_t* status, int32_t* hot_set, int32_t use_hot, void* stream)
+{
+    if (h && h->host.d.n_tslots > 0 && !t_inst)
+        return fail(CLIK_EINVAL, "clik_qp_solve_batch_t: t_inst (device, [B][2 * n_tslots]) required");
+    if (h && h->host.d.n_tslots == 0)
+        return qp_solve_common(h, B, nullptr, nullptr, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream);
+    return qp_solve_common(h, B, nullptr, t_inst, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream);
 }
 
 extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tterms, const double* q,

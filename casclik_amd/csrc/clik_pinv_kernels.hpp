@@ -798,11 +798,14 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 // body of the lane-per-instance kernel.  REGIMG: keep a register copy of the skill image (one LDS read burst and
 // one wait instead of ~40 separate ~100-cycle LDS stalls: what a lone wave per SIMD wants) or read it from LDS
 // where it is used (fewer live registers: what two waves per SIMD want)
-template <const ShapeDesc& SD, bool REGIMG>
+// PT: every instance has its own time-slot record (t_inst [B][2 * n_tslots], device): a batch of robots at
+// different phases of their trajectories in one launch.  The record is read in place, per lane, where the
+// rows use it (the uniform record of the other kernels sits in SGPRs).
+template <const ShapeDesc& SD, bool REGIMG, bool PT = false>
 __device__ __forceinline__ void pinv_solve_static_body(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const double* __restrict__ x,
-    double* __restrict__ dx, const TickArgs& tk)
+    double* __restrict__ dx, const TickArgs& tk_uniform, const double* __restrict__ t_inst = nullptr)
 {
     extern __shared__ double lds[];
     CLIK_STAMP(0);
@@ -853,6 +856,9 @@ __device__ __forceinline__ void pinv_solve_static_body(
     state_from_lds<NQ, NX>(zs, xs, lane, z);
     double vout[N];
     int acc_mode;
+    const TickArgs& tk = PT ? *reinterpret_cast<const TickArgs*>(
+                                  t_inst + (size_t)(b0 + (valid ? lane : rows_valid - 1)) * 2 * S->n_tslots)
+                            : tk_uniform;
     // Register copy of the skill image: scalar replacement keeps exactly the fields the tick
     // reads, and the scheduling barrier keeps their LDS reads together here (one wait) instead
     // of next to each use (measured: ~40 separate ~100-cycle LDS stalls per tick otherwise).
@@ -885,6 +891,17 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_kernel(
 #else
     pinv_solve_static_body<SD, true>(img_g, q, y, dq, mode_out, B, x, dx, tk);
 #endif
+}
+
+// ... with one time-slot record per instance (clik_pinv_solve_batch_t)
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_pt_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B, const double* __restrict__ x,
+    double* __restrict__ dx, const double* __restrict__ t_inst)
+{
+    TickArgs none;      // (never read)
+    pinv_solve_static_body<SD, true, true>(img_g, q, y, dq, mode_out, B, x, dx, none, t_inst);
 }
 
 // Large-batch variant (>= kOcc2MinBatch instances: every SIMD has work queued): capped at 256 registers so that
@@ -1169,18 +1186,26 @@ __global__ __launch_bounds__(SplitLayout<SD>::NW * WAVE) void pinv_solve_static_
     CLIK_STAMP_W(0, 5);
 }
 
-template <const ShapeDesc& SD>
-__global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
+// (one wave per SIMD, stated: the register copy of the skill image lives across the tick loop, and without the
+// statement the allocator parks a few of its values in scratch although the wave could use all 512 registers)
+#ifndef CLIK_ROLL_ATTR
+#define CLIK_ROLL_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
+#endif
+// RK: classical Runge-Kutta (four controller evaluations per tick) instead of explicit Euler.  Two
+// instantiations, because the Runge-Kutta bookkeeping (start state and weighted sum of the stage velocities, kept
+// in LDS) would otherwise sit in the Euler loop's registers and push the widest stacks into scratch.
+template <const ShapeDesc& SD, bool RK>
+__global__ __launch_bounds__(WAVE) CLIK_ROLL_ATTR void pinv_rollout_static_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B,
     const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed,
-    double* __restrict__ x, double* __restrict__ dx, const int stages)
+    double* __restrict__ x, double* __restrict__ dx)
 {
     // x / dx: virtual variables (path parameters, cart_on_track_1D...ipynb cells 56-60): integrated like the
     // robot variables, never clamped; unused (null) in skills without them.
-    // stages: 1 = explicit Euler (the notebooks' loop), 4 = classical Runge-Kutta with the controller as the
-    // right-hand side (integration_methods.py:17-23): k1..k4 at t, t + dt/2, t + dt/2, t + dt, each stage clamped;
-    // tterms then holds four time-slot records per tick.
+    // Euler: the notebooks' loop.  Runge-Kutta: the controller as the right-hand side
+    // (integration_methods.py:17-23): k1..k4 at t, t + dt/2, t + dt/2, t + dt, each stage clamped; tterms then
+    // holds four time-slot records per tick.
     extern __shared__ double lds[];
     constexpr int N = SD.n;
     constexpr int NX = SD.n_x, NQ = N - NX;
@@ -1212,41 +1237,59 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_static_kernel(
     int acc_mode = -1;
 #pragma unroll
     for (int j = 0; j < N; ++j) vout[j] = 0.0;
+    if constexpr (!RK) {
 #pragma unroll 1
-    for (int tick = 0; tick < n_ticks; ++tick) {
-        double z0[N], ks[N];
-        int mode0 = -1;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            z0[j] = z[j];
-            ks[j] = 0.0;
-        }
-#pragma unroll 1
-        for (int st = 0; st < stages; ++st) {
+        for (int tick = 0; tick < n_ticks; ++tick) {
             // the skill image is loop invariant: without this fence its LDS reads are all hoisted out of the
             // tick loop and the live constants spill (2.8 KB of scratch per lane)
             asm volatile("" ::: "memory");
-            // time terms are read in place ([values | derivatives], 2*nts doubles per stage, never past them)
-            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + st) * 2 * nts);
+            // time terms are read in place ([values | derivatives], 2*nts doubles per tick, never past them)
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
             pinv_tick_static<SD>(&Sreg, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
-            const double wgt = (stages == 1) ? 1.0 : ((st == 0 || st == 3) ? 1.0 : 2.0);
-            const double cnext = (st == 2) ? dt : 0.5 * dt;          // offset of the next stage's state
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 double d = vout[j];
                 if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
-                ks[j] = fma(wgt, d, ks[j]);
-                z[j] = fma(d, cnext, z0[j]);
+                vout[j] = d;
+                z[j] = fma(d, dt, z[j]);
             }
-            mode0 = (st == 0) ? acc_mode : mode0;
         }
-        const double scale = (stages == 1) ? 1.0 : 1.0 / 6.0;
+    } else {
+        double* z0s = ys + SD.n_y * WAVE;       // [N][64] state at the start of the tick, then [N][64] sum of w_i k_i
+        double* kss = z0s + N * WAVE;
+#pragma unroll 1
+        for (int tick = 0; tick < n_ticks; ++tick) {
+            int mode0 = -1;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            vout[j] = ks[j] * scale;
-            z[j] = fma(vout[j], dt, z0[j]);
+            for (int j = 0; j < N; ++j) {
+                z0s[j * WAVE + lane] = z[j];
+                kss[j * WAVE + lane] = 0.0;
+            }
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                asm volatile("" ::: "memory");
+                const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * 4 + st) * 2 * nts);
+                // (the image is read from LDS in place: with the register copy of the Euler loop the widest stacks
+                // spill here)
+                pinv_tick_static<SD>(S, tk, z, ys + lane * SD.n_y, lane, valid, vout, acc_mode);
+                const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
+                const double cnext = (st == 2) ? dt : 0.5 * dt;          // offset of the next stage's state
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double d = vout[j];
+                    if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                    kss[j * WAVE + lane] = fma(wgt, d, kss[j * WAVE + lane]);
+                    z[j] = fma(d, cnext, z0s[j * WAVE + lane]);
+                }
+                mode0 = (st == 0) ? acc_mode : mode0;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                vout[j] = kss[j * WAVE + lane] * (1.0 / 6.0);
+                z[j] = fma(vout[j], dt, z0s[j * WAVE + lane]);
+            }
+            acc_mode = mode0;       // (the mode of the first stage)
         }
-        acc_mode = mode0;       // (Runge-Kutta: the mode of the first stage)
     }
     __syncthreads();
     state_to_lds<NQ, NX>(z, zs, xs, lane);
@@ -1276,6 +1319,7 @@ struct LaunchArgs {
     double* roll_x;            // rollout of a skill with virtual variables: their state (in/out) and last rates
     double* roll_dx;
     int roll_stages;           // rollout: controller evaluations per tick (0 / 1 explicit Euler, 4 Runge-Kutta)
+    const double* t_inst;      // solve: one time-slot record per instance ([B][2 * n_tslots], device) or null
 };
 typedef hipError_t (*solve_fn)(const LaunchArgs&, const TickArgs&, long long, const double*, const double*,
                                const double*, double*, double*, int32_t*, hipStream_t);
@@ -1287,6 +1331,7 @@ inline hipError_t launch_solve(const LaunchArgs& a, const TickArgs& tk, long lon
                                const double* x, const double* y, double* dq, double* dx, int32_t* mode,
                                hipStream_t stream)
 {
+    if (a.t_inst != nullptr) return hipErrorNotSupported;   // (per-instance time: shape-specialised kernels only)
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     const size_t shmem = (size_t)pinv_lds_slots(N, a.ny) * WAVE * sizeof(double);
     hipLaunchKernelGGL((pinv_solve_kernel<N, SH>), dim3(grid), dim3(WAVE), shmem, stream, a.dS, *a.warm, tk, B, q,
@@ -1348,6 +1393,11 @@ inline hipError_t launch_solve_static(const LaunchArgs& a, const TickArgs& tk, l
                                       hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if (a.t_inst != nullptr) {
+        hipLaunchKernelGGL((pinv_solve_static_pt_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
+                           a.dImg, q, y, dq, mode, B, x, dx, a.t_inst);
+        return hipGetLastError();
+    }
     if constexpr (shape_team_ok(SD)) {
         // four lanes per instance, a block of four waves = 64 instances (same grid)
         if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch)) {
@@ -1434,9 +1484,19 @@ inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tte
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((pinv_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
-                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx,
-                       a.roll_stages == 4 ? 4 : 1);
+    if (a.roll_stages == 4) {
+        const size_t shmem = static_lds_bytes<SD>(a.ny) + (size_t)2 * SD.n * WAVE * sizeof(double);
+        if (shmem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)pinv_rollout_static_kernel<SD, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((pinv_rollout_static_kernel<SD, true>), dim3(grid), dim3(WAVE), shmem, stream,
+                           a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((pinv_rollout_static_kernel<SD, false>), dim3(grid), dim3(WAVE), static_lds_bytes<SD>(a.ny), stream,
+                       a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed, a.roll_x, a.roll_dx);
     return hipGetLastError();
 }
 

@@ -416,10 +416,11 @@ int qp_pick_static(const ShapeDesc& sd)
 const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
-                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream)
+                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,
+                            const double* t_inst)
 {
     if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
-    return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream);
+    return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream, t_inst);
 }
 
 hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,

@@ -1084,12 +1084,13 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
     }   // (dual active-set path)
 }
 
-template <const ShapeDesc& SD>
-__global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
+// PT: one time-slot record per instance (t_inst [B][2 * n_tslots], device; see pinv_solve_static_body)
+template <const ShapeDesc& SD, bool PT>
+__device__ __forceinline__ void qp_solve_static_body(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
     const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
-    const TickArgs tk)
+    const TickArgs& tk_uniform, const double* __restrict__ t_inst)
 {
     extern __shared__ double lds[];
     using LY = QpLayout<SD>;
@@ -1137,6 +1138,9 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     __builtin_amdgcn_sched_barrier(0);
 
     double v[N], sl[LY::NSA];
+    const TickArgs& tk = PT ? *reinterpret_cast<const TickArgs*>(
+                                  t_inst + (size_t)(b0 + (valid ? lane : rows_valid - 1)) * 2 * Sreg.n_tslots)
+                            : tk_uniform;
     const int status = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl,
                                           hot_set != nullptr ? hot_set + (b0 + lane) : nullptr, use_hot != 0);
     const double bad = (status == 2) ? __builtin_nan("") : 0.0;
@@ -1161,6 +1165,27 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
         if (slack_out != nullptr) rows_from_lds<NS>(slack_out + b0 * NS, rows_valid, slots + LY::O_SL * WAVE, lane);
     }
     if (status_out != nullptr && valid) status_out[b0 + lane] = status;
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    qp_solve_static_body<SD, false>(img_g, q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk, nullptr);
+}
+
+template <const ShapeDesc& SD>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_pt_kernel(
+    const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const double* __restrict__ t_inst)
+{
+    TickArgs none;      // (never read)
+    qp_solve_static_body<SD, true>(img_g, q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, none, t_inst);
 }
 
 // n_ticks of (QP tick -> clamp(+-max_speed) -> explicit Euler q += dq dt) in one launch: the host
@@ -1288,13 +1313,16 @@ inline hipError_t launch_qp_rollout_static(const void* d_img, const double* d_tt
     }
 }
 
+// t_inst: null (tk serves the whole batch) or one time-slot record per instance ([B][2 * n_tslots], device)
 typedef hipError_t (*qp_static_fn)(const void*, const TickArgs&, long long, const double*, const double*,
-                                   const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
+                                   const double*, double*, double*, double*, int32_t*, int32_t*, int, hipStream_t,
+                                   const double*);
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long long B, const double* q,
                                    const double* x, const double* y, double* dq, double* dx, double* slack,
-                                   int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream)
+                                   int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,
+                                   const double* t_inst = nullptr)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
@@ -1303,6 +1331,16 @@ inline hipError_t launch_qp_static(const void* d_img, const TickArgs& tk, long l
         hipError_t e = hipFuncSetAttribute((const void*)qp_solve_static_kernel<SD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
+    }
+    if (t_inst != nullptr) {
+        if (shmem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)qp_solve_static_pt_kernel<SD>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((qp_solve_static_pt_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq,
+                           slack, status, B, x, dx, hot_set, use_hot, t_inst);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL((qp_solve_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
                        status, B, x, dx, hot_set, use_hot, tk);

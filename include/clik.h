@@ -222,6 +222,14 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
 int clik_pinv_solve_batch(const clik_pinv* h, int64_t B, const double* tterms,
                           const double* q, const double* x, const double* y,
                           double* dq, double* dx, int32_t* mode, void* stream);
+/* The same with one time per instance (`t` of 1 or B values): a batch of robots at different
+ * phases of their trajectories in one launch.  t_inst is a DEVICE array [B][2 * n_tslots] - row b holds what
+ * `tterms` holds, evaluated at instance b's time.  Needs a shape-specialised kernel for the skill
+ * (CLIK_EUNSUPPORTED otherwise: group the instances by time and call clik_pinv_solve_batch per group, as
+ * casclik_amd's controllers do).  A skill without time slots ignores t_inst.                               */
+int clik_pinv_solve_batch_t(const clik_pinv* h, int64_t B, const double* t_inst,
+                            const double* q, const double* x, const double* y,
+                            double* dq, double* dx, int32_t* mode, void* stream);
 
 /* "next" row: n_ticks of solve -> clamp(+-max_speed) ->
  * explicit Euler q += dq*dt inside one launch, the loop every notebook runs
@@ -289,6 +297,11 @@ int clik_qp_solve_batch_hot(const clik_qp* h, int64_t B, const double* tterms,
                             const double* q, const double* x, const double* y,
                             double* dq, double* dx, double* slack, int32_t* status,
                             int32_t* hot_set, int32_t use_hot, void* stream);
+/* ... with one time per instance: t_inst as for clik_pinv_solve_batch_t (hot_set may be NULL).              */
+int clik_qp_solve_batch_t(const clik_qp* h, int64_t B, const double* t_inst,
+                          const double* q, const double* x, const double* y,
+                          double* dq, double* dx, double* slack, int32_t* status,
+                          int32_t* hot_set, int32_t use_hot, void* stream);
 
 /* "next" row for the QP controller: n_ticks of solve -> clamp(+-max_speed) ->
  * explicit Euler q += dq*dt inside one launch, the working set hot-started from tick to tick.

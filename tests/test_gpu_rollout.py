@@ -106,10 +106,17 @@ def test_rollouts_on_two_streams_do_not_share_state(ur5_fk):
         assert np.array_equal(qa.cpu().numpy(), ref_a) and np.array_equal(qb.cpu().numpy(), ref_b)
 
 
-def test_per_instance_time_stamps(ur5_fk):
-    """time_var with one entry per instance: grouped by distinct time stamps, one launch each; equals the
-    per-time-stamp calls"""
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_per_instance_time_stamps(ur5_fk, monkeypatch, dynamic):
+    """time_var with one entry per instance (`t` of 1 or B values): one launch of the
+    per-instance-time kernel (clik_pinv_solve_batch_t), or - a skill on the dynamic fallback kernel - one launch per
+    distinct time stamp; both equal the per-time-stamp calls and the oracle evaluated at each instance's own time"""
+    from oracle import clik_oracle as orc
+    from tolerances import PINV_RTOL
+    if dynamic:
+        monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
     spec, ctrl = _tracking(ur5_fk, 6)
+    assert ("dynamic" in ctrl.kernel_name) == dynamic
     rng = np.random.default_rng(12)
     home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
     Q = home + rng.normal(scale=0.1, size=(97, 6))
@@ -119,9 +126,43 @@ def test_per_instance_time_stamps(ur5_fk):
     for tv in phases:
         rows = times == tv
         ref, _, rmode = ctrl.solve_batch(float(tv), Q[rows])
-        assert np.array_equal(dq[rows], ref) and np.array_equal(mode[rows], rmode)
+        assert np.allclose(dq[rows], ref, rtol=1e-12, atol=1e-14) and np.array_equal(mode[rows], rmode)
+    # every instance at its own time
+    times = rng.uniform(0.0, 30.0, size=97)
+    dq, _, mode = ctrl.solve_batch(times, Q)
+    for b in range(97):
+        rdq, rmode = orc.pinv_solve_batch(spec, None, float(times[b]), Q[b:b + 1])
+        assert mode[b] == rmode[0]
+        assert np.allclose(dq[b], rdq[0], rtol=PINV_RTOL, atol=PINV_RTOL * max(1.0, np.abs(rdq).max()))
     with pytest.raises(ValueError):
         ctrl.solve_batch(times[:5], Q)
+
+
+def test_per_instance_time_stamps_qp(ur5_fk):
+    """the same through the QP controller (clik_qp_solve_batch_t)"""
+    from oracle import clik_oracle as orc
+    from tolerances import QP_RTOL
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = ur5_fk["T_fk"](q)[:3, 3]
+    path = cs.vertcat(0.5 * cs.sin(0.1 * t) * cs.sin(0.1 * t) + 0.2, 0.5 * cs.cos(0.1 * t) + 0.25 * cs.sin(0.1 * t),
+                      0.5 * cs.sin(0.1 * t) * cs.cos(0.1 * t) + 0.1)
+    spec = cc.SkillSpecification("track_qp", t, q, constraints=[
+        cc.EqualityConstraint("move_point", p - path, gain=0.5, constraint_type="soft"),
+        cc.VelocitySetConstraint("speed", q, set_min=-0.4 * np.ones(6), set_max=0.4 * np.ones(6))])
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    rng = np.random.default_rng(13)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.1, size=(70, 6))
+    times = rng.uniform(0.0, 30.0, size=70)
+    dq, _, sl, status = ctrl.solve_batch(times, Q)
+    assert (status == 0).all()
+    for b in range(0, 70, 3):
+        rdq = orc.qp_solve_batch(spec, float(times[b]), Q[b:b + 1])[0]
+        assert np.allclose(dq[b], rdq[0], rtol=QP_RTOL, atol=QP_RTOL * max(1.0, np.abs(rdq).max()))
+    one = ctrl.solve_batch(float(times[7]), Q[7:8])[0]
+    assert np.allclose(dq[7], one[0], rtol=1e-12, atol=1e-14)
 
 
 def test_output_tensors_are_validated(iiwa_fk):
