@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libclik_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ClikLibraryError(RuntimeError):
@@ -46,6 +46,7 @@ class clik_row(C.Structure):
 class clik_task(C.Structure):
     _fields_ = [("cls", C.c_int32), ("m", C.c_int32), ("soft", C.c_int32),
                 ("gain_is_matrix", C.c_int32),
+                ("attr_ext", C.c_int32),
                 ("out_kind", C.c_int32 * L.MAX_M),
                 ("out_row0", C.c_int32 * L.MAX_M),
                 ("out_nrows", C.c_int32 * L.MAX_M),
@@ -108,6 +109,7 @@ def desc_to_c(d):
         ct = out.tasks[k]
         ct.cls, ct.m, ct.soft = int(t["cls"]), int(t["m"]), int(t["soft"])
         ct.gain_is_matrix = int(t["gain_is_matrix"])
+        ct.attr_ext = int(t.get("attr_ext", 0))
         for i in range(L.MAX_M):
             ct.out_kind[i] = int(t["out_kind"][i])
             ct.out_row0[i] = int(t["out_row0"][i])

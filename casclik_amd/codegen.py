@@ -156,6 +156,27 @@ class TaskEmitter(object):
             raise NotImplementedError("no device code for operation '%s'" % op)
         return self._temp((op,) + tuple(args), expr)
 
+    # -- attributes given as expressions ---------------------------------------
+    def emit_attr(self, ti, nodes):
+        """C++ source of ``template <> struct ExternAttr<ti>``: ``nodes`` are the Scalar nodes of the task's
+        attribute slice in its layout order (clik_pinv_static.hpp: [gain | set_min | set_max | target], present
+        parts only).  Values only - the reference never differentiates a gain or a bound
+        (casclik/constraints.py:67-73 takes the Jacobian of ``expression``)."""
+        n = self.low.desc.n_state
+        out = ["a[%d] = %s;" % (k, self.ref(node)) for k, node in enumerate(nodes)]
+        body = "\n        ".join(self.lines + out)
+        return ("template <>\n"
+                "struct ExternAttr<%d> {\n"
+                "    template <int N>\n"
+                "    __device__ __forceinline__ static void eval(const double (&z)[N], const double* ys, const double* tv,\n"
+                "                                                const Kin<N>& K, double* a)\n"
+                "    {\n"
+                "        static_assert(N == %d, \"generated for another skill structure\");\n"
+                "        (void)z; (void)ys; (void)tv; (void)K;\n"
+                "        %s\n"
+                "    }\n"
+                "};\n" % (ti, n, body))
+
     # -- one constraint -------------------------------------------------------
     def emit_task(self, ti, nodes):
         """C++ source of ``template <> struct ExternTask<ti>`` for the column

@@ -278,15 +278,15 @@ class ReactiveQPController(BaseController):
 
             def gained(v, g=cn.gain):
                 if isinstance(g, cs.MX):
-                    g = cs.evaluate(g, {})
+                    g = cs.evaluate(g, env)       # (an expression of (t, q, y): at the initial state)
                 if isinstance(g, cs.DM):
                     g = g.toarray()
                 g = np.asarray(g, dtype=float)
-                return float(g) * v if g.size == 1 else g.reshape(m, m).dot(v)
+                return float(g.reshape(-1)[0]) * v if g.size == 1 else g.reshape(m, m).dot(v)
 
             def vec(val):
                 if isinstance(val, cs.MX):
-                    val = cs.evaluate(val, {})
+                    val = cs.evaluate(val, env)
                 a = np.asarray(val.toarray() if isinstance(val, cs.DM) else val, dtype=float).reshape(-1)
                 return np.full(m, a[0]) if a.size == 1 and m > 1 else a
 

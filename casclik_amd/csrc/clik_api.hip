@@ -197,6 +197,11 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
     for (int ti = 0; ti < d->n_tasks; ++ti) {
         const clik_task& t = d->tasks[ti];
         if (t.cls < CLIK_CLS_EQ || t.cls > CLIK_CLS_VELSET) return fail(CLIK_EINVAL, "task %d: bad class", ti);
+        if (t.attr_ext & ~(CLIK_ATTR_GAIN | CLIK_ATTR_SET_MIN | CLIK_ATTR_SET_MAX | CLIK_ATTR_TARGET))
+            return fail(CLIK_EINVAL, "task %d: bad attr_ext", ti);
+        if (t.attr_ext != 0 && ti >= clik::SHAPE_MAX_TASKS)
+            return fail(CLIK_EUNSUPPORTED, "task %d: attributes given as expressions need a shape-specialised kernel "
+                                           "(at most %d constraints)", ti, clik::SHAPE_MAX_TASKS);
         if (t.m < 1 || t.m > CLIK_MAX_M)
             return fail(CLIK_EUNSUPPORTED, "task %d: %d rows (limit %d)", ti, t.m, CLIK_MAX_M);
         for (int i = 0; i < t.m; ++i) {
@@ -254,7 +259,7 @@ static int validate_and_derive(const clik_skill_desc* d, DevSkill* S)
             S->shape.flags[ti] = fl & ~CLIK_ROW_HAS_T;
             S->shape.const_j[ti] = S->task_const_j[ti];
             S->shape.gain_matrix[ti] = t.gain_is_matrix ? 1 : 0;
-            S->shape.ext[ti] = (t.out_kind[0] == CLIK_OUT_EXTERN) ? 1 : 0;
+            S->shape.ext[ti] = ((t.out_kind[0] == CLIK_OUT_EXTERN) ? 1 : 0) | ((t.attr_ext & 15) << 1);
             int nyt = 0;
             for (int i = 0; i < t.m; ++i) {
                 const int nrw = (t.out_kind[i] == CLIK_OUT_NORM2) ? t.out_nrows[i] : 1;
@@ -530,7 +535,7 @@ static bool build_qp_image(const DevSkill& S, std::vector<char>& out)
 static bool skill_has_extern(const DevSkill& S)
 {
     for (int ti = 0; ti < S.d.n_tasks; ++ti)
-        if (S.d.tasks[ti].out_kind[0] == CLIK_OUT_EXTERN) return true;
+        if (S.d.tasks[ti].out_kind[0] == CLIK_OUT_EXTERN || S.d.tasks[ti].attr_ext != 0) return true;
     return false;
 }
 // ... and so do constraints with more rows than the built-in kernels are wide (CLIK_DYN_MAX_M)
@@ -543,7 +548,7 @@ static bool skill_has_wide_task(const DevSkill& S)
 static bool skill_needs_static(const DevSkill& S) { return skill_has_extern(S) || skill_has_wide_task(S); }
 static int extern_needs_kernel(const char* what)
 {
-    return fail(CLIK_EUNSUPPORTED, "%s: the skill has code-generated constraint rows or a constraint with more "
+    return fail(CLIK_EUNSUPPORTED, "%s: the skill has code-generated constraint rows / attributes or a constraint with more "
                                    "than %d rows, and no kernel instantiated for it is attached "
                                    "(casclik_amd.jit needs hipcc)", what, CLIK_DYN_MAX_M);
 }

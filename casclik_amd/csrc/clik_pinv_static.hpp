@@ -551,6 +551,45 @@ struct ExternTask {
     }
 };
 
+// Constraint ATTRIBUTES given as expressions - a gain, set bounds or a velocity target that depend on
+// (t, q, virtual, input): the reference multiplies / subtracts them symbolically (constraints.py:35-39, :90-92,
+// pseudo_inverse.py:301-318, reactive_qp.py:199-232) and never differentiates them.  ShapeDesc::ext[ti] bits 1..4
+// (CLIK_ATTR_* << 1) say which; the generated ExternAttr<TI>::eval writes their per-instance values into the
+// task's slice of TaskCache::attr, laid out [gain (1 or m*m) | set_min (m) | set_max (m) | target (m)], present
+// parts only.
+template <int TI>
+struct ExternAttr {
+    template <int N>
+    __device__ static void eval(const double (&)[N], const double*, const double*, const Kin<N>&, double*)
+    {
+        static_assert(TI < 0, "ShapeDesc::ext has attribute bits for a task without generated code");
+    }
+};
+constexpr int shape_attr_bits(const ShapeDesc& sd, int ti) { return (sd.ext[ti] >> 1) & 15; }
+constexpr int shape_attr_gain_size(const ShapeDesc& sd, int ti) { return sd.gain_matrix[ti] != 0 ? sd.m[ti] * sd.m[ti] : 1; }
+// offset of part `bit` (CLIK_ATTR_*) inside the task's slice; its size with bit = 16
+constexpr int shape_attr_off(const ShapeDesc& sd, int ti, int bit)
+{
+    const int b = shape_attr_bits(sd, ti);
+    int o = 0;
+    if (bit == CLIK_ATTR_GAIN) return o;
+    if (b & CLIK_ATTR_GAIN) o += shape_attr_gain_size(sd, ti);
+    if (bit == CLIK_ATTR_SET_MIN) return o;
+    if (b & CLIK_ATTR_SET_MIN) o += sd.m[ti];
+    if (bit == CLIK_ATTR_SET_MAX) return o;
+    if (b & CLIK_ATTR_SET_MAX) o += sd.m[ti];
+    if (bit == CLIK_ATTR_TARGET) return o;
+    if (b & CLIK_ATTR_TARGET) o += sd.m[ti];
+    return o;
+}
+constexpr int shape_attr_base(const ShapeDesc& sd, int ti)
+{
+    int r = 0;
+    for (int i = 0; i < ti; ++i) r += shape_attr_off(sd, i, 16);
+    return r;
+}
+constexpr int shape_attr_total(const ShapeDesc& sd) { return shape_attr_base(sd, sd.n_tasks); }
+
 // e, J, d e/d t of task TI: rows are contiguous and all affine in static shapes
 template <const ShapeDesc& SD, int TI>
 __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const TickArgs& tk,
@@ -560,7 +599,7 @@ __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const
 {
     constexpr int N = SD.n;
     constexpr int M = SD.m[TI];
-    if constexpr (SD.ext[TI] != 0) {
+    if constexpr ((SD.ext[TI] & 1) != 0) {
         ExternTask<TI>::template eval<N, M>(z, ys, tk.tv, K, e, J, Jt);
         return;
     }
@@ -604,8 +643,8 @@ __device__ __forceinline__ void task_eval_s(const Img<SD>* __restrict__ S, const
     });
 }
 
-template <int M, bool MATRIX>
-__device__ __forceinline__ void gain_apply_s(const clik_task& t, const double (&v)[M], double (&out)[M])
+template <int M, bool MATRIX, class TASK>
+__device__ __forceinline__ void gain_apply_s(const TASK& t, const double (&v)[M], double (&out)[M])
 {
     if constexpr (!MATRIX) {
         const double g = t.gain[0];
@@ -623,8 +662,8 @@ __device__ __forceinline__ void gain_apply_s(const clik_task& t, const double (&
 }
 
 // in-tangent-cone test with compile-time row count (pseudo_inverse.py:162-185, :222-252)
-template <int N, int M>
-__device__ __forceinline__ bool in_tangent_cone_s(const clik_task& t, const double (&e)[M],
+template <int N, int M, class TASK>
+__device__ __forceinline__ bool in_tangent_cone_s(const TASK& t, const double (&e)[M],
                                                   const double (&J)[M][N], const double (&Jt)[M],
                                                   const double (&v)[N])
 {
@@ -687,7 +726,55 @@ struct TaskCache {
     double e[ROWS];
     double Jt[ROWS];
     double J[ROWS][SD.n];
+    // per-instance values of the attributes given as expressions (ExternAttr)
+    static constexpr int NATTR = shape_attr_total(SD) > 0 ? shape_attr_total(SD) : 1;
+    double attr[NATTR];
 };
+
+// the constants of task TI as the tick uses them: the image's task record, or - when some of them are expressions -
+// a small per-lane record with those parts replaced by the values ExternAttr computed for this instance (same member
+// names: the code below is written against either)
+template <const ShapeDesc& SD, int TI>
+struct TaskConstsS {
+    static constexpr int M = SD.m[TI];
+    double gain[shape_attr_gain_size(SD, TI)];
+    double set_min[M], set_max[M], target[M];
+};
+template <const ShapeDesc& SD, int TI>
+__device__ __forceinline__ decltype(auto) task_consts(const Img<SD>* __restrict__ S, const TaskCache<SD>& tc)
+{
+    constexpr int bits = shape_attr_bits(SD, TI);
+    if constexpr (bits == 0) {
+        return (S->tasks[TI]);          // (a reference into the image)
+    } else {
+        constexpr int M = SD.m[TI];
+        constexpr int base = shape_attr_base(SD, TI);
+        constexpr int MG = shape_attr_gain_size(SD, TI);
+        // (the offsets must be constant expressions: evaluated at run time they make every access a dynamically
+        // indexed one, which pins the whole cache in scratch)
+        constexpr int og = base + shape_attr_off(SD, TI, CLIK_ATTR_GAIN);
+        constexpr int olo = base + shape_attr_off(SD, TI, CLIK_ATTR_SET_MIN);
+        constexpr int ohi = base + shape_attr_off(SD, TI, CLIK_ATTR_SET_MAX);
+        constexpr int otg = base + shape_attr_off(SD, TI, CLIK_ATTR_TARGET);
+        const clik_task& ti = S->tasks[TI];
+        TaskConstsS<SD, TI> t;
+        static_for<0, MG>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr ((bits & CLIK_ATTR_GAIN) != 0) t.gain[k] = tc.attr[og + k];
+            else t.gain[k] = ti.gain[k];
+        });
+        static_for<0, M>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr ((bits & CLIK_ATTR_SET_MIN) != 0) t.set_min[k] = tc.attr[olo + k];
+            else t.set_min[k] = ti.set_min[k];
+            if constexpr ((bits & CLIK_ATTR_SET_MAX) != 0) t.set_max[k] = tc.attr[ohi + k];
+            else t.set_max[k] = ti.set_max[k];
+            if constexpr ((bits & CLIK_ATTR_TARGET) != 0) t.target[k] = tc.attr[otg + k];
+            else t.target[k] = ti.target[k];
+        });
+        return t;
+    }
+}
 
 // ALL: also VelocitySetConstraints (the QP controller uses them, the pseudo-inverse one ignores them)
 template <const ShapeDesc& SD, int TI, bool ALL = false>
@@ -696,6 +783,16 @@ __device__ __forceinline__ void cache_task(const Img<SD>* __restrict__ S, const 
                                            TaskCache<SD>& tc)
 {
     if constexpr (TI < SD.n_tasks) {
+        if constexpr (shape_attr_bits(SD, TI) != 0 && (ALL || SD.cls[TI] != CLIK_CLS_VELSET)) {
+            constexpr int ab = shape_attr_base(SD, TI);
+            constexpr int an = shape_attr_off(SD, TI, 16);
+            double a[an];
+            ExternAttr<TI>::template eval<SD.n>(z, ys, tk.tv, K, a);
+            static_for<0, an>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                tc.attr[ab + k] = a[k];
+            });
+        }
         if constexpr (!SD.const_j[TI] && (ALL || SD.cls[TI] != CLIK_CLS_VELSET)) {
             constexpr int N = SD.n;
             constexpr int M = SD.m[TI];
@@ -1104,7 +1201,7 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (!P.skip) {
         CLIK_TASK_IMAGE(S, S_in);
-        const clik_task& t = S->tasks[TI];
+        decltype(auto) t = task_consts<SD, TI>(S, tc);
         double e[M], Jt[M];
         task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
         uint32_t srow = 0xffffffffu;
@@ -1255,7 +1352,7 @@ __device__ __forceinline__ void cone_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
     constexpr TaskPlan P = Plan<SD, ACT>::mode.t[TI];
     if constexpr (P.cone) {
         CLIK_TASK_IMAGE(S, S_in);
-        const clik_task& t = S->tasks[TI];
+        decltype(auto) t = task_consts<SD, TI>(S, tc);
         double e[M], Jt[M], de[M];
         task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
         if constexpr (shape_unit(SD, TI)) {
@@ -1389,7 +1486,7 @@ __device__ __forceinline__ void helper_mode_static(const Img<SD>* __restrict__ S
             constexpr int M = SD.m[TI];
             uint32_t srow = 0xffffffffu;
             if constexpr (P.set_rows) {
-                const clik_task& t = S->tasks[TI];
+                decltype(auto) t = task_consts<SD, TI>(S, tc);
                 double e[M], Jt[M];
                 task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
                 srow = 0u;

@@ -51,6 +51,7 @@ constexpr bool shape_team_ok(const ShapeDesc& sd)
 {
     if (sd.qp || sd.n_tasks != 3 || sd.n_x != 0 || sd.standard || sd.conv_last || !sd.multidim) return false;
     if (sd.cls[0] != CLIK_CLS_SET || sd.cls[1] != CLIK_CLS_EQ || sd.cls[2] != CLIK_CLS_EQ) return false;
+    if ((sd.ext[0] | sd.ext[1] | sd.ext[2]) & ~1) return false;      // (gains / bounds given as expressions)
     // the set covers every state variable exactly once (then  lam I + Jset'Jset = (1+lam) I)
     if (!shape_unit(sd, 0) || sd.m[0] != sd.n || sd.n < 2) return false;
     for (int c = 0; c < sd.n; ++c)

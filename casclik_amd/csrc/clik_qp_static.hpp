@@ -578,8 +578,8 @@ struct QpLayout {
 };
 
 // bounds  lbA, ubA  of the rows of task TI (reactive_qp.py:191-246)
-template <const ShapeDesc& SD, int TI>
-__device__ __forceinline__ void qp_bounds_s(const clik_task& t, const double (&e)[SD.m[TI]],
+template <const ShapeDesc& SD, int TI, class TASK>
+__device__ __forceinline__ void qp_bounds_s(const TASK& t, const double (&e)[SD.m[TI]],
                                             const double (&Jt)[SD.m[TI]], double (&lo)[SD.m[TI]],
                                             double (&hi)[SD.m[TI]])
 {
@@ -626,7 +626,7 @@ __device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const
         constexpr int N = SD.n;
         constexpr int M = SD.m[TI];
         constexpr QpPlanS P = LY::P;
-        const clik_task& t = S->tasks[TI];
+        decltype(auto) t = task_consts<SD, TI>(S, tc);
         double e[M], Jt[M], lo[M], hi[M];
         task_values<SD, TI>(S, tk, tc, z, ys, lane, e, Jt);
         qp_bounds_s<SD, TI>(t, e, Jt, lo, hi);

@@ -44,6 +44,7 @@ MAX_STATIC_TASKS = 8   # SHAPE_MAX_TASKS of csrc/clik_device.hpp
 ROW_HAS_Q, ROW_HAS_P, ROW_HAS_R, ROW_HAS_O, ROW_HAS_Y, ROW_HAS_T = 1, 2, 4, 8, 16, 32
 OUT_AFFINE, OUT_NORM2, OUT_EXTERN = 0, 1, 2
 CLS_EQ, CLS_SET, CLS_VELEQ, CLS_VELSET = 0, 1, 2, 3
+ATTR_GAIN, ATTR_SET_MIN, ATTR_SET_MAX, ATTR_TARGET = 1, 2, 4, 8     # clik_task::attr_ext (include/clik.h)
 
 
 class NotAffine(Exception):
@@ -387,13 +388,24 @@ class _Lowerer(object):
             raise NotImplementedError("skill needs more than %d affine rows" % MAX_ROWS)
         return len(self.desc.rows) - 1
 
-    def _const_vector(self, val, m, what, label):
-        """Numeric m-vector from float / list / ndarray / DM / constant MX."""
+    def _const_vector(self, val, m, what, label, symbolic=None):
+        """Numeric m-vector from float / list / ndarray / DM / constant MX.  An MX that depends on the skill's
+        variables goes to ``symbolic`` (a list that receives its m Scalar nodes; the returned numbers are then
+        placeholders) - or is refused when the caller passes none."""
         if isinstance(val, cs.MX):
             if not val.is_constant():
-                raise NotImplementedError(
-                    "%s of '%s' must be numeric (symbolic bounds/targets are "
-                    "not supported on the device path)" % (what, label))
+                if symbolic is None:
+                    raise NotImplementedError(
+                        "%s of '%s' must be numeric (symbolic bounds/targets are "
+                        "not supported on the device path)" % (what, label))
+                arr = cs._as_array(val)
+                flat = [arr[i, j] for i in range(arr.shape[0]) for j in range(arr.shape[1])]
+                if len(flat) == 1 and m > 1:
+                    flat = flat * m
+                if len(flat) != m:
+                    raise ValueError("%s of '%s' has %d entries, expression has %d" % (what, label, len(flat), m))
+                symbolic.extend(flat)
+                return np.zeros(m)
             val = cs.evaluate(val, {})
         arr = np.asarray(val._v if isinstance(val, cs.DM) else val, dtype=float).reshape(-1)
         if arr.size == 1 and m > 1:
@@ -424,22 +436,37 @@ class _Lowerer(object):
             raise TypeError("unknown constraint class for '%s'" % cnstr.label)
         task = {"cls": cls, "m": m, "label": cnstr.label,
                 "soft": 1 if cnstr.constraint_type == "soft" else 0,
-                "gain_is_matrix": 0, "gain": np.zeros(MAX_M * MAX_M),
+                "gain_is_matrix": 0, "attr_ext": 0, "gain": np.zeros(MAX_M * MAX_M),
                 "out_kind": [0] * MAX_M, "out_row0": [0] * MAX_M,
                 "out_nrows": [0] * MAX_M,
                 "set_min": np.zeros(MAX_M), "set_max": np.zeros(MAX_M),
                 "target": np.zeros(MAX_M),
                 "slack_weight": float(cnstr.slack_weight)}
         # gain: float | square ndarray/DM | constant MX  (constraints.py:32-65)
+        # An attribute that is an expression of (t, q, virtual, input) - the reference allows MX gains and bounds
+        # (constraints.py:35-39, :90-92, :199-206) - becomes generated code (codegen.emit_attr): attr_nodes
+        # collects its Scalar nodes in the layout [gain | set_min | set_max | target]
+        attr_nodes = []
         g = cnstr.gain
         if isinstance(g, cs.MX):
             if not g.is_constant():
-                raise NotImplementedError(
-                    "symbolic gain in '%s' is not supported" % cnstr.label)
-            g = cs.evaluate(g, {})
+                ga = cs._as_array(g)
+                if ga.shape == (1, 1):
+                    attr_nodes.append(ga[0, 0])
+                elif ga.shape == (m, m):
+                    task["gain_is_matrix"] = 1
+                    attr_nodes.extend(ga[i, j] for i in range(m) for j in range(m))
+                else:
+                    raise ValueError("gain shape %s does not fit '%s'" % (ga.shape, cnstr.label))
+                task["attr_ext"] |= ATTR_GAIN
+                g = 0.0
+            else:
+                g = cs.evaluate(g, {})
         if isinstance(g, cs.DM):
             g = g.toarray()
-        if isinstance(g, (float, int)):
+        if task["attr_ext"] & ATTR_GAIN:
+            pass
+        elif isinstance(g, (float, int)):
             task["gain"][0] = float(g)
         else:
             g = np.asarray(g, dtype=float)
@@ -457,11 +484,19 @@ class _Lowerer(object):
         if cls in (CLS_SET, CLS_VELSET):
             # an infinite bound (set_max=cs.inf, double_pendulum_2D...ipynb cell 10) becomes the value the
             # reference itself uses for "no bound" (constraints.py:199-206): the device arithmetic stays finite
-            for key, val in (("set_min", cnstr.set_min), ("set_max", cnstr.set_max)):
-                v = self._const_vector(val, m, key, cnstr.label)
+            for key, val, bit in (("set_min", cnstr.set_min, ATTR_SET_MIN), ("set_max", cnstr.set_max, ATTR_SET_MAX)):
+                sym = []
+                v = self._const_vector(val, m, key, cnstr.label, sym)
                 task[key][:m] = np.where(np.isinf(v), np.sign(v) * 1e10, v)
+                if sym:
+                    task["attr_ext"] |= bit
+                    attr_nodes.extend(sym)
         if cls == CLS_VELEQ:
-            task["target"][:m] = self._const_vector(cnstr.target, m, "target", cnstr.label)
+            sym = []
+            task["target"][:m] = self._const_vector(cnstr.target, m, "target", cnstr.label, sym)
+            if sym:
+                task["attr_ext"] |= ATTR_TARGET
+                attr_nodes.extend(sym)
         arr = cs._as_array(expr)
         memo = {}
         mark = (len(self.desc.rows), len(self.desc.tslots))
@@ -489,7 +524,26 @@ class _Lowerer(object):
             # outside the row table: the whole constraint becomes generated code (codegen.py)
             self._rollback(mark)
             self._lower_extern(task, [arr[i, 0] for i in range(m)], cnstr.label)
+        if attr_nodes:
+            self._lower_attr(task, attr_nodes, cnstr.label)
         return task
+
+    def _lower_attr(self, task, nodes, label):
+        from . import codegen
+        ti = len(self.desc.tasks)
+        if ti >= MAX_STATIC_TASKS:
+            raise NotImplementedError(
+                "constraint '%s' has a gain / bound given as an expression: generated device code, which only the "
+                "shape-specialised kernels carry (at most %d constraints)" % (label, MAX_STATIC_TASKS))
+        em = codegen.TaskEmitter(self)
+        try:
+            code = em.emit_attr(ti, nodes)
+        except NotImplementedError as why:
+            raise NotImplementedError("constraint '%s' (gain / bounds): %s" % (label, why))
+        self.desc.extern_code[ti] = self.desc.extern_code.get(ti, "") + code
+        self._extern_keep = getattr(self, "_extern_keep", []) + [em]
+        if em.uses_fk:
+            self.desc.uses_fk = True
 
     def _rollback(self, mark):
         n_rows, n_ts = mark

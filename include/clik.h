@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CLIK_ABI_VERSION 2
+#define CLIK_ABI_VERSION 3
 
 #define CLIK_MAX_DOF      8   /* n_state = n_robot_var + n_virtual_var            */
 #define CLIK_MAX_JOINTS  12   /* chain joints, fixed ones included                */
@@ -120,11 +120,19 @@ typedef struct clik_row {
 #define CLIK_CLS_VELEQ  2
 #define CLIK_CLS_VELSET 3
 
+#define CLIK_ATTR_GAIN     1
+#define CLIK_ATTR_SET_MIN  2
+#define CLIK_ATTR_SET_MAX  4
+#define CLIK_ATTR_TARGET   8
+
 typedef struct clik_task {
     int32_t cls;
     int32_t m;                          /* expression rows                        */
     int32_t soft;                       /* constraint_type == "soft"              */
     int32_t gain_is_matrix;             /* 0: scalar gain[0]; 1: m x m row-major  */
+    int32_t attr_ext;                   /* CLIK_ATTR_* bits: attributes given as expressions of (t, q, x, y)
+                                         * (constraints.py:35-39 allows MX gains and bounds); their values
+                                         * come from code generated for the skill, per instance and tick   */
     int32_t out_kind[CLIK_MAX_M];
     int32_t out_row0[CLIK_MAX_M];
     int32_t out_nrows[CLIK_MAX_M];

@@ -261,6 +261,51 @@ class ExprEvaluator(object):
 # ==========================================================================
 # helpers
 # ==========================================================================
+class _Attrs(object):
+    """The attributes of one constraint as numbers for one instance: the reference multiplies / subtracts
+    ``cnstr.gain``, ``set_min``, ``set_max``, ``target`` inside its symbolic expressions, so an MX attribute that
+    depends on (t, q, x, y) is simply evaluated with the rest (constraints.py:35-39, :90-92;
+    pseudo_inverse.py:301-318; reactive_qp.py:199-232)."""
+    __slots__ = ("gain", "set_min", "set_max", "target")
+
+
+def _is_symbolic(val):
+    return hasattr(val, "_a") and hasattr(val, "is_constant") and not val.is_constant()
+
+
+def _attr_values(evaluator, val):
+    """[B, rows, cols] values of an MX attribute"""
+    a = val._a
+    out = np.empty((evaluator.B,) + a.shape)
+    for i in range(a.shape[0]):
+        for j in range(a.shape[1]):
+            out[:, i, j] = evaluator.ev(a[i, j]).v
+    return out
+
+
+def attribute_views(evaluator, constraints):
+    """views[ci][b]: the constraint's attributes as the numbers instance b sees"""
+    views = []
+    for c in constraints:
+        per = {}
+        for name in _Attrs.__slots__:
+            val = getattr(c, name, None)
+            per[name] = _attr_values(evaluator, val) if _is_symbolic(val) else None
+        row = []
+        for b in range(evaluator.B):
+            v = _Attrs()
+            for name in _Attrs.__slots__:
+                if per[name] is None:
+                    setattr(v, name, getattr(c, name, None))
+                else:
+                    x = per[name][b]
+                    setattr(v, name, x if (name == "gain" and x.shape[0] == x.shape[1] and x.shape[0] > 1)
+                            else x.reshape(-1))
+            row.append(v)
+        views.append(row)
+    return views
+
+
 def _cls(cnstr):
     return cnstr.constraint_class
 
@@ -373,6 +418,7 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
     for c in cn:
         e, Jt, Jz = evaluator.vector(c.expression)
         data.append((e, Jt, Jz))
+    views = attribute_views(evaluator, cn)
     n_sets = sum(1 for c in cn if _cls(c) == "SetConstraint")
     amap = activation_map(n_sets)
     n_modes = 2 ** n_sets
@@ -399,32 +445,33 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                 Ji = data[ci][2][b]
                 m = e.shape[0]
                 kind = _cls(c)
+                a = views[ci][b]          # gain / bounds / target as numbers (the constraint's own unless symbolic)
                 is_first = len(Ja) == 0
                 is_last = ci == len(cn) - 1
                 is_set = kind == "SetConstraint"
                 is_eq = kind == "EqualityConstraint"
                 is_veleq = kind == "VelocityEqualityConstraint"
                 if multidim and is_set:
-                    smin = _num(c.set_min, m)
-                    smax = _num(c.set_max, m)
+                    smin = _num(a.set_min, m)
+                    smax = _num(a.set_max, m)
                     S = np.diag(((e - smax > 0.0) | (e - smin < 0.0)).astype(float))
                 # chain 1 (:317-326)
                 if is_first and is_eq:
-                    des = -_gain_apply(c.gain, e)
+                    des = -_gain_apply(a.gain, e)
                     if ff:
                         des = des - Jt
                     v = v + dpinv(Ji, opt).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 # chain 2 (:327-443) - an independent if/elif ladder
                 if is_first and is_veleq:
-                    des = _num(c.target, m).copy()
+                    des = _num(a.target, m).copy()
                     if ff:
                         des = des - Jt
                     v = v + dpinv(Ji, opt).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 elif is_set and is_last and conv_last:
                     if amap[mode_idx][set_idx]:
-                        des = _gain_apply(c.gain, _num(c.set_max, m) - e)
+                        des = _gain_apply(a.gain, _num(a.set_max, m) - e)
                         if ff:
                             des = des - Jt
                         if Ja:
@@ -438,7 +485,7 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                         tc.append(ci)
                     set_idx += 1
                 elif is_eq:
-                    des = -_gain_apply(c.gain, e)
+                    des = -_gain_apply(a.gain, e)
                     if ff:
                         des = des - Jt
                     N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
@@ -452,7 +499,7 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                         tc.append(ci)
                     set_idx += 1
                 elif is_veleq:
-                    des = _num(c.target, m).copy()
+                    des = _num(a.target, m).copy()
                     if ff:
                         des = des - Jt
                     N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
@@ -465,12 +512,12 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
             # their tangent cone (:530-550)
             ok = True
             for ci in tc:
-                c = cn[ci]
+                a = views[ci][b]
                 e = data[ci][0][b]
                 m = e.shape[0]
                 dexpr = data[ci][1][b] + data[ci][2][b].dot(v)
-                smin = _num(c.set_min, m)
-                smax = _num(c.set_max, m)
+                smin = _num(a.set_min, m)
+                smax = _num(a.set_max, m)
                 if m == 1:
                     good = in_tangent_cone_1d(e[0], smin[0], smax[0], dexpr[0])
                 else:
@@ -531,7 +578,8 @@ def qp_data_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
     nv = hd.size
     A_blocks, lb_blocks, ub_blocks = [], [], []
     slack_ind = 0
-    for c in spec.constraints:
+    views = attribute_views(evaluator, spec.constraints)
+    for ci, c in enumerate(spec.constraints):
         e, Jt, Jz = evaluator.vector(c.expression)
         m = e.shape[1]
         blk = np.zeros((B, m, nv))
@@ -539,21 +587,21 @@ def qp_data_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
         lb = -Jt.copy()
         ub = -Jt.copy()
         kind = _cls(c)
+        av = views[ci]            # gain / bounds / target as numbers per instance
         if kind == "EqualityConstraint":
-            ke = np.stack([_gain_apply(c.gain, e[b]) for b in range(B)])
+            ke = np.stack([_gain_apply(av[b].gain, e[b]) for b in range(B)])
             lb -= ke
             ub -= ke
         elif kind == "SetConstraint":
-            smin, smax = _num(c.set_min, m), _num(c.set_max, m)
-            lb += np.stack([_gain_apply(c.gain, smin - e[b]) for b in range(B)])
-            ub += np.stack([_gain_apply(c.gain, smax - e[b]) for b in range(B)])
+            lb += np.stack([_gain_apply(av[b].gain, _num(av[b].set_min, m) - e[b]) for b in range(B)])
+            ub += np.stack([_gain_apply(av[b].gain, _num(av[b].set_max, m) - e[b]) for b in range(B)])
         elif kind == "VelocityEqualityConstraint":
-            tg = _num(c.target, m)
+            tg = np.stack([_num(av[b].target, m) for b in range(B)])
             lb += tg
             ub += tg
         elif kind == "VelocitySetConstraint":
-            lb += _num(c.set_min, m)
-            ub += _num(c.set_max, m)
+            lb += np.stack([_num(av[b].set_min, m) for b in range(B)])
+            ub += np.stack([_num(av[b].set_max, m) for b in range(B)])
         if nslack > 0 and c.constraint_type == "soft":
             for i in range(m):
                 blk[:, i, nq + nvirt + slack_ind + i] = -1.0
@@ -762,17 +810,19 @@ def qp_initial_problem(spec, t0, q0, x0=None, dq0=None, y0=None, weights=None, m
     hd = np.concatenate(([mu * wv] if nvirt > 0 else []) + ([(1.0 + mu) * ws] if nslack > 0 else []))
     A_rows, lbs, ubs = [], [], []
     slack_ind = 0
-    for c in spec.constraints:
-        e, Jt, Jz = evaluator.vector(c.expression)
+    views = attribute_views(evaluator, spec.constraints)
+    for ci, c_sym in enumerate(spec.constraints):
+        e, Jt, Jz = evaluator.vector(c_sym.expression)
         e, Jt, Jz = e[0], Jt[0], Jz[0]
         m = e.size
-        found_virt = nvirt > 0 and cs.depends_on(c.expression, spec.virtual_var)     # structural, as J_virt.nnz()
+        found_virt = nvirt > 0 and cs.depends_on(c_sym.expression, spec.virtual_var)     # structural, as J_virt.nnz()
         blk = np.zeros((m, nvirt + nslack))
         if found_virt:
             blk[:, :nvirt] = Jz[:, nq:nq + nvirt]
         lb = -Jt - Jz[:, :nq].dot(dq0)
         ub = lb.copy()
-        kind = _cls(c)
+        kind = _cls(c_sym)
+        c = views[ci][0]          # gain / bounds / target as numbers
         if kind == "EqualityConstraint":
             ke = _gain_apply(c.gain, e)
             lb, ub = lb - ke, ub - ke
@@ -784,7 +834,7 @@ def qp_initial_problem(spec, t0, q0, x0=None, dq0=None, y0=None, weights=None, m
         elif kind == "VelocitySetConstraint":
             lb, ub = lb + _num(c.set_min, m), ub + _num(c.set_max, m)
         found_slack = False
-        if nslack > 0 and c.constraint_type == "soft":
+        if nslack > 0 and c_sym.constraint_type == "soft":
             for i in range(m):
                 blk[i, nvirt + slack_ind + i] = -1.0
             slack_ind += m

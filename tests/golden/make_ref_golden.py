@@ -144,6 +144,9 @@ PLAN = [   # (fixture name, robot, case, B, input distribution, times)
     ("iiwa_qp_pose", "iiwa", "qp_pose", 64, "interior", [0.0]),
     ("ur5_qp_limits", "ur5", "qp_limits", 64, "mixed", [0.0]),
     ("iiwa_qp_path", "iiwa", "qp_path", 48, "interior", [0.0]),
+    # (appended: the seeds of the entries above follow their position)
+    ("iiwa_sym_attrs", "iiwa", "sym_attrs", 64, "mixed", [0.4, 2.3]),
+    ("ur5_qp_sym_attrs", "ur5", "qp_sym_attrs", 48, "mixed", [1.1]),
 ]
 
 

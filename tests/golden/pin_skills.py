@@ -188,8 +188,63 @@ def qp_path(env):
     return dict(spec=spec, controller="qp", options={}, ny=0, nx=1)
 
 
+def sym_attrs(env):
+    """Gains and set bounds given as EXPRESSIONS of (t, q) - constraints.py:35-39 accepts MX gains, :199-206 MX
+    bounds; the controllers multiply / subtract them inside their symbolic expressions
+    (pseudo_inverse.py:301-318, :162-185): two 1-D limit sets whose bounds breathe with time and whose gain depends
+    on the state, a position task with a time- and state-dependent scalar gain, a centering task with a full
+    (n x n) matrix gain whose diagonal depends on the state"""
+    cs, cc, s = env.cs, env.cc, _syms(env)
+    n = len(env.lower)
+    t, q = s["t"], s["q"]
+    T = env.T_fk(q)
+    p_des = np.asarray(env.consts["p_des"], float) + cs.vertcat(0.05 * cs.sin(t), 0.02 * t, 0.0)
+    mid = 0.5 * (env.lower + env.upper)
+    kp = 4.0 + cs.sin(0.7 * t) + 0.5 * q[1] * q[1]
+    rows = []
+    for i in range(n):
+        rows.append(cs.horzcat(*[(0.5 + 0.25 * cs.cos(q[i]) if j == i else (0.05 if abs(i - j) == 1 else 0.0))
+                                 + 0.0 * q[0] for j in range(n)]))
+    Kc = cs.vertcat(*rows)
+    cns = [cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - p_des, gain=kp,
+                                 constraint_type="soft", priority=10),
+           cc.EqualityConstraint(label="joint_centering", expression=q - mid, gain=Kc,
+                                 constraint_type="soft", priority=20)]
+    for k, j in enumerate((1, 3)):
+        shrink = 0.8 + 0.1 * cs.sin(t + k)
+        cns.append(cc.SetConstraint(label="limit_q%d" % j, expression=q[j], set_min=float(env.lower[j]) * shrink,
+                                    set_max=float(env.upper[j]) * shrink, gain=1.0 + 0.3 * q[0] * q[0], priority=k))
+    spec = cc.SkillSpecification(label="sym_attrs", time_var=t, robot_var=q, robot_vel_var=s["dq"], constraints=cns)
+    return dict(spec=spec, controller="pinv", options={}, ny=0)
+
+
+def qp_sym_attrs(env):
+    """the same kind of attributes through the QP controller (reactive_qp.py:199-232): soft position task with an
+    expression gain, hard joint limits whose bounds breathe with time, speed limits that depend on time, and a
+    VelocityEqualityConstraint whose target is an expression"""
+    cs, cc, s = env.cs, env.cc, _syms(env, ny=3)
+    t, q = s["t"], s["q"]
+    n = len(env.lower)
+    T = env.T_fk(q)
+    kp = 3.0 + cs.sin(0.7 * t) + 0.5 * q[1] * q[1]
+    shrink = 0.9 + 0.05 * cs.sin(t)
+    pos = cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - s["y"], gain=kp,
+                                constraint_type="soft", priority=1, slack_weight=2.0)
+    lim = cc.SetConstraint(label="joint_limits", expression=q, set_min=cs.vertcat(*[float(v) * shrink for v in env.lower]),
+                           set_max=cs.vertcat(*[float(v) * shrink for v in env.upper]), gain=0.8 + 0.1 * cs.cos(t),
+                           priority=0)
+    vm = cs.vertcat(*[float(v) * (1.0 + 0.2 * cs.cos(t)) for v in env.vmax])
+    speed = cc.VelocitySetConstraint(label="joint_speed_limits", expression=q, set_min=-vm, set_max=vm, priority=0)
+    spin = cc.VelocityEqualityConstraint(label="last_joint_spin", expression=q[n - 1], target=0.1 * cs.sin(t) + 0.05 * q[0],
+                                         priority=2, constraint_type="soft")
+    spec = cc.SkillSpecification(label="qp_sym_attrs", time_var=t, robot_var=q, robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[pos, lim, speed, spin])
+    return dict(spec=spec, controller="qp", options={}, ny=3)
+
+
 CASES = {
     "position": position, "pose": pose, "stack_const": stack_const, "stack_const_time": stack_const_time,
     "stack_sets1d": stack_sets1d, "stack_noff": stack_noff, "position_standard": position_standard, "conv_last": conv_last,
     "veleq_first": veleq_first, "qp_pose": qp_pose, "qp_limits": qp_limits, "qp_path": qp_path,
+    "sym_attrs": sym_attrs, "qp_sym_attrs": qp_sym_attrs,
 }

@@ -96,3 +96,39 @@ def test_instantiated_notebook_qp_kernel_has_no_scratch(tmp_path):
     assert len(kernels) == 2
     for name, r in kernels.items():
         assert r["ScratchSize"] == 0, (name, r)
+
+
+def test_instantiated_kernels_with_expression_attributes_have_no_scratch(tmp_path):
+    """gains / bounds given as expressions (ExternAttr code + the per-lane attribute slice of the task cache)
+    must dissolve into registers: one run-time evaluated offset pins the whole task cache in scratch"""
+    import subprocess
+    import numpy as np
+    import casclik_amd as cc
+    from casclik_amd import jit, sym as cs
+    from casclik_amd.build import parse_resource_remarks, FLAGS
+    hipcc = jit._hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    lib = _capi.load_library()
+    fk = skills.ur5()
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
+    gain = 0.5 + 0.3 * cs.sin(0.2 * t) + 0.1 * q[0] * q[0]
+    lim = cs.vertcat(*[1.0 + 0.1 * cs.cos(t) for _ in range(6)])
+    spec = cc.SkillSpecification("symgain", t, q, constraints=[
+        cc.SetConstraint("lims", q, gain=gain, set_min=-lim, set_max=lim, priority=0),
+        cc.EqualityConstraint("move", fk["T_fk"](q)[:3, 3] - np.array([0.3, 0.2, 0.4]), gain=gain,
+                              constraint_type="soft", priority=1)])
+    d = lower_skill(spec)
+    cdesc = _capi.desc_to_c(d)
+    buf = C.create_string_buffer(16384)
+    assert lib.clik_qp_shape_describe(C.byref(cdesc), buf, len(buf)) == 1
+    src = tmp_path / "attr_qp.hip"
+    src.write_text(jit._QP_TEMPLATE % {"init": buf.value.decode(), "extern": d.extern_source()})
+    out = subprocess.run([hipcc] + FLAGS + ["-c", str(src), "-o", str(tmp_path / "attr_qp.o")],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()[-2000:]
+    res = parse_resource_remarks(out.stdout.decode())
+    kernels = {k: v for k, v in res.items() if "_static_" in k}
+    assert len(kernels) == 3
+    for name, r in kernels.items():
+        assert r["ScratchSize"] == 0, (name, r)

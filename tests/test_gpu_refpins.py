@@ -49,13 +49,17 @@ def test_qp_hip_matches_the_reference_run(name):
     ctrl = cc.ReactiveQPController(skill_spec=built["spec"])
     ctrl.setup_problem_functions()
     ctrl.setup_solver()
-    H, A, lb, ub = ctrl.qp_data_batch(t, Q, virtual_var=X, input_var=Y)
-    assert np.abs(H - P[name + "_H"]).max() < 1e-14
-    assert np.abs(A - P[name + "_A"]).max() < 1e-10
-    fin = np.abs(P[name + "_lbA"]) < 1e9
-    assert np.abs(lb - P[name + "_lbA"])[fin].max() < 1e-9 and np.array_equal(lb[~fin], P[name + "_lbA"][~fin])
-    fin = np.abs(P[name + "_ubA"]) < 1e9
-    assert np.abs(ub - P[name + "_ubA"])[fin].max() < 1e-9 and np.array_equal(ub[~fin], P[name + "_ubA"][~fin])
+    if not ctrl.descriptor.extern_code:
+        # (H / A / lbA / ubA come from the built-in data kernel; a skill with generated code - here: gains and
+        # bounds given as expressions - exists only inside the kernel instantiated for it, and its rows are
+        # checked through the minimiser below and through the oracle in tests/test_refpins.py)
+        H, A, lb, ub = ctrl.qp_data_batch(t, Q, virtual_var=X, input_var=Y)
+        assert np.abs(H - P[name + "_H"]).max() < 1e-14
+        assert np.abs(A - P[name + "_A"]).max() < 1e-10
+        fin = np.abs(P[name + "_lbA"]) < 1e9
+        assert np.abs(lb - P[name + "_lbA"])[fin].max() < 1e-9 and np.array_equal(lb[~fin], P[name + "_lbA"][~fin])
+        fin = np.abs(P[name + "_ubA"]) < 1e9
+        assert np.abs(ub - P[name + "_ubA"])[fin].max() < 1e-9 and np.array_equal(ub[~fin], P[name + "_ubA"][~fin])
     dq, dx, slack, status = ctrl.solve_batch(t, Q, virtual_var=X, input_var=Y)
     assert (status == 0).all(), (name, np.bincount(status))
     assert refpins.rel_err(dq, P[name + "_dq"]).max() < QP_RTOL
