@@ -453,10 +453,13 @@ class ReactiveQPController(BaseController):
                     None if status is None else status.cpu().numpy())
         return dQ, dX, SL, status
 
-    def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008, max_speed=0.0, virtual_var=None):
-        """``len(time_vars)`` ticks of QP solve -> clamp(+-max_speed) -> Euler ``q += dq*dt`` in
+    def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008, max_speed=0.0, virtual_var=None,
+                      method="euler"):
+        """``len(time_vars)`` ticks of QP solve -> clamp(+-max_speed) -> integrate in
         one launch, the working set hot-started from tick to tick (the host loop of
-        ur5_moe2016_example2.ipynb:537-545 for this controller).  Returns
+        ur5_moe2016_example2.ipynb:537-545 for this controller).  ``method="euler"``: ``q += dq*dt``;
+        ``method="rk4"``: classical Runge-Kutta with the controller as the right-hand side
+        (casclik/integration_methods.py:17-23: k1..k4 at t, t+dt/2, t+dt/2, t+dt, each clamped).  Returns
         (q_final, dq_last, slack_last | None, status [B] = worst status met); for a skill with
         virtual variables (pass ``virtual_var``; cart_on_track_1D...ipynb cell 60) they are integrated
         alongside, unclamped: (q_final, x_final, dq_last, dx_last, slack_last | None, status)."""
@@ -479,15 +482,20 @@ class ReactiveQPController(BaseController):
         Y = None
         if d.n_y > 0:
             Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        if method not in ("euler", "rk4"):
+            raise ValueError("method must be 'euler' or 'rk4'")
         times = np.asarray(time_vars, dtype=float).reshape(-1)
+        n_ticks = int(times.size)
+        if method == "rk4":
+            times = np.stack([times, times + 0.5 * dt, times + 0.5 * dt, times + dt], axis=1).reshape(-1)
         tt = np.concatenate([d.time_terms(t) for t in times]) if d.n_tslots else np.zeros(0)
         tt, ttp = _capi.tterms_arg(tt)
         dQ = torch.empty((B, d.n_q), dtype=torch.float64, device=dev)
         SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            rc = self._lib.clik_qp_rollout_batch_x(
-                self._handle, B, int(times.size), float(dt), float(max_speed), ttp,
+            rc = self._lib.clik_qp_rollout_batch_m(
+                self._handle, B, n_ticks, 1 if method == "rk4" else 0, float(dt), float(max_speed), ttp,
                 ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(SL), ptr(status), current_stream(dev))
         _capi.check(self._lib, rc)
         outs = (Q, dQ, SL, status) if X is None else (Q, X, dQ, dX, SL, status)

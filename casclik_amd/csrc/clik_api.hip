@@ -63,7 +63,8 @@ hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long l
                             const double* t_inst);
 hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
                                     double max_speed, long long B, double* q, const double* y, double* dq,
-                                    double* slack, int32_t* status, double* x, double* dx, hipStream_t stream);
+                                    double* slack, int32_t* status, double* x, double* dx, hipStream_t stream,
+                                    int stages);
 }  // namespace clik
 
 using clik::DevSkill;
@@ -101,7 +102,7 @@ typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, co
 
 typedef hipError_t (*clik_jit_qp_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
                                              const double*, double*, double*, int32_t*, double*, double*,
-                                             hipStream_t);
+                                             hipStream_t, int);
 
 struct clik_qp {
     DevSkill  host;
@@ -1143,7 +1144,18 @@ extern "C" int clik_qp_rollout_batch_x(const clik_qp* hc, int64_t B, int32_t n_t
                                        const double* tterms, double* q, double* x, const double* y, double* dq,
                                        double* dx, double* slack, int32_t* status, void* stream)
 {
+    return clik_qp_rollout_batch_m(hc, B, n_ticks, CLIK_INTEGRATE_EULER, dt, max_speed, tterms, q, x, y, dq, dx, slack,
+                                   status, stream);
+}
+
+extern "C" int clik_qp_rollout_batch_m(const clik_qp* hc, int64_t B, int32_t n_ticks, int32_t method, double dt,
+                                       double max_speed, const double* tterms, double* q, double* x, const double* y,
+                                       double* dq, double* dx, double* slack, int32_t* status, void* stream)
+{
     const clik_qp* h = hc;
+    if (method != CLIK_INTEGRATE_EULER && method != CLIK_INTEGRATE_RK4)
+        return fail(CLIK_EINVAL, "clik_qp_rollout_batch_m: unknown integration method %d", method);
+    const int stages = method == CLIK_INTEGRATE_RK4 ? 4 : 1;
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
     if (B == 0 || n_ticks == 0) return CLIK_OK;
@@ -1155,14 +1167,14 @@ extern "C" int clik_qp_rollout_batch_x(const clik_qp* hc, int64_t B, int32_t n_t
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     double* d_tt = nullptr;
-    int rc = stage_tterms(tterms, (size_t)n_ticks * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
+    int rc = stage_tterms(tterms, (size_t)n_ticks * stages * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
     if (rc) return rc;
     hipError_t e = h->jit_rollout
                        ? h->jit_rollout(h->d_img, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack,
-                                        status, x, dx, (hipStream_t)stream)
+                                        status, x, dx, (hipStream_t)stream, stages)
                        : clik::qp_launch_rollout_static(h->static_k, h->d_img, d_tt, n_ticks, dt, max_speed,
                                                         (long long)B, q, y, dq, slack, status, x, dx,
-                                                        (hipStream_t)stream);
+                                                        (hipStream_t)stream, stages);
     if (d_tt) (void)hipFreeAsync(d_tt, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "qp_rollout_kernel launch");
     return CLIK_OK;

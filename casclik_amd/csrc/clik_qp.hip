@@ -425,10 +425,12 @@ hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long l
 
 hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
                                     double max_speed, long long B, double* q, const double* y, double* dq,
-                                    double* slack, int32_t* status, double* x, double* dx, hipStream_t stream)
+                                    double* slack, int32_t* status, double* x, double* dx, hipStream_t stream,
+                                    int stages)
 {
     if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
-    return kQpShapes[k].rollout(d_img, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, slack, status, x, dx, stream);
+    return kQpShapes[k].rollout(d_img, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, slack, status, x, dx, stream,
+                                stages);
 }
 
 }  // namespace clik

@@ -1192,7 +1192,10 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_pt_kernel(
 // loop of the notebooks (ur5_moe2016_example2.ipynb:537-545) for the QP controller.  The working
 // set stays in a register from tick to tick (hot start), the skill image and the targets in LDS.
 // q is updated in place; dq / slack receive the last tick, status the worst status met.
-template <const ShapeDesc& SD>
+// RK: classical Runge-Kutta with the controller as the right-hand side (integration_methods.py:17-23; four QP
+// solves per tick, the working set hot-started from stage to stage, tterms holds four records per tick) instead of
+// explicit Euler; a tick with an infeasible stage leaves the state where it was.
+template <const ShapeDesc& SD, bool RK>
 __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
@@ -1245,19 +1248,56 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
     for (int k = 0; k < LY::NSA; ++k) sl[k] = 0.0;
     int32_t hot = 0;
     int worst = 0;
+    if constexpr (!RK) {
 #pragma unroll 1
-    for (int tick = 0; tick < n_ticks; ++tick) {
-        asm volatile("" ::: "memory");      // (keeps the image reads inside the loop, see pinv_rollout_static_kernel)
-        const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
-        const int st = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl, &hot, tick > 0);
-        worst = st > worst ? st : worst;
-        const bool okl = st != 2;           // an infeasible tick leaves the state where it is
+        for (int tick = 0; tick < n_ticks; ++tick) {
+            asm volatile("" ::: "memory");      // (keeps the image reads inside the loop, see pinv_rollout_static_kernel)
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
+            const int st = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl, &hot, tick > 0);
+            worst = st > worst ? st : worst;
+            const bool okl = st != 2;           // an infeasible tick leaves the state where it is
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            double d = v[j];
-            if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
-            v[j] = d;
-            z[j] = okl ? fma(d, dt, z[j]) : z[j];
+            for (int j = 0; j < N; ++j) {
+                double d = v[j];
+                if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                v[j] = d;
+                z[j] = okl ? fma(d, dt, z[j]) : z[j];
+            }
+        }
+    } else {
+        double* z0s = slots + LY::SLOTS * WAVE;      // [N][64] state at the start of the tick, [N][64] sum of w_i k_i
+        double* kss = z0s + N * WAVE;
+#pragma unroll 1
+        for (int tick = 0; tick < n_ticks; ++tick) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                z0s[j * WAVE + lane] = z[j];
+                kss[j * WAVE + lane] = 0.0;
+            }
+            bool okl = true;
+#pragma unroll 1
+            for (int stg = 0; stg < 4; ++stg) {
+                asm volatile("" ::: "memory");
+                const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * 4 + stg) * 2 * nts);
+                const int st = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl, &hot, (tick | stg) > 0);
+                worst = st > worst ? st : worst;
+                okl = okl & (st != 2);
+                const double wgt = (stg == 0 || stg == 3) ? 1.0 : 2.0;
+                const double cnext = (stg == 2) ? dt : 0.5 * dt;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double d = okl ? v[j] : 0.0;
+                    if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                    kss[j * WAVE + lane] = fma(wgt, d, kss[j * WAVE + lane]);
+                    z[j] = fma(d, cnext, z0s[j * WAVE + lane]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double d = kss[j * WAVE + lane] * (1.0 / 6.0);
+                v[j] = okl ? d : v[j];
+                z[j] = okl ? fma(d, dt, z0s[j * WAVE + lane]) : z0s[j * WAVE + lane];
+            }
         }
     }
     const double bad = (worst == 2) ? __builtin_nan("") : 0.0;
@@ -1289,28 +1329,40 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
     if (status_out != nullptr && valid) status_out[b0 + lane] = worst;
 }
 
+// stages: controller evaluations per tick (1 explicit Euler, 4 classical Runge-Kutta)
 typedef hipError_t (*qp_static_rollout_fn)(const void*, const double*, int, double, double, long long, double*,
-                                           const double*, double*, double*, int32_t*, double*, double*, hipStream_t);
+                                           const double*, double*, double*, int32_t*, double*, double*, hipStream_t,
+                                           int);
 
 template <const ShapeDesc& SD>
 inline hipError_t launch_qp_rollout_static(const void* d_img, const double* d_tterms, int n_ticks, double dt,
                                            double max_speed, long long B, double* q, const double* y, double* dq,
                                            double* slack, int32_t* status, double* x, double* dx,
-                                           hipStream_t stream)
+                                           hipStream_t stream, int stages = 1)
 {
     if (SD.n_x != 0 && (x == nullptr || dx == nullptr)) return hipErrorInvalidValue;
-    {
-        const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-        constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if (stages == 4) {
+        constexpr size_t shmem = QpLayout<SD>::LDS_BYTES + (size_t)2 * SD.n * WAVE * sizeof(double);
+        static_assert(shmem <= 160u * 1024u, "Runge-Kutta QP rollout needs more LDS than a CU has");
         if (shmem > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)qp_rollout_static_kernel<SD>,
+            hipError_t e = hipFuncSetAttribute((const void*)qp_rollout_static_kernel<SD, true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((qp_rollout_static_kernel<SD>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq, slack,
-                           status, B, d_tterms, n_ticks, dt, max_speed, x, dx);
+        hipLaunchKernelGGL((qp_rollout_static_kernel<SD, true>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq,
+                           slack, status, B, d_tterms, n_ticks, dt, max_speed, x, dx);
         return hipGetLastError();
     }
+    constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)qp_rollout_static_kernel<SD, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((qp_rollout_static_kernel<SD, false>), dim3(grid), dim3(WAVE), shmem, stream, d_img, q, y, dq,
+                       slack, status, B, d_tterms, n_ticks, dt, max_speed, x, dx);
+    return hipGetLastError();
 }
 
 // t_inst: null (tk serves the whole batch) or one time-slot record per instance ([B][2 * n_tslots], device)

@@ -323,6 +323,12 @@ int clik_qp_rollout_batch_x(const clik_qp* h, int64_t B, int32_t n_ticks,
                             double dt, double max_speed, const double* tterms,
                             double* q, double* x, const double* y, double* dq,
                             double* dx, double* slack, int32_t* status, void* stream);
+/* ... with the integration scheme selectable (CLIK_INTEGRATE_EULER / CLIK_INTEGRATE_RK4, see
+ * clik_pinv_rollout_batch_m): Runge-Kutta solves four QPs per tick, each stage hot-started from the previous
+ * one; tterms then holds n_ticks*4*2*n_tslots doubles.  A tick with an infeasible stage leaves q where it was. */
+int clik_qp_rollout_batch_m(const clik_qp* h, int64_t B, int32_t n_ticks, int32_t method, double dt,
+                            double max_speed, const double* tterms, double* q, double* x, const double* y,
+                            double* dq, double* dx, double* slack, int32_t* status, void* stream);
 
 /* QP data only (H diag, A, lbA, ubA as the reference's H_func/A_func/Blb/Bub,
  * reactive_qp.py:283-298) for inspection and parity tests:

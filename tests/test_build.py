@@ -92,8 +92,8 @@ def test_instantiated_notebook_qp_kernel_has_no_scratch(tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     res = parse_resource_remarks(out.stdout.decode())
-    kernels = {k: v for k, v in res.items() if "qp_solve_static_kernel" in k or "qp_rollout_static_kernel" in k}
-    assert len(kernels) == 2
+    kernels = {k: v for k, v in res.items() if "qp_solve_static" in k or "qp_rollout_static_kernel" in k}
+    assert len(kernels) == 4          # per tick (one time / one time per instance), rollout (Euler / Runge-Kutta)
     for name, r in kernels.items():
         assert r["ScratchSize"] == 0, (name, r)
 
@@ -129,6 +129,6 @@ def test_instantiated_kernels_with_expression_attributes_have_no_scratch(tmp_pat
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     res = parse_resource_remarks(out.stdout.decode())
     kernels = {k: v for k, v in res.items() if "_static_" in k}
-    assert len(kernels) == 3
+    assert len(kernels) == 4
     for name, r in kernels.items():
         assert r["ScratchSize"] == 0, (name, r)

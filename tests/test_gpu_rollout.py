@@ -79,6 +79,42 @@ def test_rk4_rollout_of_the_stack_with_sets(iiwa_fk):
     assert np.array_equal(mode_dev, modes[-4])        # the mode of the last tick's first stage
 
 
+def test_qp_rk4_rollout_matches_host_rk4(ur5_fk):
+    """the QP controller's rollout with method="rk4" (four QP solves per tick in one launch, hot-started from stage
+    to stage) against the scheme of integration_methods.py:17-23 looped on the host over the same kernel and over
+    the oracle"""
+    from oracle import clik_oracle
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = ur5_fk["T_fk"](q)[:3, 3]
+    path = cs.vertcat(0.5 * cs.sin(0.1 * t) * cs.sin(0.1 * t) + 0.2, 0.5 * cs.cos(0.1 * t) + 0.25 * cs.sin(0.1 * t),
+                      0.5 * cs.sin(0.1 * t) * cs.cos(0.1 * t) + 0.1)
+    vmax = 0.6
+    spec = cc.SkillSpecification("track_qp", t, q, constraints=[
+        cc.EqualityConstraint("move_point", p - path, gain=0.5, constraint_type="soft"),
+        cc.VelocitySetConstraint("speed", q, set_min=-vmax * np.ones(6), set_max=vmax * np.ones(6))])
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    rng = np.random.default_rng(21)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    Q = home + rng.normal(scale=0.1, size=(70, 6))
+    dt, times = 0.05, 1.0 + 0.05 * np.arange(6)
+    qf, dql, sl, status = ctrl.rollout_batch(times, Q, dt=dt, max_speed=0.5, method="rk4")
+    assert (status == 0).all()
+    qh, vh = _host_rk4(lambda tt, qq: ctrl.solve_batch(tt, qq)[0], times, Q, dt, 0.5)
+    assert np.allclose(qf, qh, rtol=1e-9, atol=1e-11) and np.allclose(dql, vh, rtol=1e-7, atol=1e-9)
+    qo, vo = _host_rk4(lambda tt, qq: clik_oracle.qp_solve_batch(spec, tt, qq)[0], times, Q[:9], dt, 0.5)
+    assert np.allclose(qf[:9], qo, rtol=1e-7, atol=1e-9)
+    # Euler through the same entry equals the Euler rollout
+    qe, dqe, _, _ = ctrl.rollout_batch(times, Q, dt=dt, max_speed=0.5, method="euler")
+    qe0, dqe0, _, _ = ctrl.rollout_batch(times, Q, dt=dt, max_speed=0.5)
+    assert np.array_equal(qe, qe0) and np.array_equal(dqe, dqe0)
+    assert np.abs(qe - qf).max() > 1e-7          # (and differs from Runge-Kutta)
+    with pytest.raises(ValueError):
+        ctrl.rollout_batch(times, Q, dt=dt, method="heun")
+
+
 def test_rollouts_on_two_streams_do_not_share_state(ur5_fk):
     """two rollouts of ONE handle with different time stamps, enqueued on two streams before either is
     waited for: each must see its own time-slot records (they used to live in the handle)"""
