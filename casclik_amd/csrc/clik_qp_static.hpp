@@ -525,8 +525,8 @@ constexpr QpPlanS make_qp_plan(const ShapeDesc& sd)
 // Box family: after the soft equalities are folded into P and g, every remaining row is a HARD bound on one
 // state variable (joint-limit SetConstraint / speed-limit VelocitySetConstraint on q, merged per state):
 //     min 1/2 v'P v - g'v   s.t.  lb_c <= v_c <= ub_c  on the bounded states c
-// (BASELINE config 4 and the QP stacks of the UR5 notebooks).  Such a QP is solved by a projected Newton
-// iteration on the states (qp_box_solve) instead of the dual active-set iteration over rows.
+// (BASELINE config 4 and the QP stacks of the UR5 notebooks).  Such a QP is solved by a primal active-set
+// iteration on the states (qp_box_pas) instead of the dual active-set iteration over rows.
 constexpr bool qp_box_family(const ShapeDesc& sd)
 {
     const QpPlanS p = make_qp_plan(sd);
@@ -538,16 +538,21 @@ constexpr bool qp_box_family(const ShapeDesc& sd)
     }
     return true;
 }
-// MEASURED AND NOT THE DEFAULT (config 4, 16384 instances, cold / hot start per tick): dual active-set
-// iteration 40.4 / 10.6 us; projected Newton below 38.5 / 25.8 us; block principal pivoting (first attempt,
-// history) 93 / 7.4 us with a cycling tail of 30+ passes.  The projected Newton needs fewer passes (2.8 on
-// average, 10 worst against 4 and 11-13) but a pass with its face re-solves costs ~1500 instructions against
-// ~1000 of an active-set iteration, so the slowest wave of the batch - which is what a tick costs - is no
-// shorter.  -DCLIK_QP_BOX_PN builds it (tools/qp_passes.py sweeps its pass cap).
-#ifdef CLIK_QP_BOX_PN
-#define CLIK_QP_BOX_OK(SD) qp_box_family(SD)
-#else
+// Solvers measured for this family on config 4 (16384 instances, cold / hot start per tick, same box):
+//   dual active-set iteration over rows (gi_solve, what every other QP shape runs)      38.7 / 10.4 us
+//   projected Newton, qp_box_solve (-DCLIK_QP_BOX_PN)                                   38.5 / 25.8 us
+//   block principal pivoting (first attempt, history)                                   93   /  7.4 us
+//   primal active set from the vertex the linear term points to, qp_box_pas (default)   see DESIGN.md section 5
+// The tick is the slowest instance of the batch (every wave has a SIMD to itself), i.e. its pass count times the
+// instructions of a pass: the dual iteration needs 11-13 passes of ~1000 instructions on the worst instance, the
+// projected Newton 10 of ~1500, the primal active set up to 19 of ~350 (mean 3.3): only 0-3 of the 7 states are
+// free at the optimum, so a method that starts from a vertex and frees one state per pass is there quickly, and
+// a pass is one masked 7 x 7 factorisation with everything in registers.  -DCLIK_QP_BOX_OFF: this family runs the
+// dual iteration like the others (regression switch).
+#if defined(CLIK_QP_BOX_OFF)
 #define CLIK_QP_BOX_OK(SD) false
+#else
+#define CLIK_QP_BOX_OK(SD) qp_box_family(SD)
 #endif
 
 template <const ShapeDesc& SD>
@@ -890,6 +895,148 @@ __device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2],
     return status;
 }
 
+// Primal active set for  min f(x) = 1/2 x'P x - g'x,  lb_c <= x_c <= ub_c  (P symmetric positive definite, packed
+// lower triangle; unbounded states carry -/+ infinity).  x is feasible throughout, W = the states held on a bound.
+// One pass:
+//   Newton direction on the free states,  d_F = P_FF^-1 grad_F  (one fixed-size LDL' of P with a 1e30 penalty on
+//     the diagonal of the held states: one instruction stream for all lanes, only the masks differ),
+//   step  x - alpha d,  alpha = min(1, first bound hit)  (ratio test on fractions, one division);
+//   alpha < 1: the states that hit join W (snapped onto their bounds);
+//   alpha = 1: x minimises f on the face; the held state whose multiplier has the wrong sign by the largest
+//     amount is released (its Newton direction then points inward, so it is not blocked at once: f decreases
+//     strictly from face to face and the iteration is finite), none: x is the KKT point.
+//   the gradient is recomputed from x (the same 49 multiply-adds an update would cost, and no drift).
+// Start: see below (cold: coordinate-wise minimisers, clipped; hot: the partition of the previous tick,
+// hot = atL | atU << 16).  Returns 0 (KKT point, checked on the final gradient), 1 (pass cap), 2 (lb > ub).
+template <int N>
+__device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
+                                          const double (&lb)[N], const double (&ub)[N], const int max_pass,
+                                          const bool valid, double (&x)[N], int32_t* hot, const bool use_hot)
+{
+    constexpr int NT = N * (N + 1) / 2;
+    constexpr int kOne = 0x3ff00000;        // high word of 1.0: the masks below are doubles 1.0 / 0.0 kept as that word
+    auto as_mask = [](const int hi) __attribute__((always_inline)) { return __hiloint2double(hi, 0); };
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < N; ++a) empty = empty | (lb[a] - ub[a] > 1e-9 * fmax(1.0, fmax(fabs(lb[a]), fabs(ub[a]))));
+    uint32_t hl = 0u, hu = 0u;
+    if (use_hot && hot != nullptr) {
+        const uint32_t h = (uint32_t)*hot;
+        hl = h & 0xffffu;
+        hu = (h >> 16) & ~hl;
+    }
+    // held[a]: the state sits on a bound and is not moved (mask word); free_ok[a]: it may be released (lb < ub)
+    int held[N], free_ok[N];
+    double tol[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        // cold start: every state at the minimiser of its own coordinate (the other states at zero), clipped -
+        // x_a = clip(g_a / P_aa): the states that clip start held.  On the config-4 bench inputs (0-3 of the 7
+        // states free at the optimum) 2.95 passes per instance on average, 8 at the 99th percentile, 14 worst of
+        // 16384; the vertex the linear term points to (all states held): 3.35 / 10 / 19; the clipped unconstrained
+        // minimiser: 5.8 / 12 / 15 (tools/qp_pass_study.py).  Hot: the partition of the previous tick.
+        const double own = g[a] * __builtin_amdgcn_rcp(Pm[tri(a, a)]);
+        const double mid = fmin(fmax(use_hot ? 0.0 : own, lb[a]), ub[a]);
+        const bool has_l = lb[a] > -1e300, has_u = ub[a] < 1e300;
+        const bool to_l = use_hot ? (((hl >> a) & 1u) != 0u) : (own <= lb[a]);
+        const bool to_u = use_hot ? (((hu >> a) & 1u) != 0u) : (own >= ub[a]);
+        const bool on_l = to_l & has_l, on_u = to_u & has_u & !on_l;
+        x[a] = empty ? 0.0 : (on_l ? lb[a] : (on_u ? ub[a] : mid));
+        const bool pin = !(ub[a] > lb[a]);
+        held[a] = (on_l | on_u | pin) ? kOne : 0;
+        free_ok[a] = pin ? 0 : kOne;
+        tol[a] = 1e-9 * fmax(1.0, fabs(g[a]));
+    }
+    double gr[N];
+    auto gradient = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double sacc = -g[a];
+#pragma unroll
+            for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
+            gr[a] = sacc;
+        }
+    };
+    gradient();
+    bool done = !valid | empty;
+    int status = empty ? 2 : 1;
+    // (masks applied arithmetically and selections by min / max: a select of a double costs two instructions and
+    // a flag test two more, and a lone wave pays every one of them in full)
+#pragma unroll 1
+    for (int pass = 0; pass < max_pass; ++pass) {
+        if (__ballot(!done) == 0ull) break;
+        // Newton direction on the free states
+        double M[NT], rd[N], d[N];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) M[a] = Pm[a];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double hm = as_mask(held[a]);
+            M[tri(a, a)] = fma(hm, 1e30, Pm[tri(a, a)]);
+            d[a] = fma(-hm, gr[a], gr[a]);
+        }
+        ldl_factor_s<N>(M, rd);
+        ldl_solve_s<N>(M, rd, d);
+        // first bound hit along x - alpha d: alpha = min(1, room_a / d_a).  The quotient needs no correct rounding (a
+        // blocked step ends on no face minimum, and the states that land are snapped onto their bounds): hardware
+        // reciprocal.  0 * inf = NaN for a held state on its bound, which min ignores.
+        double tgt[N], r[N];
+        double amin = 1.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            d[a] = fma(-as_mask(held[a]), d[a], d[a]);                    // (exactly zero on the held states)
+            tgt[a] = (d[a] > 0.0) ? lb[a] : ub[a];
+            r[a] = fabs(x[a] - tgt[a]) * __builtin_amdgcn_rcp(fabs(d[a]));
+            amin = fmin(amin, r[a]);
+        }
+        const bool blocked = amin < 1.0;
+        const double alpha = done ? 0.0 : amin;
+        const double thr = amin * (1.0 + 1e-7);
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double xn = fma(-alpha, d[a], x[a]);
+            const bool lands = blocked & !done & (r[a] <= thr);            // the blocking state (and ties): held there
+            x[a] = lands ? tgt[a] : xn;
+            held[a] = lands ? kOne : held[a];
+        }
+        gradient();
+        // at a face minimum: release the held state whose multiplier is wrong by the largest amount, or stop
+        double c[N];
+        double worst = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double push = (x[a] <= lb[a]) ? -gr[a] : gr[a];          // > 0: f decreases by leaving the bound
+            c[a] = fma(push, as_mask(held[a] & free_ok[a]), -tol[a]);
+            worst = fmax(worst, c[a]);
+        }
+        const bool release = !blocked & !done & (worst > 0.0);
+#pragma unroll
+        for (int a = 0; a < N; ++a) held[a] = (release & (c[a] == worst)) ? 0 : held[a];
+        done = done | (!blocked & !(worst > 0.0));
+    }
+    if (!empty) {
+        // the KKT conditions of the returned point (gr is the gradient at x)
+        bool kkt = true;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const bool fine = ((x[a] <= lb[a]) & (gr[a] >= -tol[a])) | ((x[a] >= ub[a]) & (gr[a] <= tol[a])) | (fabs(gr[a]) <= tol[a]);
+            kkt = kkt & fine;
+        }
+        status = (done & kkt) ? 0 : 1;
+    }
+    if (hot != nullptr && valid) {
+        uint32_t atL = 0u, atU = 0u;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const bool h = held[a] != 0;
+            if (h & (x[a] <= lb[a])) atL |= 1u << a;
+            else if (h & (x[a] >= ub[a])) atU |= 1u << a;
+        }
+        *hot = (int32_t)(atL | (atU << 16));
+    }
+    return status;
+}
+
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
@@ -926,7 +1073,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
     }
     qp_gather_s<SD, 0>(S, T, tk, tc, z, ysl, lane, L, v, slots);
     if constexpr (LY::BOX) {
-        // bounds by state (rows of the plan are unit rows on distinct states), then projected Newton
+        // bounds by state (rows of the plan are unit rows on distinct states), then the primal active set
         double lbc[N], ubc[N], gv[N];
 #pragma unroll
         for (int a = 0; a < N; ++a) {
@@ -940,7 +1087,11 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
             lbc[col] = slots[(LY::O_LB + r) * WAVE + lane];
             ubc[col] = slots[(LY::O_UB + r) * WAVE + lane];
         });
+#ifdef CLIK_QP_BOX_PN
         int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
+#else
+        int status = qp_box_pas<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
+#endif
         if (!valid) status = 0;
         // slack of the folded rows: s = J v - b
 #pragma unroll
