@@ -426,3 +426,80 @@ def test_dynamic_qp_infeasible_only_where_the_feasible_set_is_empty_by_a_hair(se
     assert ok.any() or (rst == 2).sum() > 200
     if ok.any():
         assert (np.abs(dq - rdq).max(axis=1) / (1 + np.abs(rdq).max(axis=1)))[ok].max() < 1e-6
+
+
+def _box_stack(fk, n, joint_kw, speed=(-0.8, 0.8), pos_gain=3.0):
+    """soft position task + hard joint-space bounds only: the box family of clik_qp_static.hpp (every row left after
+    folding the soft equalities is a bound on one state; joint limits and speed limits merge per state)"""
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", n)
+    y = cs.MX.sym("y", 3)
+    cons = [cc.EqualityConstraint("tool_position", fk["T_fk"](q)[:3, 3] - y, gain=pos_gain, constraint_type="soft",
+                                  priority=1)]
+    if joint_kw is not None:
+        cons.append(cc.SetConstraint("joint_limits", q, priority=0, **joint_kw))
+    if speed is not None:
+        cons.append(cc.VelocitySetConstraint("speed", q, set_min=speed[0] * np.ones(n), set_max=speed[1] * np.ones(n),
+                                             priority=0))
+    return cc.SkillSpecification("box_stack", t, q, input_var=y, constraints=cons)
+
+
+@pytest.mark.parametrize("case", ["two_sided", "one_sided", "limits_only", "tight_speed", "pinned_state"])
+def test_box_family_solver_edge_cases(iiwa_fk, case):
+    """the primal active-set box solver (Gauss-Seidel start sweeps, held / released states) on the shapes of bound
+    it has to handle: merged two-sided bounds, states with one bound only (the other side the reference's 1e10),
+    bounds that leave most states free, bounds that hold every state, and a state whose bounds coincide"""
+    from oracle import clik_oracle
+    lo, hi = np.asarray(iiwa_fk["lower"], float), np.asarray(iiwa_fk["upper"], float)
+    if case == "two_sided":
+        spec = _box_stack(iiwa_fk, 7, dict(set_min=lo, set_max=hi, gain=2.0))
+    elif case == "one_sided":
+        spec = _box_stack(iiwa_fk, 7, dict(set_min=lo, gain=2.0), speed=None)
+    elif case == "limits_only":
+        spec = _box_stack(iiwa_fk, 7, dict(set_min=lo, set_max=hi, gain=0.5), speed=(-50.0, 50.0))
+    elif case == "tight_speed":
+        spec = _box_stack(iiwa_fk, 7, None, speed=(-0.02, 0.02), pos_gain=20.0)
+    else:
+        pin_lo, pin_hi = -0.8 * np.ones(7), 0.8 * np.ones(7)
+        pin_lo[3] = pin_hi[3] = 0.25                     # dq_3 prescribed through coinciding speed limits
+        t, q, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("y", 3)
+        spec = cc.SkillSpecification("pinned", t, q, input_var=y, constraints=[
+            cc.EqualityConstraint("tool_position", iiwa_fk["T_fk"](q)[:3, 3] - y, gain=3.0, constraint_type="soft",
+                                  priority=1),
+            cc.VelocitySetConstraint("speed", q, set_min=pin_lo, set_max=pin_hi, priority=0)])
+    ctrl = _controller(spec)
+    assert ctrl.kernel_name != "dynamic"
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 700, seed=31, distribution="mixed")
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y[:, :3])
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y[:, :3])
+    assert np.array_equal(status, rstatus)
+    ok = rstatus == 0
+    assert ok.sum() > 600
+    assert _rel(dq[ok], rdq[ok]).max() < QP_RTOL and _rel(slack[ok], rslack[ok]).max() < QP_RTOL
+    if case == "pinned_state":
+        assert np.abs(dq[ok, 3] - 0.25).max() < 1e-12
+    if case == "tight_speed":
+        # (the last joint turns the flange about its own axis: it cannot move the tool point and stays at zero)
+        assert (np.abs(np.abs(dq[ok][:, :6]) - 0.02) < 1e-12).mean() > 0.9       # nearly every other state on a bound
+    # hot-started from the cold run's partition: the same minimiser
+    import torch
+    hot = torch.zeros(700, dtype=torch.int32, device="cuda")
+    Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y[:, :3].copy()).cuda()
+    d1 = ctrl.solve_batch(0.0, Qd, input_var=Yd, hot_set=hot, use_hot=False)[0]
+    d2 = ctrl.solve_batch(0.0, Qd, input_var=Yd, hot_set=hot, use_hot=True)[0]
+    assert torch.allclose(d1[torch.from_numpy(ok).cuda()], d2[torch.from_numpy(ok).cuda()], rtol=1e-9, atol=1e-11)
+
+
+def test_box_family_contradicting_bounds_are_infeasible(iiwa_fk):
+    """joint limits and speed limits that exclude each other on one state (merged row with lb > ub): status 2, NaN"""
+    lo, hi = np.asarray(iiwa_fk["lower"], float), np.asarray(iiwa_fk["upper"], float)
+    spec = _box_stack(iiwa_fk, 7, dict(set_min=lo, set_max=hi, gain=50.0), speed=(-0.1, 0.1))
+    ctrl = _controller(spec)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 200, seed=32, distribution="mixed")
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y[:, :3])
+    # a state outside its limits by more than 0.1 / 50 needs |dq| > 0.1 to come back: no feasible velocity
+    need = np.maximum(50.0 * (lo - Q), 50.0 * (Q - hi))           # required speed towards the inside
+    infeasible = (need > 0.1 * (1 + 1e-9)).any(axis=1)
+    clear = (need < 0.1 * (1 - 1e-9)).all(axis=1)
+    assert infeasible.sum() > 20 and clear.sum() > 20
+    assert (status[infeasible] == 2).all() and np.isnan(dq[infeasible]).all()
+    assert (status[clear] == 0).all() and np.isfinite(dq[clear]).all()
