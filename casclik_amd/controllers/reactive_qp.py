@@ -198,6 +198,21 @@ class ReactiveQPController(BaseController):
                 "the QP of this skill (%d variables x %d rows) exceeds the built-in kernel and no "
                 "shape-specialised kernel could be instantiated for it (jit disabled or hipcc missing)"
                 % (self.n_qp_vars, self.n_qp_rows))
+        # On request (function_opts["jit_values"] = True or CLIK_JIT_VALUES=2): the per-tick kernel with this skill's
+        # numbers and QP options compiled in, as the functions CasADi generates for the reference are
+        # (reactive_qp.py:283-298) - one more hipcc run at set-up, no skill image traffic per tick
+        self.value_kernel = None
+        if want_jit and (fopts.get("jit_values") is True or os.environ.get("CLIK_JIT_VALUES", "1") == "2") \
+                and os.environ.get("CLIK_JIT_VALUES", "1") != "0" and not d.extern_code \
+                and self.kernel_name not in ("dynamic", "none"):
+            from .. import jit
+            with torch.cuda.device(self._device):
+                try:
+                    self.value_kernel = jit.attach_qp_values(self._lib, handle, cdesc)
+                except RuntimeError as exc:
+                    import warnings
+                    warnings.warn("value-specialised QP kernel could not be built, using the image-reading one: %s"
+                                  % str(exc)[:300])
 
     def setup_solver(self):
         """The solver lives inside the kernel; make sure the handle exists
@@ -367,6 +382,10 @@ class ReactiveQPController(BaseController):
         return cs.DM(dx[0].reshape(-1, 1)), res_slack
 
     # -- per tick -----------------------------------------------------------------
+    def kernel_variant(self, batch):
+        """name of the kernel a batch of ``batch`` instances gets ("/v": with the skill's numbers compiled in)"""
+        return self.kernel_name + ("/v" if getattr(self, "value_kernel", None) else "")
+
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
                     return_status=True, hot_set=None, use_hot=True):
         """One QP tick for a batch: returns (robot_vel [B,n_q], virtual_vel |

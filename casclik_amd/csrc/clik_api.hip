@@ -38,6 +38,8 @@ const char* pinv_kernel_name(int k);
 const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B);
 bool shape_team_ok_rt(const ShapeDesc& sd);
 long long pinv_team_max_batch();
+bool shape_value_lane_ok_rt(const ShapeDesc& sd);
+long long pinv_value_lane_max_batch();
 int pinv_kernel_width(int k);
 int pinv_kernel_is_static(int k);
 hipError_t pinv_launch_solve(int k, const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
@@ -104,6 +106,9 @@ typedef hipError_t (*clik_jit_qp_rollout_fn)(const void*, const double*, int, do
                                              const double*, double*, double*, int32_t*, double*, double*,
                                              hipStream_t, int);
 
+typedef hipError_t (*clik_jit_qp_value_fn)(const TickArgs*, long long, const double*, const double*, const double*,
+                                           double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
+
 struct clik_qp {
     DevSkill  host;
     DevSkill* dev;
@@ -114,6 +119,7 @@ struct clik_qp {
     int       static_k;     // AOT shape-specialised kernel, -1 none
     clik_jit_qp_fn jit_solve;
     clik_jit_qp_rollout_fn jit_rollout;
+    clik_jit_qp_value_fn val_solve;     // per-tick kernel with this skill's numbers and QP options compiled in
     char      jit_name[64];
 };
 
@@ -662,6 +668,7 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     if (rc) { delete h; return rc; }
     DevSkill& S = h->host;
     h->d_img = nullptr;
+    h->val_solve = nullptr;
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
     h->val_solve = nullptr;
@@ -810,8 +817,10 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
 extern "C" int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
-    if (solve_fn && !clik::shape_team_ok_rt(h->host.shape))
-        return fail(CLIK_EUNSUPPORTED, "value-specialised kernels exist for the four-lanes-per-instance family only");
+    if (solve_fn && !clik::shape_team_ok_rt(h->host.shape) && !clik::shape_value_lane_ok_rt(h->host.shape))
+        return fail(CLIK_EUNSUPPORTED, "value-specialised kernels exist for the four-lanes-per-instance family and for "
+                                       "single-mode skills without virtual variables");
+    if (solve_fn && !clik::shape_team_ok_rt(h->host.shape)) rollout_fn = nullptr;      // (no value-specialised rollout there)
     h->val_solve = (clik_jit_value_fn)solve_fn;
     h->val_rollout = solve_fn ? (clik_jit_rollout_fn)rollout_fn : nullptr;
     if (solve_fn) h->mode_parallel |= 64;
@@ -890,8 +899,11 @@ static int pinv_solve_common(const clik_pinv* h, int64_t B, const double* tterms
     }
     const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, nullptr, nullptr, 1,
                                  t_inst};
-    // a value-specialised team kernel serves the batches the image-reading team kernel would serve
-    const bool team_batch = (h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch());
+    // a value-specialised kernel serves the batches the image-reading team kernel would serve (config-3 family), or
+    // the small batches of a single-mode skill
+    const bool team_batch = clik::shape_team_ok_rt(S.shape)
+                                ? ((h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch()))
+                                : (clik::shape_value_lane_ok_rt(S.shape) && B <= clik::pinv_value_lane_max_batch());
     hipError_t e = (h->val_solve && team_batch && t_inst == nullptr)
                        ? h->val_solve(&la, &tk, (long long)B, q, y, dq, mode, (hipStream_t)stream)
                    : h->jit_solve
@@ -1180,6 +1192,35 @@ extern "C" int clik_qp_rollout_batch_m(const clik_qp* hc, int64_t B, int32_t n_t
     return CLIK_OK;
 }
 
+// the skill image + QP options of this handle (what the shape-specialised QP kernels read from memory, laid out
+// as clik::QpImg) as 64-bit words, for casclik_amd/jit.py to compile into a value-specialised kernel
+extern "C" int clik_qp_image_words(const clik_qp* h, uint64_t* buf, int cap)
+{
+    if (!h || !buf || cap <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    std::vector<char> img;
+    if (!build_qp_image(h->host, img)) return fail(CLIK_EUNSUPPORTED, "skill rows are not contiguous");
+    size_t image_bytes = 0;
+    {
+        std::vector<char> plain;
+        if (!build_skill_image(h->host, plain, &image_bytes, sizeof(clik::QpTail))) return fail(CLIK_EUNSUPPORTED, "no image");
+    }
+    const size_t bytes = ((((image_bytes + 15) & ~(size_t)15) + sizeof(clik::QpTail)) + 15) & ~(size_t)15;
+    const int words = (int)(bytes / 8);
+    if (words > cap) return fail(CLIK_EINVAL, "image needs %d words, buffer holds %d", words, cap);
+    memset(buf, 0, (size_t)words * 8);
+    memcpy(buf, img.data(), img.size() < bytes ? img.size() : bytes);
+    return words;
+}
+
+extern "C" int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (solve_fn && !h->jit_solve && h->static_k < 0)
+        return fail(CLIK_EUNSUPPORTED, "value-specialised QP kernels exist for skills a shape-specialised kernel serves");
+    h->val_solve = (clik_jit_qp_value_fn)solve_fn;
+    return CLIK_OK;
+}
+
 extern "C" const char* clik_qp_kernel_name(const clik_qp* h)
 {
     if (!h) return "none";
@@ -1236,7 +1277,9 @@ static int qp_solve_common(const clik_qp* h, int64_t B, const double* tterms, co
                                        "for the skill (none built in, none attached)");
     }
     hipError_t e;
-    if (h->jit_solve)
+    if (h->val_solve && t_inst == nullptr)
+        e = h->val_solve(&tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set, use_hot, (hipStream_t)stream);
+    else if (h->jit_solve)
         e = h->jit_solve(h->d_img, &tk, (long long)B, q, x, y, dq, dx, slack, status, hot_set, use_hot,
                          (hipStream_t)stream, t_inst);
     else if (h->static_k >= 0)

@@ -1376,6 +1376,7 @@ inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long l
     if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch)))
         return (mode_parallel & 64) ? "team4v" : "team4";       // bit 6: a value-specialised team kernel is attached
     const int ns = shape_n_sets(sd);
+    if ((mode_parallel & 64) && sd.n_x == 0 && ns == 0 && !sd.qp && B <= 32768) return "lanev";   // value-specialised lane kernel attached
     if (sd.n_x == 0 && ns <= 1 && B <= kRoleSplitMaxBatch && (mode_parallel & 2)) {
         bool ok = true;
         for (int k = 0; k < (1 << ns); ++k) ok = ok && make_plan(sd, shape_mode_act(sd, k)).helper_ok;
@@ -1467,6 +1468,73 @@ inline hipError_t launch_rollout_team_values(const LaunchArgs& a, const double* 
                        team_rollout_lds_bytes<SD>(true), stream, nullptr, q, y, dq, mode, B, d_tterms, n_ticks, dt,
                        max_speed, a.roll_stages == 4 ? 4 : 1);
     return hipGetLastError();
+}
+
+// The lane-per-instance kernel with the skill's numbers compiled in (IMGV::value: the skill image as a constant
+// expression, see clik_pinv_team.hpp): nothing is staged through LDS - no image copy, no barrier - every lane
+// loads its own robot_var / input_var row and stores its own velocity row.  For the small batches where a tick
+// is the latency of one wave (kValueLaneMaxBatch); larger batches keep the kernel with the coalesced row blocks.
+constexpr long long kValueLaneMaxBatch = 32768;
+// single-mode skills without virtual variables (skills with SetConstraints keep the one-wave-per-mode kernels at
+// small batches, the config-3 family its four lanes per instance)
+constexpr bool shape_value_lane_ok(const ShapeDesc& sd) { return sd.n_x == 0 && shape_n_sets(sd) == 0 && !sd.qp; }
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
+    int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
+{
+    static_assert(SD.n_x == 0, "value-specialised lane kernel: robot variables only");
+    constexpr int N = SD.n;
+    constexpr Img<SD> Sval = IMGV::value;        // (a local constant: its loads fold to immediates)
+    const int lane = threadIdx.x;
+    const long long inst = (long long)blockIdx.x * WAVE + lane;
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = q[row * N + j];
+    const double* ys = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double vout[N];
+    int acc_mode;
+    pinv_tick_static<SD>(&Sval, tk, z, ys, lane, valid, vout, acc_mode);
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dq[inst * N + j] = vout[j];
+        if (mode_out != nullptr) mode_out[inst] = acc_mode;
+    }
+}
+
+// the value-specialised kernel of a skill for one tick: four lanes per instance where the family allows and the
+// batch is small, else the lane kernel above (hipErrorNotSupported beyond its batch range: the caller then uses
+// the image-reading kernels)
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, long long B, const double* q,
+                                      const double* y, double* dq, int32_t* mode, hipStream_t stream)
+{
+    if constexpr (shape_team_ok(SD)) {
+        if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch))
+            return launch_solve_team_values<SD, IMGV>(a, tk, B, q, y, dq, mode, stream);
+    }
+    if constexpr (shape_value_lane_ok(SD)) {
+        if (B <= kValueLaneMaxBatch) {
+            const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+            hipLaunchKernelGGL((pinv_solve_static_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
+                               mode, B, tk);
+            return hipGetLastError();
+        }
+    }
+    return hipErrorNotSupported;
+}
+
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_rollout_values(const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
+                                        double max_speed, long long B, double* q, const double* y, double* dq,
+                                        int32_t* mode, hipStream_t stream)
+{
+    if constexpr (shape_team_ok(SD))
+        return launch_rollout_team_values<SD, IMGV>(a, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, mode, stream);
+    else
+        return hipErrorNotSupported;
 }
 
 template <const ShapeDesc& SD>

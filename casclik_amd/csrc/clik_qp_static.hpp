@@ -1270,7 +1270,21 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
 }
 
 // PT: one time-slot record per instance (t_inst [B][2 * n_tslots], device; see pinv_solve_static_body)
-template <const ShapeDesc& SD, bool PT>
+template <const ShapeDesc& SD> struct QpImg;
+template <const ShapeDesc& SD, class IMGV>
+constexpr QpImg<SD> qp_values_or_zero();
+
+// skill image + QP options as one object (what the image-reading kernels find at img_g): the type a
+// value-specialised kernel's constant has (IMGV::value, see clik_pinv_team.hpp)
+template <const ShapeDesc& SD>
+struct QpImg {
+    Img<SD> img;
+    alignas(16) QpTail tail;
+};
+
+// IMGV: void - the skill image and the QP options are read from img_g (staged through LDS, copied to registers);
+// else IMGV::value is a QpImg<SD> constant and they are compiled in (no image traffic, no image registers)
+template <const ShapeDesc& SD, bool PT, class IMGV = void>
 __device__ __forceinline__ void qp_solve_static_body(
     const void* __restrict__ img_g, const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
@@ -1295,26 +1309,32 @@ __device__ __forceinline__ void qp_solve_static_body(
     double* ys = slots + LY::O_Y * WAVE;
     // one memory round trip: image + options, joint state and inputs (see pinv_solve_static_kernel)
     typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr bool VALUES = !std::is_void<IMGV>::value;
     {
         d2 img[LY::IMG_CHUNKS];
-        const d2* src = (const d2*)img_g;
+        if constexpr (!VALUES) {
+            const d2* src = (const d2*)img_g;
 #pragma unroll
-        for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
+            for (int k = 0; k < LY::IMG_CHUNKS; ++k) img[k] = src[k * WAVE + lane];
+        }
         double qv[NQ], xv[NX > 0 ? NX : 1], yv[SD.n_y > 0 ? SD.n_y : 1];
         stage_load<NQ>(q + b0 * NQ, NQ, rows_valid, lane, qv);
         if constexpr (NX > 0) stage_load<NX>(x + b0 * NX, NX, rows_valid, lane, xv);
         if constexpr (SD.n_y > 0) stage_load<SD.n_y>(y + b0 * SD.n_y, SD.n_y, rows_valid, lane, yv);
-        d2* dst = (d2*)lds;
+        if constexpr (!VALUES) {
+            d2* dst = (d2*)lds;
 #pragma unroll
-        for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
+            for (int k = 0; k < LY::IMG_CHUNKS; ++k) dst[k * WAVE + lane] = img[k];
+        }
         rows_to_lds<NQ>(qv, zs, lane);
         if constexpr (NX > 0) rows_to_lds<NX>(xv, xs, lane);
         if constexpr (SD.n_y > 0) rows_to_lds<SD.n_y>(yv, ys, lane);
     }
     __syncthreads();
-    // register copies of the skill image and the QP options (see pinv_solve_static_kernel)
-    const Img<SD> Sreg = *(const Img<SD>*)lds;
-    const QpTail Treg = *(const QpTail*)((const char*)lds + LY::TAIL_OFF);
+    // register copies of the skill image and the QP options (see pinv_solve_static_kernel), or their values
+    constexpr QpImg<SD> kValues = qp_values_or_zero<SD, IMGV>();     // (a local constant: its loads fold to immediates)
+    const Img<SD> Sreg = VALUES ? kValues.img : *(const Img<SD>*)lds;
+    const QpTail Treg = VALUES ? kValues.tail : *(const QpTail*)((const char*)lds + LY::TAIL_OFF);
     const Img<SD>* __restrict__ S = &Sreg;
     const QpTail* __restrict__ T = &Treg;
     const double* ysl = ys + lane * SD.n_y;
@@ -1360,6 +1380,41 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_kernel(
     const TickArgs tk)
 {
     qp_solve_static_body<SD, false>(img_g, q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk, nullptr);
+}
+
+template <const ShapeDesc& SD, class IMGV>
+constexpr QpImg<SD> qp_values_or_zero()
+{
+    if constexpr (std::is_void<IMGV>::value) return QpImg<SD>{};
+    else return IMGV::value;
+}
+
+// the per-tick kernel with the skill's numbers and the QP options compiled in (clik_qp_attach_value_kernel)
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    qp_solve_static_body<SD, false, IMGV>(nullptr, q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk, nullptr);
+}
+
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const double* q, const double* x,
+                                          const double* y, double* dq, double* dx, double* slack, int32_t* status,
+                                          int32_t* hot_set, int use_hot, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)qp_solve_static_values_kernel<SD, IMGV>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((qp_solve_static_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), shmem, stream, q, y, dq, slack,
+                       status, B, x, dx, hot_set, use_hot, tk);
+    return hipGetLastError();
 }
 
 template <const ShapeDesc& SD>

@@ -286,6 +286,12 @@ const char* clik_qp_kernel_name(const clik_qp* h);
  * JIT-compiles its H/A/lbA/ubA functions at the same point.                   */
 int clik_qp_shape_describe(const clik_skill_desc* desc, char* buf, int cap);
 int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, void* rollout_fn, const char* name);
+/* Value-specialised per-tick QP kernel (see clik_pinv_attach_value_kernel): clik_qp_image_words returns the skill
+ * image and the QP options (weights, weight shifter, iteration cap) of the handle as 64-bit words;
+ * casclik_amd/jit.py compiles them into the kernel template and attaches the result, which then serves
+ * clik_qp_solve_batch / _hot at every batch size (solve_fn = NULL detaches).  Needs a shape-specialised kernel. */
+int clik_qp_image_words(const clik_qp* h, uint64_t* buf, int cap);
+int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn);
 
 /* replaces solve() (reactive_qp.py:461-528).
  *   dq [B][n_q], dx [B][n_x] or NULL, slack [B][n_slack] or NULL  (device, out)

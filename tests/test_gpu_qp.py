@@ -503,3 +503,30 @@ def test_box_family_contradicting_bounds_are_infeasible(iiwa_fk):
     assert infeasible.sum() > 20 and clear.sum() > 20
     assert (status[infeasible] == 2).all() and np.isnan(dq[infeasible]).all()
     assert (status[clear] == 0).all() and np.isfinite(dq[clear]).all()
+
+
+def test_qp_value_specialised_kernel(iiwa_fk):
+    """function_opts["jit_values"] = True: the per-tick QP kernel with the skill's numbers and the QP options compiled
+    in (clik_qp_attach_value_kernel) returns what the image-reading kernel returns, cold and hot-started, and keeps
+    doing so when the handle's options differ (custom weights are part of the compiled-in values)"""
+    import torch
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 1000, seed=41, distribution="mixed")
+    ws = [3.0, 1.0, 2.0, 1.0, 1.0, 0.5]
+    for extra in ({}, {"slack_var_weights": ws}):
+        val = _controller(spec, options={"function_opts": {"jit_values": True}}, **extra)
+        img = _controller(spec, **extra)
+        assert val.value_kernel and val.kernel_variant(1000).endswith("/v") and not img.kernel_variant(1000).endswith("/v")
+        dq, _, slack, status = val.solve_batch(0.0, Q, input_var=Y)
+        dq2, _, slack2, status2 = img.solve_batch(0.0, Q, input_var=Y)
+        assert np.array_equal(status, status2) and (status == 0).all()
+        assert np.allclose(dq, dq2, rtol=1e-9, atol=1e-11) and np.allclose(slack, slack2, rtol=1e-9, atol=1e-11)
+        hot = torch.zeros(1000, dtype=torch.int32, device="cuda")
+        Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+        val.solve_batch(0.0, Qd, input_var=Yd, hot_set=hot, use_hot=False)
+        d3 = val.solve_batch(0.0, Qd, input_var=Yd, hot_set=hot, use_hot=True)[0].cpu().numpy()
+        assert np.allclose(d3, dq, rtol=1e-9, atol=1e-11)
+    weights = clik_oracle.qp_weights(spec, slack_var_weights=ws)
+    rdq = clik_oracle.qp_solve_batch(spec, 0.0, Q[:60], Y=Y[:60], weights=weights)[0]
+    assert _rel(dq[:60], rdq).max() < QP_RTOL

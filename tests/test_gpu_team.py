@@ -165,3 +165,27 @@ def test_value_specialised_and_image_reading_team_kernels_agree(iiwa_fk, ur5_fk,
     ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q[:400], Y=Y[:400])
     assert np.array_equal(mode_v, mode_i) and np.array_equal(mode_v[:400], ref_mode)
     assert _rel(dq_v, dq_i).max() < PINV_RTOL and _rel(dq_v[:400], ref).max() < PINV_RTOL
+
+
+@pytest.mark.parametrize("skill", ["pose", "position"])
+def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
+    """BASELINE configs 1 / 2 (single task, one mode): on request (function_opts["jit_values"] = True) the small-batch
+    kernel is instantiated with the skill's numbers compiled in (no skill image, no LDS staging: "lanev"); larger
+    batches keep the kernel that reads the image; both match the oracle and each other"""
+    from oracle import clik_oracle
+    from casclik_amd import skills
+    spec = skills.pose_skill(iiwa_fk) if skill == "pose" else skills.position_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options={"function_opts": {"jit_values": True}})
+    ctrl.setup_problem_functions()
+    plain = cc.PseudoInverseController(skill_spec=spec)
+    plain.setup_problem_functions()
+    assert ctrl.kernel_variant(4096).endswith("lanev") and ctrl.kernel_variant(65536).endswith("lane")
+    assert plain.kernel_variant(4096).endswith("lane")
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 4133, seed=3, distribution="mixed")
+    Y = Y[:, :spec.n_input_var]
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q[::7], Y=Y[::7])
+    assert np.array_equal(mode[::7], rmode)
+    assert (np.abs(dq[::7] - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))).max() < 1e-7
+    dq2, _, mode2 = plain.solve_batch(0.0, Q, input_var=Y)
+    assert np.array_equal(mode, mode2) and np.allclose(dq, dq2, rtol=1e-9, atol=1e-11)
