@@ -901,9 +901,10 @@ static int pinv_solve_common(const clik_pinv* h, int64_t B, const double* tterms
                                  t_inst};
     // a value-specialised kernel serves the batches the image-reading team kernel would serve (config-3 family), or
     // the small batches of a single-mode skill
+    const bool lane_values = clik::shape_value_lane_ok_rt(S.shape) && B <= clik::pinv_value_lane_max_batch();
     const bool team_batch = clik::shape_team_ok_rt(S.shape)
-                                ? ((h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch()))
-                                : (clik::shape_value_lane_ok_rt(S.shape) && B <= clik::pinv_value_lane_max_batch());
+                                ? ((h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch()) || lane_values)
+                                : lane_values;
     hipError_t e = (h->val_solve && team_batch && t_inst == nullptr)
                        ? h->val_solve(&la, &tk, (long long)B, q, y, dq, mode, (hipStream_t)stream)
                    : h->jit_solve
