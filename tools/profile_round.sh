@@ -34,6 +34,12 @@ for V in team4v:0:1 team4:0:0 lane:1:1; do
     done
 done
 unset CLIK_JIT_VALUES
+run_stats pose_lanev --workload pose
+rm -f $OUT/pmc_pose_lanev.txt
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+         "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+    run_pmc pose_lanev "$C" --workload pose
+done
 run_stats qp --workload qp
 rm -f $OUT/pmc_qp.txt
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
