@@ -114,3 +114,29 @@ def test_expression_attributes_need_the_instantiated_kernel(ur5_fk, monkeypatch)
     with pytest.raises(NotImplementedError):
         ctrl.setup_problem_functions()
         ctrl.solve_batch(0.0, _states(lo, hi, 4, 1))
+
+
+def test_expression_attributes_with_one_time_per_instance(ur5_fk):
+    """time-dependent gains / bounds and time_var with one entry per instance: the generated attribute code reads
+    the instance's own time-slot record (clik_pinv_solve_batch_t / clik_qp_solve_batch_t)"""
+    spec, lo, hi = _stack(ur5_fk, 6)
+    opts = {"multidim_sets": True}
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=opts)
+    ctrl.setup_problem_functions()
+    Q = _states(lo, hi, 90, 12)
+    times = np.random.default_rng(13).uniform(0.0, 6.0, size=90)
+    dq, _, mode = ctrl.solve_batch(times, Q)
+    for b in range(0, 90, 4):
+        ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, float(times[b]), Q[b:b + 1])
+        assert mode[b] == rmode[0]
+        assert np.abs(dq[b] - ref[0]).max() < PINV_RTOL * (1.0 + np.abs(ref).max())
+    qp = cc.ReactiveQPController(skill_spec=spec)
+    qp.setup_problem_functions()
+    qp.setup_solver()
+    r = hi - lo
+    Qi = np.random.default_rng(14).uniform(lo + 0.15 * r, hi - 0.15 * r, size=(90, 6))
+    dq, _, slack, status = qp.solve_batch(times, Qi)
+    assert (status == 0).all()
+    for b in range(0, 90, 6):
+        rdq = clik_oracle.qp_solve_batch(spec, float(times[b]), Qi[b:b + 1])[0]
+        assert np.abs(dq[b] - rdq[0]).max() < QP_RTOL * (1.0 + np.abs(rdq).max())
