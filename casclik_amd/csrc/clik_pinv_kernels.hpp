@@ -754,6 +754,13 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 {
     constexpr int N = SD.n;
     static_assert(StaticLayout<SD>::n_sets <= kStaticMaxSets, "too many SetConstraints for a static shape");
+#ifndef CLIK_NO_SOLO
+    if constexpr (shape_team_ok(SD)) {
+        // the config-3 family: both modes from shifted copies of one Gram matrix (clik_pinv_static.hpp)
+        solo_tick<SD>(S, tk, z, ys, lane, valid, vout, acc_mode);
+        return;
+    }
+#endif
     // FK and the state-dependent task rows once per tick; the FK state dies here
     TaskCache<SD> tc;
     {

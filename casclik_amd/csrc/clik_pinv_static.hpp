@@ -1510,4 +1510,207 @@ __device__ __forceinline__ void helper_mode_static(const Img<SD>* __restrict__ S
     for (int a = 0; a < N; ++a) xch[(NT + a) * WAVE + lane] = rd[a];
 }
 
+// ---- the config-3 family: [joint-limit set on every state; task with m <= n state-dependent rows; joint-space task] -----
+// Both modes of such a skill need only shifted copies of ONE Gram matrix Gm = J J' (J: the m x n Jacobian of the
+// second constraint) - see clik_pinv_team.hpp for the algebra and the four-lanes-per-instance kernel built on it.
+constexpr bool shape_team_ok(const ShapeDesc& sd)
+{
+    if (sd.qp || sd.n_tasks != 3 || sd.n_x != 0 || sd.standard || sd.conv_last || !sd.multidim) return false;
+    if (sd.cls[0] != CLIK_CLS_SET || sd.cls[1] != CLIK_CLS_EQ || sd.cls[2] != CLIK_CLS_EQ) return false;
+    if ((sd.ext[0] | sd.ext[1] | sd.ext[2]) & ~1) return false;      // (gains / bounds given as expressions)
+    // the set covers every state variable exactly once (then  lam I + Jset'Jset = (1+lam) I)
+    if (!shape_unit(sd, 0) || sd.m[0] != sd.n || sd.n < 2) return false;
+    for (int c = 0; c < sd.n; ++c)
+        if (shape_unit_row(sd, 0, c) < 0) return false;
+    if (sd.const_j[1] || sd.m[1] > sd.n || sd.m[1] < 1) return false;
+    if (!shape_unit(sd, 2)) return false;
+    return true;
+}
+
+
+// The same algebra in ONE lane (the lane-per-instance kernels of this family: large batches, rollouts): the three
+// shifted factorisations one after the other, mode 1 only when some lane of the wave needs it.
+//   A0 = Gm + lam I:      y = A0^-1 d1, y2 = A0^-1 y;  mode 0's doubly processed first equality sums to J'(y + lam y2),
+//                         mode 1's task behind the active set is N_set J'y
+//   A1 = 2 Gm + lam I:    mode 0's lower task through [J; J]:   w2 - 2 J' A1^-1 J w2            (push-through)
+//   A2 = Gm + (1+lam) I:  mode 1's lower task through [I; J] with activations s:
+//                         (x - J' A2^-1 J x) / (1+lam),  x = ((1+lam) - s) o w2                  (Woodbury)
+// 1460 instructions when every lane of the wave accepts mode 0 and 1770 with mode 1, against 1600 / 2800 of the
+// plan-driven evaluation (pinv_mode_static) this replaces for the family; same values to rounding (PINV_RTOL).
+// -DCLIK_NO_SOLO keeps the plan-driven evaluation (regression switch).
+template <const ShapeDesc& SD>
+__device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const TickArgs& tk, const double (&z)[SD.n],
+                                          const double* ys, const int lane, const bool valid, double (&vout)[SD.n],
+                                          int& acc_mode)
+{
+    constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2];
+    constexpr int NT = M * (M + 1) / 2;
+    TaskCache<SD> tc;
+    {
+        Kin<N> K;
+        if constexpr (SD.uses_fk != 0) {
+            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
+        }
+        cache_task<SD, 0>(S, tk, K, z, ys, lane, tc);
+    }
+    const double lam = S->lam;
+    const double one_lam = 1.0 + lam;
+    // desired task velocities  d = -K e - de/dt   (pseudo_inverse.py:318-321, :383-386)
+    double des1[M], w2[N];
+    {
+        double e[M], Jt[M], ke[M];
+        task_values<SD, 1>(S, tk, tc, z, ys, lane, e, Jt);
+        gain_apply_s<M, SD.gain_matrix[1] != 0>(S->tasks[1], e, ke);
+#pragma unroll
+        for (int i = 0; i < M; ++i) des1[i] = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
+    }
+    {
+        // w2 = pinv(J2) d2 of the joint-space task: one entry per row (host-side pinv of the unit rows)
+        double e[M2], Jt[M2], ke[M2];
+        task_values<SD, 2>(S, tk, tc, z, ys, lane, e, Jt);
+        gain_apply_s<M2, SD.gain_matrix[2] != 0>(S->tasks[2], e, ke);
+#pragma unroll
+        for (int j = 0; j < N; ++j) w2[j] = 0.0;
+        const double* Pm = S->cpinv[2];
+        static_for<0, M2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int col = SD.ucol[2][i] - 1;
+            const double d = SD.feedforward != 0 ? -ke[i] - Jt[i] : -ke[i];
+            w2[col] = Pm[col * CLIK_MAX_M + i] * d;
+        });
+    }
+    // Gm = J J'
+    double Gm[NT];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k <= i; ++k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
+            Gm[tri(i, k)] = acc;
+        }
+    // t = (alpha Gm + beta I)^-1 rhs, in place; the factor stays in A / rd
+    auto shifted = [&](const double alpha, const double beta, double (&A)[NT], double (&rd)[M]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? fma(alpha, Gm[tri(i, k)], beta) : alpha * Gm[tri(i, k)];
+        ldl_factor_s<M>(A, rd);
+    };
+    auto jt_times = [&](const double (&t)[M], double (&g)[N]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) sacc = fma(jac<SD, 1>(S, tc, i, j), t[i], sacc);
+            g[j] = sacc;
+        }
+    };
+    auto j_times = [&](const double (&x)[N], double (&t)[M]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) sacc = fma(jac<SD, 1>(S, tc, i, j), x[j], sacc);
+            t[i] = sacc;
+        }
+    };
+    // A0: the first equality, processed twice (mode 0) / once behind the set (mode 1)
+    double g3[N], v0[N];
+    {
+        double A[NT], rd[M], y[M], y2[M], gy2[N];
+        shifted(1.0, lam, A, rd);
+#pragma unroll
+        for (int i = 0; i < M; ++i) y[i] = des1[i];
+        ldl_solve_s<M>(A, rd, y);
+#pragma unroll
+        for (int i = 0; i < M; ++i) y2[i] = y[i];
+        ldl_solve_s<M>(A, rd, y2);
+        jt_times(y, g3);
+        jt_times(y2, gy2);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v0[j] = fma(lam, gy2[j], g3[j]);
+    }
+    // A1: mode 0's lower task
+    {
+        double A[NT], rd[M], t1[M], g1[N];
+        shifted(2.0, lam, A, rd);
+        j_times(w2, t1);
+        ldl_solve_s<M>(A, rd, t1);
+        jt_times(t1, g1);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v0[j] += fma(-2.0, g1[j], w2[j]);
+    }
+    // the set: tangent-cone test of the mode-0 candidate (:222-252), its activation by state column
+    double e0[M0], Jt0[M0];
+    task_values<SD, 0>(S, tk, tc, z, ys, lane, e0, Jt0);
+    bool in_tc;
+    {
+        const clik_task& t = S->tasks[0];
+        double le[M0], ue[M0];
+        bool inside = true;
+#pragma unroll
+        for (int i = 0; i < M0; ++i) {
+            le[i] = e0[i] - t.set_min[i];
+            ue[i] = e0[i] - t.set_max[i];
+            inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
+        }
+        in_tc = true;
+        if (__ballot(!inside) != 0ull) {
+            bool corner = true;
+            double od = 0.0, nde = 0.0, nout = 0.0;
+            static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int col = SD.ucol[0][i] - 1;
+                const double de = Jt0[i] + v0[col];
+                const double hl = half_sign(le[i]), hu = half_sign(ue[i]);     // (sign(le) + sign(ue)) / 2 = hl + hu
+                corner = corner & (hl == hu);
+                const double out = hl + hu;
+                od = fma(out, de, od);
+                nde = fma(de, de, nde);
+                nout = fma(out, out, nout);
+            });
+            bool going_in = od < 0.0;
+            if (__ballot(corner & !inside) != 0ull) {
+                const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
+                const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
+                going_in = corner ? steep : going_in;
+            }
+            in_tc = inside | going_in;
+        }
+    }
+    acc_mode = valid ? (in_tc ? 0 : 1) : -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vout[j] = v0[j];
+    // mode 1 (set active; no inactive set left: always accepted) only when some lane needs it
+    if (__ballot(valid & !in_tc) != 0ull) {
+        double sact[N], p0[N], x[N];
+        static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int col = SD.ucol[0][i] - 1;
+            sact[col] = ((e0[i] - S->tasks[0].set_max[i] > 0.0) | (e0[i] - S->tasks[0].set_min[i] < 0.0)) ? 1.0 : 0.0;
+            p0[col] = S->cpinv[0][col * CLIK_MAX_M + i];
+        });
+#pragma unroll
+        for (int j = 0; j < N; ++j) x[j] = w2[j] * (one_lam - sact[j]);
+        double A[NT], rd[M], t2[M], g2[N];
+        shifted(1.0, one_lam, A, rd);
+        j_times(x, t2);
+        ldl_solve_s<M>(A, rd, t2);
+        jt_times(t2, g2);
+        const double kap = 1.0 / one_lam;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double v1 = fma(g3[j], fma(-p0[j], sact[j], 1.0), kap * (x[j] - g2[j]));
+            vout[j] = in_tc ? vout[j] : v1;
+        }
+    }
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) vout[j] = 0.0;
+    }
+}
+
 }  // namespace clik

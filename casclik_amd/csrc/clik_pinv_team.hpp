@@ -47,20 +47,6 @@ constexpr int TEAM = 4;                     // lanes per instance = one DPP quad
 constexpr int TEAM_WAVES = 4;               // waves per block: 64 instances, one wave per SIMD of a CU
 constexpr int TEAM_INST = TEAM_WAVES * WAVE / TEAM;
 
-constexpr bool shape_team_ok(const ShapeDesc& sd)
-{
-    if (sd.qp || sd.n_tasks != 3 || sd.n_x != 0 || sd.standard || sd.conv_last || !sd.multidim) return false;
-    if (sd.cls[0] != CLIK_CLS_SET || sd.cls[1] != CLIK_CLS_EQ || sd.cls[2] != CLIK_CLS_EQ) return false;
-    if ((sd.ext[0] | sd.ext[1] | sd.ext[2]) & ~1) return false;      // (gains / bounds given as expressions)
-    // the set covers every state variable exactly once (then  lam I + Jset'Jset = (1+lam) I)
-    if (!shape_unit(sd, 0) || sd.m[0] != sd.n || sd.n < 2) return false;
-    for (int c = 0; c < sd.n; ++c)
-        if (shape_unit_row(sd, 0, c) < 0) return false;
-    if (sd.const_j[1] || sd.m[1] > sd.n || sd.m[1] < 1) return false;
-    if (!shape_unit(sd, 2)) return false;
-    return true;
-}
-
 // value of lane SRC_EVEN / SRC_ODD of each lane pair of the quad (pairs (0,1) and (2,3))
 template <int CTRL>
 __device__ __forceinline__ double quad_perm_f64(const double x)
