@@ -1315,7 +1315,10 @@ __global__ __launch_bounds__(WAVE) CLIK_ROLL_ATTR void pinv_rollout_static_kerne
 #include "clik_pinv_team.hpp"   // four lanes per instance (needs StaticLayout)
 namespace clik {
 
-// value-specialised lane kernel (pinv_solve_static_values_kernel): skills with up to this many SetConstraints
+// value-specialised lane kernel (pinv_solve_static_values_kernel): single-mode skills, and the config-3 family
+// (whose lane evaluation, solo_tick, beats the one-wave-per-mode kernel once the numbers are compiled in: 5.19 / 5.26 /
+// 5.44 us against 5.87 / 5.89 / 5.98 us at 20480 / 24576 / 32768 instances); other skills with up to
+// CLIK_VALUE_LANE_MAX_SETS SetConstraints as an experiment switch (plan-driven sequential modes: 0-6 % over mp2)
 #ifndef CLIK_VALUE_LANE_MAX_SETS
 #define CLIK_VALUE_LANE_MAX_SETS 0
 #endif
@@ -1388,7 +1391,8 @@ inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long l
     if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch)))
         return (mode_parallel & 64) ? "team4v" : "team4";       // bit 6: a value-specialised team kernel is attached
     const int ns = shape_n_sets(sd);
-    if ((mode_parallel & 64) && sd.n_x == 0 && ns <= CLIK_VALUE_LANE_MAX_SETS && !sd.qp && B <= 32768) return "lanev";   // value-specialised lane kernel attached
+    if ((mode_parallel & 64) && sd.n_x == 0 && !sd.qp && (ns <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd)) && B <= 32768)
+        return "lanev";   // value-specialised lane kernel attached
     if (sd.n_x == 0 && ns <= 1 && B <= kRoleSplitMaxBatch && (mode_parallel & 2)) {
         bool ok = true;
         for (int k = 0; k < (1 << ns); ++k) ok = ok && make_plan(sd, shape_mode_act(sd, k)).helper_ok;
@@ -1489,7 +1493,10 @@ inline hipError_t launch_rollout_team_values(const LaunchArgs& a, const double* 
 constexpr long long kValueLaneMaxBatch = 32768;
 // single-mode skills without virtual variables (skills with SetConstraints keep the one-wave-per-mode kernels at
 // small batches, the config-3 family its four lanes per instance)
-constexpr bool shape_value_lane_ok(const ShapeDesc& sd) { return sd.n_x == 0 && shape_n_sets(sd) <= CLIK_VALUE_LANE_MAX_SETS && !sd.qp; }
+constexpr bool shape_value_lane_ok(const ShapeDesc& sd)
+{
+    return sd.n_x == 0 && !sd.qp && (shape_n_sets(sd) <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd));
+}
 template <const ShapeDesc& SD, class IMGV>
 __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_kernel(
     const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,

@@ -137,7 +137,10 @@ def test_default_selection_by_batch(iiwa_fk, monkeypatch):
     ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(iiwa_fk), options=dict(skills.STACK_OPTIONS))
     ctrl.setup_problem_functions()
     assert ("/team4" in ctrl.kernel_variant(16384))
-    assert ctrl.kernel_variant(32768).endswith("/mp2")
+    # between the team kernel's range and 32768: one lane per instance with the skill's numbers compiled in when that
+    # kernel is attached (the default), else one wave per mode reading the image
+    assert ctrl.kernel_variant(32768).endswith("/lanev" if ctrl.value_kernel else "/mp2")
+    assert ctrl.kernel_variant(65536).endswith("/lane")
     assert ctrl.kernel_variant(131072).endswith("/lane")
     assert ctrl.kernel_variant(1 << 20).endswith("/lane/occ2")      # (the ahead-of-time shapes' large-batch build)
     pose = cc.PseudoInverseController(skill_spec=skills.pose_skill(iiwa_fk))
@@ -165,6 +168,29 @@ def test_value_specialised_and_image_reading_team_kernels_agree(iiwa_fk, ur5_fk,
     ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q[:400], Y=Y[:400])
     assert np.array_equal(mode_v, mode_i) and np.array_equal(mode_v[:400], ref_mode)
     assert _rel(dq_v, dq_i).max() < PINV_RTOL and _rel(dq_v[:400], ref).max() < PINV_RTOL
+
+
+def test_value_specialised_lane_kernel_of_the_stack_between_16385_and_32768(iiwa_fk):
+    """the config-3 family beyond the team kernel's batch range: "lanev" (solo_tick with the numbers compiled in)
+    against the oracle, the image-reading kernels and the team kernel on shared instances"""
+    from oracle import c_oracle
+    spec, opts = skills.stack_skill(iiwa_fk), dict(skills.STACK_OPTIONS)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
+    ctrl.setup_problem_functions()
+    plain = cc.PseudoInverseController(skill_spec=spec, options=dict(opts, function_opts={"jit_values": False}))
+    plain.setup_problem_functions()
+    B = 20000
+    assert ctrl.kernel_variant(B).endswith("/lanev") and plain.kernel_variant(B).endswith("/mp2")
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=17, distribution="mixed")
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    dq2, _, mode2 = plain.solve_batch(0.0, Q, input_var=Y)
+    co = c_oracle.CPinvOracle(spec, opts)
+    ref, _, rmode = co.solve_batch(0.0, Q, Y=Y)
+    assert set(np.unique(rmode)) == {0, 1}
+    assert np.array_equal(mode, rmode) and np.array_equal(mode2, rmode)
+    assert _rel(dq, ref).max() < PINV_RTOL and _rel(dq, dq2).max() < PINV_RTOL
+    dq3, _, mode3 = ctrl.solve_batch(0.0, Q[:16384], input_var=Y[:16384])          # (team4v on the same instances)
+    assert np.array_equal(mode3, rmode[:16384]) and _rel(dq3, dq[:16384]).max() < PINV_RTOL
 
 
 @pytest.mark.parametrize("skill", ["pose", "position"])
