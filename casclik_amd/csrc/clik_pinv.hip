@@ -84,7 +84,7 @@ const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long lon
 bool shape_team_ok_rt(const ShapeDesc& sd) { return shape_team_ok(sd); }
 long long pinv_team_max_batch() { return kTeamMaxBatch; }
 bool shape_value_lane_ok_rt(const ShapeDesc& sd) { return shape_value_lane_ok(sd); }
-long long pinv_value_lane_max_batch() { return 32768; }
+long long pinv_value_lane_max_batch() { return kValueLaneMaxBatch; }
 int pinv_kernel_width(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].N : 0; }
 int pinv_kernel_is_static(int k) { return (k >= 0 && k < kNumShapes && kShapes[k].sd) ? 1 : 0; }
 

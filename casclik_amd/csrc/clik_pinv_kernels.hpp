@@ -1322,6 +1322,12 @@ namespace clik {
 #ifndef CLIK_VALUE_LANE_MAX_SETS
 #define CLIK_VALUE_LANE_MAX_SETS 0
 #endif
+// ... at every batch size: without an image in LDS or registers the kernel fits two waves per SIMD with no spill,
+// and the rows a lane loads / stores itself cost nothing measurable - config 3: 6.18 against 7.19 us at 65536
+// instances, 10.2 against 13.3 us at 131072, 67.7 against 87.2 us at 1 M (CLIK_VALUE_LANE_MAX_BATCH caps it)
+#ifndef CLIK_VALUE_LANE_MAX_BATCH
+#define CLIK_VALUE_LANE_MAX_BATCH (1ll << 40)
+#endif
 
 // common launcher signature of the kernel table
 struct LaunchArgs {
@@ -1391,7 +1397,7 @@ inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long l
     if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch)))
         return (mode_parallel & 64) ? "team4v" : "team4";       // bit 6: a value-specialised team kernel is attached
     const int ns = shape_n_sets(sd);
-    if ((mode_parallel & 64) && sd.n_x == 0 && !sd.qp && (ns <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd)) && B <= 32768)
+    if ((mode_parallel & 64) && sd.n_x == 0 && !sd.qp && (ns <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd)) && B <= CLIK_VALUE_LANE_MAX_BATCH)
         return "lanev";   // value-specialised lane kernel attached
     if (sd.n_x == 0 && ns <= 1 && B <= kRoleSplitMaxBatch && (mode_parallel & 2)) {
         bool ok = true;
@@ -1489,8 +1495,8 @@ inline hipError_t launch_rollout_team_values(const LaunchArgs& a, const double* 
 // The lane-per-instance kernel with the skill's numbers compiled in (IMGV::value: the skill image as a constant
 // expression, see clik_pinv_team.hpp): nothing is staged through LDS - no image copy, no barrier - every lane
 // loads its own robot_var / input_var row and stores its own velocity row.  For the small batches where a tick
-// is the latency of one wave (kValueLaneMaxBatch); larger batches keep the kernel with the coalesced row blocks.
-constexpr long long kValueLaneMaxBatch = 32768;
+// is the latency of one wave, and - measured - for the large ones too (see CLIK_VALUE_LANE_MAX_BATCH above).
+constexpr long long kValueLaneMaxBatch = CLIK_VALUE_LANE_MAX_BATCH;
 // single-mode skills without virtual variables (skills with SetConstraints keep the one-wave-per-mode kernels at
 // small batches, the config-3 family its four lanes per instance)
 constexpr bool shape_value_lane_ok(const ShapeDesc& sd)

@@ -137,12 +137,18 @@ def test_default_selection_by_batch(iiwa_fk, monkeypatch):
     ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(iiwa_fk), options=dict(skills.STACK_OPTIONS))
     ctrl.setup_problem_functions()
     assert ("/team4" in ctrl.kernel_variant(16384))
-    # between the team kernel's range and 32768: one lane per instance with the skill's numbers compiled in when that
-    # kernel is attached (the default), else one wave per mode reading the image
-    assert ctrl.kernel_variant(32768).endswith("/lanev" if ctrl.value_kernel else "/mp2")
-    assert ctrl.kernel_variant(65536).endswith("/lane")
-    assert ctrl.kernel_variant(131072).endswith("/lane")
-    assert ctrl.kernel_variant(1 << 20).endswith("/lane/occ2")      # (the ahead-of-time shapes' large-batch build)
+    # beyond the team kernel's range: one lane per instance with the skill's numbers compiled in ("lanev") when the
+    # value-specialised build is attached (the default where hipcc is available); without it one wave per mode up to
+    # 32768 instances, one lane per instance above, the two-waves-per-SIMD build from 524288 on
+    assert ctrl.value_kernel
+    for B in (32768, 65536, 131072, 1 << 20):
+        assert ctrl.kernel_variant(B).endswith("/lanev")
+    img = cc.PseudoInverseController(skill_spec=skills.stack_skill(iiwa_fk),
+                                     options=dict(skills.STACK_OPTIONS, function_opts={"jit_values": False}))
+    img.setup_problem_functions()
+    assert img.kernel_variant(16384).endswith("/team4") and img.kernel_variant(32768).endswith("/mp2")
+    assert img.kernel_variant(131072).endswith("/lane")
+    assert img.kernel_variant(1 << 20).endswith("/lane/occ2")      # (the ahead-of-time shapes' large-batch build)
     pose = cc.PseudoInverseController(skill_spec=skills.pose_skill(iiwa_fk))
     pose.setup_problem_functions()
     assert pose.kernel_variant(16384).endswith("/lane")
@@ -205,7 +211,7 @@ def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
     ctrl.setup_problem_functions()
     plain = cc.PseudoInverseController(skill_spec=spec)
     plain.setup_problem_functions()
-    assert ctrl.kernel_variant(4096).endswith("lanev") and ctrl.kernel_variant(65536).endswith("lane")
+    assert ctrl.kernel_variant(4096).endswith("lanev") and ctrl.kernel_variant(65536).endswith("lanev")
     assert plain.kernel_variant(4096).endswith("lane")
     Q, Y = skills.synthetic_inputs(iiwa_fk, 4133, seed=3, distribution="mixed")
     Y = Y[:, :spec.n_input_var]
