@@ -820,7 +820,6 @@ extern "C" int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void*
     if (solve_fn && !clik::shape_team_ok_rt(h->host.shape) && !clik::shape_value_lane_ok_rt(h->host.shape))
         return fail(CLIK_EUNSUPPORTED, "value-specialised kernels exist for the four-lanes-per-instance family and for "
                                        "single-mode skills without virtual variables");
-    if (solve_fn && !clik::shape_team_ok_rt(h->host.shape)) rollout_fn = nullptr;      // (no value-specialised rollout there)
     h->val_solve = (clik_jit_value_fn)solve_fn;
     h->val_rollout = solve_fn ? (clik_jit_rollout_fn)rollout_fn : nullptr;
     if (solve_fn) h->mode_parallel |= 64;
@@ -995,8 +994,12 @@ extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t 
     int rc = stage_tterms(tterms, (size_t)n_ticks * stages * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
     if (rc) return rc;
     const clik::LaunchArgs la = {h->dev, h->d_img, &h->warm, S.d.n_q, S.d.n_x, S.d.n_y, h->mode_parallel, x, dx, stages, nullptr};
-    const bool team_batch = (h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch());
-    hipError_t e = (h->val_rollout && team_batch)
+    // the value-specialised rollout serves the batches its per-tick kernel serves (see pinv_solve_common)
+    const bool lane_values = clik::shape_value_lane_ok_rt(S.shape) && B <= clik::pinv_value_lane_max_batch();
+    const bool team_batch = clik::shape_team_ok_rt(S.shape)
+                                ? ((h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch()) || lane_values)
+                                : lane_values;
+    hipError_t e = (h->val_rollout && team_batch && S.d.n_x == 0)
                        ? h->val_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
                                         (hipStream_t)stream)
                    : h->jit_rollout

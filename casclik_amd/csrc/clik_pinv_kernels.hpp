@@ -1551,15 +1551,106 @@ inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, l
     return hipErrorNotSupported;
 }
 
+// ... and its on-device rollout (see pinv_rollout_static_kernel): state in registers from tick to tick, the rows
+// loaded once and stored once by the lane itself, no LDS (the Runge-Kutta bookkeeping lives in registers here: without
+// the image there is room)
+template <const ShapeDesc& SD, class IMGV, bool RK>
+__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_rollout_static_values_kernel(
+    double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq, int32_t* __restrict__ mode_out,
+    const long long B, const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed)
+{
+    static_assert(SD.n_x == 0, "value-specialised lane kernel: robot variables only");
+    constexpr int N = SD.n;
+    constexpr Img<SD> Sval = IMGV::value;
+    constexpr int stages = RK ? 4 : 1;
+    const int lane = threadIdx.x;
+    const long long inst = (long long)blockIdx.x * WAVE + lane;
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    const int nts = Sval.n_tslots;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = q[row * N + j];
+    const double* ys = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double vout[N];
+    int acc_mode = -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vout[j] = 0.0;
+#pragma unroll 1
+    for (int tick = 0; tick < n_ticks; ++tick) {
+        if constexpr (!RK) {
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
+            pinv_tick_static<SD>(&Sval, tk, z, ys, lane, valid, vout, acc_mode);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double d = vout[j];
+                if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                vout[j] = d;
+                z[j] = fma(d, dt, z[j]);
+            }
+        } else {
+            double z0[N], ks[N];
+            int mode0 = -1;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                z0[j] = z[j];
+                ks[j] = 0.0;
+            }
+#pragma unroll 1
+            for (int st = 0; st < stages; ++st) {
+                const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + st) * 2 * nts);
+                pinv_tick_static<SD>(&Sval, tk, z, ys, lane, valid, vout, acc_mode);
+                const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
+                const double cnext = (st == 2) ? dt : 0.5 * dt;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double d = vout[j];
+                    if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                    ks[j] = fma(wgt, d, ks[j]);
+                    z[j] = fma(d, cnext, z0[j]);
+                }
+                mode0 = (st == 0) ? acc_mode : mode0;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                vout[j] = ks[j] * (1.0 / 6.0);
+                z[j] = fma(vout[j], dt, z0[j]);
+            }
+            acc_mode = mode0;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            q[inst * N + j] = z[j];
+            dq[inst * N + j] = vout[j];
+        }
+        if (mode_out != nullptr) mode_out[inst] = acc_mode;
+    }
+}
+
 template <const ShapeDesc& SD, class IMGV>
 inline hipError_t launch_rollout_values(const LaunchArgs& a, const double* d_tterms, int n_ticks, double dt,
                                         double max_speed, long long B, double* q, const double* y, double* dq,
                                         int32_t* mode, hipStream_t stream)
 {
-    if constexpr (shape_team_ok(SD))
-        return launch_rollout_team_values<SD, IMGV>(a, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, mode, stream);
-    else
-        return hipErrorNotSupported;
+    if constexpr (shape_team_ok(SD)) {
+        if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch))
+            return launch_rollout_team_values<SD, IMGV>(a, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, mode, stream);
+    }
+    if constexpr (shape_value_lane_ok(SD)) {
+        if (B <= kValueLaneMaxBatch) {
+            const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+            if (a.roll_stages == 4)
+                hipLaunchKernelGGL((pinv_rollout_static_values_kernel<SD, IMGV, true>), dim3(grid), dim3(WAVE), 0, stream,
+                                   q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
+            else
+                hipLaunchKernelGGL((pinv_rollout_static_values_kernel<SD, IMGV, false>), dim3(grid), dim3(WAVE), 0, stream,
+                                   q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
+            return hipGetLastError();
+        }
+    }
+    return hipErrorNotSupported;
 }
 
 template <const ShapeDesc& SD>
