@@ -110,8 +110,6 @@ def make_workload(name, fk):
         spec, opts = skills.pose_skill(fk), None
         ctrl = cc.PseudoInverseController(skill_spec=spec, options={"function_opts": {"jit_values": True}})
     else:
-        # (the value-specialised QP kernel, function_opts["jit_values"], measures 12.78 against 12.86 us here: the
-        # tick is the solver's passes, not the image traffic - the profiled image-reading kernel stays the bench line)
         spec, opts = skills.qp_skill(fk), None
         ctrl = cc.ReactiveQPController(skill_spec=spec)
     ctrl.setup_problem_functions()

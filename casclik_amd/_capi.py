@@ -178,7 +178,7 @@ _SYMBOLS = [
     "clik_pinv_create", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_shape_describe", "clik_pinv_attach_kernel",
     "clik_pinv_solve_batch", "clik_pinv_solve_batch_t", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
     "clik_qp_create", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
-    "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel", "clik_qp_image_words", "clik_qp_attach_value_kernel",
+    "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel", "clik_qp_image_words", "clik_qp_attach_value_kernel", "clik_qp_is_box_family",
     "clik_qp_solve_batch", "clik_qp_solve_batch_hot", "clik_qp_solve_batch_t", "clik_qp_rollout_batch", "clik_qp_rollout_batch_x", "clik_qp_rollout_batch_m", "clik_qp_data_batch",
 ]
 
@@ -289,6 +289,8 @@ def load_library(path=None):
                                             C.POINTER(C.c_double), dp, dp, dp, dp, dp, dp, ip, vp]
     lib.clik_qp_image_words.restype = C.c_int
     lib.clik_qp_image_words.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    lib.clik_qp_is_box_family.restype = C.c_int
+    lib.clik_qp_is_box_family.argtypes = [vp]
     lib.clik_qp_attach_value_kernel.restype = C.c_int
     lib.clik_qp_attach_value_kernel.argtypes = [vp, vp]
     lib.clik_qp_rollout_batch_m.restype = C.c_int

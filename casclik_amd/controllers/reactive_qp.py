@@ -198,12 +198,16 @@ class ReactiveQPController(BaseController):
                 "the QP of this skill (%d variables x %d rows) exceeds the built-in kernel and no "
                 "shape-specialised kernel could be instantiated for it (jit disabled or hipcc missing)"
                 % (self.n_qp_vars, self.n_qp_rows))
-        # On request (function_opts["jit_values"] = True or CLIK_JIT_VALUES=2): the per-tick kernel with this skill's
-        # numbers and QP options compiled in, as the functions CasADi generates for the reference are
-        # (reactive_qp.py:283-298) - one more hipcc run at set-up, no skill image traffic per tick
+        # The per-tick kernel with this skill's numbers and QP options compiled in, as the functions CasADi generates
+        # for the reference are (reactive_qp.py:283-298): one more hipcc run at set-up.  By default for the box
+        # family (bound-constrained after the soft equalities are folded: config 4, the UR5 notebook stacks), whose
+        # value-specialised kernel needs no LDS at all (config 4: 11.3 against 12.9 us per tick, hot-started 5.6
+        # against 7.4); for other skills on request (function_opts["jit_values"] = True or CLIK_JIT_VALUES=2: it keeps
+        # the LDS work area and gains about 1 %); function_opts["jit_values"] = False or CLIK_JIT_VALUES=0: never.
         self.value_kernel = None
-        if want_jit and (fopts.get("jit_values") is True or os.environ.get("CLIK_JIT_VALUES", "1") == "2") \
-                and os.environ.get("CLIK_JIT_VALUES", "1") != "0" and not d.extern_code \
+        jv, env_jv = fopts.get("jit_values", None), os.environ.get("CLIK_JIT_VALUES", "1")
+        wanted = jv is True or env_jv == "2" or (jv is None and self._lib.clik_qp_is_box_family(handle) == 1)
+        if want_jit and wanted and jv is not False and env_jv != "0" and not d.extern_code \
                 and self.kernel_name not in ("dynamic", "none"):
             from .. import jit
             with torch.cuda.device(self._device):

@@ -59,6 +59,7 @@ int qp_pick_variant(int n, int nv, int nc);
 size_t qp_variant_lds(int k, int ny);
 int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
+bool qp_box_family_rt(const ShapeDesc& sd);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,
@@ -1214,6 +1215,15 @@ extern "C" int clik_qp_image_words(const clik_qp* h, uint64_t* buf, int cap)
     memset(buf, 0, (size_t)words * 8);
     memcpy(buf, img.data(), img.size() < bytes ? img.size() : bytes);
     return words;
+}
+
+// 1: after folding the soft equalities every remaining row of the skill's QP is a hard bound on one state (the
+// family solved by Gauss-Seidel sweeps + the primal active set, and the one whose value-specialised kernel needs no LDS)
+extern "C" int clik_qp_is_box_family(const clik_qp* h)
+{
+    if (!h) return 0;
+    if (!h->jit_solve && h->static_k < 0) return 0;
+    return clik::qp_box_family_rt(h->host.shape) ? 1 : 0;
 }
 
 extern "C" int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn)

@@ -414,6 +414,7 @@ int qp_pick_static(const ShapeDesc& sd)
     return -1;
 }
 const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
+bool qp_box_family_rt(const ShapeDesc& sd) { return CLIK_QP_BOX_OK(sd); }
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,

@@ -620,7 +620,10 @@ __device__ __forceinline__ void qp_bounds_s(const TASK& t, const double (&e)[SD.
 }
 
 // per-task pass 1: bounds; folded tasks accumulate into P and g, the others publish their bounds
-template <const ShapeDesc& SD, int TI>
+// SSTR: stride of the work-area slots - WAVE: the block's LDS area, one column per lane; 1: a private array of the
+// lane (the LDS-free value-specialised kernel of the box family; every slot index is a constant, so it dissolves
+// into registers)
+template <const ShapeDesc& SD, int TI, int SSTR = WAVE>
 __device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
                                             const TickArgs& tk, const TaskCache<SD>& tc, const double (&z)[SD.n],
                                             const double* ys, const int lane,
@@ -641,7 +644,7 @@ __device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const
                 constexpr int i = decltype(ic)::value;
                 const double hs = T->mu + T->slack_w[sb + i];
                 const double hb = hs * lo[i];
-                slots[(LY::O_SL + sb + i) * WAVE + lane] = lo[i];
+                slots[(LY::O_SL + sb + i) * SSTR + (SSTR == 1 ? 0 : lane)] = lo[i];
                 if constexpr (shape_unit(SD, TI)) {
                     constexpr int col = SD.ucol[TI][i] - 1;
                     Pm[tri(col, col)] += hs;
@@ -664,8 +667,8 @@ __device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const
             static_for<0, M>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int row = P.row_of[TI][i];
-                double* lbp = slots + (LY::O_LB + row) * WAVE + lane;
-                double* ubp = slots + (LY::O_UB + row) * WAVE + lane;
+                double* lbp = slots + (LY::O_LB + row) * SSTR + (SSTR == 1 ? 0 : lane);
+                double* ubp = slots + (LY::O_UB + row) * SSTR + (SSTR == 1 ? 0 : lane);
                 if constexpr (P.merged[TI][i]) {
                     // (the row was written by the earlier constraint of the pair: tasks are gathered in order)
                     *lbp = fmax(*lbp, lo[i]);
@@ -676,7 +679,7 @@ __device__ __forceinline__ void qp_gather_s(const Img<SD>* __restrict__ S, const
                 }
             });
         }
-        qp_gather_s<SD, TI + 1>(S, T, tk, tc, z, ys, lane, Pm, g, slots);
+        qp_gather_s<SD, TI + 1, SSTR>(S, T, tk, tc, z, ys, lane, Pm, g, slots);
     }
 }
 
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
-template <const ShapeDesc& SD>
+template <const ShapeDesc& SD, int SSTR = WAVE>
 __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
                                               const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
                                               const int lane, const bool valid, double* slots,
@@ -1105,7 +1108,8 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
 #pragma unroll
         for (int b = 0; b <= a; ++b) L[tri(a, b)] = (a == b) ? T->mu * T->state_w[a] : 0.0;
     }
-    qp_gather_s<SD, 0>(S, T, tk, tc, z, ysl, lane, L, v, slots);
+    static_assert(SSTR == WAVE || QpLayout<SD>::BOX, "private slots: box family only");
+    qp_gather_s<SD, 0, SSTR>(S, T, tk, tc, z, ysl, lane, L, v, slots);
     if constexpr (LY::BOX) {
         // bounds by state (rows of the plan are unit rows on distinct states), then the primal active set
         double lbc[N], ubc[N], gv[N];
@@ -1118,8 +1122,8 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
             constexpr int col = SD.ucol[P.row_task[r]][P.row_local[r]] - 1;
-            lbc[col] = slots[(LY::O_LB + r) * WAVE + lane];
-            ubc[col] = slots[(LY::O_UB + r) * WAVE + lane];
+            lbc[col] = slots[(LY::O_LB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
+            ubc[col] = slots[(LY::O_UB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
         });
 #ifdef CLIK_QP_BOX_PN
         int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
@@ -1129,7 +1133,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
         if (!valid) status = 0;
         // slack of the folded rows: s = J v - b
 #pragma unroll
-        for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * WAVE + lane] : 0.0;
+        for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * SSTR + (SSTR == 1 ? 0 : lane)] : 0.0;
         static_for<0, SD.n_tasks>([&](auto tc_) __attribute__((always_inline)) {
             constexpr int TI = decltype(tc_)::value;
             if constexpr (P.folded[TI]) {
@@ -1400,12 +1404,66 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_values_kernel(
     qp_solve_static_body<SD, false, IMGV>(nullptr, q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk, nullptr);
 }
 
+// ... for the box family without any LDS: its solver keeps everything in registers, the few work-area slots the row
+// gathering fills become a private array, every lane loads its own rows and stores its own results
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    using LY = QpLayout<SD>;
+    static_assert(LY::BOX, "box family only");
+    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
+    constexpr QpImg<SD> kValues = IMGV::value;
+    const int lane = threadIdx.x;
+    const long long inst = (long long)blockIdx.x * WAVE + lane;
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
+    }
+    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double priv[LY::SLOTS];
+    double v[N], sl[LY::NSA];
+    const int status = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
+                                             hot_set != nullptr ? hot_set + row : nullptr, use_hot != 0);
+    if (valid) {
+        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
+        if constexpr (NX > 0) {
+            if (dx != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
+            }
+        }
+        if constexpr (NS > 0) {
+            if (slack_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+            }
+        }
+        if (status_out != nullptr) status_out[inst] = status;
+    }
+}
+
 template <const ShapeDesc& SD, class IMGV>
 inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const double* q, const double* x,
                                           const double* y, double* dq, double* dx, double* slack, int32_t* status,
                                           int32_t* hot_set, int use_hot, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if constexpr (QpLayout<SD>::BOX) {
+        hipLaunchKernelGGL((qp_solve_static_box_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
+                           slack, status, B, x, dx, hot_set, use_hot, tk);
+        return hipGetLastError();
+    }
     constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)qp_solve_static_values_kernel<SD, IMGV>,

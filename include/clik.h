@@ -292,6 +292,10 @@ int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, void* rollout_fn, const ch
  * clik_qp_solve_batch / _hot at every batch size (solve_fn = NULL detaches).  Needs a shape-specialised kernel. */
 int clik_qp_image_words(const clik_qp* h, uint64_t* buf, int cap);
 int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn);
+/* 1 when the skill's QP, after the soft equalities are eliminated, is bound-constrained (every remaining row a hard
+ * bound on one state: joint limits / speed limits) and a shape-specialised kernel serves it - the family whose
+ * value-specialised kernel runs without LDS (casclik_amd attaches it by default).                              */
+int clik_qp_is_box_family(const clik_qp* h);
 
 /* replaces solve() (reactive_qp.py:461-528).
  *   dq [B][n_q], dx [B][n_x] or NULL, slack [B][n_slack] or NULL  (device, out)

@@ -506,17 +506,18 @@ def test_box_family_contradicting_bounds_are_infeasible(iiwa_fk):
 
 
 def test_qp_value_specialised_kernel(iiwa_fk):
-    """function_opts["jit_values"] = True: the per-tick QP kernel with the skill's numbers and the QP options compiled
-    in (clik_qp_attach_value_kernel) returns what the image-reading kernel returns, cold and hot-started, and keeps
-    doing so when the handle's options differ (custom weights are part of the compiled-in values)"""
+    """the per-tick QP kernel with the skill's numbers and the QP options compiled in (clik_qp_attach_value_kernel;
+    the default for the box family, whose instantiation runs without LDS) returns what the image-reading kernel
+    (function_opts["jit_values"] = False) returns, cold and hot-started, and keeps doing so when the handle's options
+    differ (custom weights are part of the compiled-in values)"""
     import torch
     from oracle import clik_oracle
     spec = skills.qp_skill(iiwa_fk)
     Q, Y = skills.synthetic_inputs(iiwa_fk, 1000, seed=41, distribution="mixed")
     ws = [3.0, 1.0, 2.0, 1.0, 1.0, 0.5]
     for extra in ({}, {"slack_var_weights": ws}):
-        val = _controller(spec, options={"function_opts": {"jit_values": True}}, **extra)
-        img = _controller(spec, **extra)
+        val = _controller(spec, **extra)
+        img = _controller(spec, options={"function_opts": {"jit_values": False}}, **extra)
         assert val.value_kernel and val.kernel_variant(1000).endswith("/v") and not img.kernel_variant(1000).endswith("/v")
         dq, _, slack, status = val.solve_batch(0.0, Q, input_var=Y)
         dq2, _, slack2, status2 = img.solve_batch(0.0, Q, input_var=Y)
@@ -530,3 +531,28 @@ def test_qp_value_specialised_kernel(iiwa_fk):
     weights = clik_oracle.qp_weights(spec, slack_var_weights=ws)
     rdq = clik_oracle.qp_solve_batch(spec, 0.0, Q[:60], Y=Y[:60], weights=weights)[0]
     assert _rel(dq[:60], rdq).max() < QP_RTOL
+
+
+def test_qp_value_specialised_kernel_outside_the_box_family(ur5_fk):
+    """a QP with general hard rows (tool-position box) keeps the dual active-set iteration; its value-specialised
+    kernel is opt-in (it keeps the LDS work area) and returns the same minimisers"""
+    fk = ur5_fk
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    p_home = fk["chain"].fk_numeric(home)[:3, 3]
+    cons = [cc.SetConstraint("box_%d" % i, p[i], set_min=p_home[i] - 0.15, set_max=p_home[i] + 0.15, priority=i, gain=50.0)
+            for i in range(3)]
+    cons.append(cc.EqualityConstraint("move", p - (p_home + np.array([0.3, 0.0, 0.1])), priority=10, constraint_type="soft",
+                                      gain=1.0))
+    cons.append(cc.VelocitySetConstraint("speed", q, set_min=-0.6 * np.ones(6), set_max=0.6 * np.ones(6), priority=0))
+    spec = cc.SkillSpecification("box_move", t, q, constraints=cons)
+    plain = _controller(spec)
+    val = _controller(spec, options={"function_opts": {"jit_values": True}})
+    assert not plain.value_kernel and val.value_kernel
+    Q = home + np.random.default_rng(8).normal(scale=0.06, size=(300, 6))
+    a = plain.solve_batch(0.0, Q)
+    b = val.solve_batch(0.0, Q)
+    assert np.array_equal(a[3], b[3])
+    ok = a[3] == 0
+    assert ok.sum() > 200 and np.allclose(a[0][ok], b[0][ok], rtol=1e-9, atol=1e-11)

@@ -14,7 +14,7 @@ CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per ins
     "stack_team4v": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
     "stack_team4": ("stack_mixed_B16384_kStackIiwa/team4", "kStackIiwa/team4", 172, 16384),
     "stack_lane": ("stack_mixed_B16384_kStackIiwa/mp2", "kStackIiwa/mp2", 172, 16384),
-    "qp": ("qp_mixed_B16384_qp_static_kQpPoseIiwa", "qp_static_kQpPoseIiwa", 168, 16384),
+    "qp": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 168, 16384),
     "pose_lanev": ("pose_mixed_B16384_kPose6Iiwa/lanev", "kPose6Iiwa/lanev", 172, 16384),
 }
 out = {"note": "rocprofv3 --pmc passes (one counter group per run, no tracing) of python3 bench.py --graph 0 at 16384 "
