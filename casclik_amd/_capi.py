@@ -292,7 +292,7 @@ def load_library(path=None):
     lib.clik_qp_is_box_family.restype = C.c_int
     lib.clik_qp_is_box_family.argtypes = [vp]
     lib.clik_qp_attach_value_kernel.restype = C.c_int
-    lib.clik_qp_attach_value_kernel.argtypes = [vp, vp]
+    lib.clik_qp_attach_value_kernel.argtypes = [vp, vp, vp]
     lib.clik_qp_rollout_batch_m.restype = C.c_int
     lib.clik_qp_rollout_batch_m.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                             C.POINTER(C.c_double), dp, dp, dp, dp, dp, dp, ip, vp]

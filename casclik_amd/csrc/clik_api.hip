@@ -110,6 +110,9 @@ typedef hipError_t (*clik_jit_qp_rollout_fn)(const void*, const double*, int, do
 typedef hipError_t (*clik_jit_qp_value_fn)(const TickArgs*, long long, const double*, const double*, const double*,
                                            double*, double*, double*, int32_t*, int32_t*, int, hipStream_t);
 
+typedef hipError_t (*clik_jit_qp_value_rollout_fn)(const double*, int, double, double, long long, double*, const double*,
+                                                   double*, double*, int32_t*, double*, double*, hipStream_t, int);
+
 struct clik_qp {
     DevSkill  host;
     DevSkill* dev;
@@ -121,6 +124,7 @@ struct clik_qp {
     clik_jit_qp_fn jit_solve;
     clik_jit_qp_rollout_fn jit_rollout;
     clik_jit_qp_value_fn val_solve;     // per-tick kernel with this skill's numbers and QP options compiled in
+    clik_jit_qp_value_rollout_fn val_rollout;   // ... and its on-device rollout (box family), or null
     char      jit_name[64];
 };
 
@@ -670,6 +674,7 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     DevSkill& S = h->host;
     h->d_img = nullptr;
     h->val_solve = nullptr;
+    h->val_rollout = nullptr;
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
     h->val_solve = nullptr;
@@ -1186,7 +1191,10 @@ extern "C" int clik_qp_rollout_batch_m(const clik_qp* hc, int64_t B, int32_t n_t
     double* d_tt = nullptr;
     int rc = stage_tterms(tterms, (size_t)n_ticks * stages * 2 * (size_t)S.d.n_tslots, (hipStream_t)stream, &d_tt);
     if (rc) return rc;
-    hipError_t e = h->jit_rollout
+    hipError_t e = h->val_rollout
+                       ? h->val_rollout(d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack, status, x, dx,
+                                        (hipStream_t)stream, stages)
+                   : h->jit_rollout
                        ? h->jit_rollout(h->d_img, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, slack,
                                         status, x, dx, (hipStream_t)stream, stages)
                        : clik::qp_launch_rollout_static(h->static_k, h->d_img, d_tt, n_ticks, dt, max_speed,
@@ -1226,12 +1234,14 @@ extern "C" int clik_qp_is_box_family(const clik_qp* h)
     return clik::qp_box_family_rt(h->host.shape) ? 1 : 0;
 }
 
-extern "C" int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn)
+extern "C" int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn, void* rollout_fn)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (solve_fn && !h->jit_solve && h->static_k < 0)
         return fail(CLIK_EUNSUPPORTED, "value-specialised QP kernels exist for skills a shape-specialised kernel serves");
     h->val_solve = (clik_jit_qp_value_fn)solve_fn;
+    // (the value-specialised rollout exists for the box family only)
+    h->val_rollout = (solve_fn && clik::qp_box_family_rt(h->host.shape)) ? (clik_jit_qp_value_rollout_fn)rollout_fn : nullptr;
     return CLIK_OK;
 }
 

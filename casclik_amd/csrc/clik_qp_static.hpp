@@ -1453,6 +1453,132 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
     }
 }
 
+// ... and its on-device rollout (see qp_rollout_static_kernel): state, working set and Runge-Kutta bookkeeping in
+// registers from tick to tick, rows loaded once and stored once by the lane itself
+template <const ShapeDesc& SD, class IMGV, bool RK>
+__global__ __launch_bounds__(WAVE) void qp_rollout_static_box_values_kernel(
+    double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq, double* __restrict__ slack_out,
+    int32_t* __restrict__ status_out, const long long B, const double* __restrict__ tterms, const int n_ticks,
+    const double dt, const double max_speed, double* __restrict__ x, double* __restrict__ dx)
+{
+    using LY = QpLayout<SD>;
+    static_assert(LY::BOX, "box family only");
+    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
+    constexpr QpImg<SD> kValues = IMGV::value;
+    constexpr int stages = RK ? 4 : 1;
+    const int lane = threadIdx.x;
+    const long long inst = (long long)blockIdx.x * WAVE + lane;
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    const int nts = kValues.img.n_tslots;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
+    }
+    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double v[N], sl[LY::NSA];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < LY::NSA; ++k) sl[k] = 0.0;
+    int32_t hot = 0;
+    int worst = 0;
+#pragma unroll 1
+    for (int tick = 0; tick < n_ticks; ++tick) {
+        double z0[N], ks[N];
+        bool okl = true;
+        if constexpr (RK) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                z0[j] = z[j];
+                ks[j] = 0.0;
+            }
+        }
+#pragma unroll 1
+        for (int stg = 0; stg < stages; ++stg) {
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + stg) * 2 * nts);
+            double priv[LY::SLOTS];
+            const int st = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl, &hot,
+                                                 (tick | stg) > 0);
+            worst = st > worst ? st : worst;
+            okl = okl & (st != 2);              // an infeasible tick (stage) leaves the state where it was
+            if constexpr (!RK) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double d = v[j];
+                    if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                    v[j] = d;
+                    z[j] = okl ? fma(d, dt, z[j]) : z[j];
+                }
+            } else {
+                const double wgt = (stg == 0 || stg == 3) ? 1.0 : 2.0;
+                const double cnext = (stg == 2) ? dt : 0.5 * dt;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double d = okl ? v[j] : 0.0;
+                    if (j < NQ && max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
+                    ks[j] = fma(wgt, d, ks[j]);
+                    z[j] = fma(d, cnext, z0[j]);
+                }
+            }
+        }
+        if constexpr (RK) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double d = ks[j] * (1.0 / 6.0);
+                v[j] = okl ? d : v[j];
+                z[j] = okl ? fma(d, dt, z0[j]) : z0[j];
+            }
+        }
+    }
+    if (valid) {
+        const double bad = (worst == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            q[inst * NQ + j] = z[j];
+            dq[inst * NQ + j] = v[j] + bad;
+        }
+        if constexpr (NX > 0) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                x[inst * NX + j] = z[NQ + j];
+                dx[inst * NX + j] = v[NQ + j] + bad;
+            }
+        }
+        if constexpr (NS > 0) {
+            if (slack_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+            }
+        }
+        if (status_out != nullptr) status_out[inst] = worst;
+    }
+}
+
+// hipErrorNotSupported outside the box family (the caller then uses the image-reading rollout)
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_qp_rollout_static_values(const double* d_tterms, int n_ticks, double dt, double max_speed,
+                                                  long long B, double* q, const double* y, double* dq, double* slack,
+                                                  int32_t* status, double* x, double* dx, hipStream_t stream, int stages)
+{
+    if constexpr (QpLayout<SD>::BOX) {
+        if (SD.n_x != 0 && (x == nullptr || dx == nullptr)) return hipErrorInvalidValue;
+        const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+        if (stages == 4)
+            hipLaunchKernelGGL((qp_rollout_static_box_values_kernel<SD, IMGV, true>), dim3(grid), dim3(WAVE), 0, stream, q, y,
+                               dq, slack, status, B, d_tterms, n_ticks, dt, max_speed, x, dx);
+        else
+            hipLaunchKernelGGL((qp_rollout_static_box_values_kernel<SD, IMGV, false>), dim3(grid), dim3(WAVE), 0, stream, q, y,
+                               dq, slack, status, B, d_tterms, n_ticks, dt, max_speed, x, dx);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <const ShapeDesc& SD, class IMGV>
 inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const double* q, const double* x,
                                           const double* y, double* dq, double* dx, double* slack, int32_t* status,

@@ -289,9 +289,11 @@ int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, void* rollout_fn, const ch
 /* Value-specialised per-tick QP kernel (see clik_pinv_attach_value_kernel): clik_qp_image_words returns the skill
  * image and the QP options (weights, weight shifter, iteration cap) of the handle as 64-bit words;
  * casclik_amd/jit.py compiles them into the kernel template and attaches the result, which then serves
- * clik_qp_solve_batch / _hot at every batch size (solve_fn = NULL detaches).  Needs a shape-specialised kernel. */
+ * clik_qp_solve_batch / _hot at every batch size (solve_fn = NULL detaches); rollout_fn (may be NULL) is the
+ * on-device rollout of the same instantiation, used for the bound-constrained family.  Needs a shape-specialised
+ * kernel.                                                                                                       */
 int clik_qp_image_words(const clik_qp* h, uint64_t* buf, int cap);
-int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn);
+int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn, void* rollout_fn);
 /* 1 when the skill's QP, after the soft equalities are eliminated, is bound-constrained (every remaining row a hard
  * bound on one state: joint limits / speed limits) and a shape-specialised kernel serves it - the family whose
  * value-specialised kernel runs without LDS (casclik_amd attaches it by default).                              */
