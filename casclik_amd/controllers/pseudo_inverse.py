@@ -165,11 +165,12 @@ class PseudoInverseController(BaseController):
         dd = self.descriptor
         single_mode = (dd.n_x == 0 and dd.n_sets == 0 and variant1 in ("lane", "split"))
         wanted = (variant1 == "team4" and jv is not False) or (single_mode and (jv is True or env_jv == "2"))
-        if want_jit and wanted and env_jv != "0" and not self.descriptor.extern_code:
+        if want_jit and wanted and env_jv != "0":
             from .. import jit
             with torch.cuda.device(self._device):
                 try:
-                    self.value_kernel = jit.attach_values(self._lib, handle, cdesc, copts)
+                    self.value_kernel = jit.attach_values(self._lib, handle, cdesc, copts,
+                                                          extern=self.descriptor.extern_source())
                 except RuntimeError as exc:
                     import warnings
                     warnings.warn("value-specialised kernel could not be built, using the image-reading one: %s"

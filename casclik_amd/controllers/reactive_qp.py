@@ -207,12 +207,11 @@ class ReactiveQPController(BaseController):
         self.value_kernel = None
         jv, env_jv = fopts.get("jit_values", None), os.environ.get("CLIK_JIT_VALUES", "1")
         wanted = jv is True or env_jv == "2" or (jv is None and self._lib.clik_qp_is_box_family(handle) == 1)
-        if want_jit and wanted and jv is not False and env_jv != "0" and not d.extern_code \
-                and self.kernel_name not in ("dynamic", "none"):
+        if want_jit and wanted and jv is not False and env_jv != "0" and self.kernel_name not in ("dynamic", "none"):
             from .. import jit
             with torch.cuda.device(self._device):
                 try:
-                    self.value_kernel = jit.attach_qp_values(self._lib, handle, cdesc)
+                    self.value_kernel = jit.attach_qp_values(self._lib, handle, cdesc, extern=d.extern_source())
                 except RuntimeError as exc:
                     import warnings
                     warnings.warn("value-specialised QP kernel could not be built, using the image-reading one: %s"
