@@ -132,3 +132,36 @@ def test_instantiated_kernels_with_expression_attributes_have_no_scratch(tmp_pat
     assert len(kernels) == 4
     for name, r in kernels.items():
         assert r["ScratchSize"] == 0, (name, r)
+
+
+def test_value_specialised_kernels_of_the_config3_skill_have_no_scratch(tmp_path):
+    """The kernels casclik_amd/jit.py::attach_values instantiates for BASELINE config 3 with the skill's numbers compiled
+    in (four lanes per instance, one lane per instance, their rollouts) must stay in registers, and the one-lane kernel
+    must fit two waves per SIMD (that is what makes it the large-batch kernel).  The skill image words are a fixture
+    written on a GPU box (python tools/dump_image_words.py tests/golden/stack_iiwa_image_words.txt); a changed image
+    layout fails the size static_assert here - regenerate the fixture then."""
+    import re
+    import subprocess
+    from casclik_amd import jit
+    from casclik_amd.build import parse_resource_remarks, FLAGS, CSRC
+    hipcc = jit._hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    here = os.path.dirname(os.path.abspath(__file__))
+    words = open(os.path.join(here, "golden", "stack_iiwa_image_words.txt")).read().split()
+    gen = open(os.path.join(CSRC, "clik_shapes_gen.hpp")).read()
+    init = re.search(r"kStackIiwa\s*=\s*(\{.*?\});", gen, re.S).group(1)
+    text = jit._VALUE_TEMPLATE.replace("%(nwords)d", str(len(words))).replace(
+        "%(words)s", ", ".join(w + "ull" for w in words)) % {"init": init, "extern": ""}
+    src = tmp_path / "stack_values.hip"
+    src.write_text(text)
+    out = subprocess.run([hipcc] + FLAGS + ["-DCLIK_VALUE_KERNEL", "-c", str(src), "-o", str(tmp_path / "stack_values.o")],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()[-2000:]
+    res = parse_resource_remarks(out.stdout.decode())
+    kernels = {k: v for k, v in res.items() if "_static_" in k}
+    assert len(kernels) == 5, sorted(kernels)      # team solve / rollout, lane solve, lane rollout (Euler, Runge-Kutta)
+    for name, r in kernels.items():
+        assert r["ScratchSize"] == 0, (name, r)
+        if "pinv_solve_static_values_kernel" in name:
+            assert r["VGPRs"] <= 256 and r.get("AGPRs", 0) == 0 and r["Occupancy"] >= 2, (name, r)
