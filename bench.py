@@ -106,9 +106,8 @@ def make_workload(name, fk):
         spec, opts = skills.stack_skill(fk), dict(skills.STACK_OPTIONS)
         ctrl = cc.PseudoInverseController(skill_spec=spec, options=opts)
     elif name == "pose":
-        # (single-mode skill: its small-batch kernel with the skill's numbers compiled in is opt-in)
         spec, opts = skills.pose_skill(fk), None
-        ctrl = cc.PseudoInverseController(skill_spec=spec, options={"function_opts": {"jit_values": True}})
+        ctrl = cc.PseudoInverseController(skill_spec=spec)
     else:
         spec, opts = skills.qp_skill(fk), None
         ctrl = cc.ReactiveQPController(skill_spec=spec)

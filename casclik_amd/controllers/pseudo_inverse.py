@@ -153,18 +153,18 @@ class PseudoInverseController(BaseController):
                     name = None
             if name:
                 self.kernel_name = name
-        # Skills of the four-lanes-per-instance family get that kernel with their own numbers compiled in (the
-        # reference's JIT compiles its functions with the constants of the skill too); function_opts["jit_values"]
-        # = False or CLIK_JIT_VALUES=0 keeps the kernel that reads the skill image from memory.  Single-mode skills
-        # without virtual variables (BASELINE configs 1 and 2) get a value-specialised small-batch kernel on request:
-        # function_opts["jit_values"] = True or CLIK_JIT_VALUES=2 (one more hipcc run at set-up).
+        # The skill's kernels with its own numbers compiled in (the reference's JIT compiles its functions with the
+        # constants of the skill too): for the config-3 family (four lanes per instance at small batches, one lane per
+        # instance above) and for single-mode skills without virtual variables (BASELINE configs 1 and 2: one lane
+        # per instance, no LDS) - one more hipcc run at set-up.  function_opts["jit_values"] = False or
+        # CLIK_JIT_VALUES=0 keeps the kernels that read the skill image from memory.
         self.value_kernel = None
         jv = self.options["function_opts"].get("jit_values", None)
         env_jv = os.environ.get("CLIK_JIT_VALUES", "1")
         variant1 = self._lib.clik_pinv_kernel_variant(handle, 1).decode()
         dd = self.descriptor
         single_mode = (dd.n_x == 0 and dd.n_sets == 0 and variant1 in ("lane", "split"))
-        wanted = (variant1 == "team4" and jv is not False) or (single_mode and (jv is True or env_jv == "2"))
+        wanted = (variant1 == "team4" or single_mode) and jv is not False
         if want_jit and wanted and env_jv != "0":
             from .. import jit
             with torch.cuda.device(self._device):

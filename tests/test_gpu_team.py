@@ -151,7 +151,7 @@ def test_default_selection_by_batch(iiwa_fk, monkeypatch):
     assert img.kernel_variant(1 << 20).endswith("/lane/occ2")      # (the ahead-of-time shapes' large-batch build)
     pose = cc.PseudoInverseController(skill_spec=skills.pose_skill(iiwa_fk))
     pose.setup_problem_functions()
-    assert pose.kernel_variant(16384).endswith("/lane")
+    assert pose.kernel_variant(16384).endswith("/lanev" if pose.value_kernel else "/lane")      # (never the team kernel)
 
 
 @pytest.mark.parametrize("robot", ["iiwa", "ur5"])
@@ -201,15 +201,15 @@ def test_value_specialised_lane_kernel_of_the_stack_between_16385_and_32768(iiwa
 
 @pytest.mark.parametrize("skill", ["pose", "position"])
 def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
-    """BASELINE configs 1 / 2 (single task, one mode): on request (function_opts["jit_values"] = True) the small-batch
-    kernel is instantiated with the skill's numbers compiled in (no skill image, no LDS staging: "lanev"); larger
-    batches keep the kernel that reads the image; both match the oracle and each other"""
+    """BASELINE configs 1 / 2 (single task, one mode): the kernel is instantiated with the skill's numbers compiled in
+    (no skill image, no LDS staging: "lanev") unless function_opts["jit_values"] = False; both match the oracle and
+    each other"""
     from oracle import clik_oracle
     from casclik_amd import skills
     spec = skills.pose_skill(iiwa_fk) if skill == "pose" else skills.position_skill(iiwa_fk)
-    ctrl = cc.PseudoInverseController(skill_spec=spec, options={"function_opts": {"jit_values": True}})
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
     ctrl.setup_problem_functions()
-    plain = cc.PseudoInverseController(skill_spec=spec)
+    plain = cc.PseudoInverseController(skill_spec=spec, options={"function_opts": {"jit_values": False}})
     plain.setup_problem_functions()
     assert ctrl.kernel_variant(4096).endswith("lanev") and ctrl.kernel_variant(65536).endswith("lanev")
     assert plain.kernel_variant(4096).endswith("lane")
