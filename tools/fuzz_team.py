@@ -93,6 +93,22 @@ for s in range(n_skills):
         rerr = float(np.abs(dq1 - dq).max() / (1.0 + np.abs(dq).max()))
         worst = max(worst, err)
         flag = ""
+        lerr = 0.0
+        if values == "1":
+            # the same instances inside a batch beyond the team kernel's range: one lane per instance with the
+            # numbers compiled in ("lanev": solo_tick), tick and one rollout tick, against the team kernel's answers
+            reps = 16400 // B + 1
+            Qb, Yb = np.tile(Q, (reps, 1)), np.tile(Y, (reps, 1))
+            big = ctrl.kernel_variant(len(Qb))
+            dqb, _, modeb = ctrl.solve_batch(tval, Qb, input_var=Yb)
+            same = (modeb[:B] == mode) | tie
+            cmpb = (modeb[:B] == mode) & ~tie
+            lerr = float((np.abs(dqb[:B] - dq).max(axis=1) / (1.0 + np.abs(dq).max(axis=1)))[cmpb].max()) if cmpb.any() else 0.0
+            qb1, dqb1, mb1 = ctrl.rollout_batch([tval], Qb, input_var=Yb, dt=1e-3)
+            if not big.endswith("/lanev") or (~same).any() or lerr > tol or not np.array_equal(mb1, modeb) \
+                    or np.abs(dqb1 - dqb).max() > 1e-9 * (1.0 + np.abs(dqb).max()):
+                bad += 1
+                flag = "   <-- MISMATCH (lanev %s err %.1e)" % (big, lerr)
         if (~agree).any() or err > tol or rerr > 1e-9 or not np.array_equal(m1, mode):
             bad += 1
             flag = "   <-- MISMATCH"
