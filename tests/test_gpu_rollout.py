@@ -79,6 +79,38 @@ def test_rk4_rollout_of_the_stack_with_sets(iiwa_fk):
     assert np.array_equal(mode_dev, modes[-4])        # the mode of the last tick's first stage
 
 
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_rollout_of_the_stack_beyond_the_team_kernels_range(iiwa_fk, method):
+    """the same stack at 16500 instances: the one-lane value-specialised rollout (state and Runge-Kutta bookkeeping
+    in registers, no LDS) against the host loop over the per-tick kernel of that batch size"""
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    B = 16500
+    assert ctrl.kernel_variant(B).endswith("/lanev")
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=6, distribution="mixed")
+    dt, vmax, n = 0.008, np.pi / 5, 3
+    q_dev, dq_dev, mode_dev = ctrl.rollout_batch(np.zeros(n), Q, input_var=Y, dt=dt, max_speed=vmax, method=method)
+    modes = []
+
+    def solve(t, q):
+        d, _, m = ctrl.solve_batch(t, q, input_var=Y)
+        modes.append(m)
+        return d
+    if method == "rk4":
+        qh, vh = _host_rk4(solve, np.zeros(n), Q, dt, vmax)
+        first_stage_of_last_tick = modes[-4]
+    else:
+        qh = Q.copy()
+        for _ in range(n):
+            vh = np.clip(solve(0.0, qh), -vmax, vmax)
+            qh = qh + dt * vh
+        first_stage_of_last_tick = modes[-1]
+    assert np.abs(q_dev - qh).max() < 1e-9 and np.abs(dq_dev - vh).max() < 1e-7
+    assert np.array_equal(mode_dev, first_stage_of_last_tick)
+    assert len(np.unique(mode_dev)) == 2
+
+
 def test_qp_rk4_rollout_matches_host_rk4(ur5_fk):
     """the QP controller's rollout with method="rk4" (four QP solves per tick in one launch, hot-started from stage
     to stage) against the scheme of integration_methods.py:17-23 looped on the host over the same kernel and over
