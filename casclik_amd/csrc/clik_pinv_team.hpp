@@ -193,11 +193,10 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     double rhs[M];
     {
         double x[N];
+        // (role masks applied arithmetically: a select of a double costs two instructions)
+        const double m1 = (r == 1) ? 1.0 : 0.0, m2 = (r == 2) ? 1.0 : 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double f = (r == 2) ? one_lam - sact[j] : ((r == 1) ? 1.0 : 0.0);
-            x[j] = w2[j] * f;
-        }
+        for (int j = 0; j < N; ++j) x[j] = w2[j] * fma(m2, one_lam - sact[j], m1);
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             double sacc = hsel * des1[i];
@@ -241,12 +240,14 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     const bool hi_pair = (r & 2) != 0;
     const double kap = hi_pair ? 1.0 / one_lam : 1.0;
     const double eta = hi_pair ? 1.0 : 2.0;
+    const double hp = hi_pair ? 1.0 : 0.0, oneh = hi_pair ? one_lam : 1.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const double first = quad_perm_f64<0xF0>(g[j]);      // quad_perm:[0,0,3,3]: g0 | g3
         const double second = quad_perm_f64<0xA5>(g[j]);     // quad_perm:[1,1,2,2]: g1 | g2
-        const double nmul = hi_pair ? fma(-p0[j], sact[j], 1.0) : 1.0;
-        const double xx = hi_pair ? w2[j] * (one_lam - sact[j]) : w2[j];
+        const double hs = hp * sact[j];
+        const double nmul = fma(-p0[j], hs, 1.0);            // 1 in the mode-0 pair, 1 - p0 s in the mode-1 pair
+        const double xx = w2[j] * (oneh - hs);               // w2 | w2 ((1+lam) - s)
         v[j] = fma(first, nmul, kap * fma(-eta, second, xx));
     }
     // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; lanes 2/3 evaluate it
