@@ -68,7 +68,7 @@ inline size_t team_lds_bytes(bool values = false)
 // One tick of the lane's instance in the quad: candidate velocities of both modes and the tangent-cone verdict.
 // Slds: skill image (LDS copy, or the address of a local constexpr object whose loads fold to literals);
 // z: the instance's state in every lane of the quad; a0 / a1: state variables 2r and 2r+1 (clamped to N-1) of lane
-// r; on return lanes 0/1 hold the mode-0 velocity in v, lanes 2/3 the mode-1 one, in_tc the cone test of v.
+// r; on return lane 0 holds the mode-0 velocity in v, lane 3 the mode-1 one, in_tc the cone test of v.
 template <const ShapeDesc& SD>
 __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, const TickArgs& tk,
                                           const double (&z)[SD.n], const double* ysl, const double a0, const double a1,
@@ -234,23 +234,24 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     }
 
     
-    // ---- the quad's results meet: lanes 0/1 form the mode-0 velocity, lanes 2/3 the mode-1 one --
-    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)
-    //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)
+    // ---- the quad's results meet: lane 0 forms the mode-0 velocity, lane 3 the mode-1 one --
+    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)          (lane 0)
+    //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)   (lane 3)
     const bool hi_pair = (r & 2) != 0;
     const double kap = hi_pair ? 1.0 / one_lam : 1.0;
     const double eta = hi_pair ? 1.0 : 2.0;
     const double hp = hi_pair ? 1.0 : 0.0, oneh = hi_pair ? one_lam : 1.0;
+    // (one exchange per entry: lanes swap inside their pair, so lane 0 holds g0 and receives g1, lane 3 holds g3 and
+    // receives g2 - the mode-0 velocity forms in lane 0, the mode-1 one in lane 3; lanes 1 / 2 compute unused values)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const double first = quad_perm_f64<0xF0>(g[j]);      // quad_perm:[0,0,3,3]: g0 | g3
-        const double second = quad_perm_f64<0xA5>(g[j]);     // quad_perm:[1,1,2,2]: g1 | g2
+        const double other = quad_perm_f64<0xB1>(g[j]);      // quad_perm:[1,0,3,2]
         const double hs = hp * sact[j];
         const double nmul = fma(-p0[j], hs, 1.0);            // 1 in the mode-0 pair, 1 - p0 s in the mode-1 pair
         const double xx = w2[j] * (oneh - hs);               // w2 | w2 ((1+lam) - s)
-        v[j] = fma(first, nmul, kap * fma(-eta, second, xx));
+        v[j] = fma(g[j], nmul, kap * fma(-eta, other, xx));
     }
-    // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; lanes 2/3 evaluate it
+    // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; the other lanes evaluate it
     // on the other candidate, unused)
     if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
         in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
@@ -418,13 +419,13 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     CLIK_STAMP_W(0, 6);
     const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
     if constexpr (VALUES) {
-        if (r == (ok0 ? 0 : 2) && inst < rows_valid) {
+        if (r == (ok0 ? 0 : 3) && inst < rows_valid) {
 #pragma unroll
             for (int j = 0; j < N; ++j) dq[(b0 + inst) * N + j] = v[j];
             if (mode_out != nullptr) mode_out[b0 + inst] = ok0 ? 0 : 1;
         }
     } else {
-        if (r == (ok0 ? 0 : 2)) {
+        if (r == (ok0 ? 0 : 3)) {
             // (each team reads and writes only its own row, and a team is inside one wave: no barrier needed)
 #pragma unroll
             for (int j = 0; j < N; ++j) zs[inst * N + j] = v[j];
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
             const double cnext = (st == 2) ? dt : 0.5 * dt;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                // the accepted candidate in every lane of the quad: mode 0 lives in lane 0, mode 1 in lane 2
-                const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xAA>(v[j]);
+                // the accepted candidate in every lane of the quad: mode 0 lives in lane 0, mode 1 in lane 3
+                const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xFF>(v[j]);
                 double d = ok0 ? c0 : c1;
                 if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
                 ks[j] = fma(wgt, d, ks[j]);
