@@ -165,3 +165,15 @@ def test_value_specialised_kernels_of_the_config3_skill_have_no_scratch(tmp_path
         assert r["ScratchSize"] == 0, (name, r)
         if "pinv_solve_static_values_kernel" in name:
             assert r["VGPRs"] <= 256 and r.get("AGPRs", 0) == 0 and r["Occupancy"] >= 2, (name, r)
+
+
+def test_value_kernels_of_the_baseline_skills_are_prebuilt():
+    """__graft_entry__.build() instantiates the value-specialised kernels of BASELINE configs 2, 3 and 4 ahead of time
+    (from the recorded skill-image words) under the cache names the controllers compute at set-up"""
+    from casclik_amd import jit
+    if jit._hipcc() is None:
+        pytest.skip("hipcc not available")
+    built = jit.prebuild_value_kernels()
+    assert [n for n, _ in built] == ["stack_iiwa", "pose_iiwa", "qp_iiwa"]
+    for _, tag in built:
+        assert os.path.exists(os.path.join(jit.CACHE, "clik_shape_%s.so" % tag))
