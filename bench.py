@@ -7,14 +7,27 @@ A *step* is one controller tick over the whole batch resident in HBM (one
 kernel launch per tick per GPU).  `value` = instance-steps per second =
 (N * batch * steps timed) / time, the BASELINE.json metric "CLIK steps/sec (whole
 node), 7-DoF 3-task priority stack, batch 16384" (batch is per GPU: weak
-scaling, as in BASELINE config 5 = 131072 instances over 8 GPUs).
+scaling, as in BASELINE config 5 = 131072 instances over 8 GPUs;
+`--global-batch G` cuts ONE batch of G instances over the ranks instead: strong
+scaling, reported as such).
 
 The JSON line also carries
   roofline      algorithmic HBM bytes (q 56 B + target 56 B +
-                dq 56 B + mode 4 B per instance-step) over the kernel
-                duration from HIP events on the launch stream, vs 8 TB/s
+                dq 56 B + mode 4 B per instance-step; the QP: + 48 B slack + 4 B
+                status) over the per-tick time from HIP events on the launch
+                stream, vs 8 TB/s; `tick_us` is that per-tick time (kernel body
+                + the dependent-launch boundary: an upper bound of the kernel's
+                duration); `kernel_body_us` is the kernel's own first-wave-start
+                to last-wave-end time where profiles/ holds a stamp measurement
+                of this configuration (with its source); `fp64` is the executed
+                fp64 VALU rate from the PMC passes under profiles/ against the
+                78.6 TF vector peak, and `binds` names the bound that applies
   cpu_baseline  the C restatement of the reference algorithm (oracle/, kind
                 "port") timed on this host's cores on a bounded sample
+  extras        (default N=1 run only) the other BASELINE configurations under
+                the same clock: config 2 (pose, 4096 and 16384), config 4 (QP,
+                cold, 16384), config 3 at the config-5 batch (131072), each with
+                ms_per_step / kernel / roofline / cpu_baseline
 
 Timing protocol: W untimed warm-up steps, then an untimed, time-based clock ramp
 (--ramp-ms of replays: a fresh GPU needs ~100 ms of work before its clocks
@@ -23,9 +36,10 @@ hipGraph inside ONE barrier + synchronize bracket.  The graph holds the K steps
 repeated to >= 1024 ticks (a graph launch opens with a ~10 us device bubble that
 a 20-tick graph would pay every 20 ticks).  `ms_per_step` = bracket wall time /
 timed steps (max over ranks), `value` = instances * timed steps / wall;
-`roofline.kernel_us` = median over the R replays of (HIP-event time of one
+`roofline.tick_us` = median over the R replays of (HIP-event time of one
 replay / its ticks).  R is chosen so that the bracket holds >= --min-timed-ms of
-work and >= 50 replays; R and the timed steps are stated in `config`.
+work (default 2 s for the headline) and >= 50 replays; R and the timed steps are
+stated in `config`.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
 itself (torch.distributed.run on 127.0.0.1) BEFORE anything touches a GPU and
@@ -47,7 +61,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TF = 78.6       # half of the 157.3 TF fp32 vector peak
-PROFILE_FILES = ("r2_counters.json", "r1_traffic.json")     # newest first
+PROFILE_FILES = ("r3_counters.json", "r2_counters.json", "r1_traffic.json")     # newest first
+BODY_FILES = ("r3_body_time.json",)
+METRIC = "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384"
 
 
 def parse():
@@ -55,14 +71,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=16384, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=16384, help="instances per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="G > 0: ONE batch of G instances cut into contiguous shards over the ranks "
+                         "(strong scaling; BASELINE config 5 = 131072); overrides --batch")
     ap.add_argument("--workload", default="stack", choices=["stack", "pose", "qp"])
     ap.add_argument("--dist", default="mixed", choices=["interior", "mixed"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", type=int, default=1,
                     help="replay the K ticks from one hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--allgather", type=int, default=0,
-                    help="also all-gather dq over RCCL every tick (reported separately)")
+                    help="also time the RCCL all-gather of dq (its own bracket, and tick + all-gather; "
+                         "reported separately, never folded into `value`)")
     ap.add_argument("--ticks-per-launch", type=int, default=1,
                     help="K > 1: the on-device rollout (K ticks of solve -> clamp -> Euler per launch, "
                          "SURVEY.md 8(d) 'launch-amortised'); steps must be a multiple of K")
@@ -72,10 +92,14 @@ def parse():
                     help="lanes per robot instance of the pinv kernel: 0 = the library's choice, 1 = "
                          "lane-per-instance kernels only, 4 / 8 / 16 = the multi-lane kernel (CLIK_LANES)")
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp before the timed region")
-    ap.add_argument("--min-timed-ms", type=float, default=60.0, help="least work inside the timed bracket")
+    ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="least work inside the timed bracket")
     ap.add_argument("--replays", type=int, default=0, help="R (0: from --min-timed-ms, at least 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--extras", type=int, default=-1,
+                    help="1: append the other BASELINE configurations (see the module text) as `extras`; "
+                         "-1 = only for the default headline invocation on one GPU; 0 = never")
+    ap.add_argument("--extras-timed-ms", type=float, default=400.0)
     return ap.parse_args()
 
 
@@ -116,56 +140,89 @@ def make_workload(name, fk):
     return spec, opts, ctrl
 
 
-def cpu_baseline(workload, spec, opts, Q, Y, seconds):
-    """Time the CPU restatement on the host cores this process may use.  Pseudo-inverse
-    workloads: the C restatement (oracle/clik_oracle_c.c, OpenMP over instances; the thread
-    count with the best throughput is reported).  QP: the numpy restatement (one core)."""
-    import numpy as np
+def host_cores():
+    """(cores this process may be scheduled on, CPU-time quota of its cgroup in cores or None)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    if workload == "qp":
-        from oracle import clik_oracle
-        n = min(len(Q), 256)
-        t0 = time.perf_counter()
-        clik_oracle.qp_solve_batch(spec, 0.0, Q[:n], Y=Y[:n])
-        one = time.perf_counter() - t0
-        reps = max(1, min(50, int(seconds / max(one, 1e-6)) - 1))
-        t0 = time.perf_counter()
-        for k in range(reps):
-            lo = (k * n) % max(1, len(Q) - n + 1)
-            clik_oracle.qp_solve_batch(spec, 0.0, Q[lo:lo + n], Y=Y[lo:lo + n])
-        el = time.perf_counter() - t0
-        return {"value": n * reps / el, "unit": "instance-steps/s", "cores": 1, "kind": "port",
-                "host_cores_available": avail,
-                "sample": "%d x %d instances of the bench batch, numpy restatement of reactive_qp.py:175-246 + dense "
-                          "Goldfarb-Idnani (oracle/clik_oracle.py), one core" % (reps, n)}
+    quota = None
+    for fn in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(fn) as f:
+                parts = f.read().split()
+            if fn.endswith("cpu.max"):
+                if parts[0] != "max":
+                    quota = float(parts[0]) / float(parts[1])
+            else:
+                q = float(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        quota = q / float(f.read().split()[0])
+            break
+        except Exception:
+            continue
+    return avail, quota
+
+
+_CPU_CACHE = {}
+
+
+def cpu_baseline(workload, spec, opts, Q, Y, seconds):
+    """Time the C restatement of the reference algorithm (oracle/clik_oracle_c.c, OpenMP over
+    instances) on the host cores this process may use: single core and the best thread count, each
+    the median of 3 repeats with the spread stated.  (The bound of the sweep: a cgroup CPU quota caps
+    what more threads can buy; it is reported when there is one.)"""
+    import numpy as np
+    if workload in _CPU_CACHE:
+        return dict(_CPU_CACHE[workload], note="same skill and sample as the entry above")
+    avail, quota = host_cores()
     from oracle import c_oracle
-    co = c_oracle.CPinvOracle(spec, opts)
-    # enough rows per thread to amortise the OpenMP fork/join
-    reps_rows = max(1, (8 * 16384) // len(Q))
-    Qs, Ys = np.tile(Q, (reps_rows, 1)), np.tile(Y, (reps_rows, 1))
+    if workload == "qp":
+        co = c_oracle.CQpOracle(spec)
+        rows = 16384
+        what = ("C restatement of reactive_qp.py:175-246 + dense Goldfarb-Idnani on the full QP "
+                "(oracle/clik_oracle_c.c::orc_qp_solve_batch; the reference hands the same H, A, lbA, ubA to qpOASES)")
+    else:
+        co = c_oracle.CPinvOracle(spec, opts)
+        rows = 8 * 16384          # enough rows per thread to amortise the OpenMP fork/join
+        what = "C restatement of the reference algorithm (oracle/clik_oracle_c.c)"
+    reps_rows = max(1, rows // len(Q))
+    Qs, Ys = np.tile(Q, (reps_rows, 1))[:rows], np.tile(Y, (reps_rows, 1))[:rows]
     sample = len(Qs)
-    best_rate, best_threads = 0.0, 1
-    for threads in sorted({1, min(8, avail), min(32, avail), min(64, avail), avail}):
-        co.solve_batch(0.0, Qs, Y=Ys, nthreads=threads)
+
+    def rate(threads, n_rows):
         t0 = time.perf_counter()
-        co.solve_batch(0.0, Qs, Y=Ys, nthreads=threads)
-        rate = sample / (time.perf_counter() - t0)
-        if rate > best_rate:
-            best_rate, best_threads = rate, threads
-    one = sample / best_rate
-    reps = max(1, min(5000, int(seconds / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        co.solve_batch(0.0, Qs, Y=Ys, nthreads=best_threads)
-    el = time.perf_counter() - t0
-    return {"value": sample * reps / el, "unit": "instance-steps/s", "cores": best_threads,
-            "kind": "port", "host_cores_available": avail,
-            "sample": "%d ticks of a %d-instance batch (the bench batch tiled %dx), C restatement of the "
-                      "reference algorithm (oracle/clik_oracle_c.c), OpenMP over instances, best of "
-                      "{1,8,32,64,all} threads" % (reps, sample, reps_rows)}
+        co.solve_batch(0.0, Qs[:n_rows], Y=Ys[:n_rows], nthreads=threads)
+        return n_rows / (time.perf_counter() - t0)
+
+    budget_t0 = time.perf_counter()
+    one_rows = min(sample, 4096)
+    rate(1, 256)                                   # (page the library in)
+    single = sorted(rate(1, one_rows) for _ in range(3))
+    sweep = {}
+    for threads in sorted({min(8, avail), min(16, avail), min(32, avail), min(64, avail), min(128, avail), avail}):
+        rate(threads, sample)                      # first touch / thread start-up
+        sweep[threads] = rate(threads, sample)
+        if time.perf_counter() - budget_t0 > 0.6 * seconds:
+            break
+    best_threads = max(sweep, key=sweep.get)
+    reps = sorted(rate(best_threads, sample) for _ in range(3))
+    # a bounded sample: keep going until the CPU leg has used its share of the budget
+    n_ticks = 3
+    while time.perf_counter() - budget_t0 < seconds:
+        reps.append(rate(best_threads, sample))
+        n_ticks += 1
+    reps.sort()
+    out = {"value": reps[len(reps) // 2], "unit": "instance-steps/s", "cores": best_threads, "kind": "port",
+           "host_cores_available": avail, "cgroup_cpu_quota_cores": quota,
+           "repeats": n_ticks, "spread": [reps[0], reps[-1]],
+           "single_core": {"value": single[1], "spread": [single[0], single[-1]], "rows": one_rows},
+           "thread_sweep": {str(k): v for k, v in sorted(sweep.items())},
+           "sample": "%d ticks of a %d-instance batch (the bench batch tiled %dx), %s, OpenMP over instances, "
+                     "median of the repeats at the best thread count of the sweep" % (n_ticks, sample, reps_rows, what)}
+    _CPU_CACHE[workload] = out
+    return out
 
 
 def profiled(workload, dist_name, batch, kernel):
@@ -191,78 +248,85 @@ def profiled(workload, dist_name, batch, kernel):
     return None, None
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.lanes:
-        os.environ["CLIK_LANES"] = str(args.lanes)
+def body_time(workload, dist_name, batch, kernel):
+    """Kernel body time (first wave start to last wave end, s_memrealtime stamps of the CLIK_STAMP build,
+    tools/stamp_body.py) of this configuration if profiles/ holds one."""
+    key = "%s_%s_B%d_%s" % (workload, dist_name, batch, kernel)
+    for fn in BODY_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                ent = json.load(f).get(key)
+        except Exception:
+            continue
+        if isinstance(ent, dict) and "body_us_median" in ent:
+            return ent, "profiles/" + fn + "#" + key
+    return None, None
 
-    import numpy as np
+
+WORKLOAD_TEXT = {
+    "stack": "BASELINE config 3: %d x KUKA iiwa 7-DoF per GPU, priority stack [multidim joint-limit set; 6-D pose; "
+             "joint centering], PseudoInverseController",
+    "pose": "BASELINE config 2: %d x iiwa, single 6-D pose task, PseudoInverseController",
+    "qp": "BASELINE config 4: %d x iiwa ReactiveQPController (soft 6-D pose + joint-speed VelocitySetConstraint)",
+}
+
+
+class Ctx(object):
+    def __init__(self, rank, world, dev, dist):
+        self.rank, self.world, self.dev, self.dist = rank, world, dev, dist
+
+
+def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_graph=1, ramp_ms=250.0,
+            min_timed_ms=2000.0, replays=0, allgather=0, global_batch=0):
+    """One timed configuration.  Returns (entry dict, (spec, opts, Q, Y)) on every rank; the entry is
+    complete on rank 0."""
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     from casclik_amd import skills
-    fk = skills.iiwa()
-    spec, opts, ctrl = make_workload(args.workload, fk)
-    B = args.batch
-    # every rank owns its own contiguous shard of the global batch (weak scaling)
-    Q, Y = skills.synthetic_inputs(fk, B, seed=args.seed + 1000 * rank, distribution=args.dist)
+    from casclik_amd.distributed import shard_bounds
+    dev, dist, world, rank = ctx.dev, ctx.dist, ctx.world, ctx.rank
+    spec, opts, ctrl = make_workload(workload, fk)
+    if global_batch:
+        # ONE batch, contiguous shards (casclik_amd.distributed.shard_bounds): every rank draws the same
+        # global inputs and keeps its rows
+        Qg, Yg = skills.synthetic_inputs(fk, global_batch, seed=seed, distribution=dist_name)
+        lo, hi = shard_bounds(global_batch, rank, world)
+        Q, Y = Qg[lo:hi], Yg[lo:hi]
+        B = hi - lo
+    else:
+        # every rank owns its own shard of the (weak-scaled) global batch
+        Q, Y = skills.synthetic_inputs(fk, B, seed=seed + 1000 * rank, distribution=dist_name)
     Qd = torch.from_numpy(Q).to(dev)
     Yd = torch.from_numpy(Y).to(dev)
     dQ = torch.empty((B, Q.shape[1]), dtype=torch.float64, device=dev)
-    gathered = None
-    if args.allgather and world > 1:
-        gathered = torch.empty((world * B, Q.shape[1]), dtype=torch.float64, device=dev)
 
-    TPL = args.ticks_per_launch
     if TPL > 1:
-        if args.steps % TPL or args.warmup % TPL:
+        if K % TPL or W % TPL:
             raise SystemExit("--ticks-per-launch needs steps and warmup divisible by it")
         times = [0.0] * TPL
         state = {"q": Qd}
 
         def tick():         # one launch = TPL ticks; the state is carried from launch to launch
             state["q"] = ctrl.rollout_batch(times, state["q"], input_var=Yd, dt=1e-3, max_speed=2.0)[0]
-        args.graph = 0
-        args.steps //= TPL
-        args.warmup //= TPL
-    elif args.workload == "qp":
-        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ, hot_start=bool(args.qp_hot))
+        use_graph = 0
+        K //= TPL
+        W //= TPL
+    elif workload == "qp":
+        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ, hot_start=bool(qp_hot))
     else:
         tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ)
 
-    def step():
-        tick()
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, dQ)
-
     stream = torch.cuda.Stream(device=dev)
-    K, W = args.steps, args.warmup
     with torch.cuda.stream(stream):
         for _ in range(W):
-            step()
+            tick()
         stream.synchronize()
         graph = None
         # a replay = GK steps = the K steps repeated until the graph holds >= 1024 ticks: every graph launch
         # starts with a ~10 us bubble on the device (measured: 6.26 us per step from a 20-tick graph against
         # 5.74 us from a 2000-tick graph of the same kernel), which a control loop that enqueues ticks
         # continuously never sees
-        GK = K * max(1, -(-1024 // K)) if (args.graph and gathered is None and TPL == 1) else K
-        if args.graph and gathered is None:
+        GK = K * max(1, -(-1024 // K)) if (use_graph and TPL == 1) else K
+        if use_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 for _ in range(GK):
@@ -275,7 +339,7 @@ def main():
                 graph.replay()
             else:
                 for _ in range(GK):
-                    step()
+                    tick()
 
         # untimed clock ramp; its rate also sizes R
         t_r = time.perf_counter()
@@ -285,17 +349,19 @@ def main():
             n_ramp += 1
             if n_ramp % 4 == 0 or GK >= 500:
                 stream.synchronize()
-                if (time.perf_counter() - t_r) * 1e3 >= args.ramp_ms:
+                if (time.perf_counter() - t_r) * 1e3 >= ramp_ms:
                     break
         stream.synchronize()
         est_ms = (time.perf_counter() - t_r) * 1e3 / n_ramp          # one replay, host-inclusive (upper bound)
-        R = args.replays if args.replays > 0 else max(50, int(args.min_timed_ms / max(est_ms, 1e-3)) + 1)
-        R = min(R, 20000)
+        R = replays if replays > 0 else max(50, int(min_timed_ms / max(est_ms, 1e-3)) + 1)
+        R = min(R, 200000)
         if dist is not None:
             rr = torch.tensor([R], dtype=torch.int64, device=dev)
             dist.all_reduce(rr, op=dist.ReduceOp.MAX)
             R = int(rr.item())
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+        n_ev = min(R, 2000)                                           # events around the first n_ev replays
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+        ev_end = torch.cuda.Event(enable_timing=True)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -303,78 +369,215 @@ def main():
         evs[0].record(stream)
         for r in range(R):
             replay()
-            evs[r + 1].record(stream)
+            if r < n_ev:
+                evs[r + 1].record(stream)
+        ev_end.record(stream)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         wall = time.perf_counter() - t0
-    per_replay_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(R))
-    med_ms = per_replay_ms[R // 2]
-    dev_ms = evs[0].elapsed_time(evs[R])
+
+        # the optional all-gather of dq: its own bracket, then tick + all-gather
+        # back to back on the same stream (eager launches: a collective is not captured)
+        ag = None
+        if allgather and world > 1:
+            from casclik_amd.distributed import all_gather_rows
+            n_total = global_batch if global_batch else world * B
+            full = all_gather_rows(dQ, n_total)
+            M = 200
+            for _ in range(20):
+                all_gather_rows(dQ, n_total)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(M):
+                all_gather_rows(dQ, n_total)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ag_us = (time.perf_counter() - ta) * 1e6 / M
+            for _ in range(20):
+                tick()
+                all_gather_rows(dQ, n_total)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(M):
+                tick()
+                all_gather_rows(dQ, n_total)
+            torch.cuda.synchronize()
+            dist.barrier()
+            both_us = (time.perf_counter() - ta) * 1e6 / M
+            tt = torch.tensor([ag_us, both_us], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ag = {"allgather_us": float(tt[0]), "tick_plus_allgather_us_eager": float(tt[1]),
+                  "bytes_per_rank": int(dQ.numel() * 8), "bytes_gathered": int(full.numel() * 8),
+                  "algorithm": "one torch.distributed.all_gather_into_tensor (RCCL all-gather over xGMI) per tick "
+                               "for equal shards; padded all_gather for uneven ones",
+                  "calls": M, "note": "its own bracket; never part of `value` / ms_per_step"}
+
+    per_replay_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(n_ev))
+    med_ms = per_replay_ms[n_ev // 2]
+    dev_ms = evs[0].elapsed_time(ev_end)
     if dist is not None:
         tt = torch.tensor([wall, dev_ms, med_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms, med_ms = float(tt[0]), float(tt[1]), float(tt[2])
 
-    if rank == 0:
-        K, W, GK = K * TPL, W * TPL, GK * TPL          # report in ticks
-        timed_steps = R * GK
-        total_steps = world * B * timed_steps
-        value = total_steps / wall
-        kern_us = med_ms * 1e3 / GK
-        bytes_per_inst = 8 * (Q.shape[1] + Y.shape[1] + Q.shape[1]) + (0 if args.workload == "qp" else 4)
-        alg_bytes = bytes_per_inst * B
-        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
-        kernel = getattr(ctrl, "kernel_name", None)
-        variant = getattr(ctrl, "kernel_variant", None)
-        if callable(variant):
-            kernel = variant(B)
-        # (an on-device rollout moves its bytes once per launch of TPL ticks: no per-tick traffic figure was profiled)
-        prof, prof_src = profiled(args.workload, args.dist, B, kernel) if TPL == 1 else (None, None)
+    K, W, GK = K * TPL, W * TPL, GK * TPL          # report in ticks
+    timed_steps = R * GK
+    n_inst_total = global_batch if global_batch else world * B
+    value = n_inst_total * timed_steps / wall
+    tick_us = med_ms * 1e3 / GK
+    n_q, n_y = Q.shape[1], Y.shape[1]
+    if workload == "qp":
+        n_slack = int(getattr(spec, "n_slack_var", 0) or 0)
+        bytes_per_inst = 8 * (n_q + n_y + n_q) + 8 * n_slack + 4          # q, target, dq, slack, status
+    else:
+        bytes_per_inst = 8 * (n_q + n_y + n_q) + 4                        # q, target, dq, mode
+    alg_bytes = bytes_per_inst * B
+    kernel = getattr(ctrl, "kernel_name", None)
+    variant = getattr(ctrl, "kernel_variant", None)
+    if callable(variant):
+        kernel = variant(B)
+    if TPL == 1:
+        achieved = alg_bytes / (tick_us * 1e-6) / 1e9
+        prof, prof_src = profiled(workload, dist_name, B, kernel)
+        body, body_src = body_time(workload, dist_name, B, kernel)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof.get("traffic_bytes") if prof else None,
                 "traffic_source": prof_src if (prof and "traffic_bytes" in prof) else None,
-                "kernel_us": kern_us, "kernel_us_mean": dev_ms * 1e3 / timed_steps,
+                "tick_us": tick_us, "tick_us_mean": dev_ms * 1e3 / timed_steps,
+                "tick_us_is": "HIP events on the launch stream around each graph replay / its ticks: kernel body + "
+                              "the dependent-launch boundary (an upper bound of the kernel's duration)",
+                "kernel_body_us": body.get("body_us_median") if body else None,
+                "kernel_body_source": body_src,
+                "algorithmic_bytes_per_instance": bytes_per_inst,
                 "algorithmic_bytes_per_launch": alg_bytes}
         if prof and "fp64_flops_per_launch" in prof:
             # executed fp64 flops (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes, FMA = 2) over the measured
-            # kernel time: what the VALUs did, not what the literal algorithm would need
-            roof["fp64_valu_frac_executed"] = (prof["fp64_flops_per_launch"] / (kern_us * 1e-6)
-                                               / (FP64_VALU_PEAK_TF * 1e12))
-            roof["fp64_source"] = prof_src
-        out = {
-            "metric": "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384",
-            "value": value, "unit": "instance-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall * 1e3 / timed_steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": {"stack": "BASELINE config 3: %d x KUKA iiwa 7-DoF per GPU, priority stack "
-                                      "[multidim joint-limit set; 6-D pose; joint centering], "
-                                      "PseudoInverseController" % B,
-                             "pose": "BASELINE config 2: %d x iiwa, single 6-D pose task" % B,
-                             "qp": "BASELINE config 4: %d x iiwa ReactiveQPController%s" % (
-                                 B, " (hot-started from the previous tick's working set)" if args.qp_hot else "")}[args.workload],
-                "batch_per_gpu": B, "inputs": "%s seed %d" % (args.dist, args.seed),
-                "kernel": kernel,
-                "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
-                           else "eager, one launch per tick") if TPL == 1
-                          else "on-device rollout, %d ticks per launch (solve -> clamp -> Euler)" % TPL,
-                "replays": R, "timed_steps": timed_steps, "clock_ramp_ms": args.ramp_ms,
-                "timing": "R back-to-back replays in one barrier+synchronize bracket; "
-                          "ms_per_step = wall / timed_steps, max over ranks",
-                "ticks_per_s": timed_steps / wall,
-                "parallelism": "dp%d (independent shards, no data-path collective)" % world,
-            },
-            "roofline": roof,
-        }
-        if args.cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, spec, opts, Q, Y, args.cpu_seconds)
-            except Exception as exc:            # the baseline must never sink the bench line
-                out["cpu_baseline"] = {"error": repr(exc)}
+            # tick time: what the VALUs did, not what the literal algorithm would need
+            tf = prof["fp64_flops_per_launch"] / (tick_us * 1e-6) / 1e12
+            roof["fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (executed, vector fp64)",
+                            "frac": tf / FP64_VALU_PEAK_TF, "flops_per_launch": prof["fp64_flops_per_launch"],
+                            "source": prof_src}
+            if "valu_issue_frac" in prof:
+                roof["fp64"]["valu_issue_frac"] = prof["valu_issue_frac"]
+            roof["binds"] = ("fp64 VALU issue" if roof["fp64"]["frac"] >= roof["frac"] else "hbm")
         else:
-            out["cpu_baseline"] = None
+            roof["fp64"] = None
+            roof["binds"] = None
+    else:
+        # an on-device rollout reads q / y and writes q once per LAUNCH of TPL ticks: a per-tick HBM
+        # fraction would not be a bandwidth
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "tick_us": tick_us, "tick_us_mean": dev_ms * 1e3 / timed_steps,
+                "algorithmic_bytes_per_launch": alg_bytes, "ticks_per_launch": TPL,
+                "note": "rollout: state stays in registers between ticks; bytes move once per launch"}
+    text = WORKLOAD_TEXT[workload] % B
+    if workload == "qp" and qp_hot:
+        text += " (hot-started from the previous tick's working set)"
+    entry = {
+        "value": value, "unit": "instance-steps/s", "ms_per_step": wall * 1e3 / timed_steps,
+        "config": {
+            "workload": text,
+            "batch_per_gpu": B, "inputs": "%s seed %d" % (dist_name, seed),
+            "kernel": kernel,
+            "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
+                       else "eager, one launch per tick") if TPL == 1
+                      else "on-device rollout, %d ticks per launch (solve -> clamp -> Euler)" % TPL,
+            "replays": R, "timed_steps": timed_steps, "timed_ms": wall * 1e3, "clock_ramp_ms": ramp_ms,
+            "timing": "R back-to-back replays in one barrier+synchronize bracket; "
+                      "ms_per_step = wall / timed_steps, max over ranks",
+            "ticks_per_s": timed_steps / wall,
+            "parallelism": "dp%d (independent shards, no data-path collective)" % world,
+        },
+        "roofline": roof,
+    }
+    if global_batch:
+        entry["config"]["global_batch"] = global_batch
+    if ag is not None:
+        entry["allgather"] = ag
+    del graph
+    return entry, (spec, opts, Q, Y)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.lanes:
+        os.environ["CLIK_LANES"] = str(args.lanes)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    ranks_seen, devices = 1, ["cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank))]
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ranks_seen = dist.get_world_size()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, "rank %d pid %d %s" % (rank, os.getpid(), devices[0]))
+        devices = gathered
+    ctx = Ctx(rank, world, dev, dist)
+
+    from casclik_amd import skills
+    fk = skills.iiwa()
+    head, (spec, opts, Q, Y) = measure(
+        ctx, fk, args.workload, args.batch, args.dist, args.seed, args.steps, args.warmup,
+        TPL=args.ticks_per_launch, qp_hot=args.qp_hot, use_graph=args.graph, ramp_ms=args.ramp_ms,
+        min_timed_ms=args.min_timed_ms, replays=args.replays, allgather=args.allgather,
+        global_batch=args.global_batch)
+
+    head_cpu = None
+    if rank == 0 and args.cpu_baseline and world == 1:
+        try:
+            head_cpu = cpu_baseline(args.workload, spec, opts, Q, Y, args.cpu_seconds)
+        except Exception as exc:            # the baseline must never sink the bench line
+            head_cpu = {"error": repr(exc)}
+
+    default_headline = (args.workload == "stack" and args.batch == 16384 and args.ticks_per_launch == 1
+                        and not args.global_batch and not args.qp_hot and not args.lanes and args.graph == 1)
+    want_extras = args.extras == 1 or (args.extras == -1 and default_headline and world == 1)
+    extras = []
+    if want_extras:
+        # the other BASELINE configurations under the same clock; short brackets
+        for (wl, b) in (("pose", 4096), ("pose", 16384), ("qp", 16384), ("stack", 131072)):
+            ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, args.steps, args.warmup,
+                                            ramp_ms=100.0, min_timed_ms=args.extras_timed_ms)
+            ent = dict({"name": "%s_B%d" % (wl, b), "n_gpus": world, "dtype": "f64"}, **ent)
+            if rank == 0 and args.cpu_baseline and world == 1:
+                try:
+                    ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(2.0, args.cpu_seconds / 3))
+                except Exception as exc:
+                    ent["cpu_baseline"] = {"error": repr(exc)}
+            extras.append(ent)
+
+    if rank == 0:
+        out = {
+            "metric": METRIC,
+            "value": head["value"], "unit": "instance-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": head["config"], "roofline": head["roofline"],
+            "nranks_seen": ranks_seen, "devices": devices,
+        }
+        if "allgather" in head:
+            out["allgather"] = head["allgather"]
+        out["cpu_baseline"] = head_cpu
+        if extras:
+            out["extras"] = extras
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

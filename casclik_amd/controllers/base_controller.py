@@ -32,7 +32,11 @@ def device_of(device=None):
                 "casclik_amd controllers run on an AMD GPU through the HIP "
                 "library; no GPU is visible and there is no CPU fallback.")
         return torch.device("cuda", torch.cuda.current_device())
-    return torch.device(device)
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        # ("cuda" without an index never compares equal to a tensor's "cuda:0": resolve it once, here)
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
 
 
 def check_out_tensor(t, shape, dtype_name, device, what):

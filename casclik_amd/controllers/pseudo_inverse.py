@@ -285,6 +285,12 @@ class PseudoInverseController(BaseController):
         uniq, inverse = np.unique(times, return_inverse=True)
         terms = np.asarray([np.asarray(d.time_terms(float(tv)), dtype=float).reshape(-1) for tv in uniq])
         rc = _capi.CLIK_EUNSUPPORTED
+        if terms.shape[1] == 0:
+            # no time-dependent sub-expression: every time stamp gives the same tick - the ordinary single launch
+            res = self.solve_batch(float(times[0]), Q, virtual_var=X, input_var=Y, out=out, return_mode=return_mode)
+            if was_np:
+                return tuple(None if r is None else r.cpu().numpy() for r in res)
+            return res
         if terms.shape[1] > 0:
             T = torch.from_numpy(np.ascontiguousarray(terms[inverse])).to(dev)
             with torch.cuda.device(dev):

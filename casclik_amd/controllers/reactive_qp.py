@@ -253,48 +253,73 @@ class ReactiveQPController(BaseController):
             return None, None
         if spec.n_virtual_var > 0 and spec._has_virtual:
             return self._initial_problem_with_virtual(time_var0, robot_var0, virtual_var0, robot_vel_var0, input_var0)
+        rows, dq0 = self._host_rows(time_var0, robot_var0, None, robot_vel_var0, input_var0)
+        slack = []
+        for (cn, m, Jq, Jx, lb, ub) in rows:
+            if cn.constraint_type != "soft":
+                continue
+            shift = Jq(dq0) if dq0.any() else 0.0
+            # -s in [lb, ub] - J_q dq0:  s in [-ub, -lb], the point nearest zero
+            slack.append(np.clip(0.0, -(ub - shift), -(lb - shift)))
+        return None, cs.DM(np.concatenate(slack).reshape(-1, 1))
+
+    def _host_rows(self, time_var0, robot_var0, virtual_var0, robot_vel_var0, input_var0):
+        """Rows of the QP at ONE state, evaluated from the expression graph on the host (setup-time
+        arithmetic for the initial problem, like the lowering; never on the per-tick path): per constraint
+        ``(cn, m, Jq, Jx, lb, ub)`` with ``Jq(v) = (de/dq) v`` (a callable: orientation-error nodes have no
+        symbolic q-derivative and take a directional difference), ``Jx = de/dx`` (matrix or None) and the
+        bounds of reactive_qp.py:219-232.  Also returns the held robot velocity as a flat array."""
         from .. import autodiff
+        spec = self.skill_spec
         env = {}
+
+        def flat(val):
+            return np.asarray(val.toarray() if hasattr(val, "toarray") else val, dtype=float).reshape(-1)
 
         def bind(var, val):
             if var is None or var.numel() == 0:
                 return
-            flat = np.asarray(val.toarray() if hasattr(val, "toarray") else val, dtype=float).reshape(-1)
+            fl = flat(val)
             fam = cs._families_of(var)[0]
-            env[id(fam)] = {k: float(flat[k]) for k in range(flat.size)}
+            env[id(fam)] = {k: float(fl[k]) for k in range(fl.size)}
 
         nq = spec.n_robot_var
         bind(spec.time_var, [time_var0])
         bind(spec.robot_var, robot_var0)
+        if spec.n_virtual_var > 0:
+            bind(spec.virtual_var, np.zeros(spec.n_virtual_var) if virtual_var0 is None else virtual_var0)
         if spec.n_input_var > 0:
             bind(spec.input_var, np.zeros(spec.n_input_var) if input_var0 is None else input_var0)
-        dq0 = np.zeros(nq) if robot_vel_var0 is None else \
-            np.asarray(robot_vel_var0.toarray() if hasattr(robot_vel_var0, "toarray") else robot_vel_var0,
-                       dtype=float).reshape(-1)
-        slack = []
+        dq0 = np.zeros(nq) if robot_vel_var0 is None else flat(robot_vel_var0)
+        out = []
         for cn in spec.constraints:
-            if cn.constraint_type != "soft":
-                continue
             expr = cn.expression
             m = expr.size()[0]
             e = cs.evaluate(expr, env).reshape(-1)
             base = -cs.evaluate(autodiff.jacobian(expr, spec.time_var), env).reshape(-1)
-            if dq0.any():
+
+            def Jq(v, expr=expr):
                 try:
-                    base = base - cs.evaluate(autodiff.jacobian(expr, spec.robot_var), env).dot(dq0)
+                    return cs.evaluate(autodiff.jacobian(expr, spec.robot_var), env).dot(v)
                 except NotImplementedError:
                     # (opaque orientation-error nodes have no symbolic q-derivative: directional difference)
                     fam = id(cs._families_of(spec.robot_var)[0])
                     q_at = dict(env[fam])
                     h = 1e-6
-                    env[fam] = {k: q_at[k] + h * dq0[k] for k in q_at}
-                    ep = cs.evaluate(expr, env).reshape(-1)
-                    env[fam] = {k: q_at[k] - h * dq0[k] for k in q_at}
-                    em = cs.evaluate(expr, env).reshape(-1)
-                    env[fam] = q_at
-                    base = base - (ep - em) / (2.0 * h)
+                    try:
+                        env[fam] = {k: q_at[k] + h * v[k] for k in q_at}
+                        ep = cs.evaluate(expr, env).reshape(-1)
+                        env[fam] = {k: q_at[k] - h * v[k] for k in q_at}
+                        em = cs.evaluate(expr, env).reshape(-1)
+                    finally:
+                        env[fam] = q_at
+                    return (ep - em) / (2.0 * h)
 
-            def gained(v, g=cn.gain):
+            Jx = None
+            if spec.n_virtual_var > 0 and cs.depends_on(expr, spec.virtual_var):
+                Jx = cs.evaluate(autodiff.jacobian(expr, spec.virtual_var), env).reshape(m, spec.n_virtual_var)
+
+            def gained(v, g=cn.gain, m=m):
                 if isinstance(g, cs.MX):
                     g = cs.evaluate(g, env)       # (an expression of (t, q, y): at the initial state)
                 if isinstance(g, cs.DM):
@@ -302,7 +327,7 @@ class ReactiveQPController(BaseController):
                 g = np.asarray(g, dtype=float)
                 return float(g.reshape(-1)[0]) * v if g.size == 1 else g.reshape(m, m).dot(v)
 
-            def vec(val):
+            def vec(val, m=m):
                 if isinstance(val, cs.MX):
                     val = cs.evaluate(val, env)
                 a = np.asarray(val.toarray() if isinstance(val, cs.DM) else val, dtype=float).reshape(-1)
@@ -316,9 +341,8 @@ class ReactiveQPController(BaseController):
                 lb = ub = base + vec(cn.target)
             else:
                 lb, ub = base + vec(cn.set_min), base + vec(cn.set_max)
-            # -s in [lb, ub]:  s in [-ub, -lb], the point nearest zero
-            slack.append(np.clip(0.0, -ub, -lb))
-        return None, cs.DM(np.concatenate(slack).reshape(-1, 1))
+            out.append((cn, m, Jq, Jx, lb, ub))
+        return out, dq0
 
     def _initial_problem_with_virtual(self, time_var0, robot_var0, virtual_var0, robot_vel_var0, input_var0):
         """The reference's initial problem with virtual variables (reactive_qp.py:300-459), on the device:
@@ -341,15 +365,24 @@ class ReactiveQPController(BaseController):
         q0, x0 = as1(robot_var0, nq), as1(virtual_var0, nx)
         y0 = as1(input_var0, spec.n_input_var) if spec.n_input_var > 0 and spec._has_input else None
         dq0 = as1(robot_vel_var0, nq).reshape(-1)
-        H, A, lb, ub = self.qp_data_batch(time_var0, q0, virtual_var=x0, input_var=y0)
-        H, A, lb, ub = H[0], A[0], lb[0], ub[0]
         mu = self.weight_shifter
-        w_virt = H[nq:nq + nx] / mu
-        w_slack = H[nq + nx:] - mu                      # main problem: mu + w  (:187)
+        host_rows = None
+        try:
+            H, A, lb, ub = self.qp_data_batch(time_var0, q0, virtual_var=x0, input_var=y0)
+            H, A, lb, ub = H[0], A[0], lb[0], ub[0]
+            w_virt = H[nq:nq + nx] / mu
+            w_slack = H[nq + nx:] - mu                  # main problem: mu + w  (:187)
+        except NotImplementedError:
+            # skills with generated rows / expression attributes exist only inside their instantiated kernel,
+            # which has no data entry point (clik_qp_data_batch: CLIK_EUNSUPPORTED): the same rows from the
+            # expression graph at the one initial state (setup-time host arithmetic, as without virtual variables)
+            host_rows, _ = self._host_rows(time_var0, q0, x0, robot_vel_var0, y0)
+            w_virt = np.asarray(self._virtual_var_weights, dtype=float).reshape(-1)[:nx]
+            w_slack = np.asarray(self._slack_var_weights, dtype=float).reshape(-1)
         xs = cs_.MX.sym("dx_init", nx)
         cns, slack_w, row = [], [], 0
         sl = 0
-        for cn in spec.constraints:
+        for ci, cn in enumerate(spec.constraints):
             m = cn.expression.size()[0]
             rows = slice(row, row + m)
             row += m
@@ -360,9 +393,15 @@ class ReactiveQPController(BaseController):
                 sl += m
             if not (found_virt or soft):
                 continue
-            Jv = A[rows, nq:nq + nx] if found_virt else np.zeros((m, nx))
-            shift = A[rows, :nq].dot(dq0)
-            lo, hi = lb[rows] - shift, ub[rows] - shift
+            if host_rows is None:
+                Jv = A[rows, nq:nq + nx] if found_virt else np.zeros((m, nx))
+                shift = A[rows, :nq].dot(dq0)
+                lo, hi = lb[rows] - shift, ub[rows] - shift
+            else:
+                _, _, Jq, Jx, lbr, ubr = host_rows[ci]
+                Jv = Jx if Jx is not None else np.zeros((m, nx))
+                shift = Jq(dq0) if dq0.any() else 0.0
+                lo, hi = lbr - shift, ubr - shift
             kw = dict(label="init_" + cn.label, expression=cs_.mtimes(Jv, xs), priority=len(cns),
                       constraint_type="soft" if soft else "hard")
             if np.array_equal(lo, hi):
@@ -370,13 +409,17 @@ class ReactiveQPController(BaseController):
             else:
                 cns.append(VelocitySetConstraint(set_min=lo, set_max=hi, **kw))
             if soft:
-                slack_w.extend(((1.0 + mu) * wk - mu).tolist())               # mu + w' = (1 + mu) w  (:331)
+                wd = (1.0 + mu) * wk - mu                                      # mu + w' = (1 + mu) w  (:331)
+                if np.any(wd + mu <= 0.0):
+                    raise ValueError("initial problem: slack weights must be positive")
+                slack_w.extend(wd.tolist())
         if not cns:
             return None, None
         t_ = cs_.MX.sym("t_init")
         sub = SkillSpecification(label=spec.label + "_initial", time_var=t_, robot_var=xs, constraints=cns)
         ctrl = ReactiveQPController(sub, robot_var_weights=list(w_virt), slack_var_weights=slack_w or None,
                                     options={"device": self.options.get("device")} if self.options.get("device") is not None else None)
+        ctrl.weight_shifter = mu                        # (the sub-problem's H is built with this instance's mu)
         ctrl.setup_problem_functions()
         dx, _, slack, status = ctrl.solve_batch(0.0, np.zeros((1, nx)))
         if int(status[0]) == 2:

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -910,12 +911,17 @@ static int pinv_solve_common(const clik_pinv* h, int64_t B, const double* tterms
     const bool team_batch = clik::shape_team_ok_rt(S.shape)
                                 ? ((h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch()) || lane_values)
                                 : lane_values;
-    hipError_t e = (h->val_solve && team_batch && t_inst == nullptr)
-                       ? h->val_solve(&la, &tk, (long long)B, q, y, dq, mode, (hipStream_t)stream)
-                   : h->jit_solve
-                       ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
-                       : clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
-                                                 (hipStream_t)stream);
+    // (the value-specialised library evaluates its own batch limits - it may have been built with other
+    // CLIK_VALUE_LANE_* settings than this one: hipErrorNotSupported means "not mine", and the image-reading
+    // kernels take the call)
+    hipError_t e = hipErrorNotSupported;
+    if (h->val_solve && team_batch && t_inst == nullptr)
+        e = h->val_solve(&la, &tk, (long long)B, q, y, dq, mode, (hipStream_t)stream);
+    if (e == hipErrorNotSupported)
+        e = h->jit_solve
+                ? h->jit_solve(&la, &tk, (long long)B, q, x, y, dq, dx, mode, (hipStream_t)stream)
+                : clik::pinv_launch_solve(h->kernel, la, tk, (long long)B, q, x, y, dq, dx, mode,
+                                          (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_solve_kernel launch");
     return CLIK_OK;
 }
@@ -940,20 +946,60 @@ extern "C" int clik_pinv_solve_batch_t(const clik_pinv* h, int64_t B, const doub
 
 // Time-slot records of a rollout (host) -> a device buffer that lives for this call only: allocated, filled and
 // released in stream order (hipMallocAsync / hipFreeAsync), so handles stay immutable and two rollouts on two
-// streams never share it.  The host array is consumed before the call returns (pageable source: the runtime
-// stages it synchronously), so the caller may free it right away.
+// streams never share it.  The host array is consumed before the call returns BY CONSTRUCTION: it is copied into a
+// pinned staging slot of a process-wide pool here (a plain memcpy), and the asynchronous host-to-device copy reads
+// that slot, so nothing depends on how the runtime treats a pageable source and the call never waits for the
+// stream.  A slot is reused once the event recorded behind its copy has completed.  (A rollout with time slots is
+// therefore not graph-capturable - its records are consumed at call time; a skill without time slots stages
+// nothing and captures like a tick.)
+namespace {
+struct StageSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; int dev = -1; };
+std::mutex g_stage_mu;
+std::vector<StageSlot> g_stage_slots;
+}
+
 static int stage_tterms(const double* tterms, size_t count, hipStream_t stream, double** out)
 {
     *out = nullptr;
     if (count == 0) return CLIK_OK;
     if (!tterms) return fail(CLIK_EINVAL, "tterms required");
-    hipError_t e = hipMallocAsync((void**)out, count * sizeof(double), stream);
-    if (e != hipSuccess) { *out = nullptr; return hipfail(e, "hipMallocAsync(tterms)"); }
-    e = hipMemcpyAsync(*out, tterms, count * sizeof(double), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) {
-        (void)hipFreeAsync(*out, stream);
-        *out = nullptr;
-        return hipfail(e, "hipMemcpyAsync(tterms)");
+    const size_t bytes = count * sizeof(double);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    StageSlot* slot = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        for (auto& sl : g_stage_slots) {
+            if (sl.dev != dev || sl.cap < bytes) continue;
+            if (sl.busy && hipEventQuery(sl.done) != hipSuccess) continue;
+            slot = &sl;
+            break;
+        }
+        if (!slot) {
+            StageSlot sl;
+            sl.cap = bytes < 4096 ? 4096 : bytes;
+            sl.dev = dev;
+            hipError_t e = hipHostMalloc(&sl.host, sl.cap, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                if (sl.host) (void)hipHostFree(sl.host);
+                return hipfail(e, "pinned staging slot (tterms)");
+            }
+            g_stage_slots.reserve(64);          // (pointers into the vector are taken under the lock only)
+            g_stage_slots.push_back(sl);
+            slot = &g_stage_slots.back();
+        }
+        slot->busy = true;
+        std::memcpy(slot->host, tterms, bytes);
+        hipError_t e = hipMallocAsync((void**)out, bytes, stream);
+        if (e != hipSuccess) { *out = nullptr; slot->busy = false; return hipfail(e, "hipMallocAsync(tterms)"); }
+        e = hipMemcpyAsync(*out, slot->host, bytes, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(slot->done, stream);
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(*out, stream);
+            *out = nullptr;
+            return hipfail(e, "hipMemcpyAsync(tterms)");
+        }
     }
     return CLIK_OK;
 }
@@ -1005,14 +1051,15 @@ extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t 
     const bool team_batch = clik::shape_team_ok_rt(S.shape)
                                 ? ((h->mode_parallel & 8) || ((h->mode_parallel & 4) && B <= clik::pinv_team_max_batch()) || lane_values)
                                 : lane_values;
-    hipError_t e = (h->val_rollout && team_batch && S.d.n_x == 0)
-                       ? h->val_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
-                                        (hipStream_t)stream)
-                   : h->jit_rollout
-                       ? h->jit_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
-                                        (hipStream_t)stream)
-                       : clik::pinv_launch_rollout(h->kernel, la, d_tt, n_ticks, dt, max_speed, (long long)B,
-                                                   q, y, dq, mode, (hipStream_t)stream);
+    hipError_t e = hipErrorNotSupported;
+    if (h->val_rollout && team_batch && S.d.n_x == 0)
+        e = h->val_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode, (hipStream_t)stream);
+    if (e == hipErrorNotSupported)          // (see pinv_solve_common)
+        e = h->jit_rollout
+                ? h->jit_rollout(&la, d_tt, n_ticks, dt, max_speed, (long long)B, q, y, dq, mode,
+                                 (hipStream_t)stream)
+                : clik::pinv_launch_rollout(h->kernel, la, d_tt, n_ticks, dt, max_speed, (long long)B,
+                                            q, y, dq, mode, (hipStream_t)stream);
     if (d_tt) (void)hipFreeAsync(d_tt, (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "pinv_rollout_kernel launch");
     return CLIK_OK;

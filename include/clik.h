@@ -26,7 +26,12 @@
  *   - Handles are immutable after creation: solve and rollout calls are re-entrant
  *     across streams.  Calls are asynchronous w.r.t. the host (no hidden sync); the
  *     rollouts keep their per-call time-slot records in a stream-ordered allocation
- *     (hipMallocAsync / hipFreeAsync on the caller's stream), not in the handle.
+ *     (hipMallocAsync / hipFreeAsync on the caller's stream), not in the handle, and
+ *     reach it through a pinned staging slot the library copies `tterms` into before
+ *     the call returns (the caller may free or overwrite the host array at once).
+ *     Consequence: a tick is graph-capturable; a rollout is graph-capturable only
+ *     for a skill without time slots (n_tslots == 0: nothing is staged) - the
+ *     time-slot records of a rollout are consumed at call time, not at replay.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream) so this
  *     header needs no HIP include.
  */

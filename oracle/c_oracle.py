@@ -48,6 +48,10 @@ def load():
         _lib.orc_qp_data_batch.argtypes = [
             C.POINTER(_capi.clik_skill_desc), C.POINTER(_capi.clik_qp_opts),
             C.c_int64, dp, dp, dp, dp, dp, dp, dp, dp]
+        _lib.orc_qp_solve_batch.restype = C.c_int
+        _lib.orc_qp_solve_batch.argtypes = [
+            C.POINTER(_capi.clik_skill_desc), C.POINTER(_capi.clik_qp_opts),
+            C.c_int64, dp, dp, dp, dp, dp, C.POINTER(C.c_int32), C.c_int]
         _lib.orc_num_threads.restype = C.c_int
     return _lib
 
@@ -139,6 +143,41 @@ def qp_data_batch(spec, t, Q, X=None, Y=None, mu=0.001, state_weights=None,
     lib.orc_qp_data_batch(C.byref(cdesc), C.byref(copts), B, _p(tt), _p(Q),
                           _p(Xc), _p(Yc), _p(Hd), _p(A), _p(lb), _p(ub))
     return Hd, A, lb, ub
+
+
+class CQpOracle(object):
+    """Literal ReactiveQPController.solve on the CPU (reactive_qp.py:461-528): H, A, lbA, ubA of
+    orc_qp_data_batch handed to a dense Goldfarb-Idnani in C (the same method as
+    clik_oracle.qp_solve_dense), OpenMP over instances.  Default weights only (what BASELINE config 4 uses)."""
+
+    def __init__(self, spec, mu=0.001):
+        self.lib = load()
+        self.desc = lower_skill(spec)
+        if self.desc.extern_code:
+            raise NotImplementedError("the C oracle has no rows for constraints outside the row table")
+        self.cdesc = _capi.desc_to_c(self.desc)
+        kw = []
+        for tsk in self.desc.tasks:
+            if tsk["soft"]:
+                kw += [tsk["slack_weight"]] * tsk["m"]
+        self.copts = _capi.qp_opts_to_c(mu, np.ones(self.desc.n_state), kw)
+        self.nv = self.desc.n_state + self.desc.n_slack
+
+    def solve_batch(self, t, Q, X=None, Y=None, nthreads=0):
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        B = Q.shape[0]
+        Xc = None if X is None else np.ascontiguousarray(X, dtype=np.float64)
+        Yc = None if Y is None else np.ascontiguousarray(Y, dtype=np.float64)
+        tt = np.ascontiguousarray(self.desc.time_terms(t))
+        xs = np.zeros((B, self.nv))
+        status = np.zeros(B, dtype=np.int32)
+        rc = self.lib.orc_qp_solve_batch(C.byref(self.cdesc), C.byref(self.copts), B, _p(tt), _p(Q), _p(Xc),
+                                         _p(Yc), _p(xs), status.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads))
+        if rc != 0:
+            raise RuntimeError("C QP oracle failed (%d)" % rc)
+        nq, nx = self.desc.n_q, self.desc.n_x
+        return (xs[:, :nq], xs[:, nq:nq + nx] if nx else None,
+                xs[:, nq + nx:] if self.desc.n_slack else None, status)
 
 
 def num_threads():

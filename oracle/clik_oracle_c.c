@@ -586,6 +586,165 @@ int orc_qp_data_batch(const clik_skill_desc* d, const clik_qp_opts* o, int64_t B
     return 0;
 }
 
+/* ---------------------------------------------------------------- dense QP (CPU baseline of the QP path)
+ * min 1/2 x'Hx  s.t. lb <= A x <= ub,  H = diag(hd) > 0: the problem reactive_qp.py:491-513 hands to
+ * cs.conic / qpOASES (third-party, not in the container).  Same method as oracle/clik_oracle.py::qp_solve_dense
+ * (Goldfarb & Idnani 1983, explicit dense solves per step), restated in C so that the QP has a compiled CPU
+ * baseline too.  Returns 0, or 2 when no feasible point exists / the iteration gives up. */
+#define QV_MAX 24
+#define QC_MAX 32
+typedef struct { double n[QV_MAX]; double rhs; int is_eq; int row; int sgn; } qp_act_t;
+
+static int qp_add_constraint(int nv, int nc, const double* Ginv, double* x, qp_act_t* act, int* nact,
+                             double* u, const double* nvec_in, double rhs, int is_eq, int row, int sgn)
+{
+    double nvec[QV_MAX], up[2 * QC_MAX + 1];
+    for (int j = 0; j < nv; ++j) nvec[j] = nvec_in[j];
+    for (int j = 0; j < *nact; ++j) up[j] = u[j];
+    up[*nact] = 0.0;
+    for (int guard = 0; guard < 4 * (nc + 2); ++guard) {
+        int q = *nact;
+        double s = -rhs, z[QV_MAX], rvec[2 * QC_MAX];
+        for (int j = 0; j < nv; ++j) s += nvec[j] * x[j];
+        if (q > 0) {
+            double M[2 * QC_MAX * 2 * QC_MAX], r[2 * QC_MAX];
+            for (int a = 0; a < q; ++a) {
+                for (int b = 0; b < q; ++b) {
+                    double acc = 0.0;
+                    for (int j = 0; j < nv; ++j) acc += act[a].n[j] * Ginv[j] * act[b].n[j];
+                    M[a * q + b] = acc;
+                }
+                double acc = 0.0;
+                for (int j = 0; j < nv; ++j) acc += act[a].n[j] * Ginv[j] * nvec[j];
+                r[a] = acc;
+            }
+            if (ge_solve(q, 1, M, q, r, 1)) return 2;
+            for (int a = 0; a < q; ++a) rvec[a] = r[a];
+            for (int j = 0; j < nv; ++j) {
+                double acc = nvec[j];
+                for (int a = 0; a < q; ++a) acc -= act[a].n[j] * rvec[a];
+                z[j] = Ginv[j] * acc;
+            }
+        } else {
+            for (int j = 0; j < nv; ++j) z[j] = Ginv[j] * nvec[j];
+        }
+        double zn = 0.0, nmax = 0.0, gmax = 0.0;
+        for (int j = 0; j < nv; ++j) {
+            zn += z[j] * nvec[j];
+            if (fabs(nvec[j]) > nmax) nmax = fabs(nvec[j]);
+            if (Ginv[j] > gmax) gmax = Ginv[j];
+        }
+        double t1 = INFINITY, t2 = INFINITY;
+        int drop = -1;
+        for (int a = 0; a < q; ++a)
+            if (!act[a].is_eq && rvec[a] > 1e-14) {
+                double cand = up[a] / rvec[a];
+                if (cand < t1) { t1 = cand; drop = a; }
+            }
+        double scale = nmax * nmax * gmax;
+        if (scale < 1.0) scale = 1.0;
+        if (zn > 1e-13 * scale) t2 = -s / zn;
+        if (is_eq && s > 0) {
+            for (int j = 0; j < nv; ++j) nvec[j] = -nvec[j];
+            rhs = -rhs;
+            continue;
+        }
+        double tstep = t1 < t2 ? t1 : t2;
+        if (tstep == INFINITY) return 2;
+        if (t2 != INFINITY)
+            for (int j = 0; j < nv; ++j) x[j] += tstep * z[j];
+        for (int a = 0; a < q; ++a) up[a] -= tstep * rvec[a];
+        up[q] += tstep;
+        if (t2 != INFINITY && tstep == t2) {
+            for (int j = 0; j < nv; ++j) act[q].n[j] = nvec[j];
+            act[q].rhs = rhs; act[q].is_eq = is_eq; act[q].row = row; act[q].sgn = sgn;
+            *nact = q + 1;
+            for (int a = 0; a <= q; ++a) u[a] = up[a];
+            return 0;
+        }
+        for (int a = drop; a < q - 1; ++a) act[a] = act[a + 1];
+        for (int a = drop; a < q; ++a) up[a] = up[a + 1];
+        *nact = q - 1;
+    }
+    return 2;
+}
+
+static int qp_solve_dense_c(int nv, int nc, const double* hd, const double* A, const double* lb,
+                            const double* ub, double* x, int max_iter)
+{
+    double Ginv[QV_MAX], u[2 * QC_MAX + 1];
+    qp_act_t act[2 * QC_MAX + 1];
+    int nact = 0;
+    if (nv > QV_MAX || nc > QC_MAX) return 2;
+    for (int j = 0; j < nv; ++j) { Ginv[j] = 1.0 / hd[j]; x[j] = 0.0; }
+    for (int i = 0; i < nc; ++i)
+        if (ub[i] - lb[i] <= 0.0) {
+            double rhs = 0.5 * (lb[i] + ub[i]), nvec[QV_MAX], s = -rhs;
+            for (int j = 0; j < nv; ++j) { nvec[j] = A[i * nv + j]; s += nvec[j] * x[j]; }
+            if (s > 0) { for (int j = 0; j < nv; ++j) nvec[j] = -nvec[j]; rhs = -rhs; }
+            if (qp_add_constraint(nv, nc, Ginv, x, act, &nact, u, nvec, rhs, 1, i, 0)) return 2;
+        }
+    for (int it = 0; it < max_iter; ++it) {
+        double worst = -1e-11, prhs = 0.0;
+        int pick = -1, psgn = 0;
+        for (int i = 0; i < nc; ++i) {
+            if (ub[i] - lb[i] <= 0.0) continue;
+            for (int side = 0; side < 2; ++side) {
+                int sgn = side == 0 ? +1 : -1;
+                double bound = side == 0 ? lb[i] : ub[i];
+                if (!isfinite(bound)) continue;
+                double rhs = sgn * bound, ax = 0.0;
+                int in_act = 0;
+                for (int a = 0; a < nact; ++a) in_act |= (act[a].row == i && act[a].sgn == sgn);
+                if (in_act) continue;
+                for (int j = 0; j < nv; ++j) ax += A[i * nv + j] * x[j];
+                double nrm = fabs(rhs) > 1.0 ? fabs(rhs) : 1.0;
+                double viol = (sgn * ax - rhs) / nrm;
+                if (viol < worst) { worst = viol; pick = i; psgn = sgn; prhs = rhs; }
+            }
+        }
+        if (pick < 0) {
+            for (int i = 0; i < nc; ++i) {
+                double ax = 0.0;
+                for (int j = 0; j < nv; ++j) ax += A[i * nv + j] * x[j];
+                if (isfinite(lb[i]) && (lb[i] - ax) / (fabs(lb[i]) > 1.0 ? fabs(lb[i]) : 1.0) > 1e-8) return 2;
+                if (isfinite(ub[i]) && (ax - ub[i]) / (fabs(ub[i]) > 1.0 ? fabs(ub[i]) : 1.0) > 1e-8) return 2;
+            }
+            return 0;
+        }
+        double nvec[QV_MAX];
+        for (int j = 0; j < nv; ++j) nvec[j] = psgn * A[pick * nv + j];
+        if (qp_add_constraint(nv, nc, Ginv, x, act, &nact, u, nvec, prhs, 0, pick, psgn)) return 2;
+    }
+    return 2;
+}
+
+/* literal ReactiveQPController.solve (reactive_qp.py:461-528) for a batch: xs [B][nv], status [B] */
+int orc_qp_solve_batch(const clik_skill_desc* d, const clik_qp_opts* o, int64_t B,
+                       const double* tterms, const double* q, const double* x, const double* y,
+                       double* xs, int32_t* status, int nthreads)
+{
+    int nq = d->n_q, nx = d->n_x, ny = d->n_y, n = nq + nx, ns = 0, nc = 0;
+    for (int ti = 0; ti < d->n_tasks; ++ti) {
+        nc += d->tasks[ti].m;
+        if (d->tasks[ti].soft) ns += d->tasks[ti].m;
+    }
+    int nv = n + ns;
+    if (nv > QV_MAX || nc > QC_MAX) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        double Hd[QV_MAX], A[QC_MAX * QV_MAX], lb[QC_MAX], ub[QC_MAX];
+        orc_qp_data_batch(d, o, 1, tterms, q + b * nq, x ? x + b * nx : 0, y ? y + b * ny : 0, Hd, A, lb, ub);
+        int st = qp_solve_dense_c(nv, nc, Hd, A, lb, ub, xs + b * nv, 200);
+        status[b] = st;
+        if (st) for (int j = 0; j < nv; ++j) xs[b * nv + j] = NAN;
+    }
+    return 0;
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -124,6 +124,29 @@ def test_tool_frame_products_virtual_input_and_time(iiwa_fk):
     assert _rel(np.hstack([qdq, qdx])[ok], np.hstack([rdq, rdx])[ok]).max() < 1e-7
 
 
+def test_initial_problem_of_a_skill_with_generated_rows_and_a_virtual_variable(iiwa_fk):
+    """solve_initial_problem (reactive_qp.py:300-459) for a skill whose rows are non-affine in the virtual variable
+    (exp(-x), cos(x + 0.3 t): generated code, no clik_qp_data_batch): the reduced QP is assembled from the
+    expression graph at the initial state and solved on the device - equal to the oracle's literal restatement."""
+    from oracle import clik_oracle
+    spec = mixed_frame_skill(iiwa_fk)
+    rng = np.random.default_rng(7)
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 6, seed=9)
+    qc = cc.ReactiveQPController(skill_spec=spec)
+    qc.setup_problem_functions()
+    qc.setup_solver()
+    qc.setup_initial_problem_solver()
+    with pytest.raises(NotImplementedError):
+        qc.qp_data_batch(0.4, Q[:1], virtual_var=np.zeros((1, 1)), input_var=np.zeros((1, 3)))
+    for b in range(len(Q)):
+        x0, y0 = rng.uniform(-1.0, 1.0, 1), rng.uniform(-1.0, 1.0, 3)
+        dq0 = None if b % 2 == 0 else rng.uniform(-0.3, 0.3, 7)
+        virt, slack = qc.solve_initial_problem(0.4, Q[b], virtual_var0=x0, robot_vel_var0=dq0, input_var0=y0)
+        rvirt, rslack = clik_oracle.qp_initial_problem(spec, 0.4, Q[b], x0=x0, dq0=dq0, y0=y0)
+        assert np.abs(np.asarray(virt.toarray()).reshape(-1) - rvirt).max() < 1e-8 * (1 + np.abs(rvirt).max())
+        assert np.abs(np.asarray(slack.toarray()).reshape(-1) - rslack).max() < 1e-8 * (1 + np.abs(rslack).max())
+
+
 def test_generated_constraints_need_the_instantiated_kernel(monkeypatch):
     """No silent path: with the run-time instantiation disabled the controller refuses the skill, and
     the C ABI refuses to solve it with a built-in kernel."""
