@@ -2,7 +2,12 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
 this.  It re-uses the descriptor struct mirrors of casclik_amd._capi (data
-layout only) but none of the product's compute.
+layout only) but none of the product's compute.  The descriptor it feeds the C
+code is the one casclik_amd.lowering produces from the skill script (then the C
+code witnesses the kernels' algebra, not the front-end) or, for the BASELINE
+skills, the one oracle/baseline_desc.py writes down without the front-end
+(``baseline=(robot, which)``: the full-size parity tests and bench.py's
+cpu_baseline use that one).
 """
 from __future__ import annotations
 
@@ -41,6 +46,8 @@ def load():
         _lib.orc_pinv_solve_batch.argtypes = [
             C.POINTER(_capi.clik_skill_desc), C.POINTER(_capi.clik_pinv_opts),
             C.c_int64, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_int32), C.c_int]
+        _lib.orc_pinv_solve_batch_m.restype = C.c_int
+        _lib.orc_pinv_solve_batch_m.argtypes = _lib.orc_pinv_solve_batch.argtypes + [dp]
         _lib.orc_task_eval.restype = C.c_int
         _lib.orc_task_eval.argtypes = [C.POINTER(_capi.clik_skill_desc), C.c_int,
                                        dp, dp, dp, dp, dp, dp]
@@ -70,20 +77,45 @@ def _full_pinv_options(options):
     return opt
 
 
-class CPinvOracle(object):
-    """Literal PseudoInverseController on the CPU from the lowered descriptor."""
+class _FlatDesc(object):
+    """what the wrappers below need of a descriptor that did not come from the product's lowering"""
+    extern_code = None
 
-    def __init__(self, spec, options=None):
+    def __init__(self, cdesc):
+        self.n_q, self.n_x, self.n_y = int(cdesc.n_q), int(cdesc.n_x), int(cdesc.n_y)
+        self.n_state = self.n_q + self.n_x
+        self.tasks = [{"m": int(cdesc.tasks[k].m), "soft": int(cdesc.tasks[k].soft),
+                       "slack_weight": float(cdesc.tasks[k].slack_weight)} for k in range(int(cdesc.n_tasks))]
+        self.n_slack = sum(t["m"] for t in self.tasks if t["soft"])
+        assert int(cdesc.n_tslots) == 0
+
+    def time_terms(self, t):
+        return np.zeros(0)
+
+
+class CPinvOracle(object):
+    """Literal PseudoInverseController on the CPU from a flat descriptor: the one the product's front-end
+    lowers from ``spec``, or - ``baseline=(robot, which)`` - the independently written one of
+    oracle/baseline_desc.py (BASELINE skills only), in which case nothing of casclik_amd's front-end is involved."""
+
+    def __init__(self, spec, options=None, baseline=None):
         self.lib = load()
-        self.desc = lower_skill(spec)
-        if self.desc.extern_code:
-            # (this restatement reads the lowered row table; expression-graph constraints are
-            # covered by the numpy oracle only)
-            raise NotImplementedError("the C oracle has no rows for constraints outside the row table")
-        self.cdesc = _capi.desc_to_c(self.desc)
+        if baseline is not None:
+            from . import baseline_desc
+            self.cdesc, _ = baseline_desc.baseline_descriptor(*baseline)
+            self.desc = _FlatDesc(self.cdesc)
+        else:
+            self.desc = lower_skill(spec)
+            if self.desc.extern_code:
+                # (this restatement reads the lowered row table; expression-graph constraints are
+                # covered by the numpy oracle only)
+                raise NotImplementedError("the C oracle has no rows for constraints outside the row table")
+            self.cdesc = _capi.desc_to_c(self.desc)
         self.copts = _capi.pinv_opts_to_c(_full_pinv_options(options))
 
-    def solve_batch(self, t, Q, X=None, Y=None, nthreads=0):
+    def solve_batch(self, t, Q, X=None, Y=None, nthreads=0, margins_out=None):
+        """``margins_out`` [B] (optional): per instance the smallest distance of any tangent-cone decision of its
+        mode scan from flipping (clik_oracle.tangent_cone_margin)"""
         Q = np.ascontiguousarray(Q, dtype=np.float64)
         B = Q.shape[0]
         Xc = None if X is None else np.ascontiguousarray(X, dtype=np.float64)
@@ -92,10 +124,12 @@ class CPinvOracle(object):
         dq = np.zeros((B, self.desc.n_q))
         dx = np.zeros((B, max(self.desc.n_x, 1)))
         mode = np.zeros(B, dtype=np.int32)
-        rc = self.lib.orc_pinv_solve_batch(
+        if margins_out is not None:
+            assert margins_out.dtype == np.float64 and margins_out.shape == (B,) and margins_out.flags.c_contiguous
+        rc = self.lib.orc_pinv_solve_batch_m(
             C.byref(self.cdesc), C.byref(self.copts), B, _p(tt), _p(Q), _p(Xc),
             _p(Yc), _p(dq), _p(dx), mode.ctypes.data_as(C.POINTER(C.c_int32)),
-            int(nthreads))
+            int(nthreads), _p(margins_out))
         if rc != 0:
             raise RuntimeError("C oracle failed (%d)" % rc)
         return dq, (dx[:, :self.desc.n_x] if self.desc.n_x else None), mode
@@ -150,12 +184,17 @@ class CQpOracle(object):
     orc_qp_data_batch handed to a dense Goldfarb-Idnani in C (the same method as
     clik_oracle.qp_solve_dense), OpenMP over instances.  Default weights only (what BASELINE config 4 uses)."""
 
-    def __init__(self, spec, mu=0.001):
+    def __init__(self, spec, mu=0.001, baseline=None):
         self.lib = load()
-        self.desc = lower_skill(spec)
-        if self.desc.extern_code:
-            raise NotImplementedError("the C oracle has no rows for constraints outside the row table")
-        self.cdesc = _capi.desc_to_c(self.desc)
+        if baseline is not None:
+            from . import baseline_desc
+            self.cdesc, _ = baseline_desc.baseline_descriptor(*baseline)
+            self.desc = _FlatDesc(self.cdesc)
+        else:
+            self.desc = lower_skill(spec)
+            if self.desc.extern_code:
+                raise NotImplementedError("the C oracle has no rows for constraints outside the row table")
+            self.cdesc = _capi.desc_to_c(self.desc)
         kw = []
         for tsk in self.desc.tasks:
             if tsk["soft"]:

@@ -399,10 +399,38 @@ def in_tangent_cone_multidim(e, set_min, set_max, dexpr):
     return bool(od < 0.0)
 
 
+def tangent_cone_margin(e, set_min, set_max, dexpr):
+    """Distance of one tangent-cone decision (either function above) from flipping, as the smallest of
+    the quantities it thresholds: |e - bound -/+ 1e-12| of every row (the inside test), and - outside -
+    the normalised |out_dir . de| (or the distance of the corner ratio from cos(pi/4)).  A diagnostic for
+    the parity tests: two correct fp64 evaluations of de differ by ~1e-9 relative, so a decision with a
+    margin far above that cannot depend on which of them made it."""
+    e = np.atleast_1d(np.asarray(e, dtype=float))
+    set_min = np.atleast_1d(np.asarray(set_min, dtype=float))
+    set_max = np.atleast_1d(np.asarray(set_max, dtype=float))
+    dexpr = np.atleast_1d(np.asarray(dexpr, dtype=float))
+    le, ue = e - set_min, e - set_max
+    if e.shape[0] == 1:
+        inside = (set_min[0] - e[0] < 1e-12) and (e[0] - set_max[0] < 1e-12)
+        margin = min(abs(set_min[0] - e[0] - 1e-12), abs(e[0] - set_max[0] - 1e-12))
+        return float(margin if inside else min(margin, abs(dexpr[0])))
+    inside = bool(np.all(le >= 1e-12) and np.all(ue <= 1e-12))
+    margin = float(min(np.abs(le - 1e-12).min(), np.abs(ue - 1e-12).min()))
+    if inside:
+        return margin
+    out_dir = (np.sign(le) + np.sign(ue)) / 2.0
+    od = float(out_dir.dot(dexpr))
+    scale = (np.linalg.norm(dexpr) + 1e-10) * max(np.linalg.norm(out_dir), 1e-300)
+    margin = min(margin, float(np.abs(le).min()), float(np.abs(ue).min()), abs(od) / scale)
+    if bool(np.all(np.sign(le) == np.sign(ue))) and od < 0.0:
+        margin = min(margin, abs(abs(od) / scale - math.cos(math.pi / 4)))
+    return margin
+
+
 # ==========================================================================
 # PseudoInverseController
 # ==========================================================================
-def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False):
+def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False, margins_out=None):
     """Literal PseudoInverseController: returns (dZ [B,n_state], mode [B]).
 
     dZ[:, :n_q] is robot_vel, the rest virtual_vel."""
@@ -522,6 +550,9 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     good = in_tangent_cone_1d(e[0], smin[0], smax[0], dexpr[0])
                 else:
                     good = in_tangent_cone_multidim(e, smin, smax, dexpr)
+                if margins_out is not None and modes[b] < 0:
+                    # (every decision of the scan up to and including the accepted mode)
+                    margins_out[b] = min(margins_out[b], tangent_cone_margin(e, smin, smax, dexpr))
                 if not good:
                     ok = False
                     break

@@ -299,8 +299,16 @@ static void activation_map(int n_sets, unsigned* act)
 }
 
 /* ---------------------------------------------------------------- tangent cones */
+/* diagnostic (orc_pinv_solve_batch_m): the smallest distance of any tangent-cone decision of the running mode scan
+ * from flipping - the quantities the functions below threshold (see clik_oracle.py::tangent_cone_margin) */
+static _Thread_local double g_tc_margin;
+static void margin_note(double v) { if (v < g_tc_margin) g_tc_margin = v; }
+
 static int in_tc_1d(double e, double lo, double hi, double de)
 {
+    margin_note(fabs(lo - e - 1e-12));
+    margin_note(fabs(e - hi - 1e-12));
+    if (!((lo - e < 1e-12) && (e - hi < 1e-12))) margin_note(fabs(de));
     if (lo - e < 1e-12) {
         if (e - hi < 1e-12) return 1;
         return de < 0.0;
@@ -323,7 +331,17 @@ static int in_tc_multidim(int m, const double* e, const double* lo, const double
         nde += de[i] * de[i];
         nout += out * out;
     }
+    for (int i = 0; i < m; ++i) {
+        margin_note(fabs(e[i] - lo[i] - 1e-12));
+        margin_note(fabs(e[i] - hi[i] - 1e-12));
+        if (!inside) { margin_note(fabs(e[i] - lo[i])); margin_note(fabs(e[i] - hi[i])); }
+    }
     if (inside) return 1;
+    {
+        double scale = (sqrt(nde) + 1e-10) * (nout > 0.0 ? sqrt(nout) : 1e-300);
+        margin_note(fabs(od) / scale);
+        if (corner && od < 0.0) margin_note(fabs(fabs(od) / scale - cos(M_PI / 4)));
+    }
     if (corner) {
         if (od < 0.0) {
             double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
@@ -500,9 +518,21 @@ static int pinv_one(const clik_skill_desc* d, const clik_pinv_opts* o, const uns
     return 0;
 }
 
+int orc_pinv_solve_batch_m(const clik_skill_desc* d, const clik_pinv_opts* o, int64_t B,
+                           const double* tterms, const double* q, const double* x,
+                           const double* y, double* dq, double* dx, int32_t* mode, int nthreads, double* margin);
+
 int orc_pinv_solve_batch(const clik_skill_desc* d, const clik_pinv_opts* o, int64_t B,
                          const double* tterms, const double* q, const double* x,
                          const double* y, double* dq, double* dx, int32_t* mode, int nthreads)
+{
+    return orc_pinv_solve_batch_m(d, o, B, tterms, q, x, y, dq, dx, mode, nthreads, 0);
+}
+
+/* ... margin [B] (nullable): per instance, the smallest tangent-cone decision margin of its mode scan */
+int orc_pinv_solve_batch_m(const clik_skill_desc* d, const clik_pinv_opts* o, int64_t B,
+                           const double* tterms, const double* q, const double* x,
+                           const double* y, double* dq, double* dx, int32_t* mode, int nthreads, double* margin)
 {
     int n_sets = 0, nq = d->n_q, nx = d->n_x, ny = d->n_y;
     unsigned act[1 << CLIK_MAX_SETS];
@@ -520,7 +550,9 @@ int orc_pinv_solve_batch(const clik_skill_desc* d, const clik_pinv_opts* o, int6
         int32_t md = -1;
         for (int j = 0; j < nq; ++j) z[j] = q[b * nq + j];
         for (int j = 0; j < nx; ++j) z[nq + j] = x[b * nx + j];
+        g_tc_margin = INFINITY;
         int rc = pinv_one(d, o, act, n_sets, tterms, z, y ? y + b * ny : 0, v, &md);
+        if (margin) margin[b] = g_tc_margin;
         if (rc) err |= 1;
         for (int j = 0; j < nq; ++j) dq[b * nq + j] = v[j];
         for (int j = 0; j < nx; ++j) dx[b * nx + j] = v[nq + j];

@@ -28,6 +28,30 @@ def double_pendulum_skill(track=False):
 
 
 
+def moe_box_skill(fk, soft_walls=False):
+    """The 'singular' QP skill of ur5_moe2016_example2.ipynb cells 6-8: three 1-D box sets on the tool position
+    (hard, gain 5e2), a soft tracking equality on a time trajectory, hard joint-speed limits (12 rows, 9 variables).
+    Returns (spec, home)."""
+    import numpy as np
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 6)
+    p = fk["T_fk"](q)[:3, 3]
+    omega = 0.1
+    path = cs.vertcat(0.5 * cs.sin(omega * t) * cs.sin(omega * t) + 0.2,
+                      0.5 * cs.cos(omega * t) + 0.25 * cs.sin(omega * t),
+                      0.5 * cs.sin(omega * t) * cs.cos(omega * t) + 0.1)
+    home = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) * np.pi / 180.0
+    p_home = fk["chain"].fk_numeric(home)[:3, 3]
+    box = [(c - 0.15, c + 0.15) for c in p_home]       # the notebook also starts inside its box
+    kw = dict(constraint_type="soft") if soft_walls else {}
+    cons = [cc.SetConstraint("colav_%d" % i, p[i], set_min=lo, set_max=hi, priority=7 + i, gain=5e2, **kw)
+            for i, (lo, hi) in enumerate(box)]
+    cons.append(cc.EqualityConstraint("move_point", p - path, priority=10, constraint_type="soft", gain=0.15))
+    cons.append(cc.VelocitySetConstraint("speed", q, set_min=-np.full(6, np.pi / 5), set_max=np.full(6, np.pi / 5),
+                                         priority=0))
+    return cc.SkillSpecification("box_move", t, q, constraints=cons), home
+
+
 def mixed_frame_skill(fk):
     """7-DoF arm: products / functions of tool-frame entries, a virtual variable, input and time terms."""
     t, q, x, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("x", 1), cs.MX.sym("y", 3)

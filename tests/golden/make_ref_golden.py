@@ -147,7 +147,14 @@ PLAN = [   # (fixture name, robot, case, B, input distribution, times)
     # (appended: the seeds of the entries above follow their position)
     ("iiwa_sym_attrs", "iiwa", "sym_attrs", 64, "mixed", [0.4, 2.3]),
     ("ur5_qp_sym_attrs", "ur5", "qp_sym_attrs", 48, "mixed", [1.1]),
+    # round 3
+    ("iiwa_stack_boundary", "iiwa", "stack_boundary", 192, "boundary", [0.0]),
+    ("ur5_qp_wall", "ur5", "qp_wall", 96, "mixed", [0.0]),
 ]
+# offsets from a joint limit the "boundary" distribution plants (pseudo_inverse.py:222-252 thresholds e - bound
+# at 1e-12): exactly on the limit, either side of the 1e-12 margin, and up to 1e-6 away
+BOUNDARY_OFFSETS = [0.0, 5e-13, -5e-13, 1e-12, -1e-12, 2e-12, -2e-12, 1e-10, -1e-10, 1e-9, -1e-9, 1e-7, -1e-7,
+                    1e-6, -1e-6]
 
 
 def inputs(chain, T_fk, B, dist, seed):
@@ -159,6 +166,13 @@ def inputs(chain, T_fk, B, dist, seed):
     else:
         r = hi - lo
         Q = rng.uniform(lo - 0.05 * r, hi + 0.05 * r, size=(B, len(lo)))
+    if dist == "boundary":
+        # interior configurations with one to three joints planted within 1e-6 of a limit (either limit, either side)
+        Q = rng.uniform(0.9 * lo, 0.9 * hi, size=(B, len(lo)))
+        for b in range(B):
+            for j in rng.choice(len(lo), size=int(rng.integers(1, 4)), replace=False):
+                lim = lo[j] if rng.random() < 0.5 else hi[j]
+                Q[b, j] = lim + BOUNDARY_OFFSETS[int(rng.integers(len(BOUNDARY_OFFSETS)))]
     Qd = rng.uniform(0.8 * lo, 0.8 * hi, size=(B, len(lo)))
     Y = np.zeros((B, 7))
     for b in range(B):
@@ -167,8 +181,67 @@ def inputs(chain, T_fk, B, dist, seed):
     return Q, Y
 
 
+def check_reference_held_outputs():
+    """Tie the stand-in casadi to the outputs the reference itself stores, through the
+    REFERENCE package:
+      * print_constraints() of the notebooks' skills, rebuilt with reference classes over the stand-in, must equal
+        the text the notebooks store verbatim (tests/golden/notebook_prints.json): pins MX.nnz() of a Jacobian as the
+        dependence test (skill_specification.py:228-250 -> _has_virtual / _has_input), the stable priority sort
+        (:139-152) and the per-class counters;
+      * forward kinematics multiplied out with the stand-in's sin / cos / mtimes from the reference's UR5 URDF must
+        give ||p|| = 1.0192 at UR5_home and the home dual quaternion the notebooks print."""
+    import io
+    import json
+    data = json.load(open(os.path.join(HERE, "notebook_prints.json")))
+    for fx in data["prints"]:
+        t, p, dp = cs.MX.sym("t"), cs.MX.sym("p"), cs.MX.sym("dp")
+        x, dx = (cs.MX.sym("x"), cs.MX.sym("dx")) if fx["virtual"] else (None, None)
+        sym = {"q": p, "x": x, "t": t}
+        cons = []
+        for c in fx["constraints"]:
+            expr = 0.5
+            for d in c["depends"]:
+                expr = expr + (0.4 * cs.sin(0.3 * sym[d]) if d != "q" else sym[d])
+            kw = dict(label=c["label"], expression=expr, priority=c["priority"], constraint_type=c["constraint_type"])
+            if c["cls"] == "SetConstraint":
+                cons.append(cc.SetConstraint(set_min=0.0, set_max=1.0, **kw))
+            elif c["cls"] == "VelocitySetConstraint":
+                cons.append(cc.VelocitySetConstraint(set_min=-0.275, set_max=0.275, **kw))
+            else:
+                cons.append(cc.EqualityConstraint(gain=1.0, **kw))
+        spec = cc.SkillSpecification(label=fx["label"], time_var=t, robot_var=p, robot_vel_var=dp, virtual_var=x,
+                                     virtual_vel_var=dx, constraints=cons)
+        buf, old = io.StringIO(), sys.stdout
+        sys.stdout = buf
+        try:
+            spec.print_constraints()
+        finally:
+            sys.stdout = old
+        assert buf.getvalue() == fx["stdout"], (fx["notebook"], fx["cell"], buf.getvalue(), fx["stdout"])
+    urdf, root, tip = ROBOTS["ur5"]
+    T_fk = make_T_fk(load_chain(urdf, root, tip))
+    home = [0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0]
+    T = numeric_fk(T_fk, 6, home)
+    assert abs(np.linalg.norm(T[:3, 3]) - 1.0192) < 5e-5, np.linalg.norm(T[:3, 3])
+    assert np.allclose(T[:3, 3], [0.0, 0.19145, 1.001059], atol=1e-9)
+    assert np.allclose(T[:3, :3], [[1, 0, 0], [0, 0, 1], [0, -1, 0]], atol=1e-9)
+    # the dual quaternion [r; 1/2 t (x) r] of that frame (ur5_dual_quaternion_comparison_of_controllers.ipynb cell 7)
+    r = quat_from_matrix(T[:3, :3])
+    tx, ty, tz = T[:3, 3]
+    x_, y_, z_, w_ = r
+    d = 0.5 * np.array([tx * w_ + ty * z_ - tz * y_, -tx * z_ + ty * w_ + tz * x_, tx * y_ - ty * x_ + tz * w_,
+                        -tx * x_ - ty * y_ - tz * z_])
+    printed = np.array([-0.707107, -3.46237e-12, -3.46237e-12, 0.707107, -3.40946e-13, -0.28624, 0.421616, 3.21923e-13])
+    Qh = np.concatenate([r, d])
+    assert min(np.abs(Qh - printed).max(), np.abs(Qh + printed).max()) < 5e-7, Qh
+    print("reference-held outputs reproduced through the reference package over the stand-in: %d print_constraints() "
+          "texts verbatim, UR5 home ||p|| = %.5f, home dual quaternion" % (len(data["prints"]), np.linalg.norm(T[:3, 3])))
+    return {"n_prints": len(data["prints"]), "ur5_home_norm": float(np.linalg.norm(T[:3, 3]))}
+
+
 def main():
-    out = {}
+    held = check_reference_held_outputs()
+    out = {"refheld_n_prints": np.array(held["n_prints"]), "refheld_ur5_home_norm": np.array(held["ur5_home_norm"])}
     for k, (name, robot, case, B, dist, times) in enumerate(PLAN):
         urdf, root, tip = ROBOTS[robot]
         chain = load_chain(urdf, root, tip)
@@ -219,6 +292,7 @@ def main():
             lbA, ubA = np.zeros((B, nc)), np.zeros((B, nc))
             dq, dx, slack = np.zeros((B, n)), np.zeros((B, nx)), np.zeros((B, spec.n_slack_var))
             ivirt, islack = np.zeros((B, nx)), np.zeros((B, spec.n_slack_var))
+            status = np.zeros(B, dtype=np.int32)
             worst = 0.0
             for b in range(B):
                 kw = {}
@@ -226,7 +300,25 @@ def main():
                     kw["input_var"] = Y[b, :ny]
                 if nx:
                     kw["virtual_var"] = X[b]
-                rq, rx, rs = ctrl.solve(times[0], Q[b], **kw)
+                vals_ = [times[0], Q[b]] + ([X[b]] if nx else []) + ([Y[b, :ny]] if ny else [])
+                try:
+                    rq, rx, rs = ctrl.solve(times[0], Q[b], **kw)
+                except RuntimeError:
+                    # the reference surfaces an infeasible QP as the solver's RuntimeError (reactive_qp.py:491-513):
+                    # recorded as status 2 (rows of the data functions are still the reference's)
+                    status[b] = 2
+                    Hb = ctrl.H_func(*vals_).full()
+                    H[b], A[b] = np.diag(Hb), ctrl.A_func(*vals_).full()
+                    lbA[b], ubA[b] = ctrl.Blb_func(*vals_).full().reshape(-1), ctrl.Bub_func(*vals_).full().reshape(-1)
+                    # ... and only if the rows really admit no point (an LP says so; a stand-in solver that merely
+                    # failed to converge must not become a pinned "infeasible")
+                    from scipy.optimize import linprog
+                    Aub = np.vstack([A[b], -A[b], ])
+                    bub = np.concatenate([ubA[b], -lbA[b]])
+                    lp = linprog(np.zeros(nv), A_ub=Aub, b_ub=bub, bounds=[(None, None)] * nv, method="highs")
+                    assert lp.status == 2, ("stand-in QP failed on a feasible problem", name, b, lp.status)
+                    dq[b], slack[b] = np.nan, np.nan
+                    continue
                 vals = [times[0], Q[b]] + ([X[b]] if nx else []) + ([Y[b, :ny]] if ny else [])
                 Hb = ctrl.H_func(*vals).full()
                 H[b], A[b] = np.diag(Hb), ctrl.A_func(*vals).full()
@@ -253,7 +345,10 @@ def main():
             out.update({name + "_H": H, name + "_A": A, name + "_lbA": lbA, name + "_ubA": ubA, name + "_dq": dq,
                         name + "_dx": dx, name + "_slack": slack, name + "_init_virt": ivirt,
                         name + "_init_slack": islack})
-            print("%-26s nv %d nc %d  KKT residual of the stand-in QP %.2e  max|dq| %.3g" % (name, nv, nc, worst, np.abs(dq).max()))
+            if status.any():
+                out[name + "_status"] = status
+            print("%-26s nv %d nc %d  KKT residual of the stand-in QP %.2e  max|dq| %.3g  infeasible %d" % (
+                name, nv, nc, worst, np.nanmax(np.abs(dq)), int((status == 2).sum())))
     np.savez_compressed(os.path.join(HERE, "ref_pins.npz"), **out)
     print("wrote", os.path.join(HERE, "ref_pins.npz"), "%d arrays" % len(out))
 

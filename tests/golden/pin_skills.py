@@ -242,7 +242,29 @@ def qp_sym_attrs(env):
     return dict(spec=spec, controller="qp", options={}, ny=3)
 
 
+def qp_wall(env):
+    """a GENERAL inequality row in the QP controller (reactive_qp.py:221-225): a hard SetConstraint on the tool
+    height T_fk(q)[2, 3] (the wall sets of ur5_moe2016_example2.ipynb cell 6), a soft set on the tool's x, a soft
+    position task and hard joint-speed limits"""
+    cs, cc, s = env.cs, env.cc, _syms(env, ny=3)
+    T = env.T_fk(s["q"])
+    z0 = float(np.asarray(env.consts["p_des"], float)[2])
+    x0 = float(np.asarray(env.consts["p_des"], float)[0])
+    pos = cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - s["y"], gain=3.0,
+                                constraint_type="soft", priority=5)
+    floor = cc.SetConstraint(label="floor", expression=T[2, 3], set_min=z0 - 0.25, set_max=z0 + 0.3, gain=1.0,
+                             priority=1)
+    fence = cc.SetConstraint(label="fence_x", expression=T[0, 3], set_min=x0 - 0.3, set_max=x0 + 0.35, gain=2.0,
+                             priority=2, constraint_type="soft", slack_weight=5.0)
+    speed = cc.VelocitySetConstraint(label="joint_speed_limits", expression=s["q"], set_min=-env.vmax,
+                                     set_max=env.vmax, priority=0)
+    spec = cc.SkillSpecification(label="qp_wall", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 input_var=s["y"], constraints=[pos, floor, fence, speed])
+    return dict(spec=spec, controller="qp", options={}, ny=3)
+
+
 CASES = {
+    "stack_boundary": stack_const, "qp_wall": qp_wall,
     "position": position, "pose": pose, "stack_const": stack_const, "stack_const_time": stack_const_time,
     "stack_sets1d": stack_sets1d, "stack_noff": stack_noff, "position_standard": position_standard, "conv_last": conv_last,
     "veleq_first": veleq_first, "qp_pose": qp_pose, "qp_limits": qp_limits, "qp_path": qp_path,

@@ -648,6 +648,10 @@ def _solve_qp(H, A, lb, ub, max_iter=200):
             rhs = numpy.concatenate([numpy.zeros(n), numpy.array([work[i] for i in rows])])
             sol = numpy.linalg.lstsq(K, rhs, rcond=None)[0]
             x, nu = sol[:n], sol[n:]
+            if numpy.abs(K @ sol - rhs).max() > 1e-9 * (1.0 + numpy.abs(rhs).max()):
+                # the working rows contradict each other (least squares of an inconsistent KKT system): this
+                # iteration cannot tell an infeasible problem from a bad working set - the fallback can
+                return _solve_qp_ldp(H, A, lb, ub)
         else:
             x, nu = numpy.zeros(n), numpy.zeros(0)
         # drop the inequality whose multiplier has the wrong sign the most
@@ -676,7 +680,83 @@ def _solve_qp(H, A, lb, ub, max_iter=200):
             return x, lam
         work[vi] = ub[vi] if vs > 0 else lb[vi]
         side[vi] = vs
-    raise RuntimeError("stand-in QP: no convergence")
+    return _solve_qp_ldp(H, A, lb, ub)
+
+
+def _nnls(E, f, max_iter=None):
+    """Lawson & Hanson's NNLS (Solving Least Squares Problems, ch. 23): argmin ||E u - f||, u >= 0; finite."""
+    m, n = E.shape
+    max_iter = max_iter or 30 * n
+    u = numpy.zeros(n)
+    P = numpy.zeros(n, bool)
+    w = E.T @ (f - E @ u)
+    it = 0
+    while (~P).any() and numpy.where(~P, w, -numpy.inf).max() > 1e-12 * (1.0 + numpy.abs(w).max()):
+        P[int(numpy.argmax(numpy.where(~P, w, -numpy.inf)))] = True
+        while True:
+            it += 1
+            if it > max_iter:
+                raise RuntimeError("stand-in QP: NNLS iteration cap")
+            s = numpy.zeros(n)
+            s[P] = numpy.linalg.lstsq(E[:, P], f, rcond=None)[0]
+            if (s[P] > 0).all():
+                break
+            neg = P & (s <= 0)
+            alpha = numpy.min(u[neg] / (u[neg] - s[neg]))
+            u = u + alpha * (s - u)
+            P = P & (u > 1e-15)
+            u[~P] = 0.0
+        u = s
+        w = E.T @ (f - E @ u)
+    return u
+
+
+def _solve_qp_ldp(H, A, lb, ub):
+    """The same QP as a least-distance problem (Lawson & Hanson ch. 23: min ||z|| s.t. G z >= h through one NNLS),
+    used when the working-set iteration above cycles: z = H^(1/2) x, one-sided rows C x <= d of the finite bounds.
+    NNLS identifies the active rows (and proves infeasibility: zero residual); the minimiser and multipliers then
+    come from the KKT system of those rows, solved densely.  Raises RuntimeError when no point satisfies the rows."""
+    n, m = H.shape[0], A.shape[0]
+    hd = numpy.diag(H)
+    if numpy.abs(H - numpy.diag(hd)).max() > 0:
+        raise NotImplementedError("stand-in QP fallback: diagonal H only (what casclik builds)")
+    rows, sides = [], []
+    for i in range(m):
+        if numpy.isfinite(ub[i]):
+            rows.append(i); sides.append(+1)
+        if numpy.isfinite(lb[i]):
+            rows.append(i); sides.append(-1)
+    C = numpy.array([sides[k] * A[rows[k]] for k in range(len(rows))])
+    d = numpy.array([ub[rows[k]] if sides[k] > 0 else -lb[rows[k]] for k in range(len(rows))])
+    G = -C / numpy.sqrt(hd)[None, :]
+    h = -d
+    E = numpy.vstack([G.T, h[None, :]])
+    f = numpy.zeros(n + 1); f[n] = 1.0
+    u = _nnls(E, f)
+    r = E @ u - f
+    if numpy.linalg.norm(r) < 1e-10:
+        raise RuntimeError("stand-in QP: infeasible (least-distance residual vanishes)")
+    act = [k for k in range(len(rows)) if u[k] > 0]
+    # polish on the active rows (an equality given as two opposite rows enters once)
+    work, side = {}, {}
+    for k in act:
+        i = rows[k]
+        if i in work:
+            continue
+        work[i] = ub[i] if sides[k] > 0 else lb[i]
+        side[i] = 0 if lb[i] == ub[i] else sides[k]
+    wr = sorted(work)
+    if wr:
+        Aw = A[wr]
+        K = numpy.block([[H, Aw.T], [Aw, numpy.zeros((len(wr), len(wr)))]])
+        sol = numpy.linalg.lstsq(K, numpy.concatenate([numpy.zeros(n), numpy.array([work[i] for i in wr])]), rcond=None)[0]
+        x, nu = sol[:n], sol[n:]
+    else:
+        x, nu = numpy.zeros(n), numpy.zeros(0)
+    lam = numpy.zeros(m)
+    for k, i in enumerate(wr):
+        lam[i] = nu[k]
+    return x, lam
 
 
 def conic(name, solver, structure, opts=None):

@@ -40,6 +40,13 @@ def arrays(name):
     return get("Q"), get("Y"), get("X"), PINS[name + "_t"]
 
 
+def ref_status(name):
+    """status per instance of a QP fixture: 2 where the reference's solve() raised (infeasible rows, confirmed by an
+    LP in the generator), 0 elsewhere"""
+    key = name + "_status"
+    return PINS[key] if key in PINS.files else np.zeros(len(PINS[name + "_Q"]), dtype=np.int32)
+
+
 def sigma_min_geometric(fk, Q):
     """smallest singular value of the chain's geometric Jacobian [Jv; Jw] per instance"""
     chain = fk["chain"]

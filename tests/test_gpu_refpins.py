@@ -29,7 +29,9 @@ def test_pinv_hip_matches_the_reference_run(name):
 def test_stack_kernel_variants_match_the_reference_run(lanes, monkeypatch):
     """both kernel families of the config-3 structure (lane per instance, four lanes per instance)"""
     monkeypatch.setenv("CLIK_LANES", str(lanes))
-    for name in ("iiwa_stack_const", "ur5_stack_const"):
+    # (iiwa_stack_boundary: joints planted exactly on, 5e-13 ... 1e-6 inside and outside of their limits - the
+    # 1e-12 thresholds of pseudo_inverse.py:222-252 decide the mode there, and the reference's run is the judge)
+    for name in ("iiwa_stack_const", "ur5_stack_const", "iiwa_stack_boundary"):
         built = refpins.product_skill(name)
         Q, Y, X, times = refpins.arrays(name)
         ctrl = cc.PseudoInverseController(skill_spec=built["spec"], options=dict(built["options"]))
@@ -61,11 +63,13 @@ def test_qp_hip_matches_the_reference_run(name):
         fin = np.abs(P[name + "_ubA"]) < 1e9
         assert np.abs(ub - P[name + "_ubA"])[fin].max() < 1e-9 and np.array_equal(ub[~fin], P[name + "_ubA"][~fin])
     dq, dx, slack, status = ctrl.solve_batch(t, Q, virtual_var=X, input_var=Y)
-    assert (status == 0).all(), (name, np.bincount(status))
-    assert refpins.rel_err(dq, P[name + "_dq"]).max() < QP_RTOL
-    assert refpins.rel_err(slack, P[name + "_slack"]).max() < QP_RTOL
+    assert np.array_equal(status, refpins.ref_status(name)), (name, np.bincount(status))
+    ok = status == 0
+    assert np.isnan(dq[~ok]).all()
+    assert refpins.rel_err(dq[ok], P[name + "_dq"][ok]).max() < QP_RTOL
+    assert refpins.rel_err(slack[ok], P[name + "_slack"][ok]).max() < QP_RTOL
     if X is not None:
-        assert refpins.rel_err(dx, P[name + "_dx"]).max() < QP_RTOL
+        assert refpins.rel_err(dx[ok], P[name + "_dx"][ok]).max() < QP_RTOL
 
 
 @pytest.mark.parametrize("name", refpins.QP_NAMES)
@@ -80,6 +84,8 @@ def test_initial_problem_hip_matches_the_reference_run(name):
     ctrl.setup_solver()
     ctrl.setup_initial_problem_solver()
     for b in range(0, len(Q), 11):
+        if refpins.ref_status(name)[b] != 0:
+            continue
         virt, slack = ctrl.solve_initial_problem(float(times[0]), Q[b], virtual_var0=None if X is None else X[b],
                                                  input_var0=None if Y is None else Y[b])
         ref = P[name + "_init_slack"][b]

@@ -57,7 +57,10 @@ def test_team_kernel_vs_c_oracle_and_lane_kernel_full_size(iiwa_fk, monkeypatch)
     assert ("/team4" in team.kernel_variant(B)) and not ("/team4" in lane.kernel_variant(B))
     dq_t, _, mode_t = team.solve_batch(0.0, Q, input_var=Y)
     dq_l, _, mode_l = lane.solve_batch(0.0, Q, input_var=Y)
-    ref, _, ref_mode = CPinvOracle(spec, skills.STACK_OPTIONS).solve_batch(0.0, Q, Y=Y)
+    margin = np.full(B, np.inf)
+    ref, _, ref_mode = CPinvOracle(None, skills.STACK_OPTIONS, baseline=("iiwa", "stack")).solve_batch(
+        0.0, Q, Y=Y, margins_out=margin)
+    assert margin.min() > 1e-7          # (no tangent-cone decision of this batch is within rounding of flipping)
     assert np.array_equal(mode_t, ref_mode) and np.array_equal(mode_l, ref_mode)
     assert _rel(dq_t, ref).max() < PINV_RTOL
     assert _rel(dq_t, dq_l).max() < PINV_RTOL

@@ -388,3 +388,33 @@ def test_notebook_golden_vectors_are_the_oracles_answers(ur5_fk):
     assert np.abs(dq[ok] - g["pendulum_qp_dq"][ok]).max() < 1e-12 and np.abs(slack[ok] - g["pendulum_qp_slack"][ok]).max() < 1e-12
     dq, mode = orc.pinv_solve_batch(dual_quaternion_skill(ur5_fk, "Q_dist2", for_pinv=True), None, 0.0, g["ur5_Q"])
     assert np.array_equal(mode, g["dq_pinv_mode"]) and np.abs(dq - g["dq_pinv_dq"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("robot", ["iiwa", "ur5"])
+@pytest.mark.parametrize("which", ["position", "pose", "stack", "qp"])
+def test_independent_baseline_descriptors_equal_the_lowered_ones(robot, which, iiwa_fk, ur5_fk):
+    """oracle/baseline_desc.py writes the flat descriptors of the BASELINE skills down from the URDF and SURVEY.md
+    8(d) without the product's front-end; casclik_amd/lowering.py derives them from the skill scripts' expression
+    graphs.  Two independent statements of the same skill must give the same struct, byte for byte - a check of the
+    lowering, and the reason the C restatement fed with the former is a witness of more than the kernels' algebra."""
+    from casclik_amd import _capi
+    from casclik_amd.lowering import lower_skill
+    from oracle import baseline_desc
+    fk = iiwa_fk if robot == "iiwa" else ur5_fk
+    mk = {"position": skills.position_skill, "pose": skills.pose_skill, "stack": skills.stack_skill,
+          "qp": skills.qp_skill}[which]
+    direct, dims = baseline_desc.baseline_descriptor(robot, which)
+    lowered = _capi.desc_to_c(lower_skill(mk(fk)))
+    assert bytes(direct) == bytes(lowered)
+    assert dims[0] == len(fk["joint_names"])
+
+
+def test_c_qp_port_equals_the_numpy_qp_oracle(iiwa_fk):
+    """orc_qp_solve_batch (the compiled CPU baseline of the QP path) against oracle/clik_oracle.py::qp_solve_batch"""
+    from oracle import c_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 96, seed=3, distribution="mixed")
+    dq, _, slack, status = c_oracle.CQpOracle(None, baseline=("iiwa", "qp")).solve_batch(0.0, Q, Y=Y)
+    rdq, _, rslack, rstatus = orc.qp_solve_batch(spec, 0.0, Q, Y=Y)
+    assert np.array_equal(status, rstatus) and (status == 0).all()
+    assert np.abs(dq - rdq).max() < 1e-10 and np.abs(slack - rslack).max() < 1e-10
