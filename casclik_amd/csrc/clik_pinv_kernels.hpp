@@ -645,6 +645,29 @@ __global__ __launch_bounds__(WAVE) void pinv_rollout_kernel(
     if (mode_out != nullptr && valid) mode_out[b0 + lane] = acc_mode;
 }
 
+// ---- kernel body time (only in builds with -DCLIK_BODY_STAMPS, tools/stamp_body.py; never in the shipped
+// library): every wave stamps s_memrealtime (the 100 MHz constant clock all XCDs share) when it starts and after
+// its last store has landed; body of a launch = max(end) - min(start) over its waves, read back for the LAST launch
+// of a back-to-back sequence.
+#ifdef CLIK_BODY_STAMPS
+__device__ unsigned long long g_clik_body[2 * 32768];
+#define CLIK_BODY_STAMP(slot, drain)                                                            \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
+        unsigned long long t_;                                                                  \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        const unsigned w_ = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                        \
+        if ((threadIdx.x & 63u) == 0u && w_ < 32768u) g_clik_body[2u * w_ + (slot)] = t_;        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#define CLIK_BODY_BEGIN() CLIK_BODY_STAMP(0, 0)
+#define CLIK_BODY_END() CLIK_BODY_STAMP(1, 1)
+#else
+#define CLIK_BODY_BEGIN()
+#define CLIK_BODY_END()
+#endif
+
 // ---- diagnostic time stamps (only in builds with -DCLIK_STAMPS, never in the shipped
 // library): s_memtime at phase boundaries of the static kernel, one record per block,
 // written to a buffer no other code reads.
@@ -1509,6 +1532,7 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
     int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
     static_assert(SD.n_x == 0, "value-specialised lane kernel: robot variables only");
+    CLIK_BODY_BEGIN();
     constexpr int N = SD.n;
     constexpr Img<SD> Sval = IMGV::value;        // (a local constant: its loads fold to immediates)
     const int lane = threadIdx.x;
@@ -1527,6 +1551,7 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
         for (int j = 0; j < N; ++j) dq[inst * N + j] = vout[j];
         if (mode_out != nullptr) mode_out[inst] = acc_mode;
     }
+    CLIK_BODY_END();
 }
 
 // the value-specialised kernel of a skill for one tick: four lanes per instance where the family allows and the

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     double* ys = zs + N * TEAM_INST;                        // [64][NY]
     typedef double d2 __attribute__((ext_vector_type(2)));
     CLIK_STAMP_W(0, 0);
+    CLIK_BODY_BEGIN();
     // Value-specialised instantiation: every index into the state / input rows is a literal, so each lane reads its
     // instance's rows straight from global memory into registers (the four lanes of a quad hit the same addresses,
     // a wave's 16 rows are contiguous) and the selected lane stores the velocities itself: no LDS, no barrier.
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
         }
     }
     CLIK_STAMP_W(0, 5);
+    CLIK_BODY_END();
 }
 
 // n_ticks of (tick -> clamp(+-max_speed) -> integrate) in one launch with four lanes per instance: the host loop

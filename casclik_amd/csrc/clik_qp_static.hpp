@@ -1417,6 +1417,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
     static_assert(LY::BOX, "box family only");
     constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
     constexpr QpImg<SD> kValues = IMGV::value;
+    CLIK_BODY_BEGIN();
     const int lane = threadIdx.x;
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
@@ -1451,6 +1452,7 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
         }
         if (status_out != nullptr) status_out[inst] = status;
     }
+    CLIK_BODY_END();
 }
 
 // ... and its on-device rollout (see qp_rollout_static_kernel): state, working set and Runge-Kutta bookkeeping in
