@@ -458,7 +458,12 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
                 "tick_us": tick_us, "tick_us_mean": dev_ms * 1e3 / timed_steps,
                 "tick_us_is": "HIP events on the launch stream around each graph replay / its ticks: kernel body + "
                               "the dependent-launch boundary (an upper bound of the kernel's duration)",
-                "kernel_body_us": body.get("body_us_median") if body else None,
+                # first wave start -> last wave end (s_memrealtime stamps, tools/stamp_body.py): the stamped build's
+                # own body, the dependent-launch boundary it leaves of its tick, and this run's tick minus that
+                # boundary = the shipped kernel's body
+                "kernel_body_us": (tick_us - body["boundary_us"]) if body else None,
+                "kernel_body_us_stamped_build": body.get("body_us_median") if body else None,
+                "launch_boundary_us": body.get("boundary_us") if body else None,
                 "kernel_body_source": body_src,
                 "algorithmic_bytes_per_instance": bytes_per_inst,
                 "algorithmic_bytes_per_launch": alg_bytes}

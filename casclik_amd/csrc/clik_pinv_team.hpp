@@ -553,6 +553,129 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
     }
 }
 
+// ---- resident ticks -----------------------------------------------------------------------------------------
+// ONE launch of the value-specialised team kernel that stays on the device and runs tick k whenever the producer of
+// the inputs has published ticket k (clik_ticket::in_seq >= k, written with release semantics after q / y): a closed
+// loop with fresh targets every tick then costs a device-side hand-off instead of a kernel launch.  Every wave polls
+// the ticket itself (the four waves of a block share nothing in this instantiation), reads its rows after the acquire,
+// runs the tick, stores, and adds 1 to out_count behind a release fence; tick k is complete when out_count reaches
+// k x (waves per tick).  The kernel leaves when n_ticks are done, when anyone sets `stop`, or when its watchdog (the
+// 100 MHz s_memrealtime clock against the timeout given at launch) expires - it then writes stop = 2 so that every
+// other wave and the producer leave too.  It never spins without that check.
+struct ResidentTicket {
+    unsigned in_seq, p0[15];
+    unsigned out_count, p1[15];
+    unsigned stop, p2[15];
+    unsigned waves, ticks_done, p3[14];
+};
+static_assert(sizeof(ResidentTicket) == 256, "clik_ticket layout (include/clik.h)");
+
+__device__ __forceinline__ unsigned long long realtime_100mhz()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
+    const double* q, const double* y, double* dq, int32_t* mode_out, const long long B, const TickArgs tk,
+    ResidentTicket* ticket, const int n_ticks, const unsigned long long timeout_ticks)
+{
+    static_assert(shape_team_ok(SD), "shape outside the team kernel's family");
+    static_assert(!std::is_void<IMGV>::value, "resident ticks: value-specialised instantiation only");
+    constexpr int N = SD.n, NY = SD.n_y > 0 ? SD.n_y : 0;
+    const int tid = threadIdx.x;
+    const int r = tid & (TEAM - 1);
+    const int inst = tid >> 2;
+    const long long b0 = (long long)blockIdx.x * TEAM_INST;
+    const bool valid = b0 + inst < B;
+    const long long binst = valid ? (b0 + inst) : (B - 1);
+    constexpr Img<SD> Sval = IMGV::value;
+    const unsigned long long t_start = realtime_100mhz();
+    if (blockIdx.x == 0 && tid == 0) ticket->waves = gridDim.x * TEAM_WAVES;
+    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+#pragma unroll 1
+    for (int k = 1; k <= n_ticks; ++k) {
+        bool leave = false;
+#pragma unroll 1
+        for (;;) {
+            const unsigned seq = __hip_atomic_load(&ticket->in_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seq >= (unsigned)k) break;
+            if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                leave = true;
+                break;
+            }
+            if (realtime_100mhz() - t_start > timeout_ticks) {
+                __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                leave = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (leave) break;
+        double z[N], ydir[NY > 0 ? NY : 1];
+#pragma unroll
+        for (int j = 0; j < N; ++j) z[j] = q[binst * N + j];
+        if constexpr (NY > 0) {
+#pragma unroll
+            for (int j = 0; j < NY; ++j) ydir[j] = y[binst * NY + j];
+        }
+        double a0 = z[N - 1], a1 = z[N - 1];
+        static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int kk = decltype(kc)::value;
+            if constexpr (2 * kk < N) a0 = (r == kk) ? z[2 * kk] : a0;
+            if constexpr (2 * kk + 1 < N) a1 = (r == kk) ? z[2 * kk + 1] : a1;
+        });
+        (void)j0;
+        (void)j1;
+        double v[N];
+        bool in_tc;
+        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, v, in_tc);
+        const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
+        if (r == (ok0 ? 0 : 3) && valid) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) dq[(b0 + inst) * N + j] = v[j];
+            if (mode_out != nullptr) mode_out[b0 + inst] = ok0 ? 0 : 1;
+        }
+        // every lane's stores before the wave's count (release), one add per wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if ((tid & (WAVE - 1)) == 0)
+            __hip_atomic_fetch_add(&ticket->out_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
+        if (realtime_100mhz() - t_start > timeout_ticks) {
+            __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
+// reference producer / test harness of the resident ticks: publishes tickets 1 .. n_ticks from the device, either as
+// fast as it can (closed_loop = 0: the kernel never waits - its own per-tick cost) or each one only after every wave
+// has finished the previous tick (closed_loop = 1: the hand-off both ways is on the critical path)
+__global__ void resident_feed_kernel(ResidentTicket* ticket, const int n_ticks, const int closed_loop,
+                                     const unsigned waves_per_tick, const unsigned long long timeout_ticks)
+{
+    const unsigned long long t_start = realtime_100mhz();
+#pragma unroll 1
+    for (int k = 1; k <= n_ticks; ++k) {
+        if (closed_loop) {
+            const unsigned want = (unsigned)(k - 1) * waves_per_tick;
+#pragma unroll 1
+            for (;;) {
+                if (__hip_atomic_load(&ticket->out_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) break;
+                if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+                if (realtime_100mhz() - t_start > timeout_ticks) {
+                    __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __hip_atomic_store(&ticket->in_seq, (unsigned)k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <const ShapeDesc& SD>
 inline size_t team_rollout_lds_bytes(bool values = false)
 {

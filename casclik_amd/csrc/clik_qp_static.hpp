@@ -555,9 +555,63 @@ constexpr bool qp_box_family(const ShapeDesc& sd)
 #define CLIK_QP_BOX_OK(SD) qp_box_family(SD)
 #endif
 
+// Mixed family (round 3): the rows left after folding are hard bounds on single states (the box), a few HARD
+// GENERAL rows (a SetConstraint on a task-space expression - the wall sets of ur5_moe2016_example2.ipynb cell 6 -
+// reactive_qp.py:221-225; hard equalities), and SOFT inequality rows.  A soft inequality row  lb <= a v - s <= ub
+// with cost 1/2 h s^2  is exactly a bounded variable  w = a v - s in [lb, ub]  with cost  1/2 h (a v - w)^2: it is
+// LIFTED into the box (z = [v; w]).  The hard general rows enter a primal active set next to the held states
+// (qp_mixed_pas).  Row kinds, in plan order:
+constexpr int QPK_BOX = 0, QPK_HARD = 1, QPK_LIFT = 2;
+#ifndef CLIK_QP_MIXED_MAX_Z
+#define CLIK_QP_MIXED_MAX_Z 8          // states + lifted rows carried in registers
+#endif
+#ifndef CLIK_QP_MIXED_MAX_H
+#define CLIK_QP_MIXED_MAX_H 3          // hard general rows
+#endif
+constexpr int qp_row_kind(const ShapeDesc& sd, const QpPlanS& p, int r)
+{
+    const int ti = p.row_task[r];
+    if (sd.soft[ti] != 0) return QPK_LIFT;
+    if (shape_unit(sd, ti) && (sd.cls[ti] == CLIK_CLS_SET || sd.cls[ti] == CLIK_CLS_VELSET)) return QPK_BOX;
+    return QPK_HARD;
+}
+constexpr int qp_kind_count(const ShapeDesc& sd, int kind)
+{
+    const QpPlanS p = make_qp_plan(sd);
+    int n = 0;
+    for (int r = 0; r < p.nr && r < CLIK_MAX_QPROWS; ++r) n += qp_row_kind(sd, p, r) == kind;
+    return n;
+}
+// index of row r among the rows of its kind
+constexpr int qp_kind_index(const ShapeDesc& sd, int r)
+{
+    const QpPlanS p = make_qp_plan(sd);
+    const int kind = qp_row_kind(sd, p, r);
+    int n = 0;
+    for (int q = 0; q < r; ++q) n += qp_row_kind(sd, p, q) == kind;
+    return n;
+}
+constexpr bool qp_mixed_family(const ShapeDesc& sd)
+{
+    const QpPlanS p = make_qp_plan(sd);
+    if (p.nr <= 0 || p.nr > CLIK_MAX_QPROWS || qp_box_family(sd)) return false;
+    const int nl = qp_kind_count(sd, QPK_LIFT), nh = qp_kind_count(sd, QPK_HARD);
+    if (nl + nh == 0) return false;
+    // (skills with generated attribute code keep the dual iteration: its row bounds come through another path)
+    return sd.n + nl <= CLIK_QP_MIXED_MAX_Z && nh <= CLIK_QP_MIXED_MAX_H;
+}
+#if defined(CLIK_QP_MIXED_OFF) || defined(CLIK_QP_BOX_OFF)
+#define CLIK_QP_MIXED_OK(SD) false
+#else
+#define CLIK_QP_MIXED_OK(SD) qp_mixed_family(SD)
+#endif
+
 template <const ShapeDesc& SD>
 struct QpLayout {
     static constexpr QpPlanS P = make_qp_plan(SD);
+    static constexpr bool MIXED = CLIK_QP_MIXED_OK(SD);
+    static constexpr int NL = MIXED ? qp_kind_count(SD, QPK_LIFT) : 0;      // lifted soft inequality rows
+    static constexpr int NH = MIXED ? qp_kind_count(SD, QPK_HARD) : 0;      // hard general rows
     static constexpr bool BOX = CLIK_QP_BOX_OK(SD);
     static constexpr int N = SD.n;
     static constexpr int NY = SD.n_y > 0 ? SD.n_y : 0;
@@ -573,11 +627,12 @@ struct QpLayout {
     static constexpr int O_Z = 0;
     static constexpr int O_Y = O_Z + N;
     static constexpr int O_Q = O_Y + NY;
-    static constexpr int O_LB = O_Q + (BOX ? 0 : NT);       // (the box solver keeps no Q / Y / c0 in LDS)
+    static constexpr bool PRIMAL = BOX || MIXED;            // (the primal solvers keep no Q / Y / c0 in LDS)
+    static constexpr int O_LB = O_Q + (PRIMAL ? 0 : NT);
     static constexpr int O_UB = O_LB + NRA;
     static constexpr int O_C0 = O_UB + NRA;
-    static constexpr int O_YS = O_C0 + (BOX ? 0 : NRA);      // P^-1 a_r'  (NR x N)
-    static constexpr int O_SL = O_YS + (BOX ? 0 : NRA * N);  // folded right-hand sides, then the slack output rows
+    static constexpr int O_YS = O_C0 + (PRIMAL ? 0 : NRA);      // P^-1 a_r'  (NR x N)
+    static constexpr int O_SL = O_YS + (PRIMAL ? 0 : NRA * N);  // folded right-hand sides, then the slack output rows
     static constexpr int SLOTS = O_SL + NSA;
     static constexpr size_t LDS_BYTES = ((size_t)IMG_DOUBLES + (size_t)SLOTS * WAVE) * sizeof(double);
 };
@@ -1074,6 +1129,301 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
     return status;
 }
 
+// Primal active set for  min f(z) = 1/2 z'P z - g'z,  lb_c <= z_c <= ub_c,  lbg_r <= G_r z <= ubg_r  (P symmetric
+// positive definite, packed lower triangle, NZ variables; G has NH rows that touch the first NV variables only).
+// The working set holds states on their bounds (as in qp_box_pas) AND rows on one of theirs (act_r = -1 / +1;
+// a row with lbg == ubg is an equality: always active, never released).  One pass:
+//   M = P with a 1e30 penalty on the held diagonal (one fixed-size LDL' for all lanes), d0 = M^-1 grad_F,
+//   Y_r = M^-1 G_r' (NH solves with the same factor), S = G Y (NH x NH; 1e30 on the diagonal of inactive rows),
+//   lambda = S^-1 (res - G d0)  with  res_r = G_r z - bound_r  on the active rows: the Newton step  d = d0 + Y lambda
+//     minimises f on the face AND removes the residual of its active rows, so the iteration may start with rows that
+//     are violated (they start active at the violated bound; no phase 1),
+//   ratio test along z - alpha d over the free states' bounds and the inactive rows (both kinds land and join W),
+//   alpha = 1: z is the face minimum, -lambda are the row multipliers there: the held state or active row whose
+//     multiplier is wrong by the largest amount is released; none: KKT point - unless an active row is still off its
+//     bound (S was singular on this face: its residual cannot be removed with the states that are left, and no
+//     multiplier asks for a release): the rows admit no point, status 2.
+// Start: Gauss-Seidel sweeps on the box as in qp_box_pas, rows violated there start active; hot: the partition of the
+// previous tick (hot = atL | atU << 10 | rows at their lower bound << 20 | rows at their upper bound << 24).
+// numpy prototype and its sweep against the oracle: tools/_build/qp_mixed_proto.py (1500 random problems with 1-4
+// general rows, 4-8 variables: every minimiser to 3e-10, every infeasible one recognised, no pass cap).
+// Returns 0 (KKT point), 1 (pass cap), 2 (no feasible point).
+template <int NZ, int NV, int NH>
+__device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2], const double (&g)[NZ],
+                                            const double (&lb)[NZ], const double (&ub)[NZ],
+                                            const double (&G)[NH > 0 ? NH : 1][NV], const double (&lbg)[NH > 0 ? NH : 1],
+                                            const double (&ubg)[NH > 0 ? NH : 1], const int max_pass, const bool valid,
+                                            double (&x)[NZ], int32_t* hot, const bool use_hot)
+{
+    constexpr int NT = NZ * (NZ + 1) / 2;
+    constexpr int NHA = NH > 0 ? NH : 1;
+    constexpr int NHT = NHA * (NHA + 1) / 2;
+    constexpr int kOne = 0x3ff00000;
+    auto as_mask = [](const int hi) __attribute__((always_inline)) { return __hiloint2double(hi, 0); };
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) empty = empty | (lb[a] - ub[a] > 1e-9 * fmax(1.0, fmax(fabs(lb[a]), fabs(ub[a]))));
+#pragma unroll
+    for (int r = 0; r < NH; ++r) empty = empty | (lbg[r] - ubg[r] > 1e-9 * fmax(1.0, fmax(fabs(lbg[r]), fabs(ubg[r]))));
+    uint32_t hl = 0u, hu = 0u, rl = 0u, ru = 0u;
+    if (use_hot && hot != nullptr) {
+        const uint32_t h = (uint32_t)*hot;
+        hl = h & 0x3ffu;
+        hu = (h >> 10) & 0x3ffu & ~hl;
+        rl = (h >> 20) & 0xfu;
+        ru = (h >> 24) & 0xfu & ~rl;
+    }
+    int held[NZ], free_ok[NZ];
+    double tol[NZ];
+    if (!use_hot) {
+        double ip[NZ], res[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            ip[a] = __builtin_amdgcn_rcp(Pm[tri(a, a)]);
+            x[a] = fmin(fmax(g[a] * ip[a], lb[a]), ub[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            double sacc = g[a];
+#pragma unroll
+            for (int b = 0; b < NZ; ++b) sacc = fma(-Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
+            res[a] = sacc;
+        }
+#pragma unroll 1
+        for (int sweep = 0; sweep < CLIK_QP_BOX_SWEEPS; ++sweep) {
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) {
+                const double xa = fmin(fmax(fma(res[a], ip[a], x[a]), lb[a]), ub[a]);
+                const double dl = xa - x[a];
+                x[a] = xa;
+#pragma unroll
+                for (int b = 0; b < NZ; ++b) res[b] = fma(-Pm[a >= b ? tri(a, b) : tri(b, a)], dl, res[b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) {
+        const double mid = fmin(fmax(0.0, lb[a]), ub[a]);
+        const bool has_l = lb[a] > -1e300, has_u = ub[a] < 1e300;
+        const bool on_l = (use_hot ? (((hl >> a) & 1u) != 0u) : (x[a] <= lb[a])) & has_l;
+        const bool on_u = (use_hot ? (((hu >> a) & 1u) != 0u) : (x[a] >= ub[a])) & has_u & !on_l;
+        const double xs = on_l ? lb[a] : (on_u ? ub[a] : (use_hot ? mid : x[a]));
+        x[a] = empty ? 0.0 : xs;
+        const bool pin = !(ub[a] > lb[a]);
+        held[a] = (on_l | on_u | pin) ? kOne : 0;
+        free_ok[a] = pin ? 0 : kOne;
+        tol[a] = 1e-9 * fmax(1.0, fabs(g[a]));
+    }
+    // rows: the hinted ones, the equalities, and whatever the start violates
+    int act[NHA];
+    bool eqr[NHA];
+    double tolr[NHA];
+#pragma unroll
+    for (int r = 0; r < NHA; ++r) { act[r] = 0; eqr[r] = false; tolr[r] = 0.0; }
+#pragma unroll
+    for (int r = 0; r < NH; ++r) {
+        double gx = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) gx = fma(G[r][j], x[j], gx);
+        eqr[r] = !(ubg[r] > lbg[r]);
+        const double su = 1e-12 * fmax(1.0, fabs(ubg[r])), sl = 1e-12 * fmax(1.0, fabs(lbg[r]));
+        int a0 = (gx > ubg[r] + su) ? 1 : ((gx < lbg[r] - sl) ? -1 : 0);
+        if (use_hot) a0 = ((ru >> r) & 1u) ? 1 : (((rl >> r) & 1u) ? -1 : a0);
+        act[r] = eqr[r] ? 1 : a0;
+    }
+    double gr[NZ];
+    auto gradient = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            double sacc = -g[a];
+#pragma unroll
+            for (int b = 0; b < NZ; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
+            gr[a] = sacc;
+        }
+    };
+    gradient();
+    bool done = !valid | empty;
+    int status = empty ? 2 : 1;
+    double lam[NHA];
+#pragma unroll
+    for (int r = 0; r < NHA; ++r) lam[r] = 0.0;
+#pragma unroll 1
+    for (int pass = 0; pass < max_pass; ++pass) {
+        if (__ballot(!done) == 0ull) break;
+        double M[NT], rd[NZ], d[NZ];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) M[a] = Pm[a];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            const double hm = as_mask(held[a]);
+            M[tri(a, a)] = fma(hm, 1e30, Pm[tri(a, a)]);
+            d[a] = fma(-hm, gr[a], gr[a]);
+        }
+        ldl_factor_s<NZ>(M, rd);
+        ldl_solve_s<NZ>(M, rd, d);
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) d[a] = fma(-as_mask(held[a]), d[a], d[a]);      // (exactly zero on the held states)
+        if constexpr (NH > 0) {
+            double Y[NH][NZ], S[NHT], rhs[NH];
+#pragma unroll
+            for (int r = 0; r < NH; ++r) {
+#pragma unroll
+                for (int a = 0; a < NZ; ++a) Y[r][a] = (a < NV) ? fma(-as_mask(held[a]), G[r][a < NV ? a : 0], G[r][a < NV ? a : 0]) : 0.0;
+                ldl_solve_s<NZ>(M, rd, Y[r]);
+#pragma unroll
+                for (int a = 0; a < NZ; ++a) Y[r][a] = fma(-as_mask(held[a]), Y[r][a], Y[r][a]);
+            }
+#pragma unroll
+            for (int r = 0; r < NH; ++r) {
+                double gx = 0.0, gd = 0.0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    gx = fma(G[r][j], x[j], gx);
+                    gd = fma(G[r][j], d[j], gd);
+                }
+                const double bnd = (act[r] > 0) ? ubg[r] : lbg[r];
+                rhs[r] = (act[r] != 0) ? (gx - bnd) - gd : 0.0;
+#pragma unroll
+                for (int q = 0; q <= r; ++q) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) acc = fma(G[r][j], Y[q][j], acc);
+                    S[tri(r, q)] = acc;
+                }
+                S[tri(r, r)] += (act[r] != 0) ? 1e-13 : 1e30;
+            }
+            double rs[NH];
+            ldl_factor_s<NH>(S, rs);
+            ldl_solve_s<NH>(S, rs, rhs);
+#pragma unroll
+            for (int r = 0; r < NH; ++r) {
+                lam[r] = (act[r] != 0) ? rhs[r] : 0.0;
+#pragma unroll
+                for (int a = 0; a < NZ; ++a) d[a] = fma(lam[r], Y[r][a], d[a]);
+            }
+        }
+        // first bound hit along x - alpha d: free states, then inactive rows
+        double tgt[NZ], rr[NZ];
+        double amin = 1.0;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            tgt[a] = (d[a] > 0.0) ? lb[a] : ub[a];
+            rr[a] = fabs(x[a] - tgt[a]) * __builtin_amdgcn_rcp(fabs(d[a]));
+            amin = fmin(amin, rr[a]);
+        }
+        double rq[NHA], slp[NHA];
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            double gx = 0.0, gd = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                gx = fma(G[r][j], x[j], gx);
+                gd = fma(G[r][j], d[j], gd);
+            }
+            slp[r] = gd;
+            const double tg = (gd > 0.0) ? lbg[r] : ubg[r];
+            const double q = fabs(gx - tg) * __builtin_amdgcn_rcp(fabs(gd));
+            rq[r] = (act[r] == 0 && gd != 0.0) ? q : __builtin_inf();
+            amin = fmin(amin, rq[r]);
+        }
+        const bool blocked = amin < 1.0;
+        const double alpha = done ? 0.0 : amin;
+        const double thr = amin * (1.0 + 1e-7);
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            const double xn = fma(-alpha, d[a], x[a]);
+            const bool lands = blocked & !done & (rr[a] <= thr);
+            x[a] = lands ? tgt[a] : xn;
+            held[a] = lands ? kOne : held[a];
+        }
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            const bool lands = blocked & !done & (rq[r] <= thr);
+            act[r] = lands ? ((slp[r] > 0.0) ? -1 : 1) : act[r];
+        }
+        gradient();
+        // at a face minimum: release the held state / active row whose multiplier is wrong by the largest amount
+        double c[NZ], cr[NHA];
+        double worst = 0.0;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            double gf = gr[a];
+            if (a < NV) {
+#pragma unroll
+                for (int r = 0; r < NH; ++r) gf = fma(lam[r], G[r][a < NV ? a : 0], gf);
+            }
+            const double push = (x[a] <= lb[a]) ? -gf : gf;
+            c[a] = fma(push, as_mask(held[a] & free_ok[a]), -tol[a]);
+            worst = fmax(worst, c[a]);
+        }
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            const double pr = (act[r] != 0 && !eqr[r]) ? -(double)act[r] * lam[r] : 0.0;
+            cr[r] = pr - 1e-9 * fmax(1.0, fabs(lam[r]));
+            worst = fmax(worst, cr[r]);
+        }
+        const bool release = !blocked & !done & (worst > 0.0);
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) held[a] = (release & (c[a] == worst)) ? 0 : held[a];
+#pragma unroll
+        for (int r = 0; r < NH; ++r) act[r] = (release & (cr[r] == worst)) ? 0 : act[r];
+        const bool fin = !blocked & !(worst > 0.0);
+        if (fin & !done) {
+            // the active rows must sit on their bounds now (see above)
+            bool off = false;
+#pragma unroll
+            for (int r = 0; r < NH; ++r) {
+                double gx = 0.0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) gx = fma(G[r][j], x[j], gx);
+                const double bnd = (act[r] > 0) ? ubg[r] : lbg[r];
+                off = off | ((act[r] != 0) & (fabs(gx - bnd) > 1e-8 * fmax(1.0, fabs(bnd))));
+            }
+            status = off ? 2 : 0;
+        }
+        done = done | fin;
+    }
+    if (status == 0) {
+        // the KKT conditions of the returned point: stationarity with the row multipliers, bounds, rows
+        bool kkt = true;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            double gf = gr[a];
+            if (a < NV) {
+#pragma unroll
+                for (int r = 0; r < NH; ++r) gf = fma(lam[r], G[r][a < NV ? a : 0], gf);
+            }
+            const double t5 = 10.0 * tol[a];
+            const bool fine = ((x[a] <= lb[a]) & (gf >= -t5)) | ((x[a] >= ub[a]) & (gf <= t5)) | (fabs(gf) <= t5);
+            kkt = kkt & fine;
+        }
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            double gx = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) gx = fma(G[r][j], x[j], gx);
+            kkt = kkt & !(gx > ubg[r] + 1e-7 * fmax(1.0, fabs(ubg[r]))) & !(gx < lbg[r] - 1e-7 * fmax(1.0, fabs(lbg[r])));
+        }
+        status = kkt ? 0 : 1;
+    }
+    if (hot != nullptr && valid) {
+        uint32_t atL = 0u, atU = 0u, rowL = 0u, rowU = 0u;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+            const bool h = held[a] != 0;
+            if (h & (x[a] <= lb[a])) atL |= 1u << a;
+            else if (h & (x[a] >= ub[a])) atU |= 1u << a;
+        }
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            if (act[r] < 0) rowL |= 1u << r;
+            if (act[r] > 0) rowU |= 1u << r;
+        }
+        *hot = (int32_t)(atL | (atU << 10) | (rowL << 20) | (rowU << 24));
+    }
+    return status;
+}
+
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
@@ -1110,7 +1460,110 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
     }
     static_assert(SSTR == WAVE || QpLayout<SD>::BOX, "private slots: box family only");
     qp_gather_s<SD, 0, SSTR>(S, T, tk, tc, z, ysl, lane, L, v, slots);
-    if constexpr (LY::BOX) {
+    if constexpr (LY::MIXED) {
+        // z = [v; w]: the states and one bounded variable per soft inequality row; hard general rows beside the box
+        constexpr int NL = LY::NL, NH = LY::NH, NZ = N + NL, NHA = NH > 0 ? NH : 1;
+        constexpr int NTZ = NZ * (NZ + 1) / 2;
+        double Pz[NTZ], gz[NZ], lbz[NZ], ubz[NZ], zz[NZ];
+        double Gh[NHA][N], lbg[NHA], ubg[NHA];
+#pragma unroll
+        for (int a = 0; a < NTZ; ++a) Pz[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) Pz[tri(a, b)] = L[tri(a, b)];
+            gz[a] = v[a];
+            lbz[a] = -__builtin_inf();
+            ubz[a] = __builtin_inf();
+        }
+#pragma unroll
+        for (int a = N; a < NZ; ++a) gz[a] = 0.0;
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int TI = P.row_task[r];
+            constexpr int kind = qp_row_kind(SD, P, r);
+            const double lo = slots[(LY::O_LB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
+            const double hi = slots[(LY::O_UB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
+            if constexpr (kind == QPK_BOX) {
+                constexpr int col = SD.ucol[TI][P.row_local[r]] - 1;
+                lbz[col] = lo;
+                ubz[col] = hi;
+            } else {
+                double ar[N];
+                if constexpr (shape_unit(SD, TI)) {
+                    constexpr int col = SD.ucol[TI][P.row_local[r]] - 1;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) ar[j] = (j == col) ? 1.0 : 0.0;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) ar[j] = qp_row_s<SD, r>(S, tc, j);
+                }
+                if constexpr (kind == QPK_LIFT) {
+                    constexpr int k = N + qp_kind_index(SD, r);
+                    constexpr int sk = P.slack_base[TI] + P.row_local[r];
+                    const double hs = T->mu + T->slack_w[sk];
+#pragma unroll
+                    for (int a = 0; a < N; ++a) {
+                        const double ha = hs * ar[a];
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) Pz[tri(a, b)] = fma(ha, ar[b], Pz[tri(a, b)]);
+                        Pz[tri(k, a)] = -ha;
+                    }
+                    Pz[tri(k, k)] = hs;
+                    lbz[k] = lo;
+                    ubz[k] = hi;
+                } else {
+                    constexpr int k = qp_kind_index(SD, r);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) Gh[k][j] = ar[j];
+                    lbg[k] = lo;
+                    ubg[k] = hi;
+                }
+            }
+        });
+        int status = qp_mixed_pas<NZ, N, NH>(Pz, gz, lbz, ubz, Gh, lbg, ubg, T->max_iter, valid, zz, hot, use_hot);
+        if (!valid) status = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) v[a] = zz[a];
+        // slack: folded rows s = J v - b; lifted rows s = a v - w
+#pragma unroll
+        for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * SSTR + (SSTR == 1 ? 0 : lane)] : 0.0;
+        static_for<0, SD.n_tasks>([&](auto tc_) __attribute__((always_inline)) {
+            constexpr int TI = decltype(tc_)::value;
+            if constexpr (P.folded[TI]) {
+                constexpr int sb = P.slack_base[TI];
+                static_for<0, SD.m[TI]>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    double acc = -sl[sb + i];
+                    if constexpr (shape_unit(SD, TI)) {
+                        constexpr int col = SD.ucol[TI][i] - 1;
+                        acc += v[col];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) acc = fma(jac<SD, TI>(S, tc, i, j), v[j], acc);
+                    }
+                    sl[sb + i] = acc;
+                });
+            }
+        });
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int TI = P.row_task[r];
+            if constexpr (qp_row_kind(SD, P, r) == QPK_LIFT) {
+                constexpr int k = N + qp_kind_index(SD, r);
+                constexpr int sk = P.slack_base[TI] + P.row_local[r];
+                double acc = -zz[k];
+                if constexpr (shape_unit(SD, TI)) {
+                    acc += v[SD.ucol[TI][P.row_local[r]] - 1];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc = fma(qp_row_s<SD, r>(S, tc, j), v[j], acc);
+                }
+                sl[sk] = acc;
+            }
+        });
+        return status;
+    } else if constexpr (LY::BOX) {
         // bounds by state (rows of the plan are unit rows on distinct states), then the primal active set
         double lbc[N], ubc[N], gv[N];
 #pragma unroll

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the QP MIXED family (GPU box): skills with hard GENERAL inequality rows (sets on tool
+position components - the wall sets of ur5_moe2016_example2.ipynb cell 6 - or on a task-space norm), soft inequality
+rows (lifted into the box), optional hard joint limits / speed limits (the box) and random soft tasks - the QPs
+clik_qp_static.hpp::qp_mixed_pas solves - through the kernel instantiated for each skill, against the numpy oracle
+(status and minimiser), cold and hot-started.
+
+    python tools/fuzz_qp_mixed.py [n_skills] [seed]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np                                   # noqa: E402
+
+import casclik_amd as cc                             # noqa: E402
+from casclik_amd import skills, sym as cs            # noqa: E402
+from oracle import clik_oracle                       # noqa: E402
+from tolerances import QP_RTOL                       # noqa: E402
+
+
+def random_mixed_skill(rng, fk, n):
+    t, q, y = cs.MX.sym("t"), cs.MX.sym("q", n), cs.MX.sym("y", 7)
+    T = fk["T_fk"](q)
+    lo, hi = np.asarray(fk["lower"], float), np.asarray(fk["upper"], float)
+    vmax = np.asarray(fk["velocity"], float)
+    cons, desc = [], []
+    kind = rng.integers(0, 3)
+    w = float(rng.choice([1.0, 0.3, 5.0]))
+    if kind == 0:
+        cons.append(cc.EqualityConstraint("position", T[:3, 3] - y[:3], gain=float(rng.uniform(1, 10)),
+                                          constraint_type="soft", priority=5, slack_weight=w))
+    elif kind == 1:
+        cons.append(cc.EqualityConstraint("pose", cs.vertcat(T[:3, 3] - y[:3], cs.orientation_error(T[:3, :3], y[3:7])),
+                                          gain=float(rng.uniform(1, 10)), constraint_type="soft", priority=5, slack_weight=w))
+    else:
+        cons.append(cc.EqualityConstraint("posture", q - 0.5 * (lo + hi), gain=0.5, constraint_type="soft", priority=5))
+    desc.append(["position", "pose", "posture"][kind])
+    # hard general rows: walls on tool position components around the workspace centre
+    n_hard = int(rng.integers(0, 4))
+    axes = rng.choice(3, size=n_hard, replace=False).tolist() if n_hard else []
+    for a in axes:
+        c0 = [0.3, 0.0, 0.6][a]
+        half = float(rng.uniform(0.25, 0.6))
+        side = rng.integers(0, 3)
+        kw = {"set_min": c0 - half} if side == 1 else ({"set_max": c0 + half} if side == 2 else
+                                                       {"set_min": c0 - half, "set_max": c0 + half})
+        cons.append(cc.SetConstraint("wall_%d" % a, T[a, 3], gain=float(rng.uniform(0.5, 4.0)), priority=1, **kw))
+        desc.append("hard wall %s%s" % ("xyz"[a], ["", " (min)", " (max)"][side]))
+    # soft inequality rows (lifted): a soft wall and / or soft joint limits on a joint or two
+    n_soft = int(rng.integers(0 if n_hard else 1, 3))
+    left = max(0, 8 - n)
+    n_soft = min(n_soft, left)
+    for k in range(n_soft):
+        if rng.random() < 0.5:
+            a = int(rng.integers(0, 3))
+            c0 = [0.3, 0.0, 0.6][a]
+            cons.append(cc.SetConstraint("softwall_%d" % k, T[a, 3], set_min=c0 - 0.3, set_max=c0 + 0.3,
+                                         gain=float(rng.uniform(0.5, 3.0)), priority=2, constraint_type="soft",
+                                         slack_weight=float(rng.choice([1.0, 10.0]))))
+            desc.append("soft wall %s" % "xyz"[a])
+        else:
+            j = int(rng.integers(0, n))
+            cons.append(cc.SetConstraint("softlim_%d" % k, q[j], set_min=0.7 * lo[j], set_max=0.7 * hi[j], gain=2.0,
+                                         priority=2, constraint_type="soft", slack_weight=3.0))
+            desc.append("soft limit q%d" % j)
+    if rng.random() < 0.7:
+        js = sorted(rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False).tolist())
+        s = float(rng.choice([0.3, 1.0]))
+        cons.append(cc.VelocitySetConstraint("speed", cs.vertcat(*[q[j] for j in js]), set_min=-s * vmax[js],
+                                             set_max=s * vmax[js], priority=0))
+        desc.append("speed x%.2f on %s" % (s, js))
+    if rng.random() < 0.4:
+        js = sorted(rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False).tolist())
+        cons.append(cc.SetConstraint("joint_limits", cs.vertcat(*[q[j] for j in js]), set_min=lo[js] * 0.8,
+                                     set_max=hi[js] * 0.8, gain=float(rng.uniform(0.5, 5)), priority=0))
+        desc.append("limits on %s" % js)
+    return cc.SkillSpecification("mixed_fuzz", t, q, input_var=y, constraints=cons), "; ".join(desc)
+
+
+def main():
+    n_skills = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import torch
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for k in range(n_skills):
+        robot = "iiwa" if rng.random() < 0.4 else "ur5"
+        fk = skills.iiwa() if robot == "iiwa" else skills.ur5()
+        n = len(fk["lower"])
+        spec, what = random_mixed_skill(rng, fk, n)
+        ctrl = cc.ReactiveQPController(skill_spec=spec)
+        ctrl.setup_problem_functions()
+        ctrl.setup_solver()
+        B = 1200
+        Q, Y = skills.synthetic_inputs(fk, B, seed=2000 + k, distribution="interior")
+        if robot == "ur5":
+            Q = Q * 0.35            # (the UR5's +-2 pi ranges put the tool anywhere; keep it near the walls)
+        dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+        sub = np.arange(0, B, 3)
+        rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[sub], Y=Y[sub])
+        same = np.array_equal(status[sub], rstatus)
+        ok = (rstatus == 0) & (status[sub] == 0)
+        err = (np.abs(dq[sub][ok] - rdq[ok]).max(axis=1) / (1.0 + np.abs(rdq[ok]).max(axis=1))).max() if ok.any() else 0.0
+        serr = 0.0
+        if slack is not None and ok.any():
+            serr = (np.abs(slack[sub][ok] - rslack[ok]).max(axis=1) / (1.0 + np.abs(rslack[ok]).max(axis=1))).max()
+        hot = torch.zeros(B, dtype=torch.int32, device="cuda")
+        Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+        ctrl.solve_batch(0.0, Qd, input_var=Yd, hot_set=hot, use_hot=False)
+        res2 = ctrl.solve_batch(0.0, Qd, input_var=Yd, hot_set=hot, use_hot=True)
+        d2, st2 = res2[0].cpu().numpy(), res2[3].cpu().numpy()
+        fin = (status == 0) & (st2 == 0)
+        herr = np.abs(d2[fin] - dq[fin]).max() if fin.any() else 0.0
+        hsame = np.array_equal(st2, status)
+        flag = "" if (same and hsame and err < QP_RTOL and serr < QP_RTOL and herr < 1e-8) else "   <-- MISMATCH"
+        bad += bool(flag)
+        print("%2d %-4s %-22s status %s (oracle %s)  rel err %.1e slack %.1e  hot-vs-cold %.1e%s  [%s]%s" % (
+            k, robot, ctrl.kernel_name[:22], np.bincount(status[sub], minlength=3), np.bincount(rstatus, minlength=3), err,
+            serr, herr, "" if hsame else " hot status differs", what, flag), flush=True)
+    print("mismatching skills: %d of %d" % (bad, n_skills))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,14 @@ import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+CASES_R3 = {  # round 3 (tools/profile_round3.sh): large batches too
+    "stack_team4v_16384": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
+    "stack_lanev_131072": ("stack_mixed_B131072_kStackIiwa/lanev", "kStackIiwa/lanev", 172, 131072),
+    "stack_lanev_1M": ("stack_mixed_B1048576_kStackIiwa/lanev", "kStackIiwa/lanev", 172, 1048576),
+    "qp_16384": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 220, 16384),
+    "qp_131072": ("qp_mixed_B131072_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 220, 131072),
+    "pose_lanev_16384": ("pose_mixed_B16384_kPose6Iiwa/lanev", "kPose6Iiwa/lanev", 172, 16384),
+}
 CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per instance, batch)
     "stack_team4v": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
     "stack_team4": ("stack_mixed_B16384_kStackIiwa/team4", "kStackIiwa/team4", 172, 16384),
@@ -17,7 +25,13 @@ CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per ins
     "qp": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 168, 16384),
     "pose_lanev": ("pose_mixed_B16384_kPose6Iiwa/lanev", "kPose6Iiwa/lanev", 172, 16384),
 }
-out = {"note": "rocprofv3 --pmc passes (one counter group per run, no tracing) of python3 bench.py --graph 0 at 16384 "
+if "r3" in dst:
+    CASES = CASES_R3
+out = {"note3": "round 3: the same passes (tools/profile_round3.sh, 310 dispatches each) incl. 131072 and 1 M instances; "
+                "valu_issue_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the share of the "
+                "kernel's duration in which a SIMD issues a VALU instruction, averaged over all SIMDs; "
+                "fp64_share_of_valu = fp64 FMA + MUL + ADD instructions / all VALU instructions.",
+       "note": "rocprofv3 --pmc passes (one counter group per run, no tracing) of python3 bench.py --graph 0 at 16384 "
                "instances, inputs 'mixed'; mean per dispatch over 520 dispatches, summed over XCDs "
                "(tools/rocprof_counters.py).  traffic_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the x2 is the "
                "gfx950 correction calibrated in profiles/r1_traffic.json).  fp64_flops_per_launch = 64 lanes x "
@@ -45,6 +59,11 @@ for tag, (key, kernel, bpi, B) in CASES.items():
            "clk_per_wave": {k[3:].lower(): round(4 * raw[k] / w) for k in
                             ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
                              "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS") if k in raw}}
+    if "GRBM_GUI_ACTIVE" in raw and "SQ_ACTIVE_INST_VALU" in raw:
+        ent["gpu_active_clk"] = raw["GRBM_GUI_ACTIVE"] / 8.0
+        ent["valu_issue_frac"] = 4.0 * raw["SQ_ACTIVE_INST_VALU"] / (1024.0 * raw["GRBM_GUI_ACTIVE"] / 8.0)
+        ent["fp64_share_of_valu"] = (raw["SQ_INSTS_VALU_FMA_F64"] + raw["SQ_INSTS_VALU_MUL_F64"]
+                                     + raw["SQ_INSTS_VALU_ADD_F64"]) / raw["SQ_INSTS_VALU"]
     out[key] = ent
 with open(dst, "w") as f:
     json.dump(out, f, indent=1)
