@@ -356,6 +356,59 @@ class PseudoInverseController(BaseController):
         tick.mode = mode
         return tick
 
+    # -- resident ticks ----------------------------------------------------------------------------------------
+    def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, out=None, mode_out=None, timeout_s=2.0,
+                       stream=None):
+        """Launch ONE kernel that stays on the device and runs up to ``n_ticks`` ticks, each as soon as its ticket
+        is published (include/clik.h, clik_pinv_resident_run): for closed loops whose inputs are produced on the
+        device (or copied in behind a stream) every tick, at the price of a device-side hand-off instead of a launch.
+        ``robot_var`` / ``input_var`` must be device tensors (the producer overwrites them in place).  Returns a dict
+        with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [16] out_count, [32] stop, [48] waves,
+        [49] ticks_done), ``waves`` per tick, ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
+        leaves after ``n_ticks``, on ``ticket[32] != 0`` or after ``timeout_s`` (device clock) whatever happens."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        if not isinstance(robot_var, torch.Tensor) or not robot_var.is_cuda:
+            raise ValueError("resident ticks: robot_var must be a device tensor")
+        Q, _ = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+        B = Q.shape[0]
+        Y = None
+        if d.n_y > 0:
+            if not isinstance(input_var, torch.Tensor) or not input_var.is_cuda:
+                raise ValueError("resident ticks: input_var must be a device tensor")
+            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+        if Q.data_ptr() != robot_var.data_ptr() or (Y is not None and Y.data_ptr() != input_var.data_ptr()):
+            raise ValueError("resident ticks: inputs must be contiguous float64 device tensors (they are read in place)")
+        check_out_tensor(out, (B, d.n_q), "float64", dev, "out")
+        check_out_tensor(mode_out, (B,), "int32", dev, "mode_out")
+        dQ = out if out is not None else torch.zeros((B, d.n_q), dtype=torch.float64, device=dev)
+        mode = mode_out if mode_out is not None else torch.full((B,), -1, dtype=torch.int32, device=dev)
+        ticket = torch.zeros(64, dtype=torch.int32, device=dev)
+        stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
+        torch.cuda.current_stream(dev).synchronize()       # (ticket / outputs are initialised before the kernel starts)
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_pinv_resident_run(self._handle, B, int(n_ticks), ttp, ptr(Q), ptr(Y), ptr(dQ), ptr(mode),
+                                                  ptr(ticket), float(timeout_s), C.c_void_p(stream.cuda_stream))
+        _capi.check(self._lib, rc)
+        return {"ticket": ticket, "waves": self._lib.clik_pinv_resident_waves(self._handle, B), "out": dQ, "mode": mode,
+                "stream": stream, "keep": (Q, Y, tt)}
+
+    def resident_feed(self, run, n_ticks, closed_loop=False, timeout_s=2.0, stream=None):
+        """The reference producer of resident ticks (clik_ticket_feed): one device thread that publishes tickets
+        1 .. n_ticks on ``stream`` (a stream of its own by default), back to back or - ``closed_loop`` - each only after
+        every wave has finished the previous tick."""
+        torch = _torch()
+        dev = self._device
+        stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), int(n_ticks), 1 if closed_loop else 0, int(run["waves"]),
+                                            float(timeout_s), C.c_void_p(stream.cuda_stream))
+        _capi.check(self._lib, rc)
+        return stream
+
     def rollout_batch(self, time_vars, robot_var, input_var=None, dt=0.008,
                       max_speed=0.0, virtual_var=None, method="euler"):
         """``len(time_vars)`` ticks of solve -> clamp(+-max_speed) -> integrate in one launch.

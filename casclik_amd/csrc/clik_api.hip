@@ -61,6 +61,9 @@ size_t qp_variant_lds(int k, int ny);
 int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 bool qp_box_family_rt(const ShapeDesc& sd);
+int team_waves_rt(long long B);                 // (clik_pinv.hip)
+hipError_t launch_ticket_feed(void* ticket, int n_ticks, int closed_loop, unsigned waves_per_tick,
+                              unsigned long long timeout_ticks, hipStream_t stream);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,
@@ -98,6 +101,9 @@ struct clik_pinv {
     // image-reading team kernel would serve
     clik_jit_value_fn   val_solve;
     clik_jit_rollout_fn val_rollout;
+    // ... and its resident form (clik_pinv_attach_resident_kernel)
+    hipError_t (*val_resident)(const TickArgs*, long long, const double*, const double*, double*, int32_t*, void*, int,
+                               unsigned long long, hipStream_t);
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
@@ -676,10 +682,12 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
     h->d_img = nullptr;
     h->val_solve = nullptr;
     h->val_rollout = nullptr;
+    h->val_resident = nullptr;
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
     h->val_solve = nullptr;
     h->val_rollout = nullptr;
+    h->val_resident = nullptr;
     h->jit_name[0] = 0;
     finish_pinv_shape(S, opts);
     if (opts->pinv_method != CLIK_PINV_DAMPED && opts->pinv_method != CLIK_PINV_STANDARD) {
@@ -831,6 +839,60 @@ extern "C" int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void*
     h->val_rollout = solve_fn ? (clik_jit_rollout_fn)rollout_fn : nullptr;
     if (solve_fn) h->mode_parallel |= 64;
     else h->mode_parallel &= ~64;
+    return CLIK_OK;
+}
+
+static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk);
+
+extern "C" int clik_pinv_attach_resident_kernel(clik_pinv* h, void* resident_fn)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (resident_fn && !clik::shape_team_ok_rt(h->host.shape))
+        return fail(CLIK_EUNSUPPORTED, "resident ticks exist for the four-lanes-per-instance family only");
+    h->val_resident = (decltype(h->val_resident))resident_fn;
+    return CLIK_OK;
+}
+
+extern "C" int clik_pinv_resident_waves(const clik_pinv* h, int64_t B)
+{
+    if (!h || B <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    return clik::team_waves_rt((long long)B);
+}
+
+extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms,
+                                      const double* q, const double* y, double* dq, int32_t* mode,
+                                      clik_ticket* ticket, double timeout_s, void* stream)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (!h->val_resident)
+        return fail(CLIK_EUNSUPPORTED, "resident ticks need the value-specialised kernel of the four-lanes-per-instance "
+                                       "family attached to this handle (none is)");
+    if (B <= 0 || n_ticks <= 0) return fail(CLIK_EINVAL, "B and n_ticks must be positive");
+    if (!q || !dq || !ticket) return fail(CLIK_EINVAL, "q, dq and ticket must be device pointers");
+    const DevSkill& S = h->host;
+    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
+    // every wave of the launch must be resident at once (a wave that never starts can never count): one block of four
+    // waves per CU at most, 256 CUs
+    if (clik_pinv_resident_waves(h, B) > 4 * 256 * 2)
+        return fail(CLIK_EUNSUPPORTED, "resident ticks: at most 32768 instances (all waves must be resident at once)");
+    TickArgs tk;
+    int rc = fill_tick(S, tterms, &tk);
+    if (rc) return rc;
+    hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, n_ticks,
+                                   (unsigned long long)(timeout_s * 1e8), (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "resident kernel launch");
+    return CLIK_OK;
+}
+
+extern "C" int clik_ticket_feed(clik_ticket* ticket, int32_t n_ticks, int32_t closed_loop, int32_t waves_per_tick,
+                                double timeout_s, void* stream)
+{
+    if (!ticket || n_ticks <= 0 || waves_per_tick <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
+    hipError_t e = clik::launch_ticket_feed((void*)ticket, n_ticks, closed_loop, (unsigned)waves_per_tick,
+                                            (unsigned long long)(timeout_s * 1e8), (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "ticket feeder launch");
     return CLIK_OK;
 }
 

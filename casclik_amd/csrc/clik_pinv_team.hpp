@@ -653,6 +653,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
 // reference producer / test harness of the resident ticks: publishes tickets 1 .. n_ticks from the device, either as
 // fast as it can (closed_loop = 0: the kernel never waits - its own per-tick cost) or each one only after every wave
 // has finished the previous tick (closed_loop = 1: the hand-off both ways is on the critical path)
+template <int UNIQUE = 0>        // (a template only so that the header may be included by several translation units)
 __global__ void resident_feed_kernel(ResidentTicket* ticket, const int n_ticks, const int closed_loop,
                                      const unsigned waves_per_tick, const unsigned long long timeout_ticks)
 {

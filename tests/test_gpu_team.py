@@ -224,3 +224,52 @@ def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
     assert (np.abs(dq[::7] - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))).max() < 1e-7
     dq2, _, mode2 = plain.solve_batch(0.0, Q, input_var=Y)
     assert np.array_equal(mode, mode2) and np.allclose(dq, dq2, rtol=1e-9, atol=1e-11)
+
+
+def test_resident_ticks_fed_from_outside(iiwa_fk):
+    """clik_pinv_resident_run: ONE launch of the value-specialised team kernel runs four ticks, each on targets the host
+    copies in behind a stream and publishes with a ticket (include/clik.h); every tick's velocities and modes equal
+    those of an ordinary launch on the same inputs, the counters add up, and the kernel leaves by itself."""
+    import time
+    import torch
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    B, NT = 1000, 4
+    if "team4v" not in ctrl.kernel_variant(B):
+        pytest.skip("no value-specialised team kernel attached (hipcc missing)")
+    Q, _ = skills.synthetic_inputs(iiwa_fk, B, seed=21, distribution="mixed")
+    Ys = [skills.synthetic_inputs(iiwa_fk, B, seed=30 + k, distribution="mixed")[1] for k in range(NT)]
+    Qd = torch.from_numpy(Q).cuda()
+    want = [ctrl.solve_batch(0.0, Qd, input_var=torch.from_numpy(Yk).cuda()) for Yk in Ys]
+    Yd = torch.zeros((B, 7), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    run = ctrl.resident_start(Qd, Yd, NT, timeout_s=8.0)
+    feed = torch.cuda.Stream()
+    waves = run["waves"]
+    assert waves == ((B + 63) // 64) * 4
+    try:
+        for k in range(1, NT + 1):
+            with torch.cuda.stream(feed):
+                Yd.copy_(torch.from_numpy(Ys[k - 1]))                               # fresh targets ...
+                run["ticket"][0:1].copy_(torch.tensor([k], dtype=torch.int32))     # ... then their ticket
+            feed.synchronize()
+            t0 = time.time()
+            while True:
+                with torch.cuda.stream(feed):
+                    tk = run["ticket"].cpu()
+                if int(tk[16]) >= k * waves or int(tk[32]) != 0 or time.time() - t0 > 6.0:
+                    break
+                time.sleep(0.001)
+            assert int(tk[32]) == 0 and int(tk[16]) == k * waves, (k, tk[[0, 16, 32, 48, 49]])
+            with torch.cuda.stream(feed):
+                got, gmode = run["out"].clone(), run["mode"].clone()
+            feed.synchronize()
+            assert torch.equal(gmode, want[k - 1][2]) and torch.equal(got, want[k - 1][0]), k
+    finally:
+        with torch.cuda.stream(feed):
+            run["ticket"][32:33].copy_(torch.tensor([1], dtype=torch.int32))      # (leave, whatever happened)
+        feed.synchronize()
+        run["stream"].synchronize()
+    tk = run["ticket"].cpu()
+    assert int(tk[48]) == waves and int(tk[49]) == NT

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Resident ticks (clik_pinv_resident_run): per-tick cost of the config-3 team kernel when it stays on the device and is
+fed tickets by a device-side producer, against one launch per tick (hipGraph) and the on-device rollout.
+
+  free-running   the producer publishes all tickets at once: the kernel never waits - its own per-tick cost
+                 (acquire + reload of q / y + tick + stores + release + count)
+  closed loop    the producer publishes ticket k only after every wave has counted tick k-1: both hand-offs
+                 (N waves -> 1 producer -> N waves) are on the critical path, as for a producer that needs dq
+
+    python tools/resident_probe.py [B=16384] [ticks=2000]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+import casclik_amd as cc    # noqa: E402
+from casclik_amd import skills   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+NT = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+fk = skills.iiwa()
+ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(fk), options=dict(skills.STACK_OPTIONS))
+ctrl.setup_problem_functions()
+Q, Y = skills.synthetic_inputs(fk, B, seed=0, distribution="mixed")
+Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+ref = ctrl.solve_batch(0.0, Qd, input_var=Yd)
+print("kernel", ctrl.kernel_variant(B))
+
+# one launch per tick (graph replay), for the same box
+tick = ctrl.bind_batch(Qd, input_var=Yd)
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    tick()
+torch.cuda.synchronize()
+with torch.cuda.graph(g, stream=s):
+    for _ in range(1000):
+        tick()
+for _ in range(10):
+    g.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    g.replay()
+torch.cuda.synchronize()
+print("launch per tick (hipGraph of 1000):   %.3f us per tick" % ((time.perf_counter() - t0) / 10000 * 1e6))
+
+for name, closed in (("free-running", False), ("closed loop", True)):
+    best = None
+    for rep in range(5):
+        feeder_stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        run = ctrl.resident_start(Qd, Yd, NT, timeout_s=3.0)
+        time.sleep(0.02)                      # (the resident kernel is up and polling)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ctrl.resident_feed(run, NT, closed_loop=closed, timeout_s=3.0, stream=feeder_stream)
+        run["stream"].synchronize()
+        el = time.perf_counter() - t0
+        feeder_stream.synchronize()
+        tk = run["ticket"].cpu().numpy()
+        ok = (tk[32] == 0) and (tk[49] == NT) and (tk[16] == NT * run["waves"])
+        same = torch.equal(run["out"], ref[0]) and torch.equal(run["mode"], ref[2])
+        per = el / NT * 1e6
+        best = per if best is None else min(best, per)
+        if rep == 0 or not (ok and same):
+            print("  %-13s rep %d: %.3f us per tick (host clock around feed -> kernel exit), ticks done %d, stop %d, "
+                  "out_count %d of %d, equal to the launched tick: %s" % (name, rep, per, tk[49], tk[32], tk[16],
+                                                                          NT * run["waves"], same))
+    print("resident, %-13s            %.3f us per tick (best of 5; %d ticks)" % (name, best, NT))
