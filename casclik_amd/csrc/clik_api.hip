@@ -669,6 +669,20 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
     return eligible ? 1 : 0;
 }
 
+// CLIK_HOST_ONLY=1: handles are created WITHOUT touching a device (no allocation, no upload) - for the host-side
+// queries only (clik_*_image_words, kernel names): casclik_amd/jit.py uses it to instantiate value-specialised kernels
+// ahead of time on a machine without a GPU.  Every solve / rollout / data entry point refuses such a handle.
+static bool host_only_mode()
+{
+    const char* e = getenv("CLIK_HOST_ONLY");
+    return e && e[0] == '1';
+}
+#define CLIK_NEEDS_DEVICE_HANDLE(h)                                                                        \
+    do {                                                                                                   \
+        if ((h) && (h)->dev == nullptr)                                                                    \
+            return fail(CLIK_EINVAL, "this handle was created with CLIK_HOST_ONLY=1: host-side queries only"); \
+    } while (0)
+
 extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts, clik_pinv** out)
 {
     if (!out) return fail(CLIK_EINVAL, "null out pointer");
@@ -754,11 +768,16 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         delete h;
         return fail(CLIK_EUNSUPPORTED, "skill needs %d LDS slots per lane (input_var too large)", S.lds_slots);
     }
-    hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
-    if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
-    e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
-    if (clik::pinv_kernel_is_static(h->kernel)) {
+    h->dev = nullptr;
+    const bool host_only = host_only_mode();
+    hipError_t e = hipSuccess;
+    if (!host_only) {
+        e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
+        if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
+        e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return hipfail(e, "hipMemcpy(skill)"); }
+    }
+    if (!host_only && clik::pinv_kernel_is_static(h->kernel)) {
         std::vector<char> img;
         if (!build_skill_image(S, img)) {
             // rows not laid out contiguously: serve the skill with the dynamic kernel
@@ -811,6 +830,7 @@ extern "C" int clik_pinv_attach_kernel(clik_pinv* h, void* solve_fn, void* rollo
 {
     // (rollout_fn may be NULL: the rollout then keeps the kernel chosen at creation)
     if (!h || !solve_fn) return fail(CLIK_EINVAL, "null argument");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (!h->d_img) {
         std::vector<char> img;
         if (!build_skill_image(h->host, img))
@@ -864,6 +884,7 @@ extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_t
                                       clik_ticket* ticket, double timeout_s, void* stream)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (!h->val_resident)
         return fail(CLIK_EUNSUPPORTED, "resident ticks need the value-specialised kernel of the four-lanes-per-instance "
                                        "family attached to this handle (none is)");
@@ -949,6 +970,7 @@ static int pinv_solve_common(const clik_pinv* h, int64_t B, const double* tterms
                              int32_t* mode, void* stream)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (B < 0) return fail(CLIK_EINVAL, "negative batch size");
     if (B == 0) return CLIK_OK;
     const DevSkill& S = h->host;
@@ -1086,6 +1108,7 @@ extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t 
                                          const double* y, double* dq, double* dx, int32_t* mode, void* stream)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
     if (method != CLIK_INTEGRATE_EULER && method != CLIK_INTEGRATE_RK4) return fail(CLIK_EINVAL, "unknown integration method %d", method);
     if (B == 0 || n_ticks == 0) return CLIK_OK;
@@ -1205,6 +1228,11 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
     h->jit_name[0] = 0;
+    h->dev = nullptr;
+    if (host_only_mode()) {
+        *out = h;
+        return CLIK_OK;
+    }
     hipError_t e = hipMalloc((void**)&h->dev, sizeof(DevSkill));
     if (e != hipSuccess) { delete h; return hipfail(e, "hipMalloc(skill)"); }
     e = hipMemcpy(h->dev, &S, sizeof(DevSkill), hipMemcpyHostToDevice);
@@ -1251,6 +1279,7 @@ extern "C" int clik_qp_attach_kernel(clik_qp* h, void* solve_fn, void* rollout_f
 {
     // (rollout_fn may be NULL: clik_qp_rollout_batch then needs an AOT kernel)
     if (!h || !solve_fn) return fail(CLIK_EINVAL, "null argument");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (!qp_static_eligible(h->host))
         return fail(CLIK_EUNSUPPORTED, "skill is outside the shape-specialised QP family");
     int rc = qp_upload_image(h);
@@ -1288,6 +1317,7 @@ extern "C" int clik_qp_rollout_batch_m(const clik_qp* hc, int64_t B, int32_t n_t
         return fail(CLIK_EINVAL, "clik_qp_rollout_batch_m: unknown integration method %d", method);
     const int stages = method == CLIK_INTEGRATE_RK4 ? 4 : 1;
     if (!h) return fail(CLIK_EINVAL, "null handle");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (B < 0 || n_ticks < 0) return fail(CLIK_EINVAL, "negative size");
     if (B == 0 || n_ticks == 0) return CLIK_OK;
     const DevSkill& S = h->host;
@@ -1376,6 +1406,7 @@ extern "C" int clik_qp_n_rows(const clik_qp* h) { return h ? h->host.n_qp_rows :
 
 static int qp_check_args(const clik_qp* h, int64_t B, const double* q, const double* x, const double* y)
 {
+    CLIK_NEEDS_DEVICE_HANDLE(h);
     if (!h) return fail(CLIK_EINVAL, "null handle");
     if (B < 0) return fail(CLIK_EINVAL, "negative batch size");
     const DevSkill& S = h->host;

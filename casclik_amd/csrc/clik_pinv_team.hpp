@@ -557,8 +557,8 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
 // ONE launch of the value-specialised team kernel that stays on the device and runs tick k whenever the producer of
 // the inputs has published ticket k (clik_ticket::in_seq >= k, written with release semantics after q / y): a closed
 // loop with fresh targets every tick then costs a device-side hand-off instead of a kernel launch.  Every wave polls
-// the ticket itself (the four waves of a block share nothing in this instantiation), reads its rows after the acquire,
-// runs the tick, stores, and adds 1 to out_count behind a release fence; tick k is complete when out_count reaches
+// the ticket itself (the four waves of a block share nothing in this instantiation), then reads its rows, runs the
+// tick, stores, and adds 1 to out_count once its stores are acknowledged; tick k is complete when out_count reaches
 // k x (waves per tick).  The kernel leaves when n_ticks are done, when anyone sets `stop`, or when its watchdog (the
 // 100 MHz s_memrealtime clock against the timeout given at launch) expires - it then writes stop = 2 so that every
 // other wave and the producer leave too.  It never spins without that check.
@@ -600,7 +600,9 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         bool leave = false;
 #pragma unroll 1
         for (;;) {
-            const unsigned seq = __hip_atomic_load(&ticket->in_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (relaxed, system scope = a load that bypasses the caches; no L2 invalidate: the rows below are read the
+            // same way, and a wave issues them only after this value has arrived)
+            const unsigned seq = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (seq >= (unsigned)k) break;
             if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
                 leave = true;
@@ -614,12 +616,14 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             __builtin_amdgcn_s_sleep(1);
         }
         if (leave) break;
+        asm volatile("" ::: "memory");
         double z[N], ydir[NY > 0 ? NY : 1];
 #pragma unroll
-        for (int j = 0; j < N; ++j) z[j] = q[binst * N + j];
+        for (int j = 0; j < N; ++j) z[j] = __hip_atomic_load(q + binst * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if constexpr (NY > 0) {
 #pragma unroll
-            for (int j = 0; j < NY; ++j) ydir[j] = y[binst * NY + j];
+            for (int j = 0; j < NY; ++j)
+                ydir[j] = __hip_atomic_load(y + binst * NY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         double a0 = z[N - 1], a1 = z[N - 1];
         static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
@@ -634,12 +638,15 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, v, in_tc);
         const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
         if (r == (ok0 ? 0 : 3) && valid) {
+            // (write-through stores: visible to every agent once acknowledged)
 #pragma unroll
-            for (int j = 0; j < N; ++j) dq[(b0 + inst) * N + j] = v[j];
-            if (mode_out != nullptr) mode_out[b0 + inst] = ok0 ? 0 : 1;
+            for (int j = 0; j < N; ++j)
+                __hip_atomic_store(dq + (b0 + inst) * N + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (mode_out != nullptr)
+                __hip_atomic_store(mode_out + b0 + inst, ok0 ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        // every lane's stores before the wave's count (release), one add per wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        // every lane's stores acknowledged before the wave's count, one add per wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((tid & (WAVE - 1)) == 0)
             __hip_atomic_fetch_add(&ticket->out_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
@@ -664,7 +671,7 @@ __global__ void resident_feed_kernel(ResidentTicket* ticket, const int n_ticks, 
             const unsigned want = (unsigned)(k - 1) * waves_per_tick;
 #pragma unroll 1
             for (;;) {
-                if (__hip_atomic_load(&ticket->out_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) break;
+                if (__hip_atomic_load(&ticket->out_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) break;
                 if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
                 if (realtime_100mhz() - t_start > timeout_ticks) {
                     __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -673,7 +680,8 @@ __global__ void resident_feed_kernel(ResidentTicket* ticket, const int n_ticks, 
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        __hip_atomic_store(&ticket->in_seq, (unsigned)k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ticket->in_seq, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

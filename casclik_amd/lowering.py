@@ -28,7 +28,7 @@ from .constraints import (EqualityConstraint, SetConstraint,
                           VelocityEqualityConstraint, VelocitySetConstraint)
 from .urdf import JOINT_FIXED
 
-MAX_DOF = 8
+MAX_DOF = 10
 MAX_JOINTS = 12
 MAX_TASKS = 16
 MAX_M = 12              # > DYN_MAX_M rows only in the shape-specialised kernels
@@ -182,6 +182,8 @@ class _Lowerer(object):
         self.desc.n_y = spec.n_input_var
         self._tslot_index = {}
         self._dep_memo = {}
+        self._rw, self._rw_all = {}, {}
+        self._prim_fk = self._prim_quat = None
 
     @staticmethod
     def _family(var):
@@ -208,6 +210,61 @@ class _Lowerer(object):
             r = all(self._time_only(a) for a in node.args)
         self._dep_memo[k] = r
         return r
+
+    # -- which kinematics atoms stay atoms -----------------------------------------------
+    # The kernels carry ONE chain instance (T_fk of one chain on one argument vector) and ONE orientation target as
+    # hand-written code; the first of each in priority order.  Every other 'fk' / 'ori_err' atom - a second chain or
+    # tool frame, the same chain on other arguments, a second target, a target that is neither constant nor four
+    # input_var entries, a rotation that is not the primary chain's - is rewritten into the explicit expression it
+    # stands for (expand.py) and takes the generated-code route (the reference accepts any expression,
+    # constraints.py:21-24).
+    def _scan_primary(self):
+        from . import expand
+        self._prim_fk = None            # (chain, args tuple)
+        self._prim_quat = None          # the four quaternion Scalars of the kept orientation target
+        seen = set()
+        for cn in self.spec.constraints:
+            arr = cs._as_array(cn.expression)
+            for i in range(arr.shape[0]):
+                for a in expand.atoms(arr[i, 0], seen):
+                    if a.op == "fk" and self._prim_fk is None and self._chain_args_ok(a.args):
+                        self._prim_fk = (a.aux[0], a.args)
+        if self._prim_fk is None:
+            return
+        seen = set()
+        for cn in self.spec.constraints:
+            arr = cs._as_array(cn.expression)
+            for i in range(arr.shape[0]):
+                for a in expand.atoms(arr[i, 0], seen):
+                    if a.op == "ori_err" and self._prim_quat is None and self._ori_shape_ok(a):
+                        self._prim_quat = a.args[9:13]
+
+    def _chain_args_ok(self, args):
+        return all(a.op == "sym" and a.family is not None and a.family in (self.fam_q, self.fam_x) for a in args)
+
+    def _keep_fk(self, node):
+        return (self._prim_fk is not None and node.aux[0] is self._prim_fk[0]
+                and len(node.args) == len(self._prim_fk[1])
+                and all(x is y for x, y in zip(node.args, self._prim_fk[1])))
+
+    def _ori_shape_ok(self, node):
+        for k, r in enumerate(node.args[:9]):
+            if r.op != "fk" or r.aux[1] != k // 3 or r.aux[2] != k % 3 or not self._keep_fk(r):
+                return False
+        qn = node.args[9:13]
+        return all(n.op == "const" for n in qn) or \
+            all(n.op == "sym" and n.family is self.fam_y and n.family is not None for n in qn)
+
+    def _keep_ori(self, node):
+        return (self._prim_quat is not None and self._ori_shape_ok(node)
+                and all(x is y for x, y in zip(node.args[9:13], self._prim_quat)))
+
+    def _explicit(self, node, all_ori=False):
+        """node with the atoms the kernels do not carry written out (all_ori: every orientation error - generated code
+        has no 'ori_err' atom)"""
+        from . import expand
+        memo = self._rw_all if all_ori else self._rw
+        return expand.rewrite(node, self._keep_fk, (lambda n: False) if all_ori else self._keep_ori, memo)
 
     # -- feature atoms ----------------------------------------------------
     def _use_chain(self, node):
@@ -498,11 +555,13 @@ class _Lowerer(object):
                 task["attr_ext"] |= ATTR_TARGET
                 attr_nodes.extend(sym)
         arr = cs._as_array(expr)
+        nodes = [self._explicit(arr[i, 0]) for i in range(m)]
+        attr_nodes = [self._explicit(nd, all_ori=True) for nd in attr_nodes]
         memo = {}
         mark = (len(self.desc.rows), len(self.desc.tslots))
         try:
             for i in range(m):
-                node = arr[i, 0]
+                node = nodes[i]
                 try:
                     form = self.affine(node, memo)
                     task["out_kind"][i] = OUT_AFFINE
@@ -523,7 +582,7 @@ class _Lowerer(object):
         except NotAffine:
             # outside the row table: the whole constraint becomes generated code (codegen.py)
             self._rollback(mark)
-            self._lower_extern(task, [arr[i, 0] for i in range(m)], cnstr.label)
+            self._lower_extern(task, [self._explicit(arr[i, 0], all_ori=True) for i in range(m)], cnstr.label)
         if attr_nodes:
             self._lower_attr(task, attr_nodes, cnstr.label)
         return task
@@ -586,6 +645,7 @@ class _Lowerer(object):
             raise ValueError("skill has no robot variables")
         if len(spec.constraints) > MAX_TASKS:
             raise NotImplementedError("more than %d constraints" % MAX_TASKS)
+        self._scan_primary()
         for cnstr in spec.constraints:
             d.tasks.append(self._lower_task(cnstr))
         if d.n_sets > MAX_SETS:

@@ -44,9 +44,10 @@
 extern "C" {
 #endif
 
-#define CLIK_ABI_VERSION 3
+#define CLIK_ABI_VERSION 4
 
-#define CLIK_MAX_DOF      8   /* n_state = n_robot_var + n_virtual_var            */
+#define CLIK_MAX_DOF     10   /* n_state = n_robot_var + n_virtual_var (a 7-DoF arm with two or three virtual
+                                 variables; more than 8 only in the shape-specialised kernels)                */
 #define CLIK_MAX_JOINTS  12   /* chain joints, fixed ones included                */
 #define CLIK_MAX_TASKS   16   /* constraints per skill                            */
 #define CLIK_MAX_M       12   /* rows of one constraint expression; more than

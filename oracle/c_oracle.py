@@ -38,8 +38,7 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        build()         # (rebuilds when the source or include/clik.h is newer: the descriptor layout is shared)
         _lib = C.CDLL(LIB)
         dp = C.POINTER(C.c_double)
         _lib.orc_pinv_solve_batch.restype = C.c_int

@@ -150,6 +150,8 @@ PLAN = [   # (fixture name, robot, case, B, input distribution, times)
     # round 3
     ("iiwa_stack_boundary", "iiwa", "stack_boundary", 192, "boundary", [0.0]),
     ("ur5_qp_wall", "ur5", "qp_wall", 96, "mixed", [0.0]),
+    ("iiwa_two_frames", "iiwa", "two_frames", 64, "interior", [0.0]),
+    ("iiwa_qp_two_virtual", "iiwa", "qp_two_virtual", 48, "interior", [0.0]),
 ]
 # offsets from a joint limit the "boundary" distribution plants (pseudo_inverse.py:222-252 thresholds e - bound
 # at 1e-12): exactly on the limit, either side of the 1e-12 margin, and up to 1e-6 away
@@ -255,7 +257,9 @@ def main():
         q_c = 0.35 * np.array(upper) * np.array([1, -1, 1, -1, 1, -1, 1][:n])
         Tc = numeric_fk(T_fk, n, q_c)
         consts = {"p_des": Tc[:3, 3], "quat_des": quat_from_matrix(Tc[:3, :3])}
-        env = pin_skills.Env(cs, cc, T_fk, ori_err, lower, upper, vmax, consts)
+        other = "ur5" if robot == "iiwa" else "iiwa"
+        T_fk_alt = make_T_fk(load_chain(*ROBOTS[other]))
+        env = pin_skills.Env(cs, cc, T_fk, ori_err, lower, upper, vmax, consts, T_fk_alt=T_fk_alt)
         built = pin_skills.CASES[case](env)
         spec, ny, nx = built["spec"], built["ny"], built.get("nx", 0)
         rng = np.random.default_rng(900 + k)

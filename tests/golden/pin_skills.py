@@ -17,10 +17,11 @@ import numpy as np
 
 
 class Env(object):
-    def __init__(self, cs, cc, T_fk, ori_err, lower, upper, vmax, consts=None):
+    def __init__(self, cs, cc, T_fk, ori_err, lower, upper, vmax, consts=None, T_fk_alt=None):
         self.cs, self.cc, self.T_fk, self.ori_err = cs, cc, T_fk, ori_err
         self.lower, self.upper, self.vmax = np.asarray(lower, float), np.asarray(upper, float), np.asarray(vmax, float)
         self.consts = consts or {}
+        self.T_fk_alt = T_fk_alt         # forward kinematics of the OTHER vendored robot (a second chain in one skill)
 
 
 def _syms(env, ny=0, nx=0):
@@ -263,7 +264,54 @@ def qp_wall(env):
     return dict(spec=spec, controller="qp", options={}, ny=3)
 
 
+def two_frames(env):
+    """several kinematic chains and orientation targets in ONE skill (casclik takes any expression,
+    constraints.py:21-24): the iiwa's tool pose, the tool position of a second chain (the UR5) driven by six of the
+    same joint variables, a second orientation target on the first tool frame, and a set on a product of an
+    orientation-error component with a joint angle plus the squared distance of the two tools"""
+    cs, cc, s = env.cs, env.cc, _syms(env)
+    q = s["q"]
+    T = env.T_fk(q)
+    Tb = env.T_fk_alt(cs.vertcat(q[0], q[1], q[2], q[3], q[4], q[5]))
+    p_des = np.asarray(env.consts["p_des"], float)
+    quat = np.asarray(env.consts["quat_des"], float)
+    quat2 = np.array([0.0, 0.6, 0.0, 0.8])
+    e1 = env.ori_err(T[:3, :3], quat)
+    e2 = env.ori_err(T[:3, :3], quat2)
+    dist = Tb[:3, 3] - T[:3, 3]
+    cns = [cc.EqualityConstraint(label="tool_pose", expression=cs.vertcat(T[:3, 3] - p_des, e1), gain=5.0,
+                                 constraint_type="soft", priority=0),
+           cc.EqualityConstraint(label="second_tool", expression=Tb[:3, 3] - cs.vertcat(0.3, -0.2, 0.5), gain=2.0,
+                                 constraint_type="soft", priority=1),
+           cc.EqualityConstraint(label="second_target", expression=e2, gain=1.5, constraint_type="soft", priority=2),
+           cc.SetConstraint(label="mixed", expression=e1[0] * q[0] + cs.mtimes(dist.T, dist), set_min=0.05, set_max=1.2,
+                            gain=1.0, priority=3)]
+    spec = cc.SkillSpecification(label="two_frames", time_var=s["t"], robot_var=q, robot_vel_var=s["dq"],
+                                 constraints=cns)
+    return dict(spec=spec, controller="pinv", options={}, ny=0)
+
+
+def qp_two_virtual(env):
+    """a 7-DoF arm with TWO virtual variables (9 states): the tool follows a patch p(x) = p0 + d1 x1 + d2 x2, the patch
+    parameters are driven to their goals, joint speeds are limited (cart_on_track_1D...ipynb cells 56, 75 with two
+    path parameters)"""
+    cs, cc, s = env.cs, env.cc, _syms(env, nx=2)
+    T = env.T_fk(s["q"])
+    p0 = np.asarray(env.consts["p_des"], float)
+    d1, d2 = np.array([0.1, -0.05, 0.08]), np.array([-0.04, 0.09, 0.03])
+    follow = cc.EqualityConstraint(label="follow_patch", expression=T[:3, 3] - (p0 + d1 * s["x"][0] + d2 * s["x"][1]),
+                                   gain=5.0, constraint_type="soft", priority=1)
+    goal = cc.EqualityConstraint(label="patch_goal", expression=s["x"] - np.array([1.0, 0.5]), gain=0.5,
+                                 constraint_type="soft", priority=2)
+    speed = cc.VelocitySetConstraint(label="joint_speed_limits", expression=s["q"], set_min=-env.vmax,
+                                     set_max=env.vmax, priority=0)
+    spec = cc.SkillSpecification(label="qp_two_virtual", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 virtual_var=s["x"], virtual_vel_var=s["dx"], constraints=[follow, goal, speed])
+    return dict(spec=spec, controller="qp", options={}, ny=0, nx=2)
+
+
 CASES = {
+    "two_frames": two_frames, "qp_two_virtual": qp_two_virtual,
     "stack_boundary": stack_const, "qp_wall": qp_wall,
     "position": position, "pose": pose, "stack_const": stack_const, "stack_const_time": stack_const_time,
     "stack_sets1d": stack_sets1d, "stack_noff": stack_noff, "position_standard": position_standard, "conv_last": conv_last,

@@ -30,8 +30,10 @@ def robot_fk(name):
 def product_skill(name):
     """the fixture's skill built with the product's front-end (same script as the reference side)"""
     fk = robot_fk(name)
+    other = robot_fk("ur5_x" if name.startswith("iiwa") else "iiwa_x")
     env = pin_skills.Env(cs, cc, fk["T_fk"], cs.orientation_error, fk["lower"], fk["upper"], fk["velocity"],
-                         {"p_des": PINS[name + "_p_des"], "quat_des": PINS[name + "_quat_des"]})
+                         {"p_des": PINS[name + "_p_des"], "quat_des": PINS[name + "_quat_des"]},
+                         T_fk_alt=other["T_fk"])
     return pin_skills.CASES[name.split("_", 1)[1]](env)
 
 

@@ -5,6 +5,7 @@ import os
 
 import pytest
 
+import casclik_amd as cc
 from casclik_amd import _capi, build, skills
 from casclik_amd.lowering import lower_skill
 
@@ -137,18 +138,19 @@ def test_instantiated_kernels_with_expression_attributes_have_no_scratch(tmp_pat
 def test_value_specialised_kernels_of_the_config3_skill_have_no_scratch(tmp_path):
     """The kernels casclik_amd/jit.py::attach_values instantiates for BASELINE config 3 with the skill's numbers compiled
     in (four lanes per instance, one lane per instance, their rollouts) must stay in registers, and the one-lane kernel
-    must fit two waves per SIMD (that is what makes it the large-batch kernel).  The skill image words are a fixture
-    written on a GPU box (python tools/dump_image_words.py tests/golden/stack_iiwa_image_words.txt); a changed image
-    layout fails the size static_assert here - regenerate the fixture then."""
+    must fit two waves per SIMD (that is what makes it the large-batch kernel).  The skill-image words come from a
+    host-only handle (CLIK_HOST_ONLY, include/clik.h): no GPU, no recorded fixture."""
     import re
     import subprocess
-    from casclik_amd import jit
+    from casclik_amd import jit, _capi
     from casclik_amd.build import parse_resource_remarks, FLAGS, CSRC
+    from casclik_amd.lowering import lower_skill
     hipcc = jit._hipcc()
     if hipcc is None:
         pytest.skip("hipcc not available")
-    here = os.path.dirname(os.path.abspath(__file__))
-    words = open(os.path.join(here, "golden", "stack_iiwa_image_words.txt")).read().split()
+    spec = skills.stack_skill(skills.iiwa())
+    full = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS)).options
+    words = jit.host_image_words(_capi.load_library(), "pinv", _capi.desc_to_c(lower_skill(spec)), _capi.pinv_opts_to_c(full))
     gen = open(os.path.join(CSRC, "clik_shapes_gen.hpp")).read()
     init = re.search(r"kStackIiwa\s*=\s*(\{.*?\});", gen, re.S).group(1)
     text = jit._VALUE_TEMPLATE.replace("%(nwords)d", str(len(words))).replace(

@@ -138,9 +138,6 @@ def test_what_generated_code_cannot_express_is_refused():
     fk = skills.iiwa()
     t, q, dq, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("dq", 7), cs.MX.sym("y", 4)
     T = fk["T_fk"](q)
-    with pytest.raises(NotImplementedError, match="orientation_error inside a non-affine"):
-        lower_skill(cc.SkillSpecification("s", t, q, input_var=y, constraints=[
-            cc.EqualityConstraint("o", cs.orientation_error(T[:3, :3], y)[0] * q[0])]))
     with pytest.raises(NotImplementedError, match="velocity variables"):
         lower_skill(cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint("v", dq[0] * q[0])]))
     # more constraints than a shape-specialised kernel carries: generated code has nowhere to live
@@ -148,6 +145,47 @@ def test_what_generated_code_cannot_express_is_refused():
     many.append(cc.EqualityConstraint("prod", q[0] * q[1], priority=9))
     with pytest.raises(NotImplementedError, match="generated device code"):
         lower_skill(cc.SkillSpecification("s", t, q, constraints=many))
+
+
+def two_frames_skill(iiwa, ur5):
+    """what the device path keeps as atoms (one chain, one orientation target) and what it writes out: a second chain
+    (another robot's tool in the same skill), the same chain on other arguments, a second orientation target, an
+    orientation error inside a product"""
+    t, q, p2, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("p2", 2), cs.MX.sym("y", 8)
+    T = iiwa["T_fk"](q)                                   # the primary chain instance
+    qb = cs.vertcat(q[0], q[1], q[2], q[3], q[4], q[5])
+    Tb = ur5["T_fk"](qb)                                  # a second chain driven by six of the joints
+    Tc = iiwa["T_fk"](cs.vertcat(q[6], q[5], q[4], q[3], q[2], q[1], q[0]))      # the first chain, other arguments
+    e1 = cs.orientation_error(T[:3, :3], y[:4])           # the primary orientation target
+    e2 = cs.orientation_error(T[:3, :3], y[4:8])          # a second target
+    e3 = cs.orientation_error(Tb[:3, :3], cs.vertcat(0.0, 0.0, 0.6, 0.8))        # of the second chain
+    cn = [cc.EqualityConstraint("pose", cs.vertcat(T[:3, 3] - 0.3, e1), gain=2.0, priority=0, constraint_type="soft"),
+          cc.EqualityConstraint("second_tool", Tb[:3, 3] - cs.vertcat(0.2, 0.1, 0.4), gain=1.0, priority=1,
+                                constraint_type="soft"),
+          cc.EqualityConstraint("second_target", cs.vertcat(e2, e3[2]), gain=1.5, priority=2, constraint_type="soft"),
+          cc.SetConstraint("mixed", cs.vertcat(e1[0] * q[0] + Tc[2, 3], cs.dot(Tb[:3, 3] - T[:3, 3], Tb[:3, 3] - T[:3, 3])),
+                           set_min=cs.vertcat(-0.5, 0.01), set_max=cs.vertcat(0.5, 4.0), gain=1.0, priority=3,
+                           constraint_type="soft")]
+    return cc.SkillSpecification("two_frames", t, q, input_var=y, constraints=cn)
+
+
+def test_second_chain_and_second_orientation_target_are_written_out(tmp_path):
+    """casclik takes any expression (constraints.py:21-24); the kernels keep one chain and one orientation target as
+    atoms, expand.py writes the others out in sin / cos, and the generated code equals the oracle's dual numbers
+    evaluated on the ORIGINAL atoms (an independent route: oracle/clik_oracle.py differentiates every chain by its
+    own forward-mode kinematics)."""
+    iiwa, ur5 = skills.iiwa(), skills.ur5()
+    spec = two_frames_skill(iiwa, ur5)
+    d = lower_skill(spec)
+    assert [tk["out_kind"][0] for tk in d.tasks] == [OUT_AFFINE, OUT_EXTERN, OUT_EXTERN, OUT_EXTERN]
+    assert d.quat_src == 2 and list(d.quat_yi) == [0, 1, 2, 3] and len(d.joints) == len(iiwa["chain"].joints)
+    lib = _compile(d, tmp_path)
+    rng = np.random.default_rng(5)
+    Z = rng.uniform(-1.5, 1.5, size=(6, 7))
+    Y = rng.normal(size=(6, 8))
+    Y[:, :4] /= np.linalg.norm(Y[:, :4], axis=1, keepdims=True)
+    Y[:, 4:] /= np.linalg.norm(Y[:, 4:], axis=1, keepdims=True)
+    _check(spec, d, lib, 0.3, Z, Y, fk=iiwa, tol=1e-11)
 
 
 def test_random_expression_trees(tmp_path):

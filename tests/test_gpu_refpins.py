@@ -17,7 +17,7 @@ def test_pinv_hip_matches_the_reference_run(name):
     Q, Y, X, times = refpins.arrays(name)
     ctrl = cc.PseudoInverseController(skill_spec=built["spec"], options=dict(built["options"]))
     ctrl.setup_problem_functions()
-    tol = pinv_rtol(refpins.sigma_min_geometric(refpins.robot_fk(name), Q), stacked="stack" in name)
+    tol = pinv_rtol(refpins.sigma_min_geometric(refpins.robot_fk(name), Q), stacked=("stack" in name or "two_frames" in name))
     for ti, t in enumerate(times):
         dq, _, mode = ctrl.solve_batch(float(t), Q, input_var=Y)
         assert np.array_equal(mode, refpins.PINS[name + "_mode"][ti]), (name, ctrl.kernel_name)

@@ -93,8 +93,12 @@ def main():
         n = len(fk["lower"])
         spec, what = random_mixed_skill(rng, fk, n)
         ctrl = cc.ReactiveQPController(skill_spec=spec)
-        ctrl.setup_problem_functions()
-        ctrl.setup_solver()
+        try:
+            ctrl.setup_problem_functions()
+            ctrl.setup_solver()
+        except NotImplementedError as why:
+            print("%2d %-4s skipped (%s)  [%s]" % (k, robot, str(why)[:70], what), flush=True)
+            continue
         B = 1200
         Q, Y = skills.synthetic_inputs(fk, B, seed=2000 + k, distribution="interior")
         if robot == "ur5":
