@@ -251,10 +251,10 @@ def load_library(path=None):
     lib.clik_pinv_resident_waves.restype = C.c_int
     lib.clik_pinv_resident_waves.argtypes = [vp, C.c_int64]
     lib.clik_pinv_resident_run.restype = C.c_int
-    lib.clik_pinv_resident_run.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, ip, C.c_void_p,
+    lib.clik_pinv_resident_run.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, ip, C.c_void_p, C.c_void_p,
                                            C.c_double, C.c_void_p]
     lib.clik_ticket_feed.restype = C.c_int
-    lib.clik_ticket_feed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
+    lib.clik_ticket_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
     lib.clik_pinv_kernel_variant.restype = C.c_char_p
     lib.clik_pinv_kernel_variant.argtypes = [vp, C.c_int64]
     lib.clik_pinv_attach_kernel.restype = C.c_int

@@ -363,8 +363,9 @@ class PseudoInverseController(BaseController):
         is published (include/clik.h, clik_pinv_resident_run): for closed loops whose inputs are produced on the
         device (or copied in behind a stream) every tick, at the price of a device-side hand-off instead of a launch.
         ``robot_var`` / ``input_var`` must be device tensors (the producer overwrites them in place).  Returns a dict
-        with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [16] out_count, [32] stop, [48] waves,
-        [49] ticks_done), ``waves`` per tick, ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
+        with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [32] stop, [48] waves, [49] ticks_done),
+        ``done`` (int32 device tensor, one slot per wave: the last tick that wave finished), ``waves`` per tick,
+        ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
         leaves after ``n_ticks``, on ``ticket[32] != 0`` or after ``timeout_s`` (device clock) whatever happens."""
         self._require_handle()
         torch = _torch()
@@ -386,15 +387,18 @@ class PseudoInverseController(BaseController):
         dQ = out if out is not None else torch.zeros((B, d.n_q), dtype=torch.float64, device=dev)
         mode = mode_out if mode_out is not None else torch.full((B,), -1, dtype=torch.int32, device=dev)
         ticket = torch.zeros(64, dtype=torch.int32, device=dev)
+        waves = self._lib.clik_pinv_resident_waves(self._handle, B)
+        done = torch.zeros(max(waves, 1), dtype=torch.int32, device=dev)
         stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
         torch.cuda.current_stream(dev).synchronize()       # (ticket / outputs are initialised before the kernel starts)
         with torch.cuda.device(dev):
             rc = self._lib.clik_pinv_resident_run(self._handle, B, int(n_ticks), ttp, ptr(Q), ptr(Y), ptr(dQ), ptr(mode),
-                                                  ptr(ticket), float(timeout_s), C.c_void_p(stream.cuda_stream))
+                                                  ptr(ticket), ptr(done), float(timeout_s),
+                                                  C.c_void_p(stream.cuda_stream))
         _capi.check(self._lib, rc)
-        return {"ticket": ticket, "waves": self._lib.clik_pinv_resident_waves(self._handle, B), "out": dQ, "mode": mode,
-                "stream": stream, "keep": (Q, Y, tt)}
+        return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "mode": mode, "stream": stream,
+                "keep": (Q, Y, tt)}
 
     def resident_feed(self, run, n_ticks, closed_loop=False, timeout_s=2.0, stream=None):
         """The reference producer of resident ticks (clik_ticket_feed): one device thread that publishes tickets
@@ -404,7 +408,8 @@ class PseudoInverseController(BaseController):
         dev = self._device
         stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         with torch.cuda.device(dev):
-            rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), int(n_ticks), 1 if closed_loop else 0, int(run["waves"]),
+            rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), ptr(run["done"]), int(n_ticks), 1 if closed_loop else 0,
+                                            int(run["waves"]),
                                             float(timeout_s), C.c_void_p(stream.cuda_stream))
         _capi.check(self._lib, rc)
         return stream

@@ -62,7 +62,7 @@ int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 bool qp_box_family_rt(const ShapeDesc& sd);
 int team_waves_rt(long long B);                 // (clik_pinv.hip)
-hipError_t launch_ticket_feed(void* ticket, int n_ticks, int closed_loop, unsigned waves_per_tick,
+hipError_t launch_ticket_feed(void* ticket, const unsigned* done, int n_ticks, int closed_loop, unsigned waves_per_tick,
                               unsigned long long timeout_ticks, hipStream_t stream);
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
@@ -102,8 +102,8 @@ struct clik_pinv {
     clik_jit_value_fn   val_solve;
     clik_jit_rollout_fn val_rollout;
     // ... and its resident form (clik_pinv_attach_resident_kernel)
-    hipError_t (*val_resident)(const TickArgs*, long long, const double*, const double*, double*, int32_t*, void*, int,
-                               unsigned long long, hipStream_t);
+    hipError_t (*val_resident)(const TickArgs*, long long, const double*, const double*, double*, int32_t*, void*,
+                               unsigned*, int, unsigned long long, hipStream_t);
 };
 
 typedef hipError_t (*clik_jit_qp_fn)(const void*, const TickArgs*, long long, const double*, const double*,
@@ -881,7 +881,7 @@ extern "C" int clik_pinv_resident_waves(const clik_pinv* h, int64_t B)
 
 extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms,
                                       const double* q, const double* y, double* dq, int32_t* mode,
-                                      clik_ticket* ticket, double timeout_s, void* stream)
+                                      clik_ticket* ticket, uint32_t* done, double timeout_s, void* stream)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
     CLIK_NEEDS_DEVICE_HANDLE(h);
@@ -889,7 +889,7 @@ extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_t
         return fail(CLIK_EUNSUPPORTED, "resident ticks need the value-specialised kernel of the four-lanes-per-instance "
                                        "family attached to this handle (none is)");
     if (B <= 0 || n_ticks <= 0) return fail(CLIK_EINVAL, "B and n_ticks must be positive");
-    if (!q || !dq || !ticket) return fail(CLIK_EINVAL, "q, dq and ticket must be device pointers");
+    if (!q || !dq || !ticket || !done) return fail(CLIK_EINVAL, "q, dq, ticket and done must be device pointers");
     const DevSkill& S = h->host;
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
@@ -900,18 +900,18 @@ extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_t
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, n_ticks,
+    hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, (unsigned*)done, n_ticks,
                                    (unsigned long long)(timeout_s * 1e8), (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "resident kernel launch");
     return CLIK_OK;
 }
 
-extern "C" int clik_ticket_feed(clik_ticket* ticket, int32_t n_ticks, int32_t closed_loop, int32_t waves_per_tick,
-                                double timeout_s, void* stream)
+extern "C" int clik_ticket_feed(clik_ticket* ticket, const uint32_t* done, int32_t n_ticks, int32_t closed_loop,
+                                int32_t waves_per_tick, double timeout_s, void* stream)
 {
-    if (!ticket || n_ticks <= 0 || waves_per_tick <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    if (!ticket || !done || n_ticks <= 0 || waves_per_tick <= 0) return fail(CLIK_EINVAL, "bad arguments");
     if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
-    hipError_t e = clik::launch_ticket_feed((void*)ticket, n_ticks, closed_loop, (unsigned)waves_per_tick,
+    hipError_t e = clik::launch_ticket_feed((void*)ticket, (const unsigned*)done, n_ticks, closed_loop, (unsigned)waves_per_tick,
                                             (unsigned long long)(timeout_s * 1e8), (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "ticket feeder launch");
     return CLIK_OK;

@@ -108,11 +108,11 @@ int pinv_lds_slots_host(int N, int ny) { return pinv_lds_slots(N, ny); }
 
 // resident ticks (clik_pinv_team.hpp): waves per tick of the four-lanes-per-instance launch, and the reference producer
 int team_waves_rt(long long B) { return (int)(((B + TEAM_INST - 1) / TEAM_INST) * TEAM_WAVES); }
-hipError_t launch_ticket_feed(void* ticket, int n_ticks, int closed_loop, unsigned waves_per_tick,
+hipError_t launch_ticket_feed(void* ticket, const unsigned* done, int n_ticks, int closed_loop, unsigned waves_per_tick,
                               unsigned long long timeout_ticks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(resident_feed_kernel<0>, dim3(1), dim3(1), 0, stream, (ResidentTicket*)ticket, n_ticks,
-                       closed_loop, waves_per_tick, timeout_ticks);
+    hipLaunchKernelGGL(resident_feed_kernel<0>, dim3(1), dim3(waves_per_tick < 1024u ? ((waves_per_tick + 63u) & ~63u) : 1024u),
+                       0, stream, (ResidentTicket*)ticket, done, n_ticks, closed_loop, waves_per_tick, timeout_ticks);
     return hipGetLastError();
 }
 

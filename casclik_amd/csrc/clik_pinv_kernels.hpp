@@ -1504,13 +1504,13 @@ inline hipError_t launch_solve_team_values(const LaunchArgs& a, const TickArgs& 
 
 template <const ShapeDesc& SD, class IMGV>
 inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, const double* q, const double* y,
-                                              double* dq, int32_t* mode, void* ticket, int n_ticks,
+                                              double* dq, int32_t* mode, void* ticket, unsigned* done, int n_ticks,
                                               unsigned long long timeout_ticks, hipStream_t stream)
 {
     if constexpr (shape_team_ok(SD)) {
         const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
         hipLaunchKernelGGL((pinv_resident_team_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0, stream, q, y, dq,
-                           mode, B, tk, (ResidentTicket*)ticket, n_ticks, timeout_ticks);
+                           mode, B, tk, (ResidentTicket*)ticket, done, n_ticks, timeout_ticks);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

@@ -598,7 +598,9 @@ constexpr bool qp_mixed_family(const ShapeDesc& sd)
     const int nl = qp_kind_count(sd, QPK_LIFT), nh = qp_kind_count(sd, QPK_HARD);
     if (nl + nh == 0) return false;
     // (skills with generated attribute code keep the dual iteration: its row bounds come through another path)
-    return sd.n + nl <= CLIK_QP_MIXED_MAX_Z && nh <= CLIK_QP_MIXED_MAX_H;
+    // (registers: the packed matrix and its factor dominate - without hard rows one more variable fits;
+    // measured on the 6-DoF + 3 soft walls skill: 256 VGPRs + 155 AGPRs, no scratch)
+    return sd.n + nl <= CLIK_QP_MIXED_MAX_Z + (nh == 0 ? 1 : 0) && nh <= CLIK_QP_MIXED_MAX_H;
 }
 #if defined(CLIK_QP_MIXED_OFF) || defined(CLIK_QP_BOX_OFF)
 #define CLIK_QP_MIXED_OK(SD) false
@@ -1164,7 +1166,21 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 #pragma unroll
     for (int a = 0; a < NZ; ++a) empty = empty | (lb[a] - ub[a] > 1e-9 * fmax(1.0, fmax(fabs(lb[a]), fabs(ub[a]))));
 #pragma unroll
-    for (int r = 0; r < NH; ++r) empty = empty | (lbg[r] - ubg[r] > 1e-9 * fmax(1.0, fmax(fabs(lbg[r]), fabs(ubg[r]))));
+    for (int r = 0; r < NH; ++r) {
+        empty = empty | (lbg[r] - ubg[r] > 1e-9 * fmax(1.0, fmax(fabs(lbg[r]), fabs(ubg[r]))));
+        // a row against the box alone: its range over the box is [sum min(a lb, a ub), sum max(a lb, a ub)] - a wall
+        // that asks for more than the joint-speed limits allow (the common infeasible tick of a wall skill, and the
+        // slowest one for an active-set iteration to prove) is recognised here in a dozen instructions
+        double lo = 0.0, hi = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const double a = G[r][j];
+            const double al = (a != 0.0) ? a * lb[j] : 0.0, au = (a != 0.0) ? a * ub[j] : 0.0;
+            lo += fmin(al, au);
+            hi += fmax(al, au);
+        }
+        empty = empty | (lbg[r] > hi + 1e-9 * fmax(1.0, fabs(lbg[r]))) | (ubg[r] < lo - 1e-9 * fmax(1.0, fabs(ubg[r])));
+    }
     uint32_t hl = 0u, hu = 0u, rl = 0u, ru = 0u;
     if (use_hot && hot != nullptr) {
         const uint32_t h = (uint32_t)*hot;
@@ -1373,11 +1389,14 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
             bool off = false;
 #pragma unroll
             for (int r = 0; r < NH; ++r) {
-                double gx = 0.0;
+                double gx = 0.0, mag = 1.0;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) gx = fma(G[r][j], x[j], gx);
+                for (int j = 0; j < NV; ++j) {
+                    gx = fma(G[r][j], x[j], gx);
+                    mag = fmax(mag, fabs(G[r][j] * x[j]));        // (the rounding of the sum scales with its terms)
+                }
                 const double bnd = (act[r] > 0) ? ubg[r] : lbg[r];
-                off = off | ((act[r] != 0) & (fabs(gx - bnd) > 1e-8 * fmax(1.0, fabs(bnd))));
+                off = off | ((act[r] != 0) & (fabs(gx - bnd) > 1e-8 * fmax(mag, fabs(bnd))));
             }
             status = off ? 2 : 0;
         }
@@ -1399,10 +1418,13 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
         }
 #pragma unroll
         for (int r = 0; r < NH; ++r) {
-            double gx = 0.0;
+            double gx = 0.0, mag = 1.0;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) gx = fma(G[r][j], x[j], gx);
-            kkt = kkt & !(gx > ubg[r] + 1e-7 * fmax(1.0, fabs(ubg[r]))) & !(gx < lbg[r] - 1e-7 * fmax(1.0, fabs(lbg[r])));
+            for (int j = 0; j < NV; ++j) {
+                gx = fma(G[r][j], x[j], gx);
+                mag = fmax(mag, fabs(G[r][j] * x[j]));
+            }
+            kkt = kkt & !(gx > ubg[r] + 1e-7 * fmax(mag, fabs(ubg[r]))) & !(gx < lbg[r] - 1e-7 * fmax(mag, fabs(lbg[r])));
         }
         status = kkt ? 0 : 1;
     }

@@ -235,28 +235,30 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  * zeroed by the caller before the launch):
  *   producer, per tick k = 1, 2, ...: write q / y (device memory), then  in_seq = k  with release semantics
  *     (a device-side atomic store, or a stream-ordered copy of 4 bytes behind the copies of the inputs);
- *   kernel: every wave waits for in_seq >= k (acquire), reads its rows, runs the tick, writes dq / mode, then adds 1
- *     to out_count behind a release fence; tick k is complete when  out_count == k * waves  (waves is filled in by
- *     the kernel; clik_pinv_resident_waves returns it beforehand);
+ *   kernel: every wave waits for in_seq >= k, reads its rows (cache-bypassing loads), runs the tick, writes dq / mode
+ *     (write-through), and - once those stores are acknowledged - writes k into ITS OWN slot done[w]; tick k is
+ *     complete when every one of the `waves` slots holds k (waves is filled in by the kernel; clik_pinv_resident_waves
+ *     returns it beforehand; `done` is device memory, `waves` words, zeroed by the caller);
  *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (timeout_s of the
  *     100 MHz device clock since its start; it then writes stop = 2 itself) - it never spins unguarded.
- * clik_ticket_feed launches the reference producer (one device thread publishing tickets 1 .. n_ticks, either
- * back to back or - closed_loop - each only after the previous tick has completed) on `stream`, which must differ
+ * clik_ticket_feed launches the reference producer (one device block that publishes tickets 1 .. n_ticks, either
+ * back to back or - closed_loop - each only after every slot shows the previous tick) on `stream`, which must differ
  * from the kernel's stream.  Only for handles with an attached value-specialised kernel of that family
- * (clik_pinv_attach_resident_kernel; casclik_amd/jit.py does it).  Not graph-capturable.                       */
+ * (clik_pinv_attach_resident_kernel; casclik_amd/jit.py does it).  Not graph-capturable.  Measured on one MI355X
+ * (tools/resident_probe.py): the hand-off costs more than the launch boundary it replaces.           */
 typedef struct clik_ticket {
     uint32_t in_seq;     uint32_t _p0[15];
-    uint32_t out_count;  uint32_t _p1[15];
+    uint32_t reserved;   uint32_t _p1[15];
     uint32_t stop;       uint32_t _p2[15];
     uint32_t waves;      uint32_t ticks_done;  uint32_t _p3[14];
 } clik_ticket;
 int clik_pinv_attach_resident_kernel(clik_pinv* h, void* resident_fn);
 int clik_pinv_resident_waves(const clik_pinv* h, int64_t B);
 int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
-                           const double* y, double* dq, int32_t* mode, clik_ticket* ticket, double timeout_s,
-                           void* stream);
-int clik_ticket_feed(clik_ticket* ticket, int32_t n_ticks, int32_t closed_loop, int32_t waves_per_tick,
-                     double timeout_s, void* stream);
+                           const double* y, double* dq, int32_t* mode, clik_ticket* ticket, uint32_t* done,
+                           double timeout_s, void* stream);
+int clik_ticket_feed(clik_ticket* ticket, const uint32_t* done, int32_t n_ticks, int32_t closed_loop,
+                     int32_t waves_per_tick, double timeout_s, void* stream);
 
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)

@@ -257,11 +257,11 @@ def test_resident_ticks_fed_from_outside(iiwa_fk):
             t0 = time.time()
             while True:
                 with torch.cuda.stream(feed):
-                    tk = run["ticket"].cpu()
-                if int(tk[16]) >= k * waves or int(tk[32]) != 0 or time.time() - t0 > 6.0:
+                    tk, dn = run["ticket"].cpu(), run["done"].cpu()
+                if int(dn.min()) >= k or int(tk[32]) != 0 or time.time() - t0 > 6.0:
                     break
                 time.sleep(0.001)
-            assert int(tk[32]) == 0 and int(tk[16]) == k * waves, (k, tk[[0, 16, 32, 48, 49]])
+            assert int(tk[32]) == 0 and int(dn.min()) == k and int(dn.max()) == k, (k, tk[[0, 32, 48, 49]], dn)
             with torch.cuda.stream(feed):
                 got, gmode = run["out"].clone(), run["mode"].clone()
             feed.synchronize()

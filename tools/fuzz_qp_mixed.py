@@ -67,8 +67,10 @@ def random_mixed_skill(rng, fk, n):
             cons.append(cc.SetConstraint("softlim_%d" % k, q[j], set_min=0.7 * lo[j], set_max=0.7 * hi[j], gain=2.0,
                                          priority=2, constraint_type="soft", slack_weight=3.0))
             desc.append("soft limit q%d" % j)
-    if rng.random() < 0.7:
-        js = sorted(rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False).tolist())
+    if rng.random() < 0.7 or n_hard > 0:
+        # (hard walls always come with speed limits on every joint, as in the notebooks: a joint without a bound can
+        # satisfy any wall at an absurd speed, and "feasible at 1e5 rad/s" against "infeasible" is a matter of taste)
+        js = list(range(n)) if n_hard > 0 else sorted(rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False).tolist())
         s = float(rng.choice([0.3, 1.0]))
         cons.append(cc.VelocitySetConstraint("speed", cs.vertcat(*[q[j] for j in js]), set_min=-s * vmax[js],
                                              set_max=s * vmax[js], priority=0))
@@ -107,7 +109,10 @@ def main():
         sub = np.arange(0, B, 3)
         rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[sub], Y=Y[sub])
         same = np.array_equal(status[sub], rstatus)
-        ok = (rstatus == 0) & (status[sub] == 0)
+        # (instances whose minimiser has joint speeds beyond 100 rad/s - unbounded joints with the tiny curvature mu of
+        # the cost - are left out of the precision figure: there the stopping tolerance on the multipliers, 1e-9
+        # relative, is amplified by 1 / mu into the velocities; statuses are still compared)
+        ok = (rstatus == 0) & (status[sub] == 0) & (np.abs(np.nan_to_num(rdq)).max(axis=1) < 100.0)
         err = (np.abs(dq[sub][ok] - rdq[ok]).max(axis=1) / (1.0 + np.abs(rdq[ok]).max(axis=1))).max() if ok.any() else 0.0
         serr = 0.0
         if slack is not None and ok.any():
@@ -122,6 +127,10 @@ def main():
         hsame = np.array_equal(st2, status)
         flag = "" if (same and hsame and err < QP_RTOL and serr < QP_RTOL and herr < 1e-8) else "   <-- MISMATCH"
         bad += bool(flag)
+        if not same:
+            diff = np.nonzero(status[sub] != rstatus)[0]
+            print("     status differs on sampled instances %s: device %s oracle %s" % (
+                sub[diff][:8].tolist(), status[sub][diff][:8].tolist(), rstatus[diff][:8].tolist()))
         print("%2d %-4s %-22s status %s (oracle %s)  rel err %.1e slack %.1e  hot-vs-cold %.1e%s  [%s]%s" % (
             k, robot, ctrl.kernel_name[:22], np.bincount(status[sub], minlength=3), np.bincount(rstatus, minlength=3), err,
             serr, herr, "" if hsame else " hot status differs", what, flag), flush=True)
