@@ -108,6 +108,8 @@ def self_launch(args):
     (torch.cuda.device_count() only counts), and the ranks are fresh child processes."""
     import torch
     n = torch.cuda.device_count()
+    if os.environ.get("CLIK_BENCH_SHARED_GPU", "0") == "1":
+        n = max(n, args.gpus) if n >= 1 else n
     if n < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; not running fewer ranks "
                          "under that label\n" % (args.gpus, n))
@@ -280,8 +282,21 @@ WORKLOAD_TEXT = {
 
 
 class Ctx(object):
-    def __init__(self, rank, world, dev, dist):
+    def __init__(self, rank, world, dev, dist, shared_gpu=False):
         self.rank, self.world, self.dev, self.dist = rank, world, dev, dist
+        # CLIK_BENCH_SHARED_GPU=1 (a smoke test of the multi-rank code path on a one-GPU box): every rank on
+        # cuda:0, process group "gloo", control-plane reductions and the all-gather on host tensors
+        self.shared_gpu = shared_gpu
+
+    def reduce_max(self, values, as_int=False):
+        """element-wise MAX over ranks of a short list of numbers"""
+        import torch
+        if self.dist is None:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.int64 if as_int else torch.float64,
+                         device="cpu" if self.shared_gpu else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [int(v) if as_int else float(v) for v in t.tolist()]
 
 
 def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_graph=1, ramp_ms=250.0,
@@ -363,10 +378,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         est_ms = (time.perf_counter() - t_r) * 1e3 / n_ramp          # one replay, host-inclusive (upper bound)
         R = replays if replays > 0 else max(50, int(min_timed_ms / max(est_ms, 1e-3)) + 1)
         R = min(R, 200000)
-        if dist is not None:
-            rr = torch.tensor([R], dtype=torch.int64, device=dev)
-            dist.all_reduce(rr, op=dist.ReduceOp.MAX)
-            R = int(rr.item())
+        R = ctx.reduce_max([R], as_int=True)[0]
         n_ev = min(R, 2000)                                           # events around the first n_ev replays
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
         ev_end = torch.cuda.Event(enable_timing=True)
@@ -389,8 +401,11 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         # back to back on the same stream (eager launches: a collective is not captured)
         ag = None
         if allgather and world > 1:
-            from casclik_amd.distributed import all_gather_rows
+            from casclik_amd.distributed import all_gather_rows as _agr
             n_total = global_batch if global_batch else world * B
+
+            def all_gather_rows(t, n):          # (gloo smoke test: host copies; RCCL: the device rows)
+                return _agr(t.cpu() if ctx.shared_gpu else t, n)
             full = all_gather_rows(dQ, n_total)
             M = 200
             for _ in range(20):
@@ -415,8 +430,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
             torch.cuda.synchronize()
             dist.barrier()
             both_us = (time.perf_counter() - ta) * 1e6 / M
-            tt = torch.tensor([ag_us, both_us], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tt = ctx.reduce_max([ag_us, both_us])
             ag = {"allgather_us": float(tt[0]), "tick_plus_allgather_us_eager": float(tt[1]),
                   "bytes_per_rank": int(dQ.numel() * 8), "bytes_gathered": int(full.numel() * 8),
                   "algorithm": "one torch.distributed.all_gather_into_tensor (RCCL all-gather over xGMI) per tick "
@@ -426,10 +440,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     per_replay_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(n_ev))
     med_ms = per_replay_ms[n_ev // 2]
     dev_ms = evs[0].elapsed_time(ev_end)
-    if dist is not None:
-        tt = torch.tensor([wall, dev_ms, med_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_ms, med_ms = float(tt[0]), float(tt[1]), float(tt[2])
+    wall, dev_ms, med_ms = ctx.reduce_max([wall, dev_ms, med_ms])
 
     K, W, GK = K * TPL, W * TPL, GK * TPL          # report in ticks
     timed_steps = R * GK
@@ -530,6 +541,9 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    shared_gpu = os.environ.get("CLIK_BENCH_SHARED_GPU", "0") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -537,12 +551,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         ranks_seen = dist.get_world_size()
         gathered = [None] * world
         dist.all_gather_object(gathered, "rank %d pid %d %s" % (rank, os.getpid(), devices[0]))
         devices = gathered
-    ctx = Ctx(rank, world, dev, dist)
+    ctx = Ctx(rank, world, dev, dist, shared_gpu)
 
     from casclik_amd import skills
     fk = skills.iiwa()

@@ -1147,7 +1147,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
 //     multiplier asks for a release): the rows admit no point, status 2.
 // Start: Gauss-Seidel sweeps on the box as in qp_box_pas, rows violated there start active; hot: the partition of the
 // previous tick (hot = atL | atU << 10 | rows at their lower bound << 20 | rows at their upper bound << 24).
-// numpy prototype and its sweep against the oracle: tools/_build/qp_mixed_proto.py (1500 random problems with 1-4
+// numpy prototype and its sweep against the oracle: tools/qp_mixed_proto.py (1500 random problems with 1-4
 // general rows, 4-8 variables: every minimiser to 3e-10, every infeasible one recognised, no pass cap).
 // Returns 0 (KKT point), 1 (pass cap), 2 (no feasible point).
 template <int NZ, int NV, int NH>
@@ -1283,11 +1283,15 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
             double Y[NH][NZ], S[NHT], rhs[NH];
 #pragma unroll
             for (int r = 0; r < NH; ++r) {
+                // (a row no lane of the wave has in its working set needs no solve: walls are inactive in most ticks)
+                const bool used = __ballot((act[r] != 0) & !done) != 0ull;
 #pragma unroll
-                for (int a = 0; a < NZ; ++a) Y[r][a] = (a < NV) ? fma(-as_mask(held[a]), G[r][a < NV ? a : 0], G[r][a < NV ? a : 0]) : 0.0;
-                ldl_solve_s<NZ>(M, rd, Y[r]);
+                for (int a = 0; a < NZ; ++a) Y[r][a] = (a < NV && used) ? fma(-as_mask(held[a]), G[r][a < NV ? a : 0], G[r][a < NV ? a : 0]) : 0.0;
+                if (used) {
+                    ldl_solve_s<NZ>(M, rd, Y[r]);
 #pragma unroll
-                for (int a = 0; a < NZ; ++a) Y[r][a] = fma(-as_mask(held[a]), Y[r][a], Y[r][a]);
+                    for (int a = 0; a < NZ; ++a) Y[r][a] = fma(-as_mask(held[a]), Y[r][a], Y[r][a]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < NH; ++r) {
@@ -1313,7 +1317,9 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
             ldl_solve_s<NH>(S, rs, rhs);
 #pragma unroll
             for (int r = 0; r < NH; ++r) {
-                lam[r] = (act[r] != 0) ? rhs[r] : 0.0;
+                // (a lane that is done keeps the multipliers of its final point: the passes other lanes still need
+                // must not overwrite them - its rows may not even be solved for any more, see `used`)
+                lam[r] = done ? lam[r] : ((act[r] != 0) ? rhs[r] : 0.0);
 #pragma unroll
                 for (int a = 0; a < NZ; ++a) d[a] = fma(lam[r], Y[r][a], d[a]);
             }
