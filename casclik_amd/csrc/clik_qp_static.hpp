@@ -968,10 +968,15 @@ __device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2],
 //   the gradient is recomputed from x (the same 49 multiply-adds an update would cost, and no drift).
 // Start: see below (cold: coordinate-wise minimisers, clipped; hot: the partition of the previous tick,
 // hot = atL | atU << 16).  Returns 0 (KKT point, checked on the final gradient), 1 (pass cap), 2 (lb > ub).
-template <int N>
+// QUAD (experiment, CLIK_QP_LANES=4; profiles/r3_qp_portfolio_study.md): the four lanes of a DPP quad work on the SAME
+// instance with one instruction stream and per-lane data - the over-relaxation factor `omega` of the start sweeps
+// differs per lane, so the lanes end the sweeps on different partitions - and the quad is done as soon as ONE lane has
+// reached the KKT point (the others stop with it).
+template <int N, bool QUAD = false>
 __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
                                           const double (&lb)[N], const double (&ub)[N], const int max_pass,
-                                          const bool valid, double (&x)[N], int32_t* hot, const bool use_hot)
+                                          const bool valid, double (&x)[N], int32_t* hot, const bool use_hot,
+                                          const double omega = 1.0)
 {
     constexpr int NT = N * (N + 1) / 2;
     constexpr int kOne = 0x3ff00000;        // high word of 1.0: the masks below are doubles 1.0 / 0.0 kept as that word
@@ -1020,7 +1025,8 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         for (int sweep = 0; sweep < CLIK_QP_BOX_SWEEPS; ++sweep) {
 #pragma unroll
             for (int a = 0; a < N; ++a) {
-                const double xa = fmin(fmax(fma(res[a], ip[a], x[a]), lb[a]), ub[a]);
+                const double step = QUAD ? omega * (res[a] * ip[a]) : res[a] * ip[a];
+                const double xa = fmin(fmax(QUAD ? x[a] + step : fma(res[a], ip[a], x[a]), lb[a]), ub[a]);
                 const double dl = xa - x[a];
                 x[a] = xa;
 #pragma unroll
@@ -1052,13 +1058,14 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         }
     };
     gradient();
+    bool quad_over = false;      // (QUAD: some lane of this lane's quad has finished)
     bool done = !valid | empty;
     int status = empty ? 2 : 1;
     // (masks applied arithmetically and selections by min / max: a select of a double costs two instructions and
     // a flag test two more, and a lone wave pays every one of them in full)
 #pragma unroll 1
     for (int pass = 0; pass < max_pass; ++pass) {
-        if (__ballot(!done) == 0ull) break;
+        if (__ballot(!(done | quad_over)) == 0ull) break;
         // Newton direction on the free states
         double M[NT], rd[N], d[N];
 #pragma unroll
@@ -1084,12 +1091,12 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             amin = fmin(amin, r[a]);
         }
         const bool blocked = amin < 1.0;
-        const double alpha = done ? 0.0 : amin;
+        const double alpha = (done | quad_over) ? 0.0 : amin;
         const double thr = amin * (1.0 + 1e-7);
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             const double xn = fma(-alpha, d[a], x[a]);
-            const bool lands = blocked & !done & (r[a] <= thr);            // the blocking state (and ties): held there
+            const bool lands = blocked & !(done | quad_over) & (r[a] <= thr);            // the blocking state (and ties): held there
             x[a] = lands ? tgt[a] : xn;
             held[a] = lands ? kOne : held[a];
         }
@@ -1103,10 +1110,17 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             c[a] = fma(push, as_mask(held[a] & free_ok[a]), -tol[a]);
             worst = fmax(worst, c[a]);
         }
-        const bool release = !blocked & !done & (worst > 0.0);
+        const bool release = !blocked & !(done | quad_over) & (worst > 0.0);
 #pragma unroll
         for (int a = 0; a < N; ++a) held[a] = (release & (c[a] == worst)) ? 0 : held[a];
-        done = done | (!blocked & !(worst > 0.0));
+        done = done | (!quad_over & !blocked & !(worst > 0.0));
+        if constexpr (QUAD) {
+            // a lane that has finished ends its whole quad (mov_dpp quad_perm broadcasts of the flag)
+            const int dn = (done & valid & !empty) ? 1 : 0;
+            const int any = __builtin_amdgcn_mov_dpp(dn, 0x00, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(dn, 0x55, 0xf, 0xf, true) |
+                            __builtin_amdgcn_mov_dpp(dn, 0xAA, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(dn, 0xFF, 0xf, 0xf, true);
+            quad_over = quad_over | (any != 0);
+        }
     }
     if (!empty) {
         // the KKT conditions of the returned point (gr is the gradient at x)

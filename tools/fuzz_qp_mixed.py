@@ -125,6 +125,10 @@ def main():
         fin = (status == 0) & (st2 == 0)
         herr = np.abs(d2[fin] - dq[fin]).max() if fin.any() else 0.0
         hsame = np.array_equal(st2, status)
+        if not hsame:
+            dd = np.nonzero(st2 != status)[0]
+            print("     hot-started status differs on instances %s: cold %s hot %s" % (
+                dd[:8].tolist(), status[dd][:8].tolist(), st2[dd][:8].tolist()))
         flag = "" if (same and hsame and err < QP_RTOL and serr < QP_RTOL and herr < 1e-8) else "   <-- MISMATCH"
         bad += bool(flag)
         if not same:
