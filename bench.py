@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0,
                     help="lanes per robot instance of the pinv kernel: 0 = the library's choice, 1 = "
                          "lane-per-instance kernels only, 4 / 8 / 16 = the multi-lane kernel (CLIK_LANES)")
+    ap.add_argument("--qp-lanes", type=int, default=0,
+                    help="qp workload: 4 = the four-lanes-per-instance experiment of the box-family kernel (CLIK_QP_LANES)")
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp before the timed region")
     ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="least work inside the timed bracket")
     ap.add_argument("--replays", type=int, default=0, help="R (0: from --min-timed-ms, at least 50)")
@@ -537,6 +539,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.lanes:
         os.environ["CLIK_LANES"] = str(args.lanes)
+    if args.qp_lanes:
+        os.environ["CLIK_QP_LANES"] = str(args.qp_lanes)
 
     import torch
     if not torch.cuda.is_available():

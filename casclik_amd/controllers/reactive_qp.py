@@ -430,7 +430,12 @@ class ReactiveQPController(BaseController):
     # -- per tick -----------------------------------------------------------------
     def kernel_variant(self, batch):
         """name of the kernel a batch of ``batch`` instances gets ("/v": with the skill's numbers compiled in)"""
-        return self.kernel_name + ("/v" if getattr(self, "value_kernel", None) else "")
+        import os
+        name = self.kernel_name + ("/v" if getattr(self, "value_kernel", None) else "")
+        if (getattr(self, "value_kernel", None) and os.environ.get("CLIK_QP_LANES", "")[:1] == "4" and int(batch) <= 16384
+                and self._lib.clik_qp_is_box_family(self._handle)):
+            name += "/quad4"         # (experiment: four lanes per instance, clik_qp_static.hpp)
+        return name
 
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
                     return_status=True, hot_set=None, use_hot=True):

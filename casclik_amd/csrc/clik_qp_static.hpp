@@ -1242,7 +1242,9 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
         const bool pin = !(ub[a] > lb[a]);
         held[a] = (on_l | on_u | pin) ? kOne : 0;
         free_ok[a] = pin ? 0 : kOne;
-        tol[a] = 1e-9 * fmax(1.0, fabs(g[a]));
+        // (1e-10: a held state with a wrong multiplier below the tolerance stays held, and the velocities feel that error
+        // divided by the smallest curvature, mu = 1e-3 along the directions the soft task does not see)
+        tol[a] = 1e-10 * fmax(1.0, fabs(g[a]));
     }
     // rows: the hinted ones, the equalities, and whatever the start violates
     int act[NHA];
@@ -1395,7 +1397,7 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 #pragma unroll
         for (int r = 0; r < NH; ++r) {
             const double pr = (act[r] != 0 && !eqr[r]) ? -(double)act[r] * lam[r] : 0.0;
-            cr[r] = pr - 1e-9 * fmax(1.0, fabs(lam[r]));
+            cr[r] = pr - 1e-10 * fmax(1.0, fabs(lam[r]));
             worst = fmax(worst, cr[r]);
         }
         const bool release = !blocked & !done & (worst > 0.0);
@@ -1432,7 +1434,7 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 #pragma unroll
                 for (int r = 0; r < NH; ++r) gf = fma(lam[r], G[r][a < NV ? a : 0], gf);
             }
-            const double t5 = 10.0 * tol[a];
+            const double t5 = 100.0 * tol[a];
             const bool fine = ((x[a] <= lb[a]) & (gf >= -t5)) | ((x[a] >= ub[a]) & (gf <= t5)) | (fabs(gf) <= t5);
             kkt = kkt & fine;
         }
@@ -1469,12 +1471,12 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
-template <const ShapeDesc& SD, int SSTR = WAVE>
+template <const ShapeDesc& SD, int SSTR = WAVE, bool QUAD = false>
 __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
                                               const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
                                               const int lane, const bool valid, double* slots,
                                               double (&v)[SD.n], double (&sl)[QpLayout<SD>::NSA],
-                                              int32_t* hot, const bool use_hot)
+                                              int32_t* hot, const bool use_hot, const double omega = 1.0)
 {
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
@@ -1623,7 +1625,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
 #ifdef CLIK_QP_BOX_PN
         int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
 #else
-        int status = qp_box_pas<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
+        int status = qp_box_pas<N, QUAD>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot, omega);
 #endif
         if (!valid) status = 0;
         // slack of the folded rows: s = J v - b
@@ -1950,6 +1952,66 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
     CLIK_BODY_END();
 }
 
+// ... with four lanes per instance (experiment, CLIK_QP_LANES=4, batches up to 16384 instances: 1024 waves instead of
+// 256): every lane of a quad runs the whole tick of the same instance with its own over-relaxation factor in the
+// start sweeps; the first lane at the KKT point ends the quad and stores.  Measured against the one-lane kernel in
+// DESIGN.md section 5 / profiles/r3_qp_portfolio_study.md.
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_quad_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    using LY = QpLayout<SD>;
+    static_assert(LY::BOX, "box family only");
+    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
+    constexpr QpImg<SD> kValues = IMGV::value;
+    const int tid = threadIdx.x;
+    const int r = tid & 3;
+    const long long inst = (long long)blockIdx.x * WAVE + (tid >> 2);
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
+    }
+    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double priv[LY::SLOTS];
+    double v[N], sl[LY::NSA];
+    int32_t hot_word = (hot_set != nullptr) ? hot_set[row] : 0;
+    const double omega = (r == 0) ? 1.0 : ((r == 1) ? 1.3 : ((r == 2) ? 1.5 : 1.7));
+    const int status = qp_tick_static<SD, 1, true>(&kValues.img, &kValues.tail, tk, z, ysl, tid & (WAVE - 1), valid, priv, v,
+                                                   sl, hot_set != nullptr ? &hot_word : nullptr, use_hot != 0, omega);
+    // the lowest lane of the quad that reached the KKT point stores (lane 0 when none did: its status is reported)
+    const int okl = (status == 0) ? 1 : 0;
+    const int o0 = __builtin_amdgcn_mov_dpp(okl, 0x00, 0xf, 0xf, true), o1 = __builtin_amdgcn_mov_dpp(okl, 0x55, 0xf, 0xf, true);
+    const int o2 = __builtin_amdgcn_mov_dpp(okl, 0xAA, 0xf, 0xf, true);
+    const int winner = o0 ? 0 : (o1 ? 1 : (o2 ? 2 : (__builtin_amdgcn_mov_dpp(okl, 0xFF, 0xf, 0xf, true) ? 3 : 0)));
+    if (valid && r == winner) {
+        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
+        if constexpr (NX > 0) {
+            if (dx != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
+            }
+        }
+        if constexpr (NS > 0) {
+            if (slack_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+            }
+        }
+        if (status_out != nullptr) status_out[inst] = status;
+        if (hot_set != nullptr) hot_set[inst] = hot_word;
+    }
+}
+
 // ... and its on-device rollout (see qp_rollout_static_kernel): state, working set and Runge-Kutta bookkeeping in
 // registers from tick to tick, rows loaded once and stored once by the lane itself
 template <const ShapeDesc& SD, class IMGV, bool RK>
@@ -2083,6 +2145,12 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     if constexpr (QpLayout<SD>::BOX) {
+        static const bool quad = []() { const char* e = getenv("CLIK_QP_LANES"); return e && e[0] == '4'; }();
+        if (quad && B <= 16384) {
+            hipLaunchKernelGGL((qp_solve_static_box_quad_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0, stream, q,
+                               y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((qp_solve_static_box_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
                            slack, status, B, x, dx, hot_set, use_hot, tk);
         return hipGetLastError();

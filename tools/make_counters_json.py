@@ -59,7 +59,9 @@ for tag, (key, kernel, bpi, B) in CASES.items():
            "clk_per_wave": {k[3:].lower(): round(4 * raw[k] / w) for k in
                             ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
                              "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS") if k in raw}}
-    if "GRBM_GUI_ACTIVE" in raw and "SQ_ACTIVE_INST_VALU" in raw:
+    # (GRBM_GUI_ACTIVE spans the profiler's serialised dispatch, not only the kernel: a usable denominator only
+    # where the kernel is long against that overhead: 70 us at 1 M instances against ~8 us of gaps)
+    if "GRBM_GUI_ACTIVE" in raw and "SQ_ACTIVE_INST_VALU" in raw and B >= 1048576:
         ent["gpu_active_clk"] = raw["GRBM_GUI_ACTIVE"] / 8.0
         ent["valu_issue_frac"] = 4.0 * raw["SQ_ACTIVE_INST_VALU"] / (1024.0 * raw["GRBM_GUI_ACTIVE"] / 8.0)
         ent["fp64_share_of_valu"] = (raw["SQ_INSTS_VALU_FMA_F64"] + raw["SQ_INSTS_VALU_MUL_F64"]
