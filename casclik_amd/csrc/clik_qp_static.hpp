@@ -1326,11 +1326,23 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
                     for (int j = 0; j < NV; ++j) acc = fma(G[r][j], Y[q][j], acc);
                     S[tri(r, q)] = acc;
                 }
+                // (an active row without any free state under it has S_rr = 0: the small diagonal keeps the factor finite
+                // and its huge multiplier then asks for a held state to be released.  Its bias on healthy rows - the
+                // step would leave 1e-13 x lambda of the residual - is removed by one step of iterative refinement below)
                 S[tri(r, r)] += (act[r] != 0) ? 1e-13 : 1e30;
             }
             double rs[NH];
             ldl_factor_s<NH>(S, rs);
             ldl_solve_s<NH>(S, rs, rhs);
+            {
+                // S0 lambda = rhs with S = S0 + 1e-13 I on the active rows: lambda += S^-1 (1e-13 lambda)
+                double corr[NH];
+#pragma unroll
+                for (int r = 0; r < NH; ++r) corr[r] = (act[r] != 0) ? 1e-13 * rhs[r] : 0.0;
+                ldl_solve_s<NH>(S, rs, corr);
+#pragma unroll
+                for (int r = 0; r < NH; ++r) rhs[r] += corr[r];
+            }
 #pragma unroll
             for (int r = 0; r < NH; ++r) {
                 // (a lane that is done keeps the multipliers of its final point: the passes other lanes still need

@@ -72,10 +72,12 @@ def mixed_pas(P, g, lb, ub, G, lbg, ubg, sweeps=12, max_pass=40):
         d0 = np.where(held, 0.0, np.linalg.solve(M, np.where(held, 0.0, gr)))
         if nh:
             Y = np.linalg.solve(M, G.T); Y[held, :] = 0.0
-            S = G @ Y + np.diag(np.where(act != 0, 1e-13, 1e30))
+            S0 = G @ Y
+            S = S0 + np.diag(np.where(act != 0, 1e-13, 1e30))
             bnd = np.where(act > 0, ubg, lbg)
             resid = np.where(act != 0, G @ x - bnd, 0.0)
             lam = np.linalg.solve(S, resid - G @ d0)
+            lam = lam + np.linalg.solve(S, np.where(act != 0, 1e-13 * lam, 0.0))      # (one step of iterative refinement)
             lam = np.where(act != 0, lam, 0.0)
             d = d0 + Y @ lam
         else:
@@ -114,9 +116,13 @@ def mixed_pas(P, g, lb, ub, G, lbg, ubg, sweeps=12, max_pass=40):
             if pr.max() > 0 and pr.max() > worst:
                 worst, wi, wkind = pr.max(), int(pr.argmax()), 2
         if wkind == 0:
-            mag = np.maximum(1.0, np.abs(G * x[None, :]).max(axis=1)) if nh else 1.0
-            if nh and np.any((act != 0) & (np.abs(G @ x - np.where(act > 0, ubg, lbg)) > 1e-8 * np.maximum(mag, np.abs(np.where(act > 0, ubg, lbg))))):
-                return x, lam, 2, passes       # an active row cannot be met on any face reachable: infeasible
+            if nh:
+                mag = np.maximum(1.0, np.abs(G * x[None, :]).max(axis=1))
+                bnd_ = np.where(act > 0, ubg, lbg)
+                dev = np.where(act != 0, np.abs(G @ x - bnd_), 0.0)
+                sc = np.maximum(mag, np.abs(bnd_))
+                if np.any(dev > 1e-8 * sc):
+                    return x, lam, 2, passes       # an active row cannot be met on any face reachable: infeasible
             return x, lam, 0, passes
         if wkind == 1:
             held[wi] = False
