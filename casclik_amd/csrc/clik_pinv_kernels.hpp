@@ -818,7 +818,9 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
 }
 
 // (experiment switches: -DCLIK_OCC2 / -DCLIK_OCC1 pin the occupancy of the kernels below)
-#ifdef CLIK_OCC2
+#if defined(CLIK_OCC3)
+#define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#elif defined(CLIK_OCC2)
 #define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #elif defined(CLIK_OCC1)
 #define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))

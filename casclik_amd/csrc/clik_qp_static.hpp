@@ -1279,8 +1279,12 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
     double lam[NHA];
 #pragma unroll
     for (int r = 0; r < NHA; ++r) lam[r] = 0.0;
+    // (every pass changes the working set by one entry or ends; the random sweeps need at most 2 (NZ + NH) passes; an
+    // instance still turning after 3 (NZ + NH) + 6 - rows and bounds that contradict each other jointly can make the
+    // releases cycle - is cut off and classified below)
+    const int pass_cap = max_pass < 3 * (NZ + NH) + 6 ? max_pass : 3 * (NZ + NH) + 6;
 #pragma unroll 1
-    for (int pass = 0; pass < max_pass; ++pass) {
+    for (int pass = 0; pass < pass_cap; ++pass) {
         if (__ballot(!done) == 0ull) break;
         double M[NT], rd[NZ], d[NZ];
 #pragma unroll
@@ -1435,6 +1439,22 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
             status = off ? 2 : 0;
         }
         done = done | fin;
+    }
+    if (status == 1 && valid && !done) {
+        // cut off: a point that still violates a row is reported as "no feasible point found" (the reference's solver
+        // raises in both cases), a feasible one as "pass cap"
+        bool viol = false;
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            double gx = 0.0, mag = 1.0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                gx = fma(G[r][j], x[j], gx);
+                mag = fmax(mag, fabs(G[r][j] * x[j]));
+            }
+            viol = viol | (gx > ubg[r] + 1e-8 * fmax(mag, fabs(ubg[r]))) | (gx < lbg[r] - 1e-8 * fmax(mag, fabs(lbg[r])));
+        }
+        status = viol ? 2 : 1;
     }
     if (status == 0) {
         // the KKT conditions of the returned point: stationarity with the row multipliers, bounds, rows
