@@ -900,8 +900,9 @@ extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_t
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
+    // (watchdog budget: polls, at a nominal 2.5 us each)
     hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, (unsigned*)done, n_ticks,
-                                   (unsigned long long)(timeout_s * 1e8), (hipStream_t)stream);
+                                   (unsigned long long)(timeout_s * 4e5), (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "resident kernel launch");
     return CLIK_OK;
 }
@@ -912,7 +913,7 @@ extern "C" int clik_ticket_feed(clik_ticket* ticket, const uint32_t* done, int32
     if (!ticket || !done || n_ticks <= 0 || waves_per_tick <= 0) return fail(CLIK_EINVAL, "bad arguments");
     if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
     hipError_t e = clik::launch_ticket_feed((void*)ticket, (const unsigned*)done, n_ticks, closed_loop, (unsigned)waves_per_tick,
-                                            (unsigned long long)(timeout_s * 1e8), (hipStream_t)stream);
+                                            (unsigned long long)(timeout_s * 4e5), (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "ticket feeder launch");
     return CLIK_OK;
 }

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
 // when every slot holds k.  (One shared counter was measured first: 1024 waves adding to one address serialise at
 // the memory side - 24.6 us per closed-loop tick against 4.0 us for a launch per tick.)  The kernel leaves when n_ticks are done, when anyone sets `stop`, or when its watchdog (the
 // 100 MHz s_memrealtime clock against the timeout given at launch) expires - it then writes stop = 2 so that every
-// other wave and the producer leave too.  It never spins without that check.
+// other wave and the producer leave too.  It never spins without that check.  (The watchdog counts polls, see below.)
 struct ResidentTicket {
     unsigned in_seq, p0[15];
     unsigned reserved, p1[15];
@@ -581,7 +581,7 @@ __device__ __forceinline__ unsigned long long realtime_100mhz()
 template <const ShapeDesc& SD, class IMGV>
 __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     const double* q, const double* y, double* dq, int32_t* mode_out, const long long B, const TickArgs tk,
-    ResidentTicket* ticket, unsigned* done, const int n_ticks, const unsigned long long timeout_ticks)
+    ResidentTicket* ticket, unsigned* done, const int n_ticks, const unsigned long long max_polls)
 {
     static_assert(shape_team_ok(SD), "shape outside the team kernel's family");
     static_assert(!std::is_void<IMGV>::value, "resident ticks: value-specialised instantiation only");
@@ -593,7 +593,10 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     const bool valid = b0 + inst < B;
     const long long binst = valid ? (b0 + inst) : (B - 1);
     constexpr Img<SD> Sval = IMGV::value;
-    const unsigned long long t_start = realtime_100mhz();
+    // watchdog: a budget of POLLS over the kernel's whole life (a poll is a cache-missing load plus s_sleep, 1.5-3 us):
+    // deterministic, unlike a clock - the first version compared s_memrealtime readings and misfired at the first tick
+    // inside the long test run (never alone), leaving the kernel at once with stop = 2
+    unsigned long long polls = 0;
     if (blockIdx.x == 0 && tid == 0) ticket->waves = gridDim.x * TEAM_WAVES;
     const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
 #pragma unroll 1
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
                 leave = true;
                 break;
             }
-            if (realtime_100mhz() - t_start > timeout_ticks) {
+            if (++polls > max_polls) {
                 __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 leave = true;
                 break;
@@ -652,10 +655,6 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             __hip_atomic_store(done + (blockIdx.x * TEAM_WAVES + (tid >> 6)), (unsigned)k, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
-        if (realtime_100mhz() - t_start > timeout_ticks) {
-            __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
     }
 }
 
@@ -665,11 +664,11 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
 template <int UNIQUE = 0>        // (a template only so that the header may be included by several translation units)
 __global__ __launch_bounds__(1024) void resident_feed_kernel(ResidentTicket* ticket, const unsigned* done, const int n_ticks,
                                                              const int closed_loop, const unsigned waves_per_tick,
-                                                             const unsigned long long timeout_ticks)
+                                                             const unsigned long long max_polls)
 {
     // one thread per wave slot (strided when there are more slots than threads); thread 0 publishes
     __shared__ int s_leave;
-    const unsigned long long t_start = realtime_100mhz();
+    unsigned long long polls = 0;
     if (threadIdx.x == 0) s_leave = 0;
     __syncthreads();
 #pragma unroll 1
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(1024) void resident_feed_kernel(ResidentTicket* tic
                         s_leave = 1;
                         break;
                     }
-                    if (realtime_100mhz() - t_start > timeout_ticks) {
+                    if (++polls > max_polls) {
                         __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         s_leave = 1;
                         break;

@@ -1440,9 +1440,10 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
         }
         done = done | fin;
     }
-    if (status == 1 && valid && !done) {
-        // cut off: a point that still violates a row is reported as "no feasible point found" (the reference's solver
-        // raises in both cases), a feasible one as "pass cap"
+    if (!empty) {
+        // What is handed back: a KKT point (0), or - cut off, or ended on a face whose conditions do not check out -
+        // "no feasible point found" (2) when the point still violates a row, else "pass cap" (1).  The reference's
+        // solver raises in both cases.
         bool viol = false;
 #pragma unroll
         for (int r = 0; r < NH; ++r) {
@@ -1452,13 +1453,9 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
                 gx = fma(G[r][j], x[j], gx);
                 mag = fmax(mag, fabs(G[r][j] * x[j]));
             }
-            viol = viol | (gx > ubg[r] + 1e-8 * fmax(mag, fabs(ubg[r]))) | (gx < lbg[r] - 1e-8 * fmax(mag, fabs(lbg[r])));
+            viol = viol | (gx > ubg[r] + 1e-7 * fmax(mag, fabs(ubg[r]))) | (gx < lbg[r] - 1e-7 * fmax(mag, fabs(lbg[r])));
         }
-        status = viol ? 2 : 1;
-    }
-    if (status == 0) {
-        // the KKT conditions of the returned point: stationarity with the row multipliers, bounds, rows
-        bool kkt = true;
+        bool kkt = !viol;
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
             double gf = gr[a];
@@ -1470,17 +1467,7 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
             const bool fine = ((x[a] <= lb[a]) & (gf >= -t5)) | ((x[a] >= ub[a]) & (gf <= t5)) | (fabs(gf) <= t5);
             kkt = kkt & fine;
         }
-#pragma unroll
-        for (int r = 0; r < NH; ++r) {
-            double gx = 0.0, mag = 1.0;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                gx = fma(G[r][j], x[j], gx);
-                mag = fmax(mag, fabs(G[r][j] * x[j]));
-            }
-            kkt = kkt & !(gx > ubg[r] + 1e-7 * fmax(mag, fabs(ubg[r]))) & !(gx < lbg[r] - 1e-7 * fmax(mag, fabs(lbg[r])));
-        }
-        status = kkt ? 0 : 1;
+        status = ((status == 2) | viol) ? 2 : (((status == 0) & kkt) ? 0 : 1);
     }
     if (hot != nullptr && valid) {
         uint32_t atL = 0u, atU = 0u, rowL = 0u, rowU = 0u;

@@ -239,8 +239,8 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  *     (write-through), and - once those stores are acknowledged - writes k into ITS OWN slot done[w]; tick k is
  *     complete when every one of the `waves` slots holds k (waves is filled in by the kernel; clik_pinv_resident_waves
  *     returns it beforehand; `done` is device memory, `waves` words, zeroed by the caller);
- *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (timeout_s of the
- *     100 MHz device clock since its start; it then writes stop = 2 itself) - it never spins unguarded.
+ *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (a budget of polls over
+ *     its whole life, timeout_s at a nominal 2.5 us per poll; it then writes stop = 2 itself) - it never spins unguarded.
  * clik_ticket_feed launches the reference producer (one device block that publishes tickets 1 .. n_ticks, either
  * back to back or - closed_loop - each only after every slot shows the previous tick) on `stream`, which must differ
  * from the kernel's stream.  Only for handles with an attached value-specialised kernel of that family
