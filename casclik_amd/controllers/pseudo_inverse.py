@@ -366,7 +366,9 @@ class PseudoInverseController(BaseController):
         with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [32] stop, [48] waves, [49] ticks_done),
         ``done`` (int32 device tensor, one slot per wave: the last tick that wave finished), ``waves`` per tick,
         ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
-        leaves after ``n_ticks``, on ``ticket[32] != 0`` or after ``timeout_s`` (device clock) whatever happens."""
+        leaves after ``n_ticks``, on ``ticket[32] != 0`` or when its poll budget (``timeout_s`` at a nominal 2.5 us per
+        poll) is used up, whatever happens.  Whoever feeds it (copies, producer kernels) must use a stream that does not
+        share a hardware queue with ``stream``: a stream of another priority (``torch.cuda.Stream(priority=-1)``)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -406,7 +408,9 @@ class PseudoInverseController(BaseController):
         every wave has finished the previous tick."""
         torch = _torch()
         dev = self._device
-        stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        # (a stream of another PRIORITY: the runtime multiplexes streams of one priority onto a few hardware queues,
+        # and a producer queued behind the resident kernel would wait for it to leave - see include/clik.h)
+        stream = stream if stream is not None else torch.cuda.Stream(device=dev, priority=-1)
         with torch.cuda.device(dev):
             rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), ptr(run["done"]), int(n_ticks), 1 if closed_loop else 0,
                                             int(run["waves"]),

@@ -597,7 +597,12 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     // deterministic, unlike a clock - the first version compared s_memrealtime readings and misfired at the first tick
     // inside the long test run (never alone), leaving the kernel at once with stop = 2
     unsigned long long polls = 0;
-    if (blockIdx.x == 0 && tid == 0) ticket->waves = gridDim.x * TEAM_WAVES;
+    if (blockIdx.x == 0 && tid == 0) {
+        ticket->waves = gridDim.x * TEAM_WAVES;
+        ticket->p3[0] = (unsigned)max_polls;            // (diagnostics: what the launch handed over)
+        ticket->p3[1] = (unsigned)(max_polls >> 32);
+        ticket->p3[2] = (unsigned)n_ticks;
+    }
     const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
@@ -614,6 +619,10 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             }
             if (++polls > max_polls) {
                 __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((tid & (WAVE - 1)) == 0) {
+                    ticket->p3[3] = (unsigned)polls;        // (diagnostics: the wave that gave up, and after how many polls)
+                    ticket->p3[4] = blockIdx.x * TEAM_WAVES + (tid >> 6);
+                }
                 leave = true;
                 break;
             }

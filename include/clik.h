@@ -242,8 +242,10 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (a budget of polls over
  *     its whole life, timeout_s at a nominal 2.5 us per poll; it then writes stop = 2 itself) - it never spins unguarded.
  * clik_ticket_feed launches the reference producer (one device block that publishes tickets 1 .. n_ticks, either
- * back to back or - closed_loop - each only after every slot shows the previous tick) on `stream`, which must differ
- * from the kernel's stream.  Only for handles with an attached value-specialised kernel of that family
+ * back to back or - closed_loop - each only after every slot shows the previous tick) on `stream`, which must not share
+ * a HARDWARE QUEUE with the kernel's stream (the runtime multiplexes the streams of one priority onto a few queues; a
+ * producer or copy queued behind the resident kernel waits until the watchdog lets it go): use a stream of another
+ * priority (hipStreamCreateWithPriority).  Only for handles with an attached value-specialised kernel of that family
  * (clik_pinv_attach_resident_kernel; casclik_amd/jit.py does it).  Not graph-capturable.  Measured on one MI355X
  * (tools/resident_probe.py): the hand-off costs more than the launch boundary it replaces.           */
 typedef struct clik_ticket {

@@ -556,3 +556,42 @@ def test_qp_value_specialised_kernel_outside_the_box_family(ur5_fk):
     assert np.array_equal(a[3], b[3])
     ok = a[3] == 0
     assert ok.sum() > 200 and np.allclose(a[0][ok], b[0][ok], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("soft_walls", [False, True])
+def test_qp_general_rows_mixed_family_against_the_oracle_and_the_dual_iteration(ur5_fk, soft_walls, monkeypatch):
+    """The Moe-2016 wall skill (ur5_moe2016_example2.ipynb cells 6-8: SetConstraints on tool position components,
+    reactive_qp.py:221-225) near its walls: hard walls = general rows in the primal active set, soft walls = bounded
+    variables lifted into the box (clik_qp_static.hpp::qp_mixed_pas).  Statuses (infeasible instances included) and
+    minimisers equal the oracle's, the hot-started tick equals the cold one, and the dual active-set iteration the
+    family ran before (-DCLIK_QP_MIXED_OFF, the regression switch) gives the same answers."""
+    import torch
+    from oracle import clik_oracle
+    from extern_skills import moe_box_skill
+    spec, home = moe_box_skill(ur5_fk, soft_walls=soft_walls)
+    rng = np.random.default_rng(11)
+    Q = home + rng.normal(scale=0.12, size=(768, 6))
+    ctrl = _controller(spec)
+    dq, _, slack, status = ctrl.solve_batch(3.0, Q)
+    sub = np.arange(0, len(Q), 4)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 3.0, Q[sub])
+    assert np.array_equal(status[sub], rstatus)
+    ok = rstatus == 0
+    assert ok.sum() > 100 and (soft_walls or (rstatus == 2).any())
+    assert _rel(dq[sub][ok], rdq[ok]).max() < QP_RTOL and _rel(slack[sub][ok], rslack[ok]).max() < QP_RTOL
+    assert np.isnan(dq[status == 2]).all()
+    # hot start from the tick's own working set
+    hot = torch.zeros(len(Q), dtype=torch.int32, device="cuda")
+    Qd = torch.from_numpy(Q).cuda()
+    ctrl.solve_batch(3.0, Qd, hot_set=hot, use_hot=False)
+    d2, _, _, st2 = ctrl.solve_batch(3.0, Qd, hot_set=hot, use_hot=True)
+    assert np.array_equal(st2.cpu().numpy(), status)
+    fin = status == 0
+    assert np.abs(d2.cpu().numpy()[fin] - dq[fin]).max() < 1e-8
+    # the dual iteration over all rows (what the family ran before round 3)
+    monkeypatch.setenv("CLIK_JIT_DEFINES", "-DCLIK_QP_MIXED_OFF")
+    old = _controller(spec)
+    odq, _, oslack, ostatus = old.solve_batch(3.0, Q)
+    assert np.array_equal(ostatus == 2, status == 2)
+    both = (ostatus == 0) & (status == 0)
+    assert both.sum() > 400 and _rel(odq[both], dq[both]).max() < 1e-7

@@ -54,7 +54,7 @@ print("launch per tick (hipGraph of 1000):   %.3f us per tick" % ((time.perf_cou
 for name, closed in (("free-running", False), ("closed loop", True)):
     best = None
     for rep in range(5):
-        feeder_stream = torch.cuda.Stream()
+        feeder_stream = torch.cuda.Stream(priority=-1)       # (not the hardware queue of the resident kernel)
         torch.cuda.synchronize()
         run = ctrl.resident_start(Qd, Yd, NT, timeout_s=3.0)
         time.sleep(0.02)                      # (the resident kernel is up and polling)
