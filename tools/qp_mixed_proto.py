@@ -60,6 +60,21 @@ def mixed_pas(P, g, lb, ub, G, lbg, ubg, sweeps=12, max_pass=40):
     for s in range(sweeps):
         for a in range(n):
             xa = min(max(x[a] + res[a] * ip[a], lb[a]), ub[a]); dl = xa - x[a]; x[a] = xa; res -= P[:, a] * dl
+    if nh:
+        # rows the box start violates: a few sweeps with those rows pulled in by a penalty (see qp_mixed_pas)
+        gx = G @ x
+        hi = gx > ubg + 1e-12 * np.maximum(1, np.abs(ubg))
+        lo = gx < lbg - 1e-12 * np.maximum(1, np.abs(lbg))
+        if (hi | lo).any():
+            cf = np.where(hi | lo, 1e3 * np.diag(P).max(), 0.0)
+            bv = np.where(hi, ubg, np.where(lo, lbg, 0.0))
+            P2 = P + (G.T * cf) @ G
+            g2 = g + G.T @ (cf * bv)
+            ip2 = 1.0 / np.diag(P2)
+            res = g2 - P2 @ x
+            for s_ in range(8):
+                for a in range(n):
+                    xa = min(max(x[a] + res[a] * ip2[a], lb[a]), ub[a]); dl = xa - x[a]; x[a] = xa; res -= P2[:, a] * dl
     held = (x <= lb) | (x >= ub)
     gx = G @ x
     act = np.where(gx > ubg + 1e-12 * np.maximum(1, np.abs(ubg)), 1, np.where(gx < lbg - 1e-12 * np.maximum(1, np.abs(lbg)), -1, 0))
