@@ -92,3 +92,35 @@ def test_create_rejects_malformed_descriptors(lib):
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_capi.ClikLibraryError, match="no CPU fallback|not found"):
         _capi.load_library(str(tmp_path / "libclik_hip.so"))
+
+
+def test_host_only_handles_answer_queries_and_refuse_to_solve(lib, monkeypatch):
+    """CLIK_HOST_ONLY=1 (include/clik.h): a handle without any device allocation - what casclik_amd/jit.py uses to get a
+    skill's image words on a machine without a GPU; every solve entry point refuses it"""
+    monkeypatch.setenv("CLIK_HOST_ONLY", "1")
+    desc = _capi.desc_to_c(lower_skill(skills.stack_skill()))
+    opts = _capi.pinv_opts_to_c({"feedforward": True, "multidim_sets": True, "converge_final_set_to_max": False,
+                                 "pinv_method": "damped", "damping_factor": 1e-7})
+    h = C.c_void_p()
+    assert lib.clik_pinv_create(C.byref(desc), C.byref(opts), C.byref(h)) == 0
+    buf = (C.c_uint64 * 16384)()
+    n = lib.clik_pinv_image_words(h, buf, len(buf))
+    assert n > 100 and lib.clik_pinv_n_modes(h) == 2
+    assert lib.clik_pinv_solve_batch(h, 4, None, None, None, None, None, None, None, None) == -1
+    assert b"CLIK_HOST_ONLY" in lib.clik_last_error()
+    assert lib.clik_pinv_destroy(h) == 0
+    from casclik_amd import jit
+    qd = _capi.desc_to_c(lower_skill(skills.qp_skill()))
+    words = jit.host_image_words(lib, "qp", qd, _capi.qp_opts_to_c(0.001, [1.0] * 7, [1.0] * 6))
+    assert words and len(words) > 100
+
+
+def test_ticket_layout(tmp_path):
+    """clik_ticket (resident ticks): 256 bytes, the words the Python layer indexes"""
+    src = tmp_path / "tk.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "clik.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(clik_ticket),offsetof(clik_ticket,in_seq),offsetof(clik_ticket,stop),offsetof(clik_ticket,waves),'
+                   'offsetof(clik_ticket,ticks_done));return 0;}\n')
+    exe = tmp_path / "tk"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert [int(v) for v in subprocess.check_output([str(exe)]).split()] == [256, 0, 4 * 32, 4 * 48, 4 * 49]
