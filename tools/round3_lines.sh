@@ -18,6 +18,8 @@ line --workload qp --qp-hot 1 --cpu-baseline 0 --extras 0
 line --workload qp --batch 131072 --cpu-baseline 0 --extras 0
 line --workload pose --cpu-baseline 0 --extras 0
 line --batch 1048576 --steps 400 --warmup 40 --cpu-baseline 0 --extras 0
+echo "# CLIK_JIT_DEFINES=-DCLIK_OCC3 python bench.py --batch 1048576 --steps 400 --warmup 40 --cpu-baseline 0 --extras 0   (experiment: three waves per SIMD for the lane kernel, 168 VGPRs + 624 B of scratch per lane)" >> $OUT/r3_bench_lines.jsonl
+CLIK_JIT_DEFINES=-DCLIK_OCC3 python bench.py --batch 1048576 --steps 400 --warmup 40 --cpu-baseline 0 --extras 0 2>> $OUT/err.log | grep '^{' | tail -1 >> $OUT/r3_bench_lines.jsonl
 line --batch 32768 --cpu-baseline 0 --extras 0
 line --ticks-per-launch 256 --steps 2048 --warmup 256 --cpu-baseline 0 --extras 0
 line --workload qp --ticks-per-launch 64 --steps 2048 --warmup 256 --cpu-baseline 0 --extras 0
