@@ -253,6 +253,9 @@ def test_notebook_golden_vectors(ur5_fk):
 def test_failed_instantiation_is_loud_and_falls_back_only_where_a_builtin_kernel_can_serve(ur5_fk, monkeypatch):
     """A broken hipcc invocation at setup: a row-table skill runs on the built-in dynamic kernel (with a
     warning) and still matches the oracle; a skill with generated constraints has no other kernel and fails."""
+    from casclik_amd import jit
+    if jit._hipcc() is None:
+        pytest.skip("no compiler on this box: nothing to break")
     from oracle import clik_oracle
     monkeypatch.setenv("CLIK_JIT_DEFINES", "-fthis-flag-does-not-exist-%d" % os.getpid())
     t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
