@@ -61,6 +61,7 @@ size_t qp_variant_lds(int k, int ny);
 int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 bool qp_box_family_rt(const ShapeDesc& sd);
+int qp_plan_rows_rt(const ShapeDesc& sd);
 int team_waves_rt(long long B);                 // (clik_pinv.hip)
 hipError_t launch_ticket_feed(void* ticket, const unsigned* done, int n_ticks, int closed_loop, unsigned waves_per_tick,
                               unsigned long long timeout_ticks, hipStream_t stream);
@@ -528,7 +529,9 @@ static bool qp_static_eligible(const DevSkill& S)
     std::vector<char> img;
     size_t image_bytes = 0;
     if (!build_skill_image(S, img, &image_bytes, sizeof(clik::QpTail))) return false;
-    const int nr = qp_static_rows(S);
+    // (the kernels' own count: a joint-limit row and a speed-limit row on the same state are ONE active-set row -
+    // a skill with walls, joint limits and speed limits on every joint of a 7-DoF arm has 10 such rows, not 17)
+    const int nr = clik::qp_plan_rows_rt(S.shape);
     if (nr > 16) return false;
     const int nra = nr > 0 ? nr : 1, nsa = S.n_slack > 0 ? S.n_slack : 1;
     const size_t slots = (size_t)S.n + S.d.n_y + nra * (nra + 1) / 2 + 3 * nra + (size_t)nra * S.n + nsa;

@@ -415,6 +415,8 @@ int qp_pick_static(const ShapeDesc& sd)
 }
 const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
 bool qp_box_family_rt(const ShapeDesc& sd) { return CLIK_QP_BOX_OK(sd); }
+// rows the shape-specialised kernels hand to their active set: soft equalities folded, hard bounds on the same state merged
+int qp_plan_rows_rt(const ShapeDesc& sd) { return make_qp_plan(sd).nr; }
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,

@@ -595,3 +595,37 @@ def test_qp_general_rows_mixed_family_against_the_oracle_and_the_dual_iteration(
     assert np.array_equal(ostatus == 2, status == 2)
     both = (ostatus == 0) & (status == 0)
     assert both.sum() > 400 and _rel(odq[both], dq[both]).max() < 1e-7
+
+
+def test_qp_walls_joint_limits_and_speed_limits_on_every_joint_fit_the_static_kernels(iiwa_fk):
+    """A 7-DoF pose skill with three tool walls, joint limits AND speed limits on every joint has 3 + 7 + 7 = 17
+    constraint rows as casclik writes them (reactive_qp.py:208-236), but the position and the speed bound of one joint
+    are ONE box row of the active set (clik_qp_static.hpp::make_qp_plan): 10 rows, inside the static kernels' 16.  The
+    eligibility check counts the merged rows (clik_api.hip::qp_static_eligible) - the skill is served by the
+    mixed-family kernel and equals the oracle."""
+    from oracle import clik_oracle
+    fk = iiwa_fk
+    n = 7
+    t, q, y = cs.MX.sym("t"), cs.MX.sym("q", n), cs.MX.sym("y", 7)
+    T = fk["T_fk"](q)
+    lo, hi, vm = np.array(fk["lower"]), np.array(fk["upper"]), np.array(fk["velocity"])
+    cons = [cc.EqualityConstraint("pose", cs.vertcat(T[:3, 3] - y[:3], cs.orientation_error(T[:3, :3], y[3:7])),
+                                  gain=3.0, constraint_type="soft", priority=5)]
+    for a in range(3):
+        cons.append(cc.SetConstraint("wall%d" % a, T[a, 3], set_min=-0.55, set_max=0.75, gain=2.0, priority=1))
+    cons.append(cc.VelocitySetConstraint("speed", q, set_min=-vm, set_max=vm, priority=0))
+    cons.append(cc.SetConstraint("limits", q, set_min=lo, set_max=hi, gain=1.0, priority=0))
+    spec = cc.SkillSpecification("walls_limits_speed", t, q, input_var=y, constraints=cons)
+    ctrl = _controller(spec)
+    assert ctrl.kernel_name not in ("dynamic", "none"), ctrl.kernel_name
+    rng = np.random.default_rng(5)
+    Q = rng.uniform(0.85 * lo, 0.85 * hi, size=(512, n))
+    quat = rng.normal(size=(512, 4))
+    Y = np.concatenate([rng.uniform(-0.5, 0.7, size=(512, 3)), quat / np.linalg.norm(quat, axis=1, keepdims=True)], axis=1)
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+    sub = np.arange(0, len(Q), 4)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[sub], Y=Y[sub])
+    assert np.array_equal(status[sub], rstatus)
+    ok = rstatus == 0
+    assert ok.sum() > 60
+    assert _rel(dq[sub][ok], rdq[ok]).max() < QP_RTOL and _rel(slack[sub][ok], rslack[ok]).max() < QP_RTOL
