@@ -34,7 +34,7 @@ MAX_TASKS = 16
 MAX_M = 12              # > DYN_MAX_M rows only in the shape-specialised kernels
 DYN_MAX_M = 8
 MAX_ROWS = 96
-MAX_SETS = 6
+MAX_SETS = 8
 MAX_TSLOTS = 32
 MAX_YTERMS = 4
 MAX_QPVARS = 24

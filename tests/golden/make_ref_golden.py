@@ -152,6 +152,7 @@ PLAN = [   # (fixture name, robot, case, B, input distribution, times)
     ("ur5_qp_wall", "ur5", "qp_wall", 96, "mixed", [0.0]),
     ("iiwa_two_frames", "iiwa", "two_frames", 64, "interior", [0.0]),
     ("iiwa_qp_two_virtual", "iiwa", "qp_two_virtual", 48, "interior", [0.0]),
+    ("iiwa_sets_per_joint", "iiwa", "sets_per_joint", 160, "narrow", [0.0]),
 ]
 # offsets from a joint limit the "boundary" distribution plants (pseudo_inverse.py:222-252 thresholds e - bound
 # at 1e-12): exactly on the limit, either side of the 1e-12 margin, and up to 1e-6 away
@@ -165,6 +166,9 @@ def inputs(chain, T_fk, B, dist, seed):
     rng = np.random.default_rng(seed)
     if dist == "interior":
         Q = rng.uniform(0.9 * lo, 0.9 * hi, size=(B, len(lo)))
+    elif dist == "narrow":
+        # around sets drawn at 0.3 of the joint ranges (pin_skills.sets_per_joint): each joint outside with p = 1/6
+        Q = rng.uniform(0.36 * lo, 0.36 * hi, size=(B, len(lo)))
     else:
         r = hi - lo
         Q = rng.uniform(lo - 0.05 * r, hi + 0.05 * r, size=(B, len(lo)))

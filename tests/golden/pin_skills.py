@@ -104,6 +104,26 @@ def stack_sets1d(env):
     return _stack(env, False, {})
 
 
+def sets_per_joint(env):
+    """one 1-D SetConstraint per joint (ur5_moe2016_example2.ipynb cell 6 does it for the UR5's six) in front of a
+    position and a posture task: on the 7-DoF arm 2^7 = 128 modes (pseudo_inverse.py:107-130), scanned in the
+    reference's order.  The sets sit at 0.3 of the joint ranges so that the inputs reach many modes."""
+    cs, cc, s = env.cs, env.cc, _syms(env)
+    n = len(env.lower)
+    T = env.T_fk(s["q"])
+    p_des = np.asarray(env.consts["p_des"], float)
+    cns = [cc.EqualityConstraint(label="tool_position", expression=T[:3, 3] - p_des, gain=5.0,
+                                 constraint_type="soft", priority=10),
+           cc.EqualityConstraint(label="posture", expression=s["q"][n - 2:] - np.array([0.3, -0.2]), gain=1.0,
+                                 constraint_type="soft", priority=11)]
+    for j in range(n):
+        cns.append(cc.SetConstraint(label="limit_q%d" % j, expression=s["q"][j], set_min=float(0.3 * env.lower[j]),
+                                    set_max=float(0.3 * env.upper[j]), priority=j))
+    spec = cc.SkillSpecification(label="sets_per_joint", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"],
+                                 constraints=cns)
+    return dict(spec=spec, controller="pinv", options={}, ny=0)
+
+
 def stack_noff(env):
     """feedforward off on a time-dependent target"""
     return _stack(env, False, {"feedforward": False}, time_target=True)
@@ -311,7 +331,7 @@ def qp_two_virtual(env):
 
 
 CASES = {
-    "two_frames": two_frames, "qp_two_virtual": qp_two_virtual,
+    "two_frames": two_frames, "qp_two_virtual": qp_two_virtual, "sets_per_joint": sets_per_joint,
     "stack_boundary": stack_const, "qp_wall": qp_wall,
     "position": position, "pose": pose, "stack_const": stack_const, "stack_const_time": stack_const_time,
     "stack_sets1d": stack_sets1d, "stack_noff": stack_noff, "position_standard": position_standard, "conv_last": conv_last,

@@ -179,9 +179,12 @@ def test_lowering_rejects_what_the_device_cannot_do(iiwa_fk):
     nine = lower_skill(cc.SkillSpecification("s", t, q, constraints=[
         cc.EqualityConstraint("nine", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2]))]))
     assert nine.tasks[0]["m"] == 9
+    # one 1-D set per joint of a 7-DoF arm (128 modes) lowers; nine sets (512 modes) are beyond the device limit
     seven_sets = [cc.SetConstraint("s%d" % i, q[i], set_min=-1.0, set_max=1.0, priority=i) for i in range(7)]
+    assert lower_skill(cc.SkillSpecification("s", t, q, constraints=seven_sets)).n_sets == 7
+    nine_sets = seven_sets + [cc.SetConstraint("w%d" % i, T[i, 3], set_min=-1.0, set_max=1.0, priority=9) for i in range(2)]
     with pytest.raises(NotImplementedError, match="modes"):
-        lower_skill(cc.SkillSpecification("s", t, q, constraints=seven_sets))
+        lower_skill(cc.SkillSpecification("s", t, q, constraints=nine_sets))
 
 
 def test_controller_needs_the_hip_library_or_gpu():

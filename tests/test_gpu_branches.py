@@ -338,6 +338,26 @@ def test_all_joint_limits_as_sets_64_modes(ur5_fk, kernel, monkeypatch):
     assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
 
 
+def test_one_set_per_joint_of_a_seven_dof_arm_128_modes(iiwa_fk):
+    """The Moe-2016 pattern (one 1-D SetConstraint per joint limit, ur5_moe2016_example2.ipynb cell 6) on the 7-DoF
+    iiwa: 2^7 = 128 modes (pseudo_inverse.py:107-130 builds them all), beyond the 64 mode bodies of the instantiated
+    kernels - the built-in mode-scan kernel walks the table.  Modes and velocities equal the oracle's."""
+    fk = iiwa_fk
+    t = cs.MX.sym("t")
+    q = cs.MX.sym("q", 7)
+    p = fk["T_fk"](q)[:3, 3]
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    cons = [cc.EqualityConstraint("pos", p - np.array([0.35, 0.2, 0.6]), gain=5.0, priority=10),
+            cc.EqualityConstraint("posture", q[5:7] - np.array([0.3, -0.2]), gain=1.0, priority=11)]
+    for i in range(7):
+        cons.append(cc.SetConstraint("limit_q_%d" % i, q[i], set_min=0.3 * lo[i], set_max=0.3 * hi[i], priority=i))
+    spec = cc.SkillSpecification("all_limits_7", t, q, constraints=cons)
+    rng = np.random.default_rng(31)
+    Q = rng.uniform(0.36 * lo, 0.36 * hi, size=(192, 7))
+    ctrl = _check(spec, None, Q, min_modes=12)
+    assert ctrl.n_modes == 128 and ctrl.kernel_name == "dynamic"
+
+
 @pytest.mark.parametrize("force_dynamic", [False, True])
 def test_tall_first_equality_is_processed_twice(ur5_fk, monkeypatch, force_dynamic):
     """First EqualityConstraint with more rows than joints (8 x 6): pinv takes the Gram branch

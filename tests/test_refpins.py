@@ -26,7 +26,7 @@ def test_numpy_oracle_matches_the_reference_run(name):
         err = refpins.rel_err(dq, ref)
         assert (err < tol).all(), (name, err.max())
     # the reference sorted the constraints by priority itself; the product's front-end must agree
-    assert [c.label for c in built["spec"].constraints][0] in ("joint_limits", "limit_q1", "tool_position",
+    assert [c.label for c in built["spec"].constraints][0] in ("joint_limits", "limit_q0", "limit_q1", "tool_position",
                                                                   "tool_pose", "tool_z_speed")
 
 
