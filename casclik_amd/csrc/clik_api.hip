@@ -644,9 +644,9 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
         std::vector<char> img;
         if (!build_skill_image(*S, img)) eligible = false;      // rows not in task order / too many rows
     }
-    // the static plan handles the doubly processed first EqualityConstraint only when
-    // it owns a state-dependent factor (clik_pinv_static.hpp); "standard" keeps the wide-only rule
-    // (its tall branch has no damping to carry the closed form)
+    // the static plan evaluates the doubly processed first EqualityConstraint in closed form from its own
+    // factor or from the host-precomputed inverse of a constant Jacobian (clik_pinv_static.hpp); "standard"
+    // keeps the wide-only rule (its tall branch has no damping to carry the closed form)
     for (unsigned act = 0; eligible && act < (1u << S->n_sets); ++act) {
         int r = 0, set_idx = 0;
         for (int ti = 0; ti < h.n_tasks; ++ti) {
@@ -661,7 +661,7 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
             const bool contributes = cls == CLIK_CLS_EQ || cls == CLIK_CLS_VELEQ || conv;
             if (contributes && r == 0 && cls == CLIK_CLS_EQ) {
                 const bool wide = h.standard ? (h.m[ti] < h.n) : (h.n >= h.m[ti]);
-                if (h.const_j[ti] || (!wide && h.standard)) eligible = false;
+                if (!wide && h.standard) eligible = false;
             }
             r += h.m[ti];
         }

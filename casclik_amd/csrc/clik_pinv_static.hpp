@@ -119,8 +119,8 @@ constexpr ModePlan make_plan(const ShapeDesc& sd, unsigned act)
         // a quirk task consumes its own first push even if nothing follows
         p.push_times = (ti < last_consumer) ? times : 0;
         // (the doubly processed first EqualityConstraint evaluates both of its passes in closed form from
-        // its own factor - wide or tall - and needs no push of its own; constant-Jacobian first
-        // equalities are not served by static shapes, see step_s)
+        // its own factor - wide or tall, or the host-precomputed inverse of a constant Jacobian - and
+        // needs no push of its own, see step_s)
         (void)consumed;
         if (p.push_times > 0) {
             const int r_new = r + p.push_times * m;
@@ -1244,6 +1244,8 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
                     constexpr int i = decltype(ic)::value;
                     constexpr int col = SD.ucol[TI][i] - 1;
                     w[col] = Pm[col * CLIK_MAX_M + i] * des[i];
+                    // (doubly processed first equality, see the constant-Jacobian branch below: J w = w[col])
+                    if constexpr (P.quirk) w[col] = fma(-Pm[col * CLIK_MAX_M + i], w[col], 2.0 * w[col]);
                 });
             } else if constexpr (P.const_j) {
                 const double* Pm = S->cpinv[TI];
@@ -1253,6 +1255,27 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
 #pragma unroll
                     for (int i = 0; i < M; ++i) s = fma(Pm[j * CLIK_MAX_M + i], des[i], s);
                     w[j] = s;
+                }
+                if constexpr (P.quirk) {
+                    // Doubly processed first EqualityConstraint with a CONSTANT Jacobian (the path variable's
+                    // `300 - x` of cart_on_track_1D...ipynb cell 75, a posture task): pass 1 is w = P d with the
+                    // host-precomputed P = pinv(J); pass 2 (:382-396) projects the same term through the stack
+                    // [J]: (I - P J) w.  The sum: 2 w - P (J w).
+                    double jw[M];
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) s = fma(jac<SD, TI>(S, tc, i, j), w[j], s);
+                        jw[i] = s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < M; ++i) s = fma(Pm[j * CLIK_MAX_M + i], jw[i], s);
+                        w[j] = fma(2.0, w[j], -s);
+                    }
                 }
             } else if constexpr (P.wide_self) {
 #pragma unroll
@@ -1328,7 +1351,6 @@ __device__ __forceinline__ void step_s(CLIK_MODE_IN_RAW, ModeCtx<SD, ACT, ROLE>&
             if constexpr (P.quirk) {
                 // (w already holds the sum of both passes, see above; it was added as the first task)
                 static_assert(P.first, "the doubly processed EqualityConstraint is the first contribution");
-                static_assert(!P.const_j, "static shapes need a state-dependent first EqualityConstraint");
                 if constexpr (P.push_times > 0) push_s<SD, ACT, TI, ROLE>(S, tc, c, 0xffffffffu);
             } else {
                 if constexpr (!P.first) {

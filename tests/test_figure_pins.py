@@ -1,0 +1,63 @@
+"""The oracle against outputs the reference ITSELF stores: the closed-loop simulation figures of
+cart_on_track_1D_comparison_of_controllers.ipynb (real CasADi + qpOASES, run by the reference's author), digitised
+by tests/golden/make_figure_pins.py with calibration taken from lines the notebook drew at known values.  Six runs:
+ReactiveQPController and PseudoInverseController, each moving to a point, tracking a trajectory that leaves the rail
+(SetConstraint holds the cart at the rail end; reactive_qp.py:221-225, pseudo_inverse.py:132-190) and following a
+path with a virtual variable (reactive_qp.py:191-246, pseudo_inverse.py:79-88).  Resolution of the pin: one pixel =
+0.006-0.009 m/s of speed, 0.016-0.024 m of position, 0.04-0.08 s."""
+import numpy as np
+import pytest
+
+import cart_figures as cf
+from oracle import clik_oracle
+
+PIXELS = 1.0        # a simulated curve has to pass within one pixel row of every digitised sample (measured: <= 0.52)
+
+
+def oracle_solver(case, spec_mutation=None, options=None):
+    kind, spec, dt, p0, virt = cf.build(case)
+    if spec_mutation:
+        spec_mutation(spec)
+
+    def solve(t, p, x):
+        Q = np.array([[p]])
+        X = None if x is None else np.array([[x]])
+        if kind == "pinv":
+            dz, _ = clik_oracle.pinv_solve_batch(spec, options, float(t), Q, X=X)
+            return dz[0, 0], (dz[0, 1] if virt else None)
+        dq, dxv, _, status = clik_oracle.qp_solve_batch(spec, float(t), Q, X=X)
+        assert status[0] == 0
+        return dq[0, 0], (dxv[0, 0] if virt else None)
+    return solve
+
+
+def curves_of(case):
+    return ["dp"] if case.endswith("point") else ["p", "dp"]
+
+
+@pytest.mark.parametrize("case", cf.CASES)
+def test_oracle_reproduces_the_figures_the_reference_stores(case):
+    t_sim, p_sim, dp_sim = cf.simulate(case, oracle_solver(case))
+    for curve in curves_of(case):
+        worst, n = cf.deviation_in_pixels(case, curve, t_sim, p_sim if curve == "p" else dp_sim)
+        assert n > 60
+        assert worst < PIXELS, (case, curve, worst)
+
+
+def test_the_figures_tell_a_wrong_controller_from_a_right_one():
+    """what the pin resolves: a convergence gain off by 20 %, a missing feed-forward term, a set-constraint gain off
+    by a factor two each miss the stored curves by several pixels"""
+    def gain_of(label, value):
+        def mutate(spec):
+            for c in spec.constraints:
+                if c.label == label:
+                    c.gain = value
+        return mutate
+    t_sim, _, dp_sim = cf.simulate("qp_point", oracle_solver("qp_point", gain_of("min_dist_cnstr", 1.2)))
+    assert cf.deviation_in_pixels("qp_point", "dp", t_sim, dp_sim)[0] > 3.0
+    t_sim, _, dp_sim = cf.simulate("pinv_point", oracle_solver("pinv_point", gain_of("min_dist_cnstr", 1.2)))
+    assert cf.deviation_in_pixels("pinv_point", "dp", t_sim, dp_sim)[0] > 3.0
+    t_sim, _, dp_sim = cf.simulate("qp_traj", oracle_solver("qp_traj", gain_of("cart_limit_cnstr", 2.0)))
+    assert cf.deviation_in_pixels("qp_traj", "dp", t_sim, dp_sim)[0] > 3.0
+    t_sim, _, dp_sim = cf.simulate("pinv_traj", oracle_solver("pinv_traj", options={"feedforward": False}))
+    assert cf.deviation_in_pixels("pinv_traj", "dp", t_sim, dp_sim)[0] > 3.0
