@@ -22,7 +22,13 @@ golden outputs for ``solve()``.  What pins this
 restatement instead: the UR5 forward-kinematics KAT stored in the notebooks
 (||p_tool0|| = 1.0192 at home), the constraint-order printouts, algebraic
 invariants of the damped pseudo-inverse, KKT optimality of every QP answer,
-and agreement of the AD Jacobians below with finite differences.
+and agreement of the AD Jacobians below with finite differences.  Since round 2
+also: fixtures produced by the reference's OWN Python over a stand-in casadi
+(tests/golden/make_ref_golden.py -> ref_pins.npz; tests/test_refpins.py), and
+since round 3 the closed-loop FIGURES the reference's notebooks store (its real
+CasADi + qpOASES runs), digitised with calibration from the notebooks' own
+reference lines (tests/golden/make_figure_pins.py -> notebook_figures.npz;
+tests/test_figure_pins.py: every curve reproduced within one pixel).
 
 CasADi's algorithmic differentiation (``cs.jacobian``, constraints.py:67-73) is
 restated as forward-mode dual numbers over the same expression trees the

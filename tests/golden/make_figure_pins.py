@@ -31,24 +31,46 @@ import numpy as np
 from PIL import Image
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NOTEBOOK = "/root/reference/examples/notebooks/cart_on_track_1D_comparison_of_controllers.ipynb"
-RED, BLUE = (255.0, 0.0, 0.0), (31.0, 119.0, 180.0)        # `c="r"`; the first colour of matplotlib's default cycle
-MAX_SPEED, MIN_P, MAX_P = 0.275, 0.0, 1.0                   # cell 6 of the notebook
+NOTEBOOKS = "/root/reference/examples/notebooks/"
+CART = "cart_on_track_1D_comparison_of_controllers.ipynb"
+PENDULUM = "double_pendulum_2D_comparison_of_controllers.ipynb"
+UR5 = "ur5_transformation_matrix_comparison_of_controllers.ipynb"
+BLACK = (0.0, 0.0, 0.0)
+RED, BLUE, GREEN = (255.0, 0.0, 0.0), (0.0, 0.0, 255.0), (0.0, 128.0, 0.0)              # "r", "b", "g"
+C0, C1, C2 = (31.0, 119.0, 180.0), (255.0, 127.0, 14.0), (44.0, 160.0, 44.0)         # matplotlib's default cycle
+MAX_SPEED, MIN_P, MAX_P = 0.275, 0.0, 1.0                   # cart notebook, cell 6
+UR5_HOME_Z = 1.001059                                       # T_fk(UR5_home)[2, 3] of urdf/ur5.urdf, the START of the
+#                                                             z curve of the UR5 figure (an input of that simulation;
+#                                                             with y0 = 0.19145, x0 = 0 it has the norm 1.0192 the notebook prints)
 
-# figure -> (cell, dt, [(axes index, low line value, high line value, curve name, colour)])
+# figure -> (notebook, cell, dt, ticks, [(axes index, calibration, [(curve name, colour)])])
+# calibrations:  ("lines", colour, low value, colour, high value)    two horizontal dashed lines drawn at known values
+#                ("extremes", colour, low, high)                     a dashed curve with known extreme values
+#                ("line+start", [colours], value, curve, value)      one dashed line and the known first value of a curve
+SPEED = ("lines", BLACK, -MAX_SPEED, BLACK, MAX_SPEED)
+RAIL = ("lines", BLACK, MIN_P, BLACK, MAX_P)
 FIGURES = {
-    "qp_point":   (11, 0.01, [(1, -MAX_SPEED, MAX_SPEED, "dp", RED)]),
-    "pinv_point": (22, 0.01, [(1, -MAX_SPEED, MAX_SPEED, "dp", RED)]),
-    "qp_traj":    (36, 0.02, [(0, MIN_P, MAX_P, "p", BLUE), (1, -MAX_SPEED, MAX_SPEED, "dp", RED)]),
-    "pinv_traj":  (54, 0.02, [(0, MIN_P, MAX_P, "p", BLUE), (1, -MAX_SPEED, MAX_SPEED, "dp", RED)]),
-    "qp_path":    (61, 0.02, [(0, MIN_P, MAX_P, "p", BLUE), (1, -MAX_SPEED, MAX_SPEED, "dp", RED)]),
-    "pinv_path":  (78, 0.02, [(0, MIN_P, MAX_P, "p", BLUE), (1, -MAX_SPEED, MAX_SPEED, "dp", RED)]),
+    "qp_point":   (CART, 11, 0.01, 1200, [(1, SPEED, [("dp", RED)])]),
+    "pinv_point": (CART, 22, 0.01, 1200, [(1, SPEED, [("dp", RED)])]),
+    "qp_traj":    (CART, 36, 0.02, 1200, [(0, RAIL, [("p", C0)]), (1, SPEED, [("dp", RED)])]),
+    "pinv_traj":  (CART, 54, 0.02, 1200, [(0, RAIL, [("p", C0)]), (1, SPEED, [("dp", RED)])]),
+    "qp_path":    (CART, 61, 0.02, 1200, [(0, RAIL, [("p", C0)]), (1, SPEED, [("dp", RED)])]),
+    "pinv_path":  (CART, 78, 0.02, 1200, [(0, RAIL, [("p", C0)]), (1, SPEED, [("dp", RED)])]),
+    # double pendulum, ReactiveQPController with the table SetConstraints (general inequality rows): cells 16-19 (to
+    # the point (0.75, 0.5); joint speeds with the +-0.5 rad/s lines, tool position with its dashed targets) and
+    # cells 36-38 (tracking the circle 0.25 (cos, sin)(0.5 t) + (1, 1): its dashed curves reach 0.75 and 1.25)
+    "pend_point_dq": (PENDULUM, 18, 0.01, 800, [(1, ("lines", BLACK, -0.5, BLACK, 0.5), [("dq0", C0), ("dq1", C1)])]),
+    "pend_point_p":  (PENDULUM, 19, 0.01, 800, [(0, ("lines", GREEN, 0.5, BLUE, 0.75), [("px", BLUE), ("py", GREEN)])]),
+    "pend_track_p":  (PENDULUM, 38, 0.01, 2000, [(0, ("extremes", BLACK, 0.75, 1.25), [("px", BLUE), ("py", GREEN)])]),
+    # UR5, PseudoInverseController, norm_2 position error behind six 1-D joint-limit sets, speeds saturated at pi / 5
+    # (cells 27-32): x, y, z of the tool, the dashed targets all at 0.5
+    "ur5_pinv_p":    (UR5, 32, 0.01, 1000, [(0, ("line+start", [C0, C1, C2], 0.5, "z", UR5_HOME_Z),
+                                             [("x", C0), ("y", C1), ("z", C2)])]),
 }
-N_TICKS = 1200
 
 
-def stored_png(cell):
-    nb = json.load(open(NOTEBOOK))
+def stored_png(notebook, cell):
+    nb = json.load(open(NOTEBOOKS + notebook))
     for out in nb["cells"][cell]["outputs"]:
         if "data" in out and "image/png" in out["data"]:
             raw = base64.b64decode(out["data"]["image/png"])
@@ -67,17 +89,30 @@ def axes_boxes(rgb):
     left, right = int(cols.min()), int(cols.max())
     width = right - left + 1
     rows = [y for y in range(dark.shape[0]) if dark[y, left:right + 1].sum() > 0.97 * width]
-    assert len(rows) % 2 == 0 and len(rows) >= 4, rows
+    assert len(rows) % 2 == 0 and len(rows) >= 2, rows
     return [(rows[2 * k], rows[2 * k + 1], left, right) for k in range(len(rows) // 2)]
 
 
-def dashed_rows(rgb, box):
-    """sub-pixel rows (pixel-centre coordinates) of the two black dashed lines of an axes"""
+def colour_weight(rgb, colour):
+    """closeness of every pixel to a drawing colour, 1 on the colour ... 0 (for black: darkness, cut below 0.45 so that
+    the curves' own colours and anti-aliased rims do not count)"""
+    if tuple(colour) == BLACK:
+        w = np.clip(1.0 - rgb.max(axis=2) / 255.0, 0.0, 1.0)
+        w[w < 0.6] = 0.0               # ("g" is (0, 128, 0): half as dark as black)
+        return w
+    colour = np.array(colour)
+    dist = np.sqrt(((rgb - colour) ** 2).sum(axis=2)) / np.sqrt(((255.0 - colour) ** 2).sum())
+    return np.clip(1.0 - dist / 0.6, 0.0, 1.0)
+
+
+def line_rows(rgb, box, colour):
+    """sub-pixel rows (pixel-centre coordinates, top first) of the horizontal dashed lines drawn in `colour`: the rows
+    where that colour covers a quarter of the axes' width or more"""
     top, bot, left, right = box
-    inner = rgb[top + 2:bot - 1, left + 2:right - 1]
-    darkness = np.clip(1.0 - inner.max(axis=2) / 255.0, 0.0, 1.0)
-    darkness[darkness < 0.45] = 0.0                      # (colours of the curves and their anti-aliased rims are brighter)
-    prof = darkness.sum(axis=1)
+    w = colour_weight(rgb, colour)[top + 2:bot - 1, left + 2:right - 1].copy()
+    l0, l1, c0, c1 = legend_box(rgb, box)
+    w[max(0, l0 - top - 2):max(0, l1 - top - 1), max(0, c0 - left - 2):max(0, c1 - left - 1)] = 0.0
+    prof = w.sum(axis=1)
     strong = prof > 0.25 * (right - left)
     groups, y = [], 0
     while y < len(prof):
@@ -86,13 +121,39 @@ def dashed_rows(rgb, box):
             while y1 + 1 < len(prof) and strong[y1 + 1]:
                 y1 += 1
             lo, hi = max(0, y - 1), min(len(prof) - 1, y1 + 1)
-            w = prof[lo:hi + 1]
-            groups.append(float((w * (np.arange(lo, hi + 1) + 0.5)).sum() / w.sum()) + top + 2)
+            ww = prof[lo:hi + 1]
+            groups.append(float((ww * (np.arange(lo, hi + 1) + 0.5)).sum() / ww.sum()) + top + 2)
             y = y1 + 1
         else:
             y += 1
-    assert len(groups) == 2, ("expected two dashed lines", groups)
-    return groups          # [row of the HIGH value, row of the LOW value] (rows grow downwards)
+    return groups
+
+
+def extreme_rows(rgb, box, colour):
+    """centre rows of the highest and the lowest point of a dashed curve drawn in `colour`: per pixel column the
+    centre of the topmost / bottommost run of that colour, then the extreme over the columns"""
+    top, bot, left, right = box
+    w = colour_weight(rgb, colour).copy()
+    l0, l1, c0, c1 = legend_box(rgb, box)
+    w[l0:l1 + 1, c0:c1 + 1] = 0.0
+    rows = np.arange(rgb.shape[0]) + 0.5
+    hi_row, lo_row = np.inf, -np.inf
+    for c in range(left + 3, right - 2):
+        col = w[top + 2:bot - 1, c]
+        ys = np.nonzero(col > 0.0)[0]
+        if len(ys) == 0:
+            continue
+        for first, sign in ((ys[0], 1), (ys[-1], -1)):
+            run = [first]
+            while 0 <= run[-1] + sign < len(col) and col[run[-1] + sign] > 0.0 and len(run) < 4:
+                run.append(run[-1] + sign)
+            run = np.array(run)
+            centre = float((col[run] * (rows[run + top + 2])).sum() / col[run].sum())
+            if sign > 0:
+                hi_row = min(hi_row, centre)
+            else:
+                lo_row = max(lo_row, centre)
+    return hi_row, lo_row
 
 
 def legend_box(rgb, box):
@@ -115,20 +176,29 @@ def legend_box(rgb, box):
             min(f[1] for f in found) - 4, max(f[2] for f in found) + 4)
 
 
-def trace(rgb, box, colour):
+def trace(rgb, box, colour, avoid_rows=()):
     """per pixel column the centre row of the curve drawn in `colour` (followed from the left by continuity: the
     legend holds a short sample of the same colour elsewhere in the axes)"""
     top, bot, left, right = box
     colour = np.array(colour)
     dist = np.sqrt(((rgb - colour) ** 2).sum(axis=2)) / np.sqrt(((255.0 - colour) ** 2).sum())
-    mask = dist < 0.45
+    # distance of every pixel from the segment white ... colour (the anti-aliased rim of the curve lies ON it; the
+    # greys of an anti-aliased black dash do not)
+    d, u = 255.0 - rgb, 255.0 - colour
+    a = np.clip((d * u).sum(axis=2) / (u * u).sum(), 0.0, 1.0)
+    off_mix = np.sqrt(((d - a[..., None] * u) ** 2).sum(axis=2))
+    mask = (dist < 0.45) & (off_mix < 60.0)
     mask[:top + 2] = False
     mask[bot - 1:] = False
     l0, l1, c0, c1 = legend_box(rgb, box)
     mask[l0:l1 + 1, c0:c1 + 1] = False        # (the legend's sample of the colour; a curve passing behind the frame
     #                                            loses those columns)
+    drawn = np.nonzero(mask[:, left + 2:right - 1].any(axis=0))[0] + left + 2
+    extent = (int(drawn[0]), int(drawn[-1]))   # columns where the colour is drawn at all: the plotted time range
+    for r in avoid_rows:                       # horizontal dashed lines (possibly of the curve's own colour): the
+        mask[int(np.floor(r - 2.0)):int(np.ceil(r + 2.0)) + 1] = False      # curve is not followed across them
     cols, centre, half = [], [], []
-    prev = None
+    prev, first_col = None, None
     for c in range(left + 2, right - 1):
         ys = np.nonzero(mask[:, c])[0]
         if len(ys) == 0:
@@ -141,8 +211,13 @@ def trace(rgb, box, colour):
                 start = b
         runs.append((start, ys[-1]))
         if prev is None:
-            # the curve starts at the left end of the plotted range; the legend is on the right
+            # the curve starts at the left end of the plotted range (a vertical stroke there - the notebooks leave
+            # sample 0 of some arrays at zero - is not a value: wait for the first column with a single short run)
             run = max(runs, key=lambda r: r[1] - r[0])
+            if run[1] - run[0] > 7 or len(runs) > 1:
+                if first_col is None:
+                    first_col = c
+                continue
         else:
             run = min(runs, key=lambda r: abs(0.5 * (r[0] + r[1] + 1) - prev))
             if abs(0.5 * (run[0] + run[1] + 1) - prev) > 12.0 + (run[1] - run[0]):
@@ -161,10 +236,6 @@ def trace(rgb, box, colour):
     weight[bot - 1:] = 0.0
     weight[l0:l1 + 1, c0:c1 + 1] = 0.0
     rows = np.arange(rgb.shape[0]) + 0.5
-    # distance of every pixel from the segment white ... colour (the anti-aliased rim of the curve lies ON it)
-    d, u = 255.0 - rgb, 255.0 - colour
-    a = np.clip((d * u).sum(axis=2) / (u * u).sum(), 0.0, 1.0)
-    off_mix = np.sqrt(((d - a[..., None] * u) ** 2).sum(axis=2))
     keep, refined = [], []
     for k, c in enumerate(cols):
         lo, hi = max(0, k - 4), min(len(cols), k + 5)
@@ -185,38 +256,64 @@ def trace(rgb, box, colour):
         keep.append(k)
         refined.append(float((w * rows).sum() / w.sum()))
     keep = np.array(keep)
-    return cols[keep], np.array(refined), half[keep], (cols[0], cols[-1])
+    return cols[keep], np.array(refined), half[keep], extent
 
 
 def main():
     out = {}
-    for name, (cell, dt, curves) in FIGURES.items():
-        rgb = stored_png(cell)
+    for name, (notebook, cell, dt, n_ticks, axes) in FIGURES.items():
+        rgb = stored_png(notebook, cell)
         boxes = axes_boxes(rgb)
-        t_max = dt * (N_TICKS - 1)
-        for ax, v_lo, v_hi, curve, colour in curves:
+        t_max = dt * (n_ticks - 1)
+        for ax, calib, curves in axes:
             box = boxes[ax]
             top, bot, left, right = box
-            row_hi, row_lo = dashed_rows(rgb, box)
-            per_row = (v_hi - v_lo) / (row_lo - row_hi)                  # value per pixel row
             # x: matplotlib's default limits are the data range widened by 5 % on either side; the spines (one pixel
             # wide) are centred on the limits
             x_lo, x_hi = left + 0.5, right + 0.5
             per_col = 1.1 * t_max / (x_hi - x_lo)
-            cols, centre, half, extent = trace(rgb, box, colour)
-            t = -0.05 * t_max + (cols + 0.5 - x_lo) * per_col
-            v = v_hi - (centre - row_hi) * per_row
-            # cross-check of the x calibration against a reference-drawn extent: the curve spans [0, t_max]
-            t_first, t_last = (-0.05 * t_max + (np.array(extent) + 0.5 - x_lo) * per_col)
-            assert abs(t_first) < 3.0 * per_col and abs(t_last - t_max) < 3.0 * per_col, (name, curve, t_first, t_last, t_max)
-            keep = (t >= 0.0) & (t <= t_max)
-            key = "%s_%s" % (name, curve)
-            out[key + "_t"], out[key + "_v"] = t[keep], v[keep]
-            out[key + "_half_rows"] = half[keep]
-            out[key + "_pixel"] = np.array([per_col, per_row])
-            print("%-11s %-2s  %3d samples  t in [%.3f, %.3f] of [0, %.2f]  pixel = %.4f s x %.5f  dashed rows %.2f / %.2f"
-                  "  range [%.4f, %.4f]" % (name, curve, keep.sum(), t_first, t_last, t_max, per_col, per_row, row_hi, row_lo,
-                                           v[keep].min(), v[keep].max()))
+            # y: two rows with known values
+            avoid = []
+            if calib[0] == "lines":
+                _, colour_lo, v_lo, colour_hi, v_hi = calib
+                if colour_lo == colour_hi:
+                    rows_found = line_rows(rgb, box, colour_lo)
+                    assert len(rows_found) == 2, (name, "expected two dashed lines", rows_found)
+                    row_hi, row_lo = rows_found
+                else:
+                    (row_hi,), (row_lo,) = line_rows(rgb, box, colour_hi), line_rows(rgb, box, colour_lo)
+                avoid = [row_hi, row_lo] if colour_lo != BLACK else []
+            elif calib[0] == "extremes":
+                _, colour, v_lo, v_hi = calib
+                row_hi, row_lo = extreme_rows(rgb, box, colour)
+            else:
+                _, colours, v_lo, start_curve, v_hi = calib
+                found = sorted(set(round(r, 1) for col in colours for r in line_rows(rgb, box, col)))
+                assert found and max(found) - min(found) < 1.0, (name, "the dashed targets should share a row", found)
+                row_lo = float(np.mean(found))
+                avoid = [row_lo]
+            traced = {curve: trace(rgb, box, colour, avoid) for curve, colour in curves}
+            if calib[0] == "line+start":
+                row_hi = float(np.mean(traced[start_curve][1][:2]))     # the curve's first two columns
+            per_row = (v_hi - v_lo) / (row_lo - row_hi)                  # value per pixel row
+            # cross-check of the x calibration against a reference-drawn extent: the curves span [0, t_max] (one that
+            # ends under another curve drawn over it is covered by that one)
+            first_col = min(traced[curve][3][0] for curve, _ in curves)
+            last_col = max(traced[curve][3][1] for curve, _ in curves)
+            t_first, t_last = (-0.05 * t_max + (np.array([first_col, last_col]) + 0.5 - x_lo) * per_col)
+            assert abs(t_first) < 3.0 * per_col and abs(t_last - t_max) < 3.0 * per_col, (name, t_first, t_last)
+            for curve, _ in curves:
+                cols, centre, half, extent = traced[curve]
+                t = -0.05 * t_max + (cols + 0.5 - x_lo) * per_col
+                v = v_hi - (centre - row_hi) * per_row
+                keep = (t >= 0.0) & (t <= t_max)
+                key = "%s_%s" % (name, curve)
+                out[key + "_t"], out[key + "_v"] = t[keep], v[keep]
+                out[key + "_half_rows"] = half[keep]
+                out[key + "_pixel"] = np.array([per_col, per_row])
+                print("%-13s %-3s %3d samples  t in [%.3f, %.3f] of [0, %.2f]  pixel = %.4f s x %.5f  rows %.2f / %.2f"
+                      "  range [%.4f, %.4f]" % (name, curve, keep.sum(), t_first, t_last, t_max, per_col, per_row, row_hi,
+                                               row_lo, v[keep].min(), v[keep].max()))
         out[name + "_dt"] = np.array(dt)
     path = os.path.join(HERE, "notebook_figures.npz")
     np.savez_compressed(path, **out)

@@ -1,6 +1,9 @@
-"""The six simulations of cart_on_track_1D_comparison_of_controllers.ipynb whose figures the notebook stores (cells 6-11,
-18-22, 31-36, 50-54, 56-61, 75-78), rebuilt with the product's front-end, and the comparison of a simulated curve with
-the samples digitised from those figures (tests/golden/make_figure_pins.py -> notebook_figures.npz)."""
+"""The closed-loop simulations whose FIGURES the reference's notebooks store, rebuilt with the product's front-end, and
+the comparison of a simulated curve with the samples digitised from those figures (tests/golden/make_figure_pins.py
+-> notebook_figures.npz):
+  cart_on_track_1D_comparison_of_controllers.ipynb   cells 6-11, 18-22, 31-36, 50-54, 56-61, 75-78  (QP and pinv)
+  double_pendulum_2D_comparison_of_controllers.ipynb  cells 7-19 (QP to a point above the table), 31-38 (QP on a circle)
+  ur5_transformation_matrix_comparison_of_controllers.ipynb  cells 2-9, 27-32 (pinv, six 1-D limit sets, UR5)"""
 import os
 
 import numpy as np
@@ -89,3 +92,54 @@ def deviation_in_pixels(case, curve, t_sim, values):
         miss = max(lo - vk, vk - hi, 0.0) / px_v
         worst = max(worst, miss)
     return worst, len(ft)
+
+
+# ---- double pendulum (QP with the table SetConstraints: general inequality rows) ---------------------------------
+PENDULUM_CASES = ["pend_point", "pend_track"]
+
+
+def simulate_pendulum(case, solve):
+    """cells 16 / 36: `solve(t, q)` -> dq [2].  Returns t_sim, q_sim, dq_sim, p_sim (sample 0 of p_sim stays zero, as
+    in the notebook: the figures show that stroke)."""
+    n = 800 if case == "pend_point" else 2000
+    dt = 0.01
+    t_sim = np.array([dt * i for i in range(n)])
+    q_sim, dq_sim, p_sim = np.zeros((n, 2)), np.zeros((n, 2)), np.zeros((n, 2))
+    q_sim[0] = [np.pi / 2 - 1e-5, 0.0]
+    for i in range(n - 1):
+        dq_sim[i] = solve(t_sim[i], q_sim[i])
+        q_sim[i + 1] = q_sim[i] + dq_sim[i] * dt
+        a, b = q_sim[i + 1]
+        p_sim[i + 1] = [np.cos(a) + 0.75 * np.cos(a + b), np.sin(a) + 0.75 * np.sin(a + b)]
+    return t_sim, q_sim, dq_sim, p_sim
+
+
+# ---- UR5 move-to-point, PseudoInverseController --------------------------------------------------------------------
+UR5_HOME = np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0])
+
+
+def ur5_pinv_point_skill(fk):
+    """cells 8, 27: the distance to (0.5, 0.5, 0.5) as ONE norm_2 row, least priority, behind a 1-D SetConstraint per
+    joint limit"""
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    p_fk = fk["T_fk"](q)[:3, 3]
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    cons = [cc.EqualityConstraint(label="Minimize_point_error", expression=cs.norm_2(np.array([0.5, 0.5, 0.5]) - p_fk),
+                                  gain=50.0, constraint_type="soft", priority=6)]
+    cons += [cc.SetConstraint(label="limit_q_%d" % i, expression=q[i], set_min=lo[i], set_max=hi[i], priority=i)
+             for i in range(6)]
+    return cc.SkillSpecification(label="point_skill_pinv", time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons)
+
+
+def simulate_ur5(fk, solve):
+    """cell 29: 1000 ticks of 0.01 s from UR5_home, joint speeds saturated at pi / 5.  Returns t_sim, p_sim."""
+    n, dt, max_speed = 1000, 0.01, np.pi / 5
+    t_sim = np.array([dt * i for i in range(n)])
+    q_sim, p_sim = np.zeros((n, 6)), np.zeros((n, 3))
+    q_sim[0] = UR5_HOME
+    p_sim[0] = fk["chain"].fk_numeric(UR5_HOME)[:3, 3]
+    for i in range(n - 1):
+        dq = np.clip(solve(t_sim[i], q_sim[i]), -max_speed, max_speed)
+        q_sim[i + 1] = q_sim[i] + dq * dt
+        p_sim[i + 1] = fk["chain"].fk_numeric(q_sim[i + 1])[:3, 3]
+    return t_sim, p_sim

@@ -1,14 +1,19 @@
-"""The oracle against outputs the reference ITSELF stores: the closed-loop simulation figures of
-cart_on_track_1D_comparison_of_controllers.ipynb (real CasADi + qpOASES, run by the reference's author), digitised
-by tests/golden/make_figure_pins.py with calibration taken from lines the notebook drew at known values.  Six runs:
-ReactiveQPController and PseudoInverseController, each moving to a point, tracking a trajectory that leaves the rail
-(SetConstraint holds the cart at the rail end; reactive_qp.py:221-225, pseudo_inverse.py:132-190) and following a
-path with a virtual variable (reactive_qp.py:191-246, pseudo_inverse.py:79-88).  Resolution of the pin: one pixel =
-0.006-0.009 m/s of speed, 0.016-0.024 m of position, 0.04-0.08 s."""
+"""The oracle against outputs the reference ITSELF stores: the closed-loop simulation figures of its notebooks (real
+CasADi + qpOASES, run by the reference's author), digitised by tests/golden/make_figure_pins.py with calibration
+taken from lines the notebooks drew at known values.
+  * cart_on_track_1D_comparison_of_controllers.ipynb, six runs: ReactiveQPController and PseudoInverseController,
+    each moving to a point, tracking a trajectory that leaves the rail (SetConstraint holds the cart at the rail end;
+    reactive_qp.py:221-225, pseudo_inverse.py:132-190) and following a path with a virtual variable
+    (reactive_qp.py:191-246, pseudo_inverse.py:79-88);
+  * double_pendulum_2D_comparison_of_controllers.ipynb, two runs of the ReactiveQPController with SetConstraints on
+    task-space expressions (the table: general inequality rows) and saturating joint-speed limits;
+  * ur5_transformation_matrix_comparison_of_controllers.ipynb: the PseudoInverseController moving the UR5's tool to a
+    point (forward kinematics from the URDF, a norm_2 error row, six 1-D joint-limit sets, pseudo_inverse.py:259-451).
+Resolution of the pins: one pixel = 0.006-0.011 (rad/s, m/s) of speed, 0.005-0.024 m of position, 0.03-0.08 s."""
 import numpy as np
 import pytest
 
-import cart_figures as cf
+import notebook_figures as cf
 from oracle import clik_oracle
 
 PIXELS = 1.0        # a simulated curve has to pass within one pixel row of every digitised sample (measured: <= 0.52)
@@ -61,3 +66,54 @@ def test_the_figures_tell_a_wrong_controller_from_a_right_one():
     assert cf.deviation_in_pixels("qp_traj", "dp", t_sim, dp_sim)[0] > 3.0
     t_sim, _, dp_sim = cf.simulate("pinv_traj", oracle_solver("pinv_traj", options={"feedforward": False}))
     assert cf.deviation_in_pixels("pinv_traj", "dp", t_sim, dp_sim)[0] > 3.0
+
+
+def pendulum_oracle_solver(case):
+    from extern_skills import double_pendulum_skill
+    spec = double_pendulum_skill(track=(case == "pend_track"))
+
+    def solve(t, q):
+        dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])
+        assert status[0] == 0
+        return dq[0]
+    return solve
+
+
+def pendulum_deviations(case, t_sim, dq_sim, p_sim):
+    if case == "pend_point":
+        curves = [("pend_point_dq", "dq0", dq_sim[:, 0]), ("pend_point_dq", "dq1", dq_sim[:, 1]),
+                  ("pend_point_p", "px", p_sim[:, 0]), ("pend_point_p", "py", p_sim[:, 1])]
+    else:
+        curves = [("pend_track_p", "px", p_sim[:, 0]), ("pend_track_p", "py", p_sim[:, 1])]
+    return [(fig, curve) + cf.deviation_in_pixels(fig, curve, t_sim, values) for fig, curve, values in curves]
+
+
+@pytest.mark.parametrize("case", cf.PENDULUM_CASES)
+def test_oracle_reproduces_the_double_pendulum_figures(case):
+    t_sim, _, dq_sim, p_sim = cf.simulate_pendulum(case, pendulum_oracle_solver(case))
+    for fig, curve, worst, n in pendulum_deviations(case, t_sim, dq_sim, p_sim):
+        assert n > 60 and worst < PIXELS, (fig, curve, worst, n)
+
+
+def test_oracle_reproduces_the_ur5_figure():
+    from casclik_amd import skills
+    fk = skills.ur5()
+    spec = cf.ur5_pinv_point_skill(fk)
+    modes = set()
+
+    def solve(t, q):
+        dz, mode = clik_oracle.pinv_solve_batch(spec, None, float(t), q[None, :])
+        modes.add(int(mode[0]))
+        return dz[0]
+    t_sim, p_sim = cf.simulate_ur5(fk, solve)
+    for k, curve in enumerate("xyz"):
+        worst, n = cf.deviation_in_pixels("ur5_pinv_p", curve, t_sim, p_sim[:, k])
+        assert n >= 15 and worst < PIXELS, (curve, worst, n)
+    assert modes == {0}         # (the limits are +-2 pi: never reached on this run)
+    # what this figure resolves: the run is dominated by the saturated joint speeds (gain 50: the direction of the
+    # pseudo-inverse step decides the curves); with a gain of 5 the approach misses the stored curves by pixels
+    for c in spec.constraints:
+        if c.label == "Minimize_point_error":
+            c.gain = 5.0
+    t_sim, p_sim = cf.simulate_ur5(fk, solve)
+    assert max(cf.deviation_in_pixels("ur5_pinv_p", c, t_sim, p_sim[:, k])[0] for k, c in enumerate("xyz")) > 2.0

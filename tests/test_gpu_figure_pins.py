@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import casclik_amd as cc
-import cart_figures as cf
+import notebook_figures as cf
 from test_figure_pins import PIXELS, curves_of, oracle_solver
 
 pytestmark = pytest.mark.gpu
@@ -38,3 +38,33 @@ def test_hip_controllers_reproduce_the_figures_the_reference_stores(case):
     _, p_ref, dp_ref = cf.simulate(case, oracle_solver(case))
     assert np.abs(p_sim - p_ref).max() < 1e-8 and np.abs(dp_sim - dp_ref).max() < 1e-7, (
         case, np.abs(p_sim - p_ref).max(), np.abs(dp_sim - dp_ref).max())
+
+
+@pytest.mark.parametrize("case", cf.PENDULUM_CASES)
+def test_hip_qp_reproduces_the_double_pendulum_figures(case):
+    """double_pendulum_2D_comparison_of_controllers.ipynb cells 14-19 / 35-38: the ReactiveQPController with the table
+    SetConstraints (general inequality rows: the mixed-family kernel) and saturating joint-speed limits"""
+    from extern_skills import double_pendulum_skill
+    from test_figure_pins import pendulum_deviations, pendulum_oracle_solver
+    ctrl = cc.ReactiveQPController(skill_spec=double_pendulum_skill(track=(case == "pend_track")),
+                                   robot_var_weights=[1.0, 1.0])
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    t_sim, q_sim, dq_sim, p_sim = cf.simulate_pendulum(case, lambda t, q: ctrl.solve(t, q)[0].toarray()[:, 0])
+    for fig, curve, worst, n in pendulum_deviations(case, t_sim, dq_sim, p_sim):
+        assert n > 60 and worst < PIXELS, (fig, curve, worst, n)
+    _, q_ref, dq_ref, _ = cf.simulate_pendulum(case, pendulum_oracle_solver(case))
+    assert np.abs(q_sim - q_ref).max() < 1e-7 and np.abs(dq_sim - dq_ref).max() < 1e-6, (
+        np.abs(q_sim - q_ref).max(), np.abs(dq_sim - dq_ref).max())
+
+
+def test_hip_pinv_reproduces_the_ur5_figure(ur5_fk):
+    """ur5_transformation_matrix_comparison_of_controllers.ipynb cells 27-32: PseudoInverseController, the UR5's tool to
+    (0.5, 0.5, 0.5) from UR5_home through the notebook's own loop"""
+    ctrl = cc.PseudoInverseController(skill_spec=cf.ur5_pinv_point_skill(ur5_fk))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    t_sim, p_sim = cf.simulate_ur5(ur5_fk, lambda t, q: ctrl.solve(t, q)[0].toarray()[:, 0])
+    for k, curve in enumerate("xyz"):
+        worst, n = cf.deviation_in_pixels("ur5_pinv_p", curve, t_sim, p_sim[:, k])
+        assert n >= 15 and worst < PIXELS, (curve, worst, n)
