@@ -35,6 +35,7 @@ NOTEBOOKS = "/root/reference/examples/notebooks/"
 CART = "cart_on_track_1D_comparison_of_controllers.ipynb"
 PENDULUM = "double_pendulum_2D_comparison_of_controllers.ipynb"
 UR5 = "ur5_transformation_matrix_comparison_of_controllers.ipynb"
+UR5_INPUT = "ur5_input_experiment.ipynb"
 BLACK = (0.0, 0.0, 0.0)
 RED, BLUE, GREEN = (255.0, 0.0, 0.0), (0.0, 0.0, 255.0), (0.0, 128.0, 0.0)              # "r", "b", "g"
 C0, C1, C2 = (31.0, 119.0, 180.0), (255.0, 127.0, 14.0), (44.0, 160.0, 44.0)         # matplotlib's default cycle
@@ -64,6 +65,10 @@ FIGURES = {
     "pend_track_p":  (PENDULUM, 38, 0.01, 2000, [(0, ("extremes", BLACK, 0.75, 1.25), [("px", BLUE), ("py", GREEN)])]),
     # UR5, PseudoInverseController, norm_2 position error behind six 1-D joint-limit sets, speeds saturated at pi / 5
     # (cells 27-32): x, y, z of the tool, the dashed targets all at 0.5
+    # UR5, ReactiveQPController with an input_var (a simulated disturbance from t = 10 s on), multidimensional joint
+    # limits, speed limits, solve_initial_problem and the slack warm start (ur5_input_experiment.ipynb cells 7-17);
+    # no line at a known value: calibrated from the view limits (data range = start position x0 = 0 ... z0)
+    "ur5_qp_input":  (UR5_INPUT, 17, 0.01, 4501, [(0, ("box", 0.0, UR5_HOME_Z), [("x", C0), ("y", C1), ("z", C2)])]),
     "ur5_pinv_p":    (UR5, 32, 0.01, 1000, [(0, ("line+start", [C0, C1, C2], 0.5, "z", UR5_HOME_Z),
                                              [("x", C0), ("y", C1), ("z", C2)])]),
 }
@@ -286,6 +291,14 @@ def main():
             elif calib[0] == "extremes":
                 _, colour, v_lo, v_hi = calib
                 row_hi, row_lo = extreme_rows(rgb, box, colour)
+            elif calib[0] == "box":
+                # no line at a known value in these axes: the view limits themselves - matplotlib's default is the
+                # data range widened by 5 % (as for the time axis) - and the data range is known from the INPUTS of
+                # the run (the tool's start position); the spines are centred on the limits
+                _, v_min, v_max = calib
+                span = v_max - v_min
+                v_lo, v_hi = v_min - 0.05 * span, v_max + 0.05 * span
+                row_hi, row_lo = top + 0.5, bot + 0.5
             else:
                 _, colours, v_lo, start_curve, v_hi = calib
                 found = sorted(set(round(r, 1) for col in colours for r in line_rows(rgb, box, col)))
@@ -296,6 +309,13 @@ def main():
             if calib[0] == "line+start":
                 row_hi = float(np.mean(traced[start_curve][1][:2]))     # the curve's first two columns
             per_row = (v_hi - v_lo) / (row_lo - row_hi)                  # value per pixel row
+            if calib[0] == "line+start":
+                # cross-check of the "box" calibration used for ur5_qp_input on a figure that HAS a known line: the view
+                # limits put the 0.5 line where it is found
+                span = UR5_HOME_Z - 0.0
+                predicted = (top + 0.5) + (UR5_HOME_Z + 0.05 * span - v_lo) / (1.1 * span) * (bot - top)
+                print("%-13s view-limit calibration puts the dashed targets at row %.2f, found at %.2f" % (name, predicted, row_lo))
+                assert abs(predicted - row_lo) < 0.75
             # cross-check of the x calibration against a reference-drawn extent: the curves span [0, t_max] (one that
             # ends under another curve drawn over it is covered by that one)
             first_col = min(traced[curve][3][0] for curve, _ in curves)

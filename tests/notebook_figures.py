@@ -143,3 +143,43 @@ def simulate_ur5(fk, solve):
         q_sim[i + 1] = q_sim[i] + dq * dt
         p_sim[i + 1] = fk["chain"].fk_numeric(q_sim[i + 1])[:3, 3]
     return t_sim, p_sim
+
+
+# ---- UR5 with a simulated input at the end effector, ReactiveQPController ---------------------------------------------
+def ur5_input_skill(fk):
+    """ur5_input_experiment.ipynb cells 7-13: the tool position follows `T_des[:3, 3] - y` (soft, gain 1) under the
+    multidimensional joint limits and the joint-speed limits; y is the skill's input_var"""
+    t, q, dq, y = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6), cs.MX.sym("y", 3)
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    max_speed = np.pi / 5
+    cons = [cc.EqualityConstraint(label="transfmat_dist_id", expression=fk["T_fk"](q)[:3, 3] - np.array([0.5, 0.5, 0.5]) + y,
+                                  constraint_type="soft", gain=1.0, priority=100),
+            cc.SetConstraint(label="Joint_Limits", expression=q, set_min=lo, set_max=hi),
+            cc.VelocitySetConstraint(label="Joint_speed_limits", expression=q, set_min=-np.full(6, max_speed),
+                                     set_max=np.full(6, max_speed))]
+    return cc.SkillSpecification(label="linear_input_skill", time_var=t, robot_var=q, robot_vel_var=dq, input_var=y,
+                                 constraints=cons)
+
+
+def ur5_input_signal(n=4501, dt=0.01):
+    """cell 16: nothing for 10 s, then 0.1 (cos(0.1 (t - 10)), sin(0.1 (t - 10 + pi / 2)), 0)"""
+    y = np.zeros((n, 3))
+    for i in range(n - 1):
+        if dt * i > 10.0:
+            y[i] = [0.1 * np.cos(0.1 * (dt * i - 10)), 0.1 * np.sin(0.1 * (dt * i - 10 + np.pi / 2)), 0.0]
+    return y
+
+
+def simulate_ur5_input(fk, solve):
+    """cell 16: 4500 ticks of 0.01 s from UR5_home; `solve(t, q, y)` -> dq [6] (clamped like the notebook does)."""
+    n, dt, max_speed = 4501, 0.01, np.pi / 5
+    y_sim = ur5_input_signal(n, dt)
+    t_sim = np.array([dt * i for i in range(n)])
+    q_sim, p_sim = np.zeros((n, 6)), np.zeros((n, 3))
+    q_sim[0] = UR5_HOME
+    p_sim[0] = fk["chain"].fk_numeric(UR5_HOME)[:3, 3]
+    for i in range(n - 1):
+        dq = np.clip(solve(t_sim[i], q_sim[i], y_sim[i]), -max_speed, max_speed)
+        q_sim[i + 1] = q_sim[i] + dq * dt
+        p_sim[i + 1] = fk["chain"].fk_numeric(q_sim[i + 1])[:3, 3]
+    return t_sim, p_sim

@@ -117,3 +117,24 @@ def test_oracle_reproduces_the_ur5_figure():
             c.gain = 5.0
     t_sim, p_sim = cf.simulate_ur5(fk, solve)
     assert max(cf.deviation_in_pixels("ur5_pinv_p", c, t_sim, p_sim[:, k])[0] for k, c in enumerate("xyz")) > 2.0
+
+
+INPUT_PIXELS = 1.5      # (this figure has no line at a known value: it is calibrated from the view limits, which the
+#                          cross-check on the UR5 pinv figure places to 0.6 px; measured deviation: 0.60 px)
+
+
+def test_oracle_reproduces_the_ur5_input_experiment_figure():
+    """ur5_input_experiment.ipynb cell 17: ReactiveQPController with an input_var - 45 s, a disturbance entering through
+    y from t = 10 s on (reactive_qp.py:191-246 with `_has_input`, :461-528)"""
+    from casclik_amd import skills
+    fk = skills.ur5()
+    spec = cf.ur5_input_skill(fk)
+
+    def solve(t, q, y):
+        dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :], Y=y[None, :])
+        assert status[0] == 0
+        return dq[0]
+    t_sim, p_sim = cf.simulate_ur5_input(fk, solve)
+    for k, curve in enumerate("xyz"):
+        worst, n = cf.deviation_in_pixels("ur5_qp_input", curve, t_sim, p_sim[:, k])
+        assert n > 150 and worst < INPUT_PIXELS, (curve, worst, n)

@@ -68,3 +68,25 @@ def test_hip_pinv_reproduces_the_ur5_figure(ur5_fk):
     for k, curve in enumerate("xyz"):
         worst, n = cf.deviation_in_pixels("ur5_pinv_p", curve, t_sim, p_sim[:, k])
         assert n >= 15 and worst < PIXELS, (curve, worst, n)
+
+
+def test_hip_qp_reproduces_the_ur5_input_experiment_figure(ur5_fk):
+    """ur5_input_experiment.ipynb cells 15-17 with the notebook's own calls: `setup_initial_problem_solver()`,
+    `solve_initial_problem(time_var0=0, robot_var0=UR5_home, input_var0=[0, 0, 0])[-1]`, then 4500 ticks of
+    `solve(t, q, input_var=y, warmstart_slack_var=slack)`"""
+    from test_figure_pins import INPUT_PIXELS
+    ctrl = cc.ReactiveQPController(skill_spec=cf.ur5_input_skill(ur5_fk))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    ctrl.setup_initial_problem_solver()
+    state = {"slack": ctrl.solve_initial_problem(time_var0=0, robot_var0=cf.UR5_HOME, input_var0=[0, 0, 0])[-1]}
+
+    def solve(t, q, y):
+        res = ctrl.solve(t, q, input_var=y, warmstart_slack_var=state["slack"])
+        if res[-1] is not None:
+            state["slack"] = res[-1].toarray()[:, 0]
+        return res[0].toarray()[:, 0]
+    t_sim, p_sim = cf.simulate_ur5_input(ur5_fk, solve)
+    for k, curve in enumerate("xyz"):
+        worst, n = cf.deviation_in_pixels("ur5_qp_input", curve, t_sim, p_sim[:, k])
+        assert n > 150 and worst < INPUT_PIXELS, (curve, worst, n)
