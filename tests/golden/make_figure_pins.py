@@ -36,6 +36,7 @@ CART = "cart_on_track_1D_comparison_of_controllers.ipynb"
 PENDULUM = "double_pendulum_2D_comparison_of_controllers.ipynb"
 UR5 = "ur5_transformation_matrix_comparison_of_controllers.ipynb"
 UR5_INPUT = "ur5_input_experiment.ipynb"
+UR5_DQ = "ur5_dual_quaternion_vs_transformation_matrix.ipynb"
 BLACK = (0.0, 0.0, 0.0)
 RED, BLUE, GREEN = (255.0, 0.0, 0.0), (0.0, 0.0, 255.0), (0.0, 128.0, 0.0)              # "r", "b", "g"
 C0, C1, C2 = (31.0, 119.0, 180.0), (255.0, 127.0, 14.0), (44.0, 160.0, 44.0)         # matplotlib's default cycle
@@ -69,6 +70,15 @@ FIGURES = {
     # limits, speed limits, solve_initial_problem and the slack warm start (ur5_input_experiment.ipynb cells 7-17);
     # no line at a known value: calibrated from the view limits (data range = start position x0 = 0 ... z0)
     "ur5_qp_input":  (UR5_INPUT, 17, 0.01, 4501, [(0, ("box", 0.0, UR5_HOME_Z), [("x", C0), ("y", C1), ("z", C2)])]),
+    # UR5 from home to a frame, error norm on a LOG axis (ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 14-27):
+    # the 8-row dual-quaternion deviation Q_dist1 under the ReactiveQPController (blue: visible where it leaves the
+    # curves drawn over it, from 1e-9.4 down to the rounding floor); tick labels read off the figure: 10^0 at the top
+    # tick, 2 decades per tick.  (The green curve, the PseudoInverseController of that notebook, is NOT a pin: the run
+    # starts at UR5_home - the elbow is straight, the 8 x 6 Jacobian has rank 5 - with damping_factor 1e-26, so the
+    # first ticks are rounding noise divided by 1e-26 and saturated: which way the arm leaves the singularity depends on
+    # the last bit of the linear solver, the reference's curve idles near 1 for five seconds, any other arithmetic
+    # idles differently.)
+    "ur5_qdist1_e":  (UR5_DQ, 27, 0.008, 1001, [(0, ("logticks", 0, 2), [("qp", C0)])]),
     "ur5_pinv_p":    (UR5, 32, 0.01, 1000, [(0, ("line+start", [C0, C1, C2], 0.5, "z", UR5_HOME_Z),
                                              [("x", C0), ("y", C1), ("z", C2)])]),
 }
@@ -159,6 +169,34 @@ def extreme_rows(rgb, box, colour):
             else:
                 lo_row = max(lo_row, centre)
     return hi_row, lo_row
+
+
+def coloured_extent(rgb, box):
+    """first and last pixel column of the axes in which ANY coloured curve is drawn (a curve hidden under another one
+    is covered by that one): the plotted time range"""
+    top, bot, left, right = box
+    sat = (rgb.max(axis=2) - rgb.min(axis=2)) > 60.0
+    sat[:top + 2] = False
+    sat[bot - 1:] = False
+    l0, l1, c0, c1 = legend_box(rgb, box)
+    sat[l0:l1 + 1, c0:c1 + 1] = False
+    cols = np.nonzero(sat[:, left + 2:right - 1].any(axis=0))[0] + left + 2
+    return int(cols[0]), int(cols[-1])
+
+
+def tick_rows(rgb, box):
+    """rows (pixel centres) of the tick marks on the left spine"""
+    top, bot, left, right = box
+    dark = rgb.max(axis=2) < 110.0
+    rows = []
+    for y in range(top - 2, bot + 3):
+        c, run = left - 1, 0
+        while c >= 0 and dark[y, c]:
+            run += 1
+            c -= 1
+        if run >= 2:
+            rows.append(y + 0.5)
+    return rows
 
 
 def legend_box(rgb, box):
@@ -291,6 +329,18 @@ def main():
             elif calib[0] == "extremes":
                 _, colour, v_lo, v_hi = calib
                 row_hi, row_lo = extreme_rows(rgb, box, colour)
+            elif calib[0] == "logticks":
+                # logarithmic axis (set_yscale("log")): the major tick marks left of the spine are a whole number of
+                # decades apart; which decades - the exponent at the top tick and the step - is read off the stored
+                # figure's labels BY EYE and written in the table above; a line through the tick rows gives decades
+                # per row.  The digitised values are log10 of the plotted error.
+                _, top_exp, step = calib
+                ticks = tick_rows(rgb, box)
+                exps = top_exp - step * np.arange(len(ticks))
+                slope, icpt = np.polyfit(np.array(ticks), exps, 1)
+                assert np.abs(slope * np.array(ticks) + icpt - exps).max() < 0.6 * abs(slope), "tick rows not evenly spaced"
+                row_hi, row_lo = ticks[0], ticks[-1]
+                v_hi, v_lo = float(slope * row_hi + icpt), float(slope * row_lo + icpt)
             elif calib[0] == "box":
                 # no line at a known value in these axes: the view limits themselves - matplotlib's default is the
                 # data range widened by 5 % (as for the time axis) - and the data range is known from the INPUTS of
@@ -316,10 +366,8 @@ def main():
                 predicted = (top + 0.5) + (UR5_HOME_Z + 0.05 * span - v_lo) / (1.1 * span) * (bot - top)
                 print("%-13s view-limit calibration puts the dashed targets at row %.2f, found at %.2f" % (name, predicted, row_lo))
                 assert abs(predicted - row_lo) < 0.75
-            # cross-check of the x calibration against a reference-drawn extent: the curves span [0, t_max] (one that
-            # ends under another curve drawn over it is covered by that one)
-            first_col = min(traced[curve][3][0] for curve, _ in curves)
-            last_col = max(traced[curve][3][1] for curve, _ in curves)
+            # cross-check of the x calibration against a reference-drawn extent: the curves span [0, t_max]
+            first_col, last_col = coloured_extent(rgb, box)
             t_first, t_last = (-0.05 * t_max + (np.array([first_col, last_col]) + 0.5 - x_lo) * per_col)
             assert abs(t_first) < 3.0 * per_col and abs(t_last - t_max) < 3.0 * per_col, (name, t_first, t_last)
             for curve, _ in curves:

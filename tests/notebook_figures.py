@@ -78,7 +78,7 @@ def simulate(case, solve):
     return t_sim, p_sim, dp_sim
 
 
-def deviation_in_pixels(case, curve, t_sim, values):
+def deviation_in_pixels(case, curve, t_sim, values, above=None):
     """For every sample digitised from the stored figure: how far (in pixel rows) the simulated curve misses it, where
     the simulated curve may be taken anywhere within a pixel and a half in t (a figure cannot place a jump more
     exactly).  Returns (worst deviation, samples)."""
@@ -86,6 +86,8 @@ def deviation_in_pixels(case, curve, t_sim, values):
     ft, fv = FIGS[key + "_t"], FIGS[key + "_v"]
     px_t, px_v = FIGS[key + "_pixel"]
     worst = 0.0
+    if above is not None:
+        ft, fv = ft[fv > above], fv[fv > above]
     for tk, vk in zip(ft, fv):
         near = (t_sim >= tk - 1.5 * px_t) & (t_sim <= tk + 1.5 * px_t)
         lo, hi = values[near].min(), values[near].max()
@@ -183,3 +185,48 @@ def simulate_ur5_input(fk, solve):
         q_sim[i + 1] = q_sim[i] + dq * dt
         p_sim[i + 1] = fk["chain"].fk_numeric(q_sim[i + 1])[:3, 3]
     return t_sim, p_sim
+
+
+# ---- UR5 from home to a frame: error norms on a log axis --------------------------------------------------------------
+def frame_error_skill(fk, which, controller):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 14-24: the tool frame's deviation from a desired frame
+    (5 degrees of roll at (0.5, 0, 0.5)), gain 10, soft.  QP: behind the multidimensional joint limits (no speed-limit
+    constraint: the loop saturates); pinv: the error alone, options multidim_sets / damped / damping_factor 1e-26.
+    Returns (spec, options, error norm as a function of q)."""
+    from casclik_amd import numpy_geom, casadi_geom
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
+    rpy, xyz = [5.0 * (np.pi / 180.0), 0.0, 0.0], [0.5, 0.0, 0.5]
+    if which == "Q_dist1":
+        q1, q2 = cs.SX.sym("q1", 8), cs.SX.sym("q2", 8)
+        product = cs.Function("dualquatprod", [q1, q2], [casadi_geom.dual_quaternion_product(q1, q2)])
+        conj = cs.Function("dualquatconj", [q1], [casadi_geom.dual_quaternion_conj(q1)])
+        Q_des = numpy_geom.dual_quaternion_revolute(xyz, rpy, [1, 0, 0], 0.0)
+        Q_id = numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0)
+        expr = product(fk["dual_quaternion_fk"](q), conj(Q_des)) - Q_id
+        norm = cs.norm_2(expr)
+    else:
+        raise ValueError(which)
+    error = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=10.0, priority=301)
+    if controller == "qp":
+        cons = [cc.SetConstraint(label="Joint_Limits", expression=q, set_min=np.array(fk["lower"]),
+                                 set_max=np.array(fk["upper"])), error]
+        options = None
+    else:
+        cons = [error]
+        options = {"multidim_sets": True, "pinv_method": "damped", "damping_factor": 1e-26}
+    spec = cc.SkillSpecification(label=which + "_skill", time_var=t, robot_var=q, constraints=cons)
+    return spec, options, cs.Function("e", [t, q], [norm])
+
+
+def simulate_frame_error(eval_norm, solve):
+    """cell 25: 1000 ticks of 0.008 s from UR5_home, speeds saturated at pi / 5; e_sim[i + 1] is the error norm at
+    q_sim[i + 1].  Returns t_sim, log10(e_sim)."""
+    n, dt, max_speed = 1001, 0.008, np.pi / 5
+    t_sim = np.array([dt * i for i in range(n)])
+    q = UR5_HOME.copy()
+    e_sim = np.zeros(n)
+    e_sim[0] = float(np.asarray(eval_norm(0.0, q).toarray()).ravel()[0])
+    for i in range(n - 1):
+        q = q + np.clip(solve(t_sim[i], q), -max_speed, max_speed) * dt
+        e_sim[i + 1] = float(np.asarray(eval_norm(t_sim[i], q).toarray()).ravel()[0])
+    return t_sim, np.log10(np.maximum(e_sim, 1e-300))

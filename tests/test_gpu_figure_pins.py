@@ -90,3 +90,23 @@ def test_hip_qp_reproduces_the_ur5_input_experiment_figure(ur5_fk):
     for k, curve in enumerate("xyz"):
         worst, n = cf.deviation_in_pixels("ur5_qp_input", curve, t_sim, p_sim[:, k])
         assert n > 150 and worst < INPUT_PIXELS, (curve, worst, n)
+
+
+def test_hip_qp_reproduces_the_error_decay_of_the_dual_quaternion_figure(ur5_fk):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 24-27 (log axis) with the notebook's calls: the
+    8-row dual-quaternion deviation runs as generated code in the instantiated QP kernel"""
+    spec, _, error_norm = cf.frame_error_skill(ur5_fk, "Q_dist1", "qp")
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    ctrl.setup_initial_problem_solver()
+    state = {"slack": ctrl.solve_initial_problem(0, cf.UR5_HOME)[-1]}
+
+    def solve(t, q):
+        res = ctrl.solve(t, q, warmstart_slack_var=state["slack"])
+        if res[-1] is not None:
+            state["slack"] = res[-1].toarray()[:, 0]
+        return res[0].toarray()[:, 0]
+    t_sim, log_e = cf.simulate_frame_error(error_norm, solve)
+    worst, n = cf.deviation_in_pixels("ur5_qdist1_e", "qp", t_sim, log_e, above=-13.0)
+    assert n > 25 and worst < PIXELS, (worst, n)
