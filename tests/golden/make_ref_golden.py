@@ -245,9 +245,53 @@ def check_reference_held_outputs():
     return {"n_prints": len(data["prints"]), "ur5_home_norm": float(np.linalg.norm(T[:3, 3]))}
 
 
+def check_against_the_stored_figures():
+    """The strongest tie of the stand-in casadi to the REAL one: the closed-loop figures the reference's notebooks store
+    (their author's runs on CasADi + qpOASES), digitised by make_figure_pins.py.  The REFERENCE controllers over the
+    stand-in run the same notebook loops here - the cart notebook's six runs (QP and pinv: point, trajectory leaving
+    the rail, path with a virtual variable) and the double pendulum's two QP runs (task-space SetConstraints) - and
+    every simulated curve has to pass within a pixel of every digitised sample.  Returns the worst deviation [px]."""
+    import figure_skills as fs
+    worst_all, n_curves = 0.0, 0
+    for case in fs.CASES:
+        kind, spec, dt, p0, virt = fs.build(case, cs, cc)
+        if kind == "qp":
+            ctrl = cc.ReactiveQPController(skill_spec=spec, robot_var_weights=[1.0])
+        else:
+            ctrl = cc.PseudoInverseController(skill_spec=spec)
+        ctrl.setup_problem_functions()
+        ctrl.setup_solver()
+
+        def solve(t, p, x, ctrl=ctrl, virt=virt):
+            res = ctrl.solve(t, p, x) if virt else ctrl.solve(t, p)
+            return float(res[0].toarray()[0, 0]), (float(res[1].toarray()[0, 0]) if virt else None)
+        t_sim, p_sim, dp_sim = fs.simulate(case, solve)
+        for curve in (["dp"] if case.endswith("point") else ["p", "dp"]):
+            worst, n = fs.deviation_in_pixels(case, curve, t_sim, p_sim if curve == "p" else dp_sim)
+            assert worst < 1.0, ("reference + stand-in misses the stored figure", case, curve, worst)
+            worst_all, n_curves = max(worst_all, worst), n_curves + 1
+    for case in fs.PENDULUM_CASES:
+        ctrl = cc.ReactiveQPController(skill_spec=fs.pendulum_skill(case, cs, cc), robot_var_weights=[1.0, 1.0])
+        ctrl.setup_problem_functions()
+        ctrl.setup_solver()
+        t_sim, _, dq_sim, p_sim = fs.simulate_pendulum(case, lambda t, q, ctrl=ctrl: ctrl.solve(t, q)[0].toarray()[:, 0])
+        curves = ([("pend_point_dq", "dq0", dq_sim[:, 0]), ("pend_point_dq", "dq1", dq_sim[:, 1]),
+                   ("pend_point_p", "px", p_sim[:, 0]), ("pend_point_p", "py", p_sim[:, 1])] if case == "pend_point"
+                  else [("pend_track_p", "px", p_sim[:, 0]), ("pend_track_p", "py", p_sim[:, 1])])
+        for fig, curve, values in curves:
+            worst, n = fs.deviation_in_pixels(fig, curve, t_sim, values)
+            assert worst < 1.0, ("reference + stand-in misses the stored figure", fig, curve, worst)
+            worst_all, n_curves = max(worst_all, worst), n_curves + 1
+    print("reference package + stand-in casadi: 9 stored closed-loop figures (%d curves) reproduced, worst deviation "
+          "%.2f pixel rows" % (n_curves, worst_all))
+    return worst_all
+
+
 def main():
     held = check_reference_held_outputs()
-    out = {"refheld_n_prints": np.array(held["n_prints"]), "refheld_ur5_home_norm": np.array(held["ur5_home_norm"])}
+    held["figures_worst_px"] = check_against_the_stored_figures()
+    out = {"refheld_n_prints": np.array(held["n_prints"]), "refheld_ur5_home_norm": np.array(held["ur5_home_norm"]),
+           "refheld_figures_worst_px": np.array(held["figures_worst_px"])}
     for k, (name, robot, case, B, dist, times) in enumerate(PLAN):
         urdf, root, tip = ROBOTS[robot]
         chain = load_chain(urdf, root, tip)

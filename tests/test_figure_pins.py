@@ -69,8 +69,7 @@ def test_the_figures_tell_a_wrong_controller_from_a_right_one():
 
 
 def pendulum_oracle_solver(case):
-    from extern_skills import double_pendulum_skill
-    spec = double_pendulum_skill(track=(case == "pend_track"))
+    spec = cf.pendulum_skill(case)
 
     def solve(t, q):
         dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])

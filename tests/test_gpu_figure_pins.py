@@ -44,10 +44,8 @@ def test_hip_controllers_reproduce_the_figures_the_reference_stores(case):
 def test_hip_qp_reproduces_the_double_pendulum_figures(case):
     """double_pendulum_2D_comparison_of_controllers.ipynb cells 14-19 / 35-38: the ReactiveQPController with the table
     SetConstraints (general inequality rows: the mixed-family kernel) and saturating joint-speed limits"""
-    from extern_skills import double_pendulum_skill
     from test_figure_pins import pendulum_deviations, pendulum_oracle_solver
-    ctrl = cc.ReactiveQPController(skill_spec=double_pendulum_skill(track=(case == "pend_track")),
-                                   robot_var_weights=[1.0, 1.0])
+    ctrl = cc.ReactiveQPController(skill_spec=cf.pendulum_skill(case), robot_var_weights=[1.0, 1.0])
     ctrl.setup_problem_functions()
     ctrl.setup_solver()
     t_sim, q_sim, dq_sim, p_sim = cf.simulate_pendulum(case, lambda t, q: ctrl.solve(t, q)[0].toarray()[:, 0])

@@ -102,3 +102,12 @@ def test_boundary_fixture_plants_decisions_on_the_thresholds():
     assert (mg < 1e-11).sum() >= 30 and (mg == 0.0).any()        # decisions on / within 1e-11 of a threshold
     assert np.abs(mg - mc).max() < 1e-9 * (1 + mg.max())
     assert (mode == 0).sum() > 30 and (mode == 1).sum() > 30
+
+
+def test_the_fixture_generator_reproduced_the_stored_figures_through_the_reference_package():
+    """make_ref_golden.py refuses to write ref_pins.npz unless the REFERENCE controllers over the stand-in casadi retrace
+    the closed-loop figures the reference's notebooks store (real CasADi + qpOASES runs; tests/test_figure_pins.py) to
+    within a pixel: the stand-in's arithmetic is tied to the real one's outputs, not only to the reference's formulas.
+    The fixture records the worst deviation of that run."""
+    assert "refheld_figures_worst_px" in refpins.PINS.files
+    assert float(refpins.PINS["refheld_figures_worst_px"]) < 1.0
