@@ -69,10 +69,21 @@ inline size_t team_lds_bytes(bool values = false)
 // Slds: skill image (LDS copy, or the address of a local constexpr object whose loads fold to literals);
 // z: the instance's state in every lane of the quad; a0 / a1: state variables 2r and 2r+1 (clamped to N-1) of lane
 // r; on return lane 0 holds the mode-0 velocity in v, lane 3 the mode-1 one, in_tc the cone test of v.
-template <const ShapeDesc& SD>
+// -DCLIK_RESIDENT_PIPELINE=0: the resident tick kernel without its software pipeline (every tick: poll the ticket, load
+// the rows, compute, store, wait for the acknowledgements, publish) - for tools/resident_probe.py's comparison only
+#ifndef CLIK_RESIDENT_PIPELINE
+#define CLIK_RESIDENT_PIPELINE 1
+#endif
+
+struct NoMidTick {
+    __device__ __forceinline__ void operator()() const {}
+};
+// MID: called once between the Gram build and the factorisations - the resident tick kernel puts its memory
+// traffic for the NEXT tick there (pinv_resident_team_kernel), everyone else nothing
+template <const ShapeDesc& SD, class MID = NoMidTick>
 __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, const TickArgs& tk,
                                           const double (&z)[SD.n], const double* ysl, const double a0, const double a1,
-                                          const int r, const int inst, double (&v)[SD.n], bool& in_tc)
+                                          const int r, const int inst, double (&v)[SD.n], bool& in_tc, MID&& mid = MID())
 {
     constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2];
     constexpr int NT = M * (M + 1) / 2;
@@ -178,8 +189,12 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
             }
             Gm[tri(i, k)] = acc;
         }
+    if constexpr (!std::is_same<std::decay_t<MID>, NoMidTick>::value) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
-    
     // ---- per-lane role ------------------------------------------------------------------------
     // The lower-priority task's projected contribution, with the stack matrix G = D + c J'J of the mode
     // (D = lam I in mode 0 with c = 2; D = (1+lam) I in mode 1 with c = 1) and C = G - (D - S):
@@ -603,19 +618,30 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         ticket->p3[1] = (unsigned)(max_polls >> 32);
         ticket->p3[2] = (unsigned)n_ticks;
     }
-    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-#pragma unroll 1
-    for (int k = 1; k <= n_ticks; ++k) {
-        bool leave = false;
+    // Software pipeline over the ticks (a wave has its SIMD to itself, nothing else hides memory latency).  In the
+    // order the wave issues them:
+    //   end of tick k - 1   request the ticket word again (-> `seen`), THEN store dq of tick k - 1
+    //   middle of tick k    (team_tick's hook, > 1 us later: `seen` has arrived; the stores behind it may still be
+    //                       on their way, nobody waits for them) if the producer has published tick k + 1, request
+    //                       its rows: they arrive while the factorisations of tick k run
+    //   end of tick k       publish tick k - 1's "done" slot - its stores were issued a whole tick ago -, request the
+    //                       ticket word, store dq of tick k
+    // so a wave that is being fed ahead never waits for memory.  If the producer has NOT published the next tick (a
+    // closed loop: it waits for "done"), the slot is published at once and the wave polls, as before.
+    // Loads of one wave return in order and a row is requested only after a ticket value that covers it has been SEEN
+    // by this wave, so a row is never read before its producer wrote it.
+    double zn[N], yn[NY > 0 ? NY : 1];
+    bool have_next = false, leave = false;
+    unsigned seen = 0u;             // latest ticket value this wave has requested (monotone at the producer)
+    auto poll_for = [&](const unsigned want) __attribute__((always_inline)) {
 #pragma unroll 1
         for (;;) {
-            // (relaxed, system scope = a load that bypasses the caches; no L2 invalidate: the rows below are read the
-            // same way, and a wave issues them only after this value has arrived)
-            const unsigned seq = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (seq >= (unsigned)k) break;
+            // (relaxed, system scope = a load that bypasses the caches; no L2 invalidate: the rows are read the same way)
+            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seen >= want) return;
             if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
                 leave = true;
-                break;
+                return;
             }
             if (++polls > max_polls) {
                 __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -624,32 +650,64 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
                     ticket->p3[4] = blockIdx.x * TEAM_WAVES + (tid >> 6);
                 }
                 leave = true;
-                break;
+                return;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (leave) break;
-        asm volatile("" ::: "memory");
-        double z[N], ydir[NY > 0 ? NY : 1];
+    };
+    auto request_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) z[j] = __hip_atomic_load(q + binst * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int j = 0; j < N; ++j) zn[j] = __hip_atomic_load(q + binst * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if constexpr (NY > 0) {
 #pragma unroll
             for (int j = 0; j < NY; ++j)
-                ydir[j] = __hip_atomic_load(y + binst * NY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                yn[j] = __hip_atomic_load(y + binst * NY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    };
+    auto publish_done = [&](const int k) __attribute__((always_inline)) {
+        // every lane's stores acknowledged, then the wave's own slot (no shared counter)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((tid & (WAVE - 1)) == 0)
+            __hip_atomic_store(done + (blockIdx.x * TEAM_WAVES + (tid >> 6)), (unsigned)k, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
+    };
+    int owed = 0;           // tick whose "done" slot is still to be published (0: none)
+#pragma unroll 1
+    for (int k = 1; k <= n_ticks; ++k) {
+        if (!have_next) {
+            poll_for((unsigned)k);
+            if (leave) break;
+            asm volatile("" ::: "memory");
+            request_rows();
+        }
+        double z[N], ydir[NY > 0 ? NY : 1];
+#pragma unroll
+        for (int j = 0; j < N; ++j) z[j] = zn[j];
+#pragma unroll
+        for (int j = 0; j < (NY > 0 ? NY : 1); ++j) ydir[j] = yn[j];
+        have_next = false;
         double a0 = z[N - 1], a1 = z[N - 1];
         static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
             constexpr int kk = decltype(kc)::value;
             if constexpr (2 * kk < N) a0 = (r == kk) ? z[2 * kk] : a0;
             if constexpr (2 * kk + 1 < N) a1 = (r == kk) ? z[2 * kk + 1] : a1;
         });
-        (void)j0;
-        (void)j1;
         double v[N];
         bool in_tc;
-        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, v, in_tc);
+        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, v, in_tc, [&]() __attribute__((always_inline)) {
+            if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen >= (unsigned)(k + 1)) {
+                request_rows();
+                have_next = true;
+            }
+        });
         const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
+        if (owed != 0) {
+            publish_done(owed);         // (the previous tick's stores: issued a whole tick ago)
+            owed = 0;
+        }
+        if (have_next && k + 1 < n_ticks)
+            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
         if (r == (ok0 ? 0 : 3) && valid) {
             // (write-through stores: visible to every agent once acknowledged)
 #pragma unroll
@@ -658,13 +716,10 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             if (mode_out != nullptr)
                 __hip_atomic_store(mode_out + b0 + inst, ok0 ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        // every lane's stores acknowledged, then the wave's own slot (no shared counter)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((tid & (WAVE - 1)) == 0)
-            __hip_atomic_store(done + (blockIdx.x * TEAM_WAVES + (tid >> 6)), (unsigned)k, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
+        if (have_next) owed = k;        // published at the end of the next tick
+        else publish_done(k);           // nobody has asked for the next tick yet (or this was the last): at once
     }
+    if (owed != 0) publish_done(owed);
 }
 
 // reference producer / test harness of the resident ticks: publishes tickets 1 .. n_ticks from the device, either as
@@ -680,6 +735,13 @@ __global__ __launch_bounds__(1024) void resident_feed_kernel(ResidentTicket* tic
     unsigned long long polls = 0;
     if (threadIdx.x == 0) s_leave = 0;
     __syncthreads();
+    if (!closed_loop) {
+        // every ticket at once: the resident kernel never waits - what is measured is its own per-tick cost (publishing
+        // them one by one costs a store acknowledgement each, about 4 us: the kernel would be measured waiting for THAT)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&ticket->in_seq, (unsigned)n_ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
         if (closed_loop) {

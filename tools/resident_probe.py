@@ -51,27 +51,35 @@ for _ in range(10):
 torch.cuda.synchronize()
 print("launch per tick (hipGraph of 1000):   %.3f us per tick" % ((time.perf_counter() - t0) / 10000 * 1e6))
 
-for name, closed in (("free-running", False), ("closed loop", True)):
+def run_ticks(nt, closed):
+    """best of 5: wall time [s] from the feeder's launch to the resident kernel's exit, for nt ticks"""
     best = None
     for rep in range(5):
         feeder_stream = torch.cuda.Stream(priority=-1)       # (not the hardware queue of the resident kernel)
         torch.cuda.synchronize()
-        run = ctrl.resident_start(Qd, Yd, NT, timeout_s=3.0)
+        run = ctrl.resident_start(Qd, Yd, nt, timeout_s=3.0)
         time.sleep(0.02)                      # (the resident kernel is up and polling)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ctrl.resident_feed(run, NT, closed_loop=closed, timeout_s=3.0, stream=feeder_stream)
+        ctrl.resident_feed(run, nt, closed_loop=closed, timeout_s=3.0, stream=feeder_stream)
         run["stream"].synchronize()
         el = time.perf_counter() - t0
         feeder_stream.synchronize()
         tk = run["ticket"].cpu().numpy()
         dn = run["done"].cpu().numpy()
-        ok = (tk[32] == 0) and (tk[49] == NT) and (dn == NT).all()
+        ok = (tk[32] == 0) and (tk[49] == nt) and (dn == nt).all()
         same = torch.equal(run["out"], ref[0]) and torch.equal(run["mode"], ref[2])
-        per = el / NT * 1e6
-        best = per if best is None else min(best, per)
-        if rep == 0 or not (ok and same):
-            print("  %-13s rep %d: %.3f us per tick (host clock around feed -> kernel exit), ticks done %d, stop %d, "
-                  "slots at the last tick %d of %d, equal to the launched tick: %s" % (
-                      name, rep, per, tk[49], tk[32], int((dn == NT).sum()), run["waves"], same))
-    print("resident, %-13s            %.3f us per tick (best of 5; %d ticks)" % (name, best, NT))
+        if not (ok and same):
+            print("  %s rep %d: ticks done %d, stop %d, slots at the last tick %d of %d, equal to the launched tick: %s"
+                  % ("closed loop" if closed else "free-running", rep, tk[49], tk[32], int((dn == nt).sum()), run["waves"], same))
+        best = el if best is None else min(best, el)
+    return best
+
+
+print("pipeline:", os.environ.get("CLIK_JIT_DEFINES", "") or "on (default)")
+for name, closed in (("fed ahead (all tickets published)", False), ("closed loop (ticket k after every done[k-1])", True)):
+    # two run lengths: the slope is the per-tick cost, the intercept what a run costs around its ticks
+    short, long_ = run_ticks(NT, closed), run_ticks(10 * NT, closed)
+    slope = (long_ - short) / (9 * NT) * 1e6
+    print("resident, %-46s %.3f us per tick (slope between %d and %d ticks; the runs as wholes: %.3f / %.3f us per tick, "
+          "fixed part %.0f us)" % (name, slope, NT, 10 * NT, short / NT * 1e6, long_ / (10 * NT) * 1e6,
+                                  (short - slope * 1e-6 * NT) * 1e6))
