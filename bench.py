@@ -27,7 +27,8 @@ The JSON line also carries
   extras        (default N=1 run only) the other BASELINE configurations under
                 the same clock: config 2 (pose, 4096 and 16384), config 4 (QP,
                 cold, 16384), config 3 at the config-5 batch (131072), each with
-                ms_per_step / kernel / roofline / cpu_baseline
+                ms_per_step / kernel / roofline / cpu_baseline; and config 3 at
+                16384 as resident ticks fed ahead (one launch, device-side tickets)
 
 Timing protocol: W untimed warm-up steps, then an untimed, time-based clock ramp
 (--ramp-ms of replays: a fresh GPU needs ~100 ms of work before its clocks
@@ -528,6 +529,54 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     return entry, (spec, opts, Q, Y)
 
 
+def measure_resident(fk, dist_name, seed, B=16384, short=20000):
+    """BASELINE config 3 at 16384 instances through clik_pinv_resident_run with every ticket published ahead
+    (tools/resident_probe.py is the long form, closed loop included)."""
+    import torch
+    import casclik_amd as cc
+    from casclik_amd import skills
+    ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(fk), options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    Q, Y = skills.synthetic_inputs(fk, B, seed=seed, distribution=dist_name)
+    Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+    ref = ctrl.solve_batch(0.0, Qd, input_var=Yd)
+
+    def run(nt):
+        best = None
+        for _ in range(3):
+            feeder = torch.cuda.Stream(priority=-1)
+            torch.cuda.synchronize()
+            r = ctrl.resident_start(Qd, Yd, nt, timeout_s=3.0)
+            time.sleep(0.01)
+            t0 = time.perf_counter()
+            ctrl.resident_feed(r, nt, closed_loop=False, timeout_s=3.0, stream=feeder)
+            r["stream"].synchronize()
+            el = time.perf_counter() - t0
+            feeder.synchronize()
+            if not (torch.equal(r["out"], ref[0]) and torch.equal(r["mode"], ref[2])
+                    and int(r["done"].min()) == nt):
+                raise RuntimeError("resident ticks: output differs from the launched tick")
+            best = el if best is None else min(best, el)
+        return best
+    t_short, t_long = run(short), run(3 * short)
+    per_tick = t_long / (3 * short)          # (the whole long run, its fixed ~2 ms included: the conservative figure)
+    slope = (t_long - t_short) / (2 * short)
+    return {
+        "value": B / per_tick, "unit": "instance-steps/s", "ms_per_step": per_tick * 1e3,
+        "config": {"workload": "BASELINE config 3: %d x iiwa priority stack as RESIDENT ticks (one launch; device-side "
+                               "tickets, all published ahead of the kernel)" % B, "batch_per_gpu": B,
+                   "inputs": "%s seed %d" % (dist_name, seed), "kernel": ctrl.kernel_variant(B) + "/resident",
+                   "timing": "one resident launch of %d ticks, host clock from the producer's launch to the kernel's exit "
+                             "(best of 3), divided by the ticks; outputs checked equal to the launched tick's; "
+                             "`slope_us_per_tick`: between that run and one of %d ticks (a run has a fixed part of "
+                             "about 2 ms around its ticks)" % (3 * short, short),
+                   "slope_us_per_tick": slope * 1e6,
+                   "runs_us_per_tick": [t_short / short * 1e6, t_long / (3 * short) * 1e6]},
+        "roofline": {"bound": "hbm", "achieved": 172.0 * B / per_tick / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": 172.0 * B / per_tick / 1e9 / 8000.0, "traffic": None, "tick_us": per_tick * 1e6},
+    }
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -596,6 +645,13 @@ def main():
                 except Exception as exc:
                     ent["cpu_baseline"] = {"error": repr(exc)}
             extras.append(ent)
+
+        # config 3 as RESIDENT ticks (one launch, device-side tickets, all published ahead: include/clik.h)
+        try:
+            extras.append(dict({"name": "stack_B16384_resident_fed_ahead", "n_gpus": world, "dtype": "f64"},
+                               **measure_resident(fk, args.dist, args.seed)))
+        except Exception as exc:
+            extras.append({"name": "stack_B16384_resident_fed_ahead", "error": repr(exc)})
 
     if rank == 0:
         out = {

@@ -7,7 +7,7 @@ fed tickets by a device-side producer, against one launch per tick (hipGraph) an
   closed loop    the producer publishes ticket k only after every wave has counted tick k-1: both hand-offs
                  (N waves -> 1 producer -> N waves) are on the critical path, as for a producer that needs dq
 
-    python tools/resident_probe.py [B=16384] [ticks=2000]
+    python tools/resident_probe.py [B=16384] [ticks=20000]
 """
 import os
 import sys
@@ -22,7 +22,7 @@ import casclik_amd as cc    # noqa: E402
 from casclik_amd import skills   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-NT = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+NT = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 fk = skills.iiwa()
 ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(fk), options=dict(skills.STACK_OPTIONS))
 ctrl.setup_problem_functions()
@@ -78,8 +78,8 @@ def run_ticks(nt, closed):
 print("pipeline:", os.environ.get("CLIK_JIT_DEFINES", "") or "on (default)")
 for name, closed in (("fed ahead (all tickets published)", False), ("closed loop (ticket k after every done[k-1])", True)):
     # two run lengths: the slope is the per-tick cost, the intercept what a run costs around its ticks
-    short, long_ = run_ticks(NT, closed), run_ticks(10 * NT, closed)
-    slope = (long_ - short) / (9 * NT) * 1e6
+    short, long_ = run_ticks(NT, closed), run_ticks(3 * NT, closed)
+    slope = (long_ - short) / (2 * NT) * 1e6
     print("resident, %-46s %.3f us per tick (slope between %d and %d ticks; the runs as wholes: %.3f / %.3f us per tick, "
-          "fixed part %.0f us)" % (name, slope, NT, 10 * NT, short / NT * 1e6, long_ / (10 * NT) * 1e6,
+          "fixed part %.0f us)" % (name, slope, NT, 3 * NT, short / NT * 1e6, long_ / (3 * NT) * 1e6,
                                   (short - slope * 1e-6 * NT) * 1e6))
