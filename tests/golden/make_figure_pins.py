@@ -79,6 +79,10 @@ FIGURES = {
     # the last bit of the linear solver, the reference's curve idles near 1 for five seconds, any other arithmetic
     # idles differently.)
     "ur5_qdist1_e":  (UR5_DQ, 27, 0.008, 1001, [(0, ("logticks", 0, 2), [("qp", C0)])]),
+    # (cell 29, the one-row Frobenius-norm deviation T_dist1, is not a pin either: its QP curve is visible only in its
+    # tail below 1e-7, where the closed loop of a NORM - no gradient at its zero - amplifies a 1e-13 difference of one
+    # tick into 0.3 decades at the end of the run: the oracle happens to retrace the stored tail, the HIP path, equal
+    # to the oracle to 1e-13 tick by tick, ends 0.3 decades lower)
     "ur5_pinv_p":    (UR5, 32, 0.01, 1000, [(0, ("line+start", [C0, C1, C2], 0.5, "z", UR5_HOME_Z),
                                              [("x", C0), ("y", C1), ("z", C2)])]),
 }

@@ -110,6 +110,12 @@ def frame_error_skill(fk, which, controller):
         Q_id = numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0)
         expr = product(fk["dual_quaternion_fk"](q), conj(Q_des)) - Q_id
         norm = cs.norm_2(expr)
+    elif which == "T_dist1":
+        T_des = np.eye(4)
+        T_des[:3, :3] = numpy_geom.rotation_rpy(*rpy)
+        T_des[:3, 3] = xyz
+        expr = cs.norm_fro(cs.mtimes(np.linalg.inv(T_des), fk["T_fk"](q)) - np.eye(4))
+        norm = expr
     else:
         raise ValueError(which)
     error = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=10.0, priority=301)

@@ -90,10 +90,11 @@ def test_hip_qp_reproduces_the_ur5_input_experiment_figure(ur5_fk):
         assert n > 150 and worst < INPUT_PIXELS, (curve, worst, n)
 
 
-def test_hip_qp_reproduces_the_error_decay_of_the_dual_quaternion_figure(ur5_fk):
-    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 24-27 (log axis) with the notebook's calls: the
-    8-row dual-quaternion deviation runs as generated code in the instantiated QP kernel"""
-    spec, _, error_norm = cf.frame_error_skill(ur5_fk, "Q_dist1", "qp")
+@pytest.mark.parametrize("which,figure,above,least", [("Q_dist1", "ur5_qdist1_e", -13.0, 25)])
+def test_hip_qp_reproduces_the_error_decay_of_the_frame_figures(ur5_fk, which, figure, above, least):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 24-27 (log axis) with the notebook's calls: the 8-row
+    dual-quaternion deviation runs as generated code in the instantiated QP kernel"""
+    spec, _, error_norm = cf.frame_error_skill(ur5_fk, which, "qp")
     ctrl = cc.ReactiveQPController(skill_spec=spec)
     ctrl.setup_problem_functions()
     ctrl.setup_solver()
@@ -106,5 +107,5 @@ def test_hip_qp_reproduces_the_error_decay_of_the_dual_quaternion_figure(ur5_fk)
             state["slack"] = res[-1].toarray()[:, 0]
         return res[0].toarray()[:, 0]
     t_sim, log_e = cf.simulate_frame_error(error_norm, solve)
-    worst, n = cf.deviation_in_pixels("ur5_qdist1_e", "qp", t_sim, log_e, above=-13.0)
-    assert n > 25 and worst < PIXELS, (worst, n)
+    worst, n = cf.deviation_in_pixels(figure, "qp", t_sim, log_e, above=above)
+    assert n >= least and worst < PIXELS, (worst, n)
