@@ -26,7 +26,8 @@ The JSON line also carries
                 "port") timed on this host's cores on a bounded sample
   extras        (default N=1 run only) the other BASELINE configurations under
                 the same clock: config 2 (pose, 4096 and 16384), config 4 (QP,
-                cold, 16384), config 3 at the config-5 batch (131072), each with
+                16384: cold, and hot-started as the reference's solver is after
+                its first tick), config 3 at the config-5 batch (131072), each with
                 ms_per_step / kernel / roofline / cpu_baseline; and config 3 at
                 16384 as resident ticks fed ahead (one launch, device-side tickets)
 
@@ -635,11 +636,13 @@ def main():
     extras = []
     if want_extras:
         # the other BASELINE configurations under the same clock; short brackets
-        for (wl, b) in (("pose", 4096), ("pose", 16384), ("qp", 16384), ("stack", 131072)):
-            ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, args.steps, args.warmup,
+        # (config 4 twice: cold, and hot-started from the tick's own working set - the reference's qpOASES instance
+        # hot-starts every solve after the first, reactive_qp.py:491-513: the steady state of a control loop)
+        for (wl, b, hot) in (("pose", 4096, 0), ("pose", 16384, 0), ("qp", 16384, 0), ("qp", 16384, 1), ("stack", 131072, 0)):
+            ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, args.steps, args.warmup, qp_hot=hot,
                                             ramp_ms=100.0, min_timed_ms=args.extras_timed_ms)
-            ent = dict({"name": "%s_B%d" % (wl, b), "n_gpus": world, "dtype": "f64"}, **ent)
-            if rank == 0 and args.cpu_baseline and world == 1:
+            ent = dict({"name": "%s_B%d%s" % (wl, b, "_hot" if hot else ""), "n_gpus": world, "dtype": "f64"}, **ent)
+            if rank == 0 and args.cpu_baseline and world == 1 and not hot:
                 try:
                     ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(2.0, args.cpu_seconds / 3))
                 except Exception as exc:

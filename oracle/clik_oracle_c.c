@@ -12,9 +12,14 @@
  *   ReactiveQPController      /root/reference/casclik/controllers/reactive_qp.py
  *     cost :175-189, constraint rows :191-246
  *
- * PARITY UNPINNED (see oracle/clik_oracle.py header): CasADi is not available,
- * so this file is validated against the numpy/dual-number oracle, not against
- * reference output.
+ * PARITY UNPINNED BY THE LETTER (see oracle/clik_oracle.py header): CasADi is not
+ * available, so no fixture comes from CasADi arithmetic at 1e-9.  What this file
+ * is held to: the numpy / dual-number oracle, the fixtures the reference's own
+ * Python produced over a stand-in casadi (tests/golden/ref_pins.npz,
+ * tests/test_refpins.py), and - through those - the closed-loop figures the
+ * reference's notebooks store of their real CasADi + qpOASES runs, which the
+ * numpy oracle, the reference over the stand-in and the HIP path all retrace
+ * within a pixel (tests/golden/make_figure_pins.py, tests/test_figure_pins.py).
  *
  * It follows the reference LITERALLY: full pseudo-inverse matrices, full
  * null-space projectors N = I - pinv(vstack Ja) * vstack rJa, products in the
