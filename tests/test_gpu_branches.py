@@ -338,6 +338,36 @@ def test_all_joint_limits_as_sets_64_modes(ur5_fk, kernel, monkeypatch):
     assert (ctrl.kernel_name == "dynamic") == (kernel == "dynamic")
 
 
+@pytest.mark.parametrize("first", ["unit_rows", "constant_matrix", "tall_constant_matrix"])
+def test_first_equality_with_a_constant_jacobian_is_processed_twice_in_the_instantiated_kernels(iiwa_fk, first):
+    """A joint-space first EqualityConstraint (a posture, `300 - x` of the cart notebook's path skill, any A q - b): its
+    Jacobian is constant, its damped inverse P is precomputed on the host, and the double processing of the first
+    equality (pseudo_inverse.py:317-326 + :382-396) is 2 P d - P (J (P d)) in the instantiated kernels
+    (clik_pinv_static.hpp::step_s); the tasks behind it project through the stack [J; J].  Before round 3 such skills
+    ran the built-in mode-scan kernel only."""
+    fk = iiwa_fk
+    t, q, T = _iiwa_syms(fk)
+    rng = np.random.default_rng(41)
+    if first == "unit_rows":
+        head = cc.EqualityConstraint("posture", q[:3] - np.array([0.2, -0.4, 0.3]), gain=1.5, priority=0)
+    elif first == "constant_matrix":
+        A = rng.normal(size=(3, 7))
+        head = cc.EqualityConstraint("mix", cs.mtimes(A, q) - np.array([0.1, 0.0, -0.2]), gain=1.5, priority=0)
+    else:
+        A = rng.normal(size=(9, 7))
+        head = cc.EqualityConstraint("mix", cs.mtimes(A, q) - rng.normal(size=9) * 0.1, gain=1.5, priority=0)
+    pos = cc.EqualityConstraint("pos", T[:3, 3] - np.array([0.4, 0.1, 0.6]), gain=5.0, priority=1)
+    elbow = cc.SetConstraint("elbow", q[3], set_min=-1.0, set_max=1.0, priority=2)
+    rest = cc.EqualityConstraint("rest", q - 0.1, gain=0.3, priority=3)
+    Q, _ = skills.synthetic_inputs(fk, 256, seed=9, distribution="mixed")
+    for cons in ([head], [head, pos], [head, pos, elbow, rest]):
+        spec = cc.SkillSpecification("const_first", t, q, constraints=cons)
+        # (a tall first equality fixes the whole velocity: the set behind it never decides anything on these inputs)
+        ctrl = _check(spec, {"damping_factor": 1e-5}, Q, tol=1e-8,
+                      min_modes=2 if (len(cons) == 4 and first != "tall_constant_matrix") else 1)
+        assert ctrl.kernel_name.startswith("jit_"), ctrl.kernel_name
+
+
 def test_one_set_per_joint_of_a_seven_dof_arm_128_modes(iiwa_fk):
     """The Moe-2016 pattern (one 1-D SetConstraint per joint limit, ur5_moe2016_example2.ipynb cell 6) on the 7-DoF
     iiwa: 2^7 = 128 modes (pseudo_inverse.py:107-130 builds them all), beyond the 64 mode bodies of the instantiated
