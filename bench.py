@@ -28,8 +28,10 @@ The JSON line also carries
                 the same clock: config 2 (pose, 4096 and 16384), config 4 (QP,
                 16384: cold, and hot-started as the reference's solver is after
                 its first tick), config 3 at the config-5 batch (131072), each with
-                ms_per_step / kernel / roofline / cpu_baseline; and config 3 at
-                16384 as resident ticks fed ahead (one launch, device-side tickets)
+                ms_per_step / kernel / roofline / cpu_baseline; the on-device
+                rollouts of both controllers (256 / 64 ticks per launch); and
+                config 3 at 16384 as resident ticks fed ahead (one launch,
+                device-side tickets)
 
 Timing protocol: W untimed warm-up steps, then an untimed, time-based clock ramp
 (--ramp-ms of replays: a fresh GPU needs ~100 ms of work before its clocks
@@ -638,11 +640,17 @@ def main():
         # the other BASELINE configurations under the same clock; short brackets
         # (config 4 twice: cold, and hot-started from the tick's own working set - the reference's qpOASES instance
         # hot-starts every solve after the first, reactive_qp.py:491-513: the steady state of a control loop)
-        for (wl, b, hot) in (("pose", 4096, 0), ("pose", 16384, 0), ("qp", 16384, 0), ("qp", 16384, 1), ("stack", 131072, 0)):
-            ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, args.steps, args.warmup, qp_hot=hot,
+        # ... and the on-device rollouts of both controllers (solve -> clamp -> integrate, K ticks per launch: the
+        # notebooks' simulation loops; `roofline.frac` is null for them)
+        for (wl, b, hot, tpl) in (("pose", 4096, 0, 1), ("pose", 16384, 0, 1), ("qp", 16384, 0, 1), ("qp", 16384, 1, 1),
+                                  ("stack", 131072, 0, 1), ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
+            up = lambda v: -(-max(v, tpl) // tpl) * tpl              # noqa: E731  (a whole number of launches)
+            ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, up(max(args.steps, 8 * tpl)),
+                                            up(args.warmup), TPL=tpl, qp_hot=hot,
                                             ramp_ms=100.0, min_timed_ms=args.extras_timed_ms)
-            ent = dict({"name": "%s_B%d%s" % (wl, b, "_hot" if hot else ""), "n_gpus": world, "dtype": "f64"}, **ent)
-            if rank == 0 and args.cpu_baseline and world == 1 and not hot:
+            ent = dict({"name": "%s_B%d%s%s" % (wl, b, "_hot" if hot else "", "_rollout%d" % tpl if tpl > 1 else ""),
+                        "n_gpus": world, "dtype": "f64"}, **ent)
+            if rank == 0 and args.cpu_baseline and world == 1 and not hot and tpl == 1:
                 try:
                     ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(2.0, args.cpu_seconds / 3))
                 except Exception as exc:
