@@ -44,8 +44,9 @@ def _gain_fits(gain, m, label):
                                 "are: float, MX, DM, numpy.ndarray, and list "
                                 "of floats/ints")
         return len(gain) == m
-    raise TypeError("Unknown gain type in " + label + ". Supported are: "
-                    "float, MX, DM, numpy.ndarray, and list of floats/ints.")
+    # (the text the reference raises, constraints.py:62-64, letter for letter: callers may match on it)
+    raise TypeError("Unknown gain type in " + label + "." + "Supported are: float, MX, DM, numpy."
+                    + ".ndarray, and list of floats/ints.")
 
 
 def _bound_fits(bound, m, label, which):
@@ -115,6 +116,24 @@ class EqualityConstraint(BaseConstraint):
         if not self._check_sizes():
             raise ValueError("Gain and expression dimensions do not match.")
 
+    def __add__(self, cnstrB):
+        return _refuse_sum(self, cnstrB)
+
+
+def _refuse_sum(left, right):
+    """`cnstrA + cnstrB` (constraints.py:126-146, :271-297): the reference checks priority and constraint type and then
+    builds the combined gain by MX slice assignment - `gain[:A, :A] = self.gain; gain[:-B, :-B] = cnstrB.gain` with B
+    taken from the LEFT operand - whose outcome depends on CasADi's assignment semantics (a scalar fills the block)
+    and is not what the docstring promises.  The checks are reproduced; the concatenation itself is not guessed at."""
+    if not left.priority == right.priority:
+        raise TypeError("Added constraints must have same priority.")
+    if not left.constraint_type == right.constraint_type:
+        raise TypeError("Added constrains must have same constraint type")
+    raise NotImplementedError(
+        "adding constraints (%s + %s): the reference assembles the combined gain by MX slice assignment "
+        "(constraints.py:139-142) whose result cannot be reproduced without CasADi; build one constraint from "
+        "cs.vertcat of the expressions and the gain you mean" % (left.label, right.label))
+
 
 class SetConstraint(BaseConstraint):
     """Keep ``expression`` inside [set_min, set_max]
@@ -140,6 +159,9 @@ class SetConstraint(BaseConstraint):
         ok_min = _bound_fits(self.set_min, m, self.label, "set_min")
         ok_max = _bound_fits(self.set_max, m, self.label, "set_max")
         return ok_gain and ok_min and ok_max
+
+    def __add__(self, cnstrB):
+        return _refuse_sum(self, cnstrB)
 
 
 class VelocityEqualityConstraint(BaseConstraint):

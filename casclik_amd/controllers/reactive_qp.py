@@ -41,7 +41,8 @@ def _weights(weights, n, what):
     if isinstance(weights, (list, tuple, np.ndarray)):
         arr = np.asarray(weights, dtype=float).reshape(-1)
         if arr.size != n:
-            raise ValueError(what + " and variable dimensions do not match")
+            # (reactive_qp.py:76-78, :100-102, :129-131)
+            raise ValueError(what + " and " + what[:-len("_weights")] + " dimensions do not match")
         return arr
     raise TypeError("unsupported type for " + what)
 

@@ -287,9 +287,21 @@ def check_against_the_stored_figures():
     return worst_all
 
 
+def record_error_behaviour():
+    """what the reference raises for the constructions of error_cases.py: class and message digest per case"""
+    import json
+    import error_cases
+    out = {name: [kind, error_cases.digest(text)] for name, (kind, text) in error_cases.cases(cs, cc).items()}
+    path = os.path.join(HERE, "ref_errors.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path, len(out), "cases,", sum(1 for v in out.values() if v[0] != "ok"), "of them raise")
+
+
 def main():
     held = check_reference_held_outputs()
     held["figures_worst_px"] = check_against_the_stored_figures()
+    record_error_behaviour()
     out = {"refheld_n_prints": np.array(held["n_prints"]), "refheld_ur5_home_norm": np.array(held["ur5_home_norm"]),
            "refheld_figures_worst_px": np.array(held["figures_worst_px"])}
     for k, (name, robot, case, B, dist, times) in enumerate(PLAN):
