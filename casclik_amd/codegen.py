@@ -150,6 +150,10 @@ class TaskEmitter(object):
             expr = "(%s < %s ? 1.0 : 0.0)" % (args[0], args[1])
         elif op == "cmp_le":
             expr = "(%s <= %s ? 1.0 : 0.0)" % (args[0], args[1])
+        elif op == "cmp_eq":
+            expr = "(%s == %s ? 1.0 : 0.0)" % (args[0], args[1])
+        elif op == "cmp_ne":
+            expr = "(%s != %s ? 1.0 : 0.0)" % (args[0], args[1])
         elif op == "if_else":
             expr = "(%s != 0.0 ? %s : %s)" % (args[0], args[1], args[2])
         else:

@@ -86,8 +86,78 @@ class PseudoInverseController(BaseController):
         self.n_modes = 2 ** cnt["set"]
         self.n_state_var = spec.n_robot_var + (spec.n_virtual_var
                                                if spec.virtual_var is not None else 0)
+        # (pseudo_inverse.py:79-88: the stacked state and the list of its velocity symbols)
+        self.state_var = (cs.vertcat(spec.robot_var, spec.virtual_var) if spec.virtual_var is not None
+                          else cs.vertcat(spec.robot_var))
+        self.cntrl_var = [spec.robot_vel_var] + ([spec.virtual_vel_var] if spec.virtual_var is not None else [])
         self._skill_spec = spec
         self.create_activation_map()
+
+    def pinv(self, J):
+        """The controller's pseudo-inverse of a symbolic (or numeric) matrix (pseudo_inverse.py:92-105): "standard" is
+        cs.pinv; "damped" solves with J J' + lam I when J has at least as many columns as rows, else with J'J + lam I.
+        The kernels evaluate the same rule (clik_pinv_static.hpp); this method is the reference's public helper."""
+        J = J if isinstance(J, cs.MX) else cs.MX(J)
+        if self.options["pinv_method"] == "standard":
+            return cs.pinv(J)
+        lam = self.options["damping_factor"]
+        rows, cols = J.size()
+        if cols >= rows:
+            return cs.solve(cs.mtimes(J, J.T) + lam * cs.DM.eye(rows), J).T
+        return cs.solve(cs.mtimes(J.T, J) + lam * cs.DM.eye(cols), J.T)
+
+    def _tangent_cone_signature(self, cnstr):
+        from ..constraints import SetConstraint
+        if not isinstance(cnstr, SetConstraint):
+            raise TypeError("in_tangent_cone is only available for SetConstraint")
+        spec = self.skill_spec
+        args, names = [spec.time_var, spec.robot_var], ["time_var", "robot_var"]
+        rates, rate_names = [spec.robot_vel_var], ["robot_vel_var"]
+        # de/dt along the motion: the partial time derivative plus the Jacobians times the velocity symbols
+        # (pseudo_inverse.py:155-160)
+        rate = cs.jacobian(cnstr.expression, spec.time_var) + cs.jtimes(cnstr.expression, spec.robot_var,
+                                                                         spec.robot_vel_var)
+        if spec.virtual_var is not None:
+            args, names = args + [spec.virtual_var], names + ["virtual_var"]
+            rates, rate_names = rates + [spec.virtual_vel_var], rate_names + ["virtual_vel_var"]
+            rate = rate + cs.jtimes(cnstr.expression, spec.virtual_var, spec.virtual_vel_var)
+        if spec.input_var is not None:
+            args, names = args + [spec.input_var], names + ["input_var"]
+        return rate, args + rates, names + rate_names
+
+    def get_in_tangent_cone_function(self, cnstr):
+        """cs.Function `(time_var, robot_var[, virtual_var][, input_var], robot_vel_var[, virtual_vel_var]) -> 0 / 1`:
+        is a velocity inside the tangent cone of a one-dimensional SetConstraint (pseudo_inverse.py:132-190)?  Inside
+        the set (with the 1e-12 margins): yes; below it: only when the expression increases; above: only when it
+        decreases.  The kernels run this test after every mode (clik_pinv_static.hpp::cone_s); this is the reference's
+        public, host-evaluated form of it."""
+        rate, args, names = self._tangent_cone_signature(cnstr)
+        e, lo, hi = cnstr.expression, cnstr.set_min, cnstr.set_max
+        below_ok = cs.if_else(rate > 0.0, 1.0, 0.0)
+        above_ok = cs.if_else(rate < 0.0, 1.0, 0.0)
+        in_tc = cs.if_else(lo - e < 1e-12, cs.if_else(e - hi < 1e-12, 1.0, above_ok), below_ok)
+        label = "in_tc_" + cnstr.label.replace(" ", "_")
+        return cs.Function(label, args, [in_tc], names, ["in_tc_" + cnstr.label])
+
+    def get_in_tangent_cone_function_multidim(self, cnstr):
+        """The same for a multidimensional SetConstraint (pseudo_inverse.py:192-257): inside the box (margins 1e-12
+        per row): yes; outside, the outward direction is the mean of the signs of the distances to both bounds; when
+        every row has left its interval ("corner") the velocity must also make less than 45 degrees with the inward
+        direction, otherwise a negative outward component is enough (clik_pinv_static.hpp::cone_s)."""
+        rate, args, names = self._tangent_cone_signature(cnstr)
+        le, ue = cnstr.expression - cnstr.set_min, cnstr.expression - cnstr.set_max
+        row_above, row_below = le >= 1e-12, ue <= 1e-12
+        inside = cs.logic_and(cs.dot(row_above - 1, row_above - 1) == 0, cs.dot(row_below - 1, row_below - 1) == 0)
+        outward = (cs.sign(le) + cs.sign(ue)) / 2.0
+        same = cs.sign(le) == cs.sign(ue)
+        corner = cs.dot(same - 1, same - 1) == 0
+        along = cs.dot(outward, rate)
+        spread = (cs.norm_2(rate) + 1e-10) * cs.norm_2(outward)
+        corner_ok = cs.if_else(along < 0.0, cs.fabs(cs.dot(-outward, rate)) / spread < np.cos(np.pi / 4), 0.0)
+        going_in = cs.if_else(corner, corner_ok, along < 0.0)
+        in_tc = cs.if_else(inside, 1.0, going_in)
+        label = "in_tc_" + cnstr.label.replace(" ", "_")
+        return cs.Function(label, args, [in_tc], names, ["in_tc_" + cnstr.label])
 
     def create_activation_map(self):
         """Mode order (pseudo_inverse.py:107-130): bit patterns with set 0 as

@@ -61,6 +61,9 @@ class ReactiveQPController(BaseController):
             iterations.
     """
     controller_type = "ReactiveQPController"
+    options_info = """solver_name / solver_opts / initial_solver_opts: accepted as the reference accepts them (the solver
+    here is the device active set, clik_qp_static.hpp); function_opts: `jit` (instantiate a kernel for the skill's
+    structure, default True), `jit_values` (compile the skill's numbers in), `device`."""
     weight_shifter = 0.001   # mu of the eTaSL paper (reactive_qp.py:44)
 
     def __init__(self, skill_spec, robot_var_weights=None,
@@ -263,6 +266,75 @@ class ReactiveQPController(BaseController):
             # -s in [lb, ub] - J_q dq0:  s in [-ub, -lb], the point nearest zero
             slack.append(np.clip(0.0, -(ub - shift), -(lb - shift)))
         return None, cs.DM(np.concatenate(slack).reshape(-1, 1))
+
+    def get_cost_expr(self):
+        """H of  min v' H v  over v = [robot_vel; virtual_vel; slack]: diag(mu w_robot, mu w_virtual, mu + w_slack)
+        (reactive_qp.py:175-189).  The kernels carry the same diagonal (`clik_qp_data_batch`); this is the reference's
+        public, symbolic form."""
+        mu = self.weight_shifter
+        spec = self.skill_spec
+        parts = [mu * np.asarray(self._robot_var_weights, dtype=float).reshape(-1)]
+        if spec.n_virtual_var > 0:
+            parts.append(mu * np.asarray(self._virtual_var_weights, dtype=float).reshape(-1)[:spec.n_virtual_var])
+        if spec.n_slack_var > 0:
+            parts.append(mu + np.asarray(self._slack_var_weights, dtype=float).reshape(-1))
+        return cs.diag(cs.MX(np.concatenate(parts)))
+
+    def get_constraints_expr(self):
+        """(A, lbA, ubA) of  lbA <= A v <= ubA  as expressions of (t, q[, x][, y]) (reactive_qp.py:191-246): per
+        constraint the Jacobians w.r.t. the robot and virtual variables, a block of -I in the slack columns of a soft
+        constraint, and bounds  -de/dt - K e  (equality),  -de/dt + K (set_min|max - e)  (set),  -de/dt + target
+        (velocity equality),  -de/dt + set_min|max  (velocity set).  The kernels evaluate these rows in closed form
+        (clik_qp_static.hpp); this is the reference's public, symbolic form - expressions holding an orientation-error
+        node have no symbolic derivative here and raise NotImplementedError."""
+        spec = self.skill_spec
+        n_slack = spec.n_slack_var
+        rows, lows, highs = [], [], []
+        at = 0
+
+        def times_gain(gain, vec, m):
+            if isinstance(gain, (int, float)):
+                return gain * vec
+            if isinstance(gain, cs.MX):
+                return cs.mtimes(gain, vec) if gain.size()[1] == m and gain.size()[0] == m and m > 1 else gain * vec
+            arr = np.asarray(gain.toarray() if isinstance(gain, cs.DM) else gain, dtype=float)
+            if arr.size == 1:
+                return float(arr.reshape(-1)[0]) * vec
+            if arr.size == m:
+                return cs.MX(arr.reshape(m, 1)) * vec
+            return cs.mtimes(cs.MX(arr.reshape(m, m)), vec)
+
+        def column(val, m):
+            if isinstance(val, cs.MX):
+                return val
+            arr = np.asarray(val.toarray() if isinstance(val, cs.DM) else val, dtype=float).reshape(-1)
+            return cs.MX((np.full(m, arr[0]) if arr.size == 1 else arr).reshape(m, 1))
+
+        for cn in spec.constraints:
+            m = cn.expression.size()[0]
+            block = cn.jacobian(spec.robot_var)
+            if spec.virtual_var is not None:
+                block = cs.horzcat(block, cn.jacobian(spec.virtual_var))
+            low = high = -cn.jacobian(spec.time_var)
+            if isinstance(cn, EqualityConstraint):
+                low = high = low - times_gain(cn.gain, cn.expression, m)
+            elif isinstance(cn, SetConstraint):
+                low = low + times_gain(cn.gain, column(cn.set_min, m) - cn.expression, m)
+                high = high + times_gain(cn.gain, column(cn.set_max, m) - cn.expression, m)
+            elif isinstance(cn, VelocityEqualityConstraint):
+                low = high = low + column(cn.target, m)
+            else:
+                low, high = low + column(cn.set_min, m), high + column(cn.set_max, m)
+            if n_slack > 0:
+                slack_cols = np.zeros((m, n_slack))
+                if cn.constraint_type == "soft":
+                    slack_cols[:, at:at + m] = -np.eye(m)
+                    at += m
+                block = cs.horzcat(block, cs.MX(slack_cols))
+            rows.append(block)
+            lows.append(low)
+            highs.append(high)
+        return cs.vertcat(*rows), cs.vertcat(*lows), cs.vertcat(*highs)
 
     def _host_rows(self, time_var0, robot_var0, virtual_var0, robot_vel_var0, input_var0):
         """Rows of the QP at ONE state, evaluated from the expression graph on the host (setup-time

@@ -137,7 +137,7 @@ def _s_neg(a):
 _UNARY_NUMERIC = {
     "sin": math.sin, "cos": math.cos, "sqrt": math.sqrt, "exp": math.exp,
     "log": math.log, "fabs": abs, "tan": math.tan,
-    "sign": lambda v: (v > 0) - (v < 0),
+    "sign": lambda v: float(v > 0) - float(v < 0),
 }
 
 
@@ -421,6 +421,30 @@ class MX(object):
 
     def __ge__(self, o):
         return _elementwise(lambda a, b: Scalar("cmp_le", (b, a)), self, o)
+
+    # `==` / `!=` build 0/1 valued nodes too, as CasADi's MX does (the reference's own multidimensional tangent-cone
+    # function is written with them, pseudo_inverse.py:229-236); so an MX hashes by identity and has no truth value
+    # unless it is a constant
+    def __eq__(self, o):
+        if o is None:
+            return False
+        return _elementwise(lambda a, b: Scalar("cmp_eq", (a, b)), self, o)
+
+    def __ne__(self, o):
+        if o is None:
+            return True
+        return _elementwise(lambda a, b: Scalar("cmp_ne", (a, b)), self, o)
+
+    def __hash__(self):
+        return id(self)
+
+    def __bool__(self):
+        try:
+            value = self.toarray()
+        except Exception:
+            raise TypeError("the truth value of a symbolic MX expression is undefined (compare with `is`, or "
+                            "evaluate it through a cs.Function)")
+        return bool(_np.all(value != 0.0))
 
     def __repr__(self):
         if self._a.size <= 12:
@@ -919,7 +943,10 @@ def _eval_scalar(s, env, memo):
         elif op == "mul":
             r = a[0] * a[1]
         elif op == "div":
-            r = a[0] / a[1]
+            # (IEEE semantics like CasADi's: x / 0 is inf or nan, not an exception - the reference's multidimensional
+            # tangent-cone function divides by a zero norm on the branch an if_else discards)
+            r = a[0] / a[1] if a[1] != 0.0 else (float("nan") if a[0] == 0.0 or a[0] != a[0]
+                                                  else math.copysign(float("inf"), a[0]) * math.copysign(1.0, a[1]))
         elif op == "neg":
             r = -a[0]
         elif op == "pow":
@@ -930,6 +957,10 @@ def _eval_scalar(s, env, memo):
             r = 1.0 if a[0] < a[1] else 0.0
         elif op == "cmp_le":
             r = 1.0 if a[0] <= a[1] else 0.0
+        elif op == "cmp_eq":
+            r = 1.0 if a[0] == a[1] else 0.0
+        elif op == "cmp_ne":
+            r = 1.0 if a[0] != a[1] else 0.0
         elif op == "if_else":
             r = a[1] if a[0] != 0.0 else a[2]
         elif op in _UNARY_NUMERIC:
@@ -1082,3 +1113,27 @@ def jacobian(expr, var):
     symbolic m x n matrix of partial derivatives."""
     from . import autodiff
     return autodiff.jacobian(expr, var)
+
+
+def jtimes(expr, var, vec):
+    """``cs.jtimes(expr, var, vec)``: the Jacobian of ``expr`` w.r.t. ``var`` times ``vec`` (reference use:
+    constraints.py:75-82, pseudo_inverse.py:155-160)."""
+    return mtimes(jacobian(expr, var), vec)
+
+
+def logic_and(a, b):
+    """0/1 valued elementwise conjunction (pseudo_inverse.py:230)"""
+    return (_wrap_mx(a) != 0.0) * (_wrap_mx(b) != 0.0)
+
+
+def logic_or(a, b):
+    return ((_wrap_mx(a) != 0.0) + (_wrap_mx(b) != 0.0)) != 0.0
+
+
+def logic_not(a):
+    return _wrap_mx(a) == 0.0
+
+
+def _wrap_mx(a):
+    return a if isinstance(a, MX) else MX(a)
+

@@ -36,6 +36,9 @@ def cases(cs, cc):
     run("eq_add_ok", add_ok)
     run("set_min_str", lambda: cc.SetConstraint(label="s", expression=q, set_min="low", set_max=[1, 1, 1]))
     run("set_max_str", lambda: cc.SetConstraint(label="s", expression=q, set_min=[0, 0, 0], set_max="hi"))
+    run("set_min_list", lambda: cc.SetConstraint(label="s", expression=q, set_min=[0, 0, 0], set_max=np.array([1.0, 1.0, 1.0])))
+    run("set_ndarray_ok", lambda: cc.SetConstraint(label="s", expression=q, set_min=np.zeros(3), set_max=np.ones(3)))
+    run("set_default_bounds_ok", lambda: cc.SetConstraint(label="s", expression=q[0]))
     run("set_dims", lambda: cc.SetConstraint(label="s", expression=q, set_min=[0, 0], set_max=[1, 1, 1]))
     run("set_gain_dims", lambda: cc.SetConstraint(label="s", expression=q, set_min=[0, 0, 0], set_max=[1, 1, 1], gain=[1.0, 2.0]))
     def set_add_prio():

@@ -298,12 +298,29 @@ def record_error_behaviour():
     print("wrote", path, len(out), "cases,", sum(1 for v in out.values() if v[0] != "ok"), "of them raise")
 
 
+def record_tangent_cone_api(out):
+    import make_ref_golden_cases
+    for name, (fn, rows) in make_ref_golden_cases.tangent_cone_api_cases(cs, cc).items():
+        vals = [float(np.asarray(fn(*row).full()).ravel()[0]) for row in rows]
+        out["tcapi_" + name] = np.array(vals)
+        print("tangent-cone function %-4s in the cone for %d of %d argument rows" % (name, int(sum(vals)), len(vals)))
+
+
+def record_pinv_api(out):
+    import make_ref_golden_cases
+    for name, J, val in make_ref_golden_cases.pinv_api_cases(cs, cc):
+        out["pinvapi_" + name] = val
+    print("pinv(): %d matrices recorded" % len([k for k in out if k.startswith("pinvapi_")]))
+
+
 def main():
     held = check_reference_held_outputs()
     held["figures_worst_px"] = check_against_the_stored_figures()
     record_error_behaviour()
     out = {"refheld_n_prints": np.array(held["n_prints"]), "refheld_ur5_home_norm": np.array(held["ur5_home_norm"]),
            "refheld_figures_worst_px": np.array(held["figures_worst_px"])}
+    record_tangent_cone_api(out)
+    record_pinv_api(out)
     for k, (name, robot, case, B, dist, times) in enumerate(PLAN):
         urdf, root, tip = ROBOTS[robot]
         chain = load_chain(urdf, root, tip)

@@ -111,3 +111,69 @@ def test_the_fixture_generator_reproduced_the_stored_figures_through_the_referen
     The fixture records the worst deviation of that run."""
     assert "refheld_figures_worst_px" in refpins.PINS.files
     assert float(refpins.PINS["refheld_figures_worst_px"]) < 1.0
+
+
+def test_public_tangent_cone_functions_equal_the_reference_packages():
+    """PseudoInverseController.get_in_tangent_cone_function / _multidim (pseudo_inverse.py:132-257)
+    as PUBLIC methods: built by the product's controller for the toy skills of make_ref_golden.py and evaluated on the
+    same 160 argument rows, they return what the reference's functions returned (fixtures `tcapi_one`, `tcapi_box`)."""
+    import casclik_amd as cc
+    from casclik_amd import sym as cs
+    import make_ref_golden_cases as cases            # (the case table, importable without the reference)
+    got = cases.tangent_cone_api_cases(cs, cc)
+    for name, (fn, rows) in got.items():
+        vals = np.array([float(np.asarray(fn(*row).full()).ravel()[0]) for row in rows])
+        ref = refpins.PINS["tcapi_" + name]
+        assert np.array_equal(vals, ref), (name, int((vals != ref).sum()))
+        assert 40 < ref.sum() < 130
+
+
+def test_public_pinv_method_equals_the_reference_packages():
+    """PseudoInverseController.pinv (pseudo_inverse.py:92-105) as a public method on constant matrices:
+    wide, square, tall; damped (two damping factors) and "standard" - against the reference's own method over the
+    stand-in (fixtures `pinvapi_*`)."""
+    import casclik_amd as cc
+    from casclik_amd import sym as cs
+    import make_ref_golden_cases as cases
+    got = cases.pinv_api_cases(cs, cc)
+    assert len(got) == 8
+    for name, J, val in got:
+        ref = refpins.PINS["pinvapi_" + name]
+        assert val.shape == ref.shape == (J.shape[1], J.shape[0])
+        assert np.abs(val - ref).max() < 1e-10 * (1.0 + np.abs(ref).max()), (name, np.abs(val - ref).max())
+
+
+@pytest.mark.parametrize("name", [n for n in refpins.QP_NAMES if n != "iiwa_qp_pose"])
+def test_public_qp_expressions_equal_the_reference_packages(name):
+    """ReactiveQPController.get_cost_expr / get_constraints_expr (reactive_qp.py:175-246) as PUBLIC,
+    symbolic methods: evaluated at the fixtures' inputs they give the H, A, lbA, ubA the reference's own functions gave
+    (1e-14).  (`iiwa_qp_pose` holds an orientation-error node, which has no symbolic derivative in this front-end: the
+    method says so; the kernels differentiate it in closed form.)"""
+    import casclik_amd as cc
+    from casclik_amd import sym as cs
+    built = refpins.product_skill(name)
+    spec = built["spec"]
+    ctrl = cc.ReactiveQPController(skill_spec=spec, options=dict(built["options"]) if built["options"] else None)
+    H = ctrl.get_cost_expr()
+    A, low, high = ctrl.get_constraints_expr()
+    Q, Y, X, times = refpins.arrays(name)
+    has_y = spec.input_var is not None and spec._has_input
+    args = [spec.time_var, spec.robot_var] + ([spec.virtual_var] if spec.virtual_var is not None else []) + (
+        [spec.input_var] if has_y else [])
+    rows = cs.Function("rows", args, [A, low, high])
+    assert np.abs(np.diag(np.asarray(H.toarray())) - refpins.PINS[name + "_H"][0]).max() < 1e-15
+    big = lambda v: np.clip(np.asarray(v, dtype=float).ravel(), -1e9, 1e9)        # noqa: E731  (the 1e10 "no bound" values)
+    for b in range(min(16, len(Q))):
+        vals = [float(times[0]), Q[b]] + ([X[b]] if X is not None else []) + ([Y[b]] if has_y else [])
+        Ab, lb, ub = [np.asarray(v.full()) for v in rows(*vals)]
+        assert np.abs(Ab - refpins.PINS[name + "_A"][b]).max() < 1e-13
+        assert np.abs(big(lb) - big(refpins.PINS[name + "_lbA"][b])).max() < 1e-12
+        assert np.abs(big(ub) - big(refpins.PINS[name + "_ubA"][b])).max() < 1e-12
+
+
+def test_orientation_error_has_no_symbolic_qp_rows():
+    import casclik_amd as cc
+    built = refpins.product_skill("iiwa_qp_pose")
+    ctrl = cc.ReactiveQPController(skill_spec=built["spec"])
+    with pytest.raises(NotImplementedError):
+        ctrl.get_constraints_expr()
