@@ -167,7 +167,9 @@ class SetConstraint(BaseConstraint):
 class VelocityEqualityConstraint(BaseConstraint):
     """Prescribe the time derivative of ``expression``:  J v = target - d expr/dt
     (reference: constraints.py:299-333; sizes are not checked there either)."""
-    constraint_class = "VelocityEqualityConstraint"
+    # (the reference leaves the base class's name on its two velocity constraints: constraints.py:299-368 set no
+    # `constraint_class`; kept, since `repr` and callers see it)
+    constraint_class = "BaseConstraint"
 
     def __init__(self, label, expression, gain=1.0, constraint_type="hard",
                  priority=1, target=0.0, slack_weight=1.0):
@@ -181,7 +183,9 @@ class VelocityEqualityConstraint(BaseConstraint):
 class VelocitySetConstraint(BaseConstraint):
     """Bound the time derivative of ``expression``
     (reference: constraints.py:336-368; defaults -/+1e10, no size check)."""
-    constraint_class = "VelocitySetConstraint"
+    # (the reference leaves the base class's name on its two velocity constraints: constraints.py:299-368 set no
+    # `constraint_class`; kept, since `repr` and callers see it)
+    constraint_class = "BaseConstraint"
 
     def __init__(self, label, expression, gain=1.0, set_min=-_BIG, set_max=_BIG,
                  constraint_type="hard", priority=1, slack_weight=1.0):

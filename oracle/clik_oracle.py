@@ -313,7 +313,12 @@ def attribute_views(evaluator, constraints):
 
 
 def _cls(cnstr):
-    return cnstr.constraint_class
+    # (the Python class, as the reference's isinstance tests see it - `constraint_class` is "BaseConstraint" on the two
+    # velocity constraints, constraints.py:299-368)
+    for klass in type(cnstr).__mro__:
+        if klass.__name__ in ("EqualityConstraint", "SetConstraint", "VelocityEqualityConstraint", "VelocitySetConstraint"):
+            return klass.__name__
+    return type(cnstr).__name__
 
 
 def _num(val, m):

@@ -313,10 +313,20 @@ def record_pinv_api(out):
     print("pinv(): %d matrices recorded" % len([k for k in out if k.startswith("pinvapi_")]))
 
 
+def record_api_values():
+    import json
+    import make_ref_golden_cases
+    path = os.path.join(HERE, "ref_api_values.json")
+    with open(path, "w") as f:
+        json.dump(make_ref_golden_cases.api_value_cases(cs, cc), f, indent=1, sort_keys=True)
+    print("wrote", path)
+
+
 def main():
     held = check_reference_held_outputs()
     held["figures_worst_px"] = check_against_the_stored_figures()
     record_error_behaviour()
+    record_api_values()
     out = {"refheld_n_prints": np.array(held["n_prints"]), "refheld_ur5_home_norm": np.array(held["ur5_home_norm"]),
            "refheld_figures_worst_px": np.array(held["figures_worst_px"])}
     record_tangent_cone_api(out)

@@ -48,3 +48,39 @@ def pinv_api_cases(cs, cc):
             val = res.full() if hasattr(res, "full") else res.toarray()
             out.append(("%s_%dx%d" % (opt_name, shape[0], shape[1]), J, np.asarray(val, dtype=float)))
     return out
+
+
+def api_value_cases(cs, cc):
+    """Values of the small public methods - BaseConstraint.size / jacobian / jtimes / nullspace, the constraint classes'
+    defaults and class attributes, SkillSpecification's counters, flags, priority sort and re-sort on assignment
+    (constraints.py:21-86, skill_specification.py:60-250) - on a toy skill, as one JSON-able dict."""
+    def num(v):
+        v = v.full() if hasattr(v, "full") else (v.toarray() if hasattr(v, "toarray") else v)
+        return np.round(np.asarray(v, dtype=float), 10).tolist()
+    t = cs.MX.sym("t"); q = cs.MX.sym("q", 3); dq = cs.MX.sym("dq", 3); x = cs.MX.sym("x"); dx = cs.MX.sym("dx"); y = cs.MX.sym("y", 2)
+    out = {}
+    e = cs.vertcat(q[0] * cs.sin(q[1]) + t * x, q[2] ** 2 - y[0] * q[0])
+    c = cc.EqualityConstraint(label="a", expression=e, gain=2.0, constraint_type="soft", priority=3)
+    pt = [0.3, np.array([0.2, -0.4, 0.7]), 1.5, np.array([0.5, -0.1]), np.array([1.0, 2.0, -1.0])]
+    def F(expr): return cs.Function("f", [t, q, x, y, dq], [expr])(*pt)
+    out["size"] = list(c.size())
+    out["jac_q"] = num(F(c.jacobian(q))); out["jac_t"] = num(F(c.jacobian(t))); out["jac_x"] = num(F(c.jacobian(x))); out["jac_y"] = num(F(c.jacobian(y)))
+    out["jtimes"] = num(F(c.jtimes(q, dq)))
+    try: out["nullspace"] = num(F(c.nullspace(q)))
+    except Exception as ex: out["nullspace"] = "EXC " + type(ex).__name__
+    s1 = cc.SetConstraint(label="s1", expression=q[0], set_min=-1.0, set_max=1.0, priority=5, constraint_type="soft")
+    s2 = cc.SetConstraint(label="s2", expression=q[1], priority=1)
+    ve = cc.VelocityEqualityConstraint(label="ve", expression=q[2], target=0.2, priority=2, constraint_type="soft")
+    vs = cc.VelocitySetConstraint(label="vs", expression=q, priority=2)
+    out["defaults"] = [num(s2.set_min), num(s2.set_max), num(vs.set_min), num(vs.set_max), s2.gain, ve.gain, vs.gain, s2.constraint_type, ve.slack_weight]
+    spec = cc.SkillSpecification("s", t, q, dq, virtual_var=x, virtual_vel_var=dx, input_var=y, constraints=[c, s1, s2, ve, vs])
+    def snap(spec): return {"order": [k.label for k in spec.constraints], "n": [spec.n_robot_var, spec.n_virtual_var, spec.n_input_var, spec.n_slack_var], "has": [bool(spec._has_virtual), bool(spec._has_input)], "count": dict(spec.count_constraints())}
+    out["spec"] = snap(spec)
+    spec.constraints = [vs, ve, s2, s1]
+    out["spec_after_set"] = snap(spec)
+    spec2 = cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint(label="only", expression=q)])
+    out["spec2"] = snap(spec2)
+    out["attrs"] = {k: getattr(spec2, k) for k in ("label",)}
+    for name, obj in (("eq", c), ("set", s1), ("veq", ve), ("vset", vs)):
+        out["cls_" + name] = [obj.constraint_class, obj.constraint_type, obj.priority, obj.label]
+    return out

@@ -397,3 +397,21 @@ def test_error_behaviour_equals_the_reference_packages():
             assert kind == deliberate[name], (name, kind)
             continue
         assert [kind, error_cases.digest(text)] == ref[name], (name, kind, text, ref[name])
+
+
+def test_small_public_methods_give_the_reference_packages_values():
+    """tests/golden/make_ref_golden_cases.py::api_value_cases through the product against the dict the REFERENCE classes
+    produced (tests/golden/ref_api_values.json): Jacobians, jtimes, nullspace, sizes, defaults (+-1e10 bounds, gains),
+    class attributes (the two velocity constraints report "BaseConstraint", as in the reference), the skill's counters,
+    dependence flags, priority sort and the re-sort when `constraints` is assigned."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_ref_golden_cases
+    ref = json.load(open(os.path.join(here, "golden", "ref_api_values.json")))
+    got = json.loads(json.dumps(make_ref_golden_cases.api_value_cases(cs, cc), sort_keys=True))
+    assert set(got) == set(ref)
+    for key in ref:
+        assert got[key] == ref[key], (key, got[key], ref[key])
