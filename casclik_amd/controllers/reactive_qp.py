@@ -133,12 +133,23 @@ class ReactiveQPController(BaseController):
     def options(self, opt):
         if opt is None or not isinstance(opt, dict):
             opt = {}
+        # the dictionary a caller reads back has the reference's keys and defaults (reactive_qp.py:141-173): the solver
+        # entries are accepted and kept (the solver here is the device active set), `function_opts["jit"]` decides
+        # whether a kernel is instantiated for the skill's structure
         opt.setdefault("solver_name", "qpoases")
         sopts = opt.setdefault("solver_opts", {})
         sopts.setdefault("print_time", False)
+        if opt["solver_name"] == "qpoases":
+            sopts.setdefault("printLevel", "none")
+        elif opt["solver_name"] == "ooqp":
+            sopts.setdefault("print_level", 0)
+        sopts.setdefault("jit", True)
+        sopts.setdefault("jit_options", {"flags": "-O2"})
         opt.setdefault("initial_solver_opts", sopts)
         fopts = opt.setdefault("function_opts", {})
+        fopts.setdefault("jit", True)
         fopts.setdefault("print_time", False)
+        fopts.setdefault("jit_options", {"flags": "-O2"})
         self._options = opt
 
     # -- setup ------------------------------------------------------------------

@@ -83,4 +83,24 @@ def api_value_cases(cs, cc):
     out["attrs"] = {k: getattr(spec2, k) for k in ("label",)}
     for name, obj in (("eq", c), ("set", s1), ("veq", ve), ("vset", vs)):
         out["cls_" + name] = [obj.constraint_class, obj.constraint_type, obj.priority, obj.label]
+    # controllers at construction: the mode table for 0 ... 4 SetConstraints (pseudo_inverse.py:107-130), counters, option
+    # defaults of both controllers (pseudo_inverse.py:42-66, reactive_qp.py:141-173)
+    q5 = cs.MX.sym("q", 5)
+    for n in range(0, 5):
+        cons = [cc.EqualityConstraint(label="e", expression=q5[0])] + [
+            cc.SetConstraint(label="s%d" % i, expression=q5[i], set_min=-1.0, set_max=1.0, priority=i) for i in range(n)]
+        ctrl = cc.PseudoInverseController(skill_spec=cc.SkillSpecification("s", t, q5, constraints=cons))
+        out["pinv_ctrl_%d_sets" % n] = {
+            "map": [list(map(int, m)) for m in ctrl.activation_map], "n_modes": ctrl.n_modes,
+            "n_set": ctrl.n_set_constraints, "n_state": ctrl.n_state_var,
+            "opts": {k: ctrl.options[k] for k in ("pinv_method", "damping_factor", "feedforward", "multidim_sets",
+                                                  "converge_final_set_to_max")},
+            "optkeys": sorted(ctrl.options.keys())}
+    soft = cc.SkillSpecification("s", t, q5, constraints=[cc.EqualityConstraint(label="e", expression=q5[0],
+                                                                                constraint_type="soft")])
+    qp = cc.ReactiveQPController(skill_spec=soft)
+    out["qp_ctrl"] = {"optkeys": sorted(qp.options.keys()), "solver_name": qp.options["solver_name"],
+                      "solver_opts": {k: qp.options["solver_opts"][k] for k in sorted(qp.options["solver_opts"])},
+                      "function_opts": {k: qp.options["function_opts"][k] for k in sorted(qp.options["function_opts"])},
+                      "mu": qp.weight_shifter, "type": qp.controller_type}
     return out
