@@ -1137,3 +1137,25 @@ def logic_not(a):
 def _wrap_mx(a):
     return a if isinstance(a, MX) else MX(a)
 
+
+# the common base of CasADi's matrix types, for `isinstance(w, cs.GenericMatrixCommon)` (reactive_qp.py:70)
+GenericMatrixCommon = (MX, DM)
+
+
+def trace(a):
+    """sum of the diagonal of a square matrix expression"""
+    a = _wrap_mx(a)
+    rows, cols = a.size()
+    if rows != cols:
+        raise ValueError("trace of a %d x %d matrix" % (rows, cols))
+    total = a[0, 0]
+    for i in range(1, rows):
+        total = total + a[i, i]
+    return total
+
+
+def skew(v):
+    """the cross-product matrix of a 3-vector: skew(a) b = a x b"""
+    v = _wrap_mx(v)
+    return vertcat(horzcat(0.0, -v[2], v[1]), horzcat(v[2], 0.0, -v[0]), horzcat(-v[1], v[0], 0.0))
+
