@@ -109,3 +109,36 @@ def test_hip_qp_reproduces_the_error_decay_of_the_frame_figures(ur5_fk, which, f
     t_sim, log_e = cf.simulate_frame_error(error_norm, solve)
     worst, n = cf.deviation_in_pixels(figure, "qp", t_sim, log_e, above=above)
     assert n >= least and worst < PIXELS, (worst, n)
+
+
+@pytest.mark.parametrize("case", ["qp_point", "pinv_point", "qp_traj", "pinv_traj", "qp_path"])
+def test_on_device_rollouts_reproduce_the_cart_figures(case):
+    """The same stored figures through the ON-DEVICE loop (solve -> clamp -> integrate inside one launch,
+    `rollout_batch`: SURVEY 8(f).1): 1200 ticks in launches of four, the speed of each launch's last tick and the
+    position it ends on sampled against the digitised curves.  (The pinv runs saturate at 0.275 m/s as the notebook's
+    loop does; the pinv PATH run also clamps the path speed, which the rollout leaves free - not run here.)"""
+    kind, spec, dt, p0, virt = cf.build(case)
+    ctrl = (cc.ReactiveQPController(skill_spec=spec, robot_var_weights=[1.0]) if kind == "qp"
+            else cc.PseudoInverseController(skill_spec=spec))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    chunk = 4
+    p, x = np.array([[p0]]), np.array([[0.0]])
+    ts, ps, dps = [], [], []
+    for k in range(0, cf.N_TICKS - chunk, chunk):
+        times = dt * np.arange(k, k + chunk)
+        res = ctrl.rollout_batch(times, p, dt=dt, max_speed=cf.MAX_SPEED if kind == "pinv" else 0.0,
+                                 virtual_var=x if virt else None)
+        if virt:
+            p, x, dp = res[0], res[1], res[2]
+        else:
+            p, dp = res[0], res[1]
+        ts.append(dt * (k + chunk - 1))        # the launch's last tick: its speed ...
+        dps.append(float(dp[0, 0]))
+        ps.append(float(p[0, 0]))              # ... and the position it integrates to, one tick later
+    ts, ps, dps = np.array(ts), np.array(ps), np.array(dps)
+    worst, n = cf.deviation_in_pixels(case, "dp", ts, dps)
+    assert n > 60 and worst < PIXELS, (case, "dp", worst)
+    if not case.endswith("point"):
+        worst, n = cf.deviation_in_pixels(case, "p", ts + dt, ps)
+        assert n > 60 and worst < PIXELS, (case, "p", worst)
