@@ -1415,8 +1415,9 @@ static int qp_check_args(const clik_qp* h, int64_t B, const double* q, const dou
     if (B < 0) return fail(CLIK_EINVAL, "negative batch size");
     const DevSkill& S = h->host;
     if (B > 0 && !q) return fail(CLIK_EINVAL, "q must be a device pointer");
-    if (S.d.n_x > 0 && !x) return fail(CLIK_EINVAL, "skill has virtual_var: x required");
-    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    // (an empty batch has no rows to point at: a zero-row device tensor's data pointer is null)
+    if (B > 0 && S.d.n_x > 0 && !x) return fail(CLIK_EINVAL, "skill has virtual_var: x required");
+    if (B > 0 && S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     return CLIK_OK;
 }
 

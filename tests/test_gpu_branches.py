@@ -510,3 +510,21 @@ def test_qp_rollout_with_virtual_variable_matches_the_host_loop(ur5_fk):
     assert (status == 0).all()
     assert np.abs(qf - q).max() < 1e-7 and np.abs(xf - x).max() < 1e-7
     assert np.abs(dx_last - rdx).max() < 1e-7 and np.abs(slack - rsl).max() < 1e-6
+
+
+def test_empty_batches_come_back_empty(iiwa_fk):
+    """no instance: both controllers return arrays with zero rows (the C ABI returns CLIK_OK without a launch), for
+    the tick and for the on-device rollout"""
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    Q, Y = np.zeros((0, 7)), np.zeros((0, 7))
+    dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    assert dq.shape == (0, 7) and mode.shape == (0,)
+    q1, dq1, _ = ctrl.rollout_batch(np.zeros(3), Q, input_var=Y, dt=1e-3)
+    assert q1.shape == (0, 7) and dq1.shape == (0, 7)
+    qp = cc.ReactiveQPController(skill_spec=skills.qp_skill(iiwa_fk))
+    qp.setup_problem_functions()
+    qp.setup_solver()
+    dq, _, slack, status = qp.solve_batch(0.0, Q, input_var=Y)
+    assert dq.shape == (0, 7) and status.shape == (0,) and slack.shape[0] == 0
