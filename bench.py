@@ -532,33 +532,35 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     return entry, (spec, opts, Q, Y)
 
 
-def measure_resident(fk, dist_name, seed, B=16384, short=20000):
-    """BASELINE config 3 at 16384 instances through clik_pinv_resident_run with every ticket published ahead
+def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4):
+    """BASELINE config 3 at 16384 instances through clik_pinv_resident_run over a ring of `ring` input / output slots
+    (a different synthetic batch in every slot; tick k uses slot (k - 1) % ring) with every ticket published ahead
     (tools/resident_probe.py is the long form, closed loop included)."""
     import torch
     import casclik_amd as cc
     from casclik_amd import skills
     ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(fk), options=dict(skills.STACK_OPTIONS))
     ctrl.setup_problem_functions()
-    Q, Y = skills.synthetic_inputs(fk, B, seed=seed, distribution=dist_name)
-    Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
-    ref = ctrl.solve_batch(0.0, Qd, input_var=Yd)
+    slots = [skills.synthetic_inputs(fk, B, seed=seed + 17 * s, distribution=dist_name) for s in range(ring)]
+    Qr = torch.stack([torch.from_numpy(q).cuda() for q, _ in slots]).contiguous()
+    Yr = torch.stack([torch.from_numpy(y).cuda() for _, y in slots]).contiguous()
+    refs = [ctrl.solve_batch(0.0, Qr[s], input_var=Yr[s]) for s in range(ring)]
 
     def run(nt):
         best = None
         for _ in range(3):
             feeder = torch.cuda.Stream(priority=-1)
             torch.cuda.synchronize()
-            r = ctrl.resident_start(Qd, Yd, nt, timeout_s=3.0)
+            r = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=ring)
             time.sleep(0.01)
             t0 = time.perf_counter()
             ctrl.resident_feed(r, nt, closed_loop=False, timeout_s=3.0, stream=feeder)
             r["stream"].synchronize()
             el = time.perf_counter() - t0
             feeder.synchronize()
-            if not (torch.equal(r["out"], ref[0]) and torch.equal(r["mode"], ref[2])
-                    and int(r["done"].min()) == nt):
-                raise RuntimeError("resident ticks: output differs from the launched tick")
+            same = all(torch.equal(r["out"][s], refs[s][0]) and torch.equal(r["mode"][s], refs[s][2]) for s in range(ring))
+            if not (same and int(r["done"].min()) == nt):
+                raise RuntimeError("resident ticks: an output slot differs from the launched tick on that slot's inputs")
             best = el if best is None else min(best, el)
         return best
     t_short, t_long = run(short), run(3 * short)
@@ -567,12 +569,14 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000):
     return {
         "value": B / per_tick, "unit": "instance-steps/s", "ms_per_step": per_tick * 1e3,
         "config": {"workload": "BASELINE config 3: %d x iiwa priority stack as RESIDENT ticks (one launch; device-side "
-                               "tickets, all published ahead of the kernel)" % B, "batch_per_gpu": B,
-                   "inputs": "%s seed %d" % (dist_name, seed), "kernel": ctrl.kernel_variant(B) + "/resident",
+                               "tickets published ahead of the kernel; inputs and outputs in a ring of %d slots, a "
+                               "different batch in each)" % (B, ring), "batch_per_gpu": B, "ring_depth": ring,
+                   "inputs": "%s seeds %s" % (dist_name, [seed + 17 * s for s in range(ring)]),
+                   "kernel": ctrl.kernel_variant(B) + "/resident",
                    "timing": "one resident launch of %d ticks, host clock from the producer's launch to the kernel's exit "
-                             "(best of 3), divided by the ticks; outputs checked equal to the launched tick's; "
-                             "`slope_us_per_tick`: between that run and one of %d ticks (a run has a fixed part of "
-                             "about 2 ms around its ticks)" % (3 * short, short),
+                             "(best of 3), divided by the ticks; every output slot checked equal to a launched tick on "
+                             "that slot's inputs; `slope_us_per_tick`: between that run and one of %d ticks (a run has a "
+                             "fixed part of about 2 ms around its ticks)" % (3 * short, short),
                    "slope_us_per_tick": slope * 1e6,
                    "runs_us_per_tick": [t_short / short * 1e6, t_long / (3 * short) * 1e6]},
         "roofline": {"bound": "hbm", "achieved": 172.0 * B / per_tick / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -428,11 +428,13 @@ class PseudoInverseController(BaseController):
 
     # -- resident ticks ----------------------------------------------------------------------------------------
     def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, out=None, mode_out=None, timeout_s=2.0,
-                       stream=None):
+                       stream=None, ring_depth=1):
         """Launch ONE kernel that stays on the device and runs up to ``n_ticks`` ticks, each as soon as its ticket
         is published (include/clik.h, clik_pinv_resident_run): for closed loops whose inputs are produced on the
         device (or copied in behind a stream) every tick, at the price of a device-side hand-off instead of a launch.
-        ``robot_var`` / ``input_var`` must be device tensors (the producer overwrites them in place).  Returns a dict
+        ``robot_var`` / ``input_var`` must be device tensors (the producer overwrites them in place); with
+        ``ring_depth`` D > 1 they are rings ``[D, B, n]`` and tick k uses slot ``(k - 1) % D`` (outputs likewise), so
+        that a producer can write the next tick's rows while this one runs.  Returns a dict
         with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [32] stop, [48] waves, [49] ticks_done),
         ``done`` (int32 device tensor, one slot per wave: the last tick that wave finished), ``waves`` per tick,
         ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
@@ -443,22 +445,46 @@ class PseudoInverseController(BaseController):
         torch = _torch()
         d = self.descriptor
         dev = self._device
+        D = int(ring_depth)
+        if D < 1:
+            raise ValueError("ring_depth must be at least 1")
         if not isinstance(robot_var, torch.Tensor) or not robot_var.is_cuda:
             raise ValueError("resident ticks: robot_var must be a device tensor")
-        Q, _ = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
-        B = Q.shape[0]
-        Y = None
-        if d.n_y > 0:
-            if not isinstance(input_var, torch.Tensor) or not input_var.is_cuda:
-                raise ValueError("resident ticks: input_var must be a device tensor")
-            Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
-        if Q.data_ptr() != robot_var.data_ptr() or (Y is not None and Y.data_ptr() != input_var.data_ptr()):
-            raise ValueError("resident ticks: inputs must be contiguous float64 device tensors (they are read in place)")
-        check_out_tensor(out, (B, d.n_q), "float64", dev, "out")
-        check_out_tensor(mode_out, (B,), "int32", dev, "mode_out")
-        dQ = out if out is not None else torch.zeros((B, d.n_q), dtype=torch.float64, device=dev)
-        mode = mode_out if mode_out is not None else torch.full((B,), -1, dtype=torch.int32, device=dev)
+        if D > 1:
+            # a RING of D slots: robot_var [D, B, n_q], input_var [D, B, n_y]; tick k reads and writes slot (k - 1) % D
+            # (include/clik.h): a producer fills slot k % D while tick k runs and publishes ticket k + 1 ahead
+            if robot_var.dim() != 3 or robot_var.shape[0] != D or robot_var.shape[2] != d.n_q:
+                raise ValueError("resident ticks with ring_depth %d: robot_var must have shape [%d, B, %d]" % (D, D, d.n_q))
+            B = int(robot_var.shape[1])
+            Q = robot_var
+            Y = None
+            if d.n_y > 0:
+                if (not isinstance(input_var, torch.Tensor) or not input_var.is_cuda
+                        or tuple(input_var.shape) != (D, B, d.n_y)):
+                    raise ValueError("resident ticks with ring_depth %d: input_var must be a device tensor of shape "
+                                     "[%d, %d, %d]" % (D, D, B, d.n_y))
+                Y = input_var
+            for tns in (Q, Y):
+                if tns is not None and (tns.dtype != torch.float64 or not tns.is_contiguous()):
+                    raise ValueError("resident ticks: inputs must be contiguous float64 device tensors (read in place)")
+            out_shape, mode_shape = (D, B, d.n_q), (D, B)
+        else:
+            Q, _ = to_device_matrix(robot_var, d.n_q, dev, "robot_var")
+            B = Q.shape[0]
+            Y = None
+            if d.n_y > 0:
+                if not isinstance(input_var, torch.Tensor) or not input_var.is_cuda:
+                    raise ValueError("resident ticks: input_var must be a device tensor")
+                Y, _ = to_device_matrix(input_var, d.n_y, dev, "input_var", B)
+            if Q.data_ptr() != robot_var.data_ptr() or (Y is not None and Y.data_ptr() != input_var.data_ptr()):
+                raise ValueError("resident ticks: inputs must be contiguous float64 device tensors (they are read in place)")
+            out_shape, mode_shape = (B, d.n_q), (B,)
+        check_out_tensor(out, out_shape, "float64", dev, "out")
+        check_out_tensor(mode_out, mode_shape, "int32", dev, "mode_out")
+        dQ = out if out is not None else torch.zeros(out_shape, dtype=torch.float64, device=dev)
+        mode = mode_out if mode_out is not None else torch.full(mode_shape, -1, dtype=torch.int32, device=dev)
         ticket = torch.zeros(64, dtype=torch.int32, device=dev)
+        ticket[16] = D if D > 1 else 0
         waves = self._lib.clik_pinv_resident_waves(self._handle, B)
         done = torch.zeros(max(waves, 1), dtype=torch.int32, device=dev)
         stream = stream if stream is not None else torch.cuda.Stream(device=dev)

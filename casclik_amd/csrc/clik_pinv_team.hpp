@@ -580,7 +580,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
 // other wave and the producer leave too.  It never spins without that check.  (The watchdog counts polls, see below.)
 struct ResidentTicket {
     unsigned in_seq, p0[15];
-    unsigned reserved, p1[15];
+    unsigned ring_depth, p1[15];      // input / output slots (0 or 1: one buffer)
     unsigned stop, p2[15];
     unsigned waves, ticks_done, p3[14];
 };
@@ -655,13 +655,21 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    auto request_rows = [&]() __attribute__((always_inline)) {
+    // A RING of `ring` input / output slots (ticket->ring_depth, 0 or 1: one buffer): tick k reads q / y from slot
+    // (k - 1) % ring and writes dq / mode into the same slot of the output arrays ([ring][B][.] each).  With one
+    // buffer a producer can only write the next inputs after every wave has finished the current tick (a closed loop by
+    // construction); with three or more slots it writes tick k + 1's rows while tick k runs and publishes its ticket
+    // ahead - the mode the software pipeline below is for.
+    const unsigned ring_raw = __hip_atomic_load(&ticket->ring_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long ring = ring_raw > 1u ? (long long)ring_raw : 1ll;
+    auto request_rows = [&](const int k) __attribute__((always_inline)) {
+        const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
 #pragma unroll
-        for (int j = 0; j < N; ++j) zn[j] = __hip_atomic_load(q + binst * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int j = 0; j < N; ++j) zn[j] = __hip_atomic_load(q + row * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if constexpr (NY > 0) {
 #pragma unroll
             for (int j = 0; j < NY; ++j)
-                yn[j] = __hip_atomic_load(y + binst * NY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                yn[j] = __hip_atomic_load(y + row * NY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
     auto publish_done = [&](const int k) __attribute__((always_inline)) {
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             poll_for((unsigned)k);
             if (leave) break;
             asm volatile("" ::: "memory");
-            request_rows();
+            request_rows(k);
         }
         double z[N], ydir[NY > 0 ? NY : 1];
 #pragma unroll
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         bool in_tc;
         team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, v, in_tc, [&]() __attribute__((always_inline)) {
             if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen >= (unsigned)(k + 1)) {
-                request_rows();
+                request_rows(k + 1);
                 have_next = true;
             }
         });
@@ -710,11 +718,12 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
         if (r == (ok0 ? 0 : 3) && valid) {
             // (write-through stores: visible to every agent once acknowledged)
+            const long long orow = ((long long)((k - 1) % (int)ring)) * B + b0 + inst;
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                __hip_atomic_store(dq + (b0 + inst) * N + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dq + orow * N + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (mode_out != nullptr)
-                __hip_atomic_store(mode_out + b0 + inst, ok0 ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mode_out + orow, ok0 ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (have_next) owed = k;        // published at the end of the next tick
         else publish_done(k);           // nobody has asked for the next tick yet (or this was the last): at once

@@ -242,6 +242,10 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  *     was already published the wave goes straight on and publishes done[w] = k up to one tick later); tick k is
  *     complete when every one of the `waves` slots holds k (waves is filled in by the kernel; clik_pinv_resident_waves
  *     returns it beforehand; `done` is device memory, `waves` words, zeroed by the caller);
+ *   ring: with ticket->ring_depth = D > 1 the arrays are rings of D slots - q [D][B][n_q], y [D][B][n_y], dq [D][B][n_q],
+ *     mode [D][B] - and tick k reads and writes slot (k - 1) % D.  With ONE buffer a producer can only write the next
+ *     inputs after every wave has finished the current tick; with D >= 3 it writes tick k + 1's rows (slot k % D, free
+ *     once every done[w] >= k + 1 - D) while tick k runs and publishes ticket k + 1 ahead: the kernel then never waits;
  *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (a budget of polls over
  *     its whole life, timeout_s at a nominal 2.5 us per poll; it then writes stop = 2 itself) - it never spins unguarded.
  * clik_ticket_feed launches the reference producer (one device block that publishes tickets 1 .. n_ticks, either
@@ -250,11 +254,11 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  * producer or copy queued behind the resident kernel waits until the watchdog lets it go): use a stream of another
  * priority (hipStreamCreateWithPriority).  Only for handles with an attached value-specialised kernel of that family
  * (clik_pinv_attach_resident_kernel; casclik_amd/jit.py does it).  Not graph-capturable.  Measured on one MI355X
- * (tools/resident_probe.py), 16384 instances: 3.37 us per tick when the producer publishes
- * ahead, 5.7-6.0 us when it waits for done[] (closed loop), 3.99 us for one launch per tick.                    */
+ * (tools/resident_probe.py), 16384 instances: 3.4 us per tick when the producer publishes
+ * ahead (a ring of four slots), 5.8 us when it waits for done[] (closed loop), 3.99 us for one launch per tick.   */
 typedef struct clik_ticket {
     uint32_t in_seq;     uint32_t _p0[15];
-    uint32_t reserved;   uint32_t _p1[15];
+    uint32_t ring_depth; uint32_t _p1[15];   /* input / output slots, set by the caller before the launch (0 or 1: one buffer) */
     uint32_t stop;       uint32_t _p2[15];
     uint32_t waves;      uint32_t ticks_done;  uint32_t _p3[14];
 } clik_ticket;

@@ -278,3 +278,73 @@ def test_resident_ticks_fed_from_outside(iiwa_fk):
         run["stream"].synchronize()
     tk = run["ticket"].cpu()
     assert int(tk[48]) == waves and int(tk[49]) == NT
+
+
+def test_resident_ticks_over_a_ring_of_input_slots(iiwa_fk):
+    """Resident ticks with ticket->ring_depth = 4 (include/clik.h): tick k reads its rows from slot (k - 1) % 4 of the
+    input rings and writes slot (k - 1) % 4 of the outputs.  (a) every ticket published ahead, DIFFERENT inputs in every
+    slot, ten ticks: the software-pipelined path (rows of tick k + 1 requested in the middle of tick k) must pick the
+    right slot each time - every output slot equals an ordinary launch on that slot's inputs.  (b) a producer on
+    another stream refills the slot that has come free (every done[w] >= k + 1 - 4) with new inputs while the kernel
+    runs and publishes tickets two ahead: twelve ticks, each tick's outputs equal those of a launch on ITS inputs."""
+    import time
+    import torch
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    B, D = 1000, 4
+    if "team4v" not in ctrl.kernel_variant(B):
+        pytest.skip("no value-specialised team kernel attached (hipcc missing)")
+    batches = [skills.synthetic_inputs(iiwa_fk, B, seed=60 + k, distribution="mixed") for k in range(16)]
+    dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
+    want = [ctrl.solve_batch(0.0, dev(q), input_var=dev(y)) for q, y in batches]
+
+    # ---- (a) all tickets ahead
+    NT = 10
+    Qr = torch.stack([dev(batches[s][0]) for s in range(D)]).contiguous()
+    Yr = torch.stack([dev(batches[s][1]) for s in range(D)]).contiguous()
+    torch.cuda.synchronize()
+    run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
+    feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
+    run["stream"].synchronize()
+    feeder.synchronize()
+    tk = run["ticket"].cpu()
+    assert int(tk[32]) == 0 and int(tk[49]) == NT and int(run["done"].min()) == NT
+    for s in range(D):
+        assert torch.equal(run["out"][s], want[s][0]) and torch.equal(run["mode"][s], want[s][2]), s
+
+    # ---- (b) a producer that refills slots while the kernel runs
+    NT = 12
+    Qr = torch.zeros((D, B, 7), dtype=torch.float64, device="cuda")
+    Yr = torch.zeros((D, B, 7), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    run = ctrl.resident_start(Qr, Yr, NT, timeout_s=30.0, ring_depth=D)
+    feed = torch.cuda.Stream(priority=-1)
+    seen = {}
+    try:
+        published = 0
+        t0 = time.time()
+        while len(seen) < NT and time.time() - t0 < 25.0:
+            with torch.cuda.stream(feed):
+                dn = int(run["done"].min().item())
+            # collect the outputs of finished ticks before their slot is refilled
+            for k in range(len(seen) + 1, dn + 1):
+                with torch.cuda.stream(feed):
+                    seen[k] = (run["out"][(k - 1) % D].clone(), run["mode"][(k - 1) % D].clone())
+            # tick k may be published when its slot is free (tick k - D collected) and at most two ahead of `done`
+            while published < NT and published - len(seen) < 2 and published + 1 - D <= len(seen):
+                k = published + 1
+                with torch.cuda.stream(feed):
+                    Qr[(k - 1) % D].copy_(dev(batches[k][0]))
+                    Yr[(k - 1) % D].copy_(dev(batches[k][1]))
+                    run["ticket"][0:1].copy_(torch.tensor([k], dtype=torch.int32))
+                feed.synchronize()
+                published = k
+        assert len(seen) == NT, (len(seen), run["ticket"].cpu()[[0, 32, 49]].tolist())
+    finally:
+        with torch.cuda.stream(feed):
+            run["ticket"][32:33].copy_(torch.tensor([1], dtype=torch.int32))
+        feed.synchronize()
+        run["stream"].synchronize()
+    for k in range(1, NT + 1):
+        assert torch.equal(seen[k][0], want[k][0]) and torch.equal(seen[k][1], want[k][2]), k

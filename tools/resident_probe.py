@@ -29,6 +29,13 @@ ctrl.setup_problem_functions()
 Q, Y = skills.synthetic_inputs(fk, B, seed=0, distribution="mixed")
 Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
 ref = ctrl.solve_batch(0.0, Qd, input_var=Yd)
+# a ring of RING input / output slots with a different batch in each (tick k uses slot (k - 1) % RING): what a producer
+# that runs ahead of the kernel needs - with ONE buffer it could only write after every wave has finished the tick
+RING = int(os.environ.get("CLIK_PROBE_RING", "4"))
+slots = [(Q, Y)] + [skills.synthetic_inputs(fk, B, seed=17 * s, distribution="mixed") for s in range(1, RING)]
+Qr = torch.stack([torch.from_numpy(q).cuda() for q, _ in slots]).contiguous()
+Yr = torch.stack([torch.from_numpy(y).cuda() for _, y in slots]).contiguous()
+refs = [ctrl.solve_batch(0.0, Qr[s], input_var=Yr[s]) for s in range(RING)]
 print("kernel", ctrl.kernel_variant(B))
 
 # one launch per tick (graph replay), for the same box
@@ -57,7 +64,7 @@ def run_ticks(nt, closed):
     for rep in range(5):
         feeder_stream = torch.cuda.Stream(priority=-1)       # (not the hardware queue of the resident kernel)
         torch.cuda.synchronize()
-        run = ctrl.resident_start(Qd, Yd, nt, timeout_s=3.0)
+        run = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=RING)
         time.sleep(0.02)                      # (the resident kernel is up and polling)
         t0 = time.perf_counter()
         ctrl.resident_feed(run, nt, closed_loop=closed, timeout_s=3.0, stream=feeder_stream)
@@ -67,7 +74,7 @@ def run_ticks(nt, closed):
         tk = run["ticket"].cpu().numpy()
         dn = run["done"].cpu().numpy()
         ok = (tk[32] == 0) and (tk[49] == nt) and (dn == nt).all()
-        same = torch.equal(run["out"], ref[0]) and torch.equal(run["mode"], ref[2])
+        same = all(torch.equal(run["out"][s], refs[s][0]) and torch.equal(run["mode"][s], refs[s][2]) for s in range(RING))
         if not (ok and same):
             print("  %s rep %d: ticks done %d, stop %d, slots at the last tick %d of %d, equal to the launched tick: %s"
                   % ("closed loop" if closed else "free-running", rep, tk[49], tk[32], int((dn == nt).sum()), run["waves"], same))
@@ -75,7 +82,7 @@ def run_ticks(nt, closed):
     return best
 
 
-print("pipeline:", os.environ.get("CLIK_JIT_DEFINES", "") or "on (default)")
+print("pipeline:", os.environ.get("CLIK_JIT_DEFINES", "") or "on (default)", " ring of %d slots, a different batch in each" % RING)
 for name, closed in (("fed ahead (all tickets published)", False), ("closed loop (ticket k after every done[k-1])", True)):
     # two run lengths: the slope is the per-tick cost, the intercept what a run costs around its ticks
     short, long_ = run_ticks(NT, closed), run_ticks(3 * NT, closed)
