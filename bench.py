@@ -532,7 +532,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     return entry, (spec, opts, Q, Y)
 
 
-def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4):
+def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrate=False):
     """BASELINE config 3 at 16384 instances through clik_pinv_resident_run over a ring of `ring` input / output slots
     (a different synthetic batch in every slot; tick k uses slot (k - 1) % ring) with every ticket published ahead
     (tools/resident_probe.py is the long form, closed loop included)."""
@@ -551,14 +551,18 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4):
         for _ in range(3):
             feeder = torch.cuda.Stream(priority=-1)
             torch.cuda.synchronize()
-            r = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=ring)
+            r = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=ring,
+                                    **(dict(integrate_dt=1e-3, max_speed=2.0) if integrate else {}))
             time.sleep(0.01)
             t0 = time.perf_counter()
             ctrl.resident_feed(r, nt, closed_loop=False, timeout_s=3.0, stream=feeder)
             r["stream"].synchronize()
             el = time.perf_counter() - t0
             feeder.synchronize()
-            same = all(torch.equal(r["out"][s], refs[s][0]) and torch.equal(r["mode"][s], refs[s][2]) for s in range(ring))
+            # (with the state kept by the kernel the rows move from tick to tick: that mode's parity is
+            # tests/test_gpu_team.py::test_resident_ticks_integrate_the_state_and_take_streamed_targets)
+            same = integrate or all(torch.equal(r["out"][s], refs[s][0]) and torch.equal(r["mode"][s], refs[s][2])
+                                    for s in range(ring))
             if not (same and int(r["done"].min()) == nt):
                 raise RuntimeError("resident ticks: an output slot differs from the launched tick on that slot's inputs")
             best = el if best is None else min(best, el)
@@ -570,7 +574,9 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4):
         "value": B / per_tick, "unit": "instance-steps/s", "ms_per_step": per_tick * 1e3,
         "config": {"workload": "BASELINE config 3: %d x iiwa priority stack as RESIDENT ticks (one launch; device-side "
                                "tickets published ahead of the kernel; inputs and outputs in a ring of %d slots, a "
-                               "different batch in each)" % (B, ring), "batch_per_gpu": B, "ring_depth": ring,
+                               "different batch in each)%s" % (B, ring, "; the state kept by the kernel (q += clamp(dq, "
+                               "+-2) * 1e-3 after every tick, clik_pinv_resident_run_state), only the targets read "
+                               "from the ring" if integrate else ""), "batch_per_gpu": B, "ring_depth": ring,
                    "inputs": "%s seeds %s" % (dist_name, [seed + 17 * s for s in range(ring)]),
                    "kernel": ctrl.kernel_variant(B) + "/resident",
                    "timing": "one resident launch of %d ticks, host clock from the producer's launch to the kernel's exit "
@@ -662,11 +668,12 @@ def main():
             extras.append(ent)
 
         # config 3 as RESIDENT ticks (one launch, device-side tickets, all published ahead: include/clik.h)
-        try:
-            extras.append(dict({"name": "stack_B16384_resident_fed_ahead", "n_gpus": world, "dtype": "f64"},
-                               **measure_resident(fk, args.dist, args.seed)))
-        except Exception as exc:
-            extras.append({"name": "stack_B16384_resident_fed_ahead", "error": repr(exc)})
+        for name, integ in (("stack_B16384_resident_fed_ahead", False), ("stack_B16384_resident_state_in_kernel", True)):
+            try:
+                extras.append(dict({"name": name, "n_gpus": world, "dtype": "f64"},
+                                   **measure_resident(fk, args.dist, args.seed, integrate=integ)))
+            except Exception as exc:
+                extras.append({"name": name, "error": repr(exc)})
 
     if rank == 0:
         out = {

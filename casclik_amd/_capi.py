@@ -175,7 +175,7 @@ def qp_opts_to_c(mu, state_weights, slack_weights, max_iter=0):
 
 _SYMBOLS = [
     "clik_last_error", "clik_abi_version",
-    "clik_pinv_create", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_pinv_attach_resident_kernel", "clik_pinv_resident_waves", "clik_pinv_resident_run", "clik_ticket_feed", "clik_shape_describe", "clik_pinv_attach_kernel",
+    "clik_pinv_create", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_pinv_attach_resident_kernel", "clik_pinv_resident_waves", "clik_pinv_resident_run", "clik_pinv_resident_run_state", "clik_ticket_feed", "clik_shape_describe", "clik_pinv_attach_kernel",
     "clik_pinv_solve_batch", "clik_pinv_solve_batch_t", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
     "clik_qp_create", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
     "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel", "clik_qp_image_words", "clik_qp_attach_value_kernel", "clik_qp_is_box_family",
@@ -250,6 +250,9 @@ def load_library(path=None):
     lib.clik_pinv_attach_resident_kernel.argtypes = [vp, C.c_void_p]
     lib.clik_pinv_resident_waves.restype = C.c_int
     lib.clik_pinv_resident_waves.argtypes = [vp, C.c_int64]
+    lib.clik_pinv_resident_run_state.restype = C.c_int
+    lib.clik_pinv_resident_run_state.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, ip, C.c_void_p, C.c_void_p,
+                                                 C.c_double, C.c_double, C.c_double, C.c_void_p]
     lib.clik_pinv_resident_run.restype = C.c_int
     lib.clik_pinv_resident_run.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, ip, C.c_void_p, C.c_void_p,
                                            C.c_double, C.c_void_p]

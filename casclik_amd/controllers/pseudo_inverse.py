@@ -428,13 +428,15 @@ class PseudoInverseController(BaseController):
 
     # -- resident ticks ----------------------------------------------------------------------------------------
     def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, out=None, mode_out=None, timeout_s=2.0,
-                       stream=None, ring_depth=1):
+                       stream=None, ring_depth=1, integrate_dt=0.0, max_speed=0.0):
         """Launch ONE kernel that stays on the device and runs up to ``n_ticks`` ticks, each as soon as its ticket
         is published (include/clik.h, clik_pinv_resident_run): for closed loops whose inputs are produced on the
         device (or copied in behind a stream) every tick, at the price of a device-side hand-off instead of a launch.
         ``robot_var`` / ``input_var`` must be device tensors (the producer overwrites them in place); with
         ``ring_depth`` D > 1 they are rings ``[D, B, n]`` and tick k uses slot ``(k - 1) % D`` (outputs likewise), so
-        that a producer can write the next tick's rows while this one runs.  Returns a dict
+        that a producer can write the next tick's rows while this one runs.  ``integrate_dt`` > 0 keeps the state in
+        the kernel: ``robot_var`` is read at tick 1 only and then stepped with ``q += clamp(dq, +-max_speed) * dt``
+        after every tick (the notebooks' loop), so that only the targets ``input_var`` come from outside.  Returns a dict
         with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [32] stop, [48] waves, [49] ticks_done),
         ``done`` (int32 device tensor, one slot per wave: the last tick that wave finished), ``waves`` per tick,
         ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
@@ -485,15 +487,23 @@ class PseudoInverseController(BaseController):
         mode = mode_out if mode_out is not None else torch.full(mode_shape, -1, dtype=torch.int32, device=dev)
         ticket = torch.zeros(64, dtype=torch.int32, device=dev)
         ticket[16] = D if D > 1 else 0
+
         waves = self._lib.clik_pinv_resident_waves(self._handle, B)
         done = torch.zeros(max(waves, 1), dtype=torch.int32, device=dev)
         stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
         torch.cuda.current_stream(dev).synchronize()       # (ticket / outputs are initialised before the kernel starts)
         with torch.cuda.device(dev):
-            rc = self._lib.clik_pinv_resident_run(self._handle, B, int(n_ticks), ttp, ptr(Q), ptr(Y), ptr(dQ), ptr(mode),
-                                                  ptr(ticket), ptr(done), float(timeout_s),
-                                                  C.c_void_p(stream.cuda_stream))
+            if integrate_dt > 0.0:
+                # the state stays in the kernel (include/clik.h): q is read at tick 1 and stepped with
+                # q += clamp(dq, +-max_speed) * integrate_dt after every tick; only input_var comes from outside
+                rc = self._lib.clik_pinv_resident_run_state(
+                    self._handle, B, int(n_ticks), ttp, ptr(Q), ptr(Y), ptr(dQ), ptr(mode), ptr(ticket), ptr(done),
+                    float(integrate_dt), float(max_speed), float(timeout_s), C.c_void_p(stream.cuda_stream))
+            else:
+                rc = self._lib.clik_pinv_resident_run(self._handle, B, int(n_ticks), ttp, ptr(Q), ptr(Y), ptr(dQ),
+                                                      ptr(mode), ptr(ticket), ptr(done), float(timeout_s),
+                                                      C.c_void_p(stream.cuda_stream))
         _capi.check(self._lib, rc)
         return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "mode": mode, "stream": stream,
                 "keep": (Q, Y, tt)}

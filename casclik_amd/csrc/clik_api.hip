@@ -882,9 +882,31 @@ extern "C" int clik_pinv_resident_waves(const clik_pinv* h, int64_t B)
     return clik::team_waves_rt((long long)B);
 }
 
+static int resident_run_common(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
+                               const double* y, double* dq, int32_t* mode, clik_ticket* ticket, uint32_t* done,
+                               double integrate_dt, double max_speed, double timeout_s, void* stream);
+
 extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms,
                                       const double* q, const double* y, double* dq, int32_t* mode,
                                       clik_ticket* ticket, uint32_t* done, double timeout_s, void* stream)
+{
+    return resident_run_common(h, B, n_ticks, tterms, q, y, dq, mode, ticket, done, 0.0, 0.0, timeout_s, stream);
+}
+
+extern "C" int clik_pinv_resident_run_state(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms,
+                                            const double* q, const double* y, double* dq, int32_t* mode,
+                                            clik_ticket* ticket, uint32_t* done, double integrate_dt, double max_speed,
+                                            double timeout_s, void* stream)
+{
+    if (!(integrate_dt > 0.0)) return fail(CLIK_EINVAL, "integrate_dt must be positive");
+    if (max_speed < 0.0) return fail(CLIK_EINVAL, "max_speed must not be negative (0: no clamp)");
+    return resident_run_common(h, B, n_ticks, tterms, q, y, dq, mode, ticket, done, integrate_dt, max_speed, timeout_s,
+                               stream);
+}
+
+static int resident_run_common(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
+                               const double* y, double* dq, int32_t* mode, clik_ticket* ticket, uint32_t* done,
+                               double integrate_dt, double max_speed, double timeout_s, void* stream)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
     CLIK_NEEDS_DEVICE_HANDLE(h);
@@ -904,8 +926,17 @@ extern "C" int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_t
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
     // (watchdog budget: polls, at a nominal 2.5 us each)
-    hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, (unsigned*)done, n_ticks,
-                                   (unsigned long long)(timeout_s * 4e5), (hipStream_t)stream);
+    unsigned long long budget = (unsigned long long)(timeout_s * 4e5);
+    if (integrate_dt > 0.0) {
+        // the step and the clamp travel in the ticket (stream-ordered in front of the kernel); bit 63 of the budget
+        // picks the instantiation that keeps the state
+        const double pair[2] = {integrate_dt, max_speed};
+        hipError_t ce = hipMemcpyAsync(&ticket->integrate_dt, pair, sizeof(pair), hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (ce != hipSuccess) return hipfail(ce, "resident ticks: writing the integration step into the ticket");
+        budget |= 1ull << 63;
+    }
+    hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, (unsigned*)done, n_ticks, budget,
+                                   (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "resident kernel launch");
     return CLIK_OK;
 }

@@ -1504,6 +1504,8 @@ inline hipError_t launch_solve_team_values(const LaunchArgs& a, const TickArgs& 
     return hipGetLastError();
 }
 
+constexpr unsigned long long kResidentIntegrateBit = 1ull << 63;
+
 template <const ShapeDesc& SD, class IMGV>
 inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, const double* q, const double* y,
                                               double* dq, int32_t* mode, void* ticket, unsigned* done, int n_ticks,
@@ -1511,8 +1513,14 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
 {
     if constexpr (shape_team_ok(SD)) {
         const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
-        hipLaunchKernelGGL((pinv_resident_team_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0, stream, q, y, dq,
-                           mode, B, tk, (ResidentTicket*)ticket, done, n_ticks, timeout_ticks);
+        // (bit 63 of the poll budget: the instantiation that integrates the state itself, clik_pinv_resident_run_state)
+        const unsigned long long budget = timeout_ticks & ~kResidentIntegrateBit;
+        if (timeout_ticks & kResidentIntegrateBit)
+            hipLaunchKernelGGL((pinv_resident_team_kernel<SD, IMGV, true>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0, stream,
+                               q, y, dq, mode, B, tk, (ResidentTicket*)ticket, done, n_ticks, budget);
+        else
+            hipLaunchKernelGGL((pinv_resident_team_kernel<SD, IMGV, false>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0, stream,
+                               q, y, dq, mode, B, tk, (ResidentTicket*)ticket, done, n_ticks, budget);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

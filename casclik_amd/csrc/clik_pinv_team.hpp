@@ -580,7 +580,9 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
 // other wave and the producer leave too.  It never spins without that check.  (The watchdog counts polls, see below.)
 struct ResidentTicket {
     unsigned in_seq, p0[15];
-    unsigned ring_depth, p1[15];      // input / output slots (0 or 1: one buffer)
+    unsigned ring_depth, p1a;         // input / output slots (0 or 1: one buffer)
+    double integrate_dt, max_speed;   // > 0: the state is integrated in the kernel (q read at tick 1 only)
+    unsigned p1[10];
     unsigned stop, p2[15];
     unsigned waves, ticks_done, p3[14];
 };
@@ -593,7 +595,7 @@ __device__ __forceinline__ unsigned long long realtime_100mhz()
     return t;
 }
 
-template <const ShapeDesc& SD, class IMGV>
+template <const ShapeDesc& SD, class IMGV, bool INTEGRATE = false>
 __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     const double* q, const double* y, double* dq, int32_t* mode_out, const long long B, const TickArgs tk,
     ResidentTicket* ticket, unsigned* done, const int n_ticks, const unsigned long long max_polls)
@@ -662,10 +664,21 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     // ahead - the mode the software pipeline below is for.
     const unsigned ring_raw = __hip_atomic_load(&ticket->ring_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const long long ring = ring_raw > 1u ? (long long)ring_raw : 1ll;
+    // integrate_dt > 0: the state stays in the kernel (read at tick 1, then q += clamp(dq) dt after every tick): only
+    // the targets come from outside
+    // (its own instantiation, INTEGRATE: the plain kernel carries none of this - a run-time switch cost it 0.2 us a tick)
+    const double step_dt = INTEGRATE ? ticket->integrate_dt : 0.0, step_clamp = INTEGRATE ? ticket->max_speed : 0.0;
+    constexpr bool integrate = INTEGRATE;
+    double zstate[INTEGRATE ? N : 1];
+#pragma unroll
+    for (int j = 0; j < (INTEGRATE ? N : 1); ++j) zstate[j] = 0.0;
     auto request_rows = [&](const int k) __attribute__((always_inline)) {
         const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
+        if (!integrate || k == 1) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) zn[j] = __hip_atomic_load(q + row * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int j = 0; j < N; ++j)
+                zn[j] = __hip_atomic_load(q + row * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if constexpr (NY > 0) {
 #pragma unroll
             for (int j = 0; j < NY; ++j)
@@ -691,7 +704,10 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         }
         double z[N], ydir[NY > 0 ? NY : 1];
 #pragma unroll
-        for (int j = 0; j < N; ++j) z[j] = zn[j];
+        for (int j = 0; j < N; ++j) {
+            if constexpr (INTEGRATE) z[j] = (k > 1) ? zstate[j] : zn[j];
+            else z[j] = zn[j];
+        }
 #pragma unroll
         for (int j = 0; j < (NY > 0 ? NY : 1); ++j) ydir[j] = yn[j];
         have_next = false;
@@ -710,6 +726,18 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             }
         });
         const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
+        if constexpr (INTEGRATE) {
+            // the accepted candidate in every lane of the quad (mode 0 lives in lane 0, mode 1 in lane 3), clamped,
+            // and the state stepped: exactly pinv_rollout_static_team_kernel's Euler step
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xFF>(v[j]);
+                double d = ok0 ? c0 : c1;
+                if (step_clamp > 0.0) d = fmax(fmin(d, step_clamp), -step_clamp);
+                v[j] = d;
+                zstate[j] = fma(d, step_dt, z[j]);
+            }
+        }
         if (owed != 0) {
             publish_done(owed);         // (the previous tick's stores: issued a whole tick ago)
             owed = 0;

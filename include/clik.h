@@ -246,6 +246,10 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  *     mode [D][B] - and tick k reads and writes slot (k - 1) % D.  With ONE buffer a producer can only write the next
  *     inputs after every wave has finished the current tick; with D >= 3 it writes tick k + 1's rows (slot k % D, free
  *     once every done[w] >= k + 1 - D) while tick k runs and publishes ticket k + 1 ahead: the kernel then never waits;
+ *   state on the device (clik_pinv_resident_run_state): the kernel reads q once (tick 1) and integrates it itself,
+ *     q += clamp(dq, +-max_speed) * integrate_dt after every tick (the notebooks' loop, ur5_moe2016_example2.ipynb:537-545),
+ *     so only the TARGETS y come from outside: a producer that streams them ahead through the ring never stalls the
+ *     kernel, and the loop over q closes without leaving it; dq (clamped) and mode are written per tick as before;
  *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (a budget of polls over
  *     its whole life, timeout_s at a nominal 2.5 us per poll; it then writes stop = 2 itself) - it never spins unguarded.
  * clik_ticket_feed launches the reference producer (one device block that publishes tickets 1 .. n_ticks, either
@@ -258,7 +262,10 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  * ahead (a ring of four slots), 5.8 us when it waits for done[] (closed loop), 3.99 us for one launch per tick.   */
 typedef struct clik_ticket {
     uint32_t in_seq;     uint32_t _p0[15];
-    uint32_t ring_depth; uint32_t _p1[15];   /* input / output slots, set by the caller before the launch (0 or 1: one buffer) */
+    uint32_t ring_depth; uint32_t _p1a;      /* input / output slots, set by the caller before the launch (0 or 1: one buffer) */
+    double   integrate_dt;                   /* written by clik_pinv_resident_run_state: the kernel keeps the state - it     */
+    double   max_speed;                      /*   reads q at tick 1 only and then steps q += clamp(dq, +-max_speed) * dt     */
+    uint32_t _p1[10];
     uint32_t stop;       uint32_t _p2[15];
     uint32_t waves;      uint32_t ticks_done;  uint32_t _p3[14];
 } clik_ticket;
@@ -267,6 +274,11 @@ int clik_pinv_resident_waves(const clik_pinv* h, int64_t B);
 int clik_pinv_resident_run(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
                            const double* y, double* dq, int32_t* mode, clik_ticket* ticket, uint32_t* done,
                            double timeout_s, void* stream);
+/* ... with the state kept by the kernel: q is read at tick 1 and stepped with q += clamp(dq, +-max_speed) * integrate_dt
+ * after every tick (max_speed 0: no clamp); the two numbers are written into the ticket by the call, on `stream`.   */
+int clik_pinv_resident_run_state(const clik_pinv* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
+                                 const double* y, double* dq, int32_t* mode, clik_ticket* ticket, uint32_t* done,
+                                 double integrate_dt, double max_speed, double timeout_s, void* stream);
 int clik_ticket_feed(clik_ticket* ticket, const uint32_t* done, int32_t n_ticks, int32_t closed_loop,
                      int32_t waves_per_tick, double timeout_s, void* stream);
 

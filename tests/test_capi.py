@@ -118,9 +118,12 @@ def test_host_only_handles_answer_queries_and_refuse_to_solve(lib, monkeypatch):
 def test_ticket_layout(tmp_path):
     """clik_ticket (resident ticks): 256 bytes, the words the Python layer indexes"""
     src = tmp_path / "tk.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "clik.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "clik.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(clik_ticket),offsetof(clik_ticket,in_seq),offsetof(clik_ticket,stop),offsetof(clik_ticket,waves),'
-                   'offsetof(clik_ticket,ticks_done));return 0;}\n')
+                   'offsetof(clik_ticket,ticks_done),offsetof(clik_ticket,ring_depth),offsetof(clik_ticket,integrate_dt),'
+                   'offsetof(clik_ticket,max_speed));return 0;}\n')
     exe = tmp_path / "tk"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    assert [int(v) for v in subprocess.check_output([str(exe)]).split()] == [256, 0, 4 * 32, 4 * 48, 4 * 49]
+    # (int32 words 16: ring_depth; float64 words 9, 10: integrate_dt, max_speed - casclik_amd/controllers/pseudo_inverse.py)
+    assert [int(v) for v in subprocess.check_output([str(exe)]).split()] == [256, 0, 4 * 32, 4 * 48, 4 * 49, 4 * 16,
+                                                                               8 * 9, 8 * 10]

@@ -348,3 +348,46 @@ def test_resident_ticks_over_a_ring_of_input_slots(iiwa_fk):
         run["stream"].synchronize()
     for k in range(1, NT + 1):
         assert torch.equal(seen[k][0], want[k][0]) and torch.equal(seen[k][1], want[k][2]), k
+
+
+def test_resident_ticks_integrate_the_state_and_take_streamed_targets(iiwa_fk):
+    """ticket->integrate_dt > 0 (include/clik.h): the resident kernel reads q once and steps it itself,
+    q += clamp(dq, +-max_speed) dt after every tick, while the TARGETS of every tick come from a ring that was filled
+    ahead (what a producer of y does): 24 closed-loop ticks with a different target batch each, in one launch that
+    never waits.  Every tick's clamped velocity and mode equal those of the host loop - one ordinary launch per tick
+    on the state the previous ticks produced."""
+    import torch
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    B, NT, dt, vmax = 1000, 24, 0.004, 1.5
+    if "team4v" not in ctrl.kernel_variant(B):
+        pytest.skip("no value-specialised team kernel attached (hipcc missing)")
+    Q0, _ = skills.synthetic_inputs(iiwa_fk, B, seed=90, distribution="mixed")
+    Ys = [skills.synthetic_inputs(iiwa_fk, B, seed=100 + k, distribution="interior")[1] for k in range(NT)]
+    # the host loop (the notebooks'): solve -> clamp -> Euler
+    q = torch.from_numpy(Q0).cuda()
+    want = []
+    for k in range(NT):
+        dq, _, mode = ctrl.solve_batch(0.0, q, input_var=torch.from_numpy(Ys[k]).cuda())
+        dq = dq.clamp(-vmax, vmax)
+        want.append((dq.clone(), mode.clone()))
+        q = q + dq * dt
+    # one resident launch: the state in the kernel, the targets in a ring as deep as the run (all published ahead)
+    Qr = torch.zeros((NT, B, 7), dtype=torch.float64, device="cuda")
+    Qr[0] = torch.from_numpy(Q0).cuda()
+    Yr = torch.stack([torch.from_numpy(y).cuda() for y in Ys]).contiguous()
+    torch.cuda.synchronize()
+    run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=NT, integrate_dt=dt, max_speed=vmax)
+    feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
+    run["stream"].synchronize()
+    feeder.synchronize()
+    tk = run["ticket"].cpu()
+    assert int(tk[32]) == 0 and int(tk[49]) == NT
+    worst = 0.0
+    for k in range(NT):
+        assert torch.equal(run["mode"][k], want[k][1]), k
+        worst = max(worst, float((run["out"][k] - want[k][0]).abs().max()))
+    # (the same arithmetic in the same order: the kernel's fma(d, dt, q) against the host's q + dq * dt differ by
+    # rounding in the state, which the ticks then see)
+    assert worst < 1e-8, worst          # (measured 1.4e-9: the "mixed" inputs hold near-singular configurations)

@@ -58,13 +58,14 @@ for _ in range(10):
 torch.cuda.synchronize()
 print("launch per tick (hipGraph of 1000):   %.3f us per tick" % ((time.perf_counter() - t0) / 10000 * 1e6))
 
-def run_ticks(nt, closed):
+def run_ticks(nt, closed, integrate=False):
     """best of 5: wall time [s] from the feeder's launch to the resident kernel's exit, for nt ticks"""
     best = None
     for rep in range(5):
         feeder_stream = torch.cuda.Stream(priority=-1)       # (not the hardware queue of the resident kernel)
         torch.cuda.synchronize()
-        run = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=RING)
+        run = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=RING,
+                                  **(dict(integrate_dt=1e-3, max_speed=2.0) if integrate else {}))
         time.sleep(0.02)                      # (the resident kernel is up and polling)
         t0 = time.perf_counter()
         ctrl.resident_feed(run, nt, closed_loop=closed, timeout_s=3.0, stream=feeder_stream)
@@ -75,6 +76,8 @@ def run_ticks(nt, closed):
         dn = run["done"].cpu().numpy()
         ok = (tk[32] == 0) and (tk[49] == nt) and (dn == nt).all()
         same = all(torch.equal(run["out"][s], refs[s][0]) and torch.equal(run["mode"][s], refs[s][2]) for s in range(RING))
+        if integrate:
+            same = True         # (the state moves: parity of this mode is tests/test_gpu_team.py's job)
         if not (ok and same):
             print("  %s rep %d: ticks done %d, stop %d, slots at the last tick %d of %d, equal to the launched tick: %s"
                   % ("closed loop" if closed else "free-running", rep, tk[49], tk[32], int((dn == nt).sum()), run["waves"], same))
@@ -83,10 +86,12 @@ def run_ticks(nt, closed):
 
 
 print("pipeline:", os.environ.get("CLIK_JIT_DEFINES", "") or "on (default)", " ring of %d slots, a different batch in each" % RING)
-for name, closed in (("fed ahead (all tickets published)", False), ("closed loop (ticket k after every done[k-1])", True)):
+for name, closed, integ in (("fed ahead (all tickets published)", False, False),
+                            ("fed ahead, state integrated in the kernel (targets from the ring)", False, True),
+                            ("closed loop (ticket k after every done[k-1])", True, False)):
     # two run lengths: the slope is the per-tick cost, the intercept what a run costs around its ticks
-    short, long_ = run_ticks(NT, closed), run_ticks(3 * NT, closed)
+    short, long_ = run_ticks(NT, closed, integ), run_ticks(3 * NT, closed, integ)
     slope = (long_ - short) / (2 * NT) * 1e6
-    print("resident, %-46s %.3f us per tick (slope between %d and %d ticks; the runs as wholes: %.3f / %.3f us per tick, "
+    print("resident, %-70s %.3f us per tick (slope between %d and %d ticks; the runs as wholes: %.3f / %.3f us per tick, "
           "fixed part %.0f us)" % (name, slope, NT, 3 * NT, short / NT * 1e6, long_ / (3 * NT) * 1e6,
                                   (short - slope * 1e-6 * NT) * 1e6))
