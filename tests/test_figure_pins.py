@@ -156,3 +156,20 @@ def test_oracle_reproduces_the_qp_error_decay_of_the_dual_quaternion_figure():
     t_sim, log_e = cf.simulate_frame_error(error_norm, solve)
     worst, n = cf.deviation_in_pixels("ur5_qdist1_e", "qp", t_sim, log_e, above=-13.0)
     assert n > 25 and worst < PIXELS, (worst, n)
+
+
+@pytest.mark.parametrize("case", ["qp_point", "pinv_point", "qp_traj", "pinv_traj"])
+def test_c_restatement_reproduces_the_cart_figures(case):
+    """the C restatement (oracle/clik_oracle_c.c: the CPU baseline of bench.py) through the same notebook loops and
+    stored figures - the cases whose rows fit its flat descriptor (no generated code: the path runs need sin(0.3 x))"""
+    from oracle import c_oracle
+    kind, spec, dt, p0, virt = cf.build(case)
+    orc = c_oracle.CPinvOracle(spec, None) if kind == "pinv" else c_oracle.CQpOracle(spec)
+
+    def solve(t, p, x):
+        out = orc.solve_batch(float(t), np.array([[p]]))
+        return float(out[0][0, 0]), None
+    t_sim, p_sim, dp_sim = cf.simulate(case, solve)
+    for curve in curves_of(case):
+        worst, n = cf.deviation_in_pixels(case, curve, t_sim, p_sim if curve == "p" else dp_sim)
+        assert n > 60 and worst < PIXELS, (case, curve, worst)
