@@ -528,3 +528,28 @@ def test_empty_batches_come_back_empty(iiwa_fk):
     qp.setup_solver()
     dq, _, slack, status = qp.solve_batch(0.0, Q, input_var=Y)
     assert dq.shape == (0, 7) and status.shape == (0,) and slack.shape[0] == 0
+
+
+def test_results_do_not_depend_on_the_batch_an_instance_sits_in(iiwa_fk):
+    """property (hypothesis): any prefix, suffix or strided subset of a batch gives every instance the answer it gets
+    in the full batch - ragged sizes across the 16 / 64-instance granularities of the kernels, both controllers"""
+    from hypothesis import given, settings, strategies as st
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 700, seed=3, distribution="mixed")
+    pinv = cc.PseudoInverseController(skill_spec=skills.stack_skill(iiwa_fk), options=dict(skills.STACK_OPTIONS))
+    pinv.setup_problem_functions()
+    qp = cc.ReactiveQPController(skill_spec=skills.qp_skill(iiwa_fk))
+    qp.setup_problem_functions()
+    qp.setup_solver()
+    full_p = pinv.solve_batch(0.0, Q, input_var=Y)
+    full_q = qp.solve_batch(0.0, Q, input_var=Y)
+
+    @settings(max_examples=20, deadline=None)
+    @given(start=st.integers(0, 650), count=st.integers(1, 700), step=st.integers(1, 5))
+    def check(start, count, step):
+        idx = np.arange(start, min(700, start + count * step), step)
+        dq, _, mode = pinv.solve_batch(0.0, Q[idx], input_var=Y[idx])
+        assert np.array_equal(mode, full_p[2][idx]) and np.array_equal(dq, full_p[0][idx])
+        dq, _, slack, status = qp.solve_batch(0.0, Q[idx], input_var=Y[idx])
+        assert np.array_equal(status, full_q[3][idx]) and np.array_equal(dq, full_q[0][idx])
+        assert np.array_equal(slack, full_q[2][idx])
+    check()
