@@ -655,11 +655,15 @@ def main():
         for (wl, b, hot, tpl) in (("pose", 4096, 0, 1), ("pose", 16384, 0, 1), ("qp", 16384, 0, 1), ("qp", 16384, 1, 1),
                                   ("stack", 131072, 0, 1), ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
             up = lambda v: -(-max(v, tpl) // tpl) * tpl              # noqa: E731  (a whole number of launches)
-            ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, up(max(args.steps, 8 * tpl)),
-                                            up(args.warmup), TPL=tpl, qp_hot=hot,
-                                            ramp_ms=100.0, min_timed_ms=args.extras_timed_ms)
-            ent = dict({"name": "%s_B%d%s%s" % (wl, b, "_hot" if hot else "", "_rollout%d" % tpl if tpl > 1 else ""),
-                        "n_gpus": world, "dtype": "f64"}, **ent)
+            name = "%s_B%d%s%s" % (wl, b, "_hot" if hot else "", "_rollout%d" % tpl if tpl > 1 else "")
+            try:
+                ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, up(max(args.steps, 8 * tpl)),
+                                                up(args.warmup), TPL=tpl, qp_hot=hot,
+                                                ramp_ms=100.0, min_timed_ms=args.extras_timed_ms)
+            except Exception as exc:        # (an extra must never cost the headline its line)
+                extras.append({"name": name, "error": repr(exc)})
+                continue
+            ent = dict({"name": name, "n_gpus": world, "dtype": "f64"}, **ent)
             if rank == 0 and args.cpu_baseline and world == 1 and not hot and tpl == 1:
                 try:
                     ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(2.0, args.cpu_seconds / 3))
