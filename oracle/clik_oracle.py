@@ -15,7 +15,13 @@ Line-by-line fp64 numpy restatement of the reference's per-tick hot path:
       get_constraints_expr       :191-246
       solve / result slicing     :461-528
 
-PARITY UNPINNED: the reference is pure Python on top of casadi==3.4.1
+PARITY - WHAT IT IS PINNED TO.  Outputs of the reference itself: the closed-loop figures its notebooks store of
+their real CasADi + qpOASES runs (eleven figures, every curve retraced within a pixel = 0.3 - 2 % of the plotted
+range; tests/golden/make_figure_pins.py, tests/test_figure_pins.py), the print_constraints() texts and the UR5
+forward-kinematics values the notebooks store.  Outputs of the reference's own CODE run in the build container
+over a stand-in casadi (tests/golden/make_ref_golden.py -> ref_pins.npz, 1e-9; the stand-in itself must retrace
+the same figures before any fixture is written).  NOT pinned: CasADi's rounding - no fixture comes from CasADi
+arithmetic at 1e-9, because: the reference is pure Python on top of casadi==3.4.1
 (requirements.txt:1) and urdf2casadi (un-vendored, unpinned); neither exists in
 the build container nor on the GPU box, and the reference ships no tests or
 golden outputs for ``solve()``.  What pins this
