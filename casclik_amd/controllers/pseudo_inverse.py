@@ -428,7 +428,7 @@ class PseudoInverseController(BaseController):
 
     # -- resident ticks ----------------------------------------------------------------------------------------
     def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, out=None, mode_out=None, timeout_s=2.0,
-                       stream=None, ring_depth=1, integrate_dt=0.0, max_speed=0.0):
+                       stream=None, ring_depth=1, integrate_dt=0.0, max_speed=0.0, publish_ahead=0):
         """Launch ONE kernel that stays on the device and runs up to ``n_ticks`` ticks, each as soon as its ticket
         is published (include/clik.h, clik_pinv_resident_run): for closed loops whose inputs are produced on the
         device (or copied in behind a stream) every tick, at the price of a device-side hand-off instead of a launch.
@@ -487,6 +487,10 @@ class PseudoInverseController(BaseController):
         mode = mode_out if mode_out is not None else torch.full(mode_shape, -1, dtype=torch.int32, device=dev)
         ticket = torch.zeros(64, dtype=torch.int32, device=dev)
         ticket[16] = D if D > 1 else 0
+        if publish_ahead:
+            # tickets 1 .. publish_ahead are valid before the kernel starts (the inputs of those ticks are in place):
+            # no producer has to run next to it - what a profiler that serialises kernels needs
+            ticket[0] = int(publish_ahead)
 
         waves = self._lib.clik_pinv_resident_waves(self._handle, B)
         done = torch.zeros(max(waves, 1), dtype=torch.int32, device=dev)

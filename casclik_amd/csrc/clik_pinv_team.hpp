@@ -672,17 +672,37 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     double zstate[INTEGRATE ? N : 1];
 #pragma unroll
     for (int j = 0; j < (INTEGRATE ? N : 1); ++j) zstate[j] = 0.0;
+    // The rows bypass the caches, so every request goes to memory: lane r of the quad asks for elements 2r and 2r + 1
+    // of its instance's row only (two requests per row for the whole quad, contiguous over the quad) and the quad hands
+    // them round by DPP when the tick starts (`spread`) - all four lanes asking for all N elements re-read every 64-byte
+    // line N times (PMC: 3.8x the algorithmic bytes in the stores, which had the same shape).
+    static_assert(N <= 2 * TEAM && NY <= 2 * TEAM, "two elements per lane cover a row");
+    double zp0 = 0.0, zp1 = 0.0, yp0 = 0.0, yp1 = 0.0;          // this lane's share of the next tick's rows
+    const int e0 = 2 * r < N ? 2 * r : N - 1, e1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+    const int f0 = 2 * r < NY ? 2 * r : (NY > 0 ? NY - 1 : 0), f1 = 2 * r + 1 < NY ? 2 * r + 1 : (NY > 0 ? NY - 1 : 0);
     auto request_rows = [&](const int k) __attribute__((always_inline)) {
         const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
         if (!integrate || k == 1) {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                zn[j] = __hip_atomic_load(q + row * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            zp0 = __hip_atomic_load(q + row * N + e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            zp1 = __hip_atomic_load(q + row * N + e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if constexpr (NY > 0) {
-#pragma unroll
-            for (int j = 0; j < NY; ++j)
-                yn[j] = __hip_atomic_load(y + row * NY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            yp0 = __hip_atomic_load(y + row * NY + f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            yp1 = __hip_atomic_load(y + row * NY + f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    auto spread = [&]() __attribute__((always_inline)) {        // shares -> the whole rows in every lane of the quad
+        static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int CTRL = (j / 2) * 0x55;                // quad_perm:[k,k,k,k], k = the lane that holds element j
+            zn[j] = quad_perm_f64<CTRL>((j & 1) ? zp1 : zp0);
+        });
+        if constexpr (NY > 0) {
+            static_for<0, NY>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int CTRL = (j / 2) * 0x55;
+                yn[j] = quad_perm_f64<CTRL>((j & 1) ? yp1 : yp0);
+            });
         }
     };
     auto publish_done = [&](const int k) __attribute__((always_inline)) {
@@ -702,6 +722,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             asm volatile("" ::: "memory");
             request_rows(k);
         }
+        spread();
         double z[N], ydir[NY > 0 ? NY : 1];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -711,6 +732,9 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
 #pragma unroll
         for (int j = 0; j < (NY > 0 ? NY : 1); ++j) ydir[j] = yn[j];
         have_next = false;
+        // (requesting the next rows HERE when the producer is two ticks ahead - a whole tick for them to arrive - was
+        // measured slower, 3.43 against 3.18 us: their four registers stay live through the whole tick of a kernel
+        // that has none to spare)
         double a0 = z[N - 1], a1 = z[N - 1];
         static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
             constexpr int kk = decltype(kc)::value;
@@ -726,17 +750,18 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             }
         });
         const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
-        if constexpr (INTEGRATE) {
-            // the accepted candidate in every lane of the quad (mode 0 lives in lane 0, mode 1 in lane 3), clamped,
-            // and the state stepped: exactly pinv_rollout_static_team_kernel's Euler step
+        // the accepted candidate in every lane of the quad (mode 0 lives in lane 0, mode 1 in lane 3): lane r stores
+        // elements 2r and 2r + 1 of the row (write-through stores of one lane per element cost 32 bytes each at the
+        // memory); INTEGRATE: clamped, and the state stepped - exactly pinv_rollout_static_team_kernel's Euler step
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xFF>(v[j]);
-                double d = ok0 ? c0 : c1;
+        for (int j = 0; j < N; ++j) {
+            const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xFF>(v[j]);
+            double d = ok0 ? c0 : c1;
+            if constexpr (INTEGRATE) {
                 if (step_clamp > 0.0) d = fmax(fmin(d, step_clamp), -step_clamp);
-                v[j] = d;
                 zstate[j] = fma(d, step_dt, z[j]);
             }
+            v[j] = d;
         }
         if (owed != 0) {
             publish_done(owed);         // (the previous tick's stores: issued a whole tick ago)
@@ -744,13 +769,18 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         }
         if (have_next && k + 1 < n_ticks)
             seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
-        if (r == (ok0 ? 0 : 3) && valid) {
+        if (valid) {
             // (write-through stores: visible to every agent once acknowledged)
             const long long orow = ((long long)((k - 1) % (int)ring)) * B + b0 + inst;
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                __hip_atomic_store(dq + orow * N + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (mode_out != nullptr)
+            double s0 = v[N - 1], s1 = v[N - 1];
+            static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kc)::value;
+                if constexpr (2 * kk < N) s0 = (r == kk) ? v[2 * kk] : s0;
+                if constexpr (2 * kk + 1 < N) s1 = (r == kk) ? v[2 * kk + 1] : s1;
+            });
+            if (2 * r < N) __hip_atomic_store(dq + orow * N + 2 * r, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (2 * r + 1 < N) __hip_atomic_store(dq + orow * N + 2 * r + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (mode_out != nullptr && r == 0)
                 __hip_atomic_store(mode_out + orow, ok0 ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (have_next) owed = k;        // published at the end of the next tick
