@@ -676,32 +676,41 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     // of its instance's row only (two requests per row for the whole quad, contiguous over the quad) and the quad hands
     // them round by DPP when the tick starts (`spread`) - all four lanes asking for all N elements re-read every 64-byte
     // line N times (PMC: 3.8x the algorithmic bytes in the stores, which had the same shape).
-    static_assert(N <= 2 * TEAM && NY <= 2 * TEAM, "two elements per lane cover a row");
-    double zp0 = 0.0, zp1 = 0.0, yp0 = 0.0, yp1 = 0.0;          // this lane's share of the next tick's rows
-    const int e0 = 2 * r < N ? 2 * r : N - 1, e1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-    const int f0 = 2 * r < NY ? 2 * r : (NY > 0 ? NY - 1 : 0), f1 = 2 * r + 1 < NY ? 2 * r + 1 : (NY > 0 ? NY - 1 : 0);
+    // (rows longer than eight elements take more rounds of the same: element j lives in round j / 8, lane (j % 8) / 2)
+    constexpr int RQ = (N + 2 * TEAM - 1) / (2 * TEAM), RY = NY > 0 ? (NY + 2 * TEAM - 1) / (2 * TEAM) : 1;
+    double zp[2 * RQ], yp[2 * RY];                               // this lane's share of the next tick's rows
+#pragma unroll
+    for (int i = 0; i < 2 * RQ; ++i) zp[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * RY; ++i) yp[i] = 0.0;
     auto request_rows = [&](const int k) __attribute__((always_inline)) {
         const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
         if (!integrate || k == 1) {
-            zp0 = __hip_atomic_load(q + row * N + e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            zp1 = __hip_atomic_load(q + row * N + e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int i = 0; i < 2 * RQ; ++i) {
+                const int e = 2 * TEAM * (i / 2) + 2 * r + (i & 1);
+                zp[i] = __hip_atomic_load(q + row * N + (e < N ? e : N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         if constexpr (NY > 0) {
-            yp0 = __hip_atomic_load(y + row * NY + f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            yp1 = __hip_atomic_load(y + row * NY + f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int i = 0; i < 2 * RY; ++i) {
+                const int e = 2 * TEAM * (i / 2) + 2 * r + (i & 1);
+                yp[i] = __hip_atomic_load(y + row * NY + (e < NY ? e : NY - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     };
     auto spread = [&]() __attribute__((always_inline)) {        // shares -> the whole rows in every lane of the quad
         static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            constexpr int CTRL = (j / 2) * 0x55;                // quad_perm:[k,k,k,k], k = the lane that holds element j
-            zn[j] = quad_perm_f64<CTRL>((j & 1) ? zp1 : zp0);
+            constexpr int CTRL = ((j % (2 * TEAM)) / 2) * 0x55;  // quad_perm:[k,k,k,k], k = the lane that holds element j
+            zn[j] = quad_perm_f64<CTRL>(zp[2 * (j / (2 * TEAM)) + (j & 1)]);
         });
         if constexpr (NY > 0) {
             static_for<0, NY>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int CTRL = (j / 2) * 0x55;
-                yn[j] = quad_perm_f64<CTRL>((j & 1) ? yp1 : yp0);
+                constexpr int CTRL = ((j % (2 * TEAM)) / 2) * 0x55;
+                yn[j] = quad_perm_f64<CTRL>(yp[2 * (j / (2 * TEAM)) + (j & 1)]);
             });
         }
     };
@@ -772,14 +781,19 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         if (valid) {
             // (write-through stores: visible to every agent once acknowledged)
             const long long orow = ((long long)((k - 1) % (int)ring)) * B + b0 + inst;
-            double s0 = v[N - 1], s1 = v[N - 1];
-            static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
-                constexpr int kk = decltype(kc)::value;
-                if constexpr (2 * kk < N) s0 = (r == kk) ? v[2 * kk] : s0;
-                if constexpr (2 * kk + 1 < N) s1 = (r == kk) ? v[2 * kk + 1] : s1;
+            static_for<0, RQ>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int rho = decltype(rc)::value;
+                double s0 = v[N - 1], s1 = v[N - 1];
+                static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int kk = decltype(kc)::value;
+                    constexpr int j0 = 2 * TEAM * rho + 2 * kk;
+                    if constexpr (j0 < N) s0 = (r == kk) ? v[j0] : s0;
+                    if constexpr (j0 + 1 < N) s1 = (r == kk) ? v[j0 + 1] : s1;
+                });
+                const int e = 2 * TEAM * rho + 2 * r;
+                if (e < N) __hip_atomic_store(dq + orow * N + e, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (e + 1 < N) __hip_atomic_store(dq + orow * N + e + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             });
-            if (2 * r < N) __hip_atomic_store(dq + orow * N + 2 * r, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (2 * r + 1 < N) __hip_atomic_store(dq + orow * N + 2 * r + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (mode_out != nullptr && r == 0)
                 __hip_atomic_store(mode_out + orow, ok0 ? 0 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -181,3 +181,35 @@ def test_value_kernels_of_the_baseline_skills_are_prebuilt():
     assert [n for n, _ in built] == ["stack_iiwa", "pose_iiwa", "qp_iiwa"]
     for _, tag in built:
         assert os.path.exists(os.path.join(jit.CACHE, "clik_shape_%s.so" % tag))
+
+
+def test_value_kernels_of_the_team_family_compile_for_long_input_rows():
+    """The value-specialised kernels (launched, rollout AND resident) of a config-3-family skill whose input_var has 14 /
+    13 entries (targets for the pose and for every joint): the resident kernel's quad shares its rows two elements per
+    lane and needs two rounds for rows longer than eight - a static_assert there once took the whole instantiation (and
+    with it the four-lanes kernel of such skills) down, unseen by the BASELINE skills (7 entries).  No GPU needed."""
+    import numpy as np
+    import casclik_amd as cc
+    from casclik_amd import jit, sym as cs
+    from casclik_amd.controllers.pseudo_inverse import PseudoInverseController
+    if jit._hipcc() is None:
+        pytest.skip("no hipcc")
+    lib = _capi.load_library()
+    for fk in (skills.iiwa(), skills.ur5()):
+        n = len(fk["joint_names"])
+        t, q, y = cs.MX.sym("t"), cs.MX.sym("q", n), cs.MX.sym("y", 7 + n)
+        T = fk["T_fk"](q)
+        cons = [cc.EqualityConstraint("joints", cs.vertcat(*[q[j] - y[7 + j] for j in range(n)]), gain=1.0, priority=2),
+                cc.SetConstraint(label="limits", expression=q, priority=0, set_min=np.array(fk["lower"]),
+                                 set_max=np.array(fk["upper"])),
+                cc.EqualityConstraint("task", skills._pose_expression(T, y), gain=3.0, priority=1)]
+        spec = cc.SkillSpecification("long_rows", t, q, input_var=y, constraints=cons)
+        desc = lower_skill(spec)
+        cdesc = _capi.desc_to_c(desc)
+        copts = _capi.pinv_opts_to_c(PseudoInverseController(skill_spec=spec, options={"multidim_sets": True}).options)
+        ok, init = jit.shape_of(lib, cdesc, copts)
+        assert ok and desc.n_y == 7 + n
+        words = jit.host_image_words(lib, "pinv", cdesc, copts)
+        text = jit._VALUE_TEMPLATE.replace("%(nwords)d", str(len(words))).replace("%(words)s", ", ".join(w + "ull" for w in words))
+        so, tag = jit.build_shape_library(init, False, template=text, defines=("-DCLIK_VALUE_KERNEL",), extern="")
+        assert so is not None and os.path.exists(so)

@@ -391,3 +391,41 @@ def test_resident_ticks_integrate_the_state_and_take_streamed_targets(iiwa_fk):
     # (the same arithmetic in the same order: the kernel's fma(d, dt, q) against the host's q + dq * dt differ by
     # rounding in the state, which the ticks then see)
     assert worst < 1e-8, worst          # (measured 1.4e-9: the "mixed" inputs hold near-singular configurations)
+
+
+def test_resident_ticks_with_input_rows_longer_than_eight(iiwa_fk):
+    """A member of the family whose input_var has 14 entries (pose target + one target per joint): the resident kernel's
+    quad hands its rows round two elements per lane and needs two rounds for such a row - ring of three slots with
+    different batches, every ticket published ahead, seven ticks; every slot equals an ordinary launch."""
+    import torch
+    fk = iiwa_fk
+    n = 7
+    t, q, y = cs.MX.sym("t"), cs.MX.sym("q", n), cs.MX.sym("y", 7 + n)
+    T = fk["T_fk"](q)
+    cons = [cc.EqualityConstraint("joints", cs.vertcat(*[q[j] - y[7 + j] for j in range(n)]), gain=1.0, priority=2),
+            cc.SetConstraint(label="limits", expression=q, priority=0, set_min=np.array(fk["lower"]),
+                             set_max=np.array(fk["upper"])),
+            cc.EqualityConstraint("task", skills._pose_expression(T, y), gain=3.0, priority=1)]
+    spec = cc.SkillSpecification("long_rows", t, q, input_var=y, constraints=cons)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options={"multidim_sets": True})
+    ctrl.setup_problem_functions()
+    B, D, NT = 600, 3, 7
+    if "team4v" not in ctrl.kernel_variant(B):
+        pytest.skip("no value-specialised team kernel attached (hipcc missing)")
+    rng = np.random.default_rng(8)
+    slots = []
+    for s in range(D):
+        Q, Y7 = skills.synthetic_inputs(fk, B, seed=200 + s, distribution="mixed")
+        slots.append((Q, np.hstack([Y7, rng.uniform(-0.5, 0.5, size=(B, n))])))
+    Qr = torch.stack([torch.from_numpy(a).cuda() for a, _ in slots]).contiguous()
+    Yr = torch.stack([torch.from_numpy(b).cuda() for _, b in slots]).contiguous()
+    want = [ctrl.solve_batch(0.0, Qr[s], input_var=Yr[s]) for s in range(D)]
+    torch.cuda.synchronize()
+    run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
+    feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
+    run["stream"].synchronize()
+    feeder.synchronize()
+    tk = run["ticket"].cpu()
+    assert int(tk[32]) == 0 and int(tk[49]) == NT
+    for s in range(D):
+        assert torch.equal(run["out"][s], want[s][0]) and torch.equal(run["mode"][s], want[s][2]), s
