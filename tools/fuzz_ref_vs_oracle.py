@@ -6,7 +6,7 @@ vector-free matrix), 1-D and multidimensional sets on joints and on task-space c
 virtual variable, time-dependent targets, every controller option - builds each TWICE from one recipe (the reference's
 constraint classes and controllers over the stand-in casadi with kinematics multiplied out from the reference's URDF;
 the product's front-end with its URDF converter), runs the reference's own `solve()` per instance and the numpy oracle
-on the same inputs, and compares modes, velocities, slack, QP data and statuses.
+on the same inputs, and compares `print_constraints()` texts, modes, velocities, slack, QP data and statuses.
 
     python tools/fuzz_ref_vs_oracle.py [skills=40] [seed=0]          (summary: profiles/r3_fuzz_ref_vs_oracle.txt)
 """
@@ -157,6 +157,15 @@ def main():
         ref_spec = build(rec, rcs, rcc, gen.make_T_fk(chain), gen.ori_err, lower, upper, vmax)
         own_spec = build(rec, pcs, pcc, fk["T_fk"], pcs.orientation_error, lower, upper, vmax)
         assert [c.label for c in ref_spec.constraints] == [c.label for c in own_spec.constraints], "priority sort differs"
+        texts = []
+        for built in (ref_spec, own_spec):          # print_constraints(): the same text from both packages
+            import contextlib
+            import io
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                built.print_constraints()
+            texts.append(buf.getvalue())
+        assert texts[0] == texts[1], ("print_constraints() differs", texts)
         Q = rng.uniform(0.7 * lower, 0.7 * upper, size=(B, n))
         X = rng.uniform(0.0, 2.0, size=(B, 1)) if rec["virtual"] else None
         t0 = float(rng.uniform(0.0, 2.0))
