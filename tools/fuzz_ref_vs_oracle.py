@@ -233,6 +233,23 @@ def main():
                 if r_status == 0 and ostatus[b] == 0:
                     rdq = res[0].full().ravel()
                     e_sol = max(e_sol, np.abs(odq[b] - rdq).max() / (1.0 + np.abs(rdq).max()))
+            # the initial problem (reactive_qp.py:300-459): virtual velocities and slack with the robot held still
+            e_init = 0.0
+            qp.setup_initial_problem_solver()
+            for b in range(0, B, 6):
+                kw0 = {"virtual_var0": X[b]} if rec["virtual"] else {}
+                try:
+                    r_virt, r_slack = qp.solve_initial_problem(t0, Q[b], **kw0)
+                except RuntimeError:
+                    continue
+                o_virt, o_slack = clik_oracle.qp_initial_problem(own_spec, t0, Q[b], x0=X[b] if rec["virtual"] else None)
+                for got, want in ((o_virt, r_virt), (o_slack, r_slack)):
+                    if want is None or got is None:
+                        assert (want is None) == (got is None), "initial problem: None pattern differs"
+                        continue
+                    w = np.asarray(want.full()).ravel()
+                    e_init = max(e_init, float(np.abs(np.asarray(got).ravel() - w).max() / (1.0 + np.abs(w).max())))
+            worst["qp_init"] = max(worst.get("qp_init", 0.0), e_init)
             counts["qp_runs"] += 1
             counts["status_mismatch"] += bad_status
             worst["qp"], worst["qp_data"] = max(worst["qp"], e_sol), max(worst["qp_data"], e_data)
@@ -243,10 +260,10 @@ def main():
             line += " | qp skipped (%s: %s)" % (type(exc).__name__, str(exc)[:60])
         print("%3d %-60s %s" % (k, what[:60], line), flush=True)
     print("reference package over the stand-in vs the numpy oracle: %d random skills x %d instances; pinv runs %d, worst "
-          "relative error %.2e, mismatching modes %d; QP runs %d, rows worst %.2e, minimiser worst %.2e, status "
-          "mismatches %d; refused by the reference or the oracle: %d"
+          "relative error %.2e, mismatching modes %d; QP runs %d, rows worst %.2e, minimiser worst %.2e, initial "
+          "problem worst %.2e, status mismatches %d; refused by the reference or the oracle: %d"
           % (n_skills, B, counts["pinv_runs"], worst["pinv"], counts["mode_mismatch"], counts["qp_runs"],
-             worst["qp_data"], worst["qp"], counts["status_mismatch"], counts["skipped"]))
+             worst["qp_data"], worst["qp"], worst.get("qp_init", 0.0), counts["status_mismatch"], counts["skipped"]))
 
 
 if __name__ == "__main__":
