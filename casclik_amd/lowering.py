@@ -37,7 +37,7 @@ MAX_ROWS = 96
 MAX_SETS = 8
 MAX_TSLOTS = 32
 MAX_YTERMS = 4
-MAX_QPVARS = 24
+MAX_QPVARS = 42
 MAX_QPROWS = 32
 MAX_STATIC_TASKS = 8   # SHAPE_MAX_TASKS of csrc/clik_device.hpp
 

@@ -60,7 +60,9 @@ extern "C" {
                                  1-D set per joint has 128)                        */
 #define CLIK_MAX_TSLOTS  32   /* time-only sub-expressions evaluated by the host  */
 #define CLIK_MAX_YTERMS   4   /* input_var terms per affine row                   */
-#define CLIK_MAX_QPVARS  24   /* n_state + n_slack of the reactive QP             */
+#define CLIK_MAX_QPVARS  42   /* n_state + n_slack of the reactive QP (CLIK_MAX_DOF + one slack per row; the
+                                 kernels instantiated for a skill fold the slack of soft equalities away,
+                                 the built-in ones are bounded by their rows)       */
 #define CLIK_MAX_QPROWS  32   /* constraint rows of the reactive QP               */
 
 /* error codes */

@@ -629,3 +629,28 @@ def test_qp_walls_joint_limits_and_speed_limits_on_every_joint_fit_the_static_ke
     ok = rstatus == 0
     assert ok.sum() > 60
     assert _rel(dq[sub][ok], rdq[ok]).max() < QP_RTOL and _rel(slack[sub][ok], rslack[ok]).max() < QP_RTOL
+
+
+def test_qp_with_three_soft_six_row_tasks_25_variables(iiwa_fk):
+    """Three soft 6-row pose tasks and the speed limits on a 7-DoF arm: 7 + 18 = 25 QP variables as the reference
+    writes the problem (reactive_qp.py:175-246) - one more than the old cap on variables, although the instantiated
+    kernels fold the 18 slack variables of soft equalities away and solve a 7-variable box QP.  Equal to the oracle's
+    dense solve of the full problem, slack included."""
+    from oracle import clik_oracle
+    fk = iiwa_fk
+    t, q, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("y", 7)
+    T = fk["T_fk"](q)
+    vm = np.array(fk["velocity"])
+    cons = [cc.EqualityConstraint("pose%d" % k, skills._pose_expression(T, y) + 0.02 * k, gain=float(2 + k),
+                                  constraint_type="soft", slack_weight=float(1 + 2 * k), priority=k) for k in range(3)]
+    cons.append(cc.VelocitySetConstraint("speed", q, set_min=-vm, set_max=vm, priority=9))
+    spec = cc.SkillSpecification("three_poses", t, q, input_var=y, constraints=cons)
+    ctrl = _controller(spec)
+    assert ctrl.kernel_name not in ("dynamic", "none")
+    Q, Y = skills.synthetic_inputs(fk, 256, seed=4, distribution="mixed")
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y)
+    assert slack.shape == (256, 18)
+    sub = np.arange(0, 256, 4)
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[sub], Y=Y[sub])
+    assert np.array_equal(status[sub], rstatus) and (rstatus == 0).all()
+    assert _rel(dq[sub], rdq).max() < QP_RTOL and _rel(slack[sub], rslack).max() < QP_RTOL
