@@ -313,6 +313,12 @@ def record_pinv_api(out):
     print("pinv(): %d matrices recorded" % len([k for k in out if k.startswith("pinvapi_")]))
 
 
+def return_pattern(res):
+    """shape of what solve() returns (pseudo_inverse.py:512-556, reactive_qp.py:461-528): per tuple entry -1 for None,
+    else rows * 100 + columns of its .toarray()"""
+    return np.array([-1 if r is None else int(r.full().shape[0]) * 100 + int(r.full().shape[1]) for r in res])
+
+
 def record_api_values():
     import json
     import make_ref_golden_cases
@@ -369,6 +375,7 @@ def main():
                     dq[ti, b] = res[0].full().reshape(-1)
                     mode[ti, b] = ctrl.current_mode
             out[name + "_dq"], out[name + "_mode"] = dq, mode
+            out[name + "_ret"] = return_pattern(res)
             print("%-26s modes %s  max|dq| %.3g  (%d constraints, order %s)" % (
                 name, np.bincount(mode.reshape(-1) + 1), np.abs(dq).max(), len(spec.constraints),
                 [c.label for c in spec.constraints]))
@@ -394,6 +401,7 @@ def main():
                 vals_ = [times[0], Q[b]] + ([X[b]] if nx else []) + ([Y[b, :ny]] if ny else [])
                 try:
                     rq, rx, rs = ctrl.solve(times[0], Q[b], **kw)
+                    out[name + "_ret"] = return_pattern((rq, rx, rs))
                 except RuntimeError:
                     # the reference surfaces an infeasible QP as the solver's RuntimeError (reactive_qp.py:491-513):
                     # recorded as status 2 (rows of the data functions are still the reference's)

@@ -95,3 +95,38 @@ def test_initial_problem_hip_matches_the_reference_run(name):
             assert np.abs(np.asarray(virt.toarray()).reshape(-1) - refv).max() < 1e-8 * (1 + np.abs(refv).max())
         else:
             assert virt is None
+
+
+@pytest.mark.parametrize("name", refpins.NAMES)
+def test_single_instance_solve_returns_what_the_reference_returns(name):
+    """`solve()` of one instance through the reference-shaped API (pseudo_inverse.py:512-556, reactive_qp.py:461-528):
+    a 3-tuple whose entries are None exactly where the reference's are (no virtual variable / no slack) and (n, 1)
+    matrices elsewhere (fixture `<name>_ret`, recorded from the reference's own return values), with the first
+    instance's numbers equal to the batch path's."""
+    built = refpins.product_skill(name)
+    spec = built["spec"]
+    Q, Y, X, times = refpins.arrays(name)
+    if built["controller"] == "pinv":
+        ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(built["options"]) if built["options"] else None)
+    else:
+        ctrl = cc.ReactiveQPController(skill_spec=spec, options=dict(built["options"]) if built["options"] else None)
+    try:
+        ctrl.setup_problem_functions()
+    except NotImplementedError:
+        pytest.skip("skill outside the kernels of this build (covered by its own test)")
+    ctrl.setup_solver()
+    has_y = spec.input_var is not None and spec._has_input
+    kw = {}
+    if has_y:
+        kw["input_var"] = Y[0]
+    if X is not None:
+        kw["virtual_var"] = X[0]
+    try:
+        res = ctrl.solve(float(times[0]), Q[0], **kw)
+    except RuntimeError:
+        assert refpins.ref_status(name)[0] == 2            # (the reference raises on its infeasible instances too)
+        return
+    want = refpins.PINS[name + "_ret"]
+    assert isinstance(res, tuple) and len(res) == len(want)
+    got = [-1 if r is None else r.toarray().shape[0] * 100 + r.toarray().shape[1] for r in res]
+    assert got == want.tolist(), (got, want.tolist())
