@@ -447,10 +447,17 @@ def tangent_cone_margin(e, set_min, set_max, dexpr):
 # ==========================================================================
 # PseudoInverseController
 # ==========================================================================
-def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False, margins_out=None):
+def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False, margins_out=None, _wrong=None):
     """Literal PseudoInverseController: returns (dZ [B,n_state], mode [B]).
 
-    dZ[:, :n_q] is robot_vel, the rest virtual_vel."""
+    dZ[:, :n_q] is robot_vel, the rest virtual_vel.
+
+    `_wrong` (None = the reference's algorithm) names ONE deliberate deviation, for the tests that state what the
+    reference-held figure pins resolve (tests/test_figure_pins.py): "no_S" stacks J instead of S J for an active
+    multidimensional set (:352-355, 401-404), "no_D1" processes the first equality once (the textbook reading of
+    :317-396), "textbook_projection" uses pinv(J N) instead of N pinv(J) (:387-394), "active_first" scans the modes
+    with the most active sets first (:107-130)."""
+    assert _wrong in (None, "no_S", "no_D1", "textbook_projection", "active_first"), _wrong
     opt = default_pinv_options(options)
     Q = np.atleast_2d(np.asarray(Q, dtype=float))
     B = Q.shape[0]
@@ -466,6 +473,8 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
     views = attribute_views(evaluator, cn)
     n_sets = sum(1 for c in cn if _cls(c) == "SetConstraint")
     amap = activation_map(n_sets)
+    if _wrong == "active_first":
+        amap = amap[::-1]
     n_modes = 2 ** n_sets
     ff = opt["feedforward"]
     multidim = opt["multidim_sets"]
@@ -500,8 +509,12 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     smin = _num(a.set_min, m)
                     smax = _num(a.set_max, m)
                     S = np.diag(((e - smax > 0.0) | (e - smin < 0.0)).astype(float))
+                    if _wrong == "no_S":
+                        S = np.eye(m)
+                just_processed = False
                 # chain 1 (:317-326)
                 if is_first and is_eq:
+                    just_processed = _wrong == "no_D1"
                     des = -_gain_apply(a.gain, e)
                     if ff:
                         des = des - Jt
@@ -529,12 +542,17 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     else:
                         tc.append(ci)
                     set_idx += 1
+                elif is_eq and just_processed:
+                    pass
                 elif is_eq:
                     des = -_gain_apply(a.gain, e)
                     if ff:
                         des = des - Jt
                     N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
-                    v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                    if _wrong == "textbook_projection":
+                        v = v + dpinv(Ji.dot(N), opt).dot(des - Ji.dot(v))
+                    else:
+                        v = v + N.dot(dpinv(Ji, opt)).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 elif is_set:
                     if amap[mode_idx][set_idx]:

@@ -140,3 +140,106 @@ def simulate_pendulum(case, solve):
     return t_sim, q_sim, dq_sim, p_sim
 
 
+
+
+# ---- UR5, Moe-2016 example 2: a trajectory that leaves a box (pinv with 8 modes / with a multidimensional set; QP) ---
+MOE_DT, MOE_TICKS, MOE_MAX_SPEED = 0.008, 10000, np.pi / 5                  # ur5_moe2016_example2.ipynb cells 5, 12
+MOE_HOME = np.array([-50.0, -160.0, -110.0, -90.0, -90.0, 0.0]) / 180.0 * np.pi
+MOE_WALLS = np.array([[0.1, 0.6], [-0.5, 0.4], [-0.3, 0.25]])             # cell 7: x, y, z (min, max)
+MOE_DH = dict(link_lengths=[0., -0.425, -0.392, 0., 0., 0.], link_twists=[np.pi / 2, 0., 0., np.pi / 2, -np.pi / 2, 0.],
+              link_offsets=[0.089, 0., 0., 0.109, 0.095, 0.082])           # cell 2: the UR5's classic DH table
+MOE_CASES = ["pinv_singular", "pinv_multidim", "qp_singular", "qp_multidim"]
+
+
+def moe_path(t, np_or_cs=np):
+    """cell 7: the desired tool trajectory (omega = 0.1)"""
+    m = np_or_cs
+    return [0.5 * m.sin(0.1 * t) * m.sin(0.1 * t) + 0.2, 0.5 * m.cos(0.1 * t) + 0.25 * m.sin(0.1 * t),
+            0.5 * m.sin(0.1 * t) * m.cos(0.1 * t) + 0.1]
+
+
+def moe_skill(situation, cs, cc, T_fk):
+    """ur5_moe2016_example2.ipynb cells 4-8.  'singular': three 1-D wall SetConstraints on the tool position (hard, gain
+    5e2, priorities y 7 < x 8 < z 9) in front of the soft tracking equality (gain 0.15, priority 10); 'multidim': ONE
+    3-row SetConstraint for the box.  -> (SkillSpecification, t, q)"""
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    p = T_fk(q)[:3, 3]
+    path = cs.vertcat(*moe_path(t, cs))
+    (x_min, x_max), (y_min, y_max), (z_min, z_max) = MOE_WALLS
+    track = cc.EqualityConstraint(label="move_point2", expression=p - path, priority=10, constraint_type="soft", gain=0.15)
+    if situation == "singular":
+        cons = [cc.SetConstraint(label="colav_x", expression=p[0], set_min=x_min, set_max=x_max, priority=8,
+                                 constraint_type="hard", gain=5e2),
+                cc.SetConstraint(label="colav_y", expression=p[1], set_min=y_min, set_max=y_max, priority=7,
+                                 constraint_type="hard", gain=5e2),
+                cc.SetConstraint(label="colav_z", expression=p[2], set_min=z_min, set_max=z_max, priority=9,
+                                 constraint_type="hard", gain=5e2),
+                track]
+        label = "box_move"
+    else:
+        cons = [cc.SetConstraint(label="colav_box", expression=p, set_min=MOE_WALLS[:, 0].copy(),
+                                 set_max=MOE_WALLS[:, 1].copy(), priority=7, constraint_type="hard", gain=5e2),
+                track]
+        label = "box_move_multidim"
+    spec = cc.SkillSpecification(label=label, time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons)
+    return spec, t, q
+
+
+def simulate_moe(solve, fk_position, n_ticks=MOE_TICKS):
+    """cell 12: `solve(t, q)` -> (dq [6], mode | None); `fk_position(q)` -> tool position [3].  Returns t_sim, q_sim, p_sim,
+    e_sim, mode_sim as the notebook fills them: e_sim[i + 1] is the tracking error at q_sim[i + 1] against the
+    trajectory at t_sim[i]; mode_sim[i + 1] the mode of tick i."""
+    t_sim = np.array([MOE_DT * i for i in range(n_ticks + 1)])
+    q_sim, p_sim = np.zeros((n_ticks + 1, 6)), np.zeros((n_ticks + 1, 3))
+    e_sim, mode_sim = np.zeros(n_ticks + 1), np.zeros(n_ticks + 1)
+    q_sim[0] = MOE_HOME
+    p_sim[0] = fk_position(MOE_HOME)
+    e_sim[0] = np.linalg.norm(p_sim[0] - np.array(moe_path(t_sim[0])))
+    for i in range(n_ticks):
+        dq, mode = solve(t_sim[i], q_sim[i])
+        dq = np.clip(dq, -MOE_MAX_SPEED, MOE_MAX_SPEED)
+        q_sim[i + 1] = q_sim[i] + dq * MOE_DT
+        p_sim[i + 1] = fk_position(q_sim[i + 1])
+        e_sim[i + 1] = np.linalg.norm(p_sim[i + 1] - np.array(moe_path(t_sim[i])))
+        if mode is not None:
+            mode_sim[i + 1] = mode
+    return t_sim, q_sim, p_sim, e_sim, mode_sim
+
+
+def interval_deviation(key, t_sim, values, reach=1.5, within=None):
+    """Interval pins (tests/golden/moe_figure_pins.py): per pixel column the stored figure allows the curve's centre one or
+    more intervals of values.  For every column: how far (in pixel rows) the simulated curve - taken anywhere within
+    `reach` pixels in t - stays away from the nearest of them.  Returns (worst deviation, columns, t of the worst)."""
+    ft, flo, fhi = FIGS[key + "_t"], FIGS[key + "_lo"], FIGS[key + "_hi"]
+    px_t, px_v = FIGS[key + "_pixel"]
+    order = np.argsort(ft, kind="stable")
+    ft, flo, fhi = ft[order], flo[order], fhi[order]
+    starts = np.nonzero(np.diff(ft, prepend=-np.inf) > 0)[0]
+    worst, where = 0.0, None
+    n = 0
+    for k, s in enumerate(starts):
+        e = starts[k + 1] if k + 1 < len(starts) else len(ft)
+        if ft[s] + reach * px_t > t_sim[-1] or (within is not None and not within[0] <= ft[s] <= within[1]):
+            continue                                           # (a shortened simulation: the columns it covers)
+        n += 1
+        i0, i1 = np.searchsorted(t_sim, [ft[s] - reach * px_t, ft[s] + reach * px_t])
+        smin, smax = values[i0:max(i1, i0 + 1)].min(), values[i0:max(i1, i0 + 1)].max()
+        miss = min(max(lo - smax, smin - hi, 0.0) for lo, hi in zip(flo[s:e], fhi[s:e])) / px_v
+        if miss > worst:
+            worst, where = miss, float(ft[s])
+    return worst, n, where
+
+
+def fill_deviation(key, t_sim, values, reach=1.5):
+    """columns a chattering run FILLS between two levels in the stored figure (rows: t, low level, high level): the
+    simulated run has to visit both levels within `reach` pixels of the column.  Returns (columns missed, columns)."""
+    fill = FIGS[key + "_fill"]
+    px_t = FIGS[key + "_pixel"][0]
+    missed = 0
+    for tk, lo, hi in fill:
+        if tk + reach * px_t > t_sim[-1]:
+            continue
+        i0, i1 = np.searchsorted(t_sim, [tk - reach * px_t, tk + reach * px_t])
+        seen = values[i0:max(i1, i0 + 1)]
+        missed += not (seen.min() <= lo + 0.25 and seen.max() >= hi - 0.25)
+    return missed, len(fill)

@@ -27,9 +27,12 @@ import io
 import json
 import os
 
+import sys
+
 import numpy as np
 from PIL import Image
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.dirname(os.path.abspath(__file__))
 NOTEBOOKS = "/root/reference/examples/notebooks/"
 CART = "cart_on_track_1D_comparison_of_controllers.ipynb"
@@ -96,7 +99,9 @@ def stored_png(notebook, cell):
             im = np.array(Image.open(io.BytesIO(raw)).convert("RGBA")).astype(float)
             a = im[..., 3:] / 255.0
             return im[..., :3] * a + 255.0 * (1.0 - a)          # on white
-    raise RuntimeError("cell %d stores no figure" % cell)
+    # `%matplotlib notebook` cells keep their figure as <img src="data:image/png;base64,..."> inside a text/html output
+    import moe_figure_pins
+    return moe_figure_pins.html_png(notebook, cell)
 
 
 def axes_boxes(rgb):
@@ -387,6 +392,9 @@ def main():
                       "  range [%.4f, %.4f]" % (name, curve, keep.sum(), t_first, t_last, t_max, per_col, per_row, row_hi,
                                                row_lo, v[keep].min(), v[keep].max()))
         out[name + "_dt"] = np.array(dt)
+    # ur5_moe2016_example2.ipynb cells 13-27 (html-embedded figures; interval pins, layout calibration)
+    import moe_figure_pins
+    moe_figure_pins.collect(out)
     path = os.path.join(HERE, "notebook_figures.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays,", os.path.getsize(path), "bytes")

@@ -142,3 +142,48 @@ def simulate_frame_error(eval_norm, solve):
         q = q + np.clip(solve(t_sim[i], q), -max_speed, max_speed) * dt
         e_sim[i + 1] = float(np.asarray(eval_norm(t_sim[i], q).toarray()).ravel()[0])
     return t_sim, np.log10(np.maximum(e_sim, 1e-300))
+
+
+# ---- UR5, Moe-2016 example 2 (ur5_moe2016_example2.ipynb): pinv with 8 modes / an active multidimensional set; QP ------
+from figure_skills import (MOE_CASES, MOE_DT, MOE_TICKS, MOE_HOME, moe_path, simulate_moe, interval_deviation,   # noqa: E402,F401
+                           fill_deviation)
+
+
+def moe_fk():
+    """cell 2: joint names and limits from the URDF, kinematics from the UR5's Denavit-Hartenberg table"""
+    from casclik_amd import skills
+    from casclik_amd.urdf import converter
+    fk = skills.ur5()
+    return converter.from_denavit_hartenberg(joint_angles=["s"] * 6, joint_names=fk["joint_names"],
+                                             upper_limits=fk["upper"], lower_limits=fk["lower"], **figure_skills.MOE_DH)
+
+
+def moe_skill(fk, situation):
+    return figure_skills.moe_skill(situation, cs, cc, fk["T_fk"])[0]
+
+
+def moe_options(case):
+    return {"multidim_sets": True} if case == "pinv_multidim" else None            # cell 11
+
+
+def moe_pins(case, t_sim, p_sim, e_sim, mode_sim, within=None):
+    """every pin the stored figures hold for one of the four runs -> [(pin, worst deviation in pixels, columns, t)]"""
+    kind, sit = case.split("_")
+    own = kind == "pinv"                        # the pinv curves are visible in their own colour; the QP's lie under the others
+    rows = []
+    for k, axis in enumerate("xyz"):
+        rows.append(("moe_%s_%s_union" % (axis, sit), p_sim[:, k]))
+        if own:
+            rows.append(("moe_%s_%s_pinv" % (axis, sit), p_sim[:, k]))
+    if sit == "multidim":
+        rows.append(("moe_y_multidim_inset_union", p_sim[:, 1]))
+        if own:
+            rows.append(("moe_y_multidim_inset_pinv", p_sim[:, 1]))
+    for fig in ("moe_e_%s" % sit, "moe_e_%s_small" % sit, "moe_e_%s_small_inset" % sit):
+        rows.append((fig + "_union", e_sim))
+        if own:
+            rows.append((fig + "_pinv", e_sim))
+    if own:
+        rows += [("moe_modes_multidim", mode_sim), ("moe_modes_full_multidim", mode_sim)] if sit == "multidim" else [
+            ("moe_modes_separate", mode_sim)]
+    return [(key,) + interval_deviation(key, t_sim, values, within=within) for key, values in rows]
