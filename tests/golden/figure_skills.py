@@ -243,3 +243,26 @@ def fill_deviation(key, t_sim, values, reach=1.5):
         seen = values[i0:max(i1, i0 + 1)]
         missed += not (seen.min() <= lo + 0.25 and seen.max() >= hi - 0.25)
     return missed, len(fill)
+
+
+def moe_pins(case, t_sim, p_sim, e_sim, mode_sim, within=None):
+    """every pin the stored figures hold for one of the four runs -> [(pin, worst deviation in pixels, columns, t)]"""
+    kind, sit = case.split("_")
+    own = kind == "pinv"                        # the pinv curves are visible in their own colour; the QP's lie under the others
+    rows = []
+    for k, axis in enumerate("xyz"):
+        rows.append(("moe_%s_%s_union" % (axis, sit), p_sim[:, k]))
+        if own:
+            rows.append(("moe_%s_%s_pinv" % (axis, sit), p_sim[:, k]))
+    if sit == "multidim":
+        rows.append(("moe_y_multidim_inset_union", p_sim[:, 1]))
+        if own:
+            rows.append(("moe_y_multidim_inset_pinv", p_sim[:, 1]))
+    for fig in ("moe_e_%s" % sit, "moe_e_%s_small" % sit, "moe_e_%s_small_inset" % sit):
+        rows.append((fig + "_union", e_sim))
+        if own:
+            rows.append((fig + "_pinv", e_sim))
+    if own:
+        rows += [("moe_modes_multidim", mode_sim), ("moe_modes_full_multidim", mode_sim)] if sit == "multidim" else [
+            ("moe_modes_separate", mode_sim)]
+    return [(key,) + interval_deviation(key, t_sim, values, within=within) for key, values in rows]

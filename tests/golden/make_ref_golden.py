@@ -88,6 +88,22 @@ def make_T_fk(chain):
     return T_fk
 
 
+def make_dh_T_fk(link_lengths, link_twists, link_offsets):
+    """T = prod_i Rot_z(q_i) Trans_z(d_i) Trans_x(a_i) Rot_x(alpha_i): the classic Denavit-Hartenberg table
+    ur5_moe2016_example2.ipynb cell 2 hands to urdf2casadi's `from_denavit_hartenberg`, multiplied out with the stand-in"""
+    def T_fk(q):
+        T = cs.DM.eye(4)
+        for i, (a, alpha, d) in enumerate(zip(link_lengths, link_twists, link_offsets)):
+            c, s = cs.cos(q[i]), cs.sin(q[i])
+            Rz = cs.vertcat(cs.horzcat(c, -s, 0.0, 0.0), cs.horzcat(s, c, 0.0, 0.0), cs.horzcat(0.0, 0.0, 1.0, 0.0),
+                            cs.horzcat(0.0, 0.0, 0.0, 1.0))
+            ca, sa = np.cos(alpha), np.sin(alpha)
+            link = np.array([[1.0, 0.0, 0.0, a], [0.0, ca, -sa, 0.0], [0.0, sa, ca, d], [0.0, 0.0, 0.0, 1.0]])
+            T = cs.mtimes(T, cs.mtimes(Rz, cs.DM(link)))
+        return T
+    return T_fk
+
+
 def quat_to_rot(qt):
     x, y, z, w = qt[0], qt[1], qt[2], qt[3]
     return [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
@@ -284,7 +300,40 @@ def check_against_the_stored_figures():
             worst_all, n_curves = max(worst_all, worst), n_curves + 1
     print("reference package + stand-in casadi: 9 stored closed-loop figures (%d curves) reproduced, worst deviation "
           "%.2f pixel rows" % (n_curves, worst_all))
-    return worst_all
+    # ur5_moe2016_example2.ipynb cells 2-12: the REFERENCE's PseudoInverseController (8 modes; multidim_sets with the box
+    # active for 45 % of the run) and ReactiveQPController over the stand-in, 10000 ticks each, against cells 13-27's
+    # figures (interval pins: tests/golden/moe_figure_pins.py)
+    T_fk = make_dh_T_fk(**fs.MOE_DH)
+    qsym = cs.MX.sym("q", 6)
+    p_num = cs.Function("p", [qsym], [T_fk(qsym)[:3, 3]])
+    worst_moe, n_pins = 0.0, 0
+    for case in fs.MOE_CASES:
+        kind, sit = case.split("_")
+        spec, _, _ = fs.moe_skill(sit, cs, cc, T_fk)
+        if kind == "pinv":
+            ctrl = cc.PseudoInverseController(skill_spec=spec, options={"multidim_sets": True} if sit == "multidim" else None)
+        else:
+            ctrl = cc.ReactiveQPController(skill_spec=spec)
+        ctrl.setup_problem_functions()
+        ctrl.setup_solver()
+        ctrl.setup_initial_problem_solver()
+        state = {"slack": ctrl.solve_initial_problem(0, fs.MOE_HOME)[-1]}
+
+        def solve(t, q, ctrl=ctrl, kind=kind, state=state):
+            res = ctrl.solve(t, q, warmstart_slack_var=state["slack"])
+            if res[-1] is not None:
+                state["slack"] = res[-1].toarray()[:, 0]
+            return res[0].toarray()[:, 0], (ctrl.current_mode if kind == "pinv" else None)
+        t_sim, q_sim, p_sim, e_sim, mode_sim = fs.simulate_moe(solve, lambda q: p_num(q).full()[:, 0])
+        for key, worst, n, where in fs.moe_pins(case, t_sim, p_sim, e_sim, mode_sim):
+            assert n >= 2 and worst < 1.0, ("reference + stand-in misses the stored figure", case, key, worst, where)
+            worst_moe, n_pins = max(worst_moe, worst), n_pins + 1
+        if case == "pinv_singular":
+            assert fs.fill_deviation("moe_modes_separate", t_sim, mode_sim)[0] == 0
+        print("   %s: %d ticks through the reference's solve()" % (case, len(t_sim) - 1))
+    print("reference package + stand-in casadi: the Moe-2016 notebook's 12 stored figures (%d pins over 4 runs) reproduced, worst "
+          "deviation %.2f pixel rows" % (n_pins, worst_moe))
+    return max(worst_all, worst_moe)
 
 
 def record_error_behaviour():

@@ -146,7 +146,7 @@ def simulate_frame_error(eval_norm, solve):
 
 # ---- UR5, Moe-2016 example 2 (ur5_moe2016_example2.ipynb): pinv with 8 modes / an active multidimensional set; QP ------
 from figure_skills import (MOE_CASES, MOE_DT, MOE_TICKS, MOE_HOME, moe_path, simulate_moe, interval_deviation,   # noqa: E402,F401
-                           fill_deviation)
+                           fill_deviation, moe_pins)
 
 
 def moe_fk():
@@ -164,26 +164,3 @@ def moe_skill(fk, situation):
 
 def moe_options(case):
     return {"multidim_sets": True} if case == "pinv_multidim" else None            # cell 11
-
-
-def moe_pins(case, t_sim, p_sim, e_sim, mode_sim, within=None):
-    """every pin the stored figures hold for one of the four runs -> [(pin, worst deviation in pixels, columns, t)]"""
-    kind, sit = case.split("_")
-    own = kind == "pinv"                        # the pinv curves are visible in their own colour; the QP's lie under the others
-    rows = []
-    for k, axis in enumerate("xyz"):
-        rows.append(("moe_%s_%s_union" % (axis, sit), p_sim[:, k]))
-        if own:
-            rows.append(("moe_%s_%s_pinv" % (axis, sit), p_sim[:, k]))
-    if sit == "multidim":
-        rows.append(("moe_y_multidim_inset_union", p_sim[:, 1]))
-        if own:
-            rows.append(("moe_y_multidim_inset_pinv", p_sim[:, 1]))
-    for fig in ("moe_e_%s" % sit, "moe_e_%s_small" % sit, "moe_e_%s_small_inset" % sit):
-        rows.append((fig + "_union", e_sim))
-        if own:
-            rows.append((fig + "_pinv", e_sim))
-    if own:
-        rows += [("moe_modes_multidim", mode_sim), ("moe_modes_full_multidim", mode_sim)] if sit == "multidim" else [
-            ("moe_modes_separate", mode_sim)]
-    return [(key,) + interval_deviation(key, t_sim, values, within=within) for key, values in rows]

@@ -142,3 +142,78 @@ def test_on_device_rollouts_reproduce_the_cart_figures(case):
     if not case.endswith("point"):
         worst, n = cf.deviation_in_pixels(case, "p", ts + dt, ps)
         assert n > 60 and worst < PIXELS, (case, "p", worst)
+
+
+# ---- ur5_moe2016_example2.ipynb cells 2-27: pinv with an ACTIVE multidimensional set / 8-mode wall sets, QP -------------
+def moe_hip_controller(case):
+    fk = cf.moe_fk()
+    kind, sit = case.split("_")
+    spec = cf.moe_skill(fk, sit)
+    if kind == "pinv":
+        ctrl = cc.PseudoInverseController(skill_spec=spec, options=cf.moe_options(case))            # cell 11
+    else:
+        ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    return fk, kind, ctrl
+
+
+@pytest.mark.parametrize("case", cf.MOE_CASES)
+def test_hip_controllers_reproduce_the_moe_2016_figures(case):
+    """cell 12's loop with the notebook's own calls - `setup_initial_problem_solver()`, `solve_initial_problem(0,
+    UR5_home)[-1]`, 10000 x `solve(t_sim[i], q_sim[i, :], warmstart_slack_var=slack_res)`, `current_mode` - on the
+    device path; every pin of tests/test_figure_pins.py within a pixel, and the closed loop equal to the oracle's"""
+    from test_figure_pins import assert_moe_pins, moe_oracle_run
+    fk, kind, ctrl = moe_hip_controller(case)
+    ctrl.setup_initial_problem_solver()
+    state = {"slack": ctrl.solve_initial_problem(0, cf.MOE_HOME)[-1]}
+
+    def solve(t, q):
+        res = ctrl.solve(t, q, warmstart_slack_var=state["slack"])
+        if res[-1] is not None:
+            state["slack"] = res[-1].toarray()[:, 0]
+        return res[0].toarray()[:, 0], (ctrl.current_mode if kind == "pinv" else None)
+    t_sim, q_sim, p_sim, e_sim, mode_sim = cf.simulate_moe(solve, lambda q: fk["chain"].fk_numeric(q)[:3, 3])
+    worst = assert_moe_pins(case, t_sim, p_sim, e_sim, mode_sim)
+    print("%s through the HIP solve(): worst pin %.2f px" % (case, worst))
+    if case == "pinv_singular":
+        assert cf.fill_deviation("moe_modes_separate", t_sim, mode_sim) == (0, 19)
+    ref = moe_oracle_run(case)
+    if kind == "pinv":
+        # 10000 ticks with ~15 (multidim) / ~540 (8 modes, chattering) mode switches: the same modes tick by tick
+        # outside the chattering stretches, the same joint trajectory
+        same = (mode_sim == ref[4]).mean()
+        assert np.abs(q_sim - ref[1]).max() < 1e-5 and same > 0.995, (np.abs(q_sim - ref[1]).max(), same)
+    else:
+        assert np.abs(p_sim - ref[2]).max() < 1.5e-3, np.abs(p_sim - ref[2]).max()      # (walls with K dt = 4: see the CPU test)
+
+
+@pytest.mark.parametrize("case", cf.MOE_CASES)
+def test_on_device_rollouts_reproduce_the_moe_2016_figures(case):
+    """the same four runs through the ON-DEVICE loop (`rollout_batch`: solve -> clamp at pi / 5 -> Euler step inside
+    the kernel), 10000 ticks in launches of five; the state, the tracking error and the mode at the end of every launch
+    against the same pins (a launch = 0.04 s = 0.12-0.8 pixel columns)"""
+    fk, kind, ctrl = moe_hip_controller(case)
+    chunk = 5
+    q = cf.MOE_HOME[None, :].copy()
+    ts, ps, es, ms = [0.0], [fk["chain"].fk_numeric(q[0])[:3, 3]], [None], [0.0]
+    es[0] = float(np.linalg.norm(ps[0] - np.array(cf.moe_path(0.0))))
+    for k in range(0, cf.MOE_TICKS, chunk):
+        times = np.array([cf.MOE_DT * i for i in range(k, k + chunk)])
+        res = ctrl.rollout_batch(times, q, dt=cf.MOE_DT, max_speed=figure_max_speed())
+        q = res[0]
+        if kind == "qp":
+            assert res[-1][0] == 0
+        p = fk["chain"].fk_numeric(q[0])[:3, 3]
+        ts.append(cf.MOE_DT * (k + chunk))                    # q after tick k + chunk - 1 = q_sim[k + chunk]
+        ps.append(p)
+        es.append(float(np.linalg.norm(p - np.array(cf.moe_path(times[-1])))))     # (e_sim[i + 1] against the path at t_sim[i])
+        ms.append(float(res[2][0]) if kind == "pinv" else 0.0)
+    from test_figure_pins import assert_moe_pins
+    worst = assert_moe_pins(case, np.array(ts), np.array(ps), np.array(es), np.array(ms))
+    print("%s through the on-device rollout: worst pin %.2f px" % (case, worst))
+
+
+def figure_max_speed():
+    import figure_skills
+    return figure_skills.MOE_MAX_SPEED
