@@ -39,8 +39,9 @@ def fk_entries(chain, qargs):
     """4x4 list of Scalar nodes: the chain's homogeneous transform written out in sin / cos of ``qargs`` (the
     Scalars one 'fk' atom carries), the joints of urdf.Chain in order (T = prod Trans(p) R Rot(axis, q))."""
     key = (id(chain), tuple(id(a) for a in qargs))
-    if key in _FK_CACHE:
-        return _FK_CACHE[key]
+    hit = _FK_CACHE.get(key)
+    if hit is not None and hit[0] is chain:          # (the entry keeps its chain alive: an id cannot be reused under it)
+        return hit[1]
     T = _mat(np.eye(4))
     for j in chain.joints:
         A = np.eye(4)
@@ -71,7 +72,9 @@ def fk_entries(chain, qargs):
             T = _matmul(T, M)
         elif j.type != JOINT_FIXED:
             raise NotImplementedError("joint type %r" % (j.type,))
-    _FK_CACHE[key] = T
+    if len(_FK_CACHE) > 64:                         # (a few chains per skill: bounded, oldest entries go)
+        _FK_CACHE.pop(next(iter(_FK_CACHE)))
+    _FK_CACHE[key] = (chain, T)
     return T
 
 
