@@ -106,7 +106,23 @@ def parse():
                     help="1: append the other BASELINE configurations (see the module text) as `extras`; "
                          "-1 = only for the default headline invocation on one GPU; 0 = never")
     ap.add_argument("--extras-timed-ms", type=float, default=400.0)
+    ap.add_argument("--full", type=int, default=0,
+                    help="1: print the long form of the line (every timing detail and source text) instead of the "
+                         "compact one; the compact line names where each number comes from by file")
+    ap.add_argument("--strong-batch", type=int, default=131072,
+                    help="N > 1: also time ONE batch of this many instances cut over the ranks (BASELINE config 5; 0 = skip)")
+    ap.add_argument("--big-batch", type=int, default=131072,
+                    help="N > 1: also time this many instances PER GPU (the regime where a GPU is busy; 0 = skip)")
     return ap.parse_args()
+
+
+_T0 = time.time()
+
+
+def phase(text):
+    """wall-clock stamps of the run's phases on stderr (to align a driver's GPU-utilisation samples with them)"""
+    sys.stderr.write("[bench %8.2f s] %s\n" % (time.time() - _T0, text))
+    sys.stderr.flush()
 
 
 def self_launch(args):
@@ -305,6 +321,46 @@ class Ctx(object):
         return [int(v) if as_int else float(v) for v in t.tolist()]
 
 
+def time_allgather(ctx, tick, dQ, n_total, M=200):
+    """the optional all-gather of dq: its own bracket, then tick + all-gather back to back on the same
+    stream (eager launches: a collective is not captured); reported apart, never folded into `value`"""
+    import torch
+    from casclik_amd.distributed import all_gather_rows as _agr
+    dist = ctx.dist
+    if dist is None:
+        return {"error": "no process group"}
+
+    def all_gather_rows(t, n):          # (gloo: host copies; RCCL: the device rows)
+        return _agr(t.cpu() if ctx.shared_gpu else t, n)
+    full = all_gather_rows(dQ, n_total)
+    for _ in range(20):
+        all_gather_rows(dQ, n_total)
+    dist.barrier()
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for _ in range(M):
+        all_gather_rows(dQ, n_total)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ag_us = (time.perf_counter() - ta) * 1e6 / M
+    for _ in range(20):
+        tick()
+        all_gather_rows(dQ, n_total)
+    dist.barrier()
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for _ in range(M):
+        tick()
+        all_gather_rows(dQ, n_total)
+    torch.cuda.synchronize()
+    dist.barrier()
+    both_us = (time.perf_counter() - ta) * 1e6 / M
+    tt = ctx.reduce_max([ag_us, both_us])
+    return {"allgather_us": round(float(tt[0]), 2), "tick_plus_allgather_us_eager": round(float(tt[1]), 2),
+            "bytes_per_rank": int(dQ.numel() * 8), "bytes_gathered": int(full.numel() * 8),
+            "backend": "gloo (host copies)" if ctx.shared_gpu else "nccl (RCCL all_gather_into_tensor over xGMI)", "calls": M}
+
+
 def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_graph=1, ramp_ms=250.0,
             min_timed_ms=2000.0, replays=0, allgather=0, global_batch=0):
     """One timed configuration.  Returns (entry dict, (spec, opts, Q, Y)) on every rank; the entry is
@@ -407,41 +463,12 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         # back to back on the same stream (eager launches: a collective is not captured)
         ag = None
         if allgather and world > 1:
-            from casclik_amd.distributed import all_gather_rows as _agr
-            n_total = global_batch if global_batch else world * B
-
-            def all_gather_rows(t, n):          # (gloo smoke test: host copies; RCCL: the device rows)
-                return _agr(t.cpu() if ctx.shared_gpu else t, n)
-            full = all_gather_rows(dQ, n_total)
-            M = 200
-            for _ in range(20):
-                all_gather_rows(dQ, n_total)
-            dist.barrier()
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            for _ in range(M):
-                all_gather_rows(dQ, n_total)
-            torch.cuda.synchronize()
-            dist.barrier()
-            ag_us = (time.perf_counter() - ta) * 1e6 / M
-            for _ in range(20):
-                tick()
-                all_gather_rows(dQ, n_total)
-            dist.barrier()
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            for _ in range(M):
-                tick()
-                all_gather_rows(dQ, n_total)
-            torch.cuda.synchronize()
-            dist.barrier()
-            both_us = (time.perf_counter() - ta) * 1e6 / M
-            tt = ctx.reduce_max([ag_us, both_us])
-            ag = {"allgather_us": float(tt[0]), "tick_plus_allgather_us_eager": float(tt[1]),
-                  "bytes_per_rank": int(dQ.numel() * 8), "bytes_gathered": int(full.numel() * 8),
-                  "algorithm": "one torch.distributed.all_gather_into_tensor (RCCL all-gather over xGMI) per tick "
-                               "for equal shards; padded all_gather for uneven ones",
-                  "calls": M, "note": "its own bracket; never part of `value` / ms_per_step"}
+            # (a collective that fails must not cost the compute line: the error is carried in its place, and the
+            # ranks re-align on the host-side barrier of reduce_max below only if the group still works)
+            try:
+                ag = time_allgather(ctx, tick, dQ, global_batch if global_batch else world * B)
+            except Exception as exc:
+                ag = {"error": repr(exc)[:300], "backend": "gloo (host copies)" if ctx.shared_gpu else "nccl (RCCL)"}
 
     per_replay_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(n_ev))
     med_ms = per_replay_ms[n_ev // 2]
@@ -590,6 +617,84 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrat
     }
 
 
+def compact_roofline(r):
+    if not r:
+        return r
+    f64 = r.get("fp64") or {}
+    out = {"bound": r["bound"], "achieved": _r(r.get("achieved"), 1), "peak": r["peak"], "unit": r["unit"],
+           "frac": _r(r.get("frac"), 4), "traffic": r.get("traffic"), "traffic_source": r.get("traffic_source"),
+           "tick_us": _r(r.get("tick_us"), 3), "kernel_body_us": _r(r.get("kernel_body_us"), 3),
+           "fp64_frac": _r(f64.get("frac"), 3), "valu_issue_frac": _r(f64.get("valu_issue_frac"), 3),
+           "binds": r.get("binds"), "bytes_per_instance": r.get("algorithmic_bytes_per_instance")}
+    return {k: v for k, v in out.items() if v is not None or k in ("traffic", "frac", "achieved")}
+
+
+def _r(v, n):
+    return None if v is None else round(float(v), n)
+
+
+def compact_cpu(c):
+    if not c or "error" in c:
+        return c
+    return {"value": _r(c["value"], 0), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+            "single_core": _r(c["single_core"]["value"], 0),
+            "sample": "%d ticks x %s instances, C restatement (oracle/clik_oracle_c.c), OpenMP, sustained median"
+                      % (c["repeats"], c["sample"].split(" of a ")[1].split("-instance")[0])}
+
+
+def compact_entry(e):
+    """an `extras` entry in a few numbers: us per tick, G instance-steps/s, kernel, roofline fractions, CPU port rate"""
+    if "error" in e:
+        return {"error": e["error"][:120]}
+    r = e.get("roofline") or {}
+    f64 = r.get("fp64") or {}
+    out = {"us": _r(e["ms_per_step"] * 1e3, 3), "G_per_s": _r(e["value"] / 1e9, 3), "kernel": e["config"].get("kernel"),
+           "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic"),
+           "steps": e["config"].get("timed_steps")}
+    if r.get("traffic_source"):
+        out["pmc"] = r["traffic_source"].replace("profiles/", "")
+    c = e.get("cpu_baseline")
+    if c and "value" in c:
+        out["cpu_M_per_s"] = _r(c["value"] / 1e6, 2)
+        out["cpu_cores"] = c["cores"]
+    if "allgather" in e:
+        out["allgather"] = e["allgather"]
+    return out
+
+
+NOTES = ("us = wall per tick under the driver-style bracket; roofline: 172 B/instance-step (QP 220) over the HIP-event "
+         "tick time vs 8 TB/s, fp64_frac = executed fp64 VALU flops (PMC, profiles/) vs 78.6 TF; extras = the other BASELINE "
+         "configs, rollouts (state in registers: no HBM fraction) and resident ticks; --full 1 prints every detail")
+
+
+def init_ranks(world, rank, dev, shared_gpu):
+    """process group for the barrier / max-over-ranks of the timing protocol: RCCL ("nccl" backend), and if that cannot
+    be brought up, gloo on the host - the compute lines must come out either way; what failed is carried in the line"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    errors = {}
+    if not shared_gpu:
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            import torch
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                          # the first collective is where RCCL really starts
+            torch.cuda.synchronize()
+            return dist, "nccl", errors
+        except Exception as exc:
+            errors["nccl_init"] = repr(exc)[:300]
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        return dist, "gloo", errors
+    except Exception as exc:
+        errors["gloo_init"] = repr(exc)[:300]
+        return None, None, errors
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -612,31 +717,31 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, backend, dist_errors = None, None, {}
     ranks_seen, devices = 1, ["cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank))]
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        ranks_seen = dist.get_world_size()
-        gathered = [None] * world
-        dist.all_gather_object(gathered, "rank %d pid %d %s" % (rank, os.getpid(), devices[0]))
-        devices = gathered
-    ctx = Ctx(rank, world, dev, dist, shared_gpu)
+        phase("rank %d: process group" % rank)
+        dist, backend, dist_errors = init_ranks(world, rank, dev, shared_gpu)
+        if dist is not None:
+            ranks_seen = dist.get_world_size()
+            gathered = [None] * world
+            dist.all_gather_object(gathered, "rank %d pid %d %s" % (rank, os.getpid(), devices[0]))
+            devices = gathered
+    ctx = Ctx(rank, world, dev, dist, shared_gpu or backend == "gloo")
+    ctx.gpu_collectives = backend == "nccl"
 
     from casclik_amd import skills
     fk = skills.iiwa()
+    phase("headline: %s, %d instances per GPU, %d GPU(s)" % (args.workload, args.batch, world))
     head, (spec, opts, Q, Y) = measure(
         ctx, fk, args.workload, args.batch, args.dist, args.seed, args.steps, args.warmup,
         TPL=args.ticks_per_launch, qp_hot=args.qp_hot, use_graph=args.graph, ramp_ms=args.ramp_ms,
-        min_timed_ms=args.min_timed_ms, replays=args.replays, allgather=args.allgather,
+        min_timed_ms=args.min_timed_ms, replays=args.replays, allgather=args.allgather or (1 if world > 1 else 0),
         global_batch=args.global_batch)
 
     head_cpu = None
     if rank == 0 and args.cpu_baseline and world == 1:
+        phase("cpu_baseline (C restatement on the host cores)")
         try:
             head_cpu = cpu_baseline(args.workload, spec, opts, Q, Y, args.cpu_seconds)
         except Exception as exc:            # the baseline must never sink the bench line
@@ -646,25 +751,46 @@ def main():
                         and not args.global_batch and not args.qp_hot and not args.lanes and args.graph == 1)
     want_extras = args.extras == 1 or (args.extras == -1 and default_headline and world == 1)
     extras = []
+    if default_headline and world > 1 and args.extras != 0:
+        # N > 1: next to the weak line (16384 instances per GPU: a tick is one wave per SIMD long whatever N is), the
+        # STRONG line BASELINE config 5 names (ONE batch of 131072 cut over the ranks) and the regime in which a GPU is
+        # worth a GPU (131072 instances PER GPU); the all-gather of dq is timed apart in each
+        for name, kw in (("strong_B%d" % args.strong_batch, dict(global_batch=args.strong_batch) if args.strong_batch else None),
+                         ("weak_B%d_per_gpu" % args.big_batch, dict(B=args.big_batch) if args.big_batch else None)):
+            if kw is None:
+                continue
+            phase(name)
+            try:
+                ent, _ = measure(ctx, fk, "stack", kw.get("B", args.batch), args.dist, args.seed, args.steps, args.warmup,
+                                 ramp_ms=100.0, min_timed_ms=max(args.extras_timed_ms, 800.0), allgather=1,
+                                 global_batch=kw.get("global_batch", 0))
+                extras.append(dict({"name": name, "n_gpus": world, "dtype": "f64",
+                                    "scaling": "strong" if "global_batch" in kw else "weak"}, **ent))
+            except Exception as exc:
+                extras.append({"name": name, "error": repr(exc)})
     if want_extras:
         # the other BASELINE configurations under the same clock; short brackets
         # (config 4 twice: cold, and hot-started from the tick's own working set - the reference's qpOASES instance
         # hot-starts every solve after the first, reactive_qp.py:491-513: the steady state of a control loop)
         # ... and the on-device rollouts of both controllers (solve -> clamp -> integrate, K ticks per launch: the
         # notebooks' simulation loops; `roofline.frac` is null for them)
-        for (wl, b, hot, tpl) in (("pose", 4096, 0, 1), ("pose", 16384, 0, 1), ("qp", 16384, 0, 1), ("qp", 16384, 1, 1),
-                                  ("stack", 131072, 0, 1), ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
+        for (wl, b, hot, tpl) in (("pose", 4096, 0, 1), ("qp", 16384, 0, 1), ("pose", 16384, 0, 1), ("qp", 16384, 1, 1),
+                                  ("stack", 131072, 0, 1), ("qp", 131072, 0, 1), ("stack", 1048576, 0, 1),
+                                  ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
             up = lambda v: -(-max(v, tpl) // tpl) * tpl              # noqa: E731  (a whole number of launches)
             name = "%s_B%d%s%s" % (wl, b, "_hot" if hot else "", "_rollout%d" % tpl if tpl > 1 else "")
+            phase(name)
             try:
-                ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed, up(max(args.steps, 8 * tpl)),
-                                                up(args.warmup), TPL=tpl, qp_hot=hot,
-                                                ramp_ms=100.0, min_timed_ms=args.extras_timed_ms)
+                ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed,
+                                                up(max(min(args.steps, 200) if b > 200000 else args.steps, 8 * tpl)),
+                                                up(min(args.warmup, 20) if b > 200000 else args.warmup), TPL=tpl, qp_hot=hot,
+                                                ramp_ms=100.0, min_timed_ms=args.extras_timed_ms,
+                                                replays=8 if b > 200000 else 0)
             except Exception as exc:        # (an extra must never cost the headline its line)
                 extras.append({"name": name, "error": repr(exc)})
                 continue
             ent = dict({"name": name, "n_gpus": world, "dtype": "f64"}, **ent)
-            if rank == 0 and args.cpu_baseline and world == 1 and not hot and tpl == 1:
+            if rank == 0 and args.cpu_baseline and world == 1 and not hot and tpl == 1 and b <= 131072:
                 try:
                     ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(2.0, args.cpu_seconds / 3))
                 except Exception as exc:
@@ -673,6 +799,7 @@ def main():
 
         # config 3 as RESIDENT ticks (one launch, device-side tickets, all published ahead: include/clik.h)
         for name, integ in (("stack_B16384_resident_fed_ahead", False), ("stack_B16384_resident_state_in_kernel", True)):
+            phase(name)
             try:
                 extras.append(dict({"name": name, "n_gpus": world, "dtype": "f64"},
                                    **measure_resident(fk, args.dist, args.seed, integrate=integ)))
@@ -680,24 +807,47 @@ def main():
                 extras.append({"name": name, "error": repr(exc)})
 
     if rank == 0:
+        phase("done")
         out = {
             "metric": METRIC,
-            "value": head["value"], "unit": "instance-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": head["value"], "unit": "instance-steps/s", "n_gpus": world, "steps": head["config"]["timed_steps"],
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": head["config"], "roofline": head["roofline"],
             "nranks_seen": ranks_seen, "devices": devices,
         }
+        out["config"]["steps_per_graph_arg"] = args.steps
+        if world > 1:
+            out["process_group"] = backend
+            if dist_errors:
+                out["process_group_errors"] = dist_errors
         if "allgather" in head:
             out["allgather"] = head["allgather"]
         out["cpu_baseline"] = head_cpu
         if extras:
             out["extras"] = extras
+        if not args.full:
+            c = out["config"]
+            out = dict({"notes": NOTES}, **out)
+            out["config"] = {"workload": c["workload"], "batch_per_gpu": c["batch_per_gpu"], "inputs": c["inputs"],
+                             "kernel": c["kernel"], "launch": c["launch"], "replays": c["replays"],
+                             "steps_per_graph_arg": args.steps, "timed_ms": _r(c["timed_ms"], 1),
+                             "parallelism": c["parallelism"]}
+            if "global_batch" in c:
+                out["config"]["global_batch"] = c["global_batch"]
+            out["roofline"] = compact_roofline(out["roofline"])
+            out["cpu_baseline"] = compact_cpu(head_cpu)
+            out["devices"] = [d.split(" pid ")[0] + " " + d.split(" ", 4)[-1] if " pid " in d else d for d in devices][:8]
+            if extras:
+                out["extras"] = {e["name"]: compact_entry(e) for e in extras}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
