@@ -175,9 +175,9 @@ def qp_opts_to_c(mu, state_weights, slack_weights, max_iter=0):
 
 _SYMBOLS = [
     "clik_last_error", "clik_abi_version",
-    "clik_pinv_create", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_pinv_attach_resident_kernel", "clik_pinv_resident_waves", "clik_pinv_resident_run", "clik_pinv_resident_run_state", "clik_ticket_feed", "clik_shape_describe", "clik_pinv_attach_kernel",
+    "clik_pinv_create", "clik_pinv_create_host", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_pinv_attach_resident_kernel", "clik_pinv_resident_waves", "clik_pinv_resident_run", "clik_pinv_resident_run_state", "clik_ticket_feed", "clik_shape_describe", "clik_pinv_attach_kernel",
     "clik_pinv_solve_batch", "clik_pinv_solve_batch_t", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
-    "clik_qp_create", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
+    "clik_qp_create", "clik_qp_create_host", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
     "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel", "clik_qp_image_words", "clik_qp_attach_value_kernel", "clik_qp_is_box_family",
     "clik_qp_solve_batch", "clik_qp_solve_batch_hot", "clik_qp_solve_batch_t", "clik_qp_rollout_batch", "clik_qp_rollout_batch_x", "clik_qp_rollout_batch_m", "clik_qp_data_batch",
 ]
@@ -236,6 +236,8 @@ def load_library(path=None):
     lib.clik_pinv_create.argtypes = [C.POINTER(clik_skill_desc),
                                      C.POINTER(clik_pinv_opts),
                                      C.POINTER(C.c_void_p)]
+    lib.clik_pinv_create_host.restype = C.c_int
+    lib.clik_pinv_create_host.argtypes = lib.clik_pinv_create.argtypes
     lib.clik_pinv_destroy.restype = C.c_int
     lib.clik_pinv_destroy.argtypes = [vp]
     lib.clik_pinv_n_modes.restype = C.c_int
@@ -285,6 +287,8 @@ def load_library(path=None):
     lib.clik_qp_create.argtypes = [C.POINTER(clik_skill_desc),
                                    C.POINTER(clik_qp_opts),
                                    C.POINTER(C.c_void_p)]
+    lib.clik_qp_create_host.restype = C.c_int
+    lib.clik_qp_create_host.argtypes = lib.clik_qp_create.argtypes
     lib.clik_qp_destroy.restype = C.c_int
     lib.clik_qp_destroy.argtypes = [vp]
     lib.clik_qp_kernel_name.restype = C.c_char_p

@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import sym as cs
-from .sym import Scalar, _c, _s_add, _s_sub, _s_mul, _s_div, _s_neg, _s_unary, _s_pow
+from .sym import Scalar, _c, _s_add, _s_sub, _s_mul, _s_div, _s_neg, _s_unary, _s_pow, _ZERO
 
 _ZERO = _c(0.0)
 
@@ -73,6 +73,26 @@ def diff_scalar(node, key, memo):
     elif op == "fabs":
         r = _s_mul(_s_unary("sign", node.args[0]),
                    diff_scalar(node.args[0], key, memo))
+    elif op in ("asin", "acos"):
+        a = node.args[0]
+        r = _s_div(diff_scalar(a, key, memo), _s_unary("sqrt", _s_sub(_c(1.0), _s_mul(a, a))))
+        if op == "acos":
+            r = _s_neg(r)
+    elif op == "atan":
+        a = node.args[0]
+        r = _s_div(diff_scalar(a, key, memo), _s_add(_c(1.0), _s_mul(a, a)))
+    elif op == "tanh":
+        r = _s_mul(_s_sub(_c(1.0), _s_mul(node, node)), diff_scalar(node.args[0], key, memo))
+    elif op == "atan2":
+        y, x = node.args
+        dy, dx = diff_scalar(y, key, memo), diff_scalar(x, key, memo)
+        r = _s_div(_s_sub(_s_mul(x, dy), _s_mul(y, dx)), _s_add(_s_mul(x, x), _s_mul(y, y)))
+    elif op in ("fmin", "fmax"):
+        # CasADi's rule: the first argument's derivative where it is the one taken (ties included)
+        a, b = node.args
+        first = Scalar("cmp_le", (a, b) if op == "fmin" else (b, a))
+        da, db = diff_scalar(a, key, memo), diff_scalar(b, key, memo)
+        r = _ZERO if (da.is_const() and db.is_const() and da.value == 0.0 and db.value == 0.0) else Scalar("if_else", (first, da, db))
     elif op == "sign" or op.startswith("cmp_"):
         r = _ZERO
     elif op == "norm2":

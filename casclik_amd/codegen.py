@@ -25,7 +25,8 @@ import math
 from . import autodiff
 
 _UNARY_C = {"tan": "tan", "sqrt": "sqrt", "exp": "exp", "log": "log",
-            "fabs": "fabs"}
+            "fabs": "fabs", "asin": "asin", "acos": "acos", "atan": "atan", "tanh": "tanh"}
+_BINARY_C = {"atan2": "atan2", "fmin": "fmin", "fmax": "fmax"}
 _INFIX = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
 
 
@@ -130,6 +131,8 @@ class TaskEmitter(object):
             expr = "-%s" % args[0]
         elif op in _UNARY_C:
             expr = "%s(%s)" % (_UNARY_C[op], args[0])
+        elif op in _BINARY_C:
+            expr = "%s(%s, %s)" % (_BINARY_C[op], args[0], args[1])
         elif op == "sign":
             expr = "(double)((%s > 0.0) - (%s < 0.0))" % (args[0], args[0])
         elif op == "pow":

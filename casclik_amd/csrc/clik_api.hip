@@ -675,15 +675,18 @@ extern "C" int clik_shape_describe(const clik_skill_desc* desc, const clik_pinv_
 // CLIK_HOST_ONLY=1: handles are created WITHOUT touching a device (no allocation, no upload) - for the host-side
 // queries only (clik_*_image_words, kernel names): casclik_amd/jit.py uses it to instantiate value-specialised kernels
 // ahead of time on a machine without a GPU.  Every solve / rollout / data entry point refuses such a handle.
+// (clik_*_create_host ask for it explicitly, per call and per thread; the environment variable remains for whole processes)
+static thread_local bool g_host_only_call = false;
 static bool host_only_mode()
 {
+    if (g_host_only_call) return true;
     const char* e = getenv("CLIK_HOST_ONLY");
     return e && e[0] == '1';
 }
 #define CLIK_NEEDS_DEVICE_HANDLE(h)                                                                        \
     do {                                                                                                   \
         if ((h) && (h)->dev == nullptr)                                                                    \
-            return fail(CLIK_EINVAL, "this handle was created with CLIK_HOST_ONLY=1: host-side queries only"); \
+            return fail(CLIK_EINVAL, "this handle was created host-only (clik_*_create_host / CLIK_HOST_ONLY=1): host-side queries only"); \
     } while (0)
 
 extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts, clik_pinv** out)
@@ -758,12 +761,13 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         const char* noaot = getenv("CLIK_NO_AOT");
         h->kernel = clik::pinv_pick_kernel(S, ((force && force[0] == '1') || (noaot && noaot[0] == '1')) ? 0 : 1);
     }
-    if (h->kernel < 0 && !skill_has_wide_task(S)) {
+    if (h->kernel < 0 && !skill_has_wide_task(S) && S.n <= 8) {
         delete h;
         return fail(CLIK_EUNSUPPORTED, "no kernel variant for n = %d", S.n);
     }
-    // (kernel < 0 with a wide constraint: no built-in kernel is wide enough; the handle solves once a
-    // kernel instantiated for the skill is attached)
+    // (kernel < 0 with a wide constraint or with more than eight state variables - a 7-DoF arm with two or three
+    // virtual variables, CLIK_MAX_DOF = 10: no built-in kernel is wide enough; the handle solves once a kernel
+    // instantiated for the skill is attached, and answers CLIK_EUNSUPPORTED until then)
     compute_warm(S, S.lds_slots, h->warm);
     S.zero_token = 0;
     S.lds_slots = clik::pinv_lds_slots_host(clik::pinv_kernel_width(h->kernel), S.d.n_y);
@@ -918,10 +922,8 @@ static int resident_run_common(const clik_pinv* h, int64_t B, int32_t n_ticks, c
     const DevSkill& S = h->host;
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
-    // every wave of the launch must be resident at once (a wave that never starts can never count): one block of four
-    // waves per CU at most, 256 CUs
-    if (clik_pinv_resident_waves(h, B) > 4 * 256 * 2)
-        return fail(CLIK_EUNSUPPORTED, "resident ticks: at most 32768 instances (all waves must be resident at once)");
+    // (every wave of the launch must be resident at once: the launch wrapper of the instantiated kernel checks the grid
+    // against that kernel's occupancy on this device and answers hipErrorNotSupported beyond it)
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
@@ -937,6 +939,10 @@ static int resident_run_common(const clik_pinv* h, int64_t B, int32_t n_ticks, c
     }
     hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, mode, (void*)ticket, (unsigned*)done, n_ticks, budget,
                                    (hipStream_t)stream);
+    if (e == hipErrorNotSupported)
+        return fail(CLIK_EUNSUPPORTED, "resident ticks: %lld instances need more blocks than this kernel can keep resident "
+                                       "at once on this device (every wave must be running for a tick to complete)",
+                    (long long)B);
     if (e != hipSuccess) return hipfail(e, "resident kernel launch");
     return CLIK_OK;
 }
@@ -964,6 +970,22 @@ extern "C" int clik_pinv_image_words(const clik_pinv* h, uint64_t* buf, int cap)
     if (words > cap) return fail(CLIK_EINVAL, "image needs %d words, buffer holds %d", words, cap);
     memcpy(buf, img.data(), (size_t)words * 8);
     return words;
+}
+
+extern "C" int clik_pinv_create_host(const clik_skill_desc* desc, const clik_pinv_opts* opts, clik_pinv** out)
+{
+    g_host_only_call = true;
+    const int rc = clik_pinv_create(desc, opts, out);
+    g_host_only_call = false;
+    return rc;
+}
+
+extern "C" int clik_qp_create_host(const clik_skill_desc* desc, const clik_qp_opts* opts, clik_qp** out)
+{
+    g_host_only_call = true;
+    const int rc = clik_qp_create(desc, opts, out);
+    g_host_only_call = false;
+    return rc;
 }
 
 extern "C" int clik_pinv_destroy(clik_pinv* h)

@@ -1515,6 +1515,27 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
         const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
         // (bit 63 of the poll budget: the instantiation that integrates the state itself, clik_pinv_resident_run_state)
         const unsigned long long budget = timeout_ticks & ~kResidentIntegrateBit;
+        // Every block of the launch must be resident at once - a block that never starts can never count, and the
+        // ones that did would spin until the watchdog fires.  The bound comes from THIS instantiation's occupancy on
+        // THIS device (registers of the kernel as compiled, CUs of a possibly partitioned device), less one block's
+        // room for the ticket feeder.
+        {
+            static int max_blocks[2] = {-1, -1};
+            const int which = (timeout_ticks & kResidentIntegrateBit) ? 1 : 0;
+            if (max_blocks[which] < 0) {
+                int per_cu = 0, dev = 0, cus = 0;
+                hipError_t oe = which
+                    ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pinv_resident_team_kernel<SD, IMGV, true>,
+                                                                   TEAM_WAVES * WAVE, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pinv_resident_team_kernel<SD, IMGV, false>,
+                                                                   TEAM_WAVES * WAVE, 0);
+                if (oe == hipSuccess) oe = hipGetDevice(&dev);
+                if (oe == hipSuccess) oe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                if (oe != hipSuccess) return oe;
+                max_blocks[which] = per_cu * cus - 1;
+            }
+            if ((long long)grid > (long long)max_blocks[which]) return hipErrorNotSupported;
+        }
         if (timeout_ticks & kResidentIntegrateBit)
             hipLaunchKernelGGL((pinv_resident_team_kernel<SD, IMGV, true>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0, stream,
                                q, y, dq, mode, B, tk, (ResidentTicket*)ticket, done, n_ticks, budget);

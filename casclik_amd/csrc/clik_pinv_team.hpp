@@ -640,7 +640,12 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         for (;;) {
             // (relaxed, system scope = a load that bypasses the caches; no L2 invalidate: the rows are read the same way)
             seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (seen >= want) return;
+            if (seen >= want) {
+                // the rows are requested only after this value has been consumed (loads of a wave issue in program
+                // order and bypass the caches); the fence keeps the COMPILER from hoisting a row load above it
+                __atomic_signal_fence(__ATOMIC_ACQUIRE);
+                return;
+            }
             if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
                 leave = true;
                 return;

@@ -134,11 +134,30 @@ def _s_neg(a):
     return Scalar("neg", (a,))
 
 
+def _nan_outside(f):
+    """IEEE result like CasADi's (asin(2) is nan, not an exception)"""
+    def g(v):
+        try:
+            return f(v)
+        except ValueError:
+            return float("nan")
+    return g
+
+
 _UNARY_NUMERIC = {
     "sin": math.sin, "cos": math.cos, "sqrt": math.sqrt, "exp": math.exp,
     "log": math.log, "fabs": abs, "tan": math.tan,
     "sign": lambda v: float(v > 0) - float(v < 0),
+    "asin": _nan_outside(math.asin), "acos": _nan_outside(math.acos), "atan": math.atan, "tanh": math.tanh,
 }
+# two-argument functions (casadi.atan2 / fmin / fmax: angle-type task errors, saturations)
+_BINARY_NUMERIC = {"atan2": math.atan2, "fmin": min, "fmax": max}
+
+
+def _s_binary(op, a, b):
+    if a.is_const() and b.is_const():
+        return _c(_BINARY_NUMERIC[op](a.value, b.value))
+    return Scalar(op, (a, b))
 
 
 def _s_unary(op, a):
@@ -725,6 +744,59 @@ def fabs(a):
     return _unary_dispatch("fabs", a)
 
 
+def asin(a):
+    return _unary_dispatch("asin", a)
+
+
+def acos(a):
+    return _unary_dispatch("acos", a)
+
+
+def atan(a):
+    return _unary_dispatch("atan", a)
+
+
+def tanh(a):
+    return _unary_dispatch("tanh", a)
+
+
+def _binary_dispatch(op, a, b):
+    """element-wise two-argument function with casadi's broadcasting of a scalar operand"""
+    if _is_numeric(a) and _is_numeric(b):
+        aa = _np.asarray(a._v if isinstance(a, DM) else a, dtype=float)
+        bb = _np.asarray(b._v if isinstance(b, DM) else b, dtype=float)
+        res = _np.vectorize(_BINARY_NUMERIC[op], otypes=[float])(aa, bb)
+        return DM(res) if (isinstance(a, DM) or isinstance(b, DM)) else (float(res) if res.ndim == 0 else res)
+    A, B = _as_array(a), _as_array(b)
+    if A.shape != B.shape:
+        if A.size == 1:
+            A = _np.full(B.shape, A.reshape(-1)[0], dtype=object)
+        elif B.size == 1:
+            B = _np.full(A.shape, B.reshape(-1)[0], dtype=object)
+        else:
+            raise ValueError("%s: shapes %s and %s do not match" % (op, A.shape, B.shape))
+    out = _np.empty(A.shape, dtype=object)
+    for idx in _np.ndindex(A.shape):
+        out[idx] = _s_binary(op, A[idx], B[idx])
+    return _wrap(out)
+
+
+def atan2(y, x):
+    return _binary_dispatch("atan2", y, x)
+
+
+def arctan2(y, x):
+    return _binary_dispatch("atan2", y, x)
+
+
+def fmin(a, b):
+    return _binary_dispatch("fmin", a, b)
+
+
+def fmax(a, b):
+    return _binary_dispatch("fmax", a, b)
+
+
 def sign(a):
     return _unary_dispatch("sign", a)
 
@@ -951,6 +1023,8 @@ def _eval_scalar(s, env, memo):
             r = -a[0]
         elif op == "pow":
             r = a[0] ** a[1]
+        elif op in _BINARY_NUMERIC:
+            r = _BINARY_NUMERIC[op](a[0], a[1])
         elif op == "norm2":
             r = math.sqrt(sum(v * v for v in a))
         elif op == "cmp_lt":
@@ -1076,6 +1150,8 @@ def substitute(expr, sym_list, val_list):
                 r = _s_neg(*na)
             elif s.op == "pow":
                 r = _s_pow(*na)
+            elif s.op in _BINARY_NUMERIC:
+                r = _s_binary(s.op, *na)
             elif s.op == "norm2":
                 r = _s_norm2(na)
             elif s.op in _UNARY_NUMERIC:

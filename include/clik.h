@@ -202,6 +202,12 @@ int32_t     clik_abi_version(void);
  * skill, builds the mode table (:107-130) and uploads the descriptor.        */
 int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opts* opts,
                      clik_pinv** out);
+/* the same handle WITHOUT a device (no allocation, no upload): answers the host-side queries only
+ * (clik_pinv_image_words, kernel names, clik_shape_describe) - how casclik_amd/jit.py instantiates kernels ahead of
+ * time on a machine without a GPU; every solve / rollout entry point refuses it (CLIK_EINVAL).  The environment
+ * variable CLIK_HOST_ONLY=1 makes every create of a process behave like this.                                  */
+int clik_pinv_create_host(const clik_skill_desc* desc, const clik_pinv_opts* opts,
+                          clik_pinv** out);
 int clik_pinv_destroy(clik_pinv* h);
 int clik_pinv_n_modes(const clik_pinv* h);
 /* name of the kernel variant serving this skill: an AOT shape name (guard-free
@@ -336,6 +342,8 @@ int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t n_ticks, in
 /* replaces setup_problem_functions()+setup_solver() (reactive_qp.py:248-298) */
 int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* opts,
                    clik_qp** out);
+int clik_qp_create_host(const clik_skill_desc* desc, const clik_qp_opts* opts,
+                        clik_qp** out);   /* see clik_pinv_create_host */
 int clik_qp_destroy(clik_qp* h);
 int clik_qp_n_vars(const clik_qp* h);   /* n_state + n_slack                     */
 int clik_qp_n_rows(const clik_qp* h);

@@ -242,6 +242,22 @@ class ExprEvaluator(object):
                 r = _d_unary(a[0], np.abs, np.sign)
             elif op == "sign":
                 r = Dual(np.sign(a[0].v), np.zeros((B, nd)))
+            elif op == "asin":
+                r = _d_unary(a[0], np.arcsin, lambda v: 1.0 / np.sqrt(1.0 - v * v))
+            elif op == "acos":
+                r = _d_unary(a[0], np.arccos, lambda v: -1.0 / np.sqrt(1.0 - v * v))
+            elif op == "atan":
+                r = _d_unary(a[0], np.arctan, lambda v: 1.0 / (1.0 + v * v))
+            elif op == "tanh":
+                r = _d_unary(a[0], np.tanh, lambda v: 1.0 - np.tanh(v) ** 2)
+            elif op == "atan2":
+                y, x = a
+                den = x.v * x.v + y.v * y.v
+                r = Dual(np.arctan2(y.v, x.v), (y.d * x.v[:, None] - x.d * y.v[:, None]) / den[:, None])
+            elif op in ("fmin", "fmax"):
+                # CasADi: d fmin / d(first) = (first <= second), d fmax / d(first) = (first >= second)
+                first = (a[0].v <= a[1].v) if op == "fmin" else (a[0].v >= a[1].v)
+                r = Dual(np.where(first, a[0].v, a[1].v), np.where(first[:, None], a[0].d, a[1].d))
             elif op == "pow":
                 if np.any(a[1].d != 0.0):
                     raise NotImplementedError("oracle: pow with variable exponent")

@@ -125,8 +125,13 @@ def random_expression(rng, leaves, depth):
     if depth == 0 or rng.random() < 0.15:
         leaf = leaves[int(rng.integers(len(leaves)))]
         return leaf if rng.random() < 0.8 else leaf * float(rng.uniform(-2.0, 2.0))
-    op = int(rng.integers(10))
+    op = int(rng.integers(15))
     a = random_expression(rng, leaves, depth - 1)
+    if op >= 10:
+        # angle-type and saturating functions (guarded inside their domains)
+        b = random_expression(rng, leaves, depth - 1)
+        return [cs.atan2(a, 1.5 + cs.cos(b)), cs.tanh(a), cs.fmin(a, cs.fmax(b, -0.5)),
+                cs.asin(0.9 * cs.sin(a)) + cs.acos(0.8 * cs.cos(b)), cs.atan(a * b)][op - 10]
     if op <= 3:
         b = random_expression(rng, leaves, depth - 1)
         return [a + b, a - b, a * b, a / (2.5 + cs.sin(b))][op]

@@ -169,6 +169,9 @@ PLAN = [   # (fixture name, robot, case, B, input distribution, times)
     ("iiwa_two_frames", "iiwa", "two_frames", 64, "interior", [0.0]),
     ("iiwa_qp_two_virtual", "iiwa", "qp_two_virtual", 48, "interior", [0.0]),
     ("iiwa_sets_per_joint", "iiwa", "sets_per_joint", 160, "narrow", [0.0]),
+    # round 4: atan2 / asin / acos / atan / tanh / fmin / fmax in task errors
+    ("iiwa_heading", "iiwa", "heading", 64, "mixed", [0.0, 1.3]),
+    ("ur5_qp_heading", "ur5", "qp_heading", 48, "interior", [0.7]),
 ]
 # offsets from a joint limit the "boundary" distribution plants (pseudo_inverse.py:222-252 thresholds e - bound
 # at 1e-12): exactly on the limit, either side of the 1e-12 margin, and up to 1e-6 away

@@ -330,7 +330,49 @@ def qp_two_virtual(env):
     return dict(spec=spec, controller="qp", options={}, ny=0, nx=2)
 
 
+def _heading_rows(env, s):
+    """angle-type task errors (constraints.py:21-24 takes any MX; such errors are written with atan2 / acos): the tool's
+    heading in the base frame's xy-plane against a target that drifts with time, its elevation through asin, its radius
+    held inside a band by fmin / fmax, a saturated (tanh) height error"""
+    cs = env.cs
+    T = env.T_fk(s["q"])
+    p = T[:3, 3]
+    heading = cs.atan2(p[1], p[0]) - (0.4 + 0.1 * s["t"])
+    radius = cs.sqrt(p[0] * p[0] + p[1] * p[1])
+    elevation = cs.asin(p[2] / cs.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + 0.05)) - 0.3
+    band = radius - cs.fmin(cs.fmax(radius, 0.35), 0.6)
+    tilt = cs.acos(0.9 * T[2, 2]) - 0.8
+    height = cs.tanh(3.0 * (p[2] - 0.5))
+    bend = cs.atan(2.0 * s["q"][1]) - 0.2
+    return cs.vertcat(heading, elevation, band), cs.vertcat(tilt, height, bend)
+
+
+def heading(env):
+    """PseudoInverseController on angle-type errors behind a 1-D joint set"""
+    cc, s = env.cc, _syms(env)
+    first, second = _heading_rows(env, s)
+    cns = [cc.SetConstraint(label="limit_q1", expression=s["q"][1], set_min=float(0.5 * env.lower[1]),
+                            set_max=float(0.5 * env.upper[1]), priority=0),
+           cc.EqualityConstraint(label="heading", expression=first, gain=2.0, constraint_type="soft", priority=1),
+           cc.EqualityConstraint(label="attitude", expression=second, gain=1.0, constraint_type="soft", priority=2)]
+    spec = cc.SkillSpecification(label="heading", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"], constraints=cns)
+    return dict(spec=spec, controller="pinv", options={}, ny=0)
+
+
+def qp_heading(env):
+    """the same rows under the ReactiveQPController with joint-speed limits"""
+    cc, s = env.cc, _syms(env)
+    first, second = _heading_rows(env, s)
+    cns = [cc.EqualityConstraint(label="heading", expression=first, gain=2.0, constraint_type="soft", priority=1),
+           cc.EqualityConstraint(label="attitude", expression=second, gain=1.0, constraint_type="soft", priority=2),
+           cc.VelocitySetConstraint(label="joint_speed_limits", expression=s["q"], set_min=-env.vmax, set_max=env.vmax,
+                                    priority=0)]
+    spec = cc.SkillSpecification(label="qp_heading", time_var=s["t"], robot_var=s["q"], robot_vel_var=s["dq"], constraints=cns)
+    return dict(spec=spec, controller="qp", options={}, ny=0)
+
+
 CASES = {
+    "heading": heading, "qp_heading": qp_heading,
     "two_frames": two_frames, "qp_two_virtual": qp_two_virtual, "sets_per_joint": sets_per_joint,
     "stack_boundary": stack_const, "qp_wall": qp_wall,
     "position": position, "pose": pose, "stack_const": stack_const, "stack_const_time": stack_const_time,

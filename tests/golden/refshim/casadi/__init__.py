@@ -249,6 +249,7 @@ def _is_sym_expr(*xs):
 _ELEMENTWISE = {
     "add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b,
     "pow": lambda a, b: a ** b,
+    "atan2": lambda a, b: numpy.arctan2(a, b), "fmin": lambda a, b: numpy.minimum(a, b), "fmax": lambda a, b: numpy.maximum(a, b),
     "lt": lambda a, b: (a < b).astype(float), "le": lambda a, b: (a <= b).astype(float),
     "gt": lambda a, b: (a > b).astype(float), "ge": lambda a, b: (a >= b).astype(float),
     "eq": lambda a, b: (a == b).astype(float), "ne": lambda a, b: (a != b).astype(float),
@@ -258,6 +259,7 @@ _UNARY = {
     "neg": lambda a: -a, "sin": numpy.sin, "cos": numpy.cos, "sqrt": numpy.sqrt, "fabs": numpy.abs,
     "sign": numpy.sign, "transpose": lambda a: a.T, "exp": numpy.exp, "log": numpy.log, "tan": numpy.tan,
     "arccos": numpy.arccos, "not": lambda a: (a == 0).astype(float),
+    "arcsin": numpy.arcsin, "arctan": numpy.arctan, "tanh": numpy.tanh,
 }
 
 
@@ -305,6 +307,15 @@ def exp(x): return _unary("exp", x)
 def log(x): return _unary("log", x)
 def arccos(x): return _unary("arccos", x)
 def acos(x): return _unary("arccos", x)
+def asin(x): return _unary("arcsin", x)
+def arcsin(x): return _unary("arcsin", x)
+def atan(x): return _unary("arctan", x)
+def arctan(x): return _unary("arctan", x)
+def tanh(x): return _unary("tanh", x)
+def atan2(y, x): return _binary("atan2", y, x)
+def arctan2(y, x): return _binary("atan2", y, x)
+def fmin(a, b): return _binary("fmin", a, b)
+def fmax(a, b): return _binary("fmax", a, b)
 def logic_not(x): return _unary("not", x)
 def logic_and(a, b): return _binary("and", a, b)
 def logic_or(a, b): return _binary("or", a, b)
@@ -567,6 +578,26 @@ def _dual(node, var, env, cache):
     elif op == "fabs":
         a, ta = _dual(node.args[0], var, env, cache)
         out = (numpy.abs(a), numpy.sign(a)[..., None] * ta)
+    elif op in ("arccos", "arcsin"):
+        a, ta = _dual(node.args[0], var, env, cache)
+        sgn = -1.0 if op == "arccos" else 1.0
+        out = (_UNARY[op](a), (sgn / numpy.sqrt(1.0 - a * a))[..., None] * ta)
+    elif op == "arctan":
+        a, ta = _dual(node.args[0], var, env, cache)
+        out = (numpy.arctan(a), (1.0 / (1.0 + a * a))[..., None] * ta)
+    elif op == "tanh":
+        a, ta = _dual(node.args[0], var, env, cache)
+        out = (numpy.tanh(a), (1.0 - numpy.tanh(a) ** 2)[..., None] * ta)
+    elif op in ("atan2", "fmin", "fmax"):
+        (a, ta), (b, tb) = _dual(node.args[0], var, env, cache), _dual(node.args[1], var, env, cache)
+        shape = node.shape
+        a, b = numpy.broadcast_to(a, shape), numpy.broadcast_to(b, shape)
+        ta, tb = numpy.broadcast_to(ta, shape + (k,)), numpy.broadcast_to(tb, shape + (k,))
+        if op == "atan2":           # d atan2(y, x) = (x dy - y dx) / (x^2 + y^2)
+            out = (numpy.arctan2(a, b), (b[..., None] * ta - a[..., None] * tb) / (a * a + b * b)[..., None])
+        else:                       # CasADi (casadi_math.hpp): d fmin = [x <= y, !(x <= y)], d fmax = [x >= y, !(x >= y)]
+            first = (a <= b) if op == "fmin" else (a >= b)
+            out = (numpy.where(first, a, b), numpy.where(first[..., None], ta, tb))
     elif op == "transpose":
         a, ta = _dual(node.args[0], var, env, cache)
         out = (a.T, numpy.transpose(ta, (1, 0, 2)))

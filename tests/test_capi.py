@@ -95,20 +95,29 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_host_only_handles_answer_queries_and_refuse_to_solve(lib, monkeypatch):
-    """CLIK_HOST_ONLY=1 (include/clik.h): a handle without any device allocation - what casclik_amd/jit.py uses to get a
-    skill's image words on a machine without a GPU; every solve entry point refuses it"""
-    monkeypatch.setenv("CLIK_HOST_ONLY", "1")
+    """clik_pinv_create_host / clik_qp_create_host (include/clik.h): a handle without any device allocation - what
+    casclik_amd/jit.py uses to get a skill's image words on a machine without a GPU; every solve entry point refuses it.
+    The flag is per call: an ordinary create next to it is NOT host-only (here, without a GPU, it fails in hipMalloc
+    instead of succeeding); CLIK_HOST_ONLY=1 still turns a whole process host-only."""
     desc = _capi.desc_to_c(lower_skill(skills.stack_skill()))
     opts = _capi.pinv_opts_to_c({"feedforward": True, "multidim_sets": True, "converge_final_set_to_max": False,
                                  "pinv_method": "damped", "damping_factor": 1e-7})
     h = C.c_void_p()
-    assert lib.clik_pinv_create(C.byref(desc), C.byref(opts), C.byref(h)) == 0
+    assert lib.clik_pinv_create_host(C.byref(desc), C.byref(opts), C.byref(h)) == 0
     buf = (C.c_uint64 * 16384)()
     n = lib.clik_pinv_image_words(h, buf, len(buf))
     assert n > 100 and lib.clik_pinv_n_modes(h) == 2
     assert lib.clik_pinv_solve_batch(h, 4, None, None, None, None, None, None, None, None) == -1
-    assert b"CLIK_HOST_ONLY" in lib.clik_last_error()
+    assert b"host-only" in lib.clik_last_error()
     assert lib.clik_pinv_destroy(h) == 0
+    import torch
+    if not torch.cuda.is_available():
+        h2 = C.c_void_p()
+        assert lib.clik_pinv_create(C.byref(desc), C.byref(opts), C.byref(h2)) != 0      # (no device: hipMalloc fails)
+    monkeypatch.setenv("CLIK_HOST_ONLY", "1")
+    h3 = C.c_void_p()
+    assert lib.clik_pinv_create(C.byref(desc), C.byref(opts), C.byref(h3)) == 0 and lib.clik_pinv_destroy(h3) == 0
+    monkeypatch.delenv("CLIK_HOST_ONLY")
     from casclik_amd import jit
     qd = _capi.desc_to_c(lower_skill(skills.qp_skill()))
     words = jit.host_image_words(lib, "qp", qd, _capi.qp_opts_to_c(0.001, [1.0] * 7, [1.0] * 6))

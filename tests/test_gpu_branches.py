@@ -553,3 +553,47 @@ def test_results_do_not_depend_on_the_batch_an_instance_sits_in(iiwa_fk):
         assert np.array_equal(status, full_q[3][idx]) and np.array_equal(dq, full_q[0][idx])
         assert np.array_equal(slack, full_q[2][idx])
     check()
+
+
+@pytest.mark.parametrize("nx", [2, 3])
+def test_seven_dof_arm_with_two_or_three_virtual_variables(iiwa_fk, nx):
+    """nine / ten state variables (CLIK_MAX_DOF = 10): no built-in pinv kernel is that wide, the handle is created
+    without one and solves through the kernel instantiated for the skill (pseudo_inverse.py:79-88 puts no bound on
+    virtual_var); both controllers against the oracle"""
+    from oracle import clik_oracle
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("dq", 7)
+    x, dx = cs.MX.sym("x", nx), cs.MX.sym("dx", nx)
+    T = iiwa_fk["T_fk"](q)
+    dirs = np.array([[0.1, -0.05, 0.08], [-0.04, 0.09, 0.03], [0.02, 0.03, -0.07]])[:nx]
+    patch = np.array([0.45, 0.1, 0.6]) + cs.mtimes(dirs.T, x)
+    goal = np.array([1.0, 0.5, -0.3])[:nx]
+
+    def spec_for(controller):
+        cons = [cc.EqualityConstraint(label="follow_patch", expression=T[:3, 3] - patch, gain=5.0, constraint_type="soft",
+                                      priority=1),
+                cc.EqualityConstraint(label="patch_goal", expression=x - goal, gain=0.5, constraint_type="soft",
+                                      priority=2)]
+        if controller == "qp":
+            vmax = np.array(iiwa_fk["velocity"])
+            cons.append(cc.VelocitySetConstraint(label="speed", expression=q, set_min=-vmax, set_max=vmax, priority=0))
+        else:
+            cons.append(cc.SetConstraint(label="limit_q1", expression=q[1], set_min=-1.0, set_max=1.0, priority=0))
+        return cc.SkillSpecification(label="patch", time_var=t, robot_var=q, robot_vel_var=dq, virtual_var=x,
+                                     virtual_vel_var=dx, constraints=cons)
+    Q, _ = skills.synthetic_inputs(iiwa_fk, 160, seed=21 + nx, distribution="mixed")
+    X = np.random.default_rng(5).uniform(-0.2, 1.2, size=(160, nx))
+    spec = spec_for("pinv")
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    dqv, dxv, mode = ctrl.solve_batch(0.0, Q, virtual_var=X)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
+    assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
+    assert dxv.shape == (160, nx) and _rel(np.hstack([dqv, dxv]), ref).max() < PINV_RTOL
+    spec = spec_for("qp")
+    qctrl = cc.ReactiveQPController(skill_spec=spec)
+    qctrl.setup_problem_functions()
+    qctrl.setup_solver()
+    dqv, dxv, slack, status = qctrl.solve_batch(0.0, Q, virtual_var=X)
+    rdq, rdx, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, X=X)
+    assert np.array_equal(status, rstatus) and (rstatus == 0).all()
+    assert _rel(dqv, rdq).max() < 1e-8 and _rel(dxv, rdx).max() < 1e-8 and _rel(slack, rslack).max() < 1e-8

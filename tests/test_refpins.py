@@ -27,7 +27,7 @@ def test_numpy_oracle_matches_the_reference_run(name):
         assert (err < tol).all(), (name, err.max())
     # the reference sorted the constraints by priority itself; the product's front-end must agree
     assert [c.label for c in built["spec"].constraints][0] in ("joint_limits", "limit_q0", "limit_q1", "tool_position",
-                                                                  "tool_pose", "tool_z_speed")
+                                                                  "tool_pose", "tool_z_speed", "heading")
 
 
 @pytest.mark.parametrize("name", [n for n in refpins.PINV_NAMES if "stack_const" in n or n.endswith("_pose")
