@@ -1982,11 +1982,11 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_values_kernel(
 // ... for the box family without any LDS: its solver keeps everything in registers, the few work-area slots the row
 // gathering fills become a private array, every lane loads its own rows and stores its own results
 template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
+__device__ __forceinline__ void qp_box_values_body(
     const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
     const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
-    const TickArgs tk)
+    const TickArgs& tk)
 {
     using LY = QpLayout<SD>;
     static_assert(LY::BOX, "box family only");
@@ -2028,6 +2028,33 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
         if (status_out != nullptr) status_out[inst] = status;
     }
     CLIK_BODY_END();
+}
+
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    qp_box_values_body<SD, IMGV>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
+}
+
+// The same body held to TWO waves per SIMD (at most 256 registers, accumulation registers included) for the batches
+// with more waves than SIMDs: the default build takes 256 VGPRs + 70 AGPRs = ONE wave per SIMD, so 131072 instances
+// (2048 waves on 1024 SIMDs) ran as two rounds of lone waves, each waiting out its own dependent chains (35 % VALU issue
+// utilisation, profiles/r3_counters.json); two resident waves fill each other's stalls.
+#ifndef CLIK_QP_OCC2_MIN_BATCH
+#define CLIK_QP_OCC2_MIN_BATCH 65537
+#endif
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void qp_solve_static_box_values_occ2_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    qp_box_values_body<SD, IMGV>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
 }
 
 // ... with four lanes per instance (experiment, CLIK_QP_LANES=4, batches up to 16384 instances: 1024 waves instead of
@@ -2227,6 +2254,15 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
         if (quad && B <= 16384) {
             hipLaunchKernelGGL((qp_solve_static_box_quad_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0, stream, q,
                                y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
+            return hipGetLastError();
+        }
+        static const long long occ2_from = []() {
+            const char* e = getenv("CLIK_QP_OCC2_MIN_BATCH");
+            return e ? atoll(e) : (long long)CLIK_QP_OCC2_MIN_BATCH;
+        }();
+        if (B >= occ2_from) {
+            hipLaunchKernelGGL((qp_solve_static_box_values_occ2_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y,
+                               dq, slack, status, B, x, dx, hot_set, use_hot, tk);
             return hipGetLastError();
         }
         hipLaunchKernelGGL((qp_solve_static_box_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,

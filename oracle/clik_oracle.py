@@ -388,21 +388,35 @@ def activation_map(n_sets):
     return sorted(binmaps, key=lambda s: sum(s))
 
 
-def dpinv(J, opt):
-    """pseudo_inverse.py:92-105."""
+def dpinv(J, opt, cond=None):
+    """pseudo_inverse.py:92-105.  `cond` (a one-element list, optional) collects the largest 2-norm condition number of
+    the symmetric matrices handed to the linear solver: what the result is sensitive to (tests/tolerances.py)."""
     rows, cols = J.shape
     if opt["pinv_method"] == "standard":
         # cs.pinv (CasADi GenericMatrix::pinv): size2 >= size1 -> solve(J J^T, J)^T, else solve(J^T J, J^T);
         # a square J takes the first form
+        inner = J.dot(J.T) if cols >= rows else J.T.dot(J)
+        if cond is not None:
+            cond[0] = max(cond[0], _sym_cond(inner))
         if cols >= rows:
-            return np.linalg.solve(J.dot(J.T), J).T
-        return np.linalg.solve(J.T.dot(J), J.T)
+            return np.linalg.solve(inner, J).T
+        return np.linalg.solve(inner, J.T)
     lam = opt["damping_factor"]
     if cols >= rows:
         inner = J.dot(J.T) + lam * np.eye(rows)
+        if cond is not None:
+            cond[0] = max(cond[0], _sym_cond(inner))
         return np.linalg.solve(inner, J).T
     inner = J.T.dot(J) + lam * np.eye(cols)
+    if cond is not None:
+        cond[0] = max(cond[0], _sym_cond(inner))
     return np.linalg.solve(inner, J.T)
+
+
+def _sym_cond(A):
+    w = np.linalg.eigvalsh(A)
+    lo, hi = abs(w[0]), abs(w[-1])
+    return float(hi / lo) if lo > 0.0 else float("inf")
 
 
 def in_tangent_cone_1d(e, set_min, set_max, dexpr):
@@ -463,10 +477,15 @@ def tangent_cone_margin(e, set_min, set_max, dexpr):
 # ==========================================================================
 # PseudoInverseController
 # ==========================================================================
-def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False, margins_out=None, _wrong=None):
+def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False, margins_out=None, _wrong=None,
+                     cond_out=None):
     """Literal PseudoInverseController: returns (dZ [B,n_state], mode [B]).
 
     dZ[:, :n_q] is robot_vel, the rest virtual_vel.
+
+    `cond_out` [B] (optional) receives, per instance, the largest condition number of any matrix the reference's algorithm
+    hands to its linear solver up to and including the accepted mode (pseudo_inverse.py:92-105): the yardstick of the
+    stated parity tolerance (tests/tolerances.py).
 
     `_wrong` (None = the reference's algorithm) names ONE deliberate deviation, for the tests that state what the
     reference-held figure pins resolve (tests/test_figure_pins.py): "no_S" stacks J instead of S J for an active
@@ -505,6 +524,7 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
     allv = np.zeros((B, n_modes, n)) if return_all_modes else None
     I = np.eye(n)
     for b in range(B):
+        cnd = [1.0] if cond_out is not None else None
         for mode_idx in range(n_modes):
             set_idx = 0
             v = np.zeros(n)
@@ -534,14 +554,14 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     des = -_gain_apply(a.gain, e)
                     if ff:
                         des = des - Jt
-                    v = v + dpinv(Ji, opt).dot(des)
+                    v = v + dpinv(Ji, opt, cnd).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 # chain 2 (:327-443) - an independent if/elif ladder
                 if is_first and is_veleq:
                     des = _num(a.target, m).copy()
                     if ff:
                         des = des - Jt
-                    v = v + dpinv(Ji, opt).dot(des)
+                    v = v + dpinv(Ji, opt, cnd).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 elif is_set and is_last and conv_last:
                     if amap[mode_idx][set_idx]:
@@ -549,10 +569,10 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                         if ff:
                             des = des - Jt
                         if Ja:
-                            N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
+                            N = I - dpinv(np.vstack(Ja), opt, cnd).dot(np.vstack(rJa))
                         else:
                             N = I   # never exercised by the reference (vertcat of nothing)
-                        v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                        v = v + N.dot(dpinv(Ji, opt, cnd)).dot(des)
                         Ja.append(Ji)
                         rJa.append(S.dot(Ji) if multidim else Ji)
                     else:
@@ -564,11 +584,11 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     des = -_gain_apply(a.gain, e)
                     if ff:
                         des = des - Jt
-                    N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
+                    N = I - dpinv(np.vstack(Ja), opt, cnd).dot(np.vstack(rJa))
                     if _wrong == "textbook_projection":
-                        v = v + dpinv(Ji.dot(N), opt).dot(des - Ji.dot(v))
+                        v = v + dpinv(Ji.dot(N), opt, cnd).dot(des - Ji.dot(v))
                     else:
-                        v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                        v = v + N.dot(dpinv(Ji, opt, cnd)).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 elif is_set:
                     if amap[mode_idx][set_idx]:
@@ -581,8 +601,8 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     des = _num(a.target, m).copy()
                     if ff:
                         des = des - Jt
-                    N = I - dpinv(np.vstack(Ja), opt).dot(np.vstack(rJa))
-                    v = v + N.dot(dpinv(Ji, opt)).dot(des)
+                    N = I - dpinv(np.vstack(Ja), opt, cnd).dot(np.vstack(rJa))
+                    v = v + N.dot(dpinv(Ji, opt, cnd)).dot(des)
                     Ja.append(Ji); rJa.append(Ji)
                 # VelocitySetConstraint: no branch -> ignored
             if return_all_modes:
@@ -610,8 +630,12 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
             if ok and modes[b] < 0:
                 modes[b] = mode_idx
                 dZ[b] = v
+                if cond_out is not None:
+                    cond_out[b] = cnd[0]
                 if not return_all_modes:
                     break
+        if cond_out is not None and modes[b] < 0:
+            cond_out[b] = cnd[0]
     if return_all_modes:
         return dZ, modes, allv
     return dZ, modes
@@ -843,9 +867,26 @@ def kkt_residuals(hdiag, A, lb, ub, x, act_tol=1e-8):
     return prim, stat, float(sign_bad)
 
 
-def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
+def qp_condition(hdiag, A, lb, ub, x, act_tol=1e-8):
+    """Sensitivity of the QP's minimiser x to rounding: cond(H) times the condition number of the Schur complement
+    S = Aa H^-1 Aa' of the rows active at x (x = H^-1 Aa' S^+ b_a), taken over the singular values that are not zero to
+    rounding (dependent active rows do not move x).  The yardstick of the stated QP tolerance (tests/tolerances.py)."""
+    hd = np.asarray(hdiag, dtype=float)
+    kh = float(hd.max() / hd.min())
+    Ax = A.dot(x)
+    scale = np.maximum(1.0, np.maximum(np.abs(lb), np.abs(ub)))
+    idx = np.where((np.abs(Ax - lb) <= act_tol * scale) | (np.abs(Ax - ub) <= act_tol * scale))[0]
+    if idx.size == 0:
+        return kh
+    Aa = A[idx]
+    sv = np.linalg.svd((Aa / hd[None, :]).dot(Aa.T), compute_uv=False)
+    sv = sv[sv > 1e-12 * sv[0]]
+    return kh * float(sv[0] / sv[-1])
+
+
+def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001, cond_out=None):
     """Literal ReactiveQPController.solve: (dq [B,nq], dx [B,nx] | None,
-    slack [B,ns] | None, status [B])."""
+    slack [B,ns] | None, status [B]).  `cond_out` [B]: qp_condition of every solved instance."""
     hd, A, lbA, ubA = qp_data_batch(spec, t, Q, X, Y, weights, mu)
     B, nv = hd.shape
     xs = np.zeros((B, nv))
@@ -853,6 +894,8 @@ def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
     for b in range(B):
         try:
             xs[b] = qp_solve_dense(hd[b], A[b], lbA[b], ubA[b])
+            if cond_out is not None:
+                cond_out[b] = qp_condition(hd[b], A[b], lbA[b], ubA[b], xs[b])
         except QPInfeasible:
             status[b] = 2
             xs[b] = np.nan

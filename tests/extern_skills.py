@@ -120,20 +120,22 @@ def dual_quaternion_skill(fk, which="Q_dist2", for_pinv=False):
     return cc.SkillSpecification(label=which, time_var=t, robot_var=q, robot_vel_var=dq, constraints=cn)
 
 
-def random_expression(rng, leaves, depth):
-    """Random smooth expression over the leaves (division and sqrt guarded away from singularities)."""
+def random_expression(rng, leaves, depth, angles=False):
+    """Random smooth expression over the leaves (division and sqrt guarded away from singularities).  `angles`: also the
+    angle-type and saturating functions of round 4 (off by default: the regression seeds of tools/fuzz_*.py replay the
+    random stream of the original ten operations)."""
     if depth == 0 or rng.random() < 0.15:
         leaf = leaves[int(rng.integers(len(leaves)))]
         return leaf if rng.random() < 0.8 else leaf * float(rng.uniform(-2.0, 2.0))
-    op = int(rng.integers(15))
-    a = random_expression(rng, leaves, depth - 1)
+    op = int(rng.integers(15 if angles else 10))
+    a = random_expression(rng, leaves, depth - 1, angles)
     if op >= 10:
-        # angle-type and saturating functions (guarded inside their domains)
-        b = random_expression(rng, leaves, depth - 1)
+        # (guarded inside their domains)
+        b = random_expression(rng, leaves, depth - 1, angles)
         return [cs.atan2(a, 1.5 + cs.cos(b)), cs.tanh(a), cs.fmin(a, cs.fmax(b, -0.5)),
                 cs.asin(0.9 * cs.sin(a)) + cs.acos(0.8 * cs.cos(b)), cs.atan(a * b)][op - 10]
     if op <= 3:
-        b = random_expression(rng, leaves, depth - 1)
+        b = random_expression(rng, leaves, depth - 1, angles)
         return [a + b, a - b, a * b, a / (2.5 + cs.sin(b))][op]
     if op == 4:
         return cs.sin(a)
@@ -145,6 +147,6 @@ def random_expression(rng, leaves, depth):
         return cs.exp(-(a * a) / (1.0 + a * a))
     if op == 8:
         return a ** int(rng.integers(2, 4))
-    return cs.norm_2(cs.vertcat(a, 0.7, random_expression(rng, leaves, depth - 1)))
+    return cs.norm_2(cs.vertcat(a, 0.7, random_expression(rng, leaves, depth - 1, angles)))
 
 

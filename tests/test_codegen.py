@@ -193,7 +193,7 @@ def test_random_expression_trees(tmp_path):
     variables (and tool-frame entries), generated code against the oracle's dual numbers."""
     fk = skills.ur5()
     rng = np.random.default_rng(2024)
-    for trial in range(16):
+    for trial in range(24):
         t, q, x, y = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("x", 2), cs.MX.sym("y", 2)
         T = fk["T_fk"](q)
         leaves = [q[i] for i in range(6)] + [x[0], x[1], y[0], y[1], t, cs.sin(0.3 * t)]
@@ -201,7 +201,7 @@ def test_random_expression_trees(tmp_path):
             leaves += [T[0, 3], T[1, 3], T[2, 3], T[0, 0], T[1, 2], T[2, 1]]
         rows = []
         while len(rows) < 3:
-            e = _random_expression(rng, leaves, 4)
+            e = _random_expression(rng, leaves, 4, angles=trial >= 16)       # (the last eight with atan2 / asin / ... / fmin)
             if isinstance(e, cs.MX) and not e.is_constant():
                 rows.append(e)
         cn = [cc.EqualityConstraint("rand", cs.vertcat(*rows), gain=1.0),

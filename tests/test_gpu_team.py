@@ -433,34 +433,43 @@ def test_resident_ticks_with_input_rows_longer_than_eight(iiwa_fk):
 
 def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
     """every block of a resident launch must be running for a tick to complete: the launch wrapper bounds the grid by
-    the instantiated kernel's occupancy on this device (less one block for the feeder).  32768 instances (512 blocks) fit
-    the whole MI355X - four ticks over a two-slot ring come out equal to launched ticks - and a batch beyond every
-    possible residency (4 M instances) is refused with CLIK_EUNSUPPORTED instead of stalling until the watchdog"""
+    the instantiated kernel's occupancy on this device.  On the MI355X the resident kernel holds one block per CU (its
+    waves take more than 256 registers): 16384 instances = 256 blocks is the limit, and 32768 - which the hard-coded
+    bound of round 3 let through, to spin until the watchdog - is refused with CLIK_EUNSUPPORTED.  Whatever fits must
+    come out equal to launched ticks."""
     import torch
-    from casclik_amd import _capi
     spec = skills.stack_skill(iiwa_fk)
     ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
     ctrl.setup_problem_functions()
-    B, D, NT = 32768, 2, 4
+    D, NT = 2, 4
     if "team4v" not in ctrl.kernel_variant(1000):
         pytest.skip("no value-specialised team kernel attached (hipcc missing)")
-    batches = [skills.synthetic_inputs(iiwa_fk, B, seed=90 + k, distribution="mixed") for k in range(D)]
     dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
-    # (a launched tick of this size runs the one-lane kernel: equal up to rounding, modes identical)
-    want = [ctrl.solve_batch(0.0, dev(q), input_var=dev(y)) for q, y in batches]
-    Qr = torch.stack([dev(q) for q, _ in batches]).contiguous()
-    Yr = torch.stack([dev(y) for _, y in batches]).contiguous()
-    torch.cuda.synchronize()
-    run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
-    feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
-    run["stream"].synchronize()
-    feeder.synchronize()
-    tk = run["ticket"].cpu()
-    assert int(tk[32]) == 0 and int(run["done"].min()) == NT, tk[[0, 32, 49]].tolist()
-    for s in range(D):
-        assert torch.allclose(run["out"][s], want[s][0], rtol=0, atol=1e-9) and torch.equal(run["mode"][s], want[s][2]), s
-    big = 1 << 22
-    Qb = torch.zeros((1, big, 7), dtype=torch.float64, device="cuda")
-    with pytest.raises(_capi.ClikError) as err:
-        ctrl.resident_start(Qb, Qb, 1, timeout_s=1.0, ring_depth=1)
-    assert "resident" in str(err.value)
+    accepted = []
+    for B in (16384, 32768, 1 << 22):
+        if B > 40000:
+            Qr = torch.zeros((1, B, 7), dtype=torch.float64, device="cuda")
+            with pytest.raises(NotImplementedError) as err:
+                ctrl.resident_start(Qr, Qr, 1, timeout_s=1.0, ring_depth=1)
+            assert "resident" in str(err.value)
+            continue
+        batches = [skills.synthetic_inputs(iiwa_fk, B, seed=90 + k, distribution="mixed") for k in range(D)]
+        # (a launched tick beyond 16384 instances runs the one-lane kernel: equal up to rounding, modes identical)
+        want = [ctrl.solve_batch(0.0, dev(q), input_var=dev(y)) for q, y in batches]
+        Qr = torch.stack([dev(q) for q, _ in batches]).contiguous()
+        Yr = torch.stack([dev(y) for _, y in batches]).contiguous()
+        torch.cuda.synchronize()
+        try:
+            run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
+        except NotImplementedError as exc:
+            assert "resident" in str(exc) and B > 16384
+            continue
+        feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
+        run["stream"].synchronize()
+        feeder.synchronize()
+        tk = run["ticket"].cpu()
+        assert int(tk[32]) == 0 and int(run["done"].min()) == NT, (B, tk[[0, 32, 49]].tolist())
+        for s in range(D):
+            assert torch.allclose(run["out"][s], want[s][0], rtol=0, atol=1e-9) and torch.equal(run["mode"][s], want[s][2]), (B, s)
+        accepted.append(B)
+    assert 16384 in accepted
