@@ -1517,9 +1517,10 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
         const unsigned long long budget = timeout_ticks & ~kResidentIntegrateBit;
         // Every block of the launch must be resident at once - a block that never starts can never count, and the
         // ones that did would spin until the watchdog fires.  The bound comes from THIS instantiation's occupancy on
-        // THIS device (registers of the kernel as compiled, CUs of a possibly partitioned device).  (The ticket feeder is
-        // one wave of a few registers: it fits next to a resident block, whose waves leave more than 150 of a SIMD's
-        // 512 registers free.)
+        // THIS device (registers of the kernel as compiled, CUs of a possibly partitioned device), less one block: the
+        // ticket feeder must find room too (measured on the MI355X: the occupancy is two blocks per CU, and a launch of
+        // all 512 - 32768 instances - leaves no SIMD with registers for the feeder's wave: the resident waves then
+        // spin on tickets nobody can publish until the watchdog ends them).
         {
             static int max_blocks[2] = {-1, -1};
             const int which = (timeout_ticks & kResidentIntegrateBit) ? 1 : 0;
@@ -1533,7 +1534,7 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
                 if (oe == hipSuccess) oe = hipGetDevice(&dev);
                 if (oe == hipSuccess) oe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
                 if (oe != hipSuccess) return oe;
-                max_blocks[which] = per_cu * cus;
+                max_blocks[which] = per_cu * cus - 1;
             }
             if ((long long)grid > (long long)max_blocks[which]) return hipErrorNotSupported;
         }

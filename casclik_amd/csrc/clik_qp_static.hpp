@@ -1554,7 +1554,8 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
                                               const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
                                               const int lane, const bool valid, double* slots,
                                               double (&v)[SD.n], double (&sl)[QpLayout<SD>::NSA],
-                                              int32_t* hot, const bool use_hot, const double omega = 1.0)
+                                              int32_t* hot, const bool use_hot, const double omega = 1.0,
+                                              double* jstash = nullptr)
 {
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
@@ -1700,12 +1701,28 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
             lbc[col] = slots[(LY::O_LB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
             ubc[col] = slots[(LY::O_UB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
         });
+        // (large-batch build: the cached Jacobian rows - needed again only for the slacks - wait in LDS while the solver
+        // runs, so that the solver's working set fits two waves per SIMD; lane-major, one 8-byte column per entry)
+        if (jstash != nullptr) {
+#pragma unroll
+            for (int i = 0; i < TaskCache<SD>::ROWS; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) jstash[(i * N + j) * WAVE + lane] = tc.J[i][j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #ifdef CLIK_QP_BOX_PN
         int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
 #else
         int status = qp_box_pas<N, QUAD>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot, omega);
 #endif
         if (!valid) status = 0;
+        if (jstash != nullptr) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TaskCache<SD>::ROWS; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) tc.J[i][j] = jstash[(i * N + j) * WAVE + lane];
+        }
         // slack of the folded rows: s = J v - b
 #pragma unroll
         for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * SSTR + (SSTR == 1 ? 0 : lane)] : 0.0;
@@ -1981,13 +1998,14 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_values_kernel(
 
 // ... for the box family without any LDS: its solver keeps everything in registers, the few work-area slots the row
 // gathering fills become a private array, every lane loads its own rows and stores its own results
-template <const ShapeDesc& SD, class IMGV>
+template <const ShapeDesc& SD, class IMGV, bool STASH = false>
 __device__ __forceinline__ void qp_box_values_body(
     const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
     const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
     const TickArgs& tk)
 {
+    __shared__ double jstash_lds[STASH ? TaskCache<SD>::ROWS * SD.n * WAVE : 1];
     using LY = QpLayout<SD>;
     static_assert(LY::BOX, "box family only");
     constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
@@ -2008,7 +2026,8 @@ __device__ __forceinline__ void qp_box_values_body(
     double priv[LY::SLOTS];
     double v[N], sl[LY::NSA];
     const int status = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                             hot_set != nullptr ? hot_set + row : nullptr, use_hot != 0);
+                                             hot_set != nullptr ? hot_set + row : nullptr, use_hot != 0, 1.0,
+                                             STASH ? jstash_lds : nullptr);
     if (valid) {
         const double bad = (status == 2) ? __builtin_nan("") : 0.0;
 #pragma unroll
@@ -2040,12 +2059,14 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
     qp_box_values_body<SD, IMGV>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
 }
 
-// The same body held to TWO waves per SIMD (at most 256 registers, accumulation registers included) for the batches
-// with more waves than SIMDs: the default build takes 256 VGPRs + 70 AGPRs = ONE wave per SIMD, so 131072 instances
-// (2048 waves on 1024 SIMDs) ran as two rounds of lone waves, each waiting out its own dependent chains (35 % VALU issue
-// utilisation, profiles/r3_counters.json); two resident waves fill each other's stalls.
+// The same body held to TWO waves per SIMD (at most 256 registers, accumulation registers included): an EXPERIMENT,
+// off by default (CLIK_QP_OCC2_MIN_BATCH=<batch> turns it on from that batch size).  The default build takes 256 VGPRs +
+// 70 AGPRs = one wave per SIMD, so 131072 instances (2048 waves on 1024 SIMDs) run as two rounds of lone waves; held to
+// 256 registers the compiler spills 288 B per lane to scratch memory and the two resident waves wait on those round
+// trips instead: measured 30.3 against 25.0 us at 131072 instances, 17.4 against 14.2 at 65536, 16.7 against 12.8 at
+// 32768 (profiles/r4_qp_occ2.txt).
 #ifndef CLIK_QP_OCC2_MIN_BATCH
-#define CLIK_QP_OCC2_MIN_BATCH 65537
+#define CLIK_QP_OCC2_MIN_BATCH (1ll << 60)
 #endif
 template <const ShapeDesc& SD, class IMGV>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void qp_solve_static_box_values_occ2_kernel(
@@ -2054,7 +2075,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
     const TickArgs tk)
 {
-    qp_box_values_body<SD, IMGV>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
+    qp_box_values_body<SD, IMGV, true>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
 }
 
 // ... with four lanes per instance (experiment, CLIK_QP_LANES=4, batches up to 16384 instances: 1024 waves instead of

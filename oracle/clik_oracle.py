@@ -413,6 +413,30 @@ def dpinv(J, opt, cond=None):
     return np.linalg.solve(inner, J.T)
 
 
+_LAST_CONDITION = {}
+
+
+def _remember_condition(result, kappa):
+    """the condition numbers of the most recent solve, keyed by the result array it returned (tests/tolerances.py looks
+    them up for the array a test compares against - no stale numbers for another array)"""
+    _LAST_CONDITION.clear()
+    _LAST_CONDITION["id"] = id(result)
+    _LAST_CONDITION["ref"] = result          # (keeps the id from being reused)
+    _LAST_CONDITION["kappa"] = kappa
+
+
+def condition_of(result):
+    """condition numbers [B] of the solve that returned `result` (the array itself or a basic slice of it), or None"""
+    if not _LAST_CONDITION:
+        return None
+    base = result
+    while base is not None and id(base) != _LAST_CONDITION["id"]:
+        base = getattr(base, "base", None)
+    if base is None or len(result) != len(_LAST_CONDITION["kappa"]):
+        return None
+    return _LAST_CONDITION["kappa"]
+
+
 def _sym_cond(A):
     w = np.linalg.eigvalsh(A)
     lo, hi = abs(w[0]), abs(w[-1])
@@ -523,8 +547,9 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
     modes = -np.ones(B, dtype=np.int32)
     allv = np.zeros((B, n_modes, n)) if return_all_modes else None
     I = np.eye(n)
+    cond_all = np.ones(B)
     for b in range(B):
-        cnd = [1.0] if cond_out is not None else None
+        cnd = [1.0]
         for mode_idx in range(n_modes):
             set_idx = 0
             v = np.zeros(n)
@@ -630,12 +655,14 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
             if ok and modes[b] < 0:
                 modes[b] = mode_idx
                 dZ[b] = v
-                if cond_out is not None:
-                    cond_out[b] = cnd[0]
+                cond_all[b] = cnd[0]
                 if not return_all_modes:
                     break
-        if cond_out is not None and modes[b] < 0:
-            cond_out[b] = cnd[0]
+        if modes[b] < 0:
+            cond_all[b] = cnd[0]
+    if cond_out is not None:
+        cond_out[:] = cond_all
+    _remember_condition(dZ, cond_all)
     if return_all_modes:
         return dZ, modes, allv
     return dZ, modes
@@ -891,14 +918,17 @@ def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001, cond_out=
     B, nv = hd.shape
     xs = np.zeros((B, nv))
     status = np.zeros(B, dtype=np.int32)
+    kappa = np.ones(B)
     for b in range(B):
         try:
             xs[b] = qp_solve_dense(hd[b], A[b], lbA[b], ubA[b])
-            if cond_out is not None:
-                cond_out[b] = qp_condition(hd[b], A[b], lbA[b], ubA[b], xs[b])
+            kappa[b] = qp_condition(hd[b], A[b], lbA[b], ubA[b], xs[b])
         except QPInfeasible:
             status[b] = 2
             xs[b] = np.nan
+    if cond_out is not None:
+        cond_out[:] = kappa
+    _remember_condition(xs, kappa)
     nq = spec.n_robot_var
     nvirt = spec.n_virtual_var if spec.virtual_var is not None else 0
     ns = spec.n_slack_var

@@ -7,7 +7,7 @@ import pytest
 import casclik_amd as cc
 from casclik_amd import skills
 from casclik_amd import sym as cs
-from tolerances import PINV_RTOL
+from tolerances import PINV_RTOL, pinv_close, qp_close
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,7 @@ def _rel(a, ref):
     return np.abs(a - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))
 
 
-def _check(spec, options, Q, Y=None, t=0.0, tol=PINV_RTOL, min_modes=1):
+def _check(spec, options, Q, Y=None, t=0.0, min_modes=1):
     from oracle import clik_oracle
     ctrl = cc.PseudoInverseController(skill_spec=spec, options=None if options is None else dict(options))
     ctrl.setup_problem_functions()
@@ -24,7 +24,7 @@ def _check(spec, options, Q, Y=None, t=0.0, tol=PINV_RTOL, min_modes=1):
     ref, rmode = clik_oracle.pinv_solve_batch(spec, options, t, Q, Y=Y)
     assert np.array_equal(mode, rmode)
     assert len(np.unique(mode)) >= min_modes
-    assert _rel(dq, ref).max() < tol, _rel(dq, ref).max()
+    assert pinv_close(dq, ref), _rel(dq, ref).max()
     return ctrl
 
 
@@ -43,7 +43,7 @@ def test_velocity_equality_first_and_not_first(iiwa_fk):
     pos = cc.EqualityConstraint("xy", T[:2, 3] - np.array([0.3, 0.2]), gain=2.0, priority=1)
     spec = cc.SkillSpecification("vel", t, q, constraints=[spin, pos, lift])
     Q, _ = skills.synthetic_inputs(iiwa_fk, 150, seed=1)
-    _check(spec, None, Q, tol=1e-8)
+    _check(spec, None, Q)
 
 
 def test_converge_final_set_to_max(iiwa_fk):
@@ -72,7 +72,7 @@ def test_standard_pinv_single_task(iiwa_fk):
     """pinv_method 'standard' (cs.pinv, :93-94) on a single full-rank task."""
     spec = skills.position_skill(iiwa_fk)
     Q, Y = skills.synthetic_inputs(iiwa_fk, 120, seed=4)
-    c = _check(spec, {"pinv_method": "standard"}, Q, Y[:, :3], tol=1e-8)
+    c = _check(spec, {"pinv_method": "standard"}, Q, Y[:, :3])
     assert c.kernel_name.startswith("jit_")      # no AOT shape: instantiated at setup
 
 
@@ -93,7 +93,7 @@ def test_jit_and_dynamic_kernels_agree(iiwa_fk, monkeypatch):
     assert fast.kernel_name.startswith("jit_") and slow.kernel_name == "dynamic"
     a, _, ma = fast.solve_batch(0.0, Q)
     b, _, mb = slow.solve_batch(0.0, Q)
-    assert np.array_equal(ma, mb) and _rel(a, b).max() < PINV_RTOL
+    assert np.array_equal(ma, mb) and pinv_close(a, b)
 
 
 def test_feedforward_off_and_tiny_damping(ur5_fk):
@@ -107,7 +107,7 @@ def test_feedforward_off_and_tiny_damping(ur5_fk):
     spec = cc.SkillSpecification("track", t, q, constraints=[cc.EqualityConstraint("p", p - path, gain=0.5)])
     Q, _ = skills.synthetic_inputs(fk, 100, seed=5)
     for opts in ({"feedforward": False}, {"feedforward": True}, {"damping_factor": 1e-26}):
-        _check(spec, opts, Q, t=1.3, tol=1e-8)
+        _check(spec, opts, Q, t=1.3)
 
 
 def test_matrix_gain_and_input_offset(ur5_fk):
@@ -124,7 +124,7 @@ def test_matrix_gain_and_input_offset(ur5_fk):
     spec = cc.SkillSpecification("inp", t, q, input_var=y, constraints=[c])
     Q, _ = skills.synthetic_inputs(fk, 100, seed=6)
     Y = np.random.default_rng(6).normal(scale=0.1, size=(100, 3))
-    _check(spec, None, Q, Y, tol=1e-8)
+    _check(spec, None, Q, Y)
 
 
 def test_two_multidim_sets_four_modes(iiwa_fk):
@@ -148,7 +148,7 @@ def test_velocity_set_is_ignored_by_pinv(iiwa_fk):
     speed = cc.VelocitySetConstraint("speed", q, set_min=-0.1 * np.ones(7), set_max=0.1 * np.ones(7), priority=0)
     with_speed = cc.SkillSpecification("a", t, q, constraints=[pos, speed])
     Q, _ = skills.synthetic_inputs(iiwa_fk, 64, seed=8)
-    _check(with_speed, None, Q, tol=1e-8)
+    _check(with_speed, None, Q)
 
 
 def test_multidim_set_without_option_is_refused(iiwa_fk):
@@ -215,7 +215,7 @@ def test_virtual_variable_pinv(ur5_fk, kernel, monkeypatch):
     ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
     assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
     assert dx.shape == (150, 1)
-    assert _rel(np.hstack([dq, dx]), ref).max() < PINV_RTOL
+    assert pinv_close(np.hstack([dq, dx]), ref)
     # single-instance API returns the virtual velocity as the second result (pseudo_inverse.py:553-555)
     rob, virt, _ = ctrl.solve(0.0, Q[0], virtual_var=X[0])
     assert np.allclose(rob.toarray()[:, 0], ref[0, :6], atol=1e-9) and np.allclose(virt.toarray()[:, 0], ref[0, 6:], atol=1e-9)
@@ -301,7 +301,7 @@ def test_chainless_one_dof_skill(kernel, monkeypatch):
     dq, dx, mode = ctrl.solve_batch(0.0, Q, virtual_var=X)
     ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
     assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
-    assert _rel(np.hstack([dq, dx]), ref).max() < PINV_RTOL
+    assert pinv_close(np.hstack([dq, dx]), ref)
     qp = cc.ReactiveQPController(skill_spec=spec)
     qp.setup_problem_functions()
     qp.setup_solver()
@@ -363,7 +363,7 @@ def test_first_equality_with_a_constant_jacobian_is_processed_twice_in_the_insta
     for cons in ([head], [head, pos], [head, pos, elbow, rest]):
         spec = cc.SkillSpecification("const_first", t, q, constraints=cons)
         # (a tall first equality fixes the whole velocity: the set behind it never decides anything on these inputs)
-        ctrl = _check(spec, {"damping_factor": 1e-5}, Q, tol=1e-8,
+        ctrl = _check(spec, {"damping_factor": 1e-5}, Q,
                       min_modes=2 if (len(cons) == 4 and first != "tall_constant_matrix") else 1)
         assert ctrl.kernel_name.startswith("jit_"), ctrl.kernel_name
 
@@ -405,7 +405,7 @@ def test_tall_first_equality_is_processed_twice(ur5_fk, monkeypatch, force_dynam
     for cons in ([frame], [frame, rest]):
         spec = cc.SkillSpecification("tall", t, q, constraints=cons)
         Q, _ = skills.synthetic_inputs(ur5_fk, 300, seed=6)
-        ctrl = _check(spec, {"damping_factor": 1e-4}, 0.3 * Q, tol=1e-8)
+        ctrl = _check(spec, {"damping_factor": 1e-4}, 0.3 * Q)
         assert (ctrl.kernel_name == "dynamic") == force_dynamic
 
 
@@ -588,7 +588,7 @@ def test_seven_dof_arm_with_two_or_three_virtual_variables(iiwa_fk, nx):
     dqv, dxv, mode = ctrl.solve_batch(0.0, Q, virtual_var=X)
     ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, X=X)
     assert np.array_equal(mode, rmode) and len(np.unique(mode)) == 2
-    assert dxv.shape == (160, nx) and _rel(np.hstack([dqv, dxv]), ref).max() < PINV_RTOL
+    assert dxv.shape == (160, nx) and pinv_close(np.hstack([dqv, dxv]), ref)
     spec = spec_for("qp")
     qctrl = cc.ReactiveQPController(skill_spec=spec)
     qctrl.setup_problem_functions()

@@ -10,7 +10,7 @@ from casclik_amd import skills
 from casclik_amd import sym as cs
 from casclik_amd.constraints import EqualityConstraint, SetConstraint
 from casclik_amd.skill_specification import SkillSpecification
-from tolerances import PINV_RTOL
+from tolerances import PINV_RTOL, pinv_close, qp_close
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,7 @@ def test_team_kernel_vs_numpy_oracle(iiwa_fk, ur5_fk, robot, dist, B, monkeypatc
     dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
     ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q, Y=Y)
     assert np.array_equal(mode, ref_mode)
-    assert _rel(dq, ref).max() < PINV_RTOL
+    assert pinv_close(dq, ref)
     if dist == "mixed" and B >= 200:
         assert (mode == 0).any() and (mode == 1).any()     # both candidates are exercised
 
@@ -62,8 +62,8 @@ def test_team_kernel_vs_c_oracle_and_lane_kernel_full_size(iiwa_fk, monkeypatch)
         0.0, Q, Y=Y, margins_out=margin)
     assert margin.min() > 1e-7          # (no tangent-cone decision of this batch is within rounding of flipping)
     assert np.array_equal(mode_t, ref_mode) and np.array_equal(mode_l, ref_mode)
-    assert _rel(dq_t, ref).max() < PINV_RTOL
-    assert _rel(dq_t, dq_l).max() < PINV_RTOL
+    assert pinv_close(dq_t, ref)
+    assert pinv_close(dq_t, dq_l)
     # a permuted batch gives the permuted answer bit for bit (no cross-instance coupling, no
     # dependence on the position inside the quad / wave / block)
     perm = np.random.default_rng(1).permutation(B)
@@ -111,7 +111,7 @@ def test_team_kernel_family_members(iiwa_fk, gain_matrix, one_sided, feedforward
         dq, _, mode = ctrl.solve_batch(t, Q, input_var=Y)
         ref, ref_mode = clik_oracle.pinv_solve_batch(spec, opts, t, Q, Y=Y)
         assert np.array_equal(mode, ref_mode)
-        assert _rel(dq, ref).max() < PINV_RTOL
+        assert pinv_close(dq, ref)
 
 
 def test_team_kernel_near_singular(iiwa_fk, monkeypatch):
@@ -176,7 +176,7 @@ def test_value_specialised_and_image_reading_team_kernels_agree(iiwa_fk, ur5_fk,
     dq_i, _, mode_i = img.solve_batch(0.0, Q, input_var=Y)
     ref, ref_mode = clik_oracle.pinv_solve_batch(spec, skills.STACK_OPTIONS, 0.0, Q[:400], Y=Y[:400])
     assert np.array_equal(mode_v, mode_i) and np.array_equal(mode_v[:400], ref_mode)
-    assert _rel(dq_v, dq_i).max() < PINV_RTOL and _rel(dq_v[:400], ref).max() < PINV_RTOL
+    assert pinv_close(dq_v, dq_i) and pinv_close(dq_v[:400], ref)
 
 
 def test_value_specialised_lane_kernel_of_the_stack_between_16385_and_32768(iiwa_fk):
@@ -197,9 +197,9 @@ def test_value_specialised_lane_kernel_of_the_stack_between_16385_and_32768(iiwa
     ref, _, rmode = co.solve_batch(0.0, Q, Y=Y)
     assert set(np.unique(rmode)) == {0, 1}
     assert np.array_equal(mode, rmode) and np.array_equal(mode2, rmode)
-    assert _rel(dq, ref).max() < PINV_RTOL and _rel(dq, dq2).max() < PINV_RTOL
+    assert pinv_close(dq, ref) and pinv_close(dq, dq2)
     dq3, _, mode3 = ctrl.solve_batch(0.0, Q[:16384], input_var=Y[:16384])          # (team4v on the same instances)
-    assert np.array_equal(mode3, rmode[:16384]) and _rel(dq3, dq[:16384]).max() < PINV_RTOL
+    assert np.array_equal(mode3, rmode[:16384]) and pinv_close(dq3, dq[:16384])
 
 
 @pytest.mark.parametrize("skill", ["pose", "position"])
@@ -433,10 +433,10 @@ def test_resident_ticks_with_input_rows_longer_than_eight(iiwa_fk):
 
 def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
     """every block of a resident launch must be running for a tick to complete: the launch wrapper bounds the grid by
-    the instantiated kernel's occupancy on this device.  On the MI355X the resident kernel holds one block per CU (its
-    waves take more than 256 registers): 16384 instances = 256 blocks is the limit, and 32768 - which the hard-coded
-    bound of round 3 let through, to spin until the watchdog - is refused with CLIK_EUNSUPPORTED.  Whatever fits must
-    come out equal to launched ticks."""
+    the instantiated kernel's occupancy on this device, less one block for the ticket feeder.  On the MI355X that is 511
+    blocks: 32768 instances (512 blocks) - which the hard-coded bound of round 3 let through, to spin until the watchdog
+    because the feeder found no free registers - is refused with CLIK_EUNSUPPORTED.  Whatever is accepted must come out
+    equal to launched ticks."""
     import torch
     spec = skills.stack_skill(iiwa_fk)
     ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
@@ -446,7 +446,7 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
         pytest.skip("no value-specialised team kernel attached (hipcc missing)")
     dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
     accepted = []
-    for B in (16384, 32768, 1 << 22):
+    for B in (16384, 32704, 32768, 1 << 22):
         if B > 40000:
             Qr = torch.zeros((1, B, 7), dtype=torch.float64, device="cuda")
             with pytest.raises(NotImplementedError) as err:
@@ -463,6 +463,7 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
             run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
         except NotImplementedError as exc:
             assert "resident" in str(exc) and B > 16384
+            assert B >= 32768, (B, "refused although it fits")
             continue
         feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
         run["stream"].synchronize()
@@ -473,3 +474,39 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
             assert torch.allclose(run["out"][s], want[s][0], rtol=0, atol=1e-9) and torch.equal(run["mode"][s], want[s][2]), (B, s)
         accepted.append(B)
     assert 16384 in accepted
+
+
+def test_worst_case_of_the_team_sweeps_is_held_to_its_own_bound():
+    """`tools/fuzz_team.py 20 3`, skill 15 - the largest error any randomised sweep of round 3 recorded for the pinv
+    path, 2.32e-7 (profiles/r3_fuzz_summary.txt): iiwa, 6-row first task, damping 1e-9, mixed inputs.  Its projectors
+    meet condition numbers of 3e9 ... 2e10, so the stated rule (tests/tolerances.py) bounds its instances by 3e-6 ... 2e-5
+    - two orders above the default-options ceiling, which this skill was (rightly) not held to.  Every instance against
+    ITS bound, both kernel variants."""
+    import os
+    import sys
+    from oracle import clik_oracle
+    from tolerances import rtol_from_cond, rel_err, ILL_POSED, U
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_team
+    rng = np.random.default_rng(3)
+    for _ in range(16):                      # replay the sweep's random stream up to skill 15
+        d = fuzz_team.draw(rng)
+    assert d["robot"] == "iiwa" and d["m"] == 6 and d["k3"] == 7 and 5e-10 < d["opts"]["damping_factor"] < 2e-9
+    spec, opts, Q, Y, tval = d["spec"], d["opts"], d["Q"], d["Y"], d["tval"]
+    kappa = np.zeros(len(Q))
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, opts, tval, Q, Y=Y, cond_out=kappa)
+    tol = rtol_from_cond(kappa)
+    assert (tol < ILL_POSED).all() and tol.max() > 1e-6
+    for values in ("1", "0"):
+        os.environ["CLIK_JIT_VALUES"] = values
+        try:
+            ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(opts))
+            ctrl.setup_problem_functions()
+            dq, _, mode = ctrl.solve_batch(tval, Q, input_var=Y)
+        finally:
+            os.environ.pop("CLIK_JIT_VALUES", None)
+        assert np.array_equal(mode, rmode)
+        err = rel_err(dq, ref)
+        assert (err <= tol).all(), (ctrl.kernel_variant(len(Q)), float((err / tol).max()))
+        print("%s: worst err %.2e = %.2f u kappa = %.3f of its bound" % (
+            ctrl.kernel_variant(len(Q)), err.max(), (err / (U * kappa)).max(), (err / tol).max()))

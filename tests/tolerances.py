@@ -83,3 +83,53 @@ def check_pinv(dq, ref, kappa, what=""):
                            float(err[bad].max()))
     ratio = float((err[posed] / (U * np.asarray(kappa)[posed])).max()) if posed.any() else 0.0
     return (float(err[posed].max()) if posed.any() else 0.0), ratio, int((~posed).sum())
+
+
+def _kappa_for(ref):
+    from oracle import clik_oracle
+    return clik_oracle.condition_of(ref)
+
+
+def pinv_close(a, ref, ceiling=PINV_RTOL):
+    """`a` against `ref` under the rule.  When `ref` is what the numpy oracle's last solve returned (the array itself or a
+    basic slice of it), every instance is held to ITS bound max(FLOOR, FACTOR u kappa) (ill-posed ones left out);
+    otherwise - a comparison of two device results, a fixture, a row subset - to the default-options ceiling."""
+    err = rel_err(np.atleast_2d(a), np.atleast_2d(ref))
+    kappa = _kappa_for(ref)
+    if kappa is None:
+        return bool((err < ceiling).all())
+    tol = rtol_from_cond(kappa)
+    posed = tol < ILL_POSED
+    return bool((err[posed] <= tol[posed]).all())
+
+
+def qp_close(a, ref, ceiling=QP_RTOL):
+    """the same for the QP path (kappa = clik_oracle.qp_condition of each instance; infeasible rows - NaN - are skipped)"""
+    a, ref = np.atleast_2d(a), np.atleast_2d(ref)
+    good = ~np.isnan(ref).any(axis=1)
+    err = np.zeros(len(ref))
+    err[good] = rel_err(a[good], ref[good])
+    kappa = _kappa_for(ref)
+    if kappa is None:
+        return bool((err < ceiling).all())
+    tol = rtol_from_cond(kappa)
+    posed = good & (tol < ILL_POSED)
+    return bool((err[posed] <= tol[posed]).all())
+
+
+def worst_over_tol(a, ref, rows=None):
+    """max over the well-posed instances of err / (the rule's bound), kappa looked up from the oracle solve that returned
+    `ref` (must be that array or a basic slice of it; `rows`: boolean mask of the instances to look at).  The sweeps of
+    tools/fuzz_*.py flag a skill when this exceeds 1.  Returns (ratio, worst err, instances left out as ill-posed)."""
+    kappa = _kappa_for(ref)
+    assert kappa is not None, "worst_over_tol needs the array the oracle returned"
+    a, ref = np.atleast_2d(a), np.atleast_2d(ref)
+    keep = ~np.isnan(ref).any(axis=1) & ~np.isnan(a).any(axis=1)
+    if rows is not None:
+        keep &= rows
+    tol = rtol_from_cond(kappa)
+    posed = keep & (tol < ILL_POSED)
+    if not posed.any():
+        return 0.0, 0.0, int((keep & ~posed).sum())
+    err = rel_err(a[posed], ref[posed])
+    return float((err / tol[posed]).max()), float(err.max()), int((keep & ~posed).sum())

@@ -19,7 +19,8 @@ import numpy as np                                   # noqa: E402
 import casclik_amd as cc                             # noqa: E402
 from casclik_amd import skills                       # noqa: E402
 from oracle import clik_oracle                       # noqa: E402
-import fuzz_parity                                   # noqa: E402
+import fuzz_parity
+from tolerances import worst_over_tol                                   # noqa: E402
 
 n_skills = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -58,8 +59,8 @@ for s in range(n_skills):
     false_inf = (rst == 0) & (st == 2)
     missed = (rst == 2) & (st == 0)
     ok = (rst == 0) & (st == 0)
-    err = float((np.abs(dq - rdq).max(axis=1) / (1 + np.abs(rdq).max(axis=1)))[ok].max()) if ok.any() else 0.0
-    if false_inf.any() or err > 1e-6:
+    over, err, _ = worst_over_tol(dq, rdq, rows=ok)          # (the stated rule, tests/tolerances.py)
+    if false_inf.any() or over > 1.0:
         bad_total += int(false_inf.sum())
         hits.append((seed, s, robot, np.nonzero(false_inf)[0][:6].tolist()))
         print("skill %3d %-4s rows %2d tasks %s: oracle feasible & device infeasible on %d of %d (oracle infeasible %d, missed %d) err %.1e" % (

@@ -127,6 +127,10 @@ def build(rec, cs, cc, T_fk, ori_err, lower, upper, vmax):
     return cc.SkillSpecification(label="fuzz", time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons, **kw)
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from tolerances import rtol_from_cond, ILL_POSED      # noqa: E402
+
+
 def main():
     n_skills = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -182,15 +186,21 @@ def main():
                 if rec["virtual"]:
                     ref_dz[b, n:] = res[1].full().ravel()
                 ref_mode[b] = ctrl.current_mode
-            dz, mode = clik_oracle.pinv_solve_batch(own_spec, dict(rec["options"]), t0, Q, X=X)
+            kappa = np.zeros(B)
+            dz, mode = clik_oracle.pinv_solve_batch(own_spec, dict(rec["options"]), t0, Q, X=X, cond_out=kappa)
             counts["pinv_runs"] += 1
             same_mode = mode == ref_mode
             counts["mode_mismatch"] += int((~same_mode).sum())
             err = np.abs(dz - ref_dz).max(axis=1) / (1.0 + np.abs(ref_dz).max(axis=1))
             e = float(err[same_mode].max()) if same_mode.any() else 0.0
             worst["pinv"] = max(worst["pinv"], e)
-            line = "pinv modes %s (%d sets) err %.1e mismatching modes %d" % (
-                np.bincount(ref_mode + 1).tolist(), n_sets, e, int((~same_mode).sum()))
+            # the stated rule (tests/tolerances.py): every instance against max(FLOOR, FACTOR u kappa)
+            tol_b = rtol_from_cond(kappa)
+            posed = same_mode & (tol_b < ILL_POSED)
+            over = float((err / tol_b)[posed].max()) if posed.any() else 0.0
+            worst["pinv_over"] = max(worst.get("pinv_over", 0.0), over)
+            line = "pinv modes %s (%d sets) err %.1e (%.2f x tol) mismatching modes %d" % (
+                np.bincount(ref_mode + 1).tolist(), n_sets, e, over, int((~same_mode).sum()))
         except Exception as exc:          # (skills the reference itself refuses: reported, not compared)
             counts["skipped"] += 1
             line = "pinv skipped (%s: %s)" % (type(exc).__name__, str(exc)[:60])
@@ -200,7 +210,9 @@ def main():
             qp.setup_problem_functions()
             qp.setup_solver()
             H, A, lbA, ubA = clik_oracle.qp_data_batch(own_spec, t0, Q, X)
-            odq, odx, oslack, ostatus = clik_oracle.qp_solve_batch(own_spec, t0, Q, X=X)
+            qkappa = np.ones(B)
+            odq, odx, oslack, ostatus = clik_oracle.qp_solve_batch(own_spec, t0, Q, X=X, cond_out=qkappa)
+            qtol_b = rtol_from_cond(qkappa)
             e_data = e_sol = 0.0
             bad_status = 0
             for b in range(B):
@@ -232,7 +244,10 @@ def main():
                     continue
                 if r_status == 0 and ostatus[b] == 0:
                     rdq = res[0].full().ravel()
-                    e_sol = max(e_sol, np.abs(odq[b] - rdq).max() / (1.0 + np.abs(rdq).max()))
+                    e_b = np.abs(odq[b] - rdq).max() / (1.0 + np.abs(rdq).max())
+                    e_sol = max(e_sol, e_b)
+                    if qtol_b[b] < ILL_POSED:
+                        worst["qp_over"] = max(worst.get("qp_over", 0.0), e_b / qtol_b[b])
             # the initial problem (reactive_qp.py:300-459): virtual velocities and slack with the robot held still
             e_init = 0.0
             qp.setup_initial_problem_solver()
@@ -264,6 +279,9 @@ def main():
           "problem worst %.2e, status mismatches %d; refused by the reference or the oracle: %d"
           % (n_skills, B, counts["pinv_runs"], worst["pinv"], counts["mode_mismatch"], counts["qp_runs"],
              worst["qp_data"], worst["qp"], worst.get("qp_init", 0.0), counts["status_mismatch"], counts["skipped"]))
+    print("against the stated rule (tests/tolerances.py, per instance max(FLOOR, FACTOR u kappa)): worst err / tol  pinv %.3f  "
+          "qp %.3f   %s" % (worst.get("pinv_over", 0.0), worst.get("qp_over", 0.0),
+                            "(all within)" if max(worst.get("pinv_over", 0.0), worst.get("qp_over", 0.0)) <= 1.0 else "<-- BEYOND THE RULE"))
 
 
 if __name__ == "__main__":
