@@ -649,8 +649,7 @@ def compact_entry(e):
     r = e.get("roofline") or {}
     f64 = r.get("fp64") or {}
     out = {"us": _r(e["ms_per_step"] * 1e3, 3), "G_per_s": _r(e["value"] / 1e9, 3), "kernel": e["config"].get("kernel"),
-           "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic"),
-           "steps": e["config"].get("timed_steps")}
+           "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic")}
     if r.get("traffic_source"):
         out["pmc"] = r["traffic_source"].replace("profiles/", "")
     c = e.get("cpu_baseline")
@@ -662,9 +661,8 @@ def compact_entry(e):
     return out
 
 
-NOTES = ("us = wall per tick under the driver-style bracket; roofline: 172 B/instance-step (QP 220) over the HIP-event "
-         "tick time vs 8 TB/s, fp64_frac = executed fp64 VALU flops (PMC, profiles/) vs 78.6 TF; extras = the other BASELINE "
-         "configs, rollouts (state in registers: no HBM fraction) and resident ticks; --full 1 prints every detail")
+NOTES = ("us = wall per tick; roofline = 172 B/instance-step (QP 220) / HIP-event tick time vs 8 TB/s; fp64_frac = executed "
+         "fp64 flops (PMC, profiles/) vs 78.6 TF; extras = other BASELINE configs, rollouts, resident ticks; --full 1 = details")
 
 
 def init_ranks(world, rank, dev, shared_gpu):

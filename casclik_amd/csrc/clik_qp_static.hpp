@@ -972,6 +972,37 @@ __device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2],
 // instance with one instruction stream and per-lane data - the over-relaxation factor `omega` of the start sweeps
 // differs per lane, so the lanes end the sweeps on different partitions - and the quad is done as soon as ONE lane has
 // reached the KKT point (the others stop with it).
+// Symmetric sweep of index K of the packed tableau S (lower triangle) in the lanes where m = 1.0 (m = 0.0 leaves a
+// lane's tableau untouched): with F the set of swept indices,  S_FF = -(P_FF)^-1,  S_HF = P_HF (P_FF)^-1,  S_HH = the
+// Schur complement of P_FF.  sgn = +1 sweeps K in (the state becomes free), -1 sweeps it out again (it is held): one
+// reciprocal and a rank-one update either way - what a working-set change costs qp_box_pas instead of a refactorisation.
+#ifndef CLIK_QP_BOX_SWEEP
+#define CLIK_QP_BOX_SWEEP 1
+#endif
+template <int N, int K>
+__device__ __forceinline__ void qp_sym_sweep(double (&S)[N * (N + 1) / 2], const double m, const double sgn)
+{
+    const double d = fma(m, S[tri(K, K)] - 1.0, 1.0);          // (1.0 in the lanes that sit this one out)
+    const double p = recip(d);
+    const double pm = m * p;
+    double t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = (i == K) ? 0.0 : S[i >= K ? tri(i, K) : tri(K, i)] * pm;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            if (i != K && j != K) S[tri(i, j)] = fma(-t[i], S[j >= K ? tri(j, K) : tri(K, j)], S[tri(i, j)]);
+    const double cf = m * fma(sgn, p, -1.0);                   // column: S_iK <- sgn S_iK / d   (m = 0: unchanged)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i != K) {
+            double& e = S[i >= K ? tri(i, K) : tri(K, i)];
+            e = fma(e, cf, e);
+        }
+    S[tri(K, K)] = fma(m, -p - S[tri(K, K)], S[tri(K, K)]);
+}
+
 template <int N, bool QUAD = false>
 __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
                                           const double (&lb)[N], const double (&ub)[N], const int max_pass,
@@ -1061,13 +1092,40 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
     bool quad_over = false;      // (QUAD: some lane of this lane's quad has finished)
     bool done = !valid | empty;
     int status = empty ? 2 : 1;
+#if CLIK_QP_BOX_SWEEP
+    // the swept tableau of the starting partition: one sweep per state that is free in SOME lane of the wave
+    double S[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) S[a] = Pm[a];
+    static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const bool fr = (held[k] == 0) & !done;
+        if (__ballot(fr) != 0ull) qp_sym_sweep<N, k>(S, fr ? 1.0 : 0.0, 1.0);
+    });
+#endif
     // (masks applied arithmetically and selections by min / max: a select of a double costs two instructions and
     // a flag test two more, and a lone wave pays every one of them in full)
 #pragma unroll 1
     for (int pass = 0; pass < max_pass; ++pass) {
         if (__ballot(!(done | quad_over)) == 0ull) break;
         // Newton direction on the free states
-        double M[NT], rd[N], d[N];
+        double d[N];
+#if CLIK_QP_BOX_SWEEP
+        {
+            // d_F = (P_FF)^-1 gr_F = -S_FF gr_F: a masked symmetric matrix-vector product on the tableau
+            double gm[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) gm[a] = fma(-as_mask(held[a]), gr[a], gr[a]);
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int b = 0; b < N; ++b) sacc = fma(-S[a >= b ? tri(a, b) : tri(b, a)], gm[b], sacc);
+                d[a] = sacc;
+            }
+        }
+#else
+        double M[NT], rd[N];
 #pragma unroll
         for (int a = 0; a < NT; ++a) M[a] = Pm[a];
 #pragma unroll
@@ -1078,6 +1136,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         }
         ldl_factor_s<N>(M, rd);
         ldl_solve_s<N>(M, rd, d);
+#endif
         // first bound hit along x - alpha d: alpha = min(1, room_a / d_a).  The quotient needs no correct rounding (a
         // blocked step ends on no face minimum, and the states that land are snapped onto their bounds): hardware
         // reciprocal.  0 * inf = NaN for a held state on its bound, which min ignores.
@@ -1093,13 +1152,25 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         const bool blocked = amin < 1.0;
         const double alpha = (done | quad_over) ? 0.0 : amin;
         const double thr = amin * (1.0 + 1e-7);
+#if CLIK_QP_BOX_SWEEP
+        bool lands_a[N];
+#endif
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             const double xn = fma(-alpha, d[a], x[a]);
             const bool lands = blocked & !(done | quad_over) & (r[a] <= thr);            // the blocking state (and ties): held there
             x[a] = lands ? tgt[a] : xn;
             held[a] = lands ? kOne : held[a];
+#if CLIK_QP_BOX_SWEEP
+            lands_a[a] = lands;
+#endif
         }
+#if CLIK_QP_BOX_SWEEP
+        static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if (__ballot(lands_a[k]) != 0ull) qp_sym_sweep<N, k>(S, lands_a[k] ? 1.0 : 0.0, -1.0);
+        });
+#endif
         gradient();
         // at a face minimum: release the held state whose multiplier is wrong by the largest amount, or stop
         double c[N];
@@ -1111,8 +1182,17 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             worst = fmax(worst, c[a]);
         }
         const bool release = !blocked & !(done | quad_over) & (worst > 0.0);
+#if CLIK_QP_BOX_SWEEP
+        static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const bool rel = release & (c[k] == worst) & (held[k] != 0);
+            held[k] = rel ? 0 : held[k];
+            if (__ballot(rel) != 0ull) qp_sym_sweep<N, k>(S, rel ? 1.0 : 0.0, 1.0);
+        });
+#else
 #pragma unroll
         for (int a = 0; a < N; ++a) held[a] = (release & (c[a] == worst)) ? 0 : held[a];
+#endif
         done = done | (!quad_over & !blocked & !(worst > 0.0));
         if constexpr (QUAD) {
             // a lane that has finished ends its whole quad (mov_dpp quad_perm broadcasts of the flag)
@@ -1122,6 +1202,24 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             quad_over = quad_over | (any != 0);
         }
     }
+#if CLIK_QP_BOX_SWEEP
+    if (!empty) {
+        // one more Newton step on the final face: the rank-one updates of the tableau accumulate rounding over the
+        // passes, a Newton step from a point at the minimiser to 1e-12 lands on it to rounding (the held states do not move)
+        double gm[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) gm[a] = fma(-as_mask(held[a]), gr[a], gr[a]);
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int b = 0; b < N; ++b) sacc = fma(S[a >= b ? tri(a, b) : tri(b, a)], gm[b], sacc);       // = -d_a
+            const double xn = x[a] + fma(-as_mask(held[a]), sacc, sacc);
+            x[a] = done ? fmin(fmax(xn, lb[a]), ub[a]) : x[a];
+        }
+        gradient();
+    }
+#endif
     if (!empty) {
         // the KKT conditions of the returned point (gr is the gradient at x)
         bool kkt = true;

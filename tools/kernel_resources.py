@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Registers / scratch / occupancy of the value-specialised kernels of a BASELINE skill, from the compiler's resource
-remarks (no GPU needed).      python tools/kernel_resources.py [stack|pose|qp] [-DFLAG ...]"""
+remarks (no GPU needed).      python tools/kernel_resources.py [stack|pose|qp] [-DFLAG ...] [--asm=listing.s]"""
 import os
 import subprocess
 import sys
@@ -16,7 +16,8 @@ from casclik_amd.lowering import lower_skill         # noqa: E402
 import casclik_amd as cc                             # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "qp"
-flags = [a for a in sys.argv[2:] if a.startswith("-")]
+flags = [a for a in sys.argv[2:] if a.startswith("-D")]
+asm_out = [a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--asm=")]
 lib = _capi.load_library()
 fk = skills.iiwa()
 if which == "qp":
@@ -49,6 +50,10 @@ with tempfile.TemporaryDirectory() as tmp:
     if out.returncode != 0:
         print(out.stdout.decode()[-3000:])
         sys.exit(1)
+    if asm_out:
+        # (the listing tools/isa_count.py reads)
+        subprocess.run([jit._hipcc()] + [f for f in FLAGS if not f.startswith("-Rpass")] + ["-DCLIK_VALUE_KERNEL"] + flags +
+                       ["-S", "--cuda-device-only", src, "-o", asm_out[0]], check=True)
     for name, r in sorted(parse_resource_remarks(out.stdout.decode()).items()):
         short = name.split("(")[0][-70:]
         print("%-72s VGPR %3d AGPR %3d SGPR %3d scratch %4d occupancy %d" % (
