@@ -1270,8 +1270,8 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
                 delete h;
                 if (!dyn_rows)
                     return fail(CLIK_EUNSUPPORTED,
-                                "no QP kernel variant for %d variables x %d rows (device limit: 16 rows)",
-                                S.n_qp_vars, S.n_qp_rows);
+                                "no QP kernel variant for %d variables x %d rows (device limit: %d rows)",
+                                S.n_qp_vars, S.n_qp_rows, CLIK_MAX_QPROWS);
                 return fail(CLIK_EUNSUPPORTED, "QP needs more LDS than a CU has (input_var too large)");
             }
             h->variant = -1;

@@ -1516,11 +1516,12 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
         // (bit 63 of the poll budget: the instantiation that integrates the state itself, clik_pinv_resident_run_state)
         const unsigned long long budget = timeout_ticks & ~kResidentIntegrateBit;
         // Every block of the launch must be resident at once - a block that never starts can never count, and the
-        // ones that did would spin until the watchdog fires.  The bound comes from THIS instantiation's occupancy on
-        // THIS device (registers of the kernel as compiled, CUs of a possibly partitioned device), less one block: the
-        // ticket feeder must find room too (measured on the MI355X: the occupancy is two blocks per CU, and a launch of
-        // all 512 - 32768 instances - leaves no SIMD with registers for the feeder's wave: the resident waves then
-        // spin on tickets nobody can publish until the watchdog ends them).
+        // ones that did would spin until the watchdog fires - AND the ticket feeder must find a SIMD with room for its
+        // wave while they spin.  The bound: ONE block per CU of THIS device (its CU count: a partitioned device has
+        // fewer), provided this instantiation's occupancy allows a block at all.  Measured on the MI355X (round 4): the
+        // occupancy interface reports two blocks per CU, yet launches of 511 and of 512 blocks (32704 / 32768
+        // instances) both stall until the watchdog ends them - the second block of a CU takes the registers the
+        // feeder needs -, while 256 blocks (16384 instances) run.  Round 3's hard-coded 2 x 256 let those through.
         {
             static int max_blocks[2] = {-1, -1};
             const int which = (timeout_ticks & kResidentIntegrateBit) ? 1 : 0;
@@ -1534,7 +1535,7 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
                 if (oe == hipSuccess) oe = hipGetDevice(&dev);
                 if (oe == hipSuccess) oe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
                 if (oe != hipSuccess) return oe;
-                max_blocks[which] = per_cu * cus - 1;
+                max_blocks[which] = per_cu >= 1 ? cus : 0;
             }
             if ((long long)grid > (long long)max_blocks[which]) return hipErrorNotSupported;
         }

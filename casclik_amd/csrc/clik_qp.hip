@@ -98,14 +98,19 @@ __device__ __forceinline__ int qp_rows(const DevSkill* __restrict__ S, const Tic
     return row;
 }
 
-template <int N, int NC, bool EXACT>
+// GWS: the per-wave work area (state, rows, dual Hessian, bounds: qp_lds_slots doubles per lane) lies in GLOBAL memory
+// handed in by the launch (`gws`, one area per block) instead of LDS - the variants for QPs with more than 16 rows,
+// whose work area (up to 490 KB per wave at 42 x 32) no CU holds.  Same code, slower memory: such skills are served,
+// not refused (the reference puts no bound on the number of constraints, reactive_qp.py:191-246).
+template <int N, int NC, bool EXACT, bool GWS = false>
 __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
     const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
     const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ dx, double* __restrict__ slack_out,
-    int32_t* __restrict__ status_out)
+    int32_t* __restrict__ status_out, double* __restrict__ gws = nullptr, const int ny_slots = 0)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_shared[];
+    double* lds = GWS ? gws + (size_t)blockIdx.x * (size_t)qp_lds_slots<N, NC>(ny_slots) * WAVE : lds_shared;
     constexpr int NT = NC * (NC + 1) / 2;
     const int lane = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * WAVE;
@@ -237,13 +242,15 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
 
 // H diagonal, A, lbA, ubA exactly as the reference's H_func / A_func / Blb_func /
 // Bub_func return them (reactive_qp.py:283-298), for inspection and parity tests.
-template <int N, int NC>
+template <int N, int NC, bool GWS = false>
 __global__ __launch_bounds__(WAVE) void qp_data_kernel(
     const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
     const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ Hd, double* __restrict__ A, double* __restrict__ lbA, double* __restrict__ ubA)
+    double* __restrict__ Hd, double* __restrict__ A, double* __restrict__ lbA, double* __restrict__ ubA,
+    double* __restrict__ gws = nullptr, const int ny_slots = 0)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_shared[];
+    double* lds = GWS ? gws + (size_t)blockIdx.x * (size_t)qp_lds_slots<N, NC>(ny_slots) * WAVE : lds_shared;
     constexpr int NT = NC * (NC + 1) / 2;
     const int lane = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * WAVE;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(WAVE) void qp_data_kernel(
 
 // ---- host side -----------------------------------------------------------------------
 struct QpVariant {
-    int N, NC, exact;
+    int N, NC, exact;       // exact: 1 = sizes are the skill's own (no guards), 0 = guarded, 2 = guarded + work area in global memory
     hipError_t (*solve)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
                         const double*, const double*, double*, double*, double*, int32_t*, hipStream_t);
     hipError_t (*data)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
@@ -338,14 +345,52 @@ static hipError_t qp_data_launch(const DevSkill* dS, const WarmArgs& wa, const T
     return hipGetLastError();
 }
 
+// work area in global memory (stream-ordered allocation: no hidden synchronisation, re-entrant across streams)
+template <int N, int NC>
+static hipError_t qp_solve_launch_gws(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                                      const double* q, const double* x, const double* y, double* dq, double* dx,
+                                      double* slack, int32_t* status, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    const size_t bytes = (size_t)grid * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
+    double* ws = nullptr;
+    hipError_t e = hipMallocAsync((void**)&ws, bytes, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((qp_solve_kernel<N, NC, false, true>), dim3(grid), dim3(WAVE), 0, stream, dS, wa, tk, B, q, x, y, dq,
+                       dx, slack, status, ws, ny);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : f;
+}
+
+template <int N, int NC>
+static hipError_t qp_data_launch_gws(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
+                                     const double* q, const double* x, const double* y, double* Hd, double* A,
+                                     double* lb, double* ub, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    const size_t bytes = (size_t)grid * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
+    double* ws = nullptr;
+    hipError_t e = hipMallocAsync((void**)&ws, bytes, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((qp_data_kernel<N, NC, true>), dim3(grid), dim3(WAVE), 0, stream, dS, wa, tk, B, q, x, y, Hd, A, lb,
+                       ub, ws, ny);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : f;
+}
+
 // exact-size instantiations (no guards in the active-set loop) for the common
 // problem sizes, guarded ones for everything else up to 16 rows
 #define CLIK_QP_EXACT(N, NC) {N, NC, 1, &qp_solve_launch<N, NC, true>, &qp_data_launch<N, NC>}
 #define CLIK_QP_GUARD(N, NC) {N, NC, 0, &qp_solve_launch<N, NC, false>, &qp_data_launch<N, NC>}
+#define CLIK_QP_GLOBAL(N, NC) {N, NC, 2, &qp_solve_launch_gws<N, NC>, &qp_data_launch_gws<N, NC>}
 static const QpVariant kQpVariants[] = {
     CLIK_QP_EXACT(7, 13), CLIK_QP_EXACT(6, 12), CLIK_QP_EXACT(7, 10), CLIK_QP_EXACT(6, 9),
     CLIK_QP_GUARD(6, 8),  CLIK_QP_GUARD(6, 16), CLIK_QP_GUARD(7, 8),  CLIK_QP_GUARD(7, 16),
     CLIK_QP_GUARD(8, 8),  CLIK_QP_GUARD(8, 16),
+    // beyond 16 rows (up to CLIK_MAX_QPROWS) and / or more than eight states or rows per constraint
+    CLIK_QP_GLOBAL(8, 32), CLIK_QP_GLOBAL(12, 16), CLIK_QP_GLOBAL(12, 32),
 };
 constexpr int kNumQpVariants = (int)(sizeof(kQpVariants) / sizeof(kQpVariants[0]));
 
@@ -358,9 +403,12 @@ int qp_pick_variant(int n, int nv, int nc)
         if (kQpVariants[k].exact && kQpVariants[k].N == n && kQpVariants[k].NC == nc) return k;
     for (int k = 0; k < kNumQpVariants; ++k) {
         const QpVariant& v = kQpVariants[k];
-        if (v.exact || v.N < n || v.NC < nc) continue;
+        if (v.exact == 1 || v.N < n || v.NC < nc) continue;
         // task_eval works on N x N blocks: a constraint may have up to N rows
-        if (best < 0 || v.N * 100 + v.NC < kQpVariants[best].N * 100 + kQpVariants[best].NC) best = k;
+        // (the variants with their work area in LDS first, the global-memory ones when nothing else fits)
+        const int cost = (v.exact == 2 ? 100000 : 0) + v.N * 100 + v.NC;
+        const int best_cost = best < 0 ? 0 : (kQpVariants[best].exact == 2 ? 100000 : 0) + kQpVariants[best].N * 100 + kQpVariants[best].NC;
+        if (best < 0 || cost < best_cost) best = k;
     }
     return best;
 }
@@ -371,6 +419,7 @@ size_t qp_variant_lds(int k, int ny)
 {
     if (k < 0 || k >= kNumQpVariants) return 0;
     const QpVariant& v = kQpVariants[k];
+    if (v.exact == 2) return 0;          // (work area in global memory)
     const int wk = v.NC * v.N > 6 * v.N ? v.NC * v.N : 6 * v.N;
     return (size_t)(v.N + ny + wk + v.NC * (v.NC + 1) / 2 + 3 * v.NC) * WAVE * sizeof(double);
 }

@@ -975,9 +975,14 @@ __device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2],
 // Symmetric sweep of index K of the packed tableau S (lower triangle) in the lanes where m = 1.0 (m = 0.0 leaves a
 // lane's tableau untouched): with F the set of swept indices,  S_FF = -(P_FF)^-1,  S_HF = P_HF (P_FF)^-1,  S_HH = the
 // Schur complement of P_FF.  sgn = +1 sweeps K in (the state becomes free), -1 sweeps it out again (it is held): one
-// reciprocal and a rank-one update either way - what a working-set change costs qp_box_pas instead of a refactorisation.
+// reciprocal and a rank-one update per working-set change instead of a masked refactorisation per pass - VERDICT r3
+// item 3(a).  AN EXPERIMENT, off by default (-DCLIK_QP_BOX_SWEEP=1): a lane-uniform instruction stream has to run the
+// sweep of state k for the whole wave whenever ANY lane changes state k, so a pass executes 1-3 masked sweeps (45
+// instructions each) next to the 56-instruction product with the tableau, the seven start sweeps (315) come on top, and
+// the passes are not the shorter for it: measured 13.5 against 11.3 us per tick at 16384 instances, 29.4 against 24.4
+// at 131072 (profiles/r4_qp_sweep.txt; numpy model of the same iteration: tools/qp_sweep_proto.py).
 #ifndef CLIK_QP_BOX_SWEEP
-#define CLIK_QP_BOX_SWEEP 1
+#define CLIK_QP_BOX_SWEEP 0
 #endif
 template <int N, int K>
 __device__ __forceinline__ void qp_sym_sweep(double (&S)[N * (N + 1) / 2], const double m, const double sgn)

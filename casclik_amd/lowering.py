@@ -30,10 +30,10 @@ from .urdf import JOINT_FIXED
 
 MAX_DOF = 10
 MAX_JOINTS = 12
-MAX_TASKS = 16
+MAX_TASKS = 24
 MAX_M = 12              # > DYN_MAX_M rows only in the shape-specialised kernels
 DYN_MAX_M = 8
-MAX_ROWS = 96
+MAX_ROWS = 128
 MAX_SETS = 8
 MAX_TSLOTS = 32
 MAX_YTERMS = 4

@@ -44,17 +44,17 @@
 extern "C" {
 #endif
 
-#define CLIK_ABI_VERSION 4
+#define CLIK_ABI_VERSION 5
 
 #define CLIK_MAX_DOF     10   /* n_state = n_robot_var + n_virtual_var (a 7-DoF arm with two or three virtual
                                  variables; more than 8 only in the shape-specialised kernels)                */
 #define CLIK_MAX_JOINTS  12   /* chain joints, fixed ones included                */
-#define CLIK_MAX_TASKS   16   /* constraints per skill                            */
+#define CLIK_MAX_TASKS   24   /* constraints per skill (more than 8: the built-in dynamic-shape kernels) */
 #define CLIK_MAX_M       12   /* rows of one constraint expression; more than
                                  CLIK_DYN_MAX_M only in the shape-specialised kernels
                                  (attached or AOT): the built-in kernels refuse them  */
 #define CLIK_DYN_MAX_M    8
-#define CLIK_MAX_ROWS    96   /* affine rows over all constraints                 */
+#define CLIK_MAX_ROWS   128   /* affine rows over all constraints                 */
 #define CLIK_MAX_SETS     8   /* SetConstraints -> 2^8 modes (more than 6 sets: the
                                  built-in mode-scan kernels; a 7-DoF arm with one
                                  1-D set per joint has 128)                        */

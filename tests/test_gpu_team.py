@@ -432,11 +432,10 @@ def test_resident_ticks_with_input_rows_longer_than_eight(iiwa_fk):
 
 
 def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
-    """every block of a resident launch must be running for a tick to complete: the launch wrapper bounds the grid by
-    the instantiated kernel's occupancy on this device, less one block for the ticket feeder.  On the MI355X that is 511
-    blocks: 32768 instances (512 blocks) - which the hard-coded bound of round 3 let through, to spin until the watchdog
-    because the feeder found no free registers - is refused with CLIK_EUNSUPPORTED.  Whatever is accepted must come out
-    equal to launched ticks."""
+    """every block of a resident launch must be running for a tick to complete, with room left for the ticket feeder: the
+    launch wrapper admits one block per CU of this device.  On the MI355X: 16384 instances (256 blocks) run; 16448,
+    32768 - which the hard-coded bound of round 3 let through, to spin until the watchdog - and anything larger are
+    refused with CLIK_EUNSUPPORTED at once."""
     import torch
     spec = skills.stack_skill(iiwa_fk)
     ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
@@ -445,26 +444,21 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
     if "team4v" not in ctrl.kernel_variant(1000):
         pytest.skip("no value-specialised team kernel attached (hipcc missing)")
     dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
-    accepted = []
-    for B in (16384, 32704, 32768, 1 << 22):
-        if B > 40000:
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    fits = cus * 64
+    for B in (fits, fits + 64, 2 * fits, 1 << 22):
+        if B > fits:
             Qr = torch.zeros((1, B, 7), dtype=torch.float64, device="cuda")
             with pytest.raises(NotImplementedError) as err:
                 ctrl.resident_start(Qr, Qr, 1, timeout_s=1.0, ring_depth=1)
             assert "resident" in str(err.value)
             continue
         batches = [skills.synthetic_inputs(iiwa_fk, B, seed=90 + k, distribution="mixed") for k in range(D)]
-        # (a launched tick beyond 16384 instances runs the one-lane kernel: equal up to rounding, modes identical)
         want = [ctrl.solve_batch(0.0, dev(q), input_var=dev(y)) for q, y in batches]
         Qr = torch.stack([dev(q) for q, _ in batches]).contiguous()
         Yr = torch.stack([dev(y) for _, y in batches]).contiguous()
         torch.cuda.synchronize()
-        try:
-            run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
-        except NotImplementedError as exc:
-            assert "resident" in str(exc) and B > 16384
-            assert B >= 32768, (B, "refused although it fits")
-            continue
+        run = ctrl.resident_start(Qr, Yr, NT, timeout_s=20.0, ring_depth=D)
         feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=20.0)
         run["stream"].synchronize()
         feeder.synchronize()
@@ -472,8 +466,6 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
         assert int(tk[32]) == 0 and int(run["done"].min()) == NT, (B, tk[[0, 32, 49]].tolist())
         for s in range(D):
             assert torch.allclose(run["out"][s], want[s][0], rtol=0, atol=1e-9) and torch.equal(run["mode"][s], want[s][2]), (B, s)
-        accepted.append(B)
-    assert 16384 in accepted
 
 
 def test_worst_case_of_the_team_sweeps_is_held_to_its_own_bound():
