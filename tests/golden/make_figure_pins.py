@@ -395,6 +395,8 @@ def main():
     # ur5_moe2016_example2.ipynb cells 13-27 (html-embedded figures; interval pins, layout calibration)
     import moe_figure_pins
     moe_figure_pins.collect(out)
+    # ur5_dual_quaternion_comparison_of_controllers.ipynb cells 19, 20, 41, 42 (html-embedded, log axes)
+    moe_figure_pins.collect_dq(out)
     path = os.path.join(HERE, "notebook_figures.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays,", os.path.getsize(path), "bytes")

@@ -532,7 +532,91 @@ def collect(out):
     mode_figures(out)
 
 
+# ---- ur5_dual_quaternion_comparison_of_controllers.ipynb: error norms on LOG axes (cells 19, 20, 41, 42) ------------------
+DQC = "ur5_dual_quaternion_comparison_of_controllers.ipynb"
+DQ_T_END = 45.0                      # cell 17 / 39: 4500 ticks of 0.01 s
+
+
+def major_tick_rows(rgb, box, min_len=4):
+    """pixel rows of the MAJOR tick marks left of the left spine (3.5 pt = 5 px long; the minor ticks of a log axis are
+    2 pt = 3 px)"""
+    top, bot, left, right = box
+    dark = rgb.max(axis=2) < 200.0
+    rows = []
+    for y in range(top - 2, bot + 3):
+        c, run = left - 1, 0
+        while c >= 0 and dark[y, c]:
+            run += 1
+            c -= 1
+        if run >= min_len:
+            rows.append(float(y))
+    return rows
+
+
+def log_error_figure(out, name, cell, top_decade, per_tick, hi_known=None):
+    """the error norm of the four controllers (drawn in the order qp, pinv, mpc, nlp - cell 17's printed order) on a log
+    axis: values are stored as log10(error).  The view limits are the data's range in log10 widened by 5 %; both ends are
+    OUTPUTS of the runs (the start value, where it is the largest, is an input and is cross-checked), so they are fitted to
+    the rows of the major tick marks - whole decades, the topmost one 10^`top_decade`, `per_tick` decades apart (both read
+    off the stored figure's labels by eye) - under the rule that a tick at coordinate y sits in pixel row floor(y + 0.5)."""
+    rgb = html_png(DQC, cell)
+    _, edges = layout_calibration(rgb.shape, LARGE, margins(0.0, DQ_T_END), (0.0, 1.0))
+    box0 = tuple(int(round(e)) for e in edges)
+    sp = spines(rgb)
+    ticks = np.array(major_tick_rows(rgb, (box0[0], box0[1], sp[2], box0[3])))
+    assert len(ticks) >= 2 and np.abs(np.diff(ticks) - np.diff(ticks).mean()).max() <= 1.0, (name, "major ticks", ticks)
+    labels = top_decade - per_tick * np.arange(len(ticks))
+    # rows are affine in the label: least squares for (row of decade 0, rows per decade), then the view limits
+    A = np.stack([np.ones(len(ticks)), -labels], axis=1)
+    (r0, rpd), _, _, _ = np.linalg.lstsq(A, ticks, rcond=None)
+    y_top, y_bot = edges[0], edges[1]
+    v_hi, v_lo = (r0 - y_top) / rpd, (r0 - y_bot) / rpd          # log10 at the axes' top / bottom edge
+    lo, hi = v_lo + (v_hi - v_lo) * 0.05 / 1.1, v_hi - (v_hi - v_lo) * 0.05 / 1.1
+    miss = np.abs(A.dot([r0, rpd]) - ticks).max()
+    if hi_known is not None:
+        miss = max(miss, abs(hi - hi_known) * rpd)
+    best = (miss, per_tick, lo, hi, rpd)
+    miss, per_tick, lo, hi, rpd = best
+    assert miss <= 0.75, (name, "tick rows / known top value", miss)
+    cal, edges = layout_calibration(rgb.shape, LARGE, margins(0.0, DQ_T_END), margins(lo, hi))
+    print("%-22s log axis: %d major ticks, %d decade(s) apart, data range 1e%.3f ... 1e%.3f (fit within %.2f px%s); pixel = "
+          "%.4f s x %.4f decades" % (name, len(ticks), per_tick, lo, hi, miss,
+                                    "" if hi_known is None else ", known top 1e%.4f" % hi_known, cal.pixel[0], cal.pixel[1]))
+    legend = legend_frame(rgb, box0)
+    box = check_layout(name, rgb, cal, edges, skip=[legend])
+    skip_boxes = [legend]
+    n_u = put(out, name + "_union", hidden_centre_intervals(column_bands(saturated(rgb), box, (), skip_boxes), cal, LINE_W), cal,
+              (0.0, DQ_T_END))
+    for curve, colour in (("qp", C0), ("pinv", C1)):
+        n_c = put(out, name + "_" + curve, visible_centre_intervals(column_bands(colour_mask(rgb, colour), box, (), skip_boxes),
+                                                                   cal, LINE_W), cal, (0.0, DQ_T_END))
+        print("%-22s %s visible in %d of %d columns" % (name, curve, n_c, n_u))
+    out[name + "_range"] = np.array([lo, hi])
+    if name == "dqc_cart_dist":
+        # the pinv run CHATTERS from t = 8 s on (its target is out of reach): the stored curve is a band.  Its extent -
+        # the values the curve's centre sweeps, half a line width inside the band's pixels - over the columns left of
+        # the legend:
+        m = colour_mask(rgb, C1)
+        tops, bots = [], []
+        for c in range(int(cal.x(12.0)), min(int(cal.x(38.0)), legend[2] - 2)):
+            rows = np.nonzero(m[box[0]:box[1], c])[0] + box[0]
+            tops.append(rows.min())
+            bots.append(rows.max() + 1)
+        assert max(tops) - min(tops) <= 1 and max(bots) - min(bots) <= 1, (name, "band not flat", set(tops), set(bots))
+        out[name + "_pinv_band"] = np.array([cal.v(np.median(bots) - 0.5 * LINE_W), cal.v(np.median(tops) + 0.5 * LINE_W)])
+        print("%-22s pinv chatter band (centre of the line): %.5f ... %.5f" % (name, *(10.0 ** out[name + "_pinv_band"])))
+
+
+def collect_dq(out):
+    e0 = {"cart": np.log10(1.0192018)}          # |p_tool0| at UR5_home, the KAT the notebook prints (cell 7)
+    log_error_figure(out, "dqc_cart_dist", 19, 0, 1, hi_known=e0["cart"])
+    log_error_figure(out, "dqc_quat_dist", 20, 0, 2)
+    log_error_figure(out, "dqc_Q_dist1", 41, -1, 2)
+    log_error_figure(out, "dqc_Q_dist2", 42, 0, 2)
+
+
 if __name__ == "__main__":
     arrays = {}
     collect(arrays)
+    collect_dq(arrays)
     print(len(arrays), "arrays")

@@ -164,3 +164,78 @@ def moe_skill(fk, situation):
 
 def moe_options(case):
     return {"multidim_sets": True} if case == "pinv_multidim" else None            # cell 11
+
+
+# ---- ur5_dual_quaternion_comparison_of_controllers.ipynb: error norms on log axes (cells 10-17, 33-39; figures 19, 20, 41, 42)
+DQC_CASES = [(which, kind) for which in ("cart_dist", "quat_dist", "Q_dist1", "Q_dist2") for kind in ("pinv", "qp")]
+
+
+def dqc_skill(fk, which, kind):
+    """cells 10-14 / 33-38: the constraint `which` (gain 1, soft; cart_dist / quat_dist with priority 300) in front of six
+    1-D joint-limit sets (pinv) or beside the multidimensional limits and the joint-speed limits (QP).
+    -> (spec, error norm as a Function of (t, q))"""
+    from casclik_amd import numpy_geom, casadi_geom
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    Q_fk = fk["dual_quaternion_fk"]
+    q1, q2 = cs.SX.sym("q1", 8), cs.SX.sym("q2", 8)
+    dual_quaternion_product = cs.Function("dualquatprod", [q1, q2], [casadi_geom.dual_quaternion_product(q1, q2)])
+    dual_quaternion_conj = cs.Function("dualquatconj", [q1], [casadi_geom.dual_quaternion_conj(q1)])
+    p1, p2 = cs.SX.sym("p1", 4), cs.SX.sym("p2", 4)
+    quaternion_product = cs.Function("quatprod", [p1, p2], [casadi_geom.quaternion_product(p1, p2)])
+    quaternion_conj = cs.Function("quatconj", [p1], [casadi_geom.quaternion_conj(p1)])
+    Q_des = numpy_geom.dual_quaternion_revolute([0.2, 0.2, 0.75], [0.0, 0.0, 0.0], [1, 0, 0], 0.0)            # cell 33
+    Q_id = numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0)
+    Q_r, Q_d = Q_fk(q)[:4], Q_fk(q)[4:8]
+    kw = {}
+    if which == "cart_dist":
+        expr, kw = 2 * quaternion_product(Q_d, quaternion_conj(Q_r))[:3], dict(priority=300)                  # cell 12
+    elif which == "quat_dist":
+        expr, kw = Q_d[:3] - 0.5 * quaternion_product(np.array([0.5, 0.5, 0.5, 0.0]), Q_r)[:3], dict(priority=300)
+    elif which == "Q_dist1":
+        expr = dual_quaternion_product(Q_fk(q), dual_quaternion_conj(Q_des)) - Q_id                           # cell 34
+    else:
+        expr = dual_quaternion_product(dual_quaternion_conj(Q_des - Q_fk(q)), Q_des)
+    task = cc.EqualityConstraint(label=which, expression=expr, gain=1.0, constraint_type="soft", **kw)
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    max_speed = np.pi / 5
+    if kind == "pinv":
+        cons = [task] + [cc.SetConstraint(label="limit_q_%d" % i, expression=q[i], set_min=lo[i], set_max=hi[i], priority=i)
+                         for i in range(6)]
+    else:
+        cons = [task, cc.SetConstraint(label="Joint_Limits", expression=q, set_min=lo, set_max=hi),
+                cc.VelocitySetConstraint(label="Joint_speed_limits", expression=q, set_min=-np.full(6, max_speed),
+                                         set_max=np.full(6, max_speed))]
+    spec = cc.SkillSpecification(label=which, time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons)
+    return spec, cs.Function("e", [t, q], [cs.norm_2(expr)])
+
+
+def simulate_dqc(eval_norm, solve, n_ticks=4500):
+    """cells 17 / 39: 4500 ticks of 0.01 s from UR5_home, speeds saturated at pi / 5; e_sim[i + 1] is the error norm at
+    q_sim[i + 1].  Returns t_sim, log10(e_sim)."""
+    dt, max_speed = 0.01, np.pi / 5
+    t_sim = np.array([dt * i for i in range(n_ticks + 1)])
+    q = UR5_HOME.copy()
+    e_sim = np.zeros(n_ticks + 1)
+    e_sim[0] = float(np.asarray(eval_norm(0.0, q).toarray()).ravel()[0])
+    for i in range(n_ticks):
+        q = q + np.clip(solve(t_sim[i], q), -max_speed, max_speed) * dt
+        e_sim[i + 1] = float(np.asarray(eval_norm(t_sim[i], q).toarray()).ravel()[0])
+    return t_sim, np.log10(np.maximum(e_sim, 1e-300))
+
+
+DQC_FLOOR = -12.5      # log10: below, the stored curves are the rounding floor of CasADi's arithmetic, not the controllers
+
+
+def dqc_pins(which, kind, t_sim, log_e):
+    """[(pin, worst deviation in pixels, columns, t)]: the controller's own colour where it is visible, and the band of
+    coloured pixels it otherwise hides under; columns whose stored values lie below 1e-12.5 are left out"""
+    out = []
+    for key in ("dqc_%s_%s" % (which, kind), "dqc_%s_union" % which):
+        keep = (FIGS[key + "_lo"] >= DQC_FLOOR)
+        ft = FIGS[key + "_t"]
+        ok_cols = np.array([tk for tk in np.unique(ft) if keep[ft == tk].all()])
+        if len(ok_cols) == 0:
+            continue
+        # columns are contiguous in t from the start until the curves sink below the floor (Q_dist2's pinv never does)
+        out.append((key,) + interval_deviation(key, t_sim, log_e, within=(0.0, float(ok_cols.max()))))
+    return out

@@ -288,3 +288,41 @@ def test_what_the_moe_2016_figures_resolve():
     assert worst("pinv_singular", options={"feedforward": False}) > 20.0
     assert worst("pinv_multidim", wrong="no_D1") < PIXELS and worst("pinv_singular", wrong="no_D1") < PIXELS
     assert worst("pinv_singular", options={"damping_factor": 1e-3}) < PIXELS
+
+
+# ---- ur5_dual_quaternion_comparison_of_controllers.ipynb (html-embedded figures on log axes, cells 19, 20, 41, 42) --------
+# Both controllers on four task errors written with dual quaternions (generated constraint code on the device), 4500 ticks
+# from UR5_home, the error norm over thirteen decades: the decay RATE of each controller (the QP's is lower by its weight
+# shifter mu, reactive_qp.py:44), the pinv's chatter on the cart_dist task's unreachable target, its standstill in the
+# home singularity on Q_dist2 (default damping 1e-7).  One pixel = 0.1 s x 0.043 decades (cart_dist: 0.005).
+def dqc_oracle_run(which, kind):
+    from casclik_amd import skills
+    fk = skills.ur5()
+    spec, error_norm = cf.dqc_skill(fk, which, kind)
+    if kind == "pinv":
+        def solve(t, q):
+            return clik_oracle.pinv_solve_batch(spec, None, float(t), q[None, :])[0][0]
+    else:
+        def solve(t, q):
+            dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])
+            assert status[0] == 0
+            return dq[0]
+    return cf.simulate_dqc(error_norm, solve)
+
+
+@pytest.mark.parametrize("which,kind", [("quat_dist", "pinv"), ("quat_dist", "qp"), ("cart_dist", "pinv")])
+def test_oracle_reproduces_the_dual_quaternion_comparison_figures(which, kind):
+    """(three of the eight runs here - 13 s each through the numpy oracle; all eight through the HIP controllers in
+    tests/test_gpu_figure_pins.py, held to the same pins AND to the oracle along the way)"""
+    t_sim, log_e = dqc_oracle_run(which, kind)
+    pins = cf.dqc_pins(which, kind, t_sim, log_e)
+    assert len(pins) == 2
+    for key, worst, n, where in pins:
+        assert n > 50 and worst < PIXELS, (key, worst, n, where)
+    if which == "cart_dist":
+        # the target (the base frame's origin) is out of reach: the error norm bottoms out and the pinv controller
+        # chatters above it with the amplitude of its stored curve (a band 0.0343 ... 0.0374 from t = 8 s on)
+        band, px = cf.FIGS["dqc_cart_dist_pinv_band"], cf.FIGS["dqc_cart_dist_pinv_pixel"][1]
+        tail = log_e[t_sim > 12.0]
+        assert abs(tail.min() - band[0]) < 1.5 * px and abs(tail.max() - band[1]) < 1.5 * px, (10.0 ** tail.min(), 10.0 ** tail.max(),
+                                                                                             10.0 ** band)

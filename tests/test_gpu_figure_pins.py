@@ -8,6 +8,7 @@ import pytest
 import casclik_amd as cc
 import notebook_figures as cf
 from test_figure_pins import PIXELS, curves_of, oracle_solver
+from tolerances import pinv_close, qp_close
 
 pytestmark = pytest.mark.gpu
 
@@ -217,3 +218,42 @@ def test_on_device_rollouts_reproduce_the_moe_2016_figures(case):
 def figure_max_speed():
     import figure_skills
     return figure_skills.MOE_MAX_SPEED
+
+
+@pytest.mark.parametrize("which,kind", cf.DQC_CASES)
+def test_hip_controllers_reproduce_the_dual_quaternion_comparison_figures(ur5_fk, which, kind):
+    """ur5_dual_quaternion_comparison_of_controllers.ipynb cells 17 / 39 with the notebook's own calls, all eight runs
+    (four dual-quaternion task errors x both controllers; the constraints run as generated device code): the error norm
+    over thirteen decades against the stored log-axis figures, and against the oracle at every 150th state of the run"""
+    from oracle import clik_oracle
+    spec, error_norm = cf.dqc_skill(ur5_fk, which, kind)
+    ctrl = cc.PseudoInverseController(skill_spec=spec) if kind == "pinv" else cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    ctrl.setup_initial_problem_solver()
+    state = {"slack": ctrl.solve_initial_problem(0, cf.UR5_HOME)[-1], "i": 0, "worst": 0.0}
+
+    def solve(t, q):
+        res = ctrl.solve(t, q, warmstart_slack_var=state["slack"])
+        if res[-1] is not None:
+            state["slack"] = res[-1].toarray()[:, 0]
+        dq = res[0].toarray()[:, 0]
+        if state["i"] % 150 == 0:
+            if kind == "pinv":
+                ref = clik_oracle.pinv_solve_batch(spec, None, float(t), q[None, :])[0]
+                assert pinv_close(dq[None, :], ref), (which, state["i"])
+            else:
+                ref = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])[0]
+                assert qp_close(dq[None, :], ref), (which, state["i"])
+        state["i"] += 1
+        return dq
+    t_sim, log_e = cf.simulate_dqc(error_norm, solve)
+    pins = cf.dqc_pins(which, kind, t_sim, log_e)
+    assert len(pins) == 2
+    for key, worst, n, where in pins:
+        assert n > 50 and worst < PIXELS, (key, worst, n, where)
+    if (which, kind) == ("cart_dist", "pinv"):
+        band, px = cf.FIGS["dqc_cart_dist_pinv_band"], cf.FIGS["dqc_cart_dist_pinv_pixel"][1]
+        tail = log_e[t_sim > 12.0]          # (the chatter on the unreachable target: the stored band's amplitude)
+        assert abs(tail.min() - band[0]) < 1.5 * px and abs(tail.max() - band[1]) < 1.5 * px
+    print("%s %s through the HIP solve(): %s" % (which, kind, [(k, round(w, 2)) for k, w, _, _ in pins]))
