@@ -65,7 +65,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TF = 78.6       # half of the 157.3 TF fp32 vector peak
-PROFILE_FILES = ("r3_counters.json", "r2_counters.json", "r1_traffic.json")     # newest first
+PROFILE_FILES = ("r4_counters.json", "r3_counters.json", "r2_counters.json", "r1_traffic.json")     # newest first
 BODY_FILES = ("r3_body_time.json",)
 METRIC = "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384"
 
@@ -257,12 +257,15 @@ def cpu_baseline(workload, spec, opts, Q, Y, seconds):
     return out
 
 
-def profiled(workload, dist_name, batch, kernel):
+def profiled(workload, dist_name, batch, kernel, hot=False):
     """Per-launch PMC figures of this configuration recorded under profiles/ (they cannot be collected
     from inside this process: separate rocprofv3 --pmc passes, tools/rocprof_counters.py).  Returns
     (entry, source) or (None, None): a configuration that was not profiled gets no traffic figure."""
     keys = ["%s_%s_B%d_%s" % (workload, dist_name, batch, kernel)]
-    if str(kernel).endswith(("/lane", "/mp2")) or "/" not in str(kernel):
+    if hot:
+        # a hot-started tick runs fewer passes than a cold one: only its OWN counter passes count (none: null)
+        keys = [keys[0] + "_hot"]
+    elif str(kernel).endswith(("/lane", "/mp2")) or "/" not in str(kernel):
         keys.append("%s_%s_B%d" % (workload, dist_name, batch))       # round-1 entries (recorded before variants had names)
     for fn in PROFILE_FILES:
         try:
@@ -493,7 +496,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         kernel = variant(B)
     if TPL == 1:
         achieved = alg_bytes / (tick_us * 1e-6) / 1e9
-        prof, prof_src = profiled(workload, dist_name, B, kernel)
+        prof, prof_src = profiled(workload, dist_name, B, kernel, hot=bool(qp_hot))
         body, body_src = body_time(workload, dist_name, B, kernel)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
