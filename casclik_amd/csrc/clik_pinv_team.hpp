@@ -124,11 +124,35 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
                 for (int j = 0; j < N; ++j) tc.J[i][j] = z[(i + j) % N] * css[j];
             }
         } else {
+#ifdef CLIK_TEAM_FRONT_ONCE
+        // EXPERIMENT: FK and the task rows evaluated by lane 0 of the quad only and handed to the
+        // other three by DPP broadcast, instead of all four lanes repeating them.  The masked lanes still occupy the
+        // SIMD while lane 0 works (one instruction stream per wave), so nothing is saved and the broadcast (two moves
+        // per double) comes on top - built to be MEASURED, profiles/r4_team_variants.md.
+#pragma unroll
+        for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
+            tc.e[i] = 0.0;
+            tc.Jt[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) tc.J[i][j] = 0.0;
+        }
+        if (r == 0) {
+#endif
         if constexpr (SD.uses_fk != 0) {
             forward_kinematics_sc<SD>(&Sfk, z, sns, css, K);
             if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(&Sfk, ysl, inst, K);
         }
         cache_task<SD, 0>(&Sfk, tk, K, z, ysl, inst, tc);
+#ifdef CLIK_TEAM_FRONT_ONCE
+        }
+#pragma unroll
+        for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
+            tc.e[i] = quad_perm_f64<0x00>(tc.e[i]);
+            tc.Jt[i] = quad_perm_f64<0x00>(tc.Jt[i]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) tc.J[i][j] = quad_perm_f64<0x00>(tc.J[i][j]);
+        }
+#endif
         }
     }
     

@@ -19,7 +19,9 @@ sys.path.insert(0, ROOT)
 import numpy as np          # noqa: E402
 import torch                # noqa: E402
 
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+LIGHT = "--light" in sys.argv       # -DCLIK_BODY_STAMPS=2: block 0 stamps the start, every eighth block the end (see the macro)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+S = int(args[0]) if args else 1000
 G = 64
 OUT = {}
 
@@ -74,7 +76,7 @@ def measure(name, workload, B, lanes, key_kernel):
     if kernel != key_kernel:
         print("(%s: the library serves this configuration with %s, not %s)" % (name, kernel, key_kernel))
     t_plain = tick_time_us(plain.bind_batch(Qd, input_var=Yd))
-    os.environ["CLIK_JIT_DEFINES"] = "-DCLIK_BODY_STAMPS"
+    os.environ["CLIK_JIT_DEFINES"] = "-DCLIK_BODY_STAMPS=2" if LIGHT else "-DCLIK_BODY_STAMPS"
     ctrl = make()
     lib = (jit.attach_qp_values if workload == "qp" else jit.attach_values).last_library
     tick = ctrl.bind_batch(Qd, input_var=Yd)
@@ -100,6 +102,13 @@ def measure(name, workload, B, lanes, key_kernel):
         torch.cuda.synchronize()
         assert lib.clik_jit_read_body(buf, 2 * waves) == 0
         st = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(-1, 2)
+        if LIGHT:
+            starts, ends = st[:, 0][st[:, 0] > 0], st[:, 1][st[:, 1] > 0]
+            body.append((ends.max() - starts.min()) * 0.01)
+            spread_start.append((starts.max() - starts.min()) * 0.01)
+            both = (st[:, 0] > 0) & (st[:, 1] > 0)
+            per_wave.append(np.median((st[:, 1] - st[:, 0])[both]) * 0.01 if both.any() else float("nan"))
+            continue
         body.append((st[:, 1].max() - st[:, 0].min()) * 0.01)             # 100 MHz ticks -> us
         spread_start.append((st[:, 0].max() - st[:, 0].min()) * 0.01)
         per_wave.append(np.median(st[:, 1] - st[:, 0]) * 0.01)
@@ -113,7 +122,8 @@ def measure(name, workload, B, lanes, key_kernel):
            "boundary_us": t_stamped - float(np.median(body)),
            "method": "s_memrealtime (100 MHz, 10 ns) per wave at entry and after s_waitcnt vmcnt(0) at exit; body = "
                      "max(end) - min(start) over the waves of the last launch of a %d-tick graph; tick_us = HIP events "
-                     "around graph replays / ticks; boundary = tick (stamped build) - body" % G}
+                     "around graph replays / ticks; boundary = tick (stamped build) - body" % G
+                     + ("; LIGHT stamps: block 0 stamps the start, every eighth block and the last the end" if LIGHT else "")}
     OUT["%s_mixed_B%d_%s" % (workload, B, kernel)] = ent
     print("%-34s body %.2f us (p10 %.2f, p90 %.2f)  wave lifetime %.2f  start spread %.2f   tick stamped %.3f / shipped "
           "%.3f us -> boundary %.2f us" % (name, ent["body_us_median"], ent["body_us_p10"], ent["body_us_p90"],
@@ -126,10 +136,11 @@ measure("config 3, 16384, lanev", "stack", 16384, 1, "kStackIiwa/lanev")
 measure("config 3, 131072, lanev", "stack", 131072, 0, "kStackIiwa/lanev")
 measure("config 2, 16384, lanev", "pose", 16384, 0, "kPose6Iiwa/lanev")
 measure("config 4, 16384, qp box values", "qp", 16384, 0, "qp_static_kQpPoseIiwa/v")
-os.makedirs(os.path.join(ROOT, "gpurun_out", "r3body"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r3body", "r3_body_time.json"), "w") as f:
+TAG = "r4_body_time_light" if LIGHT else "r4_body_time"
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r4body"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "r4body", TAG + ".json"), "w") as f:
     json.dump(OUT, f, indent=1)
-with open(os.path.join(ROOT, "gpurun_out", "r3body", "r3_body_time.csv"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", "r4body", TAG + ".csv"), "w") as f:
     f.write("key,kernel,batch,waves,samples,body_us_median,body_us_p10,body_us_p90,wave_lifetime_us_median,"
             "tick_us_stamped_build,tick_us_shipped_build,boundary_us\n")
     for k, e in OUT.items():
