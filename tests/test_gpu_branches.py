@@ -452,8 +452,14 @@ def test_nine_row_three_point_pose_error(ur5_fk, monkeypatch):
     monkeypatch.setenv("CLIK_JIT", "0")
     with pytest.raises(NotImplementedError, match="more rows than the built-in kernels"):
         cc.PseudoInverseController(skill_spec=spec).setup_problem_functions()
-    with pytest.raises(NotImplementedError, match="exceeds the built-in kernel"):
-        cc.ReactiveQPController(skill_spec=qspec).setup_problem_functions()
+    # ... while the QP is served (round 4: by the dynamic kernel twelve rows wide with its work area in global memory -
+    # slower, not refused) and gives the same minimisers
+    slow = cc.ReactiveQPController(skill_spec=qspec)
+    slow.setup_problem_functions()
+    slow.setup_solver()
+    assert slow.kernel_name == "dynamic"
+    sdq, _, ssl, sst = slow.solve_batch(0.0, Q)
+    assert np.array_equal(sst, rst) and _rel(sdq[ok], rdq[ok]).max() < 1e-8 and _rel(ssl[ok], rsl[ok]).max() < 1e-8
 
 
 def test_rollout_with_virtual_variable_matches_the_host_loop(ur5_fk, monkeypatch):

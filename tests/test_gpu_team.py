@@ -448,9 +448,9 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
     fits = cus * 64
     for B in (fits, fits + 64, 2 * fits, 1 << 22):
         if B > fits:
-            Qr = torch.zeros((1, B, 7), dtype=torch.float64, device="cuda")
+            Qr = torch.zeros((B, 7), dtype=torch.float64, device="cuda")
             with pytest.raises(NotImplementedError) as err:
-                ctrl.resident_start(Qr, Qr, 1, timeout_s=1.0, ring_depth=1)
+                ctrl.resident_start(Qr, Qr, 1, timeout_s=1.0)
             assert "resident" in str(err.value)
             continue
         batches = [skills.synthetic_inputs(iiwa_fk, B, seed=90 + k, distribution="mixed") for k in range(D)]

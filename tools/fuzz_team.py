@@ -124,8 +124,8 @@ def main():
                 same = (modeb[:B] == mode) | tie
                 cmpb = (modeb[:B] == mode) & ~tie
                 lrel = np.abs(dqb[:B] - dq).max(axis=1) / (1.0 + np.abs(dq).max(axis=1))
-            lerr = float(lrel[cmpb].max()) if cmpb.any() else 0.0
-            lover = float((lrel / tol_b)[cmpb & (tol_b < ILL_POSED)].max()) if (cmpb & (tol_b < ILL_POSED)).any() else 0.0
+                lerr = float(lrel[cmpb].max()) if cmpb.any() else 0.0
+                lover = float((lrel / tol_b)[cmpb & (tol_b < ILL_POSED)].max()) if (cmpb & (tol_b < ILL_POSED)).any() else 0.0
                 qb1, dqb1, mb1 = ctrl.rollout_batch([tval], Qb, input_var=Yb, dt=1e-3)
                 if not big.endswith("/lanev") or (~same).any() or lover > 1.0 or not np.array_equal(mb1, modeb) \
                         or np.abs(dqb1 - dqb).max() > 1e-9 * (1.0 + np.abs(dqb).max()):
