@@ -57,6 +57,7 @@ hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const T
                           const double* q, const double* x, const double* y, double* Hd, double* A, double* lb,
                           double* ub, hipStream_t stream);
 int qp_pick_variant(int n, int nv, int nc);
+int qp_variant_width(int k);
 size_t qp_variant_lds(int k, int ny);
 int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
@@ -1489,7 +1490,11 @@ static int qp_solve_common(const clik_qp* h, int64_t B, const double* tterms, co
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
     if (!dq) return fail(CLIK_EINVAL, "dq must be a device pointer");
-    if (!h->jit_solve && h->static_k < 0 && skill_needs_static(h->host)) return extern_needs_kernel("clik_qp_solve_batch");
+    // (a constraint with more than eight rows is fine for the dynamic QP kernels twelve rows wide - the variant picked at
+    // create time covers the widest constraint; only generated constraint code needs an instantiated kernel)
+    if (!h->jit_solve && h->static_k < 0 &&
+        (skill_has_extern(h->host) || (skill_has_wide_task(h->host) && (h->variant < 0 || clik::qp_variant_width(h->variant) <= CLIK_DYN_MAX_M))))
+        return extern_needs_kernel("clik_qp_solve_batch");
     TickArgs tk;
     if (t_inst == nullptr) {
         rc = fill_tick(h->host, tterms, &tk);
@@ -1543,7 +1548,8 @@ extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tte
     if (rc) return rc;
     if (B == 0) return CLIK_OK;
     if (!Hdiag || !A || !lbA || !ubA) return fail(CLIK_EINVAL, "output pointers required");
-    if (skill_needs_static(h->host))
+    if (skill_has_extern(h->host) ||
+        (skill_has_wide_task(h->host) && (h->variant < 0 || clik::qp_variant_width(h->variant) <= CLIK_DYN_MAX_M)))
         return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: not available for skills that only the "
                                        "shape-specialised kernels serve (generated rows, > 8 rows per constraint)");
     if (h->variant < 0)
