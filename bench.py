@@ -654,7 +654,7 @@ def compact_entry(e):
     out = {"us": _r(e["ms_per_step"] * 1e3, 3), "G_per_s": _r(e["value"] / 1e9, 3), "kernel": e["config"].get("kernel"),
            "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic")}
     if r.get("traffic_source"):
-        out["pmc"] = r["traffic_source"].replace("profiles/", "")
+        out["pmc"] = r["traffic_source"].replace("profiles/", "").split("_k")[0].split("_qp_static")[0]   # file#case
     c = e.get("cpu_baseline")
     if c and "value" in c:
         out["cpu_M_per_s"] = _r(c["value"] / 1e6, 2)

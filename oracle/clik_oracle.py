@@ -389,15 +389,16 @@ def activation_map(n_sets):
 
 
 def dpinv(J, opt, cond=None):
-    """pseudo_inverse.py:92-105.  `cond` (a one-element list, optional) collects the largest 2-norm condition number of
-    the symmetric matrices handed to the linear solver: what the result is sensitive to (tests/tolerances.py)."""
+    """pseudo_inverse.py:92-105.  `cond` (a one-element list, optional) accumulates the 2-norm condition numbers of the
+    symmetric matrices handed to the linear solver: what the result is sensitive to (tests/tolerances.py; the rounding
+    errors of the solves of one mode add up)."""
     rows, cols = J.shape
     if opt["pinv_method"] == "standard":
         # cs.pinv (CasADi GenericMatrix::pinv): size2 >= size1 -> solve(J J^T, J)^T, else solve(J^T J, J^T);
         # a square J takes the first form
         inner = J.dot(J.T) if cols >= rows else J.T.dot(J)
         if cond is not None:
-            cond[0] = max(cond[0], _sym_cond(inner))
+            cond[0] += _sym_cond(inner)
         if cols >= rows:
             return np.linalg.solve(inner, J).T
         return np.linalg.solve(inner, J.T)
@@ -405,11 +406,11 @@ def dpinv(J, opt, cond=None):
     if cols >= rows:
         inner = J.dot(J.T) + lam * np.eye(rows)
         if cond is not None:
-            cond[0] = max(cond[0], _sym_cond(inner))
+            cond[0] += _sym_cond(inner)
         return np.linalg.solve(inner, J).T
     inner = J.T.dot(J) + lam * np.eye(cols)
     if cond is not None:
-        cond[0] = max(cond[0], _sym_cond(inner))
+        cond[0] += _sym_cond(inner)
     return np.linalg.solve(inner, J.T)
 
 
@@ -507,9 +508,9 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
 
     dZ[:, :n_q] is robot_vel, the rest virtual_vel.
 
-    `cond_out` [B] (optional) receives, per instance, the largest condition number of any matrix the reference's algorithm
-    hands to its linear solver up to and including the accepted mode (pseudo_inverse.py:92-105): the yardstick of the
-    stated parity tolerance (tests/tolerances.py).
+    `cond_out` [B] (optional) receives, per instance, the SUM of the condition numbers of the matrices the reference's
+    algorithm hands to its linear solver in the accepted mode (pseudo_inverse.py:92-105; the errors of successive solves add
+    up): the yardstick of the stated parity tolerance (tests/tolerances.py).
 
     `_wrong` (None = the reference's algorithm) names ONE deliberate deviation, for the tests that state what the
     reference-held figure pins resolve (tests/test_figure_pins.py): "no_S" stacks J instead of S J for an active
@@ -549,8 +550,8 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
     I = np.eye(n)
     cond_all = np.ones(B)
     for b in range(B):
-        cnd = [1.0]
         for mode_idx in range(n_modes):
+            cnd = [1.0]                 # (per mode: only the accepted mode's solves shape the answer)
             set_idx = 0
             v = np.zeros(n)
             Ja, rJa, tc = [], [], []

@@ -9,9 +9,11 @@ The rule:       err  <=  max(FLOOR, FACTOR * u * kappa),       u = 2^-53,  FACTO
 kappa is the condition number of what the REFERENCE's algorithm hands to its linear solver for that instance - its own
 answer is defined only up to c * u * kappa, whichever correct solver (CasADi's, numpy's LU, the kernels' LDL^T) runs:
 
-  pinv   the largest 2-norm condition number of the symmetric matrices `J J' + lam I` / `J' J + lam I` of every
-         pseudo-inverse evaluated up to the accepted mode (pseudo_inverse.py:92-105), collected by the oracle itself
-         (`clik_oracle.pinv_solve_batch(..., cond_out=)`).  Closed forms, for batches too large for the numpy oracle:
+  pinv   the SUM of the 2-norm condition numbers of the symmetric matrices `J J' + lam I` / `J' J + lam I` of every
+         pseudo-inverse the accepted mode evaluates (pseudo_inverse.py:92-105; the rounding errors of successive solves
+         add up: a six-constraint stack projects five times), collected by the oracle itself
+         (`clik_oracle.pinv_solve_batch(..., cond_out=)`).  Closed forms per solve, for batches too large for the numpy
+         oracle:
            single task, m <= n rows          kappa = (smax^2 + lam) / (smin^2 + lam)
            an equality behind the first one  kappa = (c smax^2 + lam) / lam: the reference projects through the doubly
                                              stacked [J; J] (:317-326 + :382-396; c = 2, plus the rows stacked with
@@ -27,7 +29,7 @@ Instances whose bound exceeds ILL_POSED (undamped inverse of a rank-deficient st
 evidence either way and are left out, counted.  Modes must be identical wherever the smallest tangent-cone decision
 margin of the instance (`clik_oracle.tangent_cone_margin`) exceeds MODE_MARGIN.
 
-Measured against the reference's own Python over the stand-in casadi (tests/golden/ref_pins.npz): err / (u kappa) <= 1.4
+Measured against the reference's own Python over the stand-in casadi (tests/golden/ref_pins.npz): err / (u kappa) <= 0.8
 for the oracle (tests/test_refpins.py); for the HIP kernels - different algebra: LDL' without pivoting, push-through and
 Woodbury forms, DESIGN.md section 3 - <= FACTOR with the margins recorded in profiles/r4_tolerance_sweep.txt."""
 import numpy as np
