@@ -364,6 +364,9 @@ def time_allgather(ctx, tick, dQ, n_total, M=200):
             "backend": "gloo (host copies)" if ctx.shared_gpu else "nccl (RCCL all_gather_into_tensor over xGMI)", "calls": M}
 
 
+DRAWN_MAX = 131072
+
+
 def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_graph=1, ramp_ms=250.0,
             min_timed_ms=2000.0, replays=0, allgather=0, global_batch=0):
     """One timed configuration.  Returns (entry dict, (spec, opts, Q, Y)) on every rank; the entry is
@@ -382,7 +385,14 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         B = hi - lo
     else:
         # every rank owns its own shard of the (weak-scaled) global batch
-        Q, Y = skills.synthetic_inputs(fk, B, seed=seed + 1000 * rank, distribution=dist_name)
+        # (beyond 131072 instances: that many drawn, tiled - the host-side draw evaluates a forward kinematics per row
+        # in Python, 65 us each)
+        drawn = min(B, DRAWN_MAX)
+        Q, Y = skills.synthetic_inputs(fk, drawn, seed=seed + 1000 * rank, distribution=dist_name)
+        if drawn < B:
+            import numpy as np
+            reps = (B + drawn - 1) // drawn
+            Q, Y = np.tile(Q, (reps, 1))[:B].copy(), np.tile(Y, (reps, 1))[:B].copy()
     Qd = torch.from_numpy(Q).to(dev)
     Yd = torch.from_numpy(Y).to(dev)
     dQ = torch.empty((B, Q.shape[1]), dtype=torch.float64, device=dev)
@@ -541,7 +551,8 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         "value": value, "unit": "instance-steps/s", "ms_per_step": wall * 1e3 / timed_steps,
         "config": {
             "workload": text,
-            "batch_per_gpu": B, "inputs": "%s seed %d" % (dist_name, seed),
+            "batch_per_gpu": B, "inputs": "%s seed %d%s" % (dist_name, seed, "" if B <= DRAWN_MAX or global_batch else
+                                                           " (%d drawn, tiled)" % DRAWN_MAX),
             "kernel": kernel,
             "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
                        else "eager, one launch per tick") if TPL == 1

@@ -1618,6 +1618,104 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
     CLIK_BODY_END();
 }
 
+// ... and its PERSISTENT form for the batches with many waves per SIMD - a round-4 experiment, compiled only with
+// -DCLIK_LANE_PERSIST (CLIK_JIT_DEFINES): MEASURED SLOWER, profiles/r4_persistent_lane_variants.txt (1 M instances:
+// 67.2 against 65.5 us; 262144: 19.6 against 17.6), bit-identical results (tools/persist_check.py).  The idea: counters
+// of the kernel above at 1 M instances (profiles/r3_counters.json) show a wave living 15.7 k cycles, issuing for 7.3 k
+// and waiting 4.7 k on its own robot_var row, two waves to a SIMD (248 VGPRs).  Here a launch is exactly the waves the
+// device holds at once; every wave walks its chunks of 64 instances (chunk += grid) and, before it computes chunk i,
+// starts the copy of chunk i + grid straight into LDS (global_load_lds_dwordx4: 16 B per lane, no destination
+// registers - the kernel has none to spare), waits for it after the tick, and only then stores its results (so the one
+// `s_waitcnt vmcnt(0)` of an iteration waits for nothing younger than a copy issued a whole tick earlier).  Why it
+// does not pay (tools/probe_fp64_peak.hip, profiles/r4_fp64_issue_probe.txt): sixteen waves per SIMD in turn, two
+// resident, of 1792 fp64 FMAs each and NO memory at all take 54 - 56 us - the kernel's 65.5 us with its 180 MB of
+// traffic is within 16 % of pure issue, and the loop costs what the prefetch saves (256 VGPRs, constants hoisted
+// out of the loop into spilled registers unless -mllvm -disable-machine-licm).
+#ifdef CLIK_LANE_PERSIST
+#ifndef CLIK_LANE_PERSIST_MIN_BATCH
+#define CLIK_LANE_PERSIST_MIN_BATCH (1ll << 60)
+#endif
+template <const ShapeDesc& SD>
+struct PersistStage {
+    static constexpr int Q_BYTES = WAVE * SD.n * (int)sizeof(double), Y_BYTES = WAVE * SD.n_y * (int)sizeof(double);
+    static constexpr int Q_PIECES = (Q_BYTES + 1023) / 1024, Y_PIECES = (Y_BYTES + 1023) / 1024;   // 64 lanes x 16 B each
+    static constexpr int DOUBLES = (Q_PIECES + Y_PIECES) * 128;                                    // one staging image
+    static constexpr int LDS_BYTES = 2 * DOUBLES * (int)sizeof(double);
+    static constexpr bool fits = LDS_BYTES * 8 <= 160 * 1024;      // eight waves per CU keep their images
+};
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void pinv_solve_static_values_persistent_kernel(
+    const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
+    int32_t* __restrict__ mode_out, const long long n_chunks, const TickArgs tk)
+{
+    static_assert(SD.n_x == 0, "value-specialised lane kernel: robot variables only");
+    constexpr int N = SD.n, NY = SD.n_y;
+    using PS = PersistStage<SD>;
+    constexpr Img<SD> Sval = IMGV::value;
+    __shared__ __attribute__((aligned(16))) double stage[2][PS::DOUBLES];
+    const int lane = threadIdx.x;
+    long long c = blockIdx.x;
+    if (c >= n_chunks) return;
+    // chunk `chunk` (64 whole rows of robot_var and of input_var) -> staging image `buf`, asynchronously
+    auto copy_chunk = [&](long long chunk, int buf) {
+        int l16 = lane * 16;
+        asm volatile("" : "+v"(l16));      // (recomputed per use: hoisted per-lane addresses would live across the tick)
+        const char* qs = reinterpret_cast<const char*>(q) + chunk * PS::Q_BYTES;
+#pragma unroll
+        for (int k = 0; k < PS::Q_PIECES; ++k) {
+            // (last piece of a ragged image: its upper lanes re-read the chunk's last 16 bytes into words nobody reads)
+            int off = k * 1024 + l16;
+            off = off < PS::Q_BYTES - 16 ? off : PS::Q_BYTES - 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + off),
+                                             (__attribute__((address_space(3))) void*)(&stage[buf][k * 128]), 16, 0, 0);
+        }
+        if constexpr (NY > 0) {
+            const char* ysrc = reinterpret_cast<const char*>(y) + chunk * PS::Y_BYTES;
+#pragma unroll
+            for (int k = 0; k < PS::Y_PIECES; ++k) {
+                int off = k * 1024 + l16;
+                off = off < PS::Y_BYTES - 16 ? off : PS::Y_BYTES - 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ysrc + off),
+                                                 (__attribute__((address_space(3))) void*)(&stage[buf][(PS::Q_PIECES + k) * 128]),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    int buf = 0;
+    copy_chunk(c, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (;;) {
+        // (per-lane offsets are re-derived from the lane number where they are used: as loop invariants they would be
+        // hoisted, live across the tick and spilled - and a scratch reload waits for the copy in flight as well)
+        int l0 = lane;
+        asm volatile("" : "+v"(l0));
+        double z[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) z[j] = stage[buf][l0 * N + j];
+        const long long next = c + gridDim.x;
+        const bool more = next < n_chunks;
+        if (more) copy_chunk(next, buf ^ 1);
+        const double* ys = NY > 0 ? &stage[buf][PS::Q_PIECES * 128 + l0 * NY] : nullptr;
+        double vout[N];
+        int acc_mode;
+        pinv_tick_static<SD>(&Sval, tk, z, ys, lane, true, vout, acc_mode);
+        // the copy was issued a tick ago and the stores of the previous chunk before that: nothing young to wait for
+        if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int l1 = lane;
+        asm volatile("" : "+v"(l1));
+        double* out = dq + c * (WAVE * N);                       // (wave-uniform base + 32-bit lane offset)
+#pragma unroll
+        for (int j = 0; j < N; ++j) out[l1 * N + j] = vout[j];
+        if (mode_out != nullptr) (mode_out + c * WAVE)[l1] = acc_mode;
+        if (!more) break;
+        c = next;
+        buf ^= 1;
+    }
+}
+
+#endif  // CLIK_LANE_PERSIST
+
 // the value-specialised kernel of a skill for one tick: four lanes per instance where the family allows and the
 // batch is small, else the lane kernel above (hipErrorNotSupported beyond its batch range: the caller then uses
 // the image-reading kernels)
@@ -1632,6 +1730,39 @@ inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, l
     if constexpr (shape_value_lane_ok(SD)) {
         if (B <= kValueLaneMaxBatch) {
             const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+#ifdef CLIK_LANE_PERSIST
+            // (the persistent form from CLIK_LANE_PERSIST_MIN_BATCH instances on; environment CLIK_LANE_PERSIST_MIN
+            // overrides the threshold - a measuring switch, read once)
+            static long long persist_min = -1;
+            static unsigned resident = 0;
+            if (persist_min < 0) {
+                const char* e = getenv("CLIK_LANE_PERSIST_MIN");
+                long long pm = e != nullptr ? atoll(e) : (long long)CLIK_LANE_PERSIST_MIN_BATCH;
+                int per_cu = 0, dev = 0, cus = 0;
+                if (!PersistStage<SD>::fits ||
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                        &per_cu, pinv_solve_static_values_persistent_kernel<SD, IMGV>, WAVE, 0) != hipSuccess ||
+                    hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1)
+                    pm = 1ll << 60;
+                resident = (unsigned)(per_cu * cus);
+                persist_min = pm > 0 ? pm : 1;
+            }
+            if constexpr (PersistStage<SD>::fits) {
+                const long long n_full = B / WAVE;
+                if (B >= persist_min && n_full > (long long)resident) {
+                    hipLaunchKernelGGL((pinv_solve_static_values_persistent_kernel<SD, IMGV>), dim3(resident), dim3(WAVE),
+                                       0, stream, q, y, dq, mode, n_full, tk);
+                    const long long tail = B - n_full * WAVE;        // a ragged last chunk: the plain kernel, one wave
+                    if (tail > 0)
+                        hipLaunchKernelGGL((pinv_solve_static_values_kernel<SD, IMGV>), dim3(1), dim3(WAVE), 0, stream,
+                                           q + n_full * WAVE * SD.n, SD.n_y > 0 ? y + n_full * WAVE * SD.n_y : y,
+                                           dq + n_full * WAVE * SD.n, mode != nullptr ? mode + n_full * WAVE : mode, tail,
+                                           tk);
+                    return hipGetLastError();
+                }
+            }
+#endif
             hipLaunchKernelGGL((pinv_solve_static_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
                                mode, B, tk);
             return hipGetLastError();

@@ -17,6 +17,9 @@ import casclik_amd as cc                             # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "qp"
 flags = [a for a in sys.argv[2:] if a.startswith("-D")]
+for a in sys.argv[2:]:
+    if a.startswith("--mllvm="):                      # e.g. --mllvm=-disable-machine-licm
+        flags += ["-mllvm", a.split("=", 1)[1]]
 asm_out = [a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--asm=")]
 lib = _capi.load_library()
 fk = skills.iiwa()
