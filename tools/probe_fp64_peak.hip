@@ -20,6 +20,10 @@ __global__ __launch_bounds__(64) void k_fma(double* __restrict__ out, unsigned l
     // unlike the LDS bound this also decides WHICH SIMD takes the next wave
     if constexpr (REGS == 1) asm volatile("v_mov_b32 v247, 0" ::: "v247");
     if constexpr (REGS == 2) asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a63, v255" ::: "v255", "a63");
+    if constexpr (REGS == 3) asm volatile("v_mov_b32 v255, 0" ::: "v255");     // (allocation sizes: does the size alone cost issue rate?)
+    if constexpr (REGS == 4) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+    if constexpr (REGS == 5) asm volatile("v_mov_b32 v63, 0" ::: "v63");
+    if constexpr (REGS == 6) asm volatile("v_mov_b32 v217, 0" ::: "v217");
     double a[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = seed + k + threadIdx.x;
@@ -73,7 +77,7 @@ int run(const char* what, int waves_per_simd, int iters, double* out, unsigned l
     const double insts = (double)grid * iters * 16;                      // wave-instructions
     const double flops = insts * 64 * (MIX == 1 ? 1.75 : 2.0);
     char label[96];
-    snprintf(label, sizeof(label), "%s%s", what, REGS == 1 ? " [248 VGPRs]" : REGS == 2 ? " [256 VGPRs + 64 AGPRs]" : resident_per_simd == 1 ? " [LDS: 1 resident/SIMD]" : resident_per_simd == 2 ? " [LDS: 2 resident/SIMD]" : "");
+    snprintf(label, sizeof(label), "%s%s", what, REGS == 1 ? " [248 VGPRs]" : REGS == 2 ? " [256 VGPRs + 64 AGPRs]" : REGS == 3 ? " [256 VGPRs]" : REGS == 4 ? " [128 VGPRs]" : REGS == 5 ? " [64 VGPRs]" : REGS == 6 ? " [218 VGPRs]" : resident_per_simd == 1 ? " [LDS: 1 resident/SIMD]" : resident_per_simd == 2 ? " [LDS: 2 resident/SIMD]" : "");
     what = label;
     printf("%-52s waves/SIMD %2d iters %6d  %9.2f us/launch  %6.2f TFLOP/s  %5.2f cycles per wave-instruction per SIMD at 2.4 GHz;"
            "  wave 0: %llu shader clocks in %.2f us = %.3f GHz\n", what, waves_per_simd, iters, us, flops / us * 1e-6,
@@ -118,7 +122,15 @@ int main()
     if ((run<1, 1>("16 waves per SIMD in turn, 1792 instr, 3 fma : 1 mul", 16, 112, out, clk))) return 1;
     if ((run<2, 1>("sustained, two reg operands", 2, 20000, out, clk))) return 1;
     if ((run<2, 2>("sustained, two reg operands", 1, 40000, out, clk))) return 1;
+    if ((run<2, 5>("ONE wave per SIMD, sustained, two reg operands", 1, 40000, out, clk))) return 1;
+    if ((run<2, 4>("ONE wave per SIMD, sustained, two reg operands", 1, 40000, out, clk))) return 1;
+    if ((run<2, 6>("ONE wave per SIMD, sustained, two reg operands", 1, 40000, out, clk))) return 1;
+    if ((run<2, 1>("ONE wave per SIMD, sustained, two reg operands", 1, 40000, out, clk))) return 1;
+    if ((run<2, 3>("ONE wave per SIMD, sustained, two reg operands", 1, 40000, out, clk))) return 1;
+    if ((run<0, 5>("ONE wave per SIMD, sustained, constant operands", 1, 40000, out, clk))) return 1;
+    if ((run<0, 3>("ONE wave per SIMD, sustained, constant operands", 1, 40000, out, clk))) return 1;
     if ((run<4, 2>("ONE dependent chain, 1 wave per SIMD", 1, 4000, out, clk))) return 1;
+    if ((run<4, 5>("ONE dependent chain, 1 wave per SIMD", 1, 4000, out, clk))) return 1;
     if ((run<5, 2>("TWO dependent chains, 1 wave per SIMD", 1, 4000, out, clk))) return 1;
     if ((run<6, 2>("FOUR dependent chains, 1 wave per SIMD", 1, 4000, out, clk))) return 1;
     return 0;
