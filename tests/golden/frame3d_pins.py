@@ -1,0 +1,188 @@
+"""The 3-D figures the reference's notebooks store (`common_plots.frame_3d`: the tool's path in black and the tips of its
+frame's axes, p + 0.1 R e_i, as red / green / blue dashed curves, on a default `Axes3D`) as pins of the POSE trajectory.
+
+What is stored (tests/golden/notebook_figures.npz, written by make_figure_pins.py): for every figure the coordinates of the
+pixels of each curve colour inside the axes box - data read off the figure, nothing else.  What turns a simulated run
+into pixels is matplotlib's (2.x) own projection, restated here from its documentation and checked on the figures'
+dots (the desired frame's origin and axis tips: known points, no simulation involved):
+
+  view limits   the data range of everything drawn (the four curves and the dots) widened by 5 % on each side
+                (axes.xmargin / ymargin / zmargin = 0.05, autolimit_mode "data")
+  world -> unit cube -> eye at elev 30, azim -60, distance 10 from the cube's centre, up = z -> perspective (front / back
+  at -+ distance) -> the 2-D axes limits (-0.95 / dist, 0.9 / dist) in both directions, axes filling the whole
+  640 x 480 canvas (`Axes3D(plt.figure())`), rows counted from the top.
+
+Because the view limits come from the simulated curves themselves, a run that leaves the stored one anywhere near its
+extremes moves EVERY pixel."""
+import numpy as np
+
+COLOURS = ("k", "r", "g", "b")
+
+
+class OldAxes3D(object):
+    """matplotlib 2.x `Axes3D.get_proj` for given view limits [(xmin, xmax), (ymin, ymax), (zmin, zmax)]"""
+
+    def __init__(self, limits, elev=30.0, azim=-60.0, dist=10.0, width=640, height=480):
+        (x0, x1), (y0, y1), (z0, z1) = limits
+        dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
+        world = np.array([[1 / dx, 0, 0, -x0 / dx], [0, 1 / dy, 0, -y0 / dy], [0, 0, 1 / dz, -z0 / dz], [0, 0, 0, 1.0]])
+        relev, razim = np.pi * elev / 180, np.pi * azim / 180
+        centre = np.array([0.5, 0.5, 0.5])
+        eye = centre + dist * np.array([np.cos(razim) * np.cos(relev), np.sin(razim) * np.cos(relev), np.sin(relev)])
+        n = (eye - centre) / np.linalg.norm(eye - centre)
+        u = np.cross([0.0, 0.0, 1.0], n)
+        u /= np.linalg.norm(u)
+        v = np.cross(n, u)
+        rot, shift = np.eye(4), np.eye(4)
+        rot[0, :3], rot[1, :3], rot[2, :3] = u, v, n
+        shift[:3, 3] = -eye
+        zf, zb = -dist, dist
+        persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, (zf + zb) / (zf - zb), -2 * zf * zb / (zf - zb)], [0, 0, -1, 0.0]])
+        self.M = persp.dot(rot.dot(shift)).dot(world)
+        self.lo, self.hi = -0.95 / dist, 0.9 / dist
+        self.width, self.height = width, height
+        self.limits = limits
+
+    def pixels(self, X):
+        """[n, 3] world points -> [n, 2] (column, row) on the canvas"""
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        h = np.c_[X, np.ones(len(X))].dot(self.M.T)
+        x, y = h[:, 0] / h[:, 3], h[:, 1] / h[:, 3]
+        span = self.hi - self.lo
+        return np.c_[(x - self.lo) / span * self.width, self.height - (y - self.lo) / span * self.height]
+
+    def box_corners(self):
+        (x0, x1), (y0, y1), (z0, z1) = self.limits
+        return self.pixels([[x, y, z] for x in (x0, x1) for y in (y0, y1) for z in (z0, z1)])
+
+
+def autoscaled_limits(points, margin=0.05):
+    """view limits of everything drawn: [n, 3] points"""
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    d = (hi - lo) * margin
+    return [(lo[a] - d[a], hi[a] + d[a]) for a in range(3)]
+
+
+def frame_curves(p_sim, R_sim):
+    """what frame_3d draws: {"k": path, "r" / "g" / "b": p + 0.1 R e_i}"""
+    out = {"k": np.asarray(p_sim)}
+    for i, c in enumerate("rgb"):
+        out[c] = p_sim + 0.1 * R_sim[:, :, i]
+    return out
+
+
+def frame_dots(T_des=None, p_des=None):
+    if T_des is not None:
+        T_des = np.asarray(T_des, dtype=float)
+        return {"k": T_des[:3, 3]} | {c: T_des[:3, 3] + 0.1 * T_des[:3, i] for i, c in enumerate("rgb")}
+    return {"k": np.asarray(p_des, dtype=float)}
+
+
+def axes_of(p_sim, R_sim, T_des=None, p_des=None, limits=None, **kw):
+    curves, dots = frame_curves(p_sim, R_sim), frame_dots(T_des, p_des)
+    if limits is None:
+        limits = autoscaled_limits(np.vstack(list(curves.values()) + [np.atleast_2d(d) for d in dots.values()]))
+    return OldAxes3D(limits, **kw), curves, dots
+
+
+# ---- reading a stored figure ------------------------------------------------------------------------------------------
+def box_mask(rgb, shrink=6):
+    """the axes box on the canvas: its panes are light grey on a white figure; eroded by `shrink` pixels so that the
+    black axis lines and tick marks on its outline stay out"""
+    from scipy import ndimage
+    v = rgb[..., :3]
+    v = v / 255.0 if v.max() > 1.5 else v
+    shaded = (v.min(axis=2) < 0.985) & (v.min(axis=2) > 0.93) & (v.max(axis=2) - v.min(axis=2) < 0.02)   # pane grey only:
+    # (the title's letters above the box stay apart: their fringes are specks an opening removes; the grid lines that
+    # cut the panes into cells are bridged by the closing)
+    cells = ndimage.binary_closing(ndimage.binary_opening(shaded, iterations=1), iterations=3)
+    lab, n = ndimage.label(cells)
+    if n == 0:
+        return np.zeros(shaded.shape, bool)
+    sizes = ndimage.sum(cells, lab, index=np.arange(1, n + 1))
+    box = ndimage.binary_fill_holes(lab == (1 + int(np.argmax(sizes))))
+    return ndimage.binary_erosion(box, iterations=shrink)
+
+
+def colour_masks(rgb):
+    """pixels that are mostly one of matplotlib's "k" / "r" / "g" / "b" ((0, 0.5, 0) for green) over the light panes"""
+    v = rgb[..., :3]
+    v = v / 255.0 if v.max() > 1.5 else v
+    r, g, b = v[..., 0], v[..., 1], v[..., 2]
+    return {"k": (v.max(axis=2) < 0.35),
+            "r": (r > 0.7) & (g < 0.45) & (b < 0.45),
+            "g": (g > 0.35) & (g < 0.8) & (r < 0.45 * g / 0.5) & (b < 0.45 * g / 0.5) & (g - np.maximum(r, b) > 0.25),
+            "b": (b > 0.7) & (r < 0.45) & (g < 0.45)}
+
+
+def digitise(rgb):
+    """{colour: [n, 2] (column, row) centres of that colour's pixels inside the axes box}"""
+    box = box_mask(rgb)
+    out = {}
+    for c, mask in colour_masks(rgb).items():
+        rows, cols = np.nonzero(mask & box)
+        out[c] = np.c_[cols + 0.5, rows + 0.5]
+    return out
+
+
+# ---- comparing -------------------------------------------------------------------------------------------------------
+def dense(polyline, step=0.4):
+    """the projected curve sampled every `step` pixels of its length (a tool at rest adds no samples)"""
+    seg = np.linalg.norm(np.diff(polyline, axis=0), axis=1)
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    if s[-1] < step:
+        return polyline[:1].copy()
+    at = np.arange(0.0, s[-1], step)
+    return np.c_[np.interp(at, s, polyline[:, 0]), np.interp(at, s, polyline[:, 1])]
+
+
+def deviations(stored, axes, curves, dots, dot_radius=6.0):
+    """per colour: (worst distance of a stored pixel from the simulated curve, share of the simulated curve that has a
+    stored pixel of its colour - or of a curve drawn over it - within 1.5 pixels, pixels compared)"""
+    from scipy.spatial import cKDTree
+    drawn = {c: dense(axes.pixels(X)) for c, X in curves.items()}
+    dot_px = {c: axes.pixels(d)[0] for c, d in dots.items()}
+    everything = cKDTree(np.vstack([stored[c] for c in COLOURS if len(stored[c])]))
+    out = {}
+    for c in COLOURS:
+        px = stored[c]
+        if c in dot_px and len(px):
+            px = px[np.linalg.norm(px - dot_px[c], axis=1) > dot_radius]      # (the dot itself is not the curve)
+        if len(px) == 0:
+            out[c] = (0.0, 1.0, 0)
+            continue
+        d_to_curve = cKDTree(drawn[c]).query(px)[0]
+        covered = everything.query(drawn[c])[0] < 1.5
+        out[c] = (float(d_to_curve.max()), float(covered.mean()), int(len(px)))
+    return out
+
+
+# ---- the figures ------------------------------------------------------------------------------------------------------
+DQC_NOTEBOOK = "ur5_dual_quaternion_comparison_of_controllers.ipynb"
+# (constraint, controller) -> cell.  PINV(Q_dist2), cell 50, is read as well but is NOT a pin: that run starts in the
+# home singularity of the 8-row task and its first ticks ask for hundreds of rad/s, clipped to pi / 5 - a start moved
+# by 1e-9 rad changes those velocities by 2 %, one moved by 1e-6 ends with joint 6 at -1.88 instead of -1.39 rad; the
+# stored run (tool displaced 8 mm) and the oracle's (0.2 mm) are two members of that family.  Its ERROR NORM, which the
+# distance to the target dominates, is pinned all the same (dqc_Q_dist2_pinv).
+DQC_FRAMES = {("cart_dist", "qp"): 22, ("cart_dist", "pinv"): 23, ("quat_dist", "qp"): 26, ("quat_dist", "pinv"): 27,
+              ("Q_dist1", "qp"): 44, ("Q_dist1", "pinv"): 46, ("Q_dist2", "qp"): 48, ("Q_dist2", "pinv"): 50}
+DQC_P_DES = [0.5, 0.5, 0.5]                                     # cell 12
+DQC_T_DES = [[1.0, 0, 0, 0.2], [0, 1.0, 0, 0.2], [0, 0, 1.0, 0.75], [0, 0, 0, 1.0]]      # cell 33: T_rpy([0.2, 0.2, 0.75], 0, 0, 0)
+
+
+def dqc_target(which):
+    return dict(T_des=np.array(DQC_T_DES)) if which.startswith("Q_") else dict(p_des=np.array(DQC_P_DES))
+
+
+def collect_frames(out, html_png):
+    """pixel lists of the eight frame_3d figures -> out["f3d_<constraint>_<controller>_<colour>"] ([n, 2] int16, column
+    and row of each pixel)"""
+    for (which, kind), cell in DQC_FRAMES.items():
+        rgb = html_png(DQC_NOTEBOOK, cell)
+        assert rgb.shape[:2] == (480, 640)
+        for c, px in digitise(rgb).items():
+            out["f3d_%s_%s_%s" % (which, kind, c)] = np.floor(px).astype(np.int16)
+
+
+def stored_frames(figs, which, kind):
+    return {c: figs["f3d_%s_%s_%s" % (which, kind, c)].astype(float) + 0.5 for c in COLOURS}

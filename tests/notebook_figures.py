@@ -209,17 +209,22 @@ def dqc_skill(fk, which, kind):
     return spec, cs.Function("e", [t, q], [cs.norm_2(expr)])
 
 
-def simulate_dqc(eval_norm, solve, n_ticks=4500):
+def simulate_dqc(eval_norm, solve, n_ticks=4500, return_q=False):
     """cells 17 / 39: 4500 ticks of 0.01 s from UR5_home, speeds saturated at pi / 5; e_sim[i + 1] is the error norm at
-    q_sim[i + 1].  Returns t_sim, log10(e_sim)."""
+    q_sim[i + 1].  Returns t_sim, log10(e_sim) (and q_sim [n_ticks + 1, 6] with `return_q`)."""
     dt, max_speed = 0.01, np.pi / 5
     t_sim = np.array([dt * i for i in range(n_ticks + 1)])
     q = UR5_HOME.copy()
     e_sim = np.zeros(n_ticks + 1)
+    q_sim = np.zeros((n_ticks + 1, len(q)))
+    q_sim[0] = q
     e_sim[0] = float(np.asarray(eval_norm(0.0, q).toarray()).ravel()[0])
     for i in range(n_ticks):
         q = q + np.clip(solve(t_sim[i], q), -max_speed, max_speed) * dt
+        q_sim[i + 1] = q
         e_sim[i + 1] = float(np.asarray(eval_norm(t_sim[i], q).toarray()).ravel()[0])
+    if return_q:
+        return t_sim, np.log10(np.maximum(e_sim, 1e-300)), q_sim
     return t_sim, np.log10(np.maximum(e_sim, 1e-300))
 
 
@@ -239,3 +244,19 @@ def dqc_pins(which, kind, t_sim, log_e):
         # columns are contiguous in t from the start until the curves sink below the floor (Q_dist2's pinv never does)
         out.append((key,) + interval_deviation(key, t_sim, log_e, within=(0.0, float(ok_cols.max()))))
     return out
+
+
+# ---- ... and its frame_3d figures (cells 22-27, 44-48): the tool's path and the tips of its frame's axes in 3-D ----------
+FRAME_PIXELS = 2.0       # a stored pixel of a curve lies within this of the simulated curve (line half-width 1.04 px + 1)
+FRAME_COVERED = 0.9      # ... and this share of the simulated curve's length has ink within 1.5 px
+
+
+def dqc_frame_pins(fk, which, kind, q_sim):
+    """{colour: (worst distance of a stored pixel from the simulated curve [px], share of the simulated curve drawn,
+    pixels compared)} for the figure of that run; matplotlib's projection and autoscaled view limits are restated in
+    tests/golden/frame3d_pins.py"""
+    import frame3d_pins
+    T = np.array([fk["chain"].fk_numeric(q) for q in q_sim])
+    axes, curves, dots = frame3d_pins.axes_of(T[:, :3, 3], T[:, :3, :3], **frame3d_pins.dqc_target(which))
+    return frame3d_pins.deviations(frame3d_pins.stored_frames(FIGS, which, kind), axes, curves, dots)
+

@@ -307,14 +307,23 @@ def dqc_oracle_run(which, kind):
             dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])
             assert status[0] == 0
             return dq[0]
-    return cf.simulate_dqc(error_norm, solve)
+    return cf.simulate_dqc(error_norm, solve, return_q=True)
+
+
+_DQC_RUNS = {}
+
+
+def dqc_oracle_run_cached(which, kind):
+    if (which, kind) not in _DQC_RUNS:
+        _DQC_RUNS[(which, kind)] = dqc_oracle_run(which, kind)
+    return _DQC_RUNS[(which, kind)]
 
 
 @pytest.mark.parametrize("which,kind", [("quat_dist", "pinv"), ("quat_dist", "qp"), ("cart_dist", "pinv")])
 def test_oracle_reproduces_the_dual_quaternion_comparison_figures(which, kind):
     """(three of the eight runs here - 13 s each through the numpy oracle; all eight through the HIP controllers in
     tests/test_gpu_figure_pins.py, held to the same pins AND to the oracle along the way)"""
-    t_sim, log_e = dqc_oracle_run(which, kind)
+    t_sim, log_e, _ = dqc_oracle_run_cached(which, kind)
     pins = cf.dqc_pins(which, kind, t_sim, log_e)
     assert len(pins) == 2
     for key, worst, n, where in pins:
@@ -326,3 +335,36 @@ def test_oracle_reproduces_the_dual_quaternion_comparison_figures(which, kind):
         tail = log_e[t_sim > 12.0]
         assert abs(tail.min() - band[0]) < 1.5 * px and abs(tail.max() - band[1]) < 1.5 * px, (10.0 ** tail.min(), 10.0 ** tail.max(),
                                                                                              10.0 ** band)
+
+
+def assert_frame_pins(dev, what):
+    for colour, (worst, covered, n) in dev.items():
+        assert n > 250, (what, colour, n)
+        assert worst < cf.FRAME_PIXELS, (what, colour, worst)
+        assert covered > (0.97 if colour == "k" else 0.8), (what, colour, covered)
+
+
+@pytest.mark.parametrize("which,kind", [("quat_dist", "pinv"), ("quat_dist", "qp"), ("cart_dist", "pinv")])
+def test_oracle_retraces_the_stored_3d_frame_figures(which, kind):
+    """cells 23, 26, 27 of ur5_dual_quaternion_comparison_of_controllers.ipynb (`common_plots.frame_3d`): the tool's PATH
+    and the tips of its frame's three axes, through matplotlib's own projection with the view limits autoscaled from the
+    simulated curves (tests/golden/frame3d_pins.py) - every stored pixel of each of the four curves within two pixels
+    of the oracle's curve (measured: 1.0 - 1.65, the line is 2.1 wide), and the whole simulated curve under ink.  One
+    pixel = 1.4 mm of tool position or 0.8 degrees of tool orientation; the time along the path is not seen."""
+    from casclik_amd import skills
+    _, _, q_sim = dqc_oracle_run_cached(which, kind)
+    assert_frame_pins(cf.dqc_frame_pins(skills.ur5(), which, kind, q_sim), (which, kind))
+
+
+def test_what_the_3d_frame_figures_resolve():
+    """the two controllers take slightly DIFFERENT paths to the same point (the QP's weight shifter, reactive_qp.py:44,
+    and its joint-speed rows): each stored figure rejects the other controller's run - measured 2.2 - 5.7 pixels on
+    the four curves (pinv figure, QP run) against 1.0 - 1.2 for its own"""
+    from casclik_amd import skills
+    fk = skills.ur5()
+    runs = {kind: dqc_oracle_run_cached("quat_dist", kind)[2] for kind in ("pinv", "qp")}
+    for figure, other in (("pinv", "qp"), ("qp", "pinv")):
+        dev = cf.dqc_frame_pins(fk, "quat_dist", figure, runs[other])
+        beyond = [v[0] > cf.FRAME_PIXELS for v in dev.values()]
+        assert sum(beyond) >= 3 and max(v[0] for v in dev.values()) > 2 * cf.FRAME_PIXELS, (figure, other, dev)
+

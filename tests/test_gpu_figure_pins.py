@@ -247,11 +247,20 @@ def test_hip_controllers_reproduce_the_dual_quaternion_comparison_figures(ur5_fk
                 assert qp_close(dq[None, :], ref), (which, state["i"])
         state["i"] += 1
         return dq
-    t_sim, log_e = cf.simulate_dqc(error_norm, solve)
+    t_sim, log_e, q_sim = cf.simulate_dqc(error_norm, solve, return_q=True)
     pins = cf.dqc_pins(which, kind, t_sim, log_e)
     assert len(pins) == 2
     for key, worst, n, where in pins:
         assert n > 50 and worst < PIXELS, (key, worst, n, where)
+    if (which, kind) != ("Q_dist2", "pinv"):
+        # ... and the run's POSES against the stored frame_3d figure (cells 22-27, 44-48: the tool's path and the tips of
+        # its frame's axes, matplotlib's projection restated in tests/golden/frame3d_pins.py).  PINV(Q_dist2) leaves the
+        # home singularity through saturated velocities - its stored 3-D figure is one member of a family a 1e-9 rad
+        # change of the start spreads out, see frame3d_pins.DQC_FRAMES - and keeps the error-norm pin only.
+        dev = cf.dqc_frame_pins(ur5_fk, which, kind, q_sim)
+        for colour, (worst, covered, n) in dev.items():
+            assert n > 250 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (which, kind, dev)
+        print("%s %s frame_3d figure: %s" % (which, kind, {c: (round(v[0], 2), round(v[1], 2)) for c, v in dev.items()}))
     if (which, kind) == ("cart_dist", "pinv"):
         band, px = cf.FIGS["dqc_cart_dist_pinv_band"], cf.FIGS["dqc_cart_dist_pinv_pixel"][1]
         tail = log_e[t_sim > 12.0]          # (the chatter on the unreachable target: the stored band's amplitude)
