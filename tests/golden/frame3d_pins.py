@@ -174,15 +174,38 @@ def dqc_target(which):
     return dict(T_des=np.array(DQC_T_DES)) if which.startswith("Q_") else dict(p_des=np.array(DQC_P_DES))
 
 
+# ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 33, 34: the ReactiveQPController's runs on Q_dist2 and T_dist2
+# (1000 ticks of 0.008 s from UR5_home to a frame rolled by 5 degrees at (0.5, 0, 0.5)); `nice_plotting.latexify(3.5)`
+# makes the canvas 350 x 216, the cells set the view limits themselves.  (Cells 35, 36 - the PseudoInverseController with
+# damping 1e-26 from the singular home - are rounding noise / 1e-26 at the start)
+DQTM_NOTEBOOK = "ur5_dual_quaternion_vs_transformation_matrix.ipynb"
+DQTM_FRAMES = {"Q_dist2": 33, "T_dist2": 34}
+DQTM_LIMITS = [(-0.5, 1.0), (-0.5, 1.0), (0.0, 1.0)]
+DQTM_CANVAS = (350, 216)
+
+
+def dqtm_target():
+    roll = 5.0 * np.pi / 180.0                                   # cell 16: rotation_rpy(roll, 0, 0) at (0.5, 0, 0.5)
+    T = np.eye(4)
+    T[:3, :3] = [[1.0, 0.0, 0.0], [0.0, np.cos(roll), -np.sin(roll)], [0.0, np.sin(roll), np.cos(roll)]]
+    T[:3, 3] = [0.5, 0.0, 0.5]
+    return T
+
+
 def collect_frames(out, html_png):
-    """pixel lists of the eight frame_3d figures -> out["f3d_<constraint>_<controller>_<colour>"] ([n, 2] int16, column
-    and row of each pixel)"""
+    """pixel lists of the frame_3d figures -> out["f3d_<constraint>_<controller>_<colour>"] ([n, 2] int16, column and row
+    of each pixel)"""
     for (which, kind), cell in DQC_FRAMES.items():
         rgb = html_png(DQC_NOTEBOOK, cell)
         assert rgb.shape[:2] == (480, 640)
         for c, px in digitise(rgb).items():
             out["f3d_%s_%s_%s" % (which, kind, c)] = np.floor(px).astype(np.int16)
+    for which, cell in DQTM_FRAMES.items():
+        rgb = html_png(DQTM_NOTEBOOK, cell)
+        assert rgb.shape[:2] == DQTM_CANVAS[::-1]
+        for c, px in digitise(rgb).items():
+            out["f3d_dqtm_%s_qp_%s" % (which, c)] = np.floor(px).astype(np.int16)
 
 
-def stored_frames(figs, which, kind):
-    return {c: figs["f3d_%s_%s_%s" % (which, kind, c)].astype(float) + 0.5 for c in COLOURS}
+def stored_frames(figs, which, kind, prefix="f3d_"):
+    return {c: figs["%s%s_%s_%s" % (prefix, which, kind, c)].astype(float) + 0.5 for c in COLOURS}

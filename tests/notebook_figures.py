@@ -110,15 +110,32 @@ def frame_error_skill(fk, which, controller):
         Q_id = numpy_geom.dual_quaternion_revolute([0., 0., 0.], [0., 0., 0.], [1., 0., 0.], 0.0)
         expr = product(fk["dual_quaternion_fk"](q), conj(Q_des)) - Q_id
         norm = cs.norm_2(expr)
-    elif which == "T_dist1":
+    elif which == "Q_dist2":
+        # cell 18: the dual Hamilton operator "minus" of Q_des (cell 3) times the conjugation signs times Q_des - Q_fk(q)
+        Q_des = np.asarray(numpy_geom.dual_quaternion_revolute(xyz, rpy, [1, 0, 0], 0.0), dtype=float).ravel()
+        a = Q_des
+        Hm = np.array([[a[3], a[2], -a[1], a[0], 0, 0, 0, 0], [-a[2], a[3], a[0], a[1], 0, 0, 0, 0],
+                       [a[1], -a[0], a[3], a[2], 0, 0, 0, 0], [-a[0], -a[1], -a[2], a[3], 0, 0, 0, 0],
+                       [a[7], a[6], -a[5], a[4], a[3], a[2], -a[1], a[0]], [-a[6], a[7], a[4], a[5], -a[2], a[3], a[0], a[1]],
+                       [a[5], -a[4], a[7], a[6], a[1], -a[0], a[3], a[2]], [-a[4], -a[5], -a[6], a[7], -a[0], -a[1], -a[2], a[3]]])
+        expr = cs.mtimes(Hm.dot(np.diag([-1.0, -1, -1, 1, -1, -1, -1, 1])), Q_des - fk["dual_quaternion_fk"](q))
+        norm = cs.norm_2(expr)
+    elif which in ("T_dist1", "T_dist2"):
         T_des = np.eye(4)
         T_des[:3, :3] = numpy_geom.rotation_rpy(*rpy)
         T_des[:3, 3] = xyz
-        expr = cs.norm_fro(cs.mtimes(np.linalg.inv(T_des), fk["T_fk"](q)) - np.eye(4))
-        norm = expr
+        if which == "T_dist1":
+            expr = cs.norm_fro(cs.mtimes(np.linalg.inv(T_des), fk["T_fk"](q)) - np.eye(4))
+            norm = expr
+        else:
+            # cell 20: position deviation, and the Frobenius norm of the rotation's deviation from the desired one
+            T = fk["T_fk"](q)
+            expr = cs.vertcat(T[:3, 3] - T_des[:3, 3], cs.norm_fro(cs.mtimes(np.linalg.inv(T_des[:3, :3]), T[:3, :3]) - np.eye(3)))
+            norm = cs.norm_2(expr)
     else:
         raise ValueError(which)
-    error = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=10.0, priority=301)
+    error = cc.EqualityConstraint(label=which + "_cnstr", expression=expr, constraint_type="soft", gain=10.0,
+                                  priority=300 if which == "T_dist2" else 301)
     if controller == "qp":
         cons = [cc.SetConstraint(label="Joint_Limits", expression=q, set_min=np.array(fk["lower"]),
                                  set_max=np.array(fk["upper"])), error]
@@ -130,17 +147,21 @@ def frame_error_skill(fk, which, controller):
     return spec, options, cs.Function("e", [t, q], [norm])
 
 
-def simulate_frame_error(eval_norm, solve):
+def simulate_frame_error(eval_norm, solve, return_q=False):
     """cell 25: 1000 ticks of 0.008 s from UR5_home, speeds saturated at pi / 5; e_sim[i + 1] is the error norm at
-    q_sim[i + 1].  Returns t_sim, log10(e_sim)."""
+    q_sim[i + 1].  Returns t_sim, log10(e_sim) (and q_sim with `return_q`)."""
     n, dt, max_speed = 1001, 0.008, np.pi / 5
     t_sim = np.array([dt * i for i in range(n)])
     q = UR5_HOME.copy()
-    e_sim = np.zeros(n)
+    e_sim, q_sim = np.zeros(n), np.zeros((n, 6))
+    q_sim[0] = q
     e_sim[0] = float(np.asarray(eval_norm(0.0, q).toarray()).ravel()[0])
     for i in range(n - 1):
         q = q + np.clip(solve(t_sim[i], q), -max_speed, max_speed) * dt
+        q_sim[i + 1] = q
         e_sim[i + 1] = float(np.asarray(eval_norm(t_sim[i], q).toarray()).ravel()[0])
+    if return_q:
+        return t_sim, np.log10(np.maximum(e_sim, 1e-300)), q_sim
     return t_sim, np.log10(np.maximum(e_sim, 1e-300))
 
 
@@ -260,3 +281,14 @@ def dqc_frame_pins(fk, which, kind, q_sim):
     axes, curves, dots = frame3d_pins.axes_of(T[:, :3, 3], T[:, :3, :3], **frame3d_pins.dqc_target(which))
     return frame3d_pins.deviations(frame3d_pins.stored_frames(FIGS, which, kind), axes, curves, dots)
 
+
+
+def frame_error_frame_pins(fk, which, q_sim):
+    """the same for ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 33 / 34 (the QP's runs on Q_dist2 / T_dist2;
+    350 x 216 canvas, the view limits the cells set: one pixel = 7 mm)"""
+    import frame3d_pins
+    T = np.array([fk["chain"].fk_numeric(q) for q in q_sim])
+    axes, curves, dots = frame3d_pins.axes_of(T[:, :3, 3], T[:, :3, :3], T_des=frame3d_pins.dqtm_target(),
+                                              limits=frame3d_pins.DQTM_LIMITS, width=frame3d_pins.DQTM_CANVAS[0],
+                                              height=frame3d_pins.DQTM_CANVAS[1])
+    return frame3d_pins.deviations(frame3d_pins.stored_frames(FIGS, which, "qp", prefix="f3d_dqtm_"), axes, curves, dots)

@@ -368,3 +368,25 @@ def test_what_the_3d_frame_figures_resolve():
         beyond = [v[0] > cf.FRAME_PIXELS for v in dev.values()]
         assert sum(beyond) >= 3 and max(v[0] for v in dev.values()) > 2 * cf.FRAME_PIXELS, (figure, other, dev)
 
+
+@pytest.mark.parametrize("which", ["Q_dist2", "T_dist2"])
+def test_oracle_retraces_the_qp_frame_figures_of_the_frame_error_notebook(which):
+    """ur5_dual_quaternion_vs_transformation_matrix.ipynb cells 33 / 34: the ReactiveQPController driving the tool to a
+    rolled frame on the dual-quaternion deviation `Q_dist2` (a constant 8 x 8 operator times Q_des - Q_fk) and on
+    `T_dist2` (position deviation + the Frobenius norm of the rotation's deviation as ONE row) - path and frame-axis tips
+    in 3-D on a 350 x 216 canvas with the view limits the cells set (one pixel = 7 mm); the desired frame's dots land
+    within 0.2 px of where the restated projection puts them"""
+    from casclik_amd import skills
+    fk = skills.ur5()
+    spec, _, error_norm = cf.frame_error_skill(fk, which, "qp")
+
+    def solve(t, q):
+        dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])
+        assert status[0] == 0
+        return dq[0]
+    _, log_e, q_sim = cf.simulate_frame_error(error_norm, solve, return_q=True)
+    assert log_e[-1] < -13.0                                     # (the run converges to the frame)
+    dev = cf.frame_error_frame_pins(fk, which, q_sim)
+    for colour, (worst, covered, n) in dev.items():
+        assert n > 100 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (which, dev)
+
