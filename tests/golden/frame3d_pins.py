@@ -192,9 +192,41 @@ def dqtm_target():
     return T
 
 
-def collect_frames(out, html_png):
+# ur5_transformation_matrix_comparison_of_controllers.ipynb cells 17 (ReactiveQPController, the only figure its point run
+# has) and 33 (PseudoInverseController, the run of cell 32): inline backend, a 6 x 4 inch figure at 72 dpi = 432 x 288
+# canvas pixels saved with bbox_inches="tight", which pads 7.2 px and follows the tick labels beyond the canvas: the
+# stored 453 x 309 image sits at an offset only the figure can tell.  It is read off the black dot at p_des = (0.5, 0.5,
+# 0.5) (stored: the dot's centroid); view limits (-1, 1)^3 as the cells set them; one pixel = 6 mm.
+TM_NOTEBOOK = "ur5_transformation_matrix_comparison_of_controllers.ipynb"
+TM_FRAMES = {"qp": 17, "pinv": 33}
+TM_LIMITS = [(-1.0, 1.0), (-1.0, 1.0), (-1.0, 1.0)]
+TM_CANVAS = (432, 288)
+TM_P_DES = [0.5, 0.5, 0.5]
+
+
+def black_dot(rgb):
+    """centroid (column, row) of the round black marker inside the axes box: the compact blob among the black pixels (the
+    path is a 1.5-pixel line, the dot a disc of 4.5)"""
+    from scipy import ndimage
+    mask = colour_masks(rgb)["k"] & box_mask(rgb)
+    density = ndimage.uniform_filter(mask.astype(float), size=5)                   # a thin line fills 5 x 5 far less
+    r0, c0 = np.unravel_index(int(np.argmax(density)), density.shape)
+    assert density[r0, c0] * 25 >= 8, "no dot"
+    rows, cols = np.nonzero(mask)
+    near = (rows - r0) ** 2 + (cols - c0) ** 2 <= 3.5 ** 2
+    return np.array([cols[near].mean() + 0.5, rows[near].mean() + 0.5])
+
+
+def collect_frames(out, html_png, stored_png=None):
     """pixel lists of the frame_3d figures -> out["f3d_<constraint>_<controller>_<colour>"] ([n, 2] int16, column and row
     of each pixel)"""
+    if stored_png is not None:
+        for kind, cell in TM_FRAMES.items():
+            rgb = stored_png(TM_NOTEBOOK, cell)
+            assert rgb.shape[:2] == (309, 453)
+            for c, px in digitise(rgb).items():
+                out["f3d_tm_point_%s_%s" % (kind, c)] = np.floor(px).astype(np.int16)
+            out["f3d_tm_point_%s_dot" % kind] = black_dot(rgb)
     for (which, kind), cell in DQC_FRAMES.items():
         rgb = html_png(DQC_NOTEBOOK, cell)
         assert rgb.shape[:2] == (480, 640)

@@ -292,3 +292,42 @@ def frame_error_frame_pins(fk, which, q_sim):
                                               limits=frame3d_pins.DQTM_LIMITS, width=frame3d_pins.DQTM_CANVAS[0],
                                               height=frame3d_pins.DQTM_CANVAS[1])
     return frame3d_pins.deviations(frame3d_pins.stored_frames(FIGS, which, "qp", prefix="f3d_dqtm_"), axes, curves, dots)
+
+
+def ur5_qp_point_skill(fk):
+    """ur5_transformation_matrix_comparison_of_controllers.ipynb cells 8, 9: the position error as three rows (gain 50),
+    the multidimensional joint limits and the joint-speed limits"""
+    t, q, dq = cs.MX.sym("t"), cs.MX.sym("q", 6), cs.MX.sym("dq", 6)
+    max_speed = np.pi / 5
+    cons = [cc.EqualityConstraint(label="Minimize_point_error", expression=np.array([0.5, 0.5, 0.5]) - fk["T_fk"](q)[:3, 3],
+                                  gain=50.0, constraint_type="soft"),
+            cc.SetConstraint(label="Joint_Limits", expression=q, set_min=np.array(fk["lower"]), set_max=np.array(fk["upper"])),
+            cc.VelocitySetConstraint(label="Joint_speed_limits", expression=q, set_min=-np.full(6, max_speed),
+                                     set_max=np.full(6, max_speed))]
+    return cc.SkillSpecification(label="Move to point", time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons)
+
+
+def simulate_ur5_joints(solve, clamp):
+    """cells 14 / 29: 1000 samples of 0.01 s from UR5_home (the pinv loop saturates the speeds at pi / 5, the QP's
+    carries them as rows).  Returns q_sim [1000, 6]."""
+    n, dt, max_speed = 1000, 0.01, np.pi / 5
+    q_sim = np.zeros((n, 6))
+    q_sim[0] = UR5_HOME
+    for i in range(n - 1):
+        dq = solve(dt * i, q_sim[i])
+        q_sim[i + 1] = q_sim[i] + (np.clip(dq, -max_speed, max_speed) if clamp else dq) * dt
+    return q_sim
+
+
+def ur5_point_frame_pins(fk, kind, q_sim):
+    """cells 17 / 33 of that notebook: the frame_3d figure of the point run of `kind` ("qp" / "pinv"); the crop offset of
+    the stored image from the black dot at p_des (tests/golden/frame3d_pins.py)"""
+    import frame3d_pins as f3
+    T = np.array([fk["chain"].fk_numeric(q) for q in q_sim])
+    axes, curves, dots = f3.axes_of(T[:, :3, 3], T[:, :3, :3], p_des=f3.TM_P_DES, limits=f3.TM_LIMITS,
+                                    width=f3.TM_CANVAS[0], height=f3.TM_CANVAS[1])
+    offset = FIGS["f3d_tm_point_%s_dot" % kind] - axes.pixels(dots["k"])[0]
+    assert 7.2 <= offset[0] <= 14.0 and 7.2 <= offset[1] <= 14.0, offset       # (the pad, plus what the labels overhang)
+    stored = {c: v - offset for c, v in f3.stored_frames(FIGS, "point", kind, prefix="f3d_tm_").items()}
+    return f3.deviations(stored, axes, curves, dots, dot_radius=5.0)
+

@@ -390,3 +390,28 @@ def test_oracle_retraces_the_qp_frame_figures_of_the_frame_error_notebook(which)
     for colour, (worst, covered, n) in dev.items():
         assert n > 100 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (which, dev)
 
+
+@pytest.mark.parametrize("kind", ["qp", "pinv"])
+def test_oracle_retraces_the_ur5_point_frame_figures(kind):
+    """ur5_transformation_matrix_comparison_of_controllers.ipynb cells 17 / 33 (`frame_3d` of the point runs of the
+    ReactiveQPController - the only figure that run has - and of the PseudoInverseController): inline backend, 432 x 288
+    canvas cropped "tight" to 453 x 309; the crop offset is read off the black dot at p_des, the view limits (-1, 1)^3 are
+    the cells' own; one pixel = 6 mm"""
+    from casclik_amd import skills
+    fk = skills.ur5()
+    if kind == "qp":
+        spec = cf.ur5_qp_point_skill(fk)
+
+        def solve(t, q):
+            dq, _, _, status = clik_oracle.qp_solve_batch(spec, float(t), q[None, :])
+            assert status[0] == 0
+            return dq[0]
+    else:
+        spec = cf.ur5_pinv_point_skill(fk)
+
+        def solve(t, q):
+            return clik_oracle.pinv_solve_batch(spec, None, float(t), q[None, :])[0][0]
+    dev = cf.ur5_point_frame_pins(fk, kind, cf.simulate_ur5_joints(solve, clamp=(kind == "pinv")))
+    for colour, (worst, covered, n) in dev.items():
+        assert n > 50 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (kind, dev)
+

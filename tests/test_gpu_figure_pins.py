@@ -69,6 +69,24 @@ def test_hip_pinv_reproduces_the_ur5_figure(ur5_fk):
         assert n >= 15 and worst < PIXELS, (curve, worst, n)
 
 
+@pytest.mark.parametrize("kind", ["qp", "pinv"])
+def test_hip_controllers_retrace_the_ur5_point_frame_figures(ur5_fk, kind):
+    """the same notebook's frame_3d figures, cells 17 (the ReactiveQPController's point run - three error rows, the
+    multidimensional joint limits, joint-speed rows: the only figure that run has) and 33 (the pinv run of cell 32):
+    tool path and frame-axis tips, 1 px = 6 mm, the stored image's crop offset read off the black dot at p_des"""
+    if kind == "qp":
+        ctrl = cc.ReactiveQPController(skill_spec=cf.ur5_qp_point_skill(ur5_fk))
+    else:
+        ctrl = cc.PseudoInverseController(skill_spec=cf.ur5_pinv_point_skill(ur5_fk))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    q_sim = cf.simulate_ur5_joints(lambda t, q: ctrl.solve(t, q)[0].toarray()[:, 0], clamp=(kind == "pinv"))
+    dev = cf.ur5_point_frame_pins(ur5_fk, kind, q_sim)
+    for colour, (worst, covered, n) in dev.items():
+        assert n > 50 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (kind, dev)
+    print("ur5 point %s frame_3d figure: %s" % (kind, {c: (round(v[0], 2), round(v[1], 2)) for c, v in dev.items()}))
+
+
 def test_hip_qp_reproduces_the_ur5_input_experiment_figure(ur5_fk):
     """ur5_input_experiment.ipynb cells 15-17 with the notebook's own calls: `setup_initial_problem_solver()`,
     `solve_initial_problem(time_var0=0, robot_var0=UR5_home, input_var0=[0, 0, 0])[-1]`, then 4500 ticks of
