@@ -398,19 +398,16 @@ __device__ __forceinline__ void sincos_fast(const double x, double& sn, double& 
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * pc);
-    // quadrant: swap on odd k, signs from bits 1 of k and k + 1 - as BIT operations (v_bfi_b32 / v_xor_b32), not
-    // selects: four v_cndmask_b32 in a row on one VCC cost a lone wave some 60 cycles instead of 16
-    // (tools/gen_probe_banks.py, profiles/r4_issue_forms_probe.txt: "v_cmp vcc + 2 cndmask" 48 cycles against 12.4
-    // through an SGPR pair), and seven joints make seven such rows per tick
-    const unsigned q = (unsigned)(int)k;
-    const unsigned m = 0u - (q & 1u);
-    const unsigned sl = (unsigned)__double2loint(sr), sh = (unsigned)__double2hiint(sr);
-    const unsigned cl = (unsigned)__double2loint(cr), ch = (unsigned)__double2hiint(cr);
-    const unsigned s0l = (cl & m) | (sl & ~m), c0l = (sl & m) | (cl & ~m);
-    const unsigned s0h = ((ch & m) | (sh & ~m)) ^ ((q & 2u) << 30);
-    const unsigned c0h = ((sh & m) | (ch & ~m)) ^ (((q + 1u) & 2u) << 30);
-    sn = __hiloint2double((int)s0h, (int)s0l);
-    cs = __hiloint2double((int)c0h, (int)c0l);
+    // quadrant: swap on odd k, signs from bits 1 of k and k + 1.  (As selects.  The same through bit operations -
+    // v_bfi_b32 / v_xor_b32 on the halves, no VCC - was measured in round 4 after tools/gen_probe_banks.py showed two
+    // v_cndmask_b32 in a row on one VCC costing a lone wave 48 cycles instead of 12: bit-identical results, 24
+    // instructions fewer per team wave, headline unchanged at 3.96 us, lane kernel 2 % SLOWER (10.5 against 10.25 us at
+    // 131072, 69 against 68 us at 1 M) - the selects stay.)
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? cr : sr;
+    const double c0 = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
 __device__ __forceinline__ void sincos_joint(const double x, double& sn, double& cs)
