@@ -11,6 +11,7 @@ run fuzz_team_20_3      tools/fuzz_team.py 20 3
 run fuzz_qp_box_16_9    tools/fuzz_qp_box.py 16 9
 run fuzz_qp_mixed_30_13 tools/fuzz_qp_mixed.py 30 13
 run fuzz_qp_dynamic_200_5 tools/fuzz_qp_dynamic.py 200 5
+run fuzz_qp_wide_40_0 tools/fuzz_qp_wide.py 40 0 96
 s=$out/r4_fuzz_summary.txt
 {
 echo "# Round 4 randomised parity sweeps on one MI355X (final kernels; every tool holds every instance to the stated rule"
@@ -29,6 +30,7 @@ done
 echo; echo "## tools/fuzz_qp_box.py  (log fuzz_qp_box_16_9)"; tail -1 $out/fuzz_qp_box_16_9.log
 echo; echo "## tools/fuzz_qp_mixed.py  (log fuzz_qp_mixed_30_13)"; grep "skipped" $out/fuzz_qp_mixed_30_13.log | cut -c1-200; tail -1 $out/fuzz_qp_mixed_30_13.log
 echo; echo "## tools/fuzz_qp_dynamic.py  (log fuzz_qp_dynamic_200_5)"; tail -1 $out/fuzz_qp_dynamic_200_5.log
+echo; echo "## tools/fuzz_qp_wide.py  (log fuzz_qp_wide_40_0)"; tail -1 $out/fuzz_qp_wide_40_0.log
 echo; echo "## tools/fuzz_qp_mixed.py, every skill of the sweep"; grep -E "^ *[0-9]+ (ur5|iiwa)" $out/fuzz_qp_mixed_30_13.log | cut -c1-200
 echo; echo "## tools/fuzz_qp_box.py, every skill of the sweep"; grep -E "^ *[0-9]+ (ur5|iiwa)" $out/fuzz_qp_box_16_9.log | cut -c1-200
 } > $s
