@@ -88,7 +88,8 @@ def random_skill(rng, fk, n):
                                             gain=gain(6 + len(jw)), priority=pr))
     # random smooth expression trees of the joints, the tool position and time (generated code)
     leaves = [q[j] for j in range(n)] + [p[0], p[1], p[2], T[2, 2], cs.sin(0.5 * t)]
-    rexpr = cs.vertcat(random_expression(rng, leaves, 3), random_expression(rng, leaves, 3))
+    angles = os.environ.get("FUZZ_ANGLES", "0") == "1"      # (also atan2 / asin / acos / atan / tanh / fmin / fmax; another rng stream)
+    rexpr = cs.vertcat(random_expression(rng, leaves, 3, angles), random_expression(rng, leaves, 3, angles))
     pool.append(lambda pr: cc.EqualityConstraint("tree", rexpr - np.array([0.3, -0.2]), gain=gain(2), priority=pr))
     nt = int(rng.integers(2, 6))
     picks = rng.choice(len(pool), size=nt, replace=False)
