@@ -665,18 +665,21 @@ def compact_entry(e):
     out = {"us": _r(e["ms_per_step"] * 1e3, 3), "G_per_s": _r(e["value"] / 1e9, 3), "kernel": e["config"].get("kernel"),
            "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic")}
     if r.get("traffic_source"):
-        out["pmc"] = r["traffic_source"].replace("profiles/", "").split("_k")[0].split("_qp_static")[0]   # file#case
+        out["pmc"] = r["traffic_source"].split("#")[-1].split("_k")[0].split("_qp_static")[0]   # case in profiles/r4_counters.json
+    elif "resident" not in e.get("name", ""):
+        # (no counter pass for this entry: the rollouts, config 4 at 4096 - the resident entries keep their explicit nulls)
+        out = {k: v for k, v in out.items() if v is not None}
     c = e.get("cpu_baseline")
     if c and "value" in c:
         out["cpu_M_per_s"] = _r(c["value"] / 1e6, 2)
-        out["cpu_cores"] = c["cores"]
     if "allgather" in e:
         out["allgather"] = e["allgather"]
     return out
 
 
 NOTES = ("us = wall per tick; roofline = 172 B/instance-step (QP 220) / HIP-event tick time vs 8 TB/s; fp64_frac = executed "
-         "fp64 flops (PMC, profiles/) vs 78.6 TF; extras = other BASELINE configs, rollouts, resident ticks; --full 1 = details")
+         "fp64 flops (PMC) vs 78.6 TF; pmc = case in profiles/r4_counters.json; cpu_M_per_s = the C port on cpu_baseline.cores "
+         "threads; --full 1 = details")
 
 
 def init_ranks(world, rank, dev, shared_gpu):
@@ -786,7 +789,10 @@ def main():
         # hot-starts every solve after the first, reactive_qp.py:491-513: the steady state of a control loop)
         # ... and the on-device rollouts of both controllers (solve -> clamp -> integrate, K ticks per launch: the
         # notebooks' simulation loops; `roofline.frac` is null for them)
+        # (config 4 also at 4096 instances: cold ticks of batches below one block per CU run four waves per 64 instances,
+        # each with its own start of the active-set passes - clik_qp_static.hpp, FOLIO)
         for (wl, b, hot, tpl) in (("pose", 4096, 0, 1), ("qp", 16384, 0, 1), ("pose", 16384, 0, 1), ("qp", 16384, 1, 1),
+                                  ("qp", 4096, 0, 1),
                                   ("stack", 131072, 0, 1), ("qp", 131072, 0, 1), ("stack", 1048576, 0, 1),
                                   ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
             up = lambda v: -(-max(v, tpl) // tpl) * tpl              # noqa: E731  (a whole number of launches)

@@ -519,6 +519,18 @@ class ReactiveQPController(BaseController):
         if (getattr(self, "value_kernel", None) and os.environ.get("CLIK_QP_LANES", "")[:1] == "4" and int(batch) <= 16384
                 and self._lib.clik_qp_is_box_family(self._handle)):
             name += "/quad4"         # (experiment: four lanes per instance, clik_qp_static.hpp)
+        elif getattr(self, "value_kernel", None) and self._lib.clik_qp_is_box_family(self._handle):
+            # COLD ticks of small batches: four waves per 64 instances, each with its own start of the active-set passes
+            # (clik_qp_static.hpp, FOLIO); a hot-started tick keeps the lone-wave kernel
+            folio = os.environ.get("CLIK_QP_FOLIO", "")[:1]
+            try:
+                import torch
+                cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            except Exception:
+                cus = 0
+            blocks = (int(batch) + 63) // 64
+            if folio != "0" and blocks <= (cus if folio == "1" else cus - 1):
+                name += "/folio4"
         return name
 
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,

@@ -1008,11 +1008,46 @@ __device__ __forceinline__ void qp_sym_sweep(double (&S)[N * (N + 1) / 2], const
     S[tri(K, K)] = fma(m, -p - S[tri(K, K)], S[tri(K, K)]);
 }
 
-template <int N, bool QUAD = false>
+// FOLIO (round 4, small batches, cold start): FOUR WAVES of a block - one per SIMD of the CU - work on the SAME 64
+// instances, each with its own START of the active-set passes (number, order and relaxation of the Gauss-Seidel sweeps:
+// different instruction streams cost nothing across waves, unlike across the lanes of QUAD), and an instance is done as
+// soon as ANY of them has reached its KKT point.  The tick of a 16384-instance batch is its slowest instance: with the
+// sweeps (forward x 12 | forward x 6 | reverse x 6 | over-relaxed 1.5 x 18) the slowest instance of the bench inputs needs
+// 4.55 us of sweeps + passes instead of 6.25 (numpy model of the iteration, tools/qp_portfolio_study.py's functions).
+// Which wave's answer is taken must not depend on timing: every finish is recorded as a KEY = virtual time (sweeps +
+// 8 per pass: a pass costs about eight sweeps) x 4 + strategy, smallest key wins (atomic minimum in LDS); a wave gives an
+// instance up only when a key SMALLER than any it could still produce has been recorded, so the strategy that would
+// record the smallest key always gets to record it, whatever the interleaving.
+struct QpFolio {
+    int* key_slot;     // LDS word of this lane's instance (initialised to INT_MAX)
+    int sid;           // strategy 0 ... 3 (low bits of the key: ties go to the lower one)
+    int sweeps;        // Gauss-Seidel start sweeps
+    int kind;          // 0 forward, 1 reverse order, 2 forward with over-relaxation `omega`
+    double omega;
+};
+constexpr int kFolioPassUnits = 8;
+
+template <int N, bool REV, bool RELAX>
+__device__ __forceinline__ void qp_box_start_sweep(const double (&Pm)[N * (N + 1) / 2], const double (&ip)[N],
+                                                   const double (&lb)[N], const double (&ub)[N], double (&x)[N],
+                                                   double (&res)[N], const double omega)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int a = REV ? N - 1 - k : k;
+        const double xa = fmin(fmax(RELAX ? x[a] + omega * (res[a] * ip[a]) : fma(res[a], ip[a], x[a]), lb[a]), ub[a]);
+        const double dl = xa - x[a];
+        x[a] = xa;
+#pragma unroll
+        for (int b = 0; b < N; ++b) res[b] = fma(-Pm[a >= b ? tri(a, b) : tri(b, a)], dl, res[b]);
+    }
+}
+
+template <int N, bool QUAD = false, bool FOLIO = false>
 __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
                                           const double (&lb)[N], const double (&ub)[N], const int max_pass,
                                           const bool valid, double (&x)[N], int32_t* hot, const bool use_hot,
-                                          const double omega = 1.0)
+                                          const double omega = 1.0, const QpFolio* fo = nullptr, int* my_key = nullptr)
 {
     constexpr int NT = N * (N + 1) / 2;
     constexpr int kOne = 0x3ff00000;        // high word of 1.0: the masks below are doubles 1.0 / 0.0 kept as that word
@@ -1057,6 +1092,19 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             for (int b = 0; b < N; ++b) sacc = fma(-Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
             res[a] = sacc;
         }
+        if constexpr (FOLIO) {
+            // (wave-uniform choice: the four waves of the block take different branches)
+            if (fo->kind == 1) {
+#pragma unroll 1
+                for (int sweep = 0; sweep < fo->sweeps; ++sweep) qp_box_start_sweep<N, true, false>(Pm, ip, lb, ub, x, res, 1.0);
+            } else if (fo->kind == 2) {
+#pragma unroll 1
+                for (int sweep = 0; sweep < fo->sweeps; ++sweep) qp_box_start_sweep<N, false, true>(Pm, ip, lb, ub, x, res, fo->omega);
+            } else {
+#pragma unroll 1
+                for (int sweep = 0; sweep < fo->sweeps; ++sweep) qp_box_start_sweep<N, false, false>(Pm, ip, lb, ub, x, res, 1.0);
+            }
+        } else {
 #pragma unroll 1
         for (int sweep = 0; sweep < CLIK_QP_BOX_SWEEPS; ++sweep) {
 #pragma unroll
@@ -1068,6 +1116,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
 #pragma unroll
                 for (int b = 0; b < N; ++b) res[b] = fma(-Pm[a >= b ? tri(a, b) : tri(b, a)], dl, res[b]);
             }
+        }
         }
     }
 #pragma unroll
@@ -1097,6 +1146,15 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
     bool quad_over = false;      // (QUAD: some lane of this lane's quad has finished)
     bool done = !valid | empty;
     int status = empty ? 2 : 1;
+    bool gave_up = false;        // (FOLIO: another strategy has this lane's instance)
+    int seen = 0x7fffffff, mine = 0;
+    if constexpr (FOLIO) {
+        if (valid & empty) {     // (infeasible bounds: every strategy says so at once)
+            mine = (fo->sweeps << 2) | fo->sid;
+            (void)__hip_atomic_fetch_min(fo->key_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        seen = *(volatile int*)fo->key_slot;
+    }
 #if CLIK_QP_BOX_SWEEP
     // the swept tableau of the starting partition: one sweep per state that is free in SOME lane of the wave
     double S[NT];
@@ -1112,7 +1170,17 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
     // a flag test two more, and a lone wave pays every one of them in full)
 #pragma unroll 1
     for (int pass = 0; pass < max_pass; ++pass) {
+        if constexpr (FOLIO) {
+            // the key this pass would record at its end; a smaller one on record: nothing this strategy can still do wins
+            // (`seen`: the record as read at the end of the previous pass - the read's latency hides behind that pass's
+            // tail; an older value only delays giving up, never the choice of the answer)
+            const int kfin = ((fo->sweeps + kFolioPassUnits * (pass + 1)) << 2) | fo->sid;
+            const bool beaten = !done & (seen < kfin);
+            gave_up = gave_up | beaten;
+            done = done | beaten;
+        }
         if (__ballot(!(done | quad_over)) == 0ull) break;
+        const bool done_before = done;
         // Newton direction on the free states
         double d[N];
 #if CLIK_QP_BOX_SWEEP
@@ -1199,6 +1267,15 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         for (int a = 0; a < N; ++a) held[a] = (release & (c[a] == worst)) ? 0 : held[a];
 #endif
         done = done | (!quad_over & !blocked & !(worst > 0.0));
+        if constexpr (FOLIO) {
+            if (done & !done_before) {
+                mine = ((fo->sweeps + kFolioPassUnits * (pass + 1)) << 2) | fo->sid;
+                (void)__hip_atomic_fetch_min(fo->key_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            seen = *(volatile int*)fo->key_slot;
+        } else {
+            (void)done_before;
+        }
         if constexpr (QUAD) {
             // a lane that has finished ends its whole quad (mov_dpp quad_perm broadcasts of the flag)
             const int dn = (done & valid & !empty) ? 1 : 0;
@@ -1206,6 +1283,17 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
                             __builtin_amdgcn_mov_dpp(dn, 0xAA, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(dn, 0xFF, 0xf, 0xf, true);
             quad_over = quad_over | (any != 0);
         }
+    }
+    if constexpr (FOLIO) {
+        if (valid & !done) {      // (pass cap: on record all the same, behind every strategy that converged)
+            mine = ((fo->sweeps + kFolioPassUnits * (max_pass + 1)) << 2) | fo->sid;
+            (void)__hip_atomic_fetch_min(fo->key_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        *my_key = mine;
+        (void)gave_up;
+    } else {
+        (void)seen;
+        (void)mine;
     }
 #if CLIK_QP_BOX_SWEEP
     if (!empty) {
@@ -1652,13 +1740,13 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
-template <const ShapeDesc& SD, int SSTR = WAVE, bool QUAD = false>
+template <const ShapeDesc& SD, int SSTR = WAVE, bool QUAD = false, bool FOLIO = false>
 __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
                                               const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
                                               const int lane, const bool valid, double* slots,
                                               double (&v)[SD.n], double (&sl)[QpLayout<SD>::NSA],
                                               int32_t* hot, const bool use_hot, const double omega = 1.0,
-                                              double* jstash = nullptr)
+                                              double* jstash = nullptr, const QpFolio* fo = nullptr, int* my_key = nullptr)
 {
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
@@ -1816,7 +1904,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
 #ifdef CLIK_QP_BOX_PN
         int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
 #else
-        int status = qp_box_pas<N, QUAD>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot, omega);
+        int status = qp_box_pas<N, QUAD, FOLIO>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot, omega, fo, my_key);
 #endif
         if (!valid) status = 0;
         if (jstash != nullptr) {
@@ -2241,6 +2329,81 @@ __global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_quad_values_kern
     }
 }
 
+// ... with four WAVES per 64 instances, each with its own start of the passes (FOLIO, see qp_box_pas): cold ticks of
+// batches up to one block per CU.  Every wave runs the whole tick of its lanes' instances; what it finished it leaves in
+// LDS with the key it recorded, and after the block's barrier the first wave stores, per instance, the answer under the
+// smallest key.
+#ifndef CLIK_QP_FOLIO_DEFAULT
+#define CLIK_QP_FOLIO_DEFAULT 1
+#endif
+#ifndef CLIK_QP_FOLIO_WAVES
+#define CLIK_QP_FOLIO_WAVES 4
+#endif
+constexpr int kFolioWaves = CLIK_QP_FOLIO_WAVES;     // (1 and 2: measuring switches - the bookkeeping alone; the pair reverse x 6 | relaxed x 18)
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const TickArgs tk,
+    const int same_start)
+{
+    using LY = QpLayout<SD>;
+    static_assert(LY::BOX, "box family only");
+    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS, NSA = LY::NSA;
+    constexpr QpImg<SD> kValues = IMGV::value;
+    __shared__ int key_min[WAVE];
+    const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    if (w == 0) key_min[lane] = 0x7fffffff;
+    __syncthreads();
+    const long long inst = (long long)blockIdx.x * WAVE + lane;
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
+    }
+    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    // strategy 0 is the lone-wave kernel's own start (when it wins, the answer is that kernel's to the bit)
+    QpFolio fo;
+    fo.key_slot = &key_min[lane];
+    fo.sid = w;
+    // (same_start: a measuring switch, CLIK_QP_FOLIO_SAME=1 - all four waves start like the lone-wave kernel)
+    const int strat = (kFolioWaves == 2) ? w + 2 : w;
+    fo.sweeps = (strat == 0 || same_start) ? CLIK_QP_BOX_SWEEPS : ((strat == 3) ? 18 : 6);
+    fo.kind = same_start ? 0 : ((strat == 2) ? 1 : ((strat == 3) ? 2 : 0));
+    fo.omega = 1.5;
+    double priv[LY::SLOTS];
+    double v[N], sl[NSA];
+    int32_t hot_word = 0;
+    int my_key = 0;
+    const int status = qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
+                                                          &hot_word, false, 1.0, nullptr, &fo, &my_key);
+    __syncthreads();             // (every finish of the block is on record)
+    // the wave whose key is the smallest on record stores what it holds in its registers
+    if (valid && my_key != 0 && key_min[lane] == my_key) {
+        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
+        if constexpr (NX > 0) {
+            if (dx != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
+            }
+        }
+        if constexpr (NS > 0) {
+            if (slack_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+            }
+        }
+        if (status_out != nullptr) status_out[inst] = status;
+        if (hot_set != nullptr) hot_set[inst] = hot_word;
+    }
+}
+
 // ... and its on-device rollout (see qp_rollout_static_kernel): state, working set and Runge-Kutta bookkeeping in
 // registers from tick to tick, rows loaded once and stored once by the lane itself
 template <const ShapeDesc& SD, class IMGV, bool RK>
@@ -2374,6 +2537,28 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
 {
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     if constexpr (QpLayout<SD>::BOX) {
+        // (CLIK_QP_FOLIO=0 / 1: the four-waves-per-64-instances kernel for cold ticks of small batches)
+        // default: FEWER blocks than CUs (up to 16320 instances on 256 CUs) - measured per tick against the lone-wave
+        // kernel: 10.2 / 11.0 us at 1024 instances, 10.4 / 12.0 at 4096, 11.0 / 12.0 at 8192, 11.2 / 12.1 at 12288, the same
+        // at 256 and 2048, and no gain at 16384 (11.2 - 11.3 against 11.3: four identical waves per CU cost 12.2 - 12.5,
+        // the different starts win 1.0 - 1.2 of that back); CLIK_QP_FOLIO=0 never, =1 also at one block per CU
+        // (profiles/r4_qp_wave_portfolio.txt)
+        static const int folio = []() {
+            const char* e = getenv("CLIK_QP_FOLIO");
+            return e ? ((e[0] == '1') ? 2 : 0) : ((CLIK_QP_FOLIO_DEFAULT != 0) ? 1 : 0);
+        }();
+        static const int folio_same = []() { const char* e = getenv("CLIK_QP_FOLIO_SAME"); return (e && e[0] == '1') ? 1 : 0; }();
+        static const int folio_blocks = []() {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+            return cus;
+        }();
+        if (folio != 0 && !use_hot && (long long)grid <= (long long)(folio == 2 ? folio_blocks : folio_blocks - 1)) {
+            hipLaunchKernelGGL((qp_solve_static_box_folio_values_kernel<SD, IMGV>), dim3(grid), dim3(kFolioWaves * WAVE), 0,
+                               stream, q, y, dq, slack, status, B, x, dx, hot_set, tk, folio_same);
+            return hipGetLastError();
+        }
         static const bool quad = []() { const char* e = getenv("CLIK_QP_LANES"); return e && e[0] == '4'; }();
         if (quad && B <= 16384) {
             hipLaunchKernelGGL((qp_solve_static_box_quad_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0, stream, q,

@@ -518,7 +518,7 @@ def test_qp_value_specialised_kernel(iiwa_fk):
     for extra in ({}, {"slack_var_weights": ws}):
         val = _controller(spec, **extra)
         img = _controller(spec, options={"function_opts": {"jit_values": False}}, **extra)
-        assert val.value_kernel and val.kernel_variant(1000).endswith("/v") and not img.kernel_variant(1000).endswith("/v")
+        assert val.value_kernel and "/v" in val.kernel_variant(1000) and "/v" not in img.kernel_variant(1000)
         dq, _, slack, status = val.solve_batch(0.0, Q, input_var=Y)
         dq2, _, slack2, status2 = img.solve_batch(0.0, Q, input_var=Y)
         assert np.array_equal(status, status2) and (status == 0).all()
@@ -785,3 +785,37 @@ def test_twenty_constraints_in_one_skill(iiwa_fk):
     rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(qspec, 0.3, Q, Y=Y)
     assert np.array_equal(status, rstatus) and (rstatus == 0).all()
     assert qp_close(dq, rdq) and qp_close(slack, rslack), (_rel(dq, rdq).max(), _rel(slack, rslack).max())
+
+
+def test_cold_ticks_of_small_batches_run_four_waves_per_64_instances(iiwa_fk, monkeypatch):
+    """clik_qp_static.hpp FOLIO: below one block per CU the cold tick of a box-family QP runs four waves on the same 64
+    instances, each with its own start of the active-set passes (sweep count / order / relaxation), and takes per instance
+    the answer recorded under the smallest KEY (virtual time x 4 + strategy) - not the first to arrive.  So: the same
+    bits on every run; the oracle's statuses and minimisers; the lone-wave kernel's answer to rounding (its own start is
+    strategy 0: most instances are bit-equal), and a hot-started tick - which keeps the lone-wave kernel - agrees too."""
+    import torch
+    from oracle import clik_oracle
+    B = 4096 + 37
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=21, distribution="mixed")
+    ctrl = cc.ReactiveQPController(skill_spec=skills.qp_skill(iiwa_fk))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    assert ctrl.kernel_variant(B).endswith("/folio4") and not ctrl.kernel_variant(1 << 17).endswith("/folio4")
+    runs = [ctrl.solve_batch(0.0, Q, input_var=Y, use_hot=False) for _ in range(4)]
+    for r in runs[1:]:
+        assert np.array_equal(r[0], runs[0][0], equal_nan=True) and np.array_equal(r[2], runs[0][2], equal_nan=True)
+        assert np.array_equal(r[3], runs[0][3])
+    dq, _, slack, status = runs[0]
+    n = 1024
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(skills.qp_skill(iiwa_fk), 0.0, Q[:n], Y=Y[:n])
+    assert np.array_equal(status[:n], rstatus)
+    ok = rstatus == 0
+    assert qp_close(np.where(ok[:, None], dq[:n], 0.0), np.where(ok[:, None], rdq, 0.0))
+    monkeypatch.setenv("CLIK_QP_FOLIO", "0")          # (read once per process by the launcher: a fresh controller does not
+    #                                                    re-read it - compare through a hot-started tick instead)
+    hot = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot, use_hot=False)
+    dq_h, _, slack_h, status_h = ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot, use_hot=True)
+    assert np.array_equal(status_h, status)
+    good = status == 0
+    assert _rel(dq_h[good], dq[good]).max() < 1e-9 and _rel(slack_h[good], slack[good]).max() < 1e-9
