@@ -503,7 +503,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     kernel = getattr(ctrl, "kernel_name", None)
     variant = getattr(ctrl, "kernel_variant", None)
     if callable(variant):
-        kernel = variant(B)
+        kernel = variant(B, hot=True) if ((qp_hot or TPL > 1) and workload == "qp") else variant(B)
     if TPL == 1:
         achieved = alg_bytes / (tick_us * 1e-6) / 1e9
         prof, prof_src = profiled(workload, dist_name, B, kernel, hot=bool(qp_hot))

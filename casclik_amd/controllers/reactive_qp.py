@@ -512,8 +512,9 @@ class ReactiveQPController(BaseController):
         return cs.DM(dx[0].reshape(-1, 1)), res_slack
 
     # -- per tick -----------------------------------------------------------------
-    def kernel_variant(self, batch):
-        """name of the kernel a batch of ``batch`` instances gets ("/v": with the skill's numbers compiled in)"""
+    def kernel_variant(self, batch, hot=False):
+        """name of the kernel a batch of ``batch`` instances gets ("/v": with the skill's numbers compiled in; ``hot``:
+        for a hot-started tick)"""
         import os
         name = self.kernel_name + ("/v" if getattr(self, "value_kernel", None) else "")
         if (getattr(self, "value_kernel", None) and os.environ.get("CLIK_QP_LANES", "")[:1] == "4" and int(batch) <= 16384
@@ -529,7 +530,7 @@ class ReactiveQPController(BaseController):
             except Exception:
                 cus = 0
             blocks = (int(batch) + 63) // 64
-            if folio != "0" and blocks <= (cus if folio == "1" else cus - 1):
+            if folio != "0" and blocks <= cus and not hot:
                 name += "/folio4"
         return name
 

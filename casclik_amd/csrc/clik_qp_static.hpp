@@ -1207,8 +1207,21 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             M[tri(a, a)] = fma(hm, 1e30, Pm[tri(a, a)]);
             d[a] = fma(-hm, gr[a], gr[a]);
         }
+        int seen_mid = 0x7fffffff;
+        if constexpr (FOLIO) seen_mid = *(volatile int*)fo->key_slot;       // (consumed after the factorisation)
         ldl_factor_s<N>(M, rd);
         ldl_solve_s<N>(M, rd, d);
+        if constexpr (FOLIO) {
+            // a second look half-way through the pass: a wave whose last instances have just been finished elsewhere
+            // leaves now, not a pass later
+            const int kfin = ((fo->sweeps + kFolioPassUnits * (pass + 1)) << 2) | fo->sid;
+            const bool beaten = !done & (seen_mid < kfin);
+            gave_up = gave_up | beaten;
+            done = done | beaten;
+            if (__ballot(!(done | quad_over)) == 0ull) break;
+        } else {
+            (void)seen_mid;
+        }
 #endif
         // first bound hit along x - alpha d: alpha = min(1, room_a / d_a).  The quotient needs no correct rounding (a
         // blocked step ends on no face minimum, and the states that land are snapped onto their bounds): hardware
@@ -2352,9 +2365,13 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS, NSA = LY::NSA;
     constexpr QpImg<SD> kValues = IMGV::value;
     __shared__ int key_min[WAVE];
+    CLIK_BODY_BEGIN();
     const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     if (w == 0) key_min[lane] = 0x7fffffff;
     __syncthreads();
+#ifdef CLIK_QP_FOLIO_IDLE
+    if (w != 0) return;          // (measuring switch: the block shape alone - the other three waves leave at once)
+#endif
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;
@@ -2402,6 +2419,7 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
         if (status_out != nullptr) status_out[inst] = status;
         if (hot_set != nullptr) hot_set[inst] = hot_word;
     }
+    CLIK_BODY_END();
 }
 
 // ... and its on-device rollout (see qp_rollout_static_kernel): state, working set and Runge-Kutta bookkeeping in
@@ -2538,10 +2556,11 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
     const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
     if constexpr (QpLayout<SD>::BOX) {
         // (CLIK_QP_FOLIO=0 / 1: the four-waves-per-64-instances kernel for cold ticks of small batches)
-        // default: FEWER blocks than CUs (up to 16320 instances on 256 CUs) - measured per tick against the lone-wave
-        // kernel: 10.2 / 11.0 us at 1024 instances, 10.4 / 12.0 at 4096, 11.0 / 12.0 at 8192, 11.2 / 12.1 at 12288, the same
-        // at 256 and 2048, and no gain at 16384 (11.2 - 11.3 against 11.3: four identical waves per CU cost 12.2 - 12.5,
-        // the different starts win 1.0 - 1.2 of that back); CLIK_QP_FOLIO=0 never, =1 also at one block per CU
+        // default: up to ONE block per CU (16384 instances on 256 CUs) - measured per tick against the lone-wave kernel:
+        // 10.2 / 11.0 us at 1024 instances, 10.4 / 12.0 at 4096, 11.0 / 12.0 at 8192, 11.2 / 12.1 at 12288, the same at 256
+        // and 2048, 10.85 / 11.3 at 16384 (there four waves per CU slow each other by 12 % - per-wave stamps,
+        // tools/stamp_folio.py: four identical waves cost 12.2 - 12.5 us - and the different starts win 1.4 - 1.6 back, the
+        // last 0.4 of it through the second look half-way through a pass); CLIK_QP_FOLIO=0 never
         // (profiles/r4_qp_wave_portfolio.txt)
         static const int folio = []() {
             const char* e = getenv("CLIK_QP_FOLIO");
@@ -2554,7 +2573,7 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
             return cus;
         }();
-        if (folio != 0 && !use_hot && (long long)grid <= (long long)(folio == 2 ? folio_blocks : folio_blocks - 1)) {
+        if (folio != 0 && !use_hot && (long long)grid <= (long long)folio_blocks) {
             hipLaunchKernelGGL((qp_solve_static_box_folio_values_kernel<SD, IMGV>), dim3(grid), dim3(kFolioWaves * WAVE), 0,
                                stream, q, y, dq, slack, status, B, x, dx, hot_set, tk, folio_same);
             return hipGetLastError();

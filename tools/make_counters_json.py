@@ -26,6 +26,9 @@ CASES_R4 = {  # round 4 (tools/profile_round4.sh): the hot-started QP tick gets 
     "pose_lanev_4096": ("pose_mixed_B4096_kPose6Iiwa/lanev", "kPose6Iiwa/lanev", 172, 4096),
     "stack_lanev_131072": ("stack_mixed_B131072_kStackIiwa/lanev", "kStackIiwa/lanev", 172, 131072),
     "qp_131072": ("qp_mixed_B131072_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 220, 131072),
+    # (tools/profile_round4b.sh: cold ticks up to one block per CU run four waves per 64 instances)
+    "qp_16384_folio": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v/folio4", "qp_static_kQpPoseIiwa/v/folio4", 220, 16384),
+    "qp_4096_folio": ("qp_mixed_B4096_qp_static_kQpPoseIiwa/v/folio4", "qp_static_kQpPoseIiwa/v/folio4", 220, 4096),
 }
 CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per instance, batch)
     "stack_team4v": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
