@@ -241,3 +241,99 @@ def collect_frames(out, html_png, stored_png=None):
 
 def stored_frames(figs, which, kind, prefix="f3d_"):
     return {c: figs["%s%s_%s_%s" % (prefix, which, kind, c)].astype(float) + 0.5 for c in COLOURS}
+
+
+# ---- a 2-D figure read the same way: pixels of each curve colour inside an axes frame --------------------------------
+# ur5_transformation_matrix_comparison_of_controllers.ipynb cell 31 (`common_plots.joints(sim_point_pinv)`): the six joint
+# positions (top axes) and the six clamped joint speeds (bottom axes) of the PseudoInverseController's point run, in
+# matplotlib's default colour cycle - the JOINT-space side of the run whose tool position cell 32 shows: which joints move
+# is the pseudo-inverse's choice.  Inline backend, 72 dpi; the axes frames are found in the image (their spines), the view
+# limits are the simulated data's range widened by 5 %; the legend covers the right end of the top axes (left out).
+TAB10 = [(31, 119, 180), (255, 127, 14), (44, 160, 44), (214, 39, 40), (148, 103, 189), (140, 86, 75)]
+TM_JOINTS_CELL = 31
+TM_JOINTS_LEGEND_FROM = 328          # first pixel column of the legend over the top axes
+
+
+def palette_masks(rgb, palette=TAB10, coverage=0.6, off=22.0):
+    """per palette colour the pixels that are a mix of white and that colour with at least `coverage` of the colour"""
+    v = rgb[..., :3].astype(float)
+    v = v * 255.0 if v.max() <= 1.5 else v
+    d = 255.0 - v
+    best_off = np.full(v.shape[:2], np.inf)
+    best = np.full(v.shape[:2], -1)
+    cov = np.zeros(v.shape[:2])
+    for k, c in enumerate(palette):
+        u = 255.0 - np.array(c, dtype=float)
+        a = np.clip((d * u).sum(axis=2) / (u * u).sum(), 0.0, 1.2)
+        o = np.sqrt(((d - a[..., None] * u) ** 2).sum(axis=2))
+        take = o < best_off
+        best_off[take], best[take], cov[take] = o[take], k, a[take]
+    return [(best == k) & (best_off < off) & (cov > coverage) for k in range(len(palette))]
+
+
+def frames_2d(rgb):
+    """[(top, bottom, left, right)] centres of the axes' spines, top axes first"""
+    v = rgb[..., :3].astype(float)
+    v = v * 255.0 if v.max() <= 1.5 else v
+    dark = v.max(axis=2) < 90.0
+    colsum = dark.sum(axis=0)
+    cols = np.nonzero(colsum > 0.6 * colsum.max())[0]
+    left, right = int(cols.min()), int(cols.max())
+    width = right - left + 1
+    rows = [y for y in range(dark.shape[0]) if dark[y, left:right + 1].sum() > 0.97 * width]
+    assert len(rows) % 2 == 0 and len(rows) >= 2, rows
+    return [(rows[2 * k] + 0.5, rows[2 * k + 1] + 0.5, left + 0.5, right + 0.5) for k in range(len(rows) // 2)]
+
+
+def collect_joint_figure(out, stored_png):
+    rgb = stored_png(TM_NOTEBOOK, TM_JOINTS_CELL)
+    frames = frames_2d(rgb)
+    assert len(frames) == 2
+    from scipy import ndimage
+    masks = palette_masks(rgb)
+    # (where curves of different colours run together their anti-aliased rims mix into other palette colours - red over
+    # green reads as brown: a pixel next to another colour's pixel is left out)
+    clean = []
+    for k, mask in enumerate(masks):
+        others = np.zeros_like(mask)
+        for j, other in enumerate(masks):
+            if j != k:
+                others |= other
+        clean.append(mask & ~ndimage.binary_dilation(others, structure=np.ones((3, 3), bool)))
+    masks = clean
+    out["j2d_tm_pinv_frames"] = np.array(frames)
+    for a, (top, bot, left, right) in enumerate(frames):
+        for k, mask in enumerate(masks):
+            m = mask.copy()
+            m[:int(top) + 2] = False
+            m[int(bot) - 1:] = False
+            m[:, :int(left) + 2] = False
+            m[:, (TM_JOINTS_LEGEND_FROM if a == 0 else int(right) - 1):] = False
+            rows, cols = np.nonzero(m)
+            out["j2d_tm_pinv_%s_%d" % ("q" if a == 0 else "dq", k)] = np.c_[cols, rows].astype(np.int16)
+
+
+def deviations_2d(stored, frame, t, values, last_column=None):
+    """`stored`: [colour] -> [n, 2] pixel centres; `values` [n_t, n_curves] drawn against `t` in an axes whose spines sit at
+    `frame`, view limits = the data's range widened by 5 %.  Per curve (worst distance of a stored pixel from the drawn
+    polyline, share of the polyline under ink, pixels)"""
+    from scipy.spatial import cKDTree
+    top, bot, left, right = frame
+    t0, t1 = t.min(), t.max()
+    v0, v1 = values.min(), values.max()
+    t0, t1 = t0 - 0.05 * (t1 - t0), t1 + 0.05 * (t1 - t0)
+    v0, v1 = v0 - 0.05 * (v1 - v0), v1 + 0.05 * (v1 - v0)
+    col = left + (t - t0) / (t1 - t0) * (right - left)
+    ink = cKDTree(np.vstack([s for s in stored if len(s)]))
+    out = []
+    for k in range(values.shape[1]):
+        row = top + (v1 - values[:, k]) / (v1 - v0) * (bot - top)
+        line = dense(np.c_[col, row])
+        if last_column is not None:
+            line = line[line[:, 0] < last_column - 2.0]
+        px = stored[k]
+        if len(px) == 0:
+            out.append((0.0, float((ink.query(line)[0] < 1.5).mean()), 0))
+            continue
+        out.append((float(cKDTree(dense(np.c_[col, row])).query(px)[0].max()), float((ink.query(line)[0] < 1.5).mean()), len(px)))
+    return out

@@ -400,6 +400,7 @@ def main():
     # ... cells 22-27 and 44-50: the frame_3d figures of the QP and pinv runs (tool path and frame-axis tips in 3-D)
     import frame3d_pins
     frame3d_pins.collect_frames(out, moe_figure_pins.html_png, stored_png)
+    frame3d_pins.collect_joint_figure(out, stored_png)      # ... and cell 31 of the UR5 notebook: joints of the pinv point run
     path = os.path.join(HERE, "notebook_figures.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays,", os.path.getsize(path), "bytes")

@@ -307,16 +307,32 @@ def ur5_qp_point_skill(fk):
     return cc.SkillSpecification(label="Move to point", time_var=t, robot_var=q, robot_vel_var=dq, constraints=cons)
 
 
-def simulate_ur5_joints(solve, clamp):
+def simulate_ur5_joints(solve, clamp, return_dq=False):
     """cells 14 / 29: 1000 samples of 0.01 s from UR5_home (the pinv loop saturates the speeds at pi / 5, the QP's
-    carries them as rows).  Returns q_sim [1000, 6]."""
+    carries them as rows).  Returns q_sim [1000, 6] (and dq_sim as the notebooks keep it: the applied speeds, the last
+    row left at zero)."""
     n, dt, max_speed = 1000, 0.01, np.pi / 5
-    q_sim = np.zeros((n, 6))
+    q_sim, dq_sim = np.zeros((n, 6)), np.zeros((n, 6))
     q_sim[0] = UR5_HOME
     for i in range(n - 1):
         dq = solve(dt * i, q_sim[i])
-        q_sim[i + 1] = q_sim[i] + (np.clip(dq, -max_speed, max_speed) if clamp else dq) * dt
-    return q_sim
+        dq_sim[i] = np.clip(dq, -max_speed, max_speed) if clamp else dq
+        q_sim[i + 1] = q_sim[i] + dq_sim[i] * dt
+    return (q_sim, dq_sim) if return_dq else q_sim
+
+
+def ur5_point_joint_pins(q_sim, dq_sim):
+    """cell 31 of that notebook (`common_plots.joints` of the pinv point run): {"q": [...], "dq": [...]} per joint (worst
+    distance of a stored pixel of the joint's colour from the simulated curve, share of the curve under ink, pixels);
+    the legend hides the top axes from column 328 on"""
+    import frame3d_pins as f3
+    t = 0.01 * np.arange(len(q_sim))
+    frames = FIGS["j2d_tm_pinv_frames"]
+    out = {}
+    for a, (name, values) in enumerate((("q", q_sim), ("dq", dq_sim))):
+        stored = [FIGS["j2d_tm_pinv_%s_%d" % (name, k)].astype(float) + 0.5 for k in range(6)]
+        out[name] = f3.deviations_2d(stored, frames[a], t, values, last_column=f3.TM_JOINTS_LEGEND_FROM if a == 0 else None)
+    return out
 
 
 def ur5_point_frame_pins(fk, kind, q_sim):

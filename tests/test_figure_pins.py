@@ -411,7 +411,15 @@ def test_oracle_retraces_the_ur5_point_frame_figures(kind):
 
         def solve(t, q):
             return clik_oracle.pinv_solve_batch(spec, None, float(t), q[None, :])[0][0]
-    dev = cf.ur5_point_frame_pins(fk, kind, cf.simulate_ur5_joints(solve, clamp=(kind == "pinv")))
+    q_sim, dq_sim = cf.simulate_ur5_joints(solve, clamp=(kind == "pinv"), return_dq=True)
+    dev = cf.ur5_point_frame_pins(fk, kind, q_sim)
     for colour, (worst, covered, n) in dev.items():
         assert n > 50 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (kind, dev)
+    if kind == "pinv":
+        # cell 31: the six joint positions and the six clamped joint speeds of the same run against time - which joints
+        # move is the pseudo-inverse's choice (one norm_2 row, five redundant directions); one pixel = 0.023 rad x 0.033 s
+        joints = cf.ur5_point_joint_pins(q_sim, dq_sim)
+        for name, curves in joints.items():
+            for worst, covered, n in curves:
+                assert n >= 15 and worst < cf.FRAME_PIXELS and covered > 0.8, (name, joints)
 

@@ -80,10 +80,17 @@ def test_hip_controllers_retrace_the_ur5_point_frame_figures(ur5_fk, kind):
         ctrl = cc.PseudoInverseController(skill_spec=cf.ur5_pinv_point_skill(ur5_fk))
     ctrl.setup_problem_functions()
     ctrl.setup_solver()
-    q_sim = cf.simulate_ur5_joints(lambda t, q: ctrl.solve(t, q)[0].toarray()[:, 0], clamp=(kind == "pinv"))
+    q_sim, dq_sim = cf.simulate_ur5_joints(lambda t, q: ctrl.solve(t, q)[0].toarray()[:, 0], clamp=(kind == "pinv"),
+                                           return_dq=True)
     dev = cf.ur5_point_frame_pins(ur5_fk, kind, q_sim)
     for colour, (worst, covered, n) in dev.items():
         assert n > 50 and worst < cf.FRAME_PIXELS and covered > (0.97 if colour == "k" else 0.8), (kind, dev)
+    if kind == "pinv":
+        joints = cf.ur5_point_joint_pins(q_sim, dq_sim)      # (cell 31: joint positions and clamped joint speeds)
+        for name, curves in joints.items():
+            for worst, covered, n in curves:
+                assert n >= 15 and worst < cf.FRAME_PIXELS and covered > 0.8, (name, joints)
+        print("ur5 point pinv joints figure:", {k: [round(c[0], 2) for c in v] for k, v in joints.items()})
     print("ur5 point %s frame_3d figure: %s" % (kind, {c: (round(v[0], 2), round(v[1], 2)) for c, v in dev.items()}))
 
 
