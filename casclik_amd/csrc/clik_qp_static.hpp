@@ -1022,7 +1022,7 @@ struct QpFolio {
     int* key_slot;     // LDS word of this lane's instance (initialised to INT_MAX)
     int sid;           // strategy 0 ... 3 (low bits of the key: ties go to the lower one)
     int sweeps;        // Gauss-Seidel start sweeps
-    int kind;          // 0 forward, 1 reverse order, 2 forward with over-relaxation `omega`
+    int kind;          // 0 forward, 1 reverse order, 2 forward with over-relaxation `omega`, 3 reverse with it
     double omega;
 };
 constexpr int kFolioPassUnits = 8;
@@ -1100,6 +1100,9 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             } else if (fo->kind == 2) {
 #pragma unroll 1
                 for (int sweep = 0; sweep < fo->sweeps; ++sweep) qp_box_start_sweep<N, false, true>(Pm, ip, lb, ub, x, res, fo->omega);
+            } else if (fo->kind == 3) {
+#pragma unroll 1
+                for (int sweep = 0; sweep < fo->sweeps; ++sweep) qp_box_start_sweep<N, true, true>(Pm, ip, lb, ub, x, res, fo->omega);
             } else {
 #pragma unroll 1
                 for (int sweep = 0; sweep < fo->sweeps; ++sweep) qp_box_start_sweep<N, false, false>(Pm, ip, lb, ub, x, res, 1.0);
@@ -2383,14 +2386,18 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
         for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
     }
     const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
-    // strategy 0 is the lone-wave kernel's own start (when it wins, the answer is that kernel's to the bit)
     QpFolio fo;
     fo.key_slot = &key_min[lane];
     fo.sid = w;
     // (same_start: a measuring switch, CLIK_QP_FOLIO_SAME=1 - all four waves start like the lone-wave kernel)
+    // the four starts: forward x 3 | reverse x 6 | forward over-relaxed (1.5) x 12 | reverse over-relaxed x 3 - of the
+    // sets of four among {forward, reverse} x {plain, relaxed} x {3 ... 24 sweeps} the one with the shortest slowest
+    // instance on average over four batches of 16384 bench inputs (numpy model, tools/qp_wave_portfolio_study.py --sets:
+    // 4.55 / 4.18 / 5.12 / 4.35 us of sweeps + passes for seeds 0 - 3 against 6.25 / 7.2 / 7.2 / 7.2 of the lone start;
+    // round 4's first set - forward x 12 | forward x 6 | reverse x 6 | relaxed x 18 - had 4.55 / 4.55 / 6.45 / 5.3)
     const int strat = (kFolioWaves == 2) ? w + 2 : w;
-    fo.sweeps = (strat == 0 || same_start) ? CLIK_QP_BOX_SWEEPS : ((strat == 3) ? 18 : 6);
-    fo.kind = same_start ? 0 : ((strat == 2) ? 1 : ((strat == 3) ? 2 : 0));
+    fo.sweeps = same_start ? CLIK_QP_BOX_SWEEPS : ((strat == 0 || strat == 3) ? 3 : ((strat == 1) ? 6 : 12));
+    fo.kind = same_start ? 0 : ((strat == 1) ? 1 : ((strat == 2) ? 2 : ((strat == 3) ? 3 : 0)));
     fo.omega = 1.5;
     double priv[LY::SLOTS];
     double v[N], sl[NSA];

@@ -5,9 +5,11 @@ counts per instance for forward / reverse / over-relaxed (1.5) / symmetric Gauss
 time model (0.125 us per sweep, 0.95 us per pass: profiles/r3_qp_portfolio_study.md) and, for every set of four, the
 slowest instance's time when each instance is done as soon as ANY of the four has finished it.
     python tools/qp_wave_portfolio_study.py [instances = 16384] [seed = 0]        (about five minutes)
-Result on 16384 instances: the lone start (forward x 12) 6.25 us; best sets of four 4.55 us, among them
-(forward x 6, forward x 12, reverse x 6, relaxed x 18) - the one that keeps the lone-wave kernel's own start; best pair
-(reverse x 6, relaxed x 18) 5.10 us."""
+Result on 16384 instances, seed 0: the lone start (forward x 12) 6.25 us; best sets of four 4.55 us, among them
+(forward x 6, forward x 12, reverse x 6, relaxed x 18) - round 4's first choice; best pair (reverse x 6, relaxed x 18)
+5.10 us.  Over seeds 0 - 3 (and with reverse relaxed sweeps and 3 / 9 / 24 sweeps in the pool) the set with the shortest
+slowest instance on average is (forward x 3, reverse x 6, relaxed x 12, reverse relaxed x 3): 4.55 / 4.18 / 5.12 / 4.35 us
+against 4.55 / 4.55 / 6.45 / 5.3 of the first choice and 6.25 / 7.2 / 7.2 / 7.2 of the lone start - the shipped one."""
 import itertools
 import os
 import sys
@@ -56,6 +58,10 @@ for size in (2, 4):
     for t, c in best[:6]:
         print("   %.2f us  %s" % (t, c))
 print("the lone start (fwd x 12): %.2f us" % time_of[("fwd", 12)].max())
-shipped = [("fwd", 12), ("fwd", 6), ("rev", 6), ("sor", 18)]
-print("seed %d, %d instances: the shipped four (fwd x 12, fwd x 6, rev x 6, relaxed x 18): %.2f us" % (
+xs = gs(P, g, lb, ub, 3, order=list(range(6, -1, -1)), omega=1.5)          # noqa: F821   (reverse relaxed x 3)
+time_of[("rsor", 3)] = pas(P, g, lb, ub, xs, (xs <= lb) | (xs >= ub), "worst")[0] * T_PASS + 3 * T_SWEEP   # noqa: F821
+xs = gs(P, g, lb, ub, 3)                                                   # noqa: F821
+time_of[("fwd", 3)] = pas(P, g, lb, ub, xs, (xs <= lb) | (xs >= ub), "worst")[0] * T_PASS + 3 * T_SWEEP    # noqa: F821
+shipped = [("fwd", 3), ("rev", 6), ("sor", 12), ("rsor", 3)]
+print("seed %d, %d instances: the shipped four (fwd x 3, rev x 6, relaxed x 12, reverse relaxed x 3): %.2f us" % (
     SEED, B, np.minimum.reduce([time_of[k] for k in shipped]).max()))
