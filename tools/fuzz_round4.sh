@@ -12,6 +12,7 @@ run fuzz_qp_box_16_9    tools/fuzz_qp_box.py 16 9
 run fuzz_qp_mixed_30_13 tools/fuzz_qp_mixed.py 30 13
 run fuzz_qp_dynamic_200_5 tools/fuzz_qp_dynamic.py 200 5
 run fuzz_qp_wide_40_0 tools/fuzz_qp_wide.py 40 0 96
+FUZZ_ANGLES=1 python tools/fuzz_parity.py 40 77 > $out/fuzz_parity_angles_40_77.log 2>&1; echo "fuzz_parity_angles rc $?"
 s=$out/r4_fuzz_summary.txt
 {
 echo "# Round 4 randomised parity sweeps on one MI355X (final kernels; every tool holds every instance to the stated rule"
@@ -31,6 +32,8 @@ echo; echo "## tools/fuzz_qp_box.py  (log fuzz_qp_box_16_9)"; tail -1 $out/fuzz_
 echo; echo "## tools/fuzz_qp_mixed.py  (log fuzz_qp_mixed_30_13)"; grep "skipped" $out/fuzz_qp_mixed_30_13.log | cut -c1-200; tail -1 $out/fuzz_qp_mixed_30_13.log
 echo; echo "## tools/fuzz_qp_dynamic.py  (log fuzz_qp_dynamic_200_5)"; tail -1 $out/fuzz_qp_dynamic_200_5.log
 echo; echo "## tools/fuzz_qp_wide.py  (log fuzz_qp_wide_40_0)"; tail -1 $out/fuzz_qp_wide_40_0.log
+echo; echo "## FUZZ_ANGLES=1 tools/fuzz_parity.py 40 77  (generated constraints also draw atan2 / asin / acos / atan / tanh / fmin / fmax)"
+echo "instances beyond the rule (MISMATCH lines): $(grep -c MISMATCH $out/fuzz_parity_angles_40_77.log); skills whose constraints ran as generated device code: $(grep -c 'pinv dynamic refused: the skill has constraint expressions' $out/fuzz_parity_angles_40_77.log) of 40"; tail -2 $out/fuzz_parity_angles_40_77.log
 echo; echo "## tools/fuzz_qp_mixed.py, every skill of the sweep"; grep -E "^ *[0-9]+ (ur5|iiwa)" $out/fuzz_qp_mixed_30_13.log | cut -c1-200
 echo; echo "## tools/fuzz_qp_box.py, every skill of the sweep"; grep -E "^ *[0-9]+ (ur5|iiwa)" $out/fuzz_qp_box_16_9.log | cut -c1-200
 } > $s
