@@ -1012,8 +1012,9 @@ __device__ __forceinline__ void qp_sym_sweep(double (&S)[N * (N + 1) / 2], const
 // instances, each with its own START of the active-set passes (number, order and relaxation of the Gauss-Seidel sweeps:
 // different instruction streams cost nothing across waves, unlike across the lanes of QUAD), and an instance is done as
 // soon as ANY of them has reached its KKT point.  The tick of a 16384-instance batch is its slowest instance: with the
-// sweeps (forward x 12 | forward x 6 | reverse x 6 | over-relaxed 1.5 x 18) the slowest instance of the bench inputs needs
-// 4.55 us of sweeps + passes instead of 6.25 (numpy model of the iteration, tools/qp_portfolio_study.py's functions).
+// four starts of qp_solve_static_box_folio_values_kernel the slowest instance of a batch of bench inputs needs 4.2 - 5.1 us
+// of sweeps + passes instead of 6.25 - 7.2 (numpy model of the iteration, tools/qp_wave_portfolio_study.py; measured:
+// profiles/r4_qp_wave_portfolio.txt - four waves on one CU run 12 % slower each, which eats half of that).
 // Which wave's answer is taken must not depend on timing: every finish is recorded as a KEY = virtual time (sweeps +
 // 8 per pass: a pass costs about eight sweeps) x 4 + strategy, smallest key wins (atomic minimum in LDS); a wave gives an
 // instance up only when a key SMALLER than any it could still produce has been recorded, so the strategy that would
