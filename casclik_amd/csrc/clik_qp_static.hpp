@@ -2376,6 +2376,14 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
 #ifdef CLIK_QP_FOLIO_IDLE
     if (w != 0) return;          // (measuring switch: the block shape alone - the other three waves leave at once)
 #endif
+#ifdef CLIK_QP_FOLIO_DELAY
+    // (test switch, tools/qp_folio_check.py --delays: wave CLIK_QP_FOLIO_DELAY starts some 25 us late - every other wave has
+    // finished by then - and the answers must not change by a bit: the smallest KEY decides, not the first to arrive)
+    if (w == (CLIK_QP_FOLIO_DELAY)) {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;

@@ -28,6 +28,20 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     sys.exit(0)
 
 import numpy as np                                   # noqa: E402
+if "--delays" in sys.argv:
+    # the same answers when one of the four waves starts 25 us late (-DCLIK_QP_FOLIO_DELAY=<wave>): four more builds
+    B = int([a for a in sys.argv[1:] if not a.startswith("--")][0]) if len(sys.argv) > 2 else 4096
+    outs = {}
+    for tag, defines in [("none", "")] + [("wave %d late" % w, "-DCLIK_QP_FOLIO_DELAY=%d" % w) for w in range(4)]:
+        path = "/tmp/qp_folio_delay_%s.npz" % tag.replace(" ", "_")
+        subprocess.run([sys.executable, os.path.abspath(__file__), str(B), "child", path],
+                       env=dict(os.environ, CLIK_QP_FOLIO="1", CLIK_JIT_DEFINES=defines), check=True)
+        outs[tag] = np.load(path)
+    ref = outs["none"]
+    for tag, o in outs.items():
+        same = all(np.array_equal(ref[k], o[k], equal_nan=True) for k in ("dq", "slack", "status"))
+        print("%-12s answers bit-equal to the undelayed build: %s" % (tag, same))
+    sys.exit(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 res = {}
 for folio in ("1", "0"):
