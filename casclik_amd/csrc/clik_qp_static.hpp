@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void qp_sym_sweep(double (&S)[N * (N + 1) / 2], const
 // soon as ANY of them has reached its KKT point.  The tick of a 16384-instance batch is its slowest instance: with the
 // four starts of qp_solve_static_box_folio_values_kernel the slowest instance of a batch of bench inputs needs 4.2 - 5.1 us
 // of sweeps + passes instead of 6.25 - 7.2 (numpy model of the iteration, tools/qp_wave_portfolio_study.py; measured:
-// profiles/r4_qp_wave_portfolio.txt - four waves on one CU run 12 % slower each, which eats half of that).
+// profiles/r4_qp_wave_portfolio.txt - the arrangement itself costs 0.9 - 1.2 us at one block per CU, half of that).
 // Which wave's answer is taken must not depend on timing: every finish is recorded as a KEY = virtual time (sweeps +
 // 8 per pass: a pass costs about eight sweeps) x 4 + strategy, smallest key wins (atomic minimum in LDS); a wave gives an
 // instance up only when a key SMALLER than any it could still produce has been recorded, so the strategy that would
@@ -2574,9 +2574,9 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
         // (CLIK_QP_FOLIO=0 / 1: the four-waves-per-64-instances kernel for cold ticks of small batches)
         // default: up to ONE block per CU (16384 instances on 256 CUs) - measured per tick against the lone-wave kernel:
         // 10.2 / 11.0 us at 1024 instances, 10.4 / 12.0 at 4096, 11.0 / 12.0 at 8192, 11.2 / 12.1 at 12288, the same at 256
-        // and 2048, 10.85 / 11.3 at 16384 (there four waves per CU slow each other by 12 % - per-wave stamps,
-        // tools/stamp_folio.py: four identical waves cost 12.2 - 12.5 us - and the different starts win 1.4 - 1.6 back, the
-        // last 0.4 of it through the second look half-way through a pass); CLIK_QP_FOLIO=0 never
+        // and 2048, 11.0 - 11.1 / 11.3 at 16384 (four identical waves cost 12.2 - 12.5 us there - slower waves, not a slower dispatch:
+        // tools/stamp_folio.py - and the different starts win 1.3 - 1.6 back, 0.4 of it through the second look half-way
+        // through a pass; six input seeds: -7 % on average, every one a gain); CLIK_QP_FOLIO=0 never
         // (profiles/r4_qp_wave_portfolio.txt)
         static const int folio = []() {
             const char* e = getenv("CLIK_QP_FOLIO");
