@@ -423,3 +423,20 @@ def test_oracle_retraces_the_ur5_point_frame_figures(kind):
             for worst, covered, n in curves:
                 assert n >= 15 and worst < cf.FRAME_PIXELS and covered > 0.8, (name, joints)
 
+
+
+def test_the_restated_projection_puts_the_desired_frame_where_the_figures_show_it():
+    """no simulation involved: cells 33 / 34 of ur5_dual_quaternion_vs_transformation_matrix.ipynb set their view limits
+    themselves and draw the desired frame's axis tips as dots at known points - matplotlib's projection as restated in
+    tests/golden/frame3d_pins.py puts the red and the blue one within a third of a pixel of the stored dots' centroids
+    (the black dot carries the path's end, the green one is faded by the depth shading: not used)"""
+    import frame3d_pins as f3
+    axes = f3.OldAxes3D(f3.DQTM_LIMITS, width=f3.DQTM_CANVAS[0], height=f3.DQTM_CANVAS[1])
+    dots = f3.frame_dots(T_des=f3.dqtm_target())
+    for which in ("Q_dist2", "T_dist2"):
+        stored = f3.stored_frames(cf.FIGS, which, "qp", prefix="f3d_dqtm_")
+        for colour in ("r", "b"):
+            at = axes.pixels(dots[colour])[0]
+            near = stored[colour][np.linalg.norm(stored[colour] - at, axis=1) < 4.0]
+            assert len(near) >= 25, (which, colour, len(near))
+            assert np.linalg.norm(near.mean(axis=0) - at) < 0.35, (which, colour, near.mean(axis=0), at)
