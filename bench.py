@@ -524,6 +524,15 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
                 "kernel_body_source": body_src,
                 "algorithmic_bytes_per_instance": bytes_per_inst,
                 "algorithmic_bytes_per_launch": alg_bytes}
+        # what the ISSUE of the kernel's fp64 instructions costs on this machine with nothing else going on (bare-FMA waves
+        # in the same launch shape and register allocation, tools/probe_fp64_peak.hip; recorded, not measured here)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r4_fp64_issue_ceiling.json")) as f:
+                probe = json.load(f).get("%s_%s_B%d_%s" % (workload, dist_name, B, kernel))
+        except Exception:
+            probe = None
+        if probe:
+            roof["issue_probe"] = dict(probe, source="profiles/r4_fp64_issue_ceiling.json")
         if prof and "fp64_flops_per_launch" in prof:
             # executed fp64 flops (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes, FMA = 2) over the measured
             # tick time: what the VALUs did, not what the literal algorithm would need
@@ -639,7 +648,8 @@ def compact_roofline(r):
            "frac": _r(r.get("frac"), 4), "traffic": r.get("traffic"), "traffic_source": r.get("traffic_source"),
            "tick_us": _r(r.get("tick_us"), 3), "kernel_body_us": _r(r.get("kernel_body_us"), 3),
            "fp64_frac": _r(f64.get("frac"), 3), "valu_issue_frac": _r(f64.get("valu_issue_frac"), 3),
-           "binds": r.get("binds"), "bytes_per_instance": r.get("algorithmic_bytes_per_instance")}
+           "binds": r.get("binds"), "bytes_per_instance": r.get("algorithmic_bytes_per_instance"),
+           "issue_probe_body_us": (r.get("issue_probe") or {}).get("probe_body_us")}
     return {k: v for k, v in out.items() if v is not None or k in ("traffic", "frac", "achieved")}
 
 
@@ -677,9 +687,9 @@ def compact_entry(e):
     return out
 
 
-NOTES = ("us = wall per tick; roofline = 172 B/instance-step (QP 220) / HIP-event tick time vs 8 TB/s; fp64_frac = executed "
-         "fp64 flops (PMC) vs 78.6 TF; pmc = case in profiles/r4_counters.json; cpu_M_per_s = the C port on cpu_baseline.cores "
-         "threads; --full 1 = details")
+NOTES = ("us = wall per tick; roofline: 172 B/instance-step (QP 220) / tick vs 8 TB/s; fp64_frac: executed fp64 flops (PMC) vs "
+         "78.6 TF; issue_probe_body_us: bare-FMA waves in the tick's launch shape (profiles/r4_fp64_issue_ceiling.md); pmc: case "
+         "in profiles/r4_counters.json; cpu_M_per_s: C port on cpu_baseline.cores threads; --full 1: details")
 
 
 def init_ranks(world, rank, dev, shared_gpu):
