@@ -645,7 +645,8 @@ def compact_roofline(r):
         return r
     f64 = r.get("fp64") or {}
     out = {"bound": r["bound"], "achieved": _r(r.get("achieved"), 1), "peak": r["peak"], "unit": r["unit"],
-           "frac": _r(r.get("frac"), 4), "traffic": r.get("traffic"), "traffic_source": r.get("traffic_source"),
+           "frac": _r(r.get("frac"), 4), "traffic": r.get("traffic"),
+           "traffic_source": (r.get("traffic_source") or "").replace("profiles/", "").split("_k")[0] or None,
            "tick_us": _r(r.get("tick_us"), 3), "kernel_body_us": _r(r.get("kernel_body_us"), 3),
            "fp64_frac": _r(f64.get("frac"), 3), "valu_issue_frac": _r(f64.get("valu_issue_frac"), 3),
            "binds": r.get("binds"), "bytes_per_instance": r.get("algorithmic_bytes_per_instance"),
