@@ -16,25 +16,37 @@ Line-by-line fp64 numpy restatement of the reference's per-tick hot path:
       solve / result slicing     :461-528
 
 PARITY - WHAT IT IS PINNED TO.  Outputs of the reference itself: the closed-loop figures its notebooks store of
-their real CasADi + qpOASES runs (eleven figures, every curve retraced within a pixel = 0.3 - 2 % of the plotted
+their real CasADi + qpOASES runs (some forty figures, every curve retraced within a pixel = 0.3 - 2 % of the plotted
 range; tests/golden/make_figure_pins.py, tests/test_figure_pins.py), the print_constraints() texts and the UR5
-forward-kinematics values the notebooks store.  Outputs of the reference's own CODE run in the build container
-over a stand-in casadi (tests/golden/make_ref_golden.py -> ref_pins.npz, 1e-9; the stand-in itself must retrace
-the same figures before any fixture is written).  NOT pinned: CasADi's rounding - no fixture comes from CasADi
-arithmetic at 1e-9, because: the reference is pure Python on top of casadi==3.4.1
-(requirements.txt:1) and urdf2casadi (un-vendored, unpinned); neither exists in
-the build container nor on the GPU box, and the reference ships no tests or
-golden outputs for ``solve()``.  What pins this
-restatement instead: the UR5 forward-kinematics KAT stored in the notebooks
-(||p_tool0|| = 1.0192 at home), the constraint-order printouts, algebraic
-invariants of the damped pseudo-inverse, KKT optimality of every QP answer,
-and agreement of the AD Jacobians below with finite differences.  Since round 2
-also: fixtures produced by the reference's OWN Python over a stand-in casadi
-(tests/golden/make_ref_golden.py -> ref_pins.npz; tests/test_refpins.py), and
-since round 3 the closed-loop FIGURES the reference's notebooks store (its real
-CasADi + qpOASES runs), digitised with calibration from the notebooks' own
-reference lines (tests/golden/make_figure_pins.py -> notebook_figures.npz;
-tests/test_figure_pins.py: every curve reproduced within one pixel).
+forward-kinematics values the notebooks store.  WHAT THOSE FIGURES RESOLVE (profiles/r5_figure_resolution.md, made by
+tools/figure_resolution.py; asserted by tests/test_figure_pins.py::test_what_the_*_resolve): a controller that
+deviates from the reference's algorithm in ONE of the following misses a stored figure by the pixels given (the literal
+algorithm: 0.16 - 0.56):
+    first equality processed once instead of twice (quirk D1, :317-326 + :382-396)        319.5 px  dqc Q_dist2 / pinv
+    damping factor 1e-5 or 1e-3 instead of 1e-7 (:47, :92-105); 1e-9                        324 px; 2.6 px  same figure
+    pinv_method "standard" there                                                            no answer (J J' singular)
+    pinv(J N) instead of N pinv(J) (:387-394)                                               31.6 px   Moe, three walls
+    J instead of S J for an active multidimensional set (:289-298, :401-404)                30.5 px   Moe, multidim
+    mode scan with the most active sets first (:107-130)                                    106 px; 25.6 px (cart)
+    no feed-forward term (:320-321)                                                         68.2 px   Moe
+    QP weight shifter 1e-2 instead of 1e-3 (reactive_qp.py:44)                              169 px    dqc quat_dist / qp
+NOT resolved by any stored output, because no notebook exercises the difference (these rest on the line-by-line
+reading above and on the fixtures made by the reference's own Python over the stand-in casadi, nothing else):
+    the 1e-12 margins of the tangent cones and which side the boundary belongs to (D4, D5): measure-zero events
+    the multidimensional cone's corner rule against the row-wise 1-D rule (:222-252): the stored runs never leave
+        the box through a corner
+    an active set that would push back instead of freezing its rows (D2): < 0.3 px on every stored run
+    converge_final_set_to_max (D3), a leading VelocityEqualityConstraint, pinv_method "standard" away from
+        singularities: 0 uses in the notebooks
+    the slack weight mu + w against (1 + mu) w (D12): identical bit for bit at w = 1, the only weight ever used
+Outputs of the reference's own CODE run in the build container over a stand-in casadi (tests/golden/make_ref_golden.py ->
+ref_pins.npz, 1e-9; the stand-in itself must retrace the same figures before any fixture is written).  NOT pinned:
+CasADi's rounding - no fixture comes from CasADi arithmetic at 1e-9 ("parity unpinned at the stated fp64 tolerance"):
+the reference is pure Python on top of casadi==3.4.1 (requirements.txt:1) and urdf2casadi (un-vendored, unpinned);
+neither exists in the build container nor on the GPU box, and the reference ships no tests or golden outputs for
+``solve()``.  Besides the figures: the UR5 forward-kinematics KAT stored in the notebooks
+(||p_tool0|| = 1.0192 at home), the constraint-order printouts, algebraic invariants of the damped pseudo-inverse,
+KKT optimality of every QP answer, and agreement of the AD Jacobians below with finite differences.
 
 CasADi's algorithmic differentiation (``cs.jacobian``, constraints.py:67-73) is
 restated as forward-mode dual numbers over the same expression trees the
@@ -444,20 +456,25 @@ def _sym_cond(A):
     return float(hi / lo) if lo > 0.0 else float("inf")
 
 
-def in_tangent_cone_1d(e, set_min, set_max, dexpr):
-    """pseudo_inverse.py:162-185 (boundary counts as inside, 1e-12 margin)."""
-    if set_min - e < 1e-12:
-        if e - set_max < 1e-12:
+def in_tangent_cone_1d(e, set_min, set_max, dexpr, eps=1e-12):
+    """pseudo_inverse.py:162-185 (boundary counts as inside, 1e-12 margin; `eps` is that margin - only the tests that
+    state what the stored figures resolve pass another)."""
+    if set_min - e < eps:
+        if e - set_max < eps:
             return True
         return bool(dexpr < 0.0)
     return bool(dexpr > 0.0)
 
 
-def in_tangent_cone_multidim(e, set_min, set_max, dexpr):
-    """pseudo_inverse.py:222-252."""
+def in_tangent_cone_multidim(e, set_min, set_max, dexpr, eps=1e-12, loose_inside=False):
+    """pseudo_inverse.py:222-252 (`eps`, `loose_inside`: deliberate deviations for the resolution tests only -
+    `loose_inside` is the 1-D function's inside test `min - e < eps`, quirk D5)."""
     le = e - set_min
     ue = e - set_max
-    inside = bool(np.all(le >= 1e-12) and np.all(ue <= 1e-12))
+    if loose_inside:
+        inside = bool(np.all(-le < eps) and np.all(ue < eps))
+    else:
+        inside = bool(np.all(le >= eps) and np.all(ue <= eps))
     if inside:
         return True
     out_dir = (np.sign(le) + np.sign(ue)) / 2.0
@@ -516,8 +533,14 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
     reference-held figure pins resolve (tests/test_figure_pins.py): "no_S" stacks J instead of S J for an active
     multidimensional set (:352-355, 401-404), "no_D1" processes the first equality once (the textbook reading of
     :317-396), "textbook_projection" uses pinv(J N) instead of N pinv(J) (:387-394), "active_first" scans the modes
-    with the most active sets first (:107-130)."""
-    assert _wrong in (None, "no_S", "no_D1", "textbook_projection", "active_first"), _wrong
+    with the most active sets first (:107-130), "cone_1d_rows" tests a multidimensional set row by row with the 1-D
+    rule (:162-185 in place of :222-252), "boundary_flipped" moves the 1e-12 margins of both cone functions to the
+    other side of the bounds (the class docstring's reading, quirk D4), "multidim_loose" gives the multidimensional
+    cone the 1-D function's inside test (quirk D5), "set_pushes_back" lets an active set drive its violated rows
+    back to the bound with its gain instead of only freezing them (quirk D2)."""
+    assert _wrong in (None, "no_S", "no_D1", "textbook_projection", "active_first", "cone_1d_rows", "boundary_flipped",
+                      "multidim_loose", "set_pushes_back"), _wrong
+    cone_eps = -1e-12 if _wrong == "boundary_flipped" else 1e-12
     opt = default_pinv_options(options)
     Q = np.atleast_2d(np.asarray(Q, dtype=float))
     B = Q.shape[0]
@@ -618,6 +641,11 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                     Ja.append(Ji); rJa.append(Ji)
                 elif is_set:
                     if amap[mode_idx][set_idx]:
+                        if _wrong == "set_pushes_back":
+                            smin_, smax_ = _num(a.set_min, m), _num(a.set_max, m)
+                            des = _gain_apply(a.gain, np.clip(e, smin_, smax_) - e)
+                            N = I - dpinv(np.vstack(Ja), opt, cnd).dot(np.vstack(rJa)) if Ja else I
+                            v = v + N.dot(dpinv(Ji, opt, cnd)).dot(des)
                         Ja.append(Ji)
                         rJa.append(S.dot(Ji) if multidim else Ji)
                     else:
@@ -644,9 +672,11 @@ def pinv_solve_batch(spec, options, t, Q, X=None, Y=None, return_all_modes=False
                 smin = _num(a.set_min, m)
                 smax = _num(a.set_max, m)
                 if m == 1:
-                    good = in_tangent_cone_1d(e[0], smin[0], smax[0], dexpr[0])
+                    good = in_tangent_cone_1d(e[0], smin[0], smax[0], dexpr[0], cone_eps)
+                elif _wrong == "cone_1d_rows":
+                    good = all(in_tangent_cone_1d(e[k], smin[k], smax[k], dexpr[k]) for k in range(m))
                 else:
-                    good = in_tangent_cone_multidim(e, smin, smax, dexpr)
+                    good = in_tangent_cone_multidim(e, smin, smax, dexpr, cone_eps, _wrong == "multidim_loose")
                 if margins_out is not None and modes[b] < 0:
                     # (every decision of the scan up to and including the accepted mode)
                     margins_out[b] = min(margins_out[b], tangent_cone_margin(e, smin, smax, dexpr))
@@ -690,10 +720,13 @@ def qp_weights(spec, robot_var_weights=None, virtual_var_weights=None,
     return wr, wv, ws
 
 
-def qp_data_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
+def qp_data_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001, _wrong=None):
     """H (diag), A, lbA, ubA per instance (reactive_qp.py:175-246).
 
-    Returns Hdiag [B,nv], A [B,nc,nv], lb [B,nc], ub [B,nc]."""
+    Returns Hdiag [B,nv], A [B,nc,nv], lb [B,nc], ub [B,nc].
+    `_wrong` (resolution tests only): "slack_times" writes the slack weights as (1 + mu) w - the INITIAL problem's form
+    (:331) - instead of mu + w (:187; quirk D12)."""
+    assert _wrong in (None, "slack_times"), _wrong
     Q = np.atleast_2d(np.asarray(Q, dtype=float))
     B = Q.shape[0]
     Z = Q if X is None else np.hstack([Q, np.atleast_2d(np.asarray(X, dtype=float))])
@@ -707,7 +740,7 @@ def qp_data_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001):
     if nvirt > 0:
         hd.append(mu * wv)
     if nslack > 0:
-        hd.append(mu + ws)
+        hd.append((1.0 + mu) * ws if _wrong == "slack_times" else mu + ws)
     hd = np.concatenate(hd)
     nv = hd.size
     A_blocks, lb_blocks, ub_blocks = [], [], []
@@ -912,10 +945,10 @@ def qp_condition(hdiag, A, lb, ub, x, act_tol=1e-8):
     return kh * float(sv[0] / sv[-1])
 
 
-def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001, cond_out=None):
+def qp_solve_batch(spec, t, Q, X=None, Y=None, weights=None, mu=0.001, cond_out=None, _wrong=None):
     """Literal ReactiveQPController.solve: (dq [B,nq], dx [B,nx] | None,
     slack [B,ns] | None, status [B]).  `cond_out` [B]: qp_condition of every solved instance."""
-    hd, A, lbA, ubA = qp_data_batch(spec, t, Q, X, Y, weights, mu)
+    hd, A, lbA, ubA = qp_data_batch(spec, t, Q, X, Y, weights, mu, _wrong)
     B, nv = hd.shape
     xs = np.zeros((B, nv))
     status = np.zeros(B, dtype=np.int32)

@@ -319,22 +319,85 @@ def dqc_oracle_run_cached(which, kind):
     return _DQC_RUNS[(which, kind)]
 
 
-@pytest.mark.parametrize("which,kind", [("quat_dist", "pinv"), ("quat_dist", "qp"), ("cart_dist", "pinv")])
+@pytest.mark.parametrize("which,kind", cf.DQC_CASES)
 def test_oracle_reproduces_the_dual_quaternion_comparison_figures(which, kind):
-    """(three of the eight runs here - 13 s each through the numpy oracle; all eight through the HIP controllers in
+    """all eight runs through the numpy oracle (13 s each; the same eight through the HIP controllers in
     tests/test_gpu_figure_pins.py, held to the same pins AND to the oracle along the way)"""
     t_sim, log_e, _ = dqc_oracle_run_cached(which, kind)
     pins = cf.dqc_pins(which, kind, t_sim, log_e)
     assert len(pins) == 2
     for key, worst, n, where in pins:
         assert n > 50 and worst < PIXELS, (key, worst, n, where)
-    if which == "cart_dist":
+    if which == "cart_dist" and kind == "pinv":
         # the target (the base frame's origin) is out of reach: the error norm bottoms out and the pinv controller
         # chatters above it with the amplitude of its stored curve (a band 0.0343 ... 0.0374 from t = 8 s on)
         band, px = cf.FIGS["dqc_cart_dist_pinv_band"], cf.FIGS["dqc_cart_dist_pinv_pixel"][1]
         tail = log_e[t_sim > 12.0]
         assert abs(tail.min() - band[0]) < 1.5 * px and abs(tail.max() - band[1]) < 1.5 * px, (10.0 ** tail.min(), 10.0 ** tail.max(),
                                                                                              10.0 ** band)
+
+
+def dqc_deviating_run(which, wrong=None, options=None, n_ticks=600):
+    """worst pixel deviation of a deliberately WRONG PseudoInverseController over the first `n_ticks` of a stored run"""
+    from casclik_amd import skills
+    spec, error_norm = cf.dqc_skill(skills.ur5(), which, "pinv")
+
+    def solve(t, q):
+        return clik_oracle.pinv_solve_batch(spec, options, float(t), q[None, :], _wrong=wrong)[0][0]
+    t_sim, log_e = cf.simulate_dqc(error_norm, solve, n_ticks)
+    return {key: worst for key, worst, n, where in cf.dqc_pins(which, "pinv", t_sim, log_e)}
+
+
+def test_what_the_dual_quaternion_figures_resolve():
+    """The stored figure of the PseudoInverseController on `Q_dist2` (cell 42, real CasADi) is the run that STANDS STILL in
+    the UR5's home singularity: there N pinv(J) is as large as pinv(J), so the second pass over the first equality
+    (quirk D1, pseudo_inverse.py:317-326 + :382-396) and the damping factor (:47, :92-105) decide whether the arm
+    leaves.  Deliberately wrong controllers against that figure, first 6 s of 45 (whole runs: tools/figure_resolution.py ->
+    profiles/r5_figure_resolution.md):
+        the reference's algorithm as written      0.56 px           (whole run: 0.56)
+        first equality processed ONCE (textbook)  6.4 px            (whole run: 319.5 - it converges, the stored run does not)
+        damping 1e-5 / 1e-3 instead of 1e-7       32.8 / 30+ px     (whole run: 324.5 / 323.5)
+        damping 1e-9                              2.6 px            (whole run: 2.6)
+    so BOTH behaviours SURVEY section 0 says "change the numbers" are pinned by an output of the real reference: D1 here,
+    the Chiaverini projection N pinv(J) by the Moe figures (test_what_the_moe_2016_figures_resolve), the damping
+    factor to within two decades.  Away from the singularity D1 is O(damping): the other three pinv figures do not
+    move (asserted below for one of them)."""
+    literal = dqc_deviating_run("Q_dist2")
+    assert literal["dqc_Q_dist2_pinv"] < PIXELS and literal["dqc_Q_dist2_union"] < PIXELS, literal
+    no_d1 = dqc_deviating_run("Q_dist2", wrong="no_D1")
+    assert no_d1["dqc_Q_dist2_pinv"] > 5.0 and no_d1["dqc_Q_dist2_union"] > 4.0, no_d1
+    for lam, least in ((1e-5, 20.0), (1e-3, 20.0), (1e-9, 2.0)):
+        dev = dqc_deviating_run("Q_dist2", options={"damping_factor": lam})
+        assert dev["dqc_Q_dist2_pinv"] > least, (lam, dev)
+    # the undamped form has no answer at all at UR5_home (J J' is exactly singular): the stored run was not made with it
+    with pytest.raises(np.linalg.LinAlgError):
+        dqc_deviating_run("Q_dist2", options={"pinv_method": "standard"}, n_ticks=3)
+    away = dqc_deviating_run("Q_dist1", wrong="no_D1")
+    assert away["dqc_Q_dist1_pinv"] < PIXELS, away
+
+
+def test_the_resolution_matrix_of_the_stored_figures_is_the_committed_one():
+    """profiles/r5_figure_resolution.json (tools/figure_resolution.py, whole runs): every branch of SURVEY Appendix A / B
+    and every quirk D1-D5, D12 has a row; the rows that say REJECTED name a stored figure and a deviation of more than two
+    pixels AND more than three times the literal algorithm's; the rest say why no stored output can tell"""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r5_figure_resolution.json")
+    rows = json.load(open(path))["rows"]
+    text = " ".join(r["branch"] for r in rows)
+    for needed in ("D1", "D2", "D3", "D4", "D5", "D12", "damping", "S in rJ", "N pinv(J)", "mode order", "tangent cone",
+                   "feed-forward", "weight shifter", "VelocityEquality"):
+        assert needed in text, needed
+    rejected = [r for r in rows if r["verdict"].startswith("REJECTED")]
+    assert len(rejected) >= 12
+    for r in rejected:
+        if r["deviating_px"] is not None:
+            assert r["deviating_px"] > 2.0 and r["deviating_px"] > 3.0 * r["literal_px"], r
+    by = {r["branch"]: r for r in rows}
+    assert by["D1 first equality processed twice"]["deviating_px"] > 100.0 > 1.0 > by["D1 first equality processed twice"]["literal_px"]
+    assert by["N pinv(J) (Chiaverini)"]["deviating_px"] > 20.0
+    for r in rows:
+        if not r["verdict"].startswith("REJECTED"):
+            assert r["verdict"].startswith(("not resolved", "unresolvable", "no stored")), r
 
 
 def assert_frame_pins(dev, what):
@@ -344,7 +407,7 @@ def assert_frame_pins(dev, what):
         assert covered > (0.97 if colour == "k" else 0.8), (what, colour, covered)
 
 
-@pytest.mark.parametrize("which,kind", [("quat_dist", "pinv"), ("quat_dist", "qp"), ("cart_dist", "pinv")])
+@pytest.mark.parametrize("which,kind", [c for c in cf.DQC_CASES if c != ("Q_dist2", "pinv")])
 def test_oracle_retraces_the_stored_3d_frame_figures(which, kind):
     """cells 23, 26, 27 of ur5_dual_quaternion_comparison_of_controllers.ipynb (`common_plots.frame_3d`): the tool's PATH
     and the tips of its frame's three axes, through matplotlib's own projection with the view limits autoscaled from the
