@@ -101,7 +101,11 @@ def parse():
     ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="least work inside the timed bracket")
     ap.add_argument("--replays", type=int, default=0, help="R (0: from --min-timed-ms, at least 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=3.0,
+                    help="bound of the cpu_baseline leg of the headline (each extras entry: a third of it, >= 1 s)")
+    ap.add_argument("--ring", type=int, default=4,
+                    help="input / output buffers the ticks of a graph rotate through (a different synthetic batch in "
+                         "each; 1 = every tick re-reads the same rows)")
     ap.add_argument("--extras", type=int, default=-1,
                     help="1: append the other BASELINE configurations (see the module text) as `extras`; "
                          "-1 = only for the default headline invocation on one GPU; 0 = never")
@@ -368,7 +372,7 @@ DRAWN_MAX = 131072
 
 
 def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_graph=1, ramp_ms=250.0,
-            min_timed_ms=2000.0, replays=0, allgather=0, global_batch=0):
+            min_timed_ms=2000.0, replays=0, allgather=0, global_batch=0, ring=4):
     """One timed configuration.  Returns (entry dict, (spec, opts, Q, Y)) on every rank; the entry is
     complete on rank 0."""
     import torch
@@ -396,6 +400,14 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     Qd = torch.from_numpy(Q).to(dev)
     Yd = torch.from_numpy(Y).to(dev)
     dQ = torch.empty((B, Q.shape[1]), dtype=torch.float64, device=dev)
+    # successive ticks of a graph rotate through `ring` input / output buffers (slot 0 = the batch drawn above, slot s =
+    # the same rows rolled by s * B / ring instances: another instance on every lane, no second host-side draw), so that
+    # no tick finds the lines the tick before it touched; the QP's hot start keeps one working set per slot
+    ring = max(1, int(ring)) if (TPL == 1 and B > 1) else 1
+    slots = [(Qd, Yd, dQ)]
+    for s_ in range(1, ring):
+        shift = (s_ * B) // ring
+        slots.append((torch.roll(Qd, shift, 0).contiguous(), torch.roll(Yd, shift, 0).contiguous(), torch.empty_like(dQ)))
 
     if TPL > 1:
         if K % TPL or W % TPL:
@@ -408,10 +420,14 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         use_graph = 0
         K //= TPL
         W //= TPL
-    elif workload == "qp":
-        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ, hot_start=bool(qp_hot))
     else:
-        tick = ctrl.bind_batch(Qd, input_var=Yd, out=dQ)
+        kw = dict(hot_start=bool(qp_hot)) if workload == "qp" else {}
+        bound = [ctrl.bind_batch(q_, input_var=y_, out=o_, **kw) for q_, y_, o_ in slots]
+        turn = {"i": 0}
+
+        def tick():
+            bound[turn["i"] % len(bound)]()
+            turn["i"] += 1
 
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -560,8 +576,9 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         "value": value, "unit": "instance-steps/s", "ms_per_step": wall * 1e3 / timed_steps,
         "config": {
             "workload": text,
-            "batch_per_gpu": B, "inputs": "%s seed %d%s" % (dist_name, seed, "" if B <= DRAWN_MAX or global_batch else
-                                                           " (%d drawn, tiled)" % DRAWN_MAX),
+            "batch_per_gpu": B, "inputs": "%s seed %d%s%s" % (dist_name, seed, "" if B <= DRAWN_MAX or global_batch else
+                                                             " (%d drawn, tiled)" % DRAWN_MAX,
+                                                             ", ring of %d buffers" % len(slots) if len(slots) > 1 else ""),
             "kernel": kernel,
             "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
                        else "eager, one launch per tick") if TPL == 1
@@ -662,7 +679,7 @@ def compact_cpu(c):
     if not c or "error" in c:
         return c
     return {"value": _r(c["value"], 0), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
-            "single_core": _r(c["single_core"]["value"], 0),
+            "quota_cores": c.get("cgroup_cpu_quota_cores"), "single_core": _r(c["single_core"]["value"], 0),
             "sample": "%d ticks x %s instances, C restatement (oracle/clik_oracle_c.c), OpenMP, sustained median"
                       % (c["repeats"], c["sample"].split(" of a ")[1].split("-instance")[0])}
 
@@ -688,9 +705,28 @@ def compact_entry(e):
     return out
 
 
-NOTES = ("us = wall per tick; roofline: 172 B/instance-step (QP 220) / tick vs 8 TB/s; fp64_frac: executed fp64 flops (PMC) vs "
-         "78.6 TF; issue_probe_body_us: bare-FMA waves in the tick's launch shape (profiles/r4_fp64_issue_ceiling.md); pmc: case "
-         "in profiles/r4_counters.json; cpu_M_per_s: C port on cpu_baseline.cores threads; --full 1: details")
+NOTES = ("us = wall per tick; roofline.achieved = ALGORITHMIC bytes (172 B/instance-step, QP 220) / tick time vs 8 TB/s - not DRAM "
+         "traffic: the ticks rotate through --ring buffers that stay L2/MALL-resident (`traffic` = PMC bytes of one launch); "
+         "fp64_frac: executed fp64 flops (PMC) vs 78.6 TF; issue_probe_body_us: bare-FMA waves in the tick's launch shape "
+         "(profiles/r5_issue_alignment.md); pmc: case in profiles/*_counters.json; cpu_M_per_s: C port on cpu_baseline.cores "
+         "THREADS (cgroup quota in cpu_baseline.quota_cores) - a stated baseline, not a speed-up; --full 1: details")
+
+
+def device_uuid(index):
+    """the device's UUID (so that "N ranks on N distinct GPUs" can be checked from the line alone)"""
+    import torch
+    try:
+        return str(torch.cuda.get_device_properties(index).uuid)
+    except Exception:
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(index), "--showuniqueid"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=20).stdout.decode()
+            for line in out.splitlines():
+                if "Unique ID" in line:
+                    return line.split(":")[-1].strip()
+        except Exception:
+            pass
+    return "unknown"
 
 
 def init_ranks(world, rank, dev, shared_gpu):
@@ -744,7 +780,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, backend, dist_errors = None, None, {}
-    ranks_seen, devices = 1, ["cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank))]
+    ranks_seen, devices = 1, ["cuda:%d %s uuid %s" % (local_rank, torch.cuda.get_device_name(local_rank), device_uuid(local_rank))]
     if world > 1:
         phase("rank %d: process group" % rank)
         dist, backend, dist_errors = init_ranks(world, rank, dev, shared_gpu)
@@ -763,7 +799,7 @@ def main():
         ctx, fk, args.workload, args.batch, args.dist, args.seed, args.steps, args.warmup,
         TPL=args.ticks_per_launch, qp_hot=args.qp_hot, use_graph=args.graph, ramp_ms=args.ramp_ms,
         min_timed_ms=args.min_timed_ms, replays=args.replays, allgather=args.allgather or (1 if world > 1 else 0),
-        global_batch=args.global_batch)
+        global_batch=args.global_batch, ring=args.ring)
 
     head_cpu = None
     if rank == 0 and args.cpu_baseline and world == 1:
@@ -789,7 +825,7 @@ def main():
             try:
                 ent, _ = measure(ctx, fk, "stack", kw.get("B", args.batch), args.dist, args.seed, args.steps, args.warmup,
                                  ramp_ms=100.0, min_timed_ms=max(args.extras_timed_ms, 800.0), allgather=1,
-                                 global_batch=kw.get("global_batch", 0))
+                                 global_batch=kw.get("global_batch", 0), ring=args.ring)
                 extras.append(dict({"name": name, "n_gpus": world, "dtype": "f64",
                                     "scaling": "strong" if "global_batch" in kw else "weak"}, **ent))
             except Exception as exc:
@@ -814,14 +850,14 @@ def main():
                                                 up(max(min(args.steps, 200) if b > 200000 else args.steps, 8 * tpl)),
                                                 up(min(args.warmup, 20) if b > 200000 else args.warmup), TPL=tpl, qp_hot=hot,
                                                 ramp_ms=100.0, min_timed_ms=args.extras_timed_ms,
-                                                replays=8 if b > 200000 else 0)
+                                                replays=8 if b > 200000 else 0, ring=args.ring)
             except Exception as exc:        # (an extra must never cost the headline its line)
                 extras.append({"name": name, "error": repr(exc)})
                 continue
             ent = dict({"name": name, "n_gpus": world, "dtype": "f64"}, **ent)
             if rank == 0 and args.cpu_baseline and world == 1 and not hot and tpl == 1 and b <= 131072:
                 try:
-                    ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(2.0, args.cpu_seconds / 3))
+                    ent["cpu_baseline"] = cpu_baseline(wl, sp, op, q_, y_, max(1.0, args.cpu_seconds / 3))
                 except Exception as exc:
                     ent["cpu_baseline"] = {"error": repr(exc)}
             extras.append(ent)
@@ -868,6 +904,8 @@ def main():
             out["roofline"] = compact_roofline(out["roofline"])
             out["cpu_baseline"] = compact_cpu(head_cpu)
             out["devices"] = [d.split(" pid ")[0] + " " + d.split(" ", 4)[-1] if " pid " in d else d for d in devices][:8]
+            uu = [d.split(" uuid ")[-1] for d in devices if " uuid " in d]
+            out["distinct_gpus"] = len(set(uu)) if uu and "unknown" not in uu else None
             if extras:
                 out["extras"] = {e["name"]: compact_entry(e) for e in extras}
         print(json.dumps(out))

@@ -21,6 +21,9 @@
 //   - infeasible problems (hard rows only) are reported per instance, like the
 //     reference's RuntimeError from qpOASES
 #include "clik_qp_static.hpp"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace clik {
 
@@ -113,10 +116,6 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
     double* lds = GWS ? gws + (size_t)blockIdx.x * (size_t)qp_lds_slots<N, NC>(ny_slots) * WAVE : lds_shared;
     constexpr int NT = NC * (NC + 1) / 2;
     const int lane = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
     const DevSkill* __restrict__ S = warm_descriptor(S0, wa);
     const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
     double* zs = lds;
@@ -126,6 +125,15 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
     double* lbs = Qs + NT * WAVE;
     double* ubs = lbs + NC * WAVE;
     double* hsi = ubs + NC * WAVE;
+    // one block per 64 instances when the work area is LDS; the global-memory variants launch only as many blocks as the
+    // device holds at once (their work area is per RESIDENT block, not per 64 instances) and walk the batch
+    const long long nblk = (B + WAVE - 1) / WAVE;
+#pragma unroll 1
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long b0 = blk * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
 #pragma unroll
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
     for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
@@ -238,6 +246,8 @@ __global__ __launch_bounds__(WAVE) void qp_solve_kernel(
     stage_out_dyn(dq + b0 * nq, nq, rows_valid, zs, lane);
     if (nx > 0 && dx != nullptr) stage_out_dyn(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
     if (status_out != nullptr && valid) status_out[b0 + lane] = status_v;
+    __syncthreads();            // (the work area is reused by the next 64 instances of this block)
+    }
 }
 
 // H diagonal, A, lbA, ubA exactly as the reference's H_func / A_func / Blb_func /
@@ -253,10 +263,6 @@ __global__ __launch_bounds__(WAVE) void qp_data_kernel(
     double* lds = GWS ? gws + (size_t)blockIdx.x * (size_t)qp_lds_slots<N, NC>(ny_slots) * WAVE : lds_shared;
     constexpr int NT = NC * (NC + 1) / 2;
     const int lane = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
     const DevSkill* __restrict__ S = warm_descriptor(S0, wa);
     const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
     double* zs = lds;
@@ -266,6 +272,13 @@ __global__ __launch_bounds__(WAVE) void qp_data_kernel(
     double* lbs = Qs + NT * WAVE;
     double* ubs = lbs + NC * WAVE;
     double* hsi = ubs + NC * WAVE;
+    const long long nblk = (B + WAVE - 1) / WAVE;
+#pragma unroll 1
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long b0 = blk * WAVE;
+    const long long left = B - b0;
+    const int rows_valid = left < WAVE ? (int)left : WAVE;
+    const bool valid = lane < rows_valid;
 #pragma unroll
     for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
     for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
@@ -283,22 +296,25 @@ __global__ __launch_bounds__(WAVE) void qp_data_kernel(
         if (S->d.quat_src != 0) orientation_feature<N>(S, ys, lane, K);
     }
     const int nc = qp_rows<N>(S, tk, K, z, ys, lane, n, As, lbs, ubs, hsi);
-    if (!valid) return;
-    const int ns = S->n_slack, nv = n + ns;
-    const long long b = b0 + lane;
-    for (int j = 0; j < n; ++j) Hd[b * nv + j] = S->qo.weight_shifter * S->qo.state_weights[j];
-    for (int k = 0; k < ns; ++k) Hd[b * nv + n + k] = S->qo.weight_shifter + S->qo.slack_weights[k];
-    int k = 0;
-    for (int i = 0; i < nc; ++i) {
-        double* row = A + (b * nc + i) * nv;
-        for (int j = 0; j < nv; ++j) row[j] = 0.0;
-        for (int j = 0; j < n; ++j) row[j] = As[(i * N + j) * WAVE + lane];
-        if (hsi[i * WAVE + lane] != 0.0) {
-            row[n + k] = -1.0;
-            ++k;
+    if (valid) {
+        const int ns = S->n_slack, nv = n + ns;
+        const long long b = b0 + lane;
+        for (int j = 0; j < n; ++j) Hd[b * nv + j] = S->qo.weight_shifter * S->qo.state_weights[j];
+        for (int k = 0; k < ns; ++k) Hd[b * nv + n + k] = S->qo.weight_shifter + S->qo.slack_weights[k];
+        int k = 0;
+        for (int i = 0; i < nc; ++i) {
+            double* row = A + (b * nc + i) * nv;
+            for (int j = 0; j < nv; ++j) row[j] = 0.0;
+            for (int j = 0; j < n; ++j) row[j] = As[(i * N + j) * WAVE + lane];
+            if (hsi[i * WAVE + lane] != 0.0) {
+                row[n + k] = -1.0;
+                ++k;
+            }
+            lbA[b * nc + i] = lbs[i * WAVE + lane];
+            ubA[b * nc + i] = ubs[i * WAVE + lane];
         }
-        lbA[b * nc + i] = lbs[i * WAVE + lane];
-        ubA[b * nc + i] = ubs[i * WAVE + lane];
+    }
+    __syncthreads();
     }
 }
 
@@ -345,22 +361,83 @@ static hipError_t qp_data_launch(const DevSkill* dS, const WarmArgs& wa, const T
     return hipGetLastError();
 }
 
-// work area in global memory (stream-ordered allocation: no hidden synchronisation, re-entrant across streams)
+// Work area in global memory for the variants no CU's LDS holds.  One area per RESIDENT block (the kernels walk the batch
+// with a block stride), kept per (device, stream) and grown on demand: a tick costs no allocation, the footprint does
+// not scale with the batch (round 4 allocated grid x area on every tick: 1 GB at 131072 instances, 8 GB at 1 M), and a
+// tick can be captured into a hipGraph once the stream's area exists (the first tick of a stream must run outside a
+// capture - hipMalloc cannot be captured; the error says so).  Ticks of one stream are ordered, so they may share
+// the area; ticks on different streams get different areas.
+namespace {
+struct GwsArea { double* ptr; size_t bytes; };
+std::mutex g_gws_mutex;
+std::map<std::pair<int, hipStream_t>, GwsArea> g_gws;
+
+hipError_t gws_area(hipStream_t stream, size_t bytes, double** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_gws_mutex);
+    GwsArea& a = g_gws[std::make_pair(dev, stream)];
+    if (a.bytes < bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return hipErrorStreamCaptureUnsupported;    // (run one tick of this skill on the stream before capturing)
+        // (ticks already enqueued on the stream may still use the old area: they finish first)
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        if (a.ptr) (void)hipFree(a.ptr);
+        a.ptr = nullptr;
+        a.bytes = 0;
+        e = hipMalloc((void**)&a.ptr, bytes);
+        if (e != hipSuccess) return e;
+        a.bytes = bytes;
+    }
+    *out = a.ptr;
+    return hipSuccess;
+}
+
+// blocks of `kernel` the current device holds at once (64 threads, no LDS); cached per device and kernel
+hipError_t resident_blocks(const void* kernel, unsigned* out)
+{
+    static std::mutex m;
+    static std::map<std::pair<int, const void*>, unsigned> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = cache.find(std::make_pair(dev, kernel));
+    if (it != cache.end()) { *out = it->second; return hipSuccess; }
+    int cus = 0, per_cu = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0);
+    if (e != hipSuccess) return e;
+    const unsigned n = (unsigned)(cus > 0 ? cus : 1) * (unsigned)(per_cu > 0 ? per_cu : 1);
+    cache[std::make_pair(dev, kernel)] = n;
+    *out = n;
+    return hipSuccess;
+}
+}  // namespace
+
 template <int N, int NC>
 static hipError_t qp_solve_launch_gws(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                                       const double* q, const double* x, const double* y, double* dq, double* dx,
                                       double* slack, int32_t* status, hipStream_t stream)
 {
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t bytes = (size_t)grid * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
+    if (B <= 0) return hipSuccess;
+    unsigned resident = 0;
+    hipError_t e = resident_blocks((const void*)qp_solve_kernel<N, NC, false, true>, &resident);
+    if (e != hipSuccess) return e;
+    const unsigned long long nblk = (unsigned long long)((B + WAVE - 1) / WAVE);
+    const unsigned grid = (unsigned)(nblk < resident ? nblk : resident);
     double* ws = nullptr;
-    hipError_t e = hipMallocAsync((void**)&ws, bytes, stream);
+    // (the area is sized for the resident blocks whatever this batch needs: it never grows again for this kernel)
+    e = gws_area(stream, (size_t)resident * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double), &ws);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((qp_solve_kernel<N, NC, false, true>), dim3(grid), dim3(WAVE), 0, stream, dS, wa, tk, B, q, x, y, dq,
                        dx, slack, status, ws, ny);
-    e = hipGetLastError();
-    const hipError_t f = hipFreeAsync(ws, stream);
-    return e != hipSuccess ? e : f;
+    return hipGetLastError();
 }
 
 template <int N, int NC>
@@ -368,16 +445,18 @@ static hipError_t qp_data_launch_gws(const DevSkill* dS, const WarmArgs& wa, con
                                      const double* q, const double* x, const double* y, double* Hd, double* A,
                                      double* lb, double* ub, hipStream_t stream)
 {
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t bytes = (size_t)grid * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
+    if (B <= 0) return hipSuccess;
+    unsigned resident = 0;
+    hipError_t e = resident_blocks((const void*)qp_data_kernel<N, NC, true>, &resident);
+    if (e != hipSuccess) return e;
+    const unsigned long long nblk = (unsigned long long)((B + WAVE - 1) / WAVE);
+    const unsigned grid = (unsigned)(nblk < resident ? nblk : resident);
     double* ws = nullptr;
-    hipError_t e = hipMallocAsync((void**)&ws, bytes, stream);
+    e = gws_area(stream, (size_t)resident * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double), &ws);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((qp_data_kernel<N, NC, true>), dim3(grid), dim3(WAVE), 0, stream, dS, wa, tk, B, q, x, y, Hd, A, lb,
                        ub, ws, ny);
-    e = hipGetLastError();
-    const hipError_t f = hipFreeAsync(ws, stream);
-    return e != hipSuccess ? e : f;
+    return hipGetLastError();
 }
 
 // exact-size instantiations (no guards in the active-set loop) for the common

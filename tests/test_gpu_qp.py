@@ -95,7 +95,7 @@ def test_qp_moe_style_skill_ur5(ur5_fk):
         assert np.array_equal(status == 2, rstatus == 2)
         ok = rstatus == 0
         assert ok.sum() > 48
-        assert qp_close(dq[ok], rdq[ok]) and qp_close(slack[ok], rslack[ok])
+        assert qp_close(dq, rdq, rows=ok) and qp_close(slack, rslack, rows=ok)
 
 
 def test_qp_infeasible_is_reported(iiwa_fk):
@@ -317,7 +317,7 @@ def test_qp_infeasible_by_a_dependent_row_is_reported(iiwa_fk, kernel, monkeypat
     assert np.array_equal(status == 2, rstatus == 2)
     ok = rstatus == 0
     assert (status[ok] == 0).all() and np.isnan(dq[~ok]).all()
-    assert qp_close(dq[ok], rdq[ok])
+    assert qp_close(dq, rdq, rows=ok)
 
 
 @pytest.mark.parametrize("force_dynamic", [False, True])
@@ -347,7 +347,7 @@ def test_qp_one_sided_set_with_the_default_other_bound(iiwa_fk, monkeypatch, for
         assert np.array_equal(status, rstatus)
         ok = rstatus == 0
         assert ok.sum() > 250
-        assert qp_close(dq[ok], rdq[ok])
+        assert qp_close(dq, rdq, rows=ok)
         # the floor row is active on the instances that start below it: it really is enforced
         hd, A, lb, ub = clik_oracle.qp_data_batch(spec, 0.0, Q)
         row = (A[:, 0, :7] * dq).sum(axis=1)
@@ -474,7 +474,7 @@ def test_box_family_solver_edge_cases(iiwa_fk, case):
     assert np.array_equal(status, rstatus)
     ok = rstatus == 0
     assert ok.sum() > 600
-    assert qp_close(dq[ok], rdq[ok]) and qp_close(slack[ok], rslack[ok])
+    assert qp_close(dq, rdq, rows=ok) and qp_close(slack, rslack, rows=ok)
     if case == "pinned_state":
         assert np.abs(dq[ok, 3] - 0.25).max() < 1e-12
     if case == "tight_speed":
@@ -578,7 +578,7 @@ def test_qp_general_rows_mixed_family_against_the_oracle_and_the_dual_iteration(
     assert np.array_equal(status[sub], rstatus)
     ok = rstatus == 0
     assert ok.sum() > 100 and (soft_walls or (rstatus == 2).any())
-    assert qp_close(dq[sub][ok], rdq[ok]) and qp_close(slack[sub][ok], rslack[ok])
+    assert qp_close(dq[sub], rdq, rows=ok) and qp_close(slack[sub], rslack, rows=ok)
     assert np.isnan(dq[status == 2]).all()
     # hot start from the tick's own working set
     hot = torch.zeros(len(Q), dtype=torch.int32, device="cuda")
@@ -628,7 +628,7 @@ def test_qp_walls_joint_limits_and_speed_limits_on_every_joint_fit_the_static_ke
     assert np.array_equal(status[sub], rstatus)
     ok = rstatus == 0
     assert ok.sum() > 60
-    assert qp_close(dq[sub][ok], rdq[ok]) and qp_close(slack[sub][ok], rslack[ok])
+    assert qp_close(dq[sub], rdq, rows=ok) and qp_close(slack[sub], rslack, rows=ok)
 
 
 def test_qp_with_three_soft_six_row_tasks_25_variables(iiwa_fk):
@@ -735,12 +735,76 @@ def test_qp_beyond_sixteen_rows_is_served_by_the_global_workspace_kernel(iiwa_fk
     rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, Y=Y)
     assert np.array_equal(status, rstatus) and (rstatus == 0).sum() > 150
     ok = rstatus == 0
-    assert qp_close(np.where(ok[:, None], dq, 0.0), np.where(ok[:, None], rdq, 0.0), ceiling=1e-7)
+    assert qp_close(dq, rdq, rows=ok)            # (the per-instance kappa rule: rdq is the oracle's own array)
     assert _rel(dq[ok], rdq[ok]).max() < 1e-7 and _rel(slack[ok], rslack[ok]).max() < 1e-7
     # the data functions of the reference (H_func / A_func / Blb / Bub) for such a skill
     H, A, lbA, ubA = ctrl.qp_data_batch(0.0, Q[:16], input_var=Y[:16])
     rH, rA, rl, ru = clik_oracle.qp_data_batch(spec, 0.0, Q[:16], Y=Y[:16])
     assert np.abs(A - rA).max() < 1e-12 and np.abs(H - rH).max() < 1e-15
+
+
+def many_rows_skill(iiwa_fk):
+    t, q, y = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("y", 7)
+    T = iiwa_fk["T_fk"](q)
+    lo, hi, vmax = np.array(iiwa_fk["lower"]), np.array(iiwa_fk["upper"]), np.array(iiwa_fk["velocity"])
+    cons = [cc.SetConstraint(label="wall_x", expression=T[0, 3], set_min=-0.9, set_max=0.9, priority=1, constraint_type="hard", gain=5.0),
+            cc.SetConstraint(label="wall_y", expression=T[1, 3], set_min=-0.9, set_max=0.9, priority=2, constraint_type="hard", gain=5.0),
+            cc.SetConstraint(label="wall_z", expression=T[2, 3], set_min=0.05, set_max=1.4, priority=3, constraint_type="hard", gain=5.0),
+            cc.EqualityConstraint(label="pose", expression=skills._pose_expression(T, y), gain=4.0, constraint_type="soft", priority=4),
+            cc.SetConstraint(label="limits", expression=q, set_min=lo, set_max=hi, priority=0, constraint_type="hard", gain=2.0),
+            cc.VelocitySetConstraint(label="speed", expression=q, set_min=-vmax, set_max=vmax, priority=0),
+            cc.EqualityConstraint(label="posture", expression=q - 0.2, gain=0.5, constraint_type="soft", priority=6)]
+    return cc.SkillSpecification("many_rows", t, q, input_var=y, constraints=cons)
+
+
+def test_global_workspace_kernel_walks_large_batches_and_is_graph_capturable(iiwa_fk, monkeypatch):
+    """the global-memory work area of the > 16-row QP kernels is per RESIDENT block and persistent per stream (it
+    was grid x area, allocated on every tick: 1 GB at 131072 instances).  A batch of more blocks than the device holds at
+    once - the kernel walks it with a block stride - gives, instance by instance, the bits of the same instances solved
+    in small batches; the ticks of a stream that has its area can be captured into a hipGraph, and memory use does not
+    grow with the batch."""
+    import torch
+    monkeypatch.setenv("CLIK_FORCE_DYNAMIC", "1")
+    spec = many_rows_skill(iiwa_fk)
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    assert ctrl.kernel_name == "dynamic" and ctrl.n_qp_rows == 30
+    n_draw = 4096
+    Q, Y = skills.synthetic_inputs(iiwa_fk, n_draw, seed=12, distribution="interior")
+    small = ctrl.solve_batch(0.0, Q, input_var=Y)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 64 * cus * 8 * 2 + 37                    # more 64-instance blocks than any occupancy keeps resident, ragged end
+    reps = -(-B // n_draw)
+    Qd = torch.from_numpy(np.tile(Q, (reps, 1))[:B].copy()).cuda()
+    Yd = torch.from_numpy(np.tile(Y, (reps, 1))[:B].copy()).cuda()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    big = ctrl.solve_batch(0.0, Qd, input_var=Yd)
+    torch.cuda.synchronize()
+    dq, slack, status = big[0].cpu().numpy(), big[2].cpu().numpy(), big[3].cpu().numpy()
+    idx = np.arange(B) % n_draw
+    assert np.array_equal(status, small[3][idx])
+    assert np.array_equal(dq, small[0][idx], equal_nan=True) and np.array_equal(slack, small[2][idx], equal_nan=True)
+    # the work area is per resident block: well under 1.2 GB whatever the batch (round 4: 7.9 KB x B = 2.1 GB here)
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < 1.2e9 + 4 * B * (7 + 13 + 1) * 8, used
+    # graph capture of ticks on a stream that already has its area
+    stream = torch.cuda.Stream()
+    out = torch.empty((n_draw, 7), dtype=torch.float64, device="cuda")
+    Qs, Ys = Qd[:n_draw].contiguous(), Yd[:n_draw].contiguous()
+    with torch.cuda.stream(stream):
+        tick = ctrl.bind_batch(Qs, input_var=Ys, out=out)
+        tick()                                   # (outside the capture: the stream's area is created here)
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            tick()
+            tick()
+        out.zero_()
+        graph.replay()
+        stream.synchronize()
+    assert np.array_equal(out.cpu().numpy(), small[0], equal_nan=True)
 
 
 def test_twenty_constraints_in_one_skill(iiwa_fk):
@@ -810,7 +874,9 @@ def test_cold_ticks_of_small_batches_run_four_waves_per_64_instances(iiwa_fk, mo
     rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(skills.qp_skill(iiwa_fk), 0.0, Q[:n], Y=Y[:n])
     assert np.array_equal(status[:n], rstatus)
     ok = rstatus == 0
-    assert qp_close(np.where(ok[:, None], dq[:n], 0.0), np.where(ok[:, None], rdq, 0.0))
+    assert qp_close(dq[:n], rdq, rows=ok)        # (held to the per-instance kappa rule, not the flat ceiling)
+    from tolerances import LAST
+    assert LAST["rule"] == "kappa" and LAST["checked"] >= ok.sum() - LAST["left_out"]
     monkeypatch.setenv("CLIK_QP_FOLIO", "0")          # (read once per process by the launcher: a fresh controller does not
     #                                                    re-read it - compare through a hot-started tick instead)
     hot = torch.zeros(B, dtype=torch.int32, device="cuda")

@@ -26,7 +26,9 @@ answer is defined only up to c * u * kappa, whichever correct solver (CasADi's, 
          the device's answer passes the KKT check at KKT_TOL.
 
 Instances whose bound exceeds ILL_POSED (undamped inverse of a rank-deficient stack, lam ~ 1e-16) are no parity
-evidence either way and are left out, counted.  Modes must be identical wherever the smallest tangent-cone decision
+evidence either way and are left out, counted (`LAST["left_out"]`); a comparison that leaves out more than MAX_LEFT_OUT
+of its instances - or all of them - FAILS: it compared nothing.  A NaN from the device where the reference is finite
+fails.  Modes must be identical wherever the smallest tangent-cone decision
 margin of the instance (`clik_oracle.tangent_cone_margin`) exceeds MODE_MARGIN.
 
 Measured against the reference's own Python over the stand-in casadi (tests/golden/ref_pins.npz): err / (u kappa) <= 0.8
@@ -92,46 +94,76 @@ def _kappa_for(ref):
     return clik_oracle.condition_of(ref)
 
 
-def pinv_close(a, ref, ceiling=PINV_RTOL):
-    """`a` against `ref` under the rule.  When `ref` is what the numpy oracle's last solve returned (the array itself or a
-    basic slice of it), every instance is held to ITS bound max(FLOOR, FACTOR u kappa) (ill-posed ones left out);
-    otherwise - a comparison of two device results, a fixture, a row subset - to the default-options ceiling."""
-    err = rel_err(np.atleast_2d(a), np.atleast_2d(ref))
-    kappa = _kappa_for(ref)
+MAX_LEFT_OUT = 0.25     # a comparison that leaves more than this share of its instances out as ill-posed is no comparison
+LAST = {}               # what the most recent *_close / worst_over_tol call did: {"rule", "checked", "left_out", "worst"}
+
+
+def _compare(a, ref, rows, kappa, ceiling, what):
+    """the shared body of pinv_close / qp_close.  `ref` rows that are NaN (the oracle's "infeasible") are no instances;
+    a NaN in `a` where `ref` is finite is a FAILURE.  `rows`: boolean mask of the instances to compare (so that `ref` can
+    stay the array the oracle returned and every instance keeps ITS kappa); `kappa`: condition numbers [B] given
+    explicitly (`cond_out` of the oracle), else looked up from the oracle's last solve when `ref` is its result."""
+    a, ref = np.atleast_2d(np.asarray(a, dtype=float)), np.atleast_2d(np.asarray(ref, dtype=float))
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    keep = ~np.isnan(ref).any(axis=1)
+    if rows is not None:
+        keep &= np.asarray(rows, dtype=bool)
     if kappa is None:
-        return bool((err < ceiling).all())
-    tol = rtol_from_cond(kappa)
-    posed = tol < ILL_POSED
-    return bool((err[posed] <= tol[posed]).all())
-
-
-def qp_close(a, ref, ceiling=QP_RTOL):
-    """the same for the QP path (kappa = clik_oracle.qp_condition of each instance; infeasible rows - NaN - are skipped)"""
-    a, ref = np.atleast_2d(a), np.atleast_2d(ref)
-    good = ~np.isnan(ref).any(axis=1)
+        kappa = _kappa_for(ref)
+    LAST.clear()
+    if np.isnan(a[keep]).any():
+        LAST.update(rule="nan", checked=int(keep.sum()), left_out=0, worst=float("inf"))
+        return False
     err = np.zeros(len(ref))
-    err[good] = rel_err(a[good], ref[good])
-    kappa = _kappa_for(ref)
+    err[keep] = rel_err(a[keep], ref[keep])
     if kappa is None:
-        return bool((err < ceiling).all())
-    tol = rtol_from_cond(kappa)
-    posed = good & (tol < ILL_POSED)
+        LAST.update(rule="ceiling", checked=int(keep.sum()), left_out=0, worst=float(err.max() / ceiling) if len(err) else 0.0)
+        return bool((err[keep] < ceiling).all())
+    tol = rtol_from_cond(np.asarray(kappa, dtype=float))
+    assert tol.shape == err.shape, (what, "kappa does not belong to this batch", tol.shape, err.shape)
+    posed = keep & (tol < ILL_POSED)
+    left_out = int((keep & ~posed).sum())
+    LAST.update(rule="kappa", checked=int(posed.sum()), left_out=left_out,
+                worst=float((err[posed] / tol[posed]).max()) if posed.any() else 0.0)
+    if keep.any() and (not posed.any() or left_out > MAX_LEFT_OUT * keep.sum()):
+        return False            # (nothing, or too little, was actually compared)
     return bool((err[posed] <= tol[posed]).all())
 
 
-def worst_over_tol(a, ref, rows=None):
-    """max over the well-posed instances of err / (the rule's bound), kappa looked up from the oracle solve that returned
-    `ref` (must be that array or a basic slice of it; `rows`: boolean mask of the instances to look at).  The sweeps of
-    tools/fuzz_*.py flag a skill when this exceeds 1.  Returns (ratio, worst err, instances left out as ill-posed)."""
-    kappa = _kappa_for(ref)
-    assert kappa is not None, "worst_over_tol needs the array the oracle returned"
+def pinv_close(a, ref, ceiling=PINV_RTOL, rows=None, kappa=None):
+    """`a` against `ref` under the rule.  With `kappa` [B] given, or when `ref` is what the numpy oracle's last solve
+    returned (the array itself or a basic slice of it), every instance is held to ITS bound max(FLOOR, FACTOR u kappa);
+    instances beyond ILL_POSED are left out, COUNTED in `LAST`, and the comparison FAILS when it leaves out more than
+    MAX_LEFT_OUT of them (or all).  Otherwise - a comparison of two device results, a fixture - the default-options
+    ceiling applies to every row.  Select instances with `rows=mask`, not by indexing `ref` (a fancy-indexed copy is
+    no longer the oracle's array: it would silently fall back to the ceiling).  A NaN from the device where the
+    reference is finite fails."""
+    return _compare(a, ref, rows, kappa, ceiling, "pinv_close")
+
+
+def qp_close(a, ref, ceiling=QP_RTOL, rows=None, kappa=None):
+    """the same for the QP path (kappa = clik_oracle.qp_condition of each instance; rows the oracle reports infeasible -
+    NaN in `ref` - are no instances)"""
+    return _compare(a, ref, rows, kappa, ceiling, "qp_close")
+
+
+def worst_over_tol(a, ref, rows=None, kappa=None):
+    """max over the well-posed instances of err / (the rule's bound), kappa given or looked up from the oracle solve that
+    returned `ref` (then `ref` must be that array or a basic slice of it; `rows`: boolean mask of the instances to look
+    at).  The sweeps of tools/fuzz_*.py flag a skill when this exceeds 1.  A NaN from the device on an instance the oracle
+    solved counts as an infinite error.  Returns (ratio, worst err, instances left out as ill-posed)."""
+    if kappa is None:
+        kappa = _kappa_for(ref)
+    assert kappa is not None, "worst_over_tol needs the array the oracle returned (or kappa=)"
     a, ref = np.atleast_2d(a), np.atleast_2d(ref)
-    keep = ~np.isnan(ref).any(axis=1) & ~np.isnan(a).any(axis=1)
+    keep = ~np.isnan(ref).any(axis=1)
     if rows is not None:
         keep &= rows
     tol = rtol_from_cond(kappa)
     posed = keep & (tol < ILL_POSED)
     if not posed.any():
         return 0.0, 0.0, int((keep & ~posed).sum())
+    if np.isnan(a[posed]).any():
+        return float("inf"), float("inf"), int((keep & ~posed).sum())
     err = rel_err(a[posed], ref[posed])
     return float((err / tol[posed]).max()), float(err.max()), int((keep & ~posed).sum())
