@@ -576,6 +576,14 @@ static int extern_needs_kernel(const char* what)
                                    "(casclik_amd.jit needs hipcc)", what, CLIK_DYN_MAX_M);
 }
 
+// a handle created without a built-in kernel (more state variables than the dynamic-shape kernels carry) solves only
+// through an instantiated kernel: say so with the documented code instead of failing inside the launch
+static int no_kernel_for_wide_state(const DevSkill& S, const char* what)
+{
+    return fail(CLIK_EUNSUPPORTED, "%s: the skill has %d state variables (the built-in kernels carry 8) and no kernel "
+                                   "instantiated for it is attached (casclik_amd.jit needs hipcc)", what, S.n);
+}
+
 // C++ aggregate initialiser of a ShapeDesc (field order of clik_device.hpp)
 static std::string shape_to_string(const clik::ShapeDesc& h)
 {
@@ -1037,6 +1045,7 @@ static int pinv_solve_common(const clik_pinv* h, int64_t B, const double* tterms
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     const bool is_static = h->jit_solve || (h->kernel >= 0 && clik::pinv_kernel_is_static(h->kernel));
     if (!is_static && skill_needs_static(S)) return extern_needs_kernel("clik_pinv_solve_batch");
+    if (h->kernel < 0 && !h->jit_solve) return no_kernel_for_wide_state(S, "clik_pinv_solve_batch");
     TickArgs tk;
     if (t_inst == nullptr) {
         int rc = fill_tick(S, tterms, &tk);
@@ -1182,6 +1191,7 @@ extern "C" int clik_pinv_rollout_batch_m(const clik_pinv* h, int64_t B, int32_t 
         return fail(CLIK_EUNSUPPORTED, "the Runge-Kutta rollout needs a shape-specialised kernel (none attached for this skill)");
     if (!h->jit_rollout && (h->kernel < 0 || !clik::pinv_kernel_is_static(h->kernel)) && skill_needs_static(S))
         return extern_needs_kernel("clik_pinv_rollout_batch");
+    if (h->kernel < 0 && !h->jit_rollout) return no_kernel_for_wide_state(S, "clik_pinv_rollout_batch");
     if (!q || !dq) return fail(CLIK_EINVAL, "q and dq must be device pointers");
     if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
     const int stages = method == CLIK_INTEGRATE_RK4 ? 4 : 1;

@@ -603,3 +603,31 @@ def test_seven_dof_arm_with_two_or_three_virtual_variables(iiwa_fk, nx):
     rdq, rdx, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q, X=X)
     assert np.array_equal(status, rstatus) and (rstatus == 0).all()
     assert _rel(dqv, rdq).max() < 1e-8 and _rel(dxv, rdx).max() < 1e-8 and _rel(slack, rslack).max() < 1e-8
+
+
+def test_a_wide_state_skill_without_an_instantiated_kernel_reports_unsupported(iiwa_fk, monkeypatch):
+    """a pinv handle with nine state variables has no built-in kernel; with run-time instantiation switched
+    off the controller says so at set-up (NotImplementedError), and the C ABI - asked to solve with such a handle -
+    answers CLIK_EUNSUPPORTED with a message naming the cause instead of a failed launch"""
+    import ctypes as C
+    import torch
+    from casclik_amd import _capi
+    monkeypatch.setenv("CLIK_JIT", "0")
+    t, q, x = cs.MX.sym("t"), cs.MX.sym("q", 7), cs.MX.sym("x", 2)
+    T = iiwa_fk["T_fk"](q)
+    cons = [cc.EqualityConstraint(label="a", expression=T[:3, 3] - cs.vertcat(x, 0.5), gain=1.0, priority=1),
+            cc.EqualityConstraint(label="b", expression=x - np.array([0.3, 0.2]), gain=1.0, priority=2)]
+    spec = cc.SkillSpecification(label="wide", time_var=t, robot_var=q, virtual_var=x, constraints=cons)
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    with pytest.raises(NotImplementedError):
+        ctrl.setup_problem_functions()
+    lib, handle = ctrl._lib, ctrl._handle
+    assert lib.clik_pinv_kernel_name(handle).decode() == "none"
+    Q = torch.zeros((4, 7), dtype=torch.float64, device="cuda")
+    X = torch.zeros((4, 2), dtype=torch.float64, device="cuda")
+    dQ, dX = torch.empty_like(Q), torch.empty_like(X)
+    mode = torch.empty(4, dtype=torch.int32, device="cuda")
+    p = lambda tns: C.c_void_p(tns.data_ptr())          # noqa: E731
+    rc = lib.clik_pinv_solve_batch(handle, 4, None, p(Q), p(X), None, p(dQ), p(dX), p(mode), None)
+    assert rc == _capi.CLIK_EUNSUPPORTED
+    assert b"state variables" in lib.clik_last_error() and b"instantiated" in lib.clik_last_error()
