@@ -543,12 +543,12 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         # what the ISSUE of the kernel's fp64 instructions costs on this machine with nothing else going on (bare-FMA waves
         # in the same launch shape and register allocation, tools/probe_fp64_peak.hip; recorded, not measured here)
         try:
-            with open(os.path.join(ROOT, "profiles", "r4_fp64_issue_ceiling.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r5_fp64_issue_ceiling.json")) as f:
                 probe = json.load(f).get("%s_%s_B%d_%s" % (workload, dist_name, B, kernel))
         except Exception:
             probe = None
         if probe:
-            roof["issue_probe"] = dict(probe, source="profiles/r4_fp64_issue_ceiling.json")
+            roof["issue_probe"] = dict(probe, source="profiles/r5_fp64_issue_ceiling.json")
         if prof and "fp64_flops_per_launch" in prof:
             # executed fp64 flops (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes, FMA = 2) over the measured
             # tick time: what the VALUs did, not what the literal algorithm would need
