@@ -220,6 +220,7 @@ class ReactiveQPController(BaseController):
         # against 7.4); for other skills on request (function_opts["jit_values"] = True or CLIK_JIT_VALUES=2: it keeps
         # the LDS work area and gains about 1 %); function_opts["jit_values"] = False or CLIK_JIT_VALUES=0: never.
         self.value_kernel = None
+        self._value_variant_fn = None
         jv, env_jv = fopts.get("jit_values", None), os.environ.get("CLIK_JIT_VALUES", "1")
         wanted = jv is True or env_jv == "2" or (jv is None and self._lib.clik_qp_is_box_family(handle) == 1)
         if want_jit and wanted and jv is not False and env_jv != "0" and self.kernel_name not in ("dynamic", "none"):
@@ -227,6 +228,11 @@ class ReactiveQPController(BaseController):
             with torch.cuda.device(self._device):
                 try:
                     self.value_kernel = jit.attach_qp_values(self._lib, handle, cdesc, extern=d.extern_source())
+                    if self.value_kernel:
+                        import ctypes as C
+                        fn = jit.attach_qp_values.last_library.clik_jit_qp_value_variant
+                        fn.restype, fn.argtypes = C.c_char_p, [C.c_longlong, C.c_int]
+                        self._value_variant_fn = fn
                 except RuntimeError as exc:
                     import warnings
                     warnings.warn("value-specialised QP kernel could not be built, using the image-reading one: %s"
@@ -514,24 +520,17 @@ class ReactiveQPController(BaseController):
     # -- per tick -----------------------------------------------------------------
     def kernel_variant(self, batch, hot=False):
         """name of the kernel a batch of ``batch`` instances gets ("/v": with the skill's numbers compiled in; ``hot``:
-        for a hot-started tick)"""
-        import os
+        for a hot-started tick).  The suffix behind "/v" is the LAUNCHER's own decision: the instantiated library
+        exports the predicate it launches by (clik_jit_qp_value_variant, csrc/clik_qp_static.hpp::qp_values_choice) -
+        "/folio4": cold ticks of small batches, four waves per 64 instances with different starts of the passes;
+        "/front4": hot-started ticks of small batches, four lanes per instance sharing the sin / cos evaluations;
+        "/quad4", "/occ2": experiment switches; nothing: one lane per instance."""
         name = self.kernel_name + ("/v" if getattr(self, "value_kernel", None) else "")
-        if (getattr(self, "value_kernel", None) and os.environ.get("CLIK_QP_LANES", "")[:1] == "4" and int(batch) <= 16384
-                and self._lib.clik_qp_is_box_family(self._handle)):
-            name += "/quad4"         # (experiment: four lanes per instance, clik_qp_static.hpp)
-        elif getattr(self, "value_kernel", None) and self._lib.clik_qp_is_box_family(self._handle):
-            # COLD ticks of small batches: four waves per 64 instances, each with its own start of the active-set passes
-            # (clik_qp_static.hpp, FOLIO); a hot-started tick keeps the lone-wave kernel
-            folio = os.environ.get("CLIK_QP_FOLIO", "")[:1]
-            try:
-                import torch
-                cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-            except Exception:
-                cus = 0
-            blocks = (int(batch) + 63) // 64
-            if folio != "0" and blocks <= cus and not hot:
-                name += "/folio4"
+        fn = getattr(self, "_value_variant_fn", None)
+        if getattr(self, "value_kernel", None) and fn is not None:
+            torch = _torch()
+            with torch.cuda.device(self._device):
+                name += fn(int(batch), 1 if hot else 0).decode()
         return name
 
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,

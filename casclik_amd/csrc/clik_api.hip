@@ -830,6 +830,10 @@ extern "C" int clik_pinv_create(const clik_skill_desc* desc, const clik_pinv_opt
         const char* lb = getenv("CLIK_LARGE_BATCH");
         if (lb && lb[0] == '0') h->mode_parallel |= 16;
         if (clik::pinv_kernel_is_static(h->kernel)) h->mode_parallel |= 32;
+        {
+            const char* qf = getenv("CLIK_QUAD_FRONT");      // 0: single-mode skills keep one lane per instance at small batches
+            if (qf && qf[0] == '0') h->mode_parallel |= 128;
+        }
         const char* ln = getenv("CLIK_LANES");
         if (!ln || ln[0] == '0' || ln[0] == '\0') h->mode_parallel |= 4;
         else if (ln[0] == '4') h->mode_parallel |= 4 | 8;

@@ -785,10 +785,13 @@ __device__ __forceinline__ const Img<SD>* load_image(const void* __restrict__ im
     return (const Img<SD>*)lds;
 }
 
-template <const ShapeDesc& SD>
+// HAVE_SC: the sines / cosines of the state variables come from the caller (sns / css: the four lanes of a quad
+// evaluated two each, pinv_solve_static_values_quad_kernel); otherwise every lane evaluates all of them
+template <const ShapeDesc& SD, bool HAVE_SC = false>
 __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, const TickArgs& tk,
                                                  const double (&z)[SD.n], const double* ys, const int lane,
-                                                 const bool valid, double (&vout)[SD.n], int& acc_mode)
+                                                 const bool valid, double (&vout)[SD.n], int& acc_mode,
+                                                 const double* sns = nullptr, const double* css = nullptr)
 {
     constexpr int N = SD.n;
     static_assert(StaticLayout<SD>::n_sets <= kStaticMaxSets, "too many SetConstraints for a static shape");
@@ -804,7 +807,17 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     {
         Kin<N> K;
         if constexpr (SD.uses_fk != 0) {
-            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (HAVE_SC) {
+                double sn[N], cs[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    sn[j] = sns[j];
+                    cs[j] = css[j];
+                }
+                forward_kinematics_sc<SD>(S, z, sn, cs, K);
+            } else {
+                forward_kinematics_s<SD>(S, z, K);
+            }
             if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ys, lane, K);
         }
         cache_task<SD, 0>(S, tk, K, z, ys, lane, tc);
@@ -1437,8 +1450,14 @@ inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long l
     if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch)))
         return (mode_parallel & 64) ? "team4v" : "team4";       // bit 6: a value-specialised team kernel is attached
     const int ns = shape_n_sets(sd);
-    if ((mode_parallel & 64) && sd.n_x == 0 && !sd.qp && (ns <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd)) && B <= CLIK_VALUE_LANE_MAX_BATCH)
-        return "lanev";   // value-specialised lane kernel attached
+    if ((mode_parallel & 64) && sd.n_x == 0 && !sd.qp && (ns <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd)) && B <= CLIK_VALUE_LANE_MAX_BATCH) {
+        // value-specialised kernels attached: four lanes per instance (split sin / cos) at small batches of single-mode
+        // skills with forward kinematics, one lane per instance otherwise  (shape_quad_front_ok, spelled out: this
+        // function is compiled before the kernels)
+        if (!shape_team_ok(sd) && sd.uses_fk != 0 && sd.n >= 3 && sd.n <= 8 && B <= kTeamMaxBatch && !(mode_parallel & 128))
+            return "quadv";
+        return "lanev";
+    }
     if (sd.n_x == 0 && ns <= 1 && B <= kRoleSplitMaxBatch && (mode_parallel & 2)) {
         bool ok = true;
         for (int k = 0; k < (1 << ns); ++k) ok = ok && make_plan(sd, shape_mode_act(sd, k)).helper_ok;
@@ -1618,6 +1637,68 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
     CLIK_BODY_END();
 }
 
+// ... with FOUR LANES PER INSTANCE for the small batches of single-mode skills that use forward kinematics (BASELINE
+// config 2: 4096 instances are 64 waves of the kernel above on 1024 SIMDs).  A wave has one instruction stream, so
+// the quad can only split work that is the SAME instructions on DIFFERENT data: the sines / cosines of the state
+// variables (lane r evaluates variables 2r and 2r + 1, the quad exchanges them by DPP: 2 evaluations + 28 moves per lane
+// instead of N evaluations - 170 of the 1240 instructions of the config-2 stream); everything behind is evaluated by
+// all four lanes alike (the entries of the <= 8 x 8 matrices cannot be split: clik_pinv_team.hpp) and lane 0 stores.
+// Up to kTeamMaxBatch instances (one wave per SIMD).  Same values as the lane kernel bit for bit.
+constexpr bool shape_quad_front_ok(const ShapeDesc& sd)
+{
+    return shape_value_lane_ok(sd) && !shape_team_ok(sd) && sd.uses_fk != 0 && sd.n >= 3 && sd.n <= 2 * TEAM;
+}
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(TEAM_WAVES * WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_quad_kernel(
+    const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
+    int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
+{
+    static_assert(SD.n_x == 0, "value-specialised kernels: robot variables only");
+    CLIK_BODY_BEGIN();
+    constexpr int N = SD.n;
+    constexpr Img<SD> Sval = IMGV::value;
+    const int tid = threadIdx.x;
+    const int r = tid & (TEAM - 1);
+    const long long inst = (long long)blockIdx.x * TEAM_INST + (tid >> 2);
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    // this lane's two sin / cos arguments first (their loads return first), then the whole row
+    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+    const double a0 = q[row * N + j0], a1 = q[row * N + j1];
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = q[row * N + j];
+    const double* ys = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double sn0, cs0, sn1, cs1;
+    sincos_fast(a0, sn0, cs0);
+    sincos_fast(a1, sn1, cs1);
+    const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
+    if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+        if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
+        if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
+    }
+    double sns[N], css[N];
+    static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+            constexpr int CTRL = (j / 2) * 0x55;           // quad_perm:[k,k,k,k], k = the lane that evaluated variable j
+            sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
+            css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
+        } else {
+            sns[j] = css[j] = 0.0;
+        }
+    });
+    double vout[N];
+    int acc_mode;
+    pinv_tick_static<SD, true>(&Sval, tk, z, ys, tid & (WAVE - 1), valid, vout, acc_mode, sns, css);
+    if (valid && r == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dq[inst * N + j] = vout[j];
+        if (mode_out != nullptr) mode_out[inst] = acc_mode;
+    }
+    CLIK_BODY_END();
+}
+
 // ... and its PERSISTENT form for the batches with many waves per SIMD - a round-4 experiment, compiled only with
 // -DCLIK_LANE_PERSIST (CLIK_JIT_DEFINES): MEASURED SLOWER, profiles/r4_persistent_lane_variants.txt (1 M instances:
 // 67.2 against 65.5 us; 262144: 19.6 against 17.6), bit-identical results (tools/persist_check.py).  The idea: counters
@@ -1726,6 +1807,15 @@ inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, l
     if constexpr (shape_team_ok(SD)) {
         if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch))
             return launch_solve_team_values<SD, IMGV>(a, tk, B, q, y, dq, mode, stream);
+    }
+    if constexpr (shape_quad_front_ok(SD)) {
+        // (bit 7 of mode_parallel: CLIK_QUAD_FRONT=0 keeps one lane per instance - a measuring switch)
+        if (B <= kTeamMaxBatch && !(a.mode_parallel & 128)) {
+            const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
+            hipLaunchKernelGGL((pinv_solve_static_values_quad_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0,
+                               stream, q, y, dq, mode, B, tk);
+            return hipGetLastError();
+        }
     }
     if constexpr (shape_value_lane_ok(SD)) {
         if (B <= kValueLaneMaxBatch) {

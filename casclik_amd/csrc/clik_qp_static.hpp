@@ -1757,13 +1757,16 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 // One ReactiveQPController tick of the lane's instance: FK, rows, reduced QP, active set.
 // v: [robot_vel; virtual_vel], sl: slack values, hot: the lane's working-set word (nullable).
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
-template <const ShapeDesc& SD, int SSTR = WAVE, bool QUAD = false, bool FOLIO = false>
+// HAVE_SC: the sines / cosines of the state variables come from the caller (sns / css: evaluated two per lane of a
+// quad, or two per wave of a FOLIO block, and exchanged), otherwise this lane evaluates all of them
+template <const ShapeDesc& SD, int SSTR = WAVE, bool QUAD = false, bool FOLIO = false, bool HAVE_SC = false>
 __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
                                               const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
                                               const int lane, const bool valid, double* slots,
                                               double (&v)[SD.n], double (&sl)[QpLayout<SD>::NSA],
                                               int32_t* hot, const bool use_hot, const double omega = 1.0,
-                                              double* jstash = nullptr, const QpFolio* fo = nullptr, int* my_key = nullptr)
+                                              double* jstash = nullptr, const QpFolio* fo = nullptr, int* my_key = nullptr,
+                                              const double* sns = nullptr, const double* css = nullptr)
 {
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
@@ -1775,7 +1778,17 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
     {
         Kin<N> K;
         if constexpr (SD.uses_fk != 0) {
-            forward_kinematics_s<SD>(S, z, K);
+            if constexpr (HAVE_SC) {
+                double sn[N], cs[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    sn[j] = sns[j];
+                    cs[j] = css[j];
+                }
+                forward_kinematics_sc<SD>(S, z, sn, cs, K);
+            } else {
+                forward_kinematics_s<SD>(S, z, K);
+            }
             if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(S, ysl, lane, K);
         }
         cache_task<SD, 0, true>(S, tk, K, z, ysl, lane, tc);
@@ -2346,6 +2359,90 @@ __global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_quad_values_kern
     }
 }
 
+// ... and HOT-started ticks of small batches with four lanes per instance that split nothing but the sines / cosines of
+// the state variables (lane r evaluates variables 2r and 2r + 1, DPP exchange: the same split as
+// pinv_solve_static_values_quad_kernel - a wave has one instruction stream, the passes cannot be split): 1024 waves
+// at 16384 instances, one per SIMD, each 265 instructions shorter than the lone-wave kernel's 1814.  All four lanes hold
+// the same answer bit for bit; lane 0 stores.  ("front4"; CLIK_QP_FRONT4=0 keeps the lone-wave kernel.)
+template <const ShapeDesc& SD>
+constexpr bool qp_front4_ok() { return QpLayout<SD>::BOX && SD.uses_fk != 0 && SD.n >= 3 && SD.n <= 8; }
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_front4_values_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
+    const TickArgs tk)
+{
+    using LY = QpLayout<SD>;
+    static_assert(LY::BOX, "box family only");
+    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
+    constexpr QpImg<SD> kValues = IMGV::value;
+    CLIK_BODY_BEGIN();
+    const int tid = threadIdx.x;
+    const int r = tid & 3;
+    const long long inst = (long long)blockIdx.x * WAVE + (tid >> 2);
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    auto state = [&](const int j) __attribute__((always_inline)) {
+        return (j < NQ) ? q[row * NQ + j] : x[row * NX + (j - NQ)];
+    };
+    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+    const double a0 = state(j0), a1 = state(j1);
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
+    }
+    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    double sn0, cs0, sn1, cs1;
+    sincos_fast(a0, sn0, cs0);
+    sincos_fast(a1, sn1, cs1);
+    const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
+    if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+        if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
+        if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
+    }
+    double sns[N], css[N];
+    static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+            constexpr int CTRL = (j / 2) * 0x55;
+            sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
+            css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
+        } else {
+            sns[j] = css[j] = 0.0;
+        }
+    });
+    double priv[LY::SLOTS];
+    double v[N], sl[LY::NSA];
+    int32_t hot_word = (hot_set != nullptr) ? hot_set[row] : 0;
+    const int status = qp_tick_static<SD, 1, false, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, tid & (WAVE - 1),
+                                                                 valid, priv, v, sl, hot_set != nullptr ? &hot_word : nullptr,
+                                                                 use_hot != 0, 1.0, nullptr, nullptr, nullptr, sns, css);
+    if (valid && r == 0) {
+        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
+        if constexpr (NX > 0) {
+            if (dx != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
+            }
+        }
+        if constexpr (NS > 0) {
+            if (slack_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+            }
+        }
+        if (status_out != nullptr) status_out[inst] = status;
+        if (hot_set != nullptr) hot_set[inst] = hot_word;
+    }
+    CLIK_BODY_END();
+}
+
 // ... with four WAVES per 64 instances, each with its own start of the passes (FOLIO, see qp_box_pas): cold ticks of
 // batches up to one block per CU.  Every wave runs the whole tick of its lanes' instances; what it finished it leaves in
 // LDS with the key it recorded, and after the block's barrier the first wave stores, per instance, the answer under the
@@ -2369,9 +2466,32 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS, NSA = LY::NSA;
     constexpr QpImg<SD> kValues = IMGV::value;
     __shared__ int key_min[WAVE];
+    // the block's four waves work on the SAME 64 instances: wave w evaluates the sines / cosines of state variables
+    // 2w and 2w + 1 only and the block shares them through LDS (2 of N evaluations per wave: 200 instructions fewer
+    // in each wave's front end)
+    constexpr bool SHARE_SC = SD.uses_fk != 0 && kFolioWaves == 4 && N >= 3 && N <= 8;
+    __shared__ double sc_lds[SHARE_SC ? 2 * N : 1][WAVE];
     CLIK_BODY_BEGIN();
     const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     if (w == 0) key_min[lane] = 0x7fffffff;
+#ifndef CLIK_QP_FOLIO_IDLE
+    if constexpr (SHARE_SC) {
+        const long long inst_sc = (long long)blockIdx.x * WAVE + lane;
+        const long long row_sc = inst_sc < B ? inst_sc : B - 1;
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 2 * wu + k;
+            if (j < N) {
+                const double a = (j < NQ) ? q[row_sc * NQ + j] : x[row_sc * NX + (j - NQ)];
+                double sn, cs;
+                sincos_joint(a, sn, cs);
+                sc_lds[j][lane] = sn;
+                sc_lds[N + j][lane] = cs;
+            }
+        }
+    }
+#endif
     __syncthreads();
 #ifdef CLIK_QP_FOLIO_IDLE
     if (w != 0) return;          // (measuring switch: the block shape alone - the other three waves leave at once)
@@ -2412,8 +2532,20 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     double v[N], sl[NSA];
     int32_t hot_word = 0;
     int my_key = 0;
-    const int status = qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                                          &hot_word, false, 1.0, nullptr, &fo, &my_key);
+    int status;
+    if constexpr (SHARE_SC) {
+        double sns[N], css[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            sns[j] = sc_lds[j][lane];
+            css[j] = sc_lds[N + j][lane];
+        }
+        status = qp_tick_static<SD, 1, false, true, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
+                                                          &hot_word, false, 1.0, nullptr, &fo, &my_key, sns, css);
+    } else {
+        status = qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
+                                                    &hot_word, false, 1.0, nullptr, &fo, &my_key);
+    }
     __syncthreads();             // (every finish of the block is on record)
     // the wave whose key is the smallest on record stores what it holds in its registers
     if (valid && my_key != 0 && key_min[lane] == my_key) {
@@ -2564,13 +2696,28 @@ inline hipError_t launch_qp_rollout_static_values(const double* d_tterms, int n_
     }
 }
 
-template <const ShapeDesc& SD, class IMGV>
-inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const double* q, const double* x,
-                                          const double* y, double* dq, double* dx, double* slack, int32_t* status,
-                                          int32_t* hot_set, int use_hot, hipStream_t stream)
+// which value-specialised QP kernel serves a batch (ONE predicate: the launcher below and the label
+// clik_jit_qp_value_variant hands to the controllers / bench.py both call it)
+enum QpValueKernel { QPV_GENERAL = 0, QPV_LONE, QPV_FOLIO, QPV_QUAD, QPV_OCC2, QPV_FRONT4 };
+inline int current_device_cus()
 {
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    if constexpr (QpLayout<SD>::BOX) {
+    // (per CURRENT device: a process may drive several, or a partition of one)
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 16 && cached[dev] > 0) return cached[dev];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 16) cached[dev] = cus;
+    return cus;
+}
+template <const ShapeDesc& SD>
+inline QpValueKernel qp_values_choice(long long B, int use_hot)
+{
+    if constexpr (!QpLayout<SD>::BOX) {
+        return QPV_GENERAL;
+    } else {
+        const long long grid = (B + WAVE - 1) / WAVE;
         // (CLIK_QP_FOLIO=0 / 1: the four-waves-per-64-instances kernel for cold ticks of small batches)
         // default: up to ONE block per CU (16384 instances on 256 CUs) - measured per tick against the lone-wave kernel:
         // 10.2 / 11.0 us at 1024 instances, 10.4 / 12.0 at 4096, 11.0 / 12.0 at 8192, 11.2 / 12.1 at 12288, the same at 256
@@ -2582,32 +2729,64 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
             const char* e = getenv("CLIK_QP_FOLIO");
             return e ? ((e[0] == '1') ? 2 : 0) : ((CLIK_QP_FOLIO_DEFAULT != 0) ? 1 : 0);
         }();
-        static const int folio_same = []() { const char* e = getenv("CLIK_QP_FOLIO_SAME"); return (e && e[0] == '1') ? 1 : 0; }();
-        static const int folio_blocks = []() {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-            return cus;
-        }();
-        if (folio != 0 && !use_hot && (long long)grid <= (long long)folio_blocks) {
-            hipLaunchKernelGGL((qp_solve_static_box_folio_values_kernel<SD, IMGV>), dim3(grid), dim3(kFolioWaves * WAVE), 0,
-                               stream, q, y, dq, slack, status, B, x, dx, hot_set, tk, folio_same);
-            return hipGetLastError();
-        }
+        if (folio != 0 && !use_hot && grid <= (long long)current_device_cus()) return QPV_FOLIO;
         static const bool quad = []() { const char* e = getenv("CLIK_QP_LANES"); return e && e[0] == '4'; }();
-        if (quad && B <= 16384) {
-            hipLaunchKernelGGL((qp_solve_static_box_quad_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0, stream, q,
-                               y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
-            return hipGetLastError();
+        if (quad && B <= 16384) return QPV_QUAD;
+        if constexpr (qp_front4_ok<SD>()) {
+            // hot-started ticks (and, with FOLIO switched off, cold ones) of up to one wave per SIMD at four lanes per instance
+            static const bool front4 = []() { const char* e = getenv("CLIK_QP_FRONT4"); return !(e && e[0] == '0'); }();
+            if (front4 && 4 * grid <= 4ll * (long long)current_device_cus()) return QPV_FRONT4;
         }
         static const long long occ2_from = []() {
             const char* e = getenv("CLIK_QP_OCC2_MIN_BATCH");
             return e ? atoll(e) : (long long)CLIK_QP_OCC2_MIN_BATCH;
         }();
-        if (B >= occ2_from) {
+        if (B >= occ2_from) return QPV_OCC2;
+        return QPV_LONE;
+    }
+}
+template <const ShapeDesc& SD>
+inline const char* qp_values_variant(long long B, int use_hot)
+{
+    switch (qp_values_choice<SD>(B, use_hot)) {
+    case QPV_FOLIO: return "/folio4";
+    case QPV_QUAD: return "/quad4";
+    case QPV_FRONT4: return "/front4";
+    case QPV_OCC2: return "/occ2";
+    default: return "";
+    }
+}
+
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const double* q, const double* x,
+                                          const double* y, double* dq, double* dx, double* slack, int32_t* status,
+                                          int32_t* hot_set, int use_hot, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
+    if constexpr (QpLayout<SD>::BOX) {
+        static const int folio_same = []() { const char* e = getenv("CLIK_QP_FOLIO_SAME"); return (e && e[0] == '1') ? 1 : 0; }();
+        switch (qp_values_choice<SD>(B, use_hot)) {
+        case QPV_FOLIO:
+            hipLaunchKernelGGL((qp_solve_static_box_folio_values_kernel<SD, IMGV>), dim3(grid), dim3(kFolioWaves * WAVE), 0,
+                               stream, q, y, dq, slack, status, B, x, dx, hot_set, tk, folio_same);
+            return hipGetLastError();
+        case QPV_QUAD:
+            hipLaunchKernelGGL((qp_solve_static_box_quad_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0, stream, q,
+                               y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
+            return hipGetLastError();
+        case QPV_FRONT4:
+            if constexpr (qp_front4_ok<SD>()) {
+                hipLaunchKernelGGL((qp_solve_static_box_front4_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0,
+                                   stream, q, y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
+                return hipGetLastError();
+            }
+            break;
+        case QPV_OCC2:
             hipLaunchKernelGGL((qp_solve_static_box_values_occ2_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y,
                                dq, slack, status, B, x, dx, hot_set, use_hot, tk);
             return hipGetLastError();
+        default:
+            break;
         }
         hipLaunchKernelGGL((qp_solve_static_box_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
                            slack, status, B, x, dx, hot_set, use_hot, tk);

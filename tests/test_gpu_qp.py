@@ -885,3 +885,39 @@ def test_cold_ticks_of_small_batches_run_four_waves_per_64_instances(iiwa_fk, mo
     assert np.array_equal(status_h, status)
     good = status == 0
     assert _rel(dq_h[good], dq[good]).max() < 1e-9 and _rel(slack_h[good], slack[good]).max() < 1e-9
+
+
+def test_hot_started_ticks_of_small_batches_run_four_lanes_per_instance(iiwa_fk):
+    """clik_qp_static.hpp "front4": a hot-started tick of up to one wave per SIMD (16384 instances on 1024 SIMDs) runs four
+    lanes per instance that share the sin / cos evaluations (two state variables per lane, DPP exchange) and otherwise
+    the lone-wave kernel's stream: the same statuses and the same minimisers as the one-lane kernel serves above that
+    batch size BIT FOR BIT (the same instances tiled into a batch beyond the range), the oracle's within the rule; the
+    label is the launcher's own (clik_jit_qp_value_variant: one predicate for launch and name)."""
+    import torch
+    from oracle import clik_oracle
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    small, big = 64 * cus, 64 * cus + 64
+    assert ctrl.kernel_variant(small, hot=True).endswith("/v/front4") and ctrl.kernel_variant(small).endswith("/v/folio4")
+    assert ctrl.kernel_variant(big, hot=True).endswith("/v") and ctrl.kernel_variant(big).endswith("/v")
+    B = 3001
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=33, distribution="mixed")
+    hot = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot, use_hot=False)            # cold: fills the working sets
+    start = hot.clone()
+    dq, _, slack, status = ctrl.solve_batch(0.0, Q, input_var=Y, hot_set=hot, use_hot=True)      # front4
+    # the same instances, hot-started from the same working sets, inside a batch beyond front4's range (lone-wave kernel)
+    reps = -(-big // B)
+    Qb, Yb = np.tile(Q, (reps, 1))[:big], np.tile(Y, (reps, 1))[:big]
+    hot_b = start.repeat(reps)[:big].contiguous()
+    dq_b, _, slack_b, status_b = ctrl.solve_batch(0.0, Qb, input_var=Yb, hot_set=hot_b, use_hot=True)
+    assert np.array_equal(status, status_b[:B])
+    assert np.array_equal(dq, dq_b[:B], equal_nan=True) and np.array_equal(slack, slack_b[:B], equal_nan=True)
+    assert torch.equal(hot, hot_b[:B])
+    n = 400
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[:n], Y=Y[:n])
+    assert np.array_equal(status[:n], rstatus)
+    assert qp_close(dq[:n], rdq, rows=rstatus == 0) and qp_close(slack[:n], rslack, rows=rstatus == 0)

@@ -154,7 +154,10 @@ def test_default_selection_by_batch(iiwa_fk, monkeypatch):
     assert img.kernel_variant(1 << 20).endswith("/lane/occ2")      # (the ahead-of-time shapes' large-batch build)
     pose = cc.PseudoInverseController(skill_spec=skills.pose_skill(iiwa_fk))
     pose.setup_problem_functions()
-    assert pose.kernel_variant(16384).endswith("/lanev" if pose.value_kernel else "/lane")      # (never the team kernel)
+    # (never the config-3 team kernel: a single-mode skill with forward kinematics runs four lanes per instance with the
+    # sin / cos evaluations split over the quad up to 16384 instances, one lane per instance above)
+    assert pose.kernel_variant(16384).endswith("/quadv" if pose.value_kernel else "/lane")
+    assert pose.kernel_variant(16385).endswith("/lanev" if pose.value_kernel else "/lane")
 
 
 @pytest.mark.parametrize("robot", ["iiwa", "ur5"])
@@ -214,7 +217,7 @@ def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
     ctrl.setup_problem_functions()
     plain = cc.PseudoInverseController(skill_spec=spec, options={"function_opts": {"jit_values": False}})
     plain.setup_problem_functions()
-    assert ctrl.kernel_variant(4096).endswith("lanev") and ctrl.kernel_variant(65536).endswith("lanev")
+    assert ctrl.kernel_variant(4096).endswith("quadv") and ctrl.kernel_variant(65536).endswith("lanev")
     assert plain.kernel_variant(4096).endswith("lane")
     Q, Y = skills.synthetic_inputs(iiwa_fk, 4133, seed=3, distribution="mixed")
     Y = Y[:, :spec.n_input_var]
@@ -224,6 +227,45 @@ def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
     assert (np.abs(dq[::7] - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))).max() < 1e-7
     dq2, _, mode2 = plain.solve_batch(0.0, Q, input_var=Y)
     assert np.array_equal(mode, mode2) and np.allclose(dq, dq2, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("skill", ["pose", "position"])
+def test_four_lanes_per_instance_for_single_mode_skills(iiwa_fk, skill, monkeypatch):
+    """BASELINE config 2 at its own batch sizes (4096 / 16384 instances = 64 / 256 waves of the lane kernel on 1024
+    SIMDs): four lanes per instance, the sin / cos of the state variables split over the quad ("quadv",
+    pinv_solve_static_values_quad_kernel) - the same velocities as one lane per instance (CLIK_QUAD_FRONT=0) bit for
+    bit, ragged batches included, and the oracle's within the stated rule (pseudo_inverse.py:259-451, one mode)"""
+    from oracle import clik_oracle
+    from tolerances import pinv_close
+    spec = skills.pose_skill(iiwa_fk) if skill == "pose" else skills.position_skill(iiwa_fk)
+    quad = cc.PseudoInverseController(skill_spec=spec)
+    quad.setup_problem_functions()
+    if not quad.value_kernel:
+        pytest.skip("no value-specialised kernel attached (hipcc missing)")
+    monkeypatch.setenv("CLIK_QUAD_FRONT", "0")
+    lane = cc.PseudoInverseController(skill_spec=spec)
+    lane.setup_problem_functions()
+    for B in (1, 3, 63, 64, 65, 4096, 16384):
+        assert quad.kernel_variant(B).endswith("/quadv") and lane.kernel_variant(B).endswith("/lanev")
+        Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=40 + B % 7, distribution="mixed")
+        Y = Y[:, :spec.n_input_var]
+        a, _, ma = quad.solve_batch(0.0, Q, input_var=Y)
+        b, _, mb = lane.solve_batch(0.0, Q, input_var=Y)
+        assert np.array_equal(ma, mb) and np.array_equal(a, b), (B, np.abs(a - b).max())
+        if B <= 4096:
+            n = min(B, 300)
+            ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q[:n], Y=Y[:n])
+            assert np.array_equal(ma[:n], rmode) and pinv_close(a[:n], ref)
+    # a joint angle beyond the fast sin / cos range in ONE lane of a quad takes the cold path there only
+    Q, Y = skills.synthetic_inputs(iiwa_fk, 64, seed=2, distribution="interior")
+    Y = Y[:, :spec.n_input_var]
+    Q[5, 2] += 2.0 * np.pi * 40000.0
+    Q[17, 6] -= 2.0 * np.pi * 30000.0
+    a, _, _ = quad.solve_batch(0.0, Q, input_var=Y)
+    b, _, _ = lane.solve_batch(0.0, Q, input_var=Y)
+    assert np.array_equal(a, b)
+    ref, _ = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, Y=Y)
+    assert pinv_close(a, ref, ceiling=1e-6)
 
 
 def test_resident_ticks_fed_from_outside(iiwa_fk):
