@@ -229,7 +229,6 @@ class ReactiveQPController(BaseController):
                 try:
                     self.value_kernel = jit.attach_qp_values(self._lib, handle, cdesc, extern=d.extern_source())
                     if self.value_kernel:
-                        import ctypes as C
                         fn = jit.attach_qp_values.last_library.clik_jit_qp_value_variant
                         fn.restype, fn.argtypes = C.c_char_p, [C.c_longlong, C.c_int]
                         self._value_variant_fn = fn
