@@ -1643,13 +1643,13 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
 // variables (lane r evaluates variables 2r and 2r + 1, the quad exchanges them by DPP: 2 evaluations + 28 moves per lane
 // instead of N evaluations - 170 of the 1240 instructions of the config-2 stream); everything behind is evaluated by
 // all four lanes alike (the entries of the <= 8 x 8 matrices cannot be split: clik_pinv_team.hpp) and lane 0 stores.
-// Up to kTeamMaxBatch instances (one wave per SIMD).  Same values as the lane kernel bit for bit.
+// Up to kTeamMaxBatch instances (one wave per SIMD).  Same values as the lane kernel to rounding.
 constexpr bool shape_quad_front_ok(const ShapeDesc& sd)
 {
     return shape_value_lane_ok(sd) && !shape_team_ok(sd) && sd.uses_fk != 0 && sd.n >= 3 && sd.n <= 2 * TEAM;
 }
 template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(TEAM_WAVES * WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_quad_kernel(
+__global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_quad_kernel(
     const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
     int32_t* __restrict__ mode_out, const long long B, const TickArgs tk)
 {
@@ -1659,7 +1659,9 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) CLIK_OCC_ATTR void pinv_solve_st
     constexpr Img<SD> Sval = IMGV::value;
     const int tid = threadIdx.x;
     const int r = tid & (TEAM - 1);
-    const long long inst = (long long)blockIdx.x * TEAM_INST + (tid >> 2);
+    // (one wave = 16 instances per block - a compile-time shape: reading blockDim.x costs a scalar load from the dispatch
+    // packet and its round trip at the start of every wave, measured as +0.13 us on the config-3 team kernel)
+    const long long inst = (long long)blockIdx.x * (WAVE / TEAM) + (tid >> 2);
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;
     // this lane's two sin / cos arguments first (their loads return first), then the whole row
@@ -1811,8 +1813,13 @@ inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, l
     if constexpr (shape_quad_front_ok(SD)) {
         // (bit 7 of mode_parallel: CLIK_QUAD_FRONT=0 keeps one lane per instance - a measuring switch)
         if (B <= kTeamMaxBatch && !(a.mode_parallel & 128)) {
-            const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
-            hipLaunchKernelGGL((pinv_solve_static_values_quad_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE), 0,
+            // one WAVE per block (16 instances): the dispatcher spreads blocks over the CUs, so up to 4096 instances every
+            // wave has a CU to itself - waves that share a CU run slower each (measured: 3.02 against 3.17 us at 4096
+            // instances with four waves per block, profiles/r5_quad_ab.txt)
+            constexpr int block = WAVE;
+            constexpr int per_block = block / TEAM;
+            const unsigned grid = (unsigned)((B + per_block - 1) / per_block);
+            hipLaunchKernelGGL((pinv_solve_static_values_quad_kernel<SD, IMGV>), dim3(grid), dim3(block), 0,
                                stream, q, y, dq, mode, B, tk);
             return hipGetLastError();
         }

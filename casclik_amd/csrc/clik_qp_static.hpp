@@ -2331,8 +2331,10 @@ __global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_quad_values_kern
     double v[N], sl[LY::NSA];
     int32_t hot_word = (hot_set != nullptr) ? hot_set[row] : 0;
     const double omega = (r == 0) ? 1.0 : ((r == 1) ? 1.3 : ((r == 2) ? 1.5 : 1.7));
+    // (round 5: `hot_set != nullptr ? &hot_word : nullptr` had put the working set into scratch memory - 16 bytes of
+    // private segment, a memory round trip per access; round 3's measurements of this experiment carry that cost)
     const int status = qp_tick_static<SD, 1, true>(&kValues.img, &kValues.tail, tk, z, ysl, tid & (WAVE - 1), valid, priv, v,
-                                                   sl, hot_set != nullptr ? &hot_word : nullptr, use_hot != 0, omega);
+                                                   sl, &hot_word, use_hot != 0 && hot_set != nullptr, omega);
     // the lowest lane of the quad that reached the KKT point stores (lane 0 when none did: its status is reported)
     const int okl = (status == 0) ? 1 : 0;
     const int o0 = __builtin_amdgcn_mov_dpp(okl, 0x00, 0xf, 0xf, true), o1 = __builtin_amdgcn_mov_dpp(okl, 0x55, 0xf, 0xf, true);
@@ -2359,15 +2361,15 @@ __global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_quad_values_kern
     }
 }
 
-// ... and HOT-started ticks of small batches with four lanes per instance that split nothing but the sines / cosines of
+// ... an EXPERIMENT, off by default (see qp_values_choice): ticks of small batches with four lanes per instance that split nothing but the sines / cosines of
 // the state variables (lane r evaluates variables 2r and 2r + 1, DPP exchange: the same split as
 // pinv_solve_static_values_quad_kernel - a wave has one instruction stream, the passes cannot be split): 1024 waves
 // at 16384 instances, one per SIMD, each 265 instructions shorter than the lone-wave kernel's 1814.  All four lanes hold
-// the same answer bit for bit; lane 0 stores.  ("front4"; CLIK_QP_FRONT4=0 keeps the lone-wave kernel.)
+// the same answer; lane 0 stores.  ("front4"; CLIK_QP_FRONT4=<waves per CU> turns it on.)
 template <const ShapeDesc& SD>
 constexpr bool qp_front4_ok() { return QpLayout<SD>::BOX && SD.uses_fk != 0 && SD.n >= 3 && SD.n <= 8; }
 template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_front4_values_kernel(
+__global__ __launch_bounds__(WAVE) void qp_solve_static_box_front4_values_kernel(
     const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
     const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
@@ -2380,7 +2382,7 @@ __global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_front4_values_ke
     CLIK_BODY_BEGIN();
     const int tid = threadIdx.x;
     const int r = tid & 3;
-    const long long inst = (long long)blockIdx.x * WAVE + (tid >> 2);
+    const long long inst = (long long)blockIdx.x * (WAVE / 4) + (tid >> 2);      // (one wave = 16 instances per block)
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;
     auto state = [&](const int j) __attribute__((always_inline)) {
@@ -2417,10 +2419,13 @@ __global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_front4_values_ke
     });
     double priv[LY::SLOTS];
     double v[N], sl[LY::NSA];
+    // (the working set in a register: a conditional pointer to it would put it into scratch memory - a memory round trip
+    // per access, measured as 0.25 - 0.7 us per hot tick)
     int32_t hot_word = (hot_set != nullptr) ? hot_set[row] : 0;
     const int status = qp_tick_static<SD, 1, false, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, tid & (WAVE - 1),
-                                                                 valid, priv, v, sl, hot_set != nullptr ? &hot_word : nullptr,
-                                                                 use_hot != 0, 1.0, nullptr, nullptr, nullptr, sns, css);
+                                                                 valid, priv, v, sl, &hot_word,
+                                                                 use_hot != 0 && hot_set != nullptr, 1.0, nullptr, nullptr,
+                                                                 nullptr, sns, css);
     if (valid && r == 0) {
         const double bad = (status == 2) ? __builtin_nan("") : 0.0;
 #pragma unroll
@@ -2469,15 +2474,29 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     // the block's four waves work on the SAME 64 instances: wave w evaluates the sines / cosines of state variables
     // 2w and 2w + 1 only and the block shares them through LDS (2 of N evaluations per wave: 200 instructions fewer
     // in each wave's front end)
-    constexpr bool SHARE_SC = SD.uses_fk != 0 && kFolioWaves == 4 && N >= 3 && N <= 8;
+#ifndef CLIK_QP_FOLIO_SHARE_SC
+#define CLIK_QP_FOLIO_SHARE_SC 1
+#endif
+    constexpr bool SHARE_SC = (CLIK_QP_FOLIO_SHARE_SC != 0) && SD.uses_fk != 0 && kFolioWaves == 4 && N >= 3 && N <= 8;
     __shared__ double sc_lds[SHARE_SC ? 2 * N : 1][WAVE];
     CLIK_BODY_BEGIN();
     const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     if (w == 0) key_min[lane] = 0x7fffffff;
+    // (the rows are requested BEFORE the block's barrier: one memory round trip, not two)
+    const long long inst = (long long)blockIdx.x * WAVE + lane;
+    const bool valid = inst < B;
+    const long long row = valid ? inst : B - 1;
+    double z[N];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
+    if constexpr (NX > 0) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
+    }
+    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
 #ifndef CLIK_QP_FOLIO_IDLE
     if constexpr (SHARE_SC) {
-        const long long inst_sc = (long long)blockIdx.x * WAVE + lane;
-        const long long row_sc = inst_sc < B ? inst_sc : B - 1;
+        const long long row_sc = row;
         const int wu = __builtin_amdgcn_readfirstlane(w);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -2504,17 +2523,6 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
         for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    const long long inst = (long long)blockIdx.x * WAVE + lane;
-    const bool valid = inst < B;
-    const long long row = valid ? inst : B - 1;
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
-    if constexpr (NX > 0) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
-    }
-    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
     QpFolio fo;
     fo.key_slot = &key_min[lane];
     fo.sid = w;
@@ -2733,9 +2741,13 @@ inline QpValueKernel qp_values_choice(long long B, int use_hot)
         static const bool quad = []() { const char* e = getenv("CLIK_QP_LANES"); return e && e[0] == '4'; }();
         if (quad && B <= 16384) return QPV_QUAD;
         if constexpr (qp_front4_ok<SD>()) {
-            // hot-started ticks (and, with FOLIO switched off, cold ones) of up to one wave per SIMD at four lanes per instance
-            static const bool front4 = []() { const char* e = getenv("CLIK_QP_FRONT4"); return !(e && e[0] == '0'); }();
-            if (front4 && 4 * grid <= 4ll * (long long)current_device_cus()) return QPV_FRONT4;
+            // MEASURED, NOT THE DEFAULT (profiles/r5_quad_ab.txt): cold ticks gain 1.5 - 2 % over the lone wave (FOLIO gains
+            // more), hot-started ticks LOSE 0.25 - 0.7 us at every batch size although each wave issues 266
+            // instructions fewer.  CLIK_QP_FRONT4=<n> (read at every launch: a measuring switch) turns it on for
+            // batches of up to n waves per CU.
+            const char* e = getenv("CLIK_QP_FRONT4");
+            const int front4 = e ? atoi(e) : 0;
+            if (front4 > 0 && 4 * grid <= (long long)front4 * (long long)current_device_cus()) return QPV_FRONT4;
         }
         static const long long occ2_from = []() {
             const char* e = getenv("CLIK_QP_OCC2_MIN_BATCH");
@@ -2776,8 +2788,9 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
             return hipGetLastError();
         case QPV_FRONT4:
             if constexpr (qp_front4_ok<SD>()) {
-                hipLaunchKernelGGL((qp_solve_static_box_front4_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0,
-                                   stream, q, y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
+                // (one wave = 16 instances per block: the dispatcher spreads the blocks over the CUs)
+                hipLaunchKernelGGL((qp_solve_static_box_front4_values_kernel<SD, IMGV>), dim3((unsigned)((B + 15) / 16)),
+                                   dim3(WAVE), 0, stream, q, y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
                 return hipGetLastError();
             }
             break;

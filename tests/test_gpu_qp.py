@@ -887,11 +887,12 @@ def test_cold_ticks_of_small_batches_run_four_waves_per_64_instances(iiwa_fk, mo
     assert _rel(dq_h[good], dq[good]).max() < 1e-9 and _rel(slack_h[good], slack[good]).max() < 1e-9
 
 
-def test_hot_started_ticks_of_small_batches_run_four_lanes_per_instance(iiwa_fk):
-    """clik_qp_static.hpp "front4": a hot-started tick of up to one wave per SIMD (16384 instances on 1024 SIMDs) runs four
+def test_four_lanes_per_instance_qp_experiment_and_the_launchers_own_labels(iiwa_fk, monkeypatch):
+    """clik_qp_static.hpp "front4" (an experiment, CLIK_QP_FRONT4=<waves per CU>; measured slower for hot-started ticks,
+    profiles/r5_quad_ab.txt): a tick of a small batch runs four
     lanes per instance that share the sin / cos evaluations (two state variables per lane, DPP exchange) and otherwise
-    the lone-wave kernel's stream: the same statuses and the same minimisers as the one-lane kernel serves above that
-    batch size BIT FOR BIT (the same instances tiled into a batch beyond the range), the oracle's within the rule; the
+    the lone-wave kernel's stream: the same statuses, the same working sets and - to rounding - the same minimisers as
+    the one-lane kernel that serves batches above that size (the same instances tiled into such a batch), the oracle's within the rule; the
     label is the launcher's own (clik_jit_qp_value_variant: one predicate for launch and name)."""
     import torch
     from oracle import clik_oracle
@@ -901,6 +902,8 @@ def test_hot_started_ticks_of_small_batches_run_four_lanes_per_instance(iiwa_fk)
     ctrl.setup_solver()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     small, big = 64 * cus, 64 * cus + 64
+    assert ctrl.kernel_variant(small, hot=True).endswith("/v") and ctrl.kernel_variant(small).endswith("/v/folio4")
+    monkeypatch.setenv("CLIK_QP_FRONT4", "4")
     assert ctrl.kernel_variant(small, hot=True).endswith("/v/front4") and ctrl.kernel_variant(small).endswith("/v/folio4")
     assert ctrl.kernel_variant(big, hot=True).endswith("/v") and ctrl.kernel_variant(big).endswith("/v")
     B = 3001
@@ -914,9 +917,11 @@ def test_hot_started_ticks_of_small_batches_run_four_lanes_per_instance(iiwa_fk)
     Qb, Yb = np.tile(Q, (reps, 1))[:big], np.tile(Y, (reps, 1))[:big]
     hot_b = start.repeat(reps)[:big].contiguous()
     dq_b, _, slack_b, status_b = ctrl.solve_batch(0.0, Qb, input_var=Yb, hot_set=hot_b, use_hot=True)
-    assert np.array_equal(status, status_b[:B])
-    assert np.array_equal(dq, dq_b[:B], equal_nan=True) and np.array_equal(slack, slack_b[:B], equal_nan=True)
-    assert torch.equal(hot, hot_b[:B])
+    assert np.array_equal(status, status_b[:B]) and torch.equal(hot, hot_b[:B])
+    good = status == 0
+    # (two instantiations of the same source: the compiler fuses and orders their arithmetic differently - equal to rounding)
+    assert _rel(dq[good], dq_b[:B][good]).max() < 1e-9 and _rel(slack[good], slack_b[:B][good]).max() < 1e-9
+    print("front4 against the one-lane kernel: %.2e" % _rel(dq[good], dq_b[:B][good]).max())
     n = 400
     rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[:n], Y=Y[:n])
     assert np.array_equal(status[:n], rstatus)
