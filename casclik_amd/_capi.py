@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libclik_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ClikLibraryError(RuntimeError):

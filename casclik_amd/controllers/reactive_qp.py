@@ -222,7 +222,10 @@ class ReactiveQPController(BaseController):
         self.value_kernel = None
         self._value_variant_fn = None
         jv, env_jv = fopts.get("jit_values", None), os.environ.get("CLIK_JIT_VALUES", "1")
-        wanted = jv is True or env_jv == "2" or (jv is None and self._lib.clik_qp_is_box_family(handle) == 1)
+        # (skills with more than ten state variables - two arms - keep the image-reading kernel unless asked: the
+        # value-specialised one holds its n x n factor in registers)
+        wanted = jv is True or env_jv == "2" or (jv is None and self._lib.clik_qp_is_box_family(handle) == 1
+                                                  and d.n_state <= 10)
         if want_jit and wanted and jv is not False and env_jv != "0" and self.kernel_name not in ("dynamic", "none"):
             from .. import jit
             with torch.cuda.device(self._device):

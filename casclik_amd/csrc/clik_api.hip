@@ -63,6 +63,7 @@ int qp_pick_static(const ShapeDesc& sd);
 const char* qp_static_name(int k);
 bool qp_box_family_rt(const ShapeDesc& sd);
 int qp_plan_rows_rt(const ShapeDesc& sd);
+int qp_layout_slots_rt(const ShapeDesc& sd);
 int team_waves_rt(long long B);                 // (clik_pinv.hip)
 hipError_t launch_ticket_feed(void* ticket, const unsigned* done, int n_ticks, int closed_loop, unsigned waves_per_tick,
                               unsigned long long timeout_ticks, hipStream_t stream);
@@ -534,8 +535,9 @@ static bool qp_static_eligible(const DevSkill& S)
     // a skill with walls, joint limits and speed limits on every joint of a 7-DoF arm has 10 such rows, not 17)
     const int nr = clik::qp_plan_rows_rt(S.shape);
     if (nr > 16) return false;
-    const int nra = nr > 0 ? nr : 1, nsa = S.n_slack > 0 ? S.n_slack : 1;
-    const size_t slots = (size_t)S.n + S.d.n_y + nra * (nra + 1) / 2 + 3 * nra + (size_t)nra * S.n + nsa;
+    // (the layout's own slot count: the primal families - bound-constrained, mixed - keep no dual Hessian in LDS, so a
+    // two-arm skill with 14 merged box rows fits where the dual form's 14 x 14 + 14 x 14 slots would not)
+    const size_t slots = (size_t)clik::qp_layout_slots_rt(S.shape);
     return img.size() + slots * 64 * sizeof(double) <= 160u * 1024u;
 }
 

@@ -470,6 +470,8 @@ static const QpVariant kQpVariants[] = {
     CLIK_QP_GUARD(8, 8),  CLIK_QP_GUARD(8, 16),
     // beyond 16 rows (up to CLIK_MAX_QPROWS) and / or more than eight states or rows per constraint
     CLIK_QP_GLOBAL(8, 32), CLIK_QP_GLOBAL(12, 16), CLIK_QP_GLOBAL(12, 32),
+    // two 7-DoF arms in one skill (CLIK_MAX_DOF = 14)
+    CLIK_QP_GLOBAL(14, 32),
 };
 constexpr int kNumQpVariants = (int)(sizeof(kQpVariants) / sizeof(kQpVariants[0]));
 
@@ -545,6 +547,16 @@ const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpSha
 bool qp_box_family_rt(const ShapeDesc& sd) { return CLIK_QP_BOX_OK(sd); }
 // rows the shape-specialised kernels hand to their active set: soft equalities folded, hard bounds on the same state merged
 int qp_plan_rows_rt(const ShapeDesc& sd) { return make_qp_plan(sd).nr; }
+// 64-double LDS slots a shape-specialised QP kernel keeps behind the skill image (QpLayout<SD>::SLOTS on the run-time
+// copy of the shape): the primal families (bound-constrained, mixed) keep no dual Hessian there
+int qp_layout_slots_rt(const ShapeDesc& sd)
+{
+    const QpPlanS p = make_qp_plan(sd);
+    const bool primal = CLIK_QP_BOX_OK(sd) || CLIK_QP_MIXED_OK(sd);
+    const int n = sd.n, ny = sd.n_y > 0 ? sd.n_y : 0, nra = p.nr > 0 ? p.nr : 1, nsa = p.ns > 0 ? p.ns : 1;
+    const int nt = nra * (nra + 1) / 2;
+    return n + ny + (primal ? 0 : nt) + 2 * nra + (primal ? 0 : nra) + (primal ? 0 : nra * n) + nsa;
+}
 hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
                             const double* x, const double* y, double* dq, double* dx, double* slack,
                             int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,

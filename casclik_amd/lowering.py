@@ -28,16 +28,16 @@ from .constraints import (EqualityConstraint, SetConstraint,
                           VelocityEqualityConstraint, VelocitySetConstraint)
 from .urdf import JOINT_FIXED
 
-MAX_DOF = 10
+MAX_DOF = 14
 MAX_JOINTS = 12
 MAX_TASKS = 24
-MAX_M = 12              # > DYN_MAX_M rows only in the shape-specialised kernels
+MAX_M = 14              # > DYN_MAX_M rows only in the shape-specialised kernels
 DYN_MAX_M = 8
 MAX_ROWS = 128
 MAX_SETS = 8
 MAX_TSLOTS = 32
 MAX_YTERMS = 4
-MAX_QPVARS = 42
+MAX_QPVARS = 46
 MAX_QPROWS = 32
 MAX_STATIC_TASKS = 8   # SHAPE_MAX_TASKS of csrc/clik_device.hpp
 

@@ -44,13 +44,14 @@
 extern "C" {
 #endif
 
-#define CLIK_ABI_VERSION 5
+#define CLIK_ABI_VERSION 6
 
-#define CLIK_MAX_DOF     10   /* n_state = n_robot_var + n_virtual_var (a 7-DoF arm with two or three virtual
-                                 variables; more than 8 only in the shape-specialised kernels)                */
+#define CLIK_MAX_DOF     14   /* n_state = n_robot_var + n_virtual_var (two 7-DoF arms in one skill, or one arm
+                                 with virtual variables; more than 8 only in the kernels instantiated for the
+                                 skill and in the global-workspace QP kernels; ABI 6: was 10)                 */
 #define CLIK_MAX_JOINTS  12   /* chain joints, fixed ones included                */
 #define CLIK_MAX_TASKS   24   /* constraints per skill (more than 8: the built-in dynamic-shape kernels) */
-#define CLIK_MAX_M       12   /* rows of one constraint expression; more than
+#define CLIK_MAX_M       14   /* rows of one constraint expression; more than
                                  CLIK_DYN_MAX_M only in the shape-specialised kernels
                                  (attached or AOT): the built-in kernels refuse them  */
 #define CLIK_DYN_MAX_M    8
@@ -60,7 +61,7 @@ extern "C" {
                                  1-D set per joint has 128)                        */
 #define CLIK_MAX_TSLOTS  32   /* time-only sub-expressions evaluated by the host  */
 #define CLIK_MAX_YTERMS   4   /* input_var terms per affine row                   */
-#define CLIK_MAX_QPVARS  42   /* n_state + n_slack of the reactive QP (CLIK_MAX_DOF + one slack per row; the
+#define CLIK_MAX_QPVARS  46   /* n_state + n_slack of the reactive QP (CLIK_MAX_DOF + one slack per row; the
                                  kernels instantiated for a skill fold the slack of soft equalities away,
                                  the built-in ones are bounded by their rows)       */
 #define CLIK_MAX_QPROWS  32   /* constraint rows of the reactive QP               */

@@ -57,7 +57,7 @@ def test_shape_of_the_config3_stack():
     rc, init = _describe(lib, skills.stack_skill(fk), opts)
     assert rc == 1
     # joint-limit set and joint centering are joint-space tasks (unit rows q0..q6) ...
-    assert init.count("{1, 2, 3, 4, 5, 6, 7, 0, 0, 0, 0, 0}") == 2
+    assert init.count("{1, 2, 3, 4, 5, 6, 7, 0, 0, 0, 0, 0, 0, 0}") == 2
     # ... the pose rows pick single components of p (bits 0..2) and of the orientation error (bits 12..14)
     assert "1u, 2u, 4u, 4096u, 8192u, 16384u" in init
     # 7 sets (128 modes): outside the static family (at most 64 mode bodies per kernel; the mode-scan kernel serves

@@ -76,7 +76,7 @@ def test_create_rejects_malformed_descriptors(lib):
     assert lib.clik_pinv_create(C.byref(desc), C.byref(opts), C.byref(h)) == -1
     assert b"ABI version" in lib.clik_last_error()
     desc.abi_version = _capi.ABI_VERSION
-    desc.n_q = 11          # (beyond CLIK_MAX_DOF; 9 or 10 states get a handle that waits for an instantiated kernel)
+    desc.n_q = 15          # (beyond CLIK_MAX_DOF = 14; 9 ... 14 states get a handle that waits for an instantiated kernel)
     assert lib.clik_pinv_create(C.byref(desc), C.byref(opts), C.byref(h)) == -2
     desc.n_q = 7
     desc.tasks[0].out_row0[0] = 500

@@ -251,8 +251,11 @@ def test_four_lanes_per_instance_for_single_mode_skills(iiwa_fk, skill, monkeypa
         Y = Y[:, :spec.n_input_var]
         a, _, ma = quad.solve_batch(0.0, Q, input_var=Y)
         b, _, mb = lane.solve_batch(0.0, Q, input_var=Y)
-        # (two instantiations of the same source: equal to rounding, not necessarily to the bit)
-        assert np.array_equal(ma, mb) and pinv_close(a, b, ceiling=1e-9), (B, np.abs(a - b).max())
+        # (two instantiations of the same source: equal to rounding, not necessarily to the bit - held to the rule's
+        # ceiling at the default damping, 8 u (smax^2 + lam) / lam: "mixed" batches of this size hold instances within 1e-4 of
+        # a singularity, where the rounding of either kernel is amplified by 1e7)
+        assert np.array_equal(ma, mb) and pinv_close(a, b), (B, np.abs(a - b).max())
+        assert np.median(np.abs(a - b).max(axis=1)) < 1e-13
         if B <= 4096:
             n = min(B, 300)
             ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q[:n], Y=Y[:n])
@@ -264,7 +267,7 @@ def test_four_lanes_per_instance_for_single_mode_skills(iiwa_fk, skill, monkeypa
     Q[17, 6] -= 2.0 * np.pi * 30000.0
     a, _, _ = quad.solve_batch(0.0, Q, input_var=Y)
     b, _, _ = lane.solve_batch(0.0, Q, input_var=Y)
-    assert pinv_close(a, b, ceiling=1e-9)
+    assert pinv_close(a, b)
     ref, _ = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q, Y=Y)
     assert pinv_close(a, ref, ceiling=1e-6)
 
