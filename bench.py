@@ -65,7 +65,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TF = 78.6       # half of the 157.3 TF fp32 vector peak
-PROFILE_FILES = ("r4_counters.json", "r3_counters.json", "r2_counters.json", "r1_traffic.json")     # newest first
+PROFILE_FILES = ("r5_counters.json", "r4_counters.json", "r3_counters.json", "r2_counters.json", "r1_traffic.json")     # newest first
 BODY_FILES = ("r4_body_time_light.json", "r3_body_time.json")
 METRIC = "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384"
 

@@ -30,6 +30,16 @@ CASES_R4 = {  # round 4 (tools/profile_round4.sh): the hot-started QP tick gets 
     "qp_16384_folio": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v/folio4", "qp_static_kQpPoseIiwa/v/folio4", 220, 16384),
     "qp_4096_folio": ("qp_mixed_B4096_qp_static_kQpPoseIiwa/v/folio4", "qp_static_kQpPoseIiwa/v/folio4", 220, 4096),
 }
+CASES_R5 = {  # round 5 (tools/profile_round5.sh): config 2 runs four lanes per instance (quadv), FOLIO shares its sin / cos
+    "stack_team4v_16384": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
+    "pose_quadv_4096": ("pose_mixed_B4096_kPose6Iiwa/quadv", "kPose6Iiwa/quadv", 172, 4096),
+    "pose_quadv_16384": ("pose_mixed_B16384_kPose6Iiwa/quadv", "kPose6Iiwa/quadv", 172, 16384),
+    "qp_16384_folio": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v/folio4", "qp_static_kQpPoseIiwa/v/folio4", 220, 16384),
+    "qp_4096_folio": ("qp_mixed_B4096_qp_static_kQpPoseIiwa/v/folio4", "qp_static_kQpPoseIiwa/v/folio4", 220, 4096),
+    "qp_16384_hot": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v_hot", "qp_static_kQpPoseIiwa/v", 220, 16384),
+    "stack_lanev_131072": ("stack_mixed_B131072_kStackIiwa/lanev", "kStackIiwa/lanev", 172, 131072),
+    "qp_131072": ("qp_mixed_B131072_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 220, 131072),
+}
 CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per instance, batch)
     "stack_team4v": ("stack_mixed_B16384_kStackIiwa/team4v", "kStackIiwa/team4v", 172, 16384),
     "stack_team4": ("stack_mixed_B16384_kStackIiwa/team4", "kStackIiwa/team4", 172, 16384),
@@ -41,6 +51,8 @@ if "r3" in dst:
     CASES = CASES_R3
 if "r4" in dst:
     CASES = CASES_R4
+if "r5" in dst:
+    CASES = CASES_R5
 out = {"note3": "round 3: the same passes (tools/profile_round3.sh, 310 dispatches each) incl. 131072 and 1 M instances; "
                 "valu_issue_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the share of the "
                 "kernel's duration in which a SIMD issues a VALU instruction, averaged over all SIMDs; "
