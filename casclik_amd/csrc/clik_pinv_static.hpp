@@ -1557,7 +1557,7 @@ constexpr bool shape_team_ok(const ShapeDesc& sd)
 //   A1 = 2 Gm + lam I:    mode 0's lower task through [J; J]:   w2 - 2 J' A1^-1 J w2            (push-through)
 //   A2 = Gm + (1+lam) I:  mode 1's lower task through [I; J] with activations s:
 //                         (x - J' A2^-1 J x) / (1+lam),  x = ((1+lam) - s) o w2                  (Woodbury)
-// 1460 instructions when every lane of the wave accepts mode 0 and 1770 with mode 1, against 1600 / 2800 of the
+// 1460 instructions when every lane of the wave accepts mode 0 and 1770 with mode 1 (round 5: 72 / 30 fewer), against 1600 / 2800 of the
 // plan-driven evaluation (pinv_mode_static) this replaces for the family; same values to rounding (PINV_RTOL).
 // -DCLIK_NO_SOLO keeps the plan-driven evaluation (regression switch).
 template <const ShapeDesc& SD>
@@ -1639,31 +1639,36 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
             t[i] = sacc;
         }
     };
-    // A0: the first equality, processed twice (mode 0) / once behind the set (mode 1)
-    double g3[N], v0[N];
+    // A0: the first equality, processed twice (mode 0) / once behind the set (mode 1);  A1: mode 0's lower task.
+    // Mode 0's velocity is ONE product with J':  J'(y + lam y2) + (w2 - 2 J' t1) = J'(y + lam y2 - 2 t1) + w2
+    // (round 5: three products before, 72 instructions more); J'y alone is mode 1's and is formed there.
+    double v0[N], ysol[M];
     {
-        double A[NT], rd[M], y[M], y2[M], gy2[N];
-        shifted(1.0, lam, A, rd);
+        double u[M];
+        {
+            double A[NT], rd[M], y2[M];
+            shifted(1.0, lam, A, rd);
 #pragma unroll
-        for (int i = 0; i < M; ++i) y[i] = des1[i];
-        ldl_solve_s<M>(A, rd, y);
+            for (int i = 0; i < M; ++i) ysol[i] = des1[i];
+            ldl_solve_s<M>(A, rd, ysol);
 #pragma unroll
-        for (int i = 0; i < M; ++i) y2[i] = y[i];
-        ldl_solve_s<M>(A, rd, y2);
-        jt_times(y, g3);
-        jt_times(y2, gy2);
+            for (int i = 0; i < M; ++i) y2[i] = ysol[i];
+            ldl_solve_s<M>(A, rd, y2);
 #pragma unroll
-        for (int j = 0; j < N; ++j) v0[j] = fma(lam, gy2[j], g3[j]);
-    }
-    // A1: mode 0's lower task
-    {
-        double A[NT], rd[M], t1[M], g1[N];
-        shifted(2.0, lam, A, rd);
-        j_times(w2, t1);
-        ldl_solve_s<M>(A, rd, t1);
-        jt_times(t1, g1);
+            for (int i = 0; i < M; ++i) u[i] = fma(lam, y2[i], ysol[i]);
+        }
+        {
+            double A[NT], rd[M], t1[M];
+            shifted(2.0, lam, A, rd);
+            j_times(w2, t1);
+            ldl_solve_s<M>(A, rd, t1);
 #pragma unroll
-        for (int j = 0; j < N; ++j) v0[j] += fma(-2.0, g1[j], w2[j]);
+            for (int i = 0; i < M; ++i) u[i] = fma(-2.0, t1[i], u[i]);
+        }
+        double gu[N];
+        jt_times(u, gu);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v0[j] = gu[j] + w2[j];
     }
     // the set: tangent-cone test of the mode-0 candidate (:222-252), its activation by state column
     double e0[M0], Jt0[M0];
@@ -1717,11 +1722,12 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
         });
 #pragma unroll
         for (int j = 0; j < N; ++j) x[j] = w2[j] * (one_lam - sact[j]);
-        double A[NT], rd[M], t2[M], g2[N];
+        double A[NT], rd[M], t2[M], g2[N], g3[N];
         shifted(1.0, one_lam, A, rd);
         j_times(x, t2);
         ldl_solve_s<M>(A, rd, t2);
         jt_times(t2, g2);
+        jt_times(ysol, g3);
         const double kap = 1.0 / one_lam;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
