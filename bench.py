@@ -735,6 +735,20 @@ def init_ranks(world, rank, dev, shared_gpu):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     errors = {}
+    # (the communication libraries print their greetings on the process's stdout - "[Gloo] Rank 0 is connected to ..." -;
+    # stdout belongs to the ONE JSON line: send file descriptor 1 to stderr while the group comes up)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _init_ranks(dist, world, rank, dev, shared_gpu, errors)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+
+def _init_ranks(dist, world, rank, dev, shared_gpu, errors):
     if not shared_gpu:
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
