@@ -173,7 +173,10 @@ def test_lowering_rejects_what_the_device_cannot_do(iiwa_fk):
         lower_skill(cc.SkillSpecification("s", t, q, dq, constraints=[cc.EqualityConstraint("v", dq[0])]))
     with pytest.raises(NotImplementedError, match="rows"):
         lower_skill(cc.SkillSpecification("s", t, q, constraints=[
-            cc.EqualityConstraint("thirteen", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3], q[0]))]))
+            cc.EqualityConstraint("fifteen", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3], q[0], q[1], q[2]))]))
+    # (thirteen rows fit since ABI 6: CLIK_MAX_M = 14)
+    assert lower_skill(cc.SkillSpecification("s", t, q, constraints=[
+        cc.EqualityConstraint("thirteen", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3], q[0]))])).tasks[0]["m"] == 13
     # nine rows (the "three point" pose error of ur5_dual_quaternion_vs_transformation_matrix.ipynb cell 20)
     # fit the ABI; only the shape-specialised kernels are wide enough for them
     nine = lower_skill(cc.SkillSpecification("s", t, q, constraints=[
