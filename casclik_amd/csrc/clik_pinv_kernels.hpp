@@ -1368,6 +1368,9 @@ __global__ __launch_bounds__(WAVE) CLIK_ROLL_ATTR void pinv_rollout_static_kerne
 #include "clik_pinv_team.hpp"   // four lanes per instance (needs StaticLayout)
 namespace clik {
 
+#ifndef CLIK_DEFER_INPUT_ROWS
+#define CLIK_DEFER_INPUT_ROWS 1
+#endif
 // value-specialised lane kernel (pinv_solve_static_values_kernel): single-mode skills, and the config-3 family
 // (whose lane evaluation, solo_tick, beats the one-wave-per-mode kernel once the numbers are compiled in: 5.19 / 5.26 /
 // 5.44 us against 5.87 / 5.89 / 5.98 us at 20480 / 24576 / 32768 instances); other skills with up to
@@ -1626,6 +1629,25 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = q[row * N + j];
     const double* ys = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+#if CLIK_DEFER_INPUT_ROWS
+    // The input_var row is requested only once the robot_var row has ARRIVED (its address is made to depend on z[0]).
+    // A batch that fills the device in one generation of waves (65536 - 262144 instances) starts as one burst of loads at
+    // HBM bandwidth - 15 MB at 131072 instances, 2.4 us of a 10 us tick - and a wave cannot start before ITS robot_var
+    // row is through; with the input rows behind the robot_var rows of EVERY wave the last wave starts after half
+    // the burst, and the input rows stream in under the sin / cos and forward-kinematics work that does not need them.
+    // (... requested THERE, into registers: left to itself the compiler issues them 75 instructions before their first use)
+    double yrow[SD.n_y > 0 ? SD.n_y : 1];
+    if constexpr (SD.n_y > 0) {
+        double dep = z[0];
+        int off = 0;             // (an offset, not the pointer: a laundered pointer loses its address space and its loads become FLAT)
+        asm volatile("" : "+v"(off) : "v"(dep));
+        const double* yp = ys + off;
+#pragma unroll
+        for (int k = 0; k < SD.n_y; ++k) yrow[k] = yp[k];
+        __builtin_amdgcn_sched_barrier(0);
+        ys = yrow;
+    }
+#endif
     double vout[N];
     int acc_mode;
     pinv_tick_static<SD>(&Sval, tk, z, ys, lane, valid, vout, acc_mode);

@@ -2244,6 +2244,9 @@ __device__ __forceinline__ void qp_box_values_body(
         for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
     }
     const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    // (requesting the input_var row behind the robot_var row, as pinv_solve_static_values_kernel does, was measured here
+    // too: +1 - 3 % at every batch size, 16384 ... 524288, cold and hot - the row's registers are seven more in a kernel
+    // that already parks 70 in AGPRs; profiles/r5_defer_input_rows.txt)
     double priv[LY::SLOTS];
     double v[N], sl[LY::NSA];
     const int status = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
