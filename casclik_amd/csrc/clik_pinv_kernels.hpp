@@ -1371,6 +1371,9 @@ namespace clik {
 #ifndef CLIK_DEFER_INPUT_ROWS
 #define CLIK_DEFER_INPUT_ROWS 1
 #endif
+#ifndef CLIK_STAGGER_SLEEP
+#define CLIK_STAGGER_SLEEP 0
+#endif
 // value-specialised lane kernel (pinv_solve_static_values_kernel): single-mode skills, and the config-3 family
 // (whose lane evaluation, solo_tick, beats the one-wave-per-mode kernel once the numbers are compiled in: 5.19 / 5.26 /
 // 5.44 us against 5.87 / 5.89 / 5.98 us at 20480 / 24576 / 32768 instances); other skills with up to
@@ -1622,6 +1625,13 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
     constexpr int N = SD.n;
     constexpr Img<SD> Sval = IMGV::value;        // (a local constant: its loads fold to immediates)
     const int lane = threadIdx.x;
+#if CLIK_STAGGER_SLEEP > 0
+    // EXPERIMENT (round 5): batches of several generations of waves (two resident per SIMD, all of the same length) keep
+    // the two waves of a SIMD in lockstep - both end together, both successors wait for their rows together, the SIMD
+    // idles for a memory round trip at every generation.  The second resident wave of every SIMD (blocks 1024 ... 2047 of
+    // the first generation) starts half a wave late, so that the pairs stay out of phase for the rest of the launch.
+    if (B >= 262144 && blockIdx.x >= 1024u && blockIdx.x < 2048u) __builtin_amdgcn_s_sleep(CLIK_STAGGER_SLEEP);
+#endif
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;

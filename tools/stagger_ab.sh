@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 5 experiment: the second resident wave of every SIMD starts late (CLIK_STAGGER_SLEEP x 64 cycles)
+cd "$(dirname "$0")/.."
+run() {
+    label="$1"; shift
+    line=$(env "$@" timeout 200 python bench.py --extras 0 --cpu-baseline 0 --min-timed-ms 500 --ramp-ms 150 $BARGS 2>/dev/null | tail -1)
+    python -c "import json,sys; d=json.loads(sys.argv[1]); print('%-56s %-24s %.3f us/tick' % (sys.argv[2], d['config']['kernel'], d['ms_per_step']*1e3))" "$line" "$label" 2>/dev/null || echo "$label FAILED: ${line:0:200}"
+}
+for b in 262144 1048576; do
+    BARGS="--workload stack --batch $b --steps 200 --warmup 20 --replays 8"
+    run "stack B=$b shipped" CLIK_NOOP=1
+    for v in 28 56 100; do
+        run "stack B=$b second wave of a SIMD $v x 64 cycles late" CLIK_JIT_DEFINES=-DCLIK_STAGGER_SLEEP=$v
+    done
+    run "stack B=$b shipped again" CLIK_NOOP=1
+done
