@@ -599,14 +599,17 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     return entry, (spec, opts, Q, Y)
 
 
-def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrate=False):
+def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrate=False, workload="stack"):
     """BASELINE config 3 at 16384 instances through clik_pinv_resident_run over a ring of `ring` input / output slots
     (a different synthetic batch in every slot; tick k uses slot (k - 1) % ring) with every ticket published ahead
     (tools/resident_probe.py is the long form, closed loop included)."""
     import torch
     import casclik_amd as cc
     from casclik_amd import skills
-    ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(fk), options=dict(skills.STACK_OPTIONS))
+    if workload == "pose":
+        ctrl = cc.PseudoInverseController(skill_spec=skills.pose_skill(fk))
+    else:
+        ctrl = cc.PseudoInverseController(skill_spec=skills.stack_skill(fk), options=dict(skills.STACK_OPTIONS))
     ctrl.setup_problem_functions()
     slots = [skills.synthetic_inputs(fk, B, seed=seed + 17 * s, distribution=dist_name) for s in range(ring)]
     Qr = torch.stack([torch.from_numpy(q).cuda() for q, _ in slots]).contiguous()
@@ -639,9 +642,10 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrat
     slope = (t_long - t_short) / (2 * short)
     return {
         "value": B / per_tick, "unit": "instance-steps/s", "ms_per_step": per_tick * 1e3,
-        "config": {"workload": "BASELINE config 3: %d x iiwa priority stack as RESIDENT ticks (one launch; device-side "
-                               "tickets published ahead of the kernel; inputs and outputs in a ring of %d slots, a "
-                               "different batch in each)%s" % (B, ring, "; the state kept by the kernel (q += clamp(dq, "
+        "config": {"workload": (("BASELINE config 2: %d x iiwa single pose task" if workload == "pose" else
+                                 "BASELINE config 3: %d x iiwa priority stack") + " as RESIDENT ticks (one launch; device-side "
+                                "tickets published ahead of the kernel; inputs and outputs in a ring of %d slots, a "
+                                "different batch in each)%s") % (B, ring, "; the state kept by the kernel (q += clamp(dq, "
                                "+-2) * 1e-3 after every tick, clik_pinv_resident_run_state), only the targets read "
                                "from the ring" if integrate else ""), "batch_per_gpu": B, "ring_depth": ring,
                    "inputs": "%s seeds %s" % (dist_name, [seed + 17 * s for s in range(ring)]),
@@ -877,11 +881,14 @@ def main():
             extras.append(ent)
 
         # config 3 as RESIDENT ticks (one launch, device-side tickets, all published ahead: include/clik.h)
-        for name, integ in (("stack_B16384_resident_fed_ahead", False), ("stack_B16384_resident_state_in_kernel", True)):
+        for name, integ, wl, b in (("stack_B16384_resident_fed_ahead", False, "stack", 16384),
+                                   ("stack_B16384_resident_state_in_kernel", True, "stack", 16384),
+                                   ("pose_B4096_resident_fed_ahead", False, "pose", 4096),
+                                   ("pose_B16384_resident_fed_ahead", False, "pose", 16384)):
             phase(name)
             try:
                 extras.append(dict({"name": name, "n_gpus": world, "dtype": "f64"},
-                                   **measure_resident(fk, args.dist, args.seed, integrate=integ)))
+                                   **measure_resident(fk, args.dist, args.seed, B=b, integrate=integ, workload=wl)))
             except Exception as exc:
                 extras.append({"name": name, "error": repr(exc)})
 

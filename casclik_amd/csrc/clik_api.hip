@@ -38,6 +38,7 @@ int pinv_pick_kernel(const DevSkill& S, int allow_static);
 const char* pinv_kernel_name(int k);
 const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B);
 bool shape_team_ok_rt(const ShapeDesc& sd);
+bool shape_quad_front_ok_rt(const ShapeDesc& sd);
 long long pinv_team_max_batch();
 bool shape_value_lane_ok_rt(const ShapeDesc& sd);
 long long pinv_value_lane_max_batch();
@@ -889,8 +890,9 @@ static int fill_tick(const DevSkill& S, const double* tterms, TickArgs* tk);
 extern "C" int clik_pinv_attach_resident_kernel(clik_pinv* h, void* resident_fn)
 {
     if (!h) return fail(CLIK_EINVAL, "null handle");
-    if (resident_fn && !clik::shape_team_ok_rt(h->host.shape))
-        return fail(CLIK_EUNSUPPORTED, "resident ticks exist for the four-lanes-per-instance family only");
+    if (resident_fn && !clik::shape_team_ok_rt(h->host.shape) && !clik::shape_quad_front_ok_rt(h->host.shape))
+        return fail(CLIK_EUNSUPPORTED, "resident ticks exist for the four-lanes-per-instance kernels only (the config-3 family, "
+                                       "single-mode skills with forward kinematics)");
     h->val_resident = (decltype(h->val_resident))resident_fn;
     return CLIK_OK;
 }
@@ -898,6 +900,8 @@ extern "C" int clik_pinv_attach_resident_kernel(clik_pinv* h, void* resident_fn)
 extern "C" int clik_pinv_resident_waves(const clik_pinv* h, int64_t B)
 {
     if (!h || B <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    // (the config-3 family runs four waves per 64 instances, the single-mode skills one wave per 16: one slot per wave)
+    if (!clik::shape_team_ok_rt(h->host.shape) && clik::shape_quad_front_ok_rt(h->host.shape)) return (int)((B + 15) / 16);
     return clik::team_waves_rt((long long)B);
 }
 

@@ -82,6 +82,7 @@ int pinv_pick_kernel(const DevSkill& S, int allow_static)
 const char* pinv_kernel_name(int k) { return (k >= 0 && k < kNumShapes) ? kShapes[k].name : "none"; }
 const char* pinv_static_variant(const ShapeDesc& sd, int mode_parallel, long long B) { return static_variant(sd, mode_parallel, B); }
 bool shape_team_ok_rt(const ShapeDesc& sd) { return shape_team_ok(sd); }
+bool shape_quad_front_ok_rt(const ShapeDesc& sd) { return shape_quad_front_ok(sd); }
 long long pinv_team_max_batch() { return kTeamMaxBatch; }
 bool shape_value_lane_ok_rt(const ShapeDesc& sd) { return shape_value_lane_ok(sd); }
 long long pinv_value_lane_max_batch() { return kValueLaneMaxBatch; }

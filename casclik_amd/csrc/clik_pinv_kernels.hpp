@@ -1545,6 +1545,10 @@ inline hipError_t launch_solve_team_values(const LaunchArgs& a, const TickArgs& 
 }
 
 constexpr unsigned long long kResidentIntegrateBit = 1ull << 63;
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_resident_quad_values(const TickArgs& tk, long long B, const double* q, const double* y, double* dq,
+                                              int32_t* mode, void* ticket, unsigned* done, int n_ticks,
+                                              unsigned long long timeout_ticks, hipStream_t stream);
 
 template <const ShapeDesc& SD, class IMGV>
 inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, const double* q, const double* y,
@@ -1587,7 +1591,7 @@ inline hipError_t launch_resident_team_values(const TickArgs& tk, long long B, c
                                q, y, dq, mode, B, tk, (ResidentTicket*)ticket, done, n_ticks, budget);
         return hipGetLastError();
     } else {
-        return hipErrorNotSupported;
+        return launch_resident_quad_values<SD, IMGV>(tk, B, q, y, dq, mode, ticket, done, n_ticks, timeout_ticks, stream);
     }
 }
 
@@ -1731,6 +1735,189 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_q
         if (mode_out != nullptr) mode_out[inst] = acc_mode;
     }
     CLIK_BODY_END();
+}
+
+// ... and RESIDENT: one launch that runs tick k whenever ticket k is published (clik_pinv_team.hpp, ResidentTicket: the
+// protocol, the watchdog and the ring of input / output slots are pinv_resident_team_kernel's) - the per-tick launch
+// boundary of 1.1 us is a third of a config-2 tick.  One wave = 16 instances per block, at most one wave per SIMD
+// (launch_resident_team_values); lane r of a quad requests elements 2r and 2r + 1 of its instance's rows - its own sin / cos
+// arguments - and stores the same elements of the velocity row.  The kernel has registers to spare (164 of 512), so
+// the NEXT tick's rows are requested before this tick's arithmetic starts whenever its ticket is already out.
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
+    const double* q, const double* y, double* dq, int32_t* mode_out, const long long B, const TickArgs tk,
+    ResidentTicket* ticket, unsigned* done, const int n_ticks, const unsigned long long max_polls)
+{
+    static_assert(SD.n_x == 0, "value-specialised kernels: robot variables only");
+    constexpr int N = SD.n, NY = SD.n_y > 0 ? SD.n_y : 0;
+    constexpr Img<SD> Sval = IMGV::value;
+    const int tid = threadIdx.x;
+    const int r = tid & (TEAM - 1);
+    const long long inst = (long long)blockIdx.x * (WAVE / TEAM) + (tid >> 2);
+    const bool valid = inst < B;
+    const long long binst = valid ? inst : (B - 1);
+    unsigned long long polls = 0;
+    if (blockIdx.x == 0 && tid == 0) {
+        ticket->waves = gridDim.x;
+        ticket->p3[0] = (unsigned)max_polls;
+        ticket->p3[1] = (unsigned)(max_polls >> 32);
+        ticket->p3[2] = (unsigned)n_ticks;
+    }
+    bool leave = false, have_next = false;
+    unsigned seen = 0u;
+    auto poll_for = [&](const unsigned want) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (;;) {
+            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seen >= want) {
+                __atomic_signal_fence(__ATOMIC_ACQUIRE);
+                return;
+            }
+            if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                leave = true;
+                return;
+            }
+            if (++polls > max_polls) {
+                __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((tid & (WAVE - 1)) == 0) {
+                    ticket->p3[3] = (unsigned)polls;
+                    ticket->p3[4] = blockIdx.x;
+                }
+                leave = true;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    const unsigned ring_raw = __hip_atomic_load(&ticket->ring_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long ring = ring_raw > 1u ? (long long)ring_raw : 1ll;
+    constexpr int RQ = (N + 2 * TEAM - 1) / (2 * TEAM), RY = NY > 0 ? (NY + 2 * TEAM - 1) / (2 * TEAM) : 1;
+    static_assert(RQ == 1, "resident quad kernel: at most eight state variables");
+    double zp[2], yp[2 * RY], zp_next[2], yp_next[2 * RY];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) zp[i] = zp_next[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i] = 0.0;
+    auto request_rows = [&](const int k, double (&zq)[2], double (&yq)[2 * RY]) __attribute__((always_inline)) {
+        const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = 2 * r + i;
+            zq[i] = __hip_atomic_load(q + row * N + (e < N ? e : N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if constexpr (NY > 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * RY; ++i) {
+                const int e = 2 * TEAM * (i / 2) + 2 * r + (i & 1);
+                yq[i] = __hip_atomic_load(y + row * NY + (e < NY ? e : NY - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    auto publish_done = [&](const int k) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((tid & (WAVE - 1)) == 0)
+            __hip_atomic_store(done + blockIdx.x, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
+    };
+    int owed = 0;           // tick whose "done" slot is still to be published (0: none)
+#pragma unroll 1
+    for (int k = 1; k <= n_ticks; ++k) {
+        if (!have_next) {
+            poll_for((unsigned)k);
+            if (leave) break;
+            asm volatile("" ::: "memory");
+            request_rows(k, zp, yp);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) zp[i] = zp_next[i];
+#pragma unroll
+            for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i];
+        }
+        have_next = false;
+        // the next tick's rows, if their ticket is already out: they arrive under this tick's arithmetic
+        if (k < n_ticks && seen >= (unsigned)(k + 1)) {
+            request_rows(k + 1, zp_next, yp_next);
+            have_next = true;
+        }
+        // this lane's own two sin / cos arguments are its share of the row
+        double sn0, cs0, sn1, cs1;
+        sincos_fast(zp[0], sn0, cs0);
+        sincos_fast(zp[1], sn1, cs1);
+        const bool huge = (fabs(zp[0]) > kSinCosFastMax) | (fabs(zp[1]) > kSinCosFastMax);
+        if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+            if (fabs(zp[0]) > kSinCosFastMax) { const SinCos sc = sincos_slow(zp[0]); sn0 = sc.s; cs0 = sc.c; }
+            if (fabs(zp[1]) > kSinCosFastMax) { const SinCos sc = sincos_slow(zp[1]); sn1 = sc.s; cs1 = sc.c; }
+        }
+        double z[N], sns[N], css[N], yrow[NY > 0 ? NY : 1];
+        static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int CTRL = (j / 2) * 0x55;           // quad_perm:[k,k,k,k], k = the lane that holds element j
+            z[j] = quad_perm_f64<CTRL>(zp[j & 1]);
+            if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
+                sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
+                css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
+            } else {
+                sns[j] = css[j] = 0.0;
+            }
+        });
+        if constexpr (NY > 0) {
+            static_for<0, NY>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int CTRL = ((j % (2 * TEAM)) / 2) * 0x55;
+                yrow[j] = quad_perm_f64<CTRL>(yp[2 * (j / (2 * TEAM)) + (j & 1)]);
+            });
+        }
+        double vout[N];
+        int acc_mode;
+        pinv_tick_static<SD, true>(&Sval, tk, z, yrow, tid & (WAVE - 1), valid, vout, acc_mode, sns, css);
+        if (owed != 0) {
+            publish_done(owed);         // (the previous tick's stores: issued a whole tick ago, nothing to wait for)
+            owed = 0;
+        }
+        if (have_next && k + 1 < n_ticks)
+            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
+        if (valid) {
+            const long long orow = ((long long)((k - 1) % (int)ring)) * B + inst;
+            double s0 = vout[N - 1], s1 = vout[N - 1];
+            static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kc)::value;
+                if constexpr (2 * kk < N) s0 = (r == kk) ? vout[2 * kk] : s0;
+                if constexpr (2 * kk + 1 < N) s1 = (r == kk) ? vout[2 * kk + 1] : s1;
+            });
+            const int e = 2 * r;
+            if (e < N) __hip_atomic_store(dq + orow * N + e, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (e + 1 < N) __hip_atomic_store(dq + orow * N + e + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (mode_out != nullptr && r == 0)
+                __hip_atomic_store(mode_out + orow, acc_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (have_next) owed = k;        // published at the end of the next tick (fed ahead: nobody waits for it)
+        else publish_done(k);           // nobody has asked for the next tick yet (a closed loop), or the last one: at once
+    }
+    if (owed != 0) publish_done(owed);
+}
+
+template <const ShapeDesc& SD, class IMGV>
+inline hipError_t launch_resident_quad_values(const TickArgs& tk, long long B, const double* q, const double* y, double* dq,
+                                              int32_t* mode, void* ticket, unsigned* done, int n_ticks,
+                                              unsigned long long timeout_ticks, hipStream_t stream)
+{
+    if constexpr (shape_quad_front_ok(SD)) {
+        if (timeout_ticks & kResidentIntegrateBit) return hipErrorNotSupported;     // (the state kept by the kernel: team family only)
+        const unsigned grid = (unsigned)((B + WAVE / TEAM - 1) / (WAVE / TEAM));
+        // every wave must be resident at once, with room left for the ticket feeder: at most one wave per SIMD
+        int dev = 0, cus = 0, per_cu = 0;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pinv_resident_quad_kernel<SD, IMGV>, WAVE, 0);
+        if (oe == hipSuccess) oe = hipGetDevice(&dev);
+        if (oe == hipSuccess) oe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (oe != hipSuccess) return oe;
+        const long long max_blocks = (long long)cus * (per_cu < 4 ? per_cu : 4);
+        if ((long long)grid > max_blocks) return hipErrorNotSupported;
+        hipLaunchKernelGGL((pinv_resident_quad_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq, mode, B, tk,
+                           (ResidentTicket*)ticket, done, n_ticks, timeout_ticks);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
 }
 
 // ... and its PERSISTENT form for the batches with many waves per SIMD - a round-4 experiment, compiled only with
