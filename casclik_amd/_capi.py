@@ -179,6 +179,7 @@ _SYMBOLS = [
     "clik_pinv_solve_batch", "clik_pinv_solve_batch_t", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
     "clik_qp_create", "clik_qp_create_host", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
     "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel", "clik_qp_image_words", "clik_qp_attach_value_kernel", "clik_qp_is_box_family",
+    "clik_qp_attach_resident_kernel", "clik_qp_resident_waves", "clik_qp_resident_run",
     "clik_qp_solve_batch", "clik_qp_solve_batch_hot", "clik_qp_solve_batch_t", "clik_qp_rollout_batch", "clik_qp_rollout_batch_x", "clik_qp_rollout_batch_m", "clik_qp_data_batch",
 ]
 
@@ -252,6 +253,13 @@ def load_library(path=None):
     lib.clik_pinv_attach_resident_kernel.argtypes = [vp, C.c_void_p]
     lib.clik_pinv_resident_waves.restype = C.c_int
     lib.clik_pinv_resident_waves.argtypes = [vp, C.c_int64]
+    lib.clik_qp_attach_resident_kernel.restype = C.c_int
+    lib.clik_qp_attach_resident_kernel.argtypes = [vp, C.c_void_p]
+    lib.clik_qp_resident_waves.restype = C.c_int
+    lib.clik_qp_resident_waves.argtypes = [vp, C.c_int64]
+    lib.clik_qp_resident_run.restype = C.c_int
+    lib.clik_qp_resident_run.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, ip, C.c_void_p, C.c_void_p,
+                                         C.c_double, C.c_void_p]
     lib.clik_pinv_resident_run_state.restype = C.c_int
     lib.clik_pinv_resident_run_state.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, ip, C.c_void_p, C.c_void_p,
                                                  C.c_double, C.c_double, C.c_double, C.c_void_p]

@@ -535,6 +535,66 @@ class ReactiveQPController(BaseController):
                 name += fn(int(batch), 1 if hot else 0).decode()
         return name
 
+    # -- resident ticks ----------------------------------------------------------------------------------------
+    def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, timeout_s=2.0, stream=None, ring_depth=1):
+        """Launch ONE kernel that stays on the device and solves tick k's QP as soon as ticket k is published
+        (include/clik.h, clik_qp_resident_run - the QP's form of PseudoInverseController.resident_start: same ticket,
+        same ``done`` slots, same rings).  ``robot_var`` / ``input_var`` are device tensors read in place, ``[B, n]`` or
+        with ``ring_depth`` D > 1 rings ``[D, B, n]`` (tick k uses slot ``(k - 1) % D``, outputs likewise).  Every
+        instance's working set stays in the kernel: tick 1 is a cold solve, every later tick is hot-started (the
+        reference's qpOASES instance hot-starts the same way, reactive_qp.py:491-513).  For bound-constrained skills
+        with forward kinematics and without virtual variables; ``NotImplementedError`` otherwise.  Returns a dict with
+        ``ticket``, ``done``, ``waves``, ``out`` (velocities), ``slack``, ``status`` and the launch ``stream``."""
+        self._require_handle()
+        torch = _torch()
+        d = self.descriptor
+        dev = self._device
+        D = int(ring_depth)
+        if D < 1:
+            raise ValueError("ring_depth must be at least 1")
+        if d.n_x > 0:
+            raise NotImplementedError("resident QP ticks: skills without virtual variables only")
+        for name, tns, n in (("robot_var", robot_var, d.n_q), ("input_var", input_var, d.n_y)):
+            if n == 0:
+                continue
+            if not isinstance(tns, torch.Tensor) or not tns.is_cuda or tns.dtype != torch.float64 or not tns.is_contiguous():
+                raise ValueError("resident ticks: %s must be a contiguous float64 device tensor (read in place)" % name)
+            want = (D, tns.shape[-2], n) if D > 1 else (tns.shape[0], n)
+            if tuple(tns.shape) != tuple(want):
+                raise ValueError("resident ticks with ring_depth %d: %s must have shape %s" % (D, name, list(want)))
+        B = int(robot_var.shape[-2])
+        lead = (D,) if D > 1 else ()
+        dQ = torch.zeros(lead + (B, d.n_q), dtype=torch.float64, device=dev)
+        slack = torch.zeros(lead + (B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack > 0 else None
+        status = torch.full(lead + (B,), -1, dtype=torch.int32, device=dev)
+        ticket = torch.zeros(64, dtype=torch.int32, device=dev)
+        ticket[16] = D if D > 1 else 0
+        waves = self._lib.clik_qp_resident_waves(self._handle, B)
+        done = torch.zeros(max(waves, 1), dtype=torch.int32, device=dev)
+        stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        tt, ttp = _capi.tterms_arg(d.time_terms(time_var))
+        torch.cuda.current_stream(dev).synchronize()       # (ticket / outputs are initialised before the kernel starts)
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_qp_resident_run(self._handle, B, int(n_ticks), ttp, ptr(robot_var),
+                                                ptr(input_var) if d.n_y > 0 else None, ptr(dQ), ptr(slack), ptr(status),
+                                                ptr(ticket), ptr(done), float(timeout_s), C.c_void_p(stream.cuda_stream))
+        if rc == _capi.CLIK_EUNSUPPORTED:
+            raise NotImplementedError(self._lib.clik_last_error().decode())
+        _capi.check(self._lib, rc)
+        return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "slack": slack, "status": status,
+                "stream": stream, "keep": (robot_var, input_var, tt)}
+
+    def resident_feed(self, run, n_ticks, closed_loop=False, timeout_s=2.0, stream=None):
+        """The reference producer of resident ticks (clik_ticket_feed, see PseudoInverseController.resident_feed)."""
+        torch = _torch()
+        dev = self._device
+        stream = stream if stream is not None else torch.cuda.Stream(device=dev, priority=-1)
+        with torch.cuda.device(dev):
+            rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), ptr(run["done"]), int(n_ticks), 1 if closed_loop else 0,
+                                            int(run["waves"]), float(timeout_s), C.c_void_p(stream.cuda_stream))
+        _capi.check(self._lib, rc)
+        return stream
+
     def solve_batch(self, time_var, robot_var, virtual_var=None, input_var=None,
                     return_status=True, hot_set=None, use_hot=True):
         """One QP tick for a batch: returns (robot_vel [B,n_q], virtual_vel |

@@ -136,6 +136,9 @@ struct clik_qp {
     clik_jit_qp_rollout_fn jit_rollout;
     clik_jit_qp_value_fn val_solve;     // per-tick kernel with this skill's numbers and QP options compiled in
     clik_jit_qp_value_rollout_fn val_rollout;   // ... and its on-device rollout (box family), or null
+    // ... and its resident form (clik_qp_attach_resident_kernel), or null
+    hipError_t (*val_resident)(const TickArgs*, long long, const double*, const double*, double*, double*, int32_t*, void*,
+                               unsigned*, int, unsigned long long, hipStream_t);
     char      jit_name[64];
 };
 
@@ -1305,6 +1308,7 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     h->static_k = -1;
     h->jit_solve = nullptr;
     h->jit_rollout = nullptr;
+    h->val_resident = nullptr;
     h->jit_name[0] = 0;
     h->dev = nullptr;
     if (host_only_mode()) {
@@ -1459,6 +1463,50 @@ extern "C" int clik_qp_attach_value_kernel(clik_qp* h, void* solve_fn, void* rol
     h->val_solve = (clik_jit_qp_value_fn)solve_fn;
     // (the value-specialised rollout exists for the box family only)
     h->val_rollout = (solve_fn && clik::qp_box_family_rt(h->host.shape)) ? (clik_jit_qp_value_rollout_fn)rollout_fn : nullptr;
+    return CLIK_OK;
+}
+
+extern "C" int clik_qp_attach_resident_kernel(clik_qp* h, void* resident_fn)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    if (resident_fn && !(clik::qp_box_family_rt(h->host.shape) && h->host.d.n_x == 0 && h->host.shape.uses_fk != 0 &&
+                         h->host.n >= 3 && h->host.n <= 8))
+        return fail(CLIK_EUNSUPPORTED, "resident QP ticks exist for bound-constrained skills with forward kinematics and "
+                                       "without virtual variables");
+    h->val_resident = (decltype(h->val_resident))resident_fn;
+    return CLIK_OK;
+}
+
+extern "C" int clik_qp_resident_waves(const clik_qp* h, int64_t B)
+{
+    if (!h || B <= 0) return fail(CLIK_EINVAL, "bad arguments");
+    return (int)((B + 15) / 16);         // (four lanes per instance: one wave per 16 instances, one `done` slot per wave)
+}
+
+extern "C" int clik_qp_resident_run(const clik_qp* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
+                                    const double* y, double* dq, double* slack, int32_t* status, clik_ticket* ticket,
+                                    uint32_t* done, double timeout_s, void* stream)
+{
+    if (!h) return fail(CLIK_EINVAL, "null handle");
+    CLIK_NEEDS_DEVICE_HANDLE(h);
+    if (!h->val_resident)
+        return fail(CLIK_EUNSUPPORTED, "resident QP ticks need the value-specialised kernel of a bound-constrained skill "
+                                       "attached to this handle (none is)");
+    if (B <= 0 || n_ticks <= 0) return fail(CLIK_EINVAL, "B and n_ticks must be positive");
+    if (!q || !dq || !ticket || !done) return fail(CLIK_EINVAL, "q, dq, ticket and done must be device pointers");
+    const DevSkill& S = h->host;
+    if (S.d.n_y > 0 && !y) return fail(CLIK_EINVAL, "skill has input_var: y required");
+    if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
+    TickArgs tk;
+    int rc = fill_tick(S, tterms, &tk);
+    if (rc) return rc;
+    const unsigned long long budget = (unsigned long long)(timeout_s * 4e5);       // (polls, at a nominal 2.5 us each)
+    hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, slack, status, (void*)ticket, (unsigned*)done, n_ticks,
+                                   budget, (hipStream_t)stream);
+    if (e == hipErrorNotSupported)
+        return fail(CLIK_EUNSUPPORTED, "resident QP ticks: %lld instances need more waves than this kernel can keep resident "
+                                       "at once on this device", (long long)B);
+    if (e != hipSuccess) return hipfail(e, "resident QP kernel launch");
     return CLIK_OK;
 }
 

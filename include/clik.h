@@ -291,6 +291,21 @@ int clik_pinv_resident_run_state(const clik_pinv* h, int64_t B, int32_t n_ticks,
 int clik_ticket_feed(clik_ticket* ticket, const uint32_t* done, int32_t n_ticks, int32_t closed_loop,
                      int32_t waves_per_tick, double timeout_s, void* stream);
 
+/* Resident ticks of the ReactiveQPController (round 5; the per-tick body of reactive_qp.py:461-528 as ONE launch that
+ * solves tick k's QP whenever ticket k is published - same ticket, same `done` slots (clik_qp_resident_waves of them),
+ * same ring of input / output slots as clik_pinv_resident_run).  For bound-constrained skills without virtual
+ * variables whose value-specialised kernel is attached (clik_qp_attach_resident_kernel, done by casclik_amd.jit);
+ * CLIK_EUNSUPPORTED otherwise, or when B needs more waves than the device keeps resident.  Every instance's working
+ * set stays in the kernel from tick to tick: tick 1 is a cold solve, every later tick is hot-started, as the
+ * reference's qpOASES instance is (reactive_qp.py:491-513).
+ *   q [ring][B][n_q], y [ring][B][n_y] (device, read in place)  ->  dq [ring][B][n_q], slack [ring][B][n_slack] or NULL,
+ *   status [ring][B] or NULL                                                                                          */
+int clik_qp_attach_resident_kernel(clik_qp* h, void* resident_fn);
+int clik_qp_resident_waves(const clik_qp* h, int64_t B);
+int clik_qp_resident_run(const clik_qp* h, int64_t B, int32_t n_ticks, const double* tterms, const double* q,
+                         const double* y, double* dq, double* slack, int32_t* status, clik_ticket* ticket,
+                         uint32_t* done, double timeout_s, void* stream);
+
 /* replaces solve() (pseudo_inverse.py:512-556) for B instances at once.
  *   q  [B][n_q]   x [B][n_x] or NULL   y [B][n_y] or NULL      (device, in)
  *   dq [B][n_q]   dx [B][n_x] or NULL                           (device, out)
