@@ -2512,23 +2512,25 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
     const long long ring = ring_raw > 1u ? (long long)ring_raw : 1ll;
     static_assert(N <= 8, "resident QP kernel: at most eight state variables");
     constexpr int RY = NY > 0 ? (NY + 7) / 8 : 1;
-    double zp[2], yp[2 * RY];
+    // (a lane's share of the rows is two doubles each: the NEXT tick's shares are requested before this tick's
+    // arithmetic whenever their ticket is already out, and arrive under it)
+    double zp[2], yp[2 * RY], zp_next[2], yp_next[2 * RY];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) zp[i] = 0.0;
+    for (int i = 0; i < 2; ++i) zp[i] = zp_next[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 2 * RY; ++i) yp[i] = 0.0;
-    auto request_rows = [&](const int k) __attribute__((always_inline)) {
+    for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i] = 0.0;
+    auto request_rows = [&](const int k, double (&zq)[2], double (&yq)[2 * RY]) __attribute__((always_inline)) {
         const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = 2 * r + i;
-            zp[i] = __hip_atomic_load(q + row * N + (e < N ? e : N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            zq[i] = __hip_atomic_load(q + row * N + (e < N ? e : N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if constexpr (NY > 0) {
 #pragma unroll
             for (int i = 0; i < 2 * RY; ++i) {
                 const int e = 8 * (i / 2) + 2 * r + (i & 1);
-                yp[i] = __hip_atomic_load(y + row * NY + (e < NY ? e : NY - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                yq[i] = __hip_atomic_load(y + row * NY + (e < NY ? e : NY - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     };
@@ -2540,13 +2542,24 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
     };
     int32_t hot_word = 0;       // the instance's working set: in a register for the whole run
     int owed = 0;
-    (void)have_next;
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
-        poll_for((unsigned)k);
-        if (leave) break;
-        asm volatile("" ::: "memory");
-        request_rows(k);
+        if (!have_next) {
+            poll_for((unsigned)k);
+            if (leave) break;
+            asm volatile("" ::: "memory");
+            request_rows(k, zp, yp);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) zp[i] = zp_next[i];
+#pragma unroll
+            for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i];
+        }
+        have_next = false;
+        if (k < n_ticks && seen >= (unsigned)(k + 1)) {
+            request_rows(k + 1, zp_next, yp_next);
+            have_next = true;
+        }
         double sn0, cs0, sn1, cs1;
         sincos_fast(zp[0], sn0, cs0);
         sincos_fast(zp[1], sn1, cs1);
@@ -2616,8 +2629,8 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         }
         // (the next ticket may be out already: then this tick's "done" is published behind the next tick's arithmetic,
         // its stores a whole tick old; otherwise - a closed loop waits for it - at once)
-        const unsigned peek = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (k < n_ticks && peek >= (unsigned)(k + 1)) owed = k;
+        seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (have_next) owed = k;
         else publish_done(k);
     }
     if (owed != 0) publish_done(owed);
