@@ -748,8 +748,8 @@ def compact_entry(e):
            "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic")}
     if r.get("traffic_source"):
         out["pmc"] = r["traffic_source"].split("#")[-1].split("_k")[0].split("_qp_static")[0]   # case in profiles/r4_counters.json
-    elif "resident" not in e.get("name", ""):
-        # (no counter pass for this entry: the rollouts, config 4 at 4096 - the resident entries keep their explicit nulls)
+    else:
+        # (no counter pass for this entry - the rollouts, the resident ticks: no traffic / fp64 figures)
         out = {k: v for k, v in out.items() if v is not None}
     c = e.get("cpu_baseline")
     if c and "value" in c:
@@ -759,11 +759,10 @@ def compact_entry(e):
     return out
 
 
-NOTES = ("us = wall per tick; roofline.achieved = ALGORITHMIC bytes (172 B/instance-step, QP 220) / tick time vs 8 TB/s - not DRAM "
-         "traffic: the ticks rotate through --ring buffers that stay L2/MALL-resident (`traffic` = PMC bytes of one launch); "
-         "fp64_frac: executed fp64 flops (PMC) vs 78.6 TF; issue_probe_body_us: bare-FMA waves in the tick's launch shape "
-         "(profiles/r5_issue_alignment.md); pmc: case in profiles/*_counters.json; cpu_M_per_s: C port on cpu_baseline.cores "
-         "THREADS (cgroup quota in cpu_baseline.quota_cores) - a stated baseline, not a speed-up; --full 1: details")
+NOTES = ("us = wall per tick; roofline.achieved = ALGORITHMIC bytes (172 B/instance-step, QP 220) / tick vs 8 TB/s, not DRAM traffic "
+         "(ticks rotate through --ring buffers; `traffic` = PMC bytes per launch, profiles/r5_counters.json); fp64_frac: executed "
+         "flops (PMC) vs 78.6 TF; cpu_M_per_s: C port on cpu_baseline.cores threads (quota_cores: cgroup), a baseline not a "
+         "speed-up; cost model: profiles/r5_tick_cost_model.md; --full 1: details")
 
 
 def device_uuid(index):
