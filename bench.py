@@ -744,10 +744,11 @@ def compact_entry(e):
         return {"error": e["error"][:120]}
     r = e.get("roofline") or {}
     f64 = r.get("fp64") or {}
-    out = {"us": _r(e["ms_per_step"] * 1e3, 3), "G_per_s": _r(e["value"] / 1e9, 3), "kernel": e["config"].get("kernel"),
+    out = {"us": _r(e["ms_per_step"] * 1e3, 3), "G_per_s": _r(e["value"] / 1e9, 3),
+           "kernel": str(e["config"].get("kernel")).replace("qp_static_kQpPoseIiwa", "kQp").replace("Iiwa", ""),
            "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic")}
     if r.get("traffic_source"):
-        out["pmc"] = r["traffic_source"].split("#")[-1].split("_k")[0].split("_qp_static")[0]   # case in profiles/r4_counters.json
+        pass        # (the counter case is the entry's own name, workload_inputs_B<batch>, in profiles/r5_counters.json)
     else:
         # (no counter pass for this entry - the rollouts, the resident ticks: no traffic / fp64 figures)
         out = {k: v for k, v in out.items() if v is not None}
