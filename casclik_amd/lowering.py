@@ -34,7 +34,7 @@ MAX_TASKS = 24
 MAX_M = 14              # > DYN_MAX_M rows only in the shape-specialised kernels
 DYN_MAX_M = 8
 MAX_ROWS = 128
-MAX_SETS = 8
+MAX_SETS = 10
 MAX_TSLOTS = 32
 MAX_YTERMS = 4
 MAX_QPVARS = 46

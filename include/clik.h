@@ -56,9 +56,9 @@ extern "C" {
                                  (attached or AOT): the built-in kernels refuse them  */
 #define CLIK_DYN_MAX_M    8
 #define CLIK_MAX_ROWS   128   /* affine rows over all constraints                 */
-#define CLIK_MAX_SETS     8   /* SetConstraints -> 2^8 modes (more than 6 sets: the
-                                 built-in mode-scan kernels; a 7-DoF arm with one
-                                 1-D set per joint has 128)                        */
+#define CLIK_MAX_SETS    10   /* SetConstraints -> 2^10 modes (more than 6 sets: the built-in mode-scan kernels, which
+                                 walk the reference's mode table; a 7-DoF arm with one 1-D set per joint has 128, six
+                                 joint limits and three walls 512)                 */
 #define CLIK_MAX_TSLOTS  32   /* time-only sub-expressions evaluated by the host  */
 #define CLIK_MAX_YTERMS   4   /* input_var terms per affine row                   */
 #define CLIK_MAX_QPVARS  46   /* n_state + n_slack of the reactive QP (CLIK_MAX_DOF + one slack per row; the

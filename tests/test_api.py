@@ -182,12 +182,15 @@ def test_lowering_rejects_what_the_device_cannot_do(iiwa_fk):
     nine = lower_skill(cc.SkillSpecification("s", t, q, constraints=[
         cc.EqualityConstraint("nine", cs.vertcat(T[:3, 0], T[:3, 1], T[:3, 2]))]))
     assert nine.tasks[0]["m"] == 9
-    # one 1-D set per joint of a 7-DoF arm (128 modes) lowers; nine sets (512 modes) are beyond the device limit
+    # one 1-D set per joint of a 7-DoF arm (128 modes) lowers, and so do ten sets (1024 modes, CLIK_MAX_SETS since round 5);
+    # eleven are beyond the device limit
     seven_sets = [cc.SetConstraint("s%d" % i, q[i], set_min=-1.0, set_max=1.0, priority=i) for i in range(7)]
     assert lower_skill(cc.SkillSpecification("s", t, q, constraints=seven_sets)).n_sets == 7
-    nine_sets = seven_sets + [cc.SetConstraint("w%d" % i, T[i, 3], set_min=-1.0, set_max=1.0, priority=9) for i in range(2)]
+    ten_sets = seven_sets + [cc.SetConstraint("w%d" % i, T[i, 3], set_min=-1.0, set_max=1.0, priority=9) for i in range(3)]
+    assert lower_skill(cc.SkillSpecification("s", t, q, constraints=ten_sets)).n_sets == 10
+    eleven_sets = ten_sets + [cc.SetConstraint("w3", T[0, 0], set_min=-1.0, set_max=1.0, priority=9)]
     with pytest.raises(NotImplementedError, match="modes"):
-        lower_skill(cc.SkillSpecification("s", t, q, constraints=nine_sets))
+        lower_skill(cc.SkillSpecification("s", t, q, constraints=eleven_sets))
 
 
 def test_controller_needs_the_hip_library_or_gpu():

@@ -658,3 +658,32 @@ def test_two_seven_dof_arms_in_one_skill(iiwa_fk):
     rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(qspec, 0.0, Q, Y=Y)
     assert np.array_equal(status, rstatus) and (rstatus == 0).all()
     assert qp_close(dqv, rdq) and qp_close(slack, rslack), (_rel(dqv, rdq).max(), _rel(slack, rslack).max())
+
+
+def test_nine_set_constraints_512_modes(ur5_fk):
+    """CLIK_MAX_SETS is 10 since round 5: the six 1-D joint-limit sets of the dual-quaternion notebooks
+    (ur5_dual_quaternion_comparison_of_controllers.ipynb cell 14) together with the three task-space walls of the
+    Moe-2016 example (ur5_moe2016_example2.ipynb cell 9) in ONE skill: nine sets, 512 modes, walked in the reference's
+    order (pseudo_inverse.py:107-130, :530-550) by the built-in mode-scan kernel; modes and velocities against the
+    oracle on states planted near limits and walls"""
+    from oracle import clik_oracle
+    fk = ur5_fk
+    t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
+    T = fk["T_fk"](q)
+    lo, hi = np.array(fk["lower"]), np.array(fk["upper"])
+    cons = [cc.SetConstraint(label="limit_q%d" % i, expression=q[i], set_min=max(lo[i], -2.5), set_max=min(hi[i], 2.5), priority=i)
+            for i in range(6)]
+    cons += [cc.SetConstraint(label="wall_%s" % ax, expression=T[k, 3], set_min=-0.3, set_max=0.3, priority=6 + k)
+             for k, ax in enumerate("xyz")]
+    # (a target beyond the walls: the tool pushes against several of them at once)
+    cons.append(cc.EqualityConstraint(label="reach", expression=T[:3, 3] - np.array([0.9, -0.8, 0.9]), gain=2.0, priority=20))
+    spec = cc.SkillSpecification(label="nine_sets", time_var=t, robot_var=q, constraints=cons)
+    ctrl = cc.PseudoInverseController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    assert ctrl.n_modes == 512
+    rng = np.random.default_rng(9)
+    Q = rng.uniform(-3.0, 3.0, size=(128, 6))           # (beyond +-2.5 in some joints, the tool beyond the walls for many)
+    dq, _, mode = ctrl.solve_batch(0.0, Q)
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q)
+    assert np.array_equal(mode, rmode) and len(np.unique(mode)) > 30 and mode.max() > 100
+    assert pinv_close(dq, ref), _rel(dq, ref).max()
