@@ -1756,41 +1756,10 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
     const long long inst = (long long)blockIdx.x * (WAVE / TEAM) + (tid >> 2);
     const bool valid = inst < B;
     const long long binst = valid ? inst : (B - 1);
-    unsigned long long polls = 0;
-    if (blockIdx.x == 0 && tid == 0) {
-        ticket->waves = gridDim.x;
-        ticket->p3[0] = (unsigned)max_polls;
-        ticket->p3[1] = (unsigned)(max_polls >> 32);
-        ticket->p3[2] = (unsigned)n_ticks;
-    }
-    bool leave = false, have_next = false;
-    unsigned seen = 0u;
-    auto poll_for = [&](const unsigned want) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (;;) {
-            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (seen >= want) {
-                __atomic_signal_fence(__ATOMIC_ACQUIRE);
-                return;
-            }
-            if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
-                leave = true;
-                return;
-            }
-            if (++polls > max_polls) {
-                __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((tid & (WAVE - 1)) == 0) {
-                    ticket->p3[3] = (unsigned)polls;
-                    ticket->p3[4] = blockIdx.x;
-                }
-                leave = true;
-                return;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    const unsigned ring_raw = __hip_atomic_load(&ticket->ring_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const long long ring = ring_raw > 1u ? (long long)ring_raw : 1ll;
+    ResidentWave rw;
+    rw.init(ticket, done, max_polls, n_ticks, blockIdx.x, gridDim.x, tid);
+    bool have_next = false;
+    const long long ring = rw.ring_depth();
     constexpr int RQ = (N + 2 * TEAM - 1) / (2 * TEAM), RY = NY > 0 ? (NY + 2 * TEAM - 1) / (2 * TEAM) : 1;
     static_assert(RQ == 1, "resident quad kernel: at most eight state variables");
     double zp[2], yp[2 * RY], zp_next[2], yp_next[2 * RY];
@@ -1813,18 +1782,12 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
             }
         }
     };
-    auto publish_done = [&](const int k) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((tid & (WAVE - 1)) == 0)
-            __hip_atomic_store(done + blockIdx.x, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
-    };
     int owed = 0;           // tick whose "done" slot is still to be published (0: none)
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
         if (!have_next) {
-            poll_for((unsigned)k);
-            if (leave) break;
+            rw.poll_for((unsigned)k);
+            if (rw.leave) break;
             asm volatile("" ::: "memory");
             request_rows(k, zp, yp);
         } else {
@@ -1835,7 +1798,7 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
         }
         have_next = false;
         // the next tick's rows, if their ticket is already out: they arrive under this tick's arithmetic
-        if (k < n_ticks && seen >= (unsigned)(k + 1)) {
+        if (k < n_ticks && rw.seen >= (unsigned)(k + 1)) {
             request_rows(k + 1, zp_next, yp_next);
             have_next = true;
         }
@@ -1871,11 +1834,11 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
         int acc_mode;
         pinv_tick_static<SD, true>(&Sval, tk, z, yrow, tid & (WAVE - 1), valid, vout, acc_mode, sns, css);
         if (owed != 0) {
-            publish_done(owed);         // (the previous tick's stores: issued a whole tick ago, nothing to wait for)
+            rw.publish_done(owed);         // (the previous tick's stores: issued a whole tick ago, nothing to wait for)
             owed = 0;
         }
         if (have_next && k + 1 < n_ticks)
-            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
+            rw.peek();   // (for tick k + 2)
         if (valid) {
             const long long orow = ((long long)((k - 1) % (int)ring)) * B + inst;
             double s0 = vout[N - 1], s1 = vout[N - 1];
@@ -1891,9 +1854,9 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
                 __hip_atomic_store(mode_out + orow, acc_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (have_next) owed = k;        // published at the end of the next tick (fed ahead: nobody waits for it)
-        else publish_done(k);           // nobody has asked for the next tick yet (a closed loop), or the last one: at once
+        else rw.publish_done(k);           // nobody has asked for the next tick yet (a closed loop), or the last one: at once
     }
-    if (owed != 0) publish_done(owed);
+    if (owed != 0) rw.publish_done(owed);
 }
 
 template <const ShapeDesc& SD, class IMGV>

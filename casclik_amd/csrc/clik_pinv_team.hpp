@@ -619,6 +619,77 @@ __device__ __forceinline__ unsigned long long realtime_100mhz()
     return t;
 }
 
+// One wave's side of the ticket protocol (round 5: shared by the resident kernels that run one wave per block -
+// pinv_resident_quad_kernel, qp_resident_box_front4_kernel; pinv_resident_team_kernel above keeps its own copy, with
+// four waves per block).  `slot`: this wave's index into the `done` array.
+struct ResidentWave {
+    ResidentTicket* ticket;
+    unsigned* done;
+    unsigned long long polls, max_polls;
+    unsigned seen, slot;
+    bool leave, lane0, first;
+
+    __device__ __forceinline__ void init(ResidentTicket* t, unsigned* d, const unsigned long long budget, const int n_ticks,
+                                         const unsigned wave_slot, const unsigned n_waves, const int tid)
+    {
+        ticket = t;
+        done = d;
+        polls = 0;
+        max_polls = budget;
+        seen = 0u;
+        slot = wave_slot;
+        leave = false;
+        lane0 = (tid & (WAVE - 1)) == 0;
+        first = wave_slot == 0u && tid == 0;
+        if (first) {
+            ticket->waves = n_waves;
+            ticket->p3[0] = (unsigned)budget;            // (diagnostics: what the launch handed over)
+            ticket->p3[1] = (unsigned)(budget >> 32);
+            ticket->p3[2] = (unsigned)n_ticks;
+        }
+    }
+    // wait until ticket `want` is out (-> `seen`), someone sets `stop`, or the poll budget is used up (-> `leave`)
+    __device__ __forceinline__ void poll_for(const unsigned want)
+    {
+#pragma unroll 1
+        for (;;) {
+            // (relaxed, system scope = a load that bypasses the caches; the rows are read the same way)
+            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seen >= want) {
+                __atomic_signal_fence(__ATOMIC_ACQUIRE);     // (keeps the COMPILER from hoisting a row load above it)
+                return;
+            }
+            if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                leave = true;
+                return;
+            }
+            if (++polls > max_polls) {
+                __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane0) {
+                    ticket->p3[3] = (unsigned)polls;        // (diagnostics: the wave that gave up, and after how many polls)
+                    ticket->p3[4] = slot;
+                }
+                leave = true;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __device__ __forceinline__ void peek() { seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    // every lane's stores acknowledged, then the wave's own slot (no shared counter)
+    __device__ __forceinline__ void publish_done(const int k)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane0) __hip_atomic_store(done + slot, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (first) ticket->ticks_done = (unsigned)k;
+    }
+    __device__ __forceinline__ long long ring_depth() const
+    {
+        const unsigned raw = __hip_atomic_load(&ticket->ring_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return raw > 1u ? (long long)raw : 1ll;
+    }
+};
+
 template <const ShapeDesc& SD, class IMGV, bool INTEGRATE = false>
 __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     const double* q, const double* y, double* dq, int32_t* mode_out, const long long B, const TickArgs tk,

@@ -2475,41 +2475,10 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
     const long long inst = (long long)blockIdx.x * (WAVE / 4) + (tid >> 2);
     const bool valid = inst < B;
     const long long binst = valid ? inst : (B - 1);
-    unsigned long long polls = 0;
-    if (blockIdx.x == 0 && tid == 0) {
-        ticket->waves = gridDim.x;
-        ticket->p3[0] = (unsigned)max_polls;
-        ticket->p3[1] = (unsigned)(max_polls >> 32);
-        ticket->p3[2] = (unsigned)n_ticks;
-    }
-    bool leave = false, have_next = false;
-    unsigned seen = 0u;
-    auto poll_for = [&](const unsigned want) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (;;) {
-            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (seen >= want) {
-                __atomic_signal_fence(__ATOMIC_ACQUIRE);
-                return;
-            }
-            if (__hip_atomic_load(&ticket->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
-                leave = true;
-                return;
-            }
-            if (++polls > max_polls) {
-                __hip_atomic_store(&ticket->stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((tid & (WAVE - 1)) == 0) {
-                    ticket->p3[3] = (unsigned)polls;
-                    ticket->p3[4] = blockIdx.x;
-                }
-                leave = true;
-                return;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    const unsigned ring_raw = __hip_atomic_load(&ticket->ring_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const long long ring = ring_raw > 1u ? (long long)ring_raw : 1ll;
+    ResidentWave rw;
+    rw.init(ticket, done, max_polls, n_ticks, blockIdx.x, gridDim.x, tid);
+    bool have_next = false;
+    const long long ring = rw.ring_depth();
     static_assert(N <= 8, "resident QP kernel: at most eight state variables");
     constexpr int RY = NY > 0 ? (NY + 7) / 8 : 1;
     // (a lane's share of the rows is two doubles each: the NEXT tick's shares are requested before this tick's
@@ -2534,19 +2503,13 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
             }
         }
     };
-    auto publish_done = [&](const int k) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((tid & (WAVE - 1)) == 0)
-            __hip_atomic_store(done + blockIdx.x, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (blockIdx.x == 0 && tid == 0) ticket->ticks_done = (unsigned)k;
-    };
     int32_t hot_word = 0;       // the instance's working set: in a register for the whole run
     int owed = 0;
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
         if (!have_next) {
-            poll_for((unsigned)k);
-            if (leave) break;
+            rw.poll_for((unsigned)k);
+            if (rw.leave) break;
             asm volatile("" ::: "memory");
             request_rows(k, zp, yp);
         } else {
@@ -2556,7 +2519,7 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
             for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i];
         }
         have_next = false;
-        if (k < n_ticks && seen >= (unsigned)(k + 1)) {
+        if (k < n_ticks && rw.seen >= (unsigned)(k + 1)) {
             request_rows(k + 1, zp_next, yp_next);
             have_next = true;
         }
@@ -2593,7 +2556,7 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
                                                                      valid, priv, v, sl, &hot_word, k > 1, 1.0, nullptr, nullptr,
                                                                      nullptr, sns, css);
         if (owed != 0) {
-            publish_done(owed);
+            rw.publish_done(owed);
             owed = 0;
         }
         if (valid) {
@@ -2629,11 +2592,11 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         }
         // (the next ticket may be out already: then this tick's "done" is published behind the next tick's arithmetic,
         // its stores a whole tick old; otherwise - a closed loop waits for it - at once)
-        seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        rw.peek();
         if (have_next) owed = k;
-        else publish_done(k);
+        else rw.publish_done(k);
     }
-    if (owed != 0) publish_done(owed);
+    if (owed != 0) rw.publish_done(owed);
 }
 
 template <const ShapeDesc& SD, class IMGV>
