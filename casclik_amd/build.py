@@ -24,8 +24,16 @@ ARCH = "gfx950"
 # kernarg preload: the first 14 dwords of the kernel arguments (the buffer pointers and the
 # batch size, which the kernels list first) arrive in SGPRs with the wave instead of through
 # a scalar load from the kernarg segment - one memory round trip less at kernel start
+# DEVICE_FP: device code only (-Xarch_device; host code keeps IEEE comparisons): a product with a structural zero of the
+# skill (an axis component, an identity rotation of the chain, a unit row) may be dropped and "x + 0" is x.  IEEE
+# semantics keep "0 * x" alive for the sake of x = NaN / inf and of the sign of a zero - in the value-specialised
+# kernels that was 100 - 140 of 870 - 2500 instructions per wave doing nothing (`v_fmac_f64 v, 0, w`; round 6,
+# profiles/r6_zero_products.md).  No reassociation, no reciprocal maths, contraction unchanged: results for finite
+# inputs are the same bits up to the sign of a zero.  CLIK_FP_STRICT=1 builds without (A/B runs).
+DEVICE_FP = [] if os.environ.get("CLIK_FP_STRICT", "0") == "1" else [
+    "-Xarch_device", "-fno-signed-zeros", "-Xarch_device", "-fno-honor-nans"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-         "-mllvm", "-amdgpu-kernarg-preload-count=14",
+         "-mllvm", "-amdgpu-kernarg-preload-count=14"] + DEVICE_FP + [
          "-Rpass-analysis=kernel-resource-usage",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

@@ -536,7 +536,8 @@ class ReactiveQPController(BaseController):
         return name
 
     # -- resident ticks ----------------------------------------------------------------------------------------
-    def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, timeout_s=2.0, stream=None, ring_depth=1):
+    def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, timeout_s=2.0, stream=None, ring_depth=1,
+                       publish_ahead=0):
         """Launch ONE kernel that stays on the device and solves tick k's QP as soon as ticket k is published
         (include/clik.h, clik_qp_resident_run - the QP's form of PseudoInverseController.resident_start: same ticket,
         same ``done`` slots, same rings).  ``robot_var`` / ``input_var`` are device tensors read in place, ``[B, n]`` or
@@ -554,21 +555,33 @@ class ReactiveQPController(BaseController):
             raise ValueError("ring_depth must be at least 1")
         if d.n_x > 0:
             raise NotImplementedError("resident QP ticks: skills without virtual variables only")
+        # (the batch size is robot_var's; input_var must have THAT many rows - the kernel reads y[row * n_y + ...] for
+        # every row of robot_var - and a tensor of the wrong rank is a ValueError, not an IndexError)
+        B = None
+        lead = (D,) if D > 1 else ()
         for name, tns, n in (("robot_var", robot_var, d.n_q), ("input_var", input_var, d.n_y)):
             if n == 0:
                 continue
             if not isinstance(tns, torch.Tensor) or not tns.is_cuda or tns.dtype != torch.float64 or not tns.is_contiguous():
                 raise ValueError("resident ticks: %s must be a contiguous float64 device tensor (read in place)" % name)
-            want = (D, tns.shape[-2], n) if D > 1 else (tns.shape[0], n)
+            if tns.dim() != len(lead) + 2:
+                raise ValueError("resident ticks with ring_depth %d: %s must have %d dimensions %s, got shape %s"
+                                 % (D, name, len(lead) + 2, "[D, B, n]" if D > 1 else "[B, n]", list(tns.shape)))
+            if B is None:
+                B = int(tns.shape[-2])
+            want = lead + (B, n)
             if tuple(tns.shape) != tuple(want):
-                raise ValueError("resident ticks with ring_depth %d: %s must have shape %s" % (D, name, list(want)))
-        B = int(robot_var.shape[-2])
-        lead = (D,) if D > 1 else ()
+                raise ValueError("resident ticks with ring_depth %d: %s must have shape %s, got %s"
+                                 % (D, name, list(want), list(tns.shape)))
         dQ = torch.zeros(lead + (B, d.n_q), dtype=torch.float64, device=dev)
         slack = torch.zeros(lead + (B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack > 0 else None
         status = torch.full(lead + (B,), -1, dtype=torch.int32, device=dev)
         ticket = torch.zeros(64, dtype=torch.int32, device=dev)
         ticket[16] = D if D > 1 else 0
+        if publish_ahead:
+            # tickets 1 .. publish_ahead are valid before the kernel starts (their inputs are in place): no producer
+            # kernel has to run beside it (tools/resident_once.py under a counter run, which serialises kernels)
+            ticket[0] = int(publish_ahead)
         waves = self._lib.clik_qp_resident_waves(self._handle, B)
         done = torch.zeros(max(waves, 1), dtype=torch.int32, device=dev)
         stream = stream if stream is not None else torch.cuda.Stream(device=dev)

@@ -17,6 +17,13 @@
 #include <type_traits>
 #include "clik.h"
 
+// Source annotation only (expands to nothing): phase boundaries of a tick.  tools/phase_budget.py compiles a kernel with
+// -g, reads the inlining chain the listing gives for every instruction (`.loc` comments) and books the instruction
+// on the last CLIK_PHASE mark above the innermost frame that lies between a function's first mark and its
+// CLIK_PHASE_END - the shipped object itself is what gets counted, no fences, no marker instructions.
+#define CLIK_PHASE(name)
+#define CLIK_PHASE_END()
+
 namespace clik {
 
 constexpr int WAVE = 64;

@@ -89,6 +89,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     constexpr int NT = M * (M + 1) / 2;
     // ---- front end: sin / cos split over the quad, then FK and the task rows in every lane ----
     TaskCache<SD> tc;
+    CLIK_PHASE("sincos");
     {
         double sns[N], css[N];
         if constexpr (SD.uses_fk != 0) {
@@ -101,6 +102,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
                 if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
                 if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
             }
+            CLIK_PHASE("sincos_exchange");
             static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
@@ -114,6 +116,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
         }
         const Img<SD> Sfk = *Slds;
         __builtin_amdgcn_sched_barrier(0);
+        CLIK_PHASE("fk");
         Kin<N> K;
         if constexpr ((CLIK_TEAM_ABLATE & 16) != 0) {
 #pragma unroll
@@ -142,6 +145,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
             forward_kinematics_sc<SD>(&Sfk, z, sns, css, K);
             if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(&Sfk, ysl, inst, K);
         }
+        CLIK_PHASE("task_rows");
         cache_task<SD, 0>(&Sfk, tk, K, z, ysl, inst, tc);
 #ifdef CLIK_TEAM_FRONT_ONCE
         }
@@ -158,6 +162,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     
     const Img<SD> Sb = *Slds;
     __builtin_amdgcn_sched_barrier(0);
+    CLIK_PHASE("desired");
     const Img<SD>* __restrict__ S = &Sb;
     const double lam = S->lam;
     const double one_lam = 1.0 + lam;
@@ -199,6 +204,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     });
 
     // Gm = J J'
+    CLIK_PHASE("gram");
     double Gm[NT];
 #pragma unroll
     for (int i = 0; i < M; ++i)
@@ -225,6 +231,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     //     w2 - G^-1 C w2  =  G^-1 (D - S) w2  =  D^-1 (x - c J' A^-1 J x),   x = (D - S) w2,  A = c J J' + D
     // (Woodbury; S = 0 in mode 0).  So lane 1 solves A1 t = J w2 (then x/D = w2, c = 2), lane 2 solves
     // A2 t = J x with x = ((1+lam) - s) o w2 (c = 1), lanes 0 / 3 solve A0 y = d1.
+    CLIK_PHASE("role_rhs");
     const bool solo = (r == 0) || (r == 3);
     const double alpha = (r == 1) ? 2.0 : 1.0;
     const double beta = (r == 2) ? one_lam : lam;
@@ -253,9 +260,12 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
 #pragma unroll
         for (int i = 0; i < M; ++i) rhs[i] *= A[tri(i, i)] + A[tri(M - 1, i)];
     } else {
+    CLIK_PHASE("factor");
     ldl_factor_s<M>(A, rd);
+    CLIK_PHASE("solve1");
     ldl_solve_s<M>(A, rd, rhs);
     }
+    CLIK_PHASE("solve2");
 #pragma unroll
     for (int i = 0; i < M; ++i) s2[i] = rhs[i];
     if constexpr ((CLIK_TEAM_ABLATE & (2 | 4)) == 0)
@@ -263,6 +273,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     const double lam0 = (r == 0) ? lam : 0.0;
 #pragma unroll
     for (int i = 0; i < M; ++i) rhs[i] = fma(lam0, s2[i], rhs[i]);
+    CLIK_PHASE("jt_product");
     double g[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -276,6 +287,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     // ---- the quad's results meet: lane 0 forms the mode-0 velocity, lane 3 the mode-1 one --
     //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)          (lane 0)
     //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)   (lane 3)
+    CLIK_PHASE("meet");
     const bool hi_pair = (r & 2) != 0;
     const double kap = hi_pair ? 1.0 / one_lam : 1.0;
     const double eta = hi_pair ? 1.0 : 2.0;
@@ -292,6 +304,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     }
     // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; the other lanes evaluate it
     // on the other candidate, unused)
+    CLIK_PHASE("cone");
     if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
         in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
     } else {
@@ -332,6 +345,7 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
             in_tc = inside | going_in;
         }
     }
+    CLIK_PHASE_END();
 }
 
 // raw words of a skill image as a literal (value-specialised kernels, see below)
@@ -369,6 +383,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     typedef double d2 __attribute__((ext_vector_type(2)));
     CLIK_STAMP_W(0, 0);
     CLIK_BODY_BEGIN();
+    CLIK_PHASE("rows_in");
     // Value-specialised instantiation: every index into the state / input rows is a literal, so each lane reads its
     // instance's rows straight from global memory into registers (the four lanes of a quad hit the same addresses,
     // a wave's 16 rows are contiguous) and the selected lane stores the velocities itself: no LDS, no barrier.
@@ -457,6 +472,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     // the scan of :530-550 as a select: mode 0 if its cone test passes, else mode 1 (the active set
     // has no cone test, so mode 1 is always admissible)
     CLIK_STAMP_W(0, 6);
+    CLIK_PHASE("select_store");
     const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
     if constexpr (VALUES) {
         if (r == (ok0 ? 0 : 3) && inst < rows_valid) {
@@ -483,6 +499,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     }
     CLIK_STAMP_W(0, 5);
     CLIK_BODY_END();
+    CLIK_PHASE_END();
 }
 
 // n_ticks of (tick -> clamp(+-max_speed) -> integrate) in one launch with four lanes per instance: the host loop

@@ -928,6 +928,23 @@ def test_four_lanes_per_instance_qp_experiment_and_the_launchers_own_labels(iiwa
     assert qp_close(dq[:n], rdq, rows=rstatus == 0) and qp_close(slack[:n], rslack, rows=rstatus == 0)
 
 
+def test_resident_qp_start_refuses_mismatched_batches(iiwa_fk):
+    """input_var must have robot_var's batch (the kernel reads y[row * n_y + ...] for every row of robot_var:
+    fewer rows would be read out of bounds for n_ticks), and a tensor of the wrong rank is a ValueError."""
+    import torch
+    ctrl = cc.ReactiveQPController(skill_spec=skills.qp_skill(iiwa_fk))
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    Q = torch.zeros((64, 7), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError, match="input_var must have shape"):
+        ctrl.resident_start(Q, torch.zeros((32, 7), dtype=torch.float64, device="cuda"), 1)
+    with pytest.raises(ValueError, match="dimensions"):
+        ctrl.resident_start(Q, torch.zeros(7, dtype=torch.float64, device="cuda"), 1)
+    with pytest.raises(ValueError, match="input_var must have shape"):
+        ctrl.resident_start(torch.zeros((2, 64, 7), dtype=torch.float64, device="cuda"),
+                            torch.zeros((2, 48, 7), dtype=torch.float64, device="cuda"), 1, ring_depth=2)
+
+
 def test_resident_qp_ticks(iiwa_fk):
     """Round 5 (VERDICT r4 missing 3): resident ticks of the ReactiveQPController (clik_qp_resident_run,
     qp_resident_box_front4_kernel): ONE launch solves tick k's QP whenever ticket k is published; every instance's working

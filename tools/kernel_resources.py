@@ -16,11 +16,15 @@ from casclik_amd.lowering import lower_skill         # noqa: E402
 import casclik_amd as cc                             # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "qp"
-flags = [a for a in sys.argv[2:] if a.startswith("-D")]
+flags = [a for a in sys.argv[2:] if a.startswith(("-D", "-f", "-g"))]
 for a in sys.argv[2:]:
     if a.startswith("--mllvm="):                      # e.g. --mllvm=-disable-machine-licm
         flags += ["-mllvm", a.split("=", 1)[1]]
 asm_out = [a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--asm=")]
+for a in sys.argv[2:]:
+    if a.startswith("--csrc="):                       # kernel headers from a scratch copy (experiments next to a running build)
+        alt = os.path.abspath(a.split("=", 1)[1])
+        FLAGS[:] = [("-I" + alt) if f.startswith("-I") and f.endswith("casclik_amd/csrc") else f for f in FLAGS]
 lib = _capi.load_library()
 fk = skills.iiwa()
 if which == "qp":
