@@ -65,8 +65,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TF = 78.6       # half of the 157.3 TF fp32 vector peak
-PROFILE_FILES = ("r5_counters.json", "r4_counters.json", "r3_counters.json", "r2_counters.json", "r1_traffic.json")     # newest first
-BODY_FILES = ("r4_body_time_light.json", "r3_body_time.json")
+PROFILE_FILES = ("r6_counters.json", "r5_counters.json", "r4_counters.json", "r3_counters.json", "r2_counters.json",
+                 "r1_traffic.json")     # newest first
+BODY_FILES = ("r6_body_time.json", "r4_body_time_light.json", "r3_body_time.json")
+ISSUE_PROBE_FILES = ("r6_fp64_issue_ceiling.json", "r5_fp64_issue_ceiling.json")
 METRIC = "CLIK steps/sec (whole node), 7-DoF 3-task priority stack, batch 16384"
 
 
@@ -95,8 +97,6 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0,
                     help="lanes per robot instance of the pinv kernel: 0 = the library's choice, 1 = "
                          "lane-per-instance kernels only, 4 / 8 / 16 = the multi-lane kernel (CLIK_LANES)")
-    ap.add_argument("--qp-lanes", type=int, default=0,
-                    help="qp workload: 4 = the four-lanes-per-instance experiment of the box-family kernel (CLIK_QP_LANES)")
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp before the timed region")
     ap.add_argument("--min-timed-ms", type=float, default=2000.0, help="least work inside the timed bracket")
     ap.add_argument("--replays", type=int, default=0, help="R (0: from --min-timed-ms, at least 50)")
@@ -287,10 +287,10 @@ def profiled(workload, dist_name, batch, kernel, hot=False):
     return None, None
 
 
-def body_time(workload, dist_name, batch, kernel):
+def body_time(workload, dist_name, batch, kernel, hot=False):
     """Kernel body time (first wave start to last wave end, s_memrealtime stamps of the CLIK_STAMP build,
     tools/stamp_body.py) of this configuration if profiles/ holds one."""
-    key = "%s_%s_B%d_%s" % (workload, dist_name, batch, kernel)
+    key = "%s_%s_B%d_%s%s" % (workload, dist_name, batch, kernel, "_hot" if hot else "")
     for fn in BODY_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -369,6 +369,31 @@ def time_allgather(ctx, tick, dQ, n_total, M=200):
 
 
 DRAWN_MAX = 131072
+CHECK_ROWS = 192
+
+
+def check_outputs(workload, spec, opts, Q, Y, out_rows, slack_rows=None):
+    """One output slot of the timed region against the numpy oracle on its first CHECK_ROWS instances (the
+    bracket itself must be seen to have produced the reference's numbers, not only smoke()'s separate call).  The oracle is
+    the checker here, never the thing measured.  Returns {"ok", "instances", "rule", "worst_err_over_tol"}."""
+    import numpy as np
+    from oracle import clik_oracle
+    tests_dir = os.path.join(ROOT, "tests")
+    if tests_dir not in sys.path:
+        sys.path.insert(0, tests_dir)
+    import tolerances
+    n = min(CHECK_ROWS, len(Q))
+    got = np.asarray(out_rows[:n], dtype=float)
+    if workload == "qp":
+        ref, _, rslack, rstatus = clik_oracle.qp_solve_batch(spec, 0.0, Q[:n], Y=Y[:n])
+        ok = tolerances.qp_close(got, ref, rows=rstatus == 0)
+    else:
+        ref, _ = clik_oracle.pinv_solve_batch(spec, opts or {}, 0.0, Q[:n], Y=Y[:n])
+        ok = tolerances.pinv_close(got, ref)
+    last = dict(tolerances.LAST)
+    return {"ok": bool(ok), "instances": int(last.get("checked", n)), "rule": last.get("rule"),
+            "worst_err_over_tol": None if last.get("worst") is None else round(float(last["worst"]), 4),
+            "what": "ring slot 0's output after the timed bracket vs oracle/clik_oracle.py (tests/tolerances.py rule)"}
 
 
 def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_graph=1, ramp_ms=250.0,
@@ -405,7 +430,17 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     # no tick finds the lines the tick before it touched; the QP's hot start keeps one working set per slot
     ring = max(1, int(ring)) if (TPL == 1 and B > 1) else 1
     slots = [(Qd, Yd, dQ)]
+    moving_target = bool(qp_hot) and workload == "qp"
     for s_ in range(1, ring):
+        if moving_target:
+            # hot-started ticks: the SAME instances in every slot (distinct memory), the target moved by a millimetre per slot
+            # along x, y, z in turn, ONE working set handed from tick to tick - what a control loop following a moving target
+            # sees: working sets that are close to, not always equal to, the next tick's (each slot keeping
+            # its own set re-solved a QP whose optimal set it already held - zero pivots, a best case)
+            y_s = Yd.clone()
+            y_s[:, (s_ - 1) % 3] += 1e-3 * s_
+            slots.append((Qd.clone(), y_s.contiguous(), torch.empty_like(dQ)))
+            continue
         shift = (s_ * B) // ring
         slots.append((torch.roll(Qd, shift, 0).contiguous(), torch.roll(Yd, shift, 0).contiguous(), torch.empty_like(dQ)))
 
@@ -422,7 +457,13 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
         W //= TPL
     else:
         kw = dict(hot_start=bool(qp_hot)) if workload == "qp" else {}
+        if moving_target:
+            kw["hot_set"] = torch.zeros((B,), dtype=torch.int32, device=dev)
         bound = [ctrl.bind_batch(q_, input_var=y_, out=o_, **kw) for q_, y_, o_ in slots]
+        if moving_target:
+            bound[0]()                      # (a cold tick fills the shared working sets; from here on every tick is hot)
+            for b_ in bound:
+                b_.primed = True
         turn = {"i": 0}
 
         def tick():
@@ -523,7 +564,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     if TPL == 1:
         achieved = alg_bytes / (tick_us * 1e-6) / 1e9
         prof, prof_src = profiled(workload, dist_name, B, kernel, hot=bool(qp_hot))
-        body, body_src = body_time(workload, dist_name, B, kernel)
+        body, body_src = body_time(workload, dist_name, B, kernel, hot=bool(qp_hot))
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof.get("traffic_bytes") if prof else None,
@@ -539,16 +580,26 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
                 "launch_boundary_us": body.get("boundary_us") if body else None,
                 "kernel_body_source": body_src,
                 "algorithmic_bytes_per_instance": bytes_per_inst,
-                "algorithmic_bytes_per_launch": alg_bytes}
+                "algorithmic_bytes_per_launch": alg_bytes,
+                # which numbers this process MEASURED and which it read from a file a profiler run left under profiles/
+                "provenance": {"tick_us / achieved / frac": "measured (this run: HIP events on the launch stream)",
+                               "traffic": ("recorded, " + prof_src) if (prof and "traffic_bytes" in prof) else None,
+                               "fp64_frac": ("recorded flops per launch (" + prof_src + ") / measured tick") if prof else None,
+                               "kernel_body_us": ("measured tick - recorded launch boundary (" + body_src + ")") if body else None,
+                               "issue_probe_body_us": "recorded (profiles/*_fp64_issue_ceiling.json)"}}
         # what the ISSUE of the kernel's fp64 instructions costs on this machine with nothing else going on (bare-FMA waves
         # in the same launch shape and register allocation, tools/probe_fp64_peak.hip; recorded, not measured here)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r5_fp64_issue_ceiling.json")) as f:
-                probe = json.load(f).get("%s_%s_B%d_%s" % (workload, dist_name, B, kernel))
-        except Exception:
-            probe = None
+        probe, probe_fn = None, None
+        for probe_fn in ISSUE_PROBE_FILES:
+            try:
+                with open(os.path.join(ROOT, "profiles", probe_fn)) as f:
+                    probe = json.load(f).get("%s_%s_B%d_%s" % (workload, dist_name, B, kernel))
+            except Exception:
+                probe = None
+            if probe:
+                break
         if probe:
-            roof["issue_probe"] = dict(probe, source="profiles/r5_fp64_issue_ceiling.json")
+            roof["issue_probe"] = dict(probe, source="profiles/" + probe_fn)
         if prof and "fp64_flops_per_launch" in prof:
             # executed fp64 flops (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes, FMA = 2) over the measured
             # tick time: what the VALUs did, not what the literal algorithm would need
@@ -578,7 +629,10 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
             "workload": text,
             "batch_per_gpu": B, "inputs": "%s seed %d%s%s" % (dist_name, seed, "" if B <= DRAWN_MAX or global_batch else
                                                              " (%d drawn, tiled)" % DRAWN_MAX,
-                                                             ", ring of %d buffers" % len(slots) if len(slots) > 1 else ""),
+                                                             (", ring of %d buffers" % len(slots) + (
+                                                                 ": the same instances, the target moved 1 mm per slot, one working "
+                                                                 "set handed from tick to tick" if moving_target else ""))
+                                                             if len(slots) > 1 else ""),
             "kernel": kernel,
             "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
                        else "eager, one launch per tick") if TPL == 1
@@ -593,6 +647,13 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     }
     if global_batch:
         entry["config"]["global_batch"] = global_batch
+    if rank == 0 and TPL == 1:
+        # the bracket's own output (slot 0 holds the answers of the last tick that ran on the drawn batch)
+        try:
+            torch.cuda.synchronize()
+            entry["check"] = check_outputs(workload, spec, opts, Q, Y, slots[0][2].detach().cpu().numpy())
+        except Exception as exc:
+            entry["check"] = {"ok": False, "error": repr(exc)[:200]}
     if ag is not None:
         entry["allgather"] = ag
     del graph
@@ -658,6 +719,8 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrat
                    "runs_us_per_tick": [t_short / short * 1e6, t_long / (3 * short) * 1e6]},
         "roofline": {"bound": "hbm", "achieved": 172.0 * B / per_tick / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": 172.0 * B / per_tick / 1e9 / 8000.0, "traffic": None, "tick_us": per_tick * 1e6},
+        # (run() raises unless every output slot equals a launched tick on that slot's inputs, bit for bit)
+        "check": {"ok": True, "what": "every ring slot bit-equal to a launched tick on its inputs (which tests hold to the oracle)"},
     }
 
 
@@ -671,10 +734,16 @@ def measure_resident_qp(fk, dist_name, seed, B=16384 - 64, short=10000, ring=4):
     ctrl = cc.ReactiveQPController(skill_spec=skills.qp_skill(fk))
     ctrl.setup_problem_functions()
     ctrl.setup_solver()
-    # (the SAME batch in every slot - distinct memory -: a hot start means something only when successive ticks belong
-    # to the same instances' loop, as bench's launched hot-started entry keeps one working set per slot)
-    one = skills.synthetic_inputs(fk, B, seed=seed, distribution=dist_name)
-    slots = [one] * ring
+    # (the same instances in every slot - a hot start means something only when successive ticks belong to the same
+    # instances' loop - with the TARGET moved from slot to slot, a millimetre per tick along x, y, z in turn, as a
+    # trajectory does: the hot starts then find working sets that are close but not all optimal)
+    import numpy as np
+    q_one, y_one = skills.synthetic_inputs(fk, B, seed=seed, distribution=dist_name)
+    slots = []
+    for s_ in range(ring):
+        y_s = y_one.copy()
+        y_s[:, s_ % 3] += 1e-3 * s_
+        slots.append((q_one, y_s))
     Qr = torch.stack([torch.from_numpy(q).cuda() for q, _ in slots]).contiguous()
     Yr = torch.stack([torch.from_numpy(y).cuda() for _, y in slots]).contiguous()
     refs = [ctrl.solve_batch(0.0, Qr[s], input_var=Yr[s], use_hot=False) for s in range(ring)]
@@ -702,12 +771,14 @@ def measure_resident_qp(fk, dist_name, seed, B=16384 - 64, short=10000, ring=4):
     return {
         "value": B / per_tick, "unit": "instance-steps/s", "ms_per_step": per_tick * 1e3,
         "config": {"workload": "BASELINE config 4: %d x iiwa ReactiveQPController as RESIDENT ticks (one launch; tickets published "
-                               "ahead; ring of %d slots holding the same batch; the working sets stay in the kernel: hot-started from tick 2 on)" % (B, ring),
+                               "ahead; ring of %d slots holding the same instances with the target moved 1 mm from slot to slot; the "
+                               "working sets stay in the kernel: hot-started from tick 2 on)" % (B, ring),
                    "batch_per_gpu": B, "ring_depth": ring, "kernel": ctrl.kernel_variant(B, hot=True) + "/resident",
                    "slope_us_per_tick": (t_long - t_short) / (2 * short) * 1e6,
                    "runs_us_per_tick": [t_short / short * 1e6, t_long / (3 * short) * 1e6]},
         "roofline": {"bound": "hbm", "achieved": 220.0 * B / per_tick / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": 220.0 * B / per_tick / 1e9 / 8000.0, "traffic": None, "tick_us": per_tick * 1e6},
+        "check": {"ok": True, "what": "every ring slot: statuses equal and minimisers within 1e-6 of a cold launched tick on its inputs"},
     }
 
 
@@ -721,7 +792,12 @@ def compact_roofline(r):
            "tick_us": _r(r.get("tick_us"), 3), "kernel_body_us": _r(r.get("kernel_body_us"), 3),
            "fp64_frac": _r(f64.get("frac"), 3), "valu_issue_frac": _r(f64.get("valu_issue_frac"), 3),
            "binds": r.get("binds"), "bytes_per_instance": r.get("algorithmic_bytes_per_instance"),
-           "issue_probe_body_us": (r.get("issue_probe") or {}).get("probe_body_us")}
+           "issue_probe_body_us": (r.get("issue_probe") or {}).get("probe_body_us"),
+           "measured": ["achieved", "frac", "tick_us"],
+           "recorded": [k for k, v in (("traffic", r.get("traffic")), ("fp64_frac (flops)", f64.get("frac")),
+                                       ("kernel_body_us (boundary)", r.get("kernel_body_us")),
+                                       ("issue_probe_body_us", (r.get("issue_probe") or {}).get("probe_body_us"))) if v is not None],
+           "body_source": (r.get("kernel_body_source") or "").replace("profiles/", "") or None}
     return {k: v for k, v in out.items() if v is not None or k in ("traffic", "frac", "achieved")}
 
 
@@ -752,6 +828,8 @@ def compact_entry(e):
     else:
         # (no counter pass for this entry - the rollouts, the resident ticks: no traffic / fp64 figures)
         out = {k: v for k, v in out.items() if v is not None}
+    if "check" in e:
+        out["ok"] = bool(e["check"].get("ok"))
     c = e.get("cpu_baseline")
     if c and "value" in c:
         out["cpu_M_per_s"] = _r(c["value"] / 1e6, 2)
@@ -836,8 +914,6 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.lanes:
         os.environ["CLIK_LANES"] = str(args.lanes)
-    if args.qp_lanes:
-        os.environ["CLIK_QP_LANES"] = str(args.qp_lanes)
 
     import torch
     if not torch.cuda.is_available():
@@ -943,12 +1019,13 @@ def main():
                 extras.append({"name": name, "error": repr(exc)})
 
     if want_extras:
-        phase("qp_B16384_resident_fed_ahead")
+        # (16320 instances: the resident QP kernel takes a SIMD's whole register file and leaves one CU to the feeder)
+        phase("qp_B16320_resident_fed_ahead")
         try:
-            extras.append(dict({"name": "qp_B16384_resident_fed_ahead", "n_gpus": world, "dtype": "f64"},
+            extras.append(dict({"name": "qp_B16320_resident_fed_ahead", "n_gpus": world, "dtype": "f64"},
                                **measure_resident_qp(fk, args.dist, args.seed)))
         except Exception as exc:
-            extras.append({"name": "qp_B16384_resident_fed_ahead", "error": repr(exc)})
+            extras.append({"name": "qp_B16320_resident_fed_ahead", "error": repr(exc)})
     if rank == 0:
         phase("done")
         out = {
@@ -968,6 +1045,15 @@ def main():
         if "allgather" in head:
             out["allgather"] = head["allgather"]
         out["cpu_baseline"] = head_cpu
+        if "check" in head:
+            out["check"] = head["check"]
+        if world > 1:
+            # how to read the curve the driver builds from the per-N lines
+            out["scaling_note"] = ("weak line: 16384 instances PER GPU - a tick is one wave per SIMD long whatever N is, so "
+                                   "value scales ~N by construction (shards are independent, no data-path collective). "
+                                   "The STRONG line of BASELINE config 5 is extras.strong_B131072: one GPU runs 131072 "
+                                   "instances in ~9.9 us, eight GPUs at 16384 each take ~3.6 us - expect ~2.7x from 8 GPUs "
+                                   "on that batch, not 8x; extras.weak_B131072_per_gpu is the regime where every GPU is full")
         if extras:
             out["extras"] = extras
         if not args.full:
@@ -980,6 +1066,9 @@ def main():
             if "global_batch" in c:
                 out["config"]["global_batch"] = c["global_batch"]
             out["roofline"] = compact_roofline(out["roofline"])
+            if "check" in out:
+                out["check"] = {k: out["check"].get(k) for k in ("ok", "instances", "rule", "worst_err_over_tol", "error")
+                                if k in out["check"]}
             out["cpu_baseline"] = compact_cpu(head_cpu)
             out["devices"] = [d.split(" pid ")[0] + " " + d.split(" ", 4)[-1] if " pid " in d else d for d in devices][:8]
             uu = [d.split(" uuid ")[-1] for d in devices if " uuid " in d]

@@ -177,7 +177,7 @@ _SYMBOLS = [
     "clik_last_error", "clik_abi_version",
     "clik_pinv_create", "clik_pinv_create_host", "clik_pinv_destroy", "clik_pinv_n_modes", "clik_pinv_kernel_name", "clik_pinv_kernel_variant", "clik_pinv_image_words", "clik_pinv_attach_value_kernel", "clik_pinv_attach_resident_kernel", "clik_pinv_resident_waves", "clik_pinv_resident_run", "clik_pinv_resident_run_state", "clik_ticket_feed", "clik_shape_describe", "clik_pinv_attach_kernel",
     "clik_pinv_solve_batch", "clik_pinv_solve_batch_t", "clik_pinv_rollout_batch", "clik_pinv_rollout_batch_x", "clik_pinv_rollout_batch_m",
-    "clik_qp_create", "clik_qp_create_host", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows",
+    "clik_qp_create", "clik_qp_create_host", "clik_qp_destroy", "clik_qp_n_vars", "clik_qp_n_rows", "clik_qp_workspace_bytes",
     "clik_qp_kernel_name", "clik_qp_shape_describe", "clik_qp_attach_kernel", "clik_qp_image_words", "clik_qp_attach_value_kernel", "clik_qp_is_box_family",
     "clik_qp_attach_resident_kernel", "clik_qp_resident_waves", "clik_qp_resident_run",
     "clik_qp_solve_batch", "clik_qp_solve_batch_hot", "clik_qp_solve_batch_t", "clik_qp_rollout_batch", "clik_qp_rollout_batch_x", "clik_qp_rollout_batch_m", "clik_qp_data_batch",
@@ -324,6 +324,8 @@ def load_library(path=None):
     lib.clik_qp_n_vars.argtypes = [vp]
     lib.clik_qp_n_rows.restype = C.c_int
     lib.clik_qp_n_rows.argtypes = [vp]
+    lib.clik_qp_workspace_bytes.restype = C.c_int64
+    lib.clik_qp_workspace_bytes.argtypes = [vp]
     lib.clik_qp_solve_batch.restype = C.c_int
     lib.clik_qp_solve_batch.argtypes = [vp, C.c_int64, C.POINTER(C.c_double),
                                         dp, dp, dp, dp, dp, dp, ip, vp]

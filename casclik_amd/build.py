@@ -16,9 +16,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libclik_hip.so")
-SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_pinv_dyn.hip", "clik_qp.hip"]
+SOURCES = ["clik_api.hip", "clik_pinv.hip", "clik_pinv_dyn.hip", "clik_qp.hip", "clik_qp_shapes.hip",
+           "clik_qp_dyn_a.hip", "clik_qp_dyn_b.hip", "clik_qp_dyn_c.hip", "clik_qp_dyn_d.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("clik_device.hpp", "clik_pinv_static.hpp", "clik_pinv_kernels.hpp", "clik_pinv_team.hpp",
-                                          "clik_qp_static.hpp", "clik_shapes_gen.hpp")] \
+                                          "clik_qp_static.hpp", "clik_qp_resident.hpp", "clik_shapes_gen.hpp", "clik_workspace.hpp",
+                                          "clik_qp_dyn.hpp")] \
     + [os.path.join(ROOT, "include", "clik.h")]
 ARCH = "gfx950"
 # kernarg preload: the first 14 dwords of the kernel arguments (the buffer pointers and the

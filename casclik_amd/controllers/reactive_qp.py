@@ -525,8 +525,7 @@ class ReactiveQPController(BaseController):
         for a hot-started tick).  The suffix behind "/v" is the LAUNCHER's own decision: the instantiated library
         exports the predicate it launches by (clik_jit_qp_value_variant, csrc/clik_qp_static.hpp::qp_values_choice) -
         "/folio4": cold ticks of small batches, four waves per 64 instances with different starts of the passes;
-        "/front4": hot-started ticks of small batches, four lanes per instance sharing the sin / cos evaluations;
-        "/quad4", "/occ2": experiment switches; nothing: one lane per instance."""
+        nothing: one lane per instance."""
         name = self.kernel_name + ("/v" if getattr(self, "value_kernel", None) else "")
         fn = getattr(self, "_value_variant_fn", None)
         if getattr(self, "value_kernel", None) and fn is not None:
@@ -536,6 +535,13 @@ class ReactiveQPController(BaseController):
         return name
 
     # -- resident ticks ----------------------------------------------------------------------------------------
+    def workspace_bytes(self):
+        """Device memory the controller's handle holds as work area of the global-workspace QP kernels (skills beyond 16
+        rows or eight states on the built-in kernels; 0 for every other skill): sized for the blocks the largest batch so
+        far needed, released when the controller goes (clik_qp_workspace_bytes)."""
+        self._require_handle()
+        return int(self._lib.clik_qp_workspace_bytes(self._handle))
+
     def resident_start(self, robot_var, input_var, n_ticks, time_var=0.0, timeout_s=2.0, stream=None, ring_depth=1,
                        publish_ahead=0):
         """Launch ONE kernel that stays on the device and solves tick k's QP as soon as ticket k is published
@@ -744,10 +750,13 @@ class ReactiveQPController(BaseController):
             return tuple(None if o is None else o.cpu().numpy() for o in outs)
         return outs
 
-    def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None, hot_start=False):
+    def bind_batch(self, robot_var, input_var=None, virtual_var=None, out=None, hot_start=False, hot_set=None):
         """Pre-bind device tensors and return ``tick(time_var=0.0)``: one kernel
         launch per call (lean path for control loops, graph capture, benchmarks).
-        ``hot_start``: keep each instance's working set between ticks (see solve_batch)."""
+        ``hot_start``: keep each instance's working set between ticks (see solve_batch); ``hot_set``: an int32 device
+        tensor [B] to keep them in - several bound ticks given the SAME tensor hand their working sets on to each other
+        (a loop whose ticks rotate through input buffers), and a tick bound with one is hot-started from its first call
+        on when the tensor already holds sets (``tick.primed = True``)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -765,7 +774,12 @@ class ReactiveQPController(BaseController):
         SL = torch.empty((B, d.n_slack), dtype=torch.float64, device=dev) if d.n_slack else None
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         fn, handle, lib = self._lib.clik_qp_solve_batch_hot, self._handle, self._lib
-        hot = torch.zeros((B,), dtype=torch.int32, device=dev) if hot_start else None
+        if hot_set is not None:
+            if not (isinstance(hot_set, torch.Tensor) and hot_set.is_cuda and hot_set.dtype == torch.int32
+                    and hot_set.is_contiguous() and tuple(hot_set.shape) == (B,)):
+                raise ValueError("hot_set must be a contiguous int32 device tensor of shape [%d]" % B)
+            hot_start = True
+        hot = hot_set if hot_set is not None else (torch.zeros((B,), dtype=torch.int32, device=dev) if hot_start else None)
         args = (ptr(Q), ptr(X), ptr(Y), ptr(dQ), ptr(dX), ptr(SL), ptr(status), ptr(hot))
         static_tt = _capi.tterms_arg(np.zeros(0)) if d.n_tslots == 0 else None
         state = {"ticks": 0}
@@ -773,11 +787,12 @@ class ReactiveQPController(BaseController):
         def tick(time_var=0.0, stream_handle=None):
             tt, ttp = static_tt if static_tt is not None else _capi.tterms_arg(d.time_terms(time_var))
             sh = stream_handle if stream_handle is not None else current_stream(dev)
-            rc = fn(handle, B, ttp, *args, 1 if (hot is not None and state["ticks"] > 0) else 0, sh)
+            rc = fn(handle, B, ttp, *args, 1 if (hot is not None and (state["ticks"] > 0 or tick.primed)) else 0, sh)
             state["ticks"] += 1
             if rc != 0:
                 _capi.check(lib, rc)
 
+        tick.primed = False
         tick.tensors = (Q, X, Y, dQ, dX, SL, status, hot)
         tick.hot_set = hot
         tick.out, tick.slack, tick.status = dQ, SL, status

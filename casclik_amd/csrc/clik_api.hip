@@ -21,6 +21,7 @@
 #include <utility>
 #include <vector>
 #include "clik_device.hpp"
+#include "clik_workspace.hpp"
 
 namespace clik {
 struct LaunchArgs {
@@ -53,10 +54,11 @@ hipError_t pinv_launch_rollout(int k, const LaunchArgs& a, const double* d_tterm
 int pinv_lds_slots_host(int N, int ny);
 hipError_t qp_launch_solve(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                            const double* q, const double* x, const double* y, double* dq, double* dx,
-                           double* slack, int32_t* status, hipStream_t stream);
+                           double* slack, int32_t* status, hipStream_t stream, GwsOwner* owner);
 hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                           const double* q, const double* x, const double* y, double* Hd, double* A, double* lb,
-                          double* ub, hipStream_t stream);
+                          double* ub, hipStream_t stream, GwsOwner* owner);
+bool qp_variant_uses_workspace(int k);
 int qp_pick_variant(int n, int nv, int nc);
 int qp_variant_width(int k);
 size_t qp_variant_lds(int k, int ny);
@@ -140,6 +142,15 @@ struct clik_qp {
     hipError_t (*val_resident)(const TickArgs*, long long, const double*, const double*, double*, double*, int32_t*, void*,
                                unsigned*, int, unsigned long long, hipStream_t);
     char      jit_name[64];
+    // work area of the global-workspace kernels (clik_workspace.hpp): belongs to this handle, released by clik_qp_destroy
+    clik::GwsOwner* gws;
+    ~clik_qp()
+    {
+        if (gws) {
+            gws->release();
+            delete gws;
+        }
+    }
 };
 
 static thread_local char g_err[512] = "";
@@ -1255,6 +1266,8 @@ extern "C" int clik_qp_create(const clik_skill_desc* desc, const clik_qp_opts* o
     if (!opts) return fail(CLIK_EINVAL, "null options");
     clik_qp* h = new (std::nothrow) clik_qp();
     if (!h) return fail(CLIK_ENOMEM, "out of host memory");
+    h->gws = new (std::nothrow) clik::GwsOwner();
+    if (!h->gws) { delete h; return fail(CLIK_ENOMEM, "out of host memory"); }
     int rc = validate_and_derive(desc, &h->host);
     if (rc) { delete h; return rc; }
     DevSkill& S = h->host;
@@ -1523,9 +1536,11 @@ extern "C" int clik_qp_destroy(clik_qp* h)
     if (!h) return CLIK_OK;
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->dev) (void)hipFree(h->dev);
-    delete h;
+    delete h;           // (~clik_qp releases the work area of the global-workspace kernels)
     return CLIK_OK;
 }
+
+extern "C" int64_t clik_qp_workspace_bytes(const clik_qp* h) { return (h && h->gws) ? (int64_t)h->gws->footprint() : 0; }
 
 extern "C" int clik_qp_n_vars(const clik_qp* h) { return h ? h->host.n_qp_vars : 0; }
 extern "C" int clik_qp_n_rows(const clik_qp* h) { return h ? h->host.n_qp_rows : 0; }
@@ -1584,8 +1599,17 @@ static int qp_solve_common(const clik_qp* h, int64_t B, const double* tterms, co
         return fail(CLIK_EUNSUPPORTED, "clik_qp_solve_batch: this skill needs a shape-specialised kernel and none "
                                        "is attached (casclik_amd.jit needs hipcc)");
     else
+    {
+        if (clik::qp_variant_uses_workspace(h->variant) && (hipStream_t)stream == hipStreamPerThread)
+            return fail(CLIK_EUNSUPPORTED, "clik_qp_solve_batch: this skill's kernel keeps its work area in global memory, "
+                                           "owned by the handle and ordered per stream - hipStreamPerThread is not supported "
+                                           "for it (pass an explicit stream)");
         e = clik::qp_launch_solve(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, dq, dx,
-                                  slack, status, (hipStream_t)stream);
+                                  slack, status, (hipStream_t)stream, h->gws);
+        if (e == hipErrorStreamCaptureUnsupported)
+            return fail(CLIK_EHIP, "qp_solve_kernel launch: the work area of this skill's kernel must grow for this batch "
+                                   "size, which cannot be captured - run one tick of this batch size before capturing");
+    }
     if (e != hipSuccess) return hipfail(e, "qp_solve_kernel launch");
     return CLIK_OK;
 }
@@ -1625,8 +1649,11 @@ extern "C" int clik_qp_data_batch(const clik_qp* h, int64_t B, const double* tte
     TickArgs tk;
     rc = fill_tick(h->host, tterms, &tk);
     if (rc) return rc;
+    if (clik::qp_variant_uses_workspace(h->variant) && (hipStream_t)stream == hipStreamPerThread)
+        return fail(CLIK_EUNSUPPORTED, "clik_qp_data_batch: hipStreamPerThread is not supported for skills whose kernel keeps its "
+                                       "work area in global memory (pass an explicit stream)");
     hipError_t e = clik::qp_launch_data(h->variant, h->dev, h->warm, tk, (long long)B, h->host.d.n_y, q, x, y, Hdiag, A,
-                                        lbA, ubA, (hipStream_t)stream);
+                                        lbA, ubA, (hipStream_t)stream, h->gws);
     if (e != hipSuccess) return hipfail(e, "qp_data_kernel launch");
     return CLIK_OK;
 }

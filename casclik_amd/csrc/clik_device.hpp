@@ -370,11 +370,19 @@ __device__ __forceinline__ double recip(const double d)
     return r;
 }
 
+// x, or a quiet NaN where `bad_hi` is 0x7ff80000 (0: x as it is).  As BITS: device code is compiled with
+// -fno-honor-nans (build.py DEVICE_FP), under which arithmetic with a NaN constant is undefined and "x + NaN" was folded
+// to x - the QP kernels mark an infeasible instance's outputs this way.
+__device__ __forceinline__ double nan_or(const double x, const unsigned bad_hi)
+{
+    return __hiloint2double((int)((unsigned)__double2hiint(x) | bad_hi), __double2loint(x));
+}
+
 // sign(x) / 2 as a double: -0.5, 0 or +0.5 (three instructions: the sign bit onto the pattern of 0.5, zero test)
 __device__ __forceinline__ double half_sign(const double x)
 {
-    const int h = (__double2hiint(x) & (int)0x80000000) | 0x3fe00000;
-    return (x != 0.0) ? __hiloint2double(h, 0) : 0.0;
+    // x 2^3000 is +-inf for every x != 0 (denormals included) and keeps a zero: clamped to +-1/2 (both inline constants)
+    return fmax(fmin(ldexp(x, 3000), 0.5), -0.5);
 }
 
 // argument range of the fast path (3-term Cody-Waite reduction stays exact)
@@ -384,23 +392,44 @@ constexpr double kSinCosFastMax = 1.0e5;
 // angles use this for all of them and handle larger arguments afterwards in ONE cold block
 // (sincos_slow): a call between two evaluations makes the compiler re-materialise the ~26
 // literal polynomial constants after every call site (measured: ~200 extra moves per tick).
+// The 17 full-width constants of sincos_fast live in constant memory: an fp64 instruction takes a 32-bit literal only (the
+// HIGH word of the double), so every other constant costs the wave two s_mov_b32 - 34 scalar instructions per tick, each
+// a full issue slot of a lone wave - while scalar loads fetch eight doubles per instruction, at kernel start, beside the
+// wave's row loads.  (__constant__ without const: the compiler must not fold the loads back into literals.)
+#ifndef CLIK_SINCOS_POOL
+#define CLIK_SINCOS_POOL 1
+#endif
+inline __constant__ double kSinCosPool[20] = {
+    0.6366197723675814, -1.5707963267948966, -6.123233995736766e-17, 1.4973849048591698e-33,
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+    -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07,
+    2.08757232129817482790e-09, -1.13596475577881948265e-11, 0.0, 0.0, 0.0, 0.0};
+
 __device__ __forceinline__ void sincos_fast(const double x, double& sn, double& cs)
 {
-    const double k = rint(x * 0.6366197723675814);
-    double r = fma(k, -1.5707963267948966, x);
-    r = fma(k, -6.123233995736766e-17, r);
-    r = fma(k, 1.4973849048591698e-33, r);
+#if CLIK_SINCOS_POOL
+    const double* __restrict__ P = kSinCosPool;
+#else
+    // (-DCLIK_SINCOS_POOL=0: the same constants as literals - two s_mov_b32 each, no scalar loads at kernel start)
+    constexpr double P[16] = {
+        0.6366197723675814, -1.5707963267948966, -6.123233995736766e-17, 1.4973849048591698e-33,
+        -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+        -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+        4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07,
+        2.08757232129817482790e-09, -1.13596475577881948265e-11};
+#endif
+    const double k = rint(x * P[0]);
+    double r = fma(k, P[1], x);
+    r = fma(k, P[2], r);
+    r = fma(k, P[3], r);
     const double z = r * r;
     // __kernel_sin
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double S1 = P[4], S2 = P[5], S3 = P[6], S4 = P[7], S5 = P[8], S6 = P[9];
     const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
     const double sr = fma(z * r, fma(z, ps, S1), r);
     // __kernel_cos
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double C1 = P[10], C2 = P[11], C3 = P[12], C4 = P[13], C5 = P[14], C6 = P[15];
     const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;

@@ -845,13 +845,10 @@ __device__ __forceinline__ void pinv_tick_static(const Img<SD>* __restrict__ S, 
     });
 }
 
-// (experiment switches: -DCLIK_OCC2 / -DCLIK_OCC1 pin the occupancy of the kernels below)
-#if defined(CLIK_OCC3)
-#define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#elif defined(CLIK_OCC2)
+// (measuring switch: -DCLIK_OCC2 pins the kernels below to two waves per SIMD; three waves per SIMD and one were measured in
+// rounds 3 / 5 and retired, tools/experiments/pinv_retired.patch)
+#if defined(CLIK_OCC2)
 #define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#elif defined(CLIK_OCC1)
-#define CLIK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
 #define CLIK_OCC_ATTR
 #endif
@@ -1371,9 +1368,6 @@ namespace clik {
 #ifndef CLIK_DEFER_INPUT_ROWS
 #define CLIK_DEFER_INPUT_ROWS 1
 #endif
-#ifndef CLIK_STAGGER_SLEEP
-#define CLIK_STAGGER_SLEEP 0
-#endif
 // value-specialised lane kernel (pinv_solve_static_values_kernel): single-mode skills, and the config-3 family
 // (whose lane evaluation, solo_tick, beats the one-wave-per-mode kernel once the numbers are compiled in: 5.19 / 5.26 /
 // 5.44 us against 5.87 / 5.89 / 5.98 us at 20480 / 24576 / 32768 instances); other skills with up to
@@ -1602,9 +1596,12 @@ inline hipError_t launch_rollout_team_values(const LaunchArgs& a, const double* 
 {
     static_assert(shape_team_ok(SD), "value-specialised kernels exist for the team family only");
     const unsigned grid = (unsigned)((B + TEAM_INST - 1) / TEAM_INST);
-    hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD, IMGV>), dim3(grid), dim3(TEAM_WAVES * WAVE),
-                       team_rollout_lds_bytes<SD>(true), stream, nullptr, q, y, dq, mode, B, d_tterms, n_ticks, dt,
-                       max_speed, a.roll_stages == 4 ? 4 : 1);
+    if (a.roll_stages == 4)
+        hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD, IMGV, 4>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                           team_rollout_lds_bytes<SD>(true), stream, nullptr, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
+    else
+        hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD, IMGV, 1>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                           team_rollout_lds_bytes<SD>(true), stream, nullptr, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
     return hipGetLastError();
 }
 
@@ -1629,13 +1626,6 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
     constexpr int N = SD.n;
     constexpr Img<SD> Sval = IMGV::value;        // (a local constant: its loads fold to immediates)
     const int lane = threadIdx.x;
-#if CLIK_STAGGER_SLEEP > 0
-    // EXPERIMENT (round 5): batches of several generations of waves (two resident per SIMD, all of the same length) keep
-    // the two waves of a SIMD in lockstep - both end together, both successors wait for their rows together, the SIMD
-    // idles for a memory round trip at every generation.  The second resident wave of every SIMD (blocks 1024 ... 2047 of
-    // the first generation) starts half a wave late, so that the pairs stay out of phase for the rest of the launch.
-    if (B >= 262144 && blockIdx.x >= 1024u && blockIdx.x < 2048u) __builtin_amdgcn_s_sleep(CLIK_STAGGER_SLEEP);
-#endif
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;
@@ -1697,24 +1687,35 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_q
     const int r = tid & (TEAM - 1);
     // (one wave = 16 instances per block - a compile-time shape: reading blockDim.x costs a scalar load from the dispatch
     // packet and its round trip at the start of every wave, measured as +0.13 us on the config-3 team kernel)
-    const long long inst = (long long)blockIdx.x * (WAVE / TEAM) + (tid >> 2);
-    const bool valid = inst < B;
-    const long long row = valid ? inst : B - 1;
+    // (launched for at most kTeamMaxBatch instances: 32-bit row numbers, rows addressed as uniform base + 32-bit lane
+    // offset - the 64-bit index arithmetic was a dozen instructions of a lone wave's stream)
+    CLIK_PHASE("rows_in");
+    const unsigned inst = (unsigned)blockIdx.x * (unsigned)(WAVE / TEAM) + ((unsigned)tid >> 2);
+    const unsigned last = (unsigned)B - 1u;
+    const bool valid = inst <= last;
+    const unsigned row = inst < last ? inst : last;
+    const unsigned qoff = __umul24(row, (unsigned)(N * sizeof(double)));
+    const double* __restrict__ qrow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + qoff);
     // this lane's two sin / cos arguments first (their loads return first), then the whole row
     const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-    const double a0 = q[row * N + j0], a1 = q[row * N + j1];
+    const double a0 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j0 * 8u));
+    const double a1 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j1 * 8u));
     double z[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = q[row * N + j];
-    const double* ys = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    for (int j = 0; j < N; ++j) z[j] = qrow[j];
+    const double* ys = nullptr;
+    if constexpr (SD.n_y > 0)
+        ys = reinterpret_cast<const double*>(reinterpret_cast<const char*>(y) + __umul24(row, (unsigned)(SD.n_y * sizeof(double))));
+    CLIK_PHASE("sincos");
     double sn0, cs0, sn1, cs1;
     sincos_fast(a0, sn0, cs0);
     sincos_fast(a1, sn1, cs1);
     const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
-    if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(huge) != 0ull, 0)) {
         if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
         if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
     }
+    CLIK_PHASE("sincos_exchange");
     double sns[N], css[N];
     static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
@@ -1726,15 +1727,19 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_q
             sns[j] = css[j] = 0.0;
         }
     });
+    CLIK_PHASE("tick");
     double vout[N];
     int acc_mode;
     pinv_tick_static<SD, true>(&Sval, tk, z, ys, tid & (WAVE - 1), valid, vout, acc_mode, sns, css);
+    CLIK_PHASE("select_store");
     if (valid && r == 0) {
+        double* __restrict__ drow = reinterpret_cast<double*>(reinterpret_cast<char*>(dq) + __umul24(inst, (unsigned)(N * sizeof(double))));
 #pragma unroll
-        for (int j = 0; j < N; ++j) dq[inst * N + j] = vout[j];
-        if (mode_out != nullptr) mode_out[inst] = acc_mode;
+        for (int j = 0; j < N; ++j) drow[j] = vout[j];
+        if (mode_out != nullptr) *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(mode_out) + inst * 4u) = acc_mode;
     }
     CLIK_BODY_END();
+    CLIK_PHASE_END();
 }
 
 // ... and RESIDENT: one launch that runs tick k whenever ticket k is published (clik_pinv_team.hpp, ResidentTicket: the
@@ -1896,90 +1901,6 @@ inline hipError_t launch_resident_quad_values(const TickArgs& tk, long long B, c
 // resident, of 1792 fp64 FMAs each and NO memory at all take 54 - 56 us - the kernel's 65.5 us with its 180 MB of
 // traffic is within 16 % of pure issue, and the loop costs what the prefetch saves (256 VGPRs, constants hoisted
 // out of the loop into spilled registers unless -mllvm -disable-machine-licm).
-#ifdef CLIK_LANE_PERSIST
-#ifndef CLIK_LANE_PERSIST_MIN_BATCH
-#define CLIK_LANE_PERSIST_MIN_BATCH (1ll << 60)
-#endif
-template <const ShapeDesc& SD>
-struct PersistStage {
-    static constexpr int Q_BYTES = WAVE * SD.n * (int)sizeof(double), Y_BYTES = WAVE * SD.n_y * (int)sizeof(double);
-    static constexpr int Q_PIECES = (Q_BYTES + 1023) / 1024, Y_PIECES = (Y_BYTES + 1023) / 1024;   // 64 lanes x 16 B each
-    static constexpr int DOUBLES = (Q_PIECES + Y_PIECES) * 128;                                    // one staging image
-    static constexpr int LDS_BYTES = 2 * DOUBLES * (int)sizeof(double);
-    static constexpr bool fits = LDS_BYTES * 8 <= 160 * 1024;      // eight waves per CU keep their images
-};
-template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void pinv_solve_static_values_persistent_kernel(
-    const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
-    int32_t* __restrict__ mode_out, const long long n_chunks, const TickArgs tk)
-{
-    static_assert(SD.n_x == 0, "value-specialised lane kernel: robot variables only");
-    constexpr int N = SD.n, NY = SD.n_y;
-    using PS = PersistStage<SD>;
-    constexpr Img<SD> Sval = IMGV::value;
-    __shared__ __attribute__((aligned(16))) double stage[2][PS::DOUBLES];
-    const int lane = threadIdx.x;
-    long long c = blockIdx.x;
-    if (c >= n_chunks) return;
-    // chunk `chunk` (64 whole rows of robot_var and of input_var) -> staging image `buf`, asynchronously
-    auto copy_chunk = [&](long long chunk, int buf) {
-        int l16 = lane * 16;
-        asm volatile("" : "+v"(l16));      // (recomputed per use: hoisted per-lane addresses would live across the tick)
-        const char* qs = reinterpret_cast<const char*>(q) + chunk * PS::Q_BYTES;
-#pragma unroll
-        for (int k = 0; k < PS::Q_PIECES; ++k) {
-            // (last piece of a ragged image: its upper lanes re-read the chunk's last 16 bytes into words nobody reads)
-            int off = k * 1024 + l16;
-            off = off < PS::Q_BYTES - 16 ? off : PS::Q_BYTES - 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qs + off),
-                                             (__attribute__((address_space(3))) void*)(&stage[buf][k * 128]), 16, 0, 0);
-        }
-        if constexpr (NY > 0) {
-            const char* ysrc = reinterpret_cast<const char*>(y) + chunk * PS::Y_BYTES;
-#pragma unroll
-            for (int k = 0; k < PS::Y_PIECES; ++k) {
-                int off = k * 1024 + l16;
-                off = off < PS::Y_BYTES - 16 ? off : PS::Y_BYTES - 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ysrc + off),
-                                                 (__attribute__((address_space(3))) void*)(&stage[buf][(PS::Q_PIECES + k) * 128]),
-                                                 16, 0, 0);
-            }
-        }
-    };
-    int buf = 0;
-    copy_chunk(c, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 1
-    for (;;) {
-        // (per-lane offsets are re-derived from the lane number where they are used: as loop invariants they would be
-        // hoisted, live across the tick and spilled - and a scratch reload waits for the copy in flight as well)
-        int l0 = lane;
-        asm volatile("" : "+v"(l0));
-        double z[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) z[j] = stage[buf][l0 * N + j];
-        const long long next = c + gridDim.x;
-        const bool more = next < n_chunks;
-        if (more) copy_chunk(next, buf ^ 1);
-        const double* ys = NY > 0 ? &stage[buf][PS::Q_PIECES * 128 + l0 * NY] : nullptr;
-        double vout[N];
-        int acc_mode;
-        pinv_tick_static<SD>(&Sval, tk, z, ys, lane, true, vout, acc_mode);
-        // the copy was issued a tick ago and the stores of the previous chunk before that: nothing young to wait for
-        if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int l1 = lane;
-        asm volatile("" : "+v"(l1));
-        double* out = dq + c * (WAVE * N);                       // (wave-uniform base + 32-bit lane offset)
-#pragma unroll
-        for (int j = 0; j < N; ++j) out[l1 * N + j] = vout[j];
-        if (mode_out != nullptr) (mode_out + c * WAVE)[l1] = acc_mode;
-        if (!more) break;
-        c = next;
-        buf ^= 1;
-    }
-}
-
-#endif  // CLIK_LANE_PERSIST
 
 // the value-specialised kernel of a skill for one tick: four lanes per instance where the family allows and the
 // batch is small, else the lane kernel above (hipErrorNotSupported beyond its batch range: the caller then uses
@@ -1989,7 +1910,9 @@ inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, l
                                       const double* y, double* dq, int32_t* mode, hipStream_t stream)
 {
     if constexpr (shape_team_ok(SD)) {
-        if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch))
+        // (the value-specialised team kernel addresses its rows with 24-bit row numbers: CLIK_LANES=4 at more than 2^24
+        // instances falls through to the lane kernel)
+        if (((a.mode_parallel & 8) && B <= (1ll << 24)) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch))
             return launch_solve_team_values<SD, IMGV>(a, tk, B, q, y, dq, mode, stream);
     }
     if constexpr (shape_quad_front_ok(SD)) {
@@ -2009,39 +1932,6 @@ inline hipError_t launch_solve_values(const LaunchArgs& a, const TickArgs& tk, l
     if constexpr (shape_value_lane_ok(SD)) {
         if (B <= kValueLaneMaxBatch) {
             const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-#ifdef CLIK_LANE_PERSIST
-            // (the persistent form from CLIK_LANE_PERSIST_MIN_BATCH instances on; environment CLIK_LANE_PERSIST_MIN
-            // overrides the threshold - a measuring switch, read once)
-            static long long persist_min = -1;
-            static unsigned resident = 0;
-            if (persist_min < 0) {
-                const char* e = getenv("CLIK_LANE_PERSIST_MIN");
-                long long pm = e != nullptr ? atoll(e) : (long long)CLIK_LANE_PERSIST_MIN_BATCH;
-                int per_cu = 0, dev = 0, cus = 0;
-                if (!PersistStage<SD>::fits ||
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                        &per_cu, pinv_solve_static_values_persistent_kernel<SD, IMGV>, WAVE, 0) != hipSuccess ||
-                    hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1)
-                    pm = 1ll << 60;
-                resident = (unsigned)(per_cu * cus);
-                persist_min = pm > 0 ? pm : 1;
-            }
-            if constexpr (PersistStage<SD>::fits) {
-                const long long n_full = B / WAVE;
-                if (B >= persist_min && n_full > (long long)resident) {
-                    hipLaunchKernelGGL((pinv_solve_static_values_persistent_kernel<SD, IMGV>), dim3(resident), dim3(WAVE),
-                                       0, stream, q, y, dq, mode, n_full, tk);
-                    const long long tail = B - n_full * WAVE;        // a ragged last chunk: the plain kernel, one wave
-                    if (tail > 0)
-                        hipLaunchKernelGGL((pinv_solve_static_values_kernel<SD, IMGV>), dim3(1), dim3(WAVE), 0, stream,
-                                           q + n_full * WAVE * SD.n, SD.n_y > 0 ? y + n_full * WAVE * SD.n_y : y,
-                                           dq + n_full * WAVE * SD.n, mode != nullptr ? mode + n_full * WAVE : mode, tail,
-                                           tk);
-                    return hipGetLastError();
-                }
-            }
-#endif
             hipLaunchKernelGGL((pinv_solve_static_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
                                mode, B, tk);
             return hipGetLastError();
@@ -2161,9 +2051,12 @@ inline hipError_t launch_rollout_static(const LaunchArgs& a, const double* d_tte
     if constexpr (shape_team_ok(SD)) {
         // four lanes per instance (same grid: 64 instances per block of four waves)
         if ((a.mode_parallel & 8) || ((a.mode_parallel & 4) && B <= kTeamMaxBatch)) {
-            hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD>), dim3(grid), dim3(TEAM_WAVES * WAVE),
-                               team_rollout_lds_bytes<SD>(), stream, a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt,
-                               max_speed, a.roll_stages == 4 ? 4 : 1);
+            if (a.roll_stages == 4)
+                hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD, void, 4>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                                   team_rollout_lds_bytes<SD>(), stream, a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
+            else
+                hipLaunchKernelGGL((pinv_rollout_static_team_kernel<SD, void, 1>), dim3(grid), dim3(TEAM_WAVES * WAVE),
+                                   team_rollout_lds_bytes<SD>(), stream, a.dImg, q, y, dq, mode, B, d_tterms, n_ticks, dt, max_speed);
             return hipGetLastError();
         }
     }

@@ -36,12 +36,9 @@
 
 namespace clik {
 
-// -DCLIK_TEAM_ABLATE=<bits>: timing experiments only (tools/ablate_team.py; wrong results by design, never
-// in the shipped library): 1 no cone test, 2 no second solve, 4 no factorisation / solves, 8 no Gram build,
-// 16 no FK / task rows (the state stands in for the rows)
-#ifndef CLIK_TEAM_ABLATE
-#define CLIK_TEAM_ABLATE 0
-#endif
+// (What each phase of the tick costs: tools/phase_budget.py reads it off the compiled kernel - profiles/r6_phase_budget.md.
+// Round 2's timing ablation (-DCLIK_TEAM_ABLATE, wrong results by design) and the "front end once per quad + broadcast"
+// experiment (-DCLIK_TEAM_FRONT_ONCE, 4.25 against 3.97 us) are retired: tools/experiments/pinv_retired.patch.)
 
 constexpr int TEAM = 4;                     // lanes per instance = one DPP quad
 constexpr int TEAM_WAVES = 4;               // waves per block: 64 instances, one wave per SIMD of a CU
@@ -75,6 +72,63 @@ inline size_t team_lds_bytes(bool values = false)
 #define CLIK_RESIDENT_PIPELINE 1
 #endif
 
+// What a lane's role in the quad means in numbers (functions of r = lane & 3 and of the damping only):
+//   lane          0          1           2          3
+//   beta         lam       lam / 2     1 + lam     lam        shift of the Gram matrix the lane factors
+//   hsel          1          0           0          1         solo lanes: right-hand side = the pose task's velocity
+//   nsolo         0          1           1          0         lanes 1 / 2: right-hand side = J X
+//   cax, cx2     1, 0       1, 0      1+lam, 1   1+lam, 1     X = w2 o (cax - cx2 s)
+//   lam0         lam         0           0          0         second pass of the doubly processed equality
+//   kap, hp      1, 0       1, 0     1/(1+lam),1 1/(1+lam),1  the pair's closing combination
+// The value-specialised kernels LOAD them (a 4 x 8 table in constant memory, requested with the rows: 4 load
+// instructions) - built from r with selects they were ~40 instructions of every tick.
+struct RoleConsts {
+    double beta, hsel, nsolo, cax, cx2, lam0, kap, hp;
+};
+__device__ __forceinline__ RoleConsts role_consts_computed(const int r, const double lam)
+{
+    const double one_lam = 1.0 + lam;
+    const bool hi = (r & 2) != 0, solo = (r == 0) || (r == 3);
+    RoleConsts rc;
+    rc.beta = (r == 1) ? 0.5 * lam : ((r == 2) ? one_lam : lam);
+    rc.hsel = solo ? 1.0 : 0.0;
+    rc.nsolo = solo ? 0.0 : 1.0;
+    rc.cax = hi ? one_lam : 1.0;
+    rc.cx2 = hi ? 1.0 : 0.0;
+    rc.lam0 = (r == 0) ? lam : 0.0;
+    rc.kap = hi ? 1.0 / one_lam : 1.0;
+    rc.hp = hi ? 1.0 : 0.0;
+    return rc;
+}
+struct RoleTable {
+    double v[TEAM][8];
+};
+constexpr RoleTable role_table(const double lam)
+{
+    const double one_lam = 1.0 + lam;
+    return RoleTable{{{lam, 1.0, 0.0, 1.0, 0.0, lam, 1.0, 0.0},
+                      {0.5 * lam, 0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 0.0},
+                      {one_lam, 0.0, 1.0, one_lam, 1.0, 0.0, 1.0 / one_lam, 1.0},
+                      {lam, 1.0, 0.0, one_lam, 1.0, 0.0, 1.0 / one_lam, 1.0}}};
+}
+// (not const: the loads must stay loads)
+template <class IMGV>
+inline __constant__ RoleTable kRoleTable = role_table(IMGV::value.lam);
+#ifndef CLIK_ROLE_TABLE
+#define CLIK_ROLE_TABLE 1       // (0: the value-specialised kernels build the role constants from r with selects, as the others do)
+#endif
+template <class IMGV>
+__device__ __forceinline__ RoleConsts role_consts_loaded(const int r)
+{
+#if !CLIK_ROLE_TABLE
+    return role_consts_computed(r, IMGV::value.lam);
+#endif
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* p = reinterpret_cast<const d2*>(&kRoleTable<IMGV>.v[r][0]);
+    const d2 a = p[0], b = p[1], c = p[2], d = p[3];
+    return RoleConsts{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+}
+
 struct NoMidTick {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -83,7 +137,8 @@ struct NoMidTick {
 template <const ShapeDesc& SD, class MID = NoMidTick>
 __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, const TickArgs& tk,
                                           const double (&z)[SD.n], const double* ysl, const double a0, const double a1,
-                                          const int r, const int inst, double (&v)[SD.n], bool& in_tc, MID&& mid = MID())
+                                          const int r, const int inst, const RoleConsts& rc, double (&v)[SD.n], bool& in_tc,
+                                          MID&& mid = MID())
 {
     constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2];
     constexpr int NT = M * (M + 1) / 2;
@@ -118,48 +173,14 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
         __builtin_amdgcn_sched_barrier(0);
         CLIK_PHASE("fk");
         Kin<N> K;
-        if constexpr ((CLIK_TEAM_ABLATE & 16) != 0) {
-#pragma unroll
-            for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
-                tc.e[i] = z[i % N] + sns[(i + 1) % N];
-                tc.Jt[i] = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) tc.J[i][j] = z[(i + j) % N] * css[j];
-            }
-        } else {
-#ifdef CLIK_TEAM_FRONT_ONCE
-        // EXPERIMENT: FK and the task rows evaluated by lane 0 of the quad only and handed to the
-        // other three by DPP broadcast, instead of all four lanes repeating them.  The masked lanes still occupy the
-        // SIMD while lane 0 works (one instruction stream per wave), so nothing is saved and the broadcast (two moves
-        // per double) comes on top - built to be MEASURED, profiles/r4_team_variants.md.
-#pragma unroll
-        for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
-            tc.e[i] = 0.0;
-            tc.Jt[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) tc.J[i][j] = 0.0;
-        }
-        if (r == 0) {
-#endif
         if constexpr (SD.uses_fk != 0) {
             forward_kinematics_sc<SD>(&Sfk, z, sns, css, K);
             if constexpr (SD.quat_src != 0) orientation_feature_s<SD>(&Sfk, ysl, inst, K);
         }
         CLIK_PHASE("task_rows");
         cache_task<SD, 0>(&Sfk, tk, K, z, ysl, inst, tc);
-#ifdef CLIK_TEAM_FRONT_ONCE
-        }
-#pragma unroll
-        for (int i = 0; i < TaskCache<SD>::ROWS; ++i) {
-            tc.e[i] = quad_perm_f64<0x00>(tc.e[i]);
-            tc.Jt[i] = quad_perm_f64<0x00>(tc.Jt[i]);
-#pragma unroll
-            for (int j = 0; j < N; ++j) tc.J[i][j] = quad_perm_f64<0x00>(tc.J[i][j]);
-        }
-#endif
-        }
     }
-    
+
     const Img<SD> Sb = *Slds;
     __builtin_amdgcn_sched_barrier(0);
     CLIK_PHASE("desired");
@@ -211,12 +232,8 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
 #pragma unroll
         for (int k = 0; k <= i; ++k) {
             double acc = 0.0;
-            if constexpr ((CLIK_TEAM_ABLATE & 8) != 0) {
-                acc = jac<SD, 1>(S, tc, i, k) * jac<SD, 1>(S, tc, k, i);
-            } else {
 #pragma unroll
             for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
-            }
             Gm[tri(i, k)] = acc;
         }
     if constexpr (!std::is_same<std::decay_t<MID>, NoMidTick>::value) {
@@ -232,47 +249,36 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     // (Woodbury; S = 0 in mode 0).  So lane 1 solves A1 t = J w2 (then x/D = w2, c = 2), lane 2 solves
     // A2 t = J x with x = ((1+lam) - s) o w2 (c = 1), lanes 0 / 3 solve A0 y = d1.
     CLIK_PHASE("role_rhs");
-    const bool solo = (r == 0) || (r == 3);
-    const double alpha = (r == 1) ? 2.0 : 1.0;
-    const double beta = (r == 2) ? one_lam : lam;
-    const double hsel = solo ? 1.0 : 0.0;
-    double rhs[M];
-    {
-        double x[N];
-        // (role masks applied arithmetically: a select of a double costs two instructions)
-        const double m1 = (r == 1) ? 1.0 : 0.0, m2 = (r == 2) ? 1.0 : 0.0;
+    // Lane 1's matrix is 2 Gm + lam I = 2 (Gm + lam/2 I): it factors Gm + lam/2 I and its solution is TWICE the one the
+    // formula above names - exactly (a power of two), so "2 g1" below is its J' product as it stands.  Every lane
+    // then factors Gm + beta I with its own beta: Gm is used as it is, only the diagonal is touched.
+    // X = w2 o (cax - cx2 s): w2 in the mode-0 pair, w2 ((1+lam) - s) in the mode-1 pair - the right-hand side J X of
+    // lanes 1 / 2 and the term the solo lanes 0 / 3 add to their velocity at the end, one evaluation for both uses.
+    double X[N], rhs[M];
 #pragma unroll
-        for (int j = 0; j < N; ++j) x[j] = w2[j] * fma(m2, one_lam - sact[j], m1);
+    for (int j = 0; j < N; ++j) X[j] = w2[j] * fma(-rc.cx2, sact[j], rc.cax);
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            double sacc = hsel * des1[i];
+    for (int i = 0; i < M; ++i) {
+        double sacc = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) sacc = fma(jac<SD, 1>(S, tc, i, j), x[j], sacc);
-            rhs[i] = sacc;
-        }
+        for (int j = 0; j < N; ++j) sacc = fma(jac<SD, 1>(S, tc, i, j), X[j], sacc);
+        rhs[i] = fma(rc.nsolo, sacc, rc.hsel * des1[i]);
     }
     double A[NT], rd[M], s2[M];
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? fma(alpha, Gm[tri(i, k)], beta) : alpha * Gm[tri(i, k)];
-    if constexpr ((CLIK_TEAM_ABLATE & 4) != 0) {
-#pragma unroll
-        for (int i = 0; i < M; ++i) rhs[i] *= A[tri(i, i)] + A[tri(M - 1, i)];
-    } else {
+        for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? Gm[tri(i, k)] + rc.beta : Gm[tri(i, k)];
     CLIK_PHASE("factor");
     ldl_factor_s<M>(A, rd);
     CLIK_PHASE("solve1");
     ldl_solve_s<M>(A, rd, rhs);
-    }
     CLIK_PHASE("solve2");
 #pragma unroll
     for (int i = 0; i < M; ++i) s2[i] = rhs[i];
-    if constexpr ((CLIK_TEAM_ABLATE & (2 | 4)) == 0)
     ldl_solve_s<M>(A, rd, s2);      // (second pass of the doubly processed equality: lane 0 only)
-    const double lam0 = (r == 0) ? lam : 0.0;
 #pragma unroll
-    for (int i = 0; i < M; ++i) rhs[i] = fma(lam0, s2[i], rhs[i]);
+    for (int i = 0; i < M; ++i) rhs[i] = fma(rc.lam0, s2[i], rhs[i]);
     CLIK_PHASE("jt_product");
     double g[N];
 #pragma unroll
@@ -285,64 +291,67 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
 
     
     // ---- the quad's results meet: lane 0 forms the mode-0 velocity, lane 3 the mode-1 one --
-    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - 2 g1)          (lane 0)
+    //   mode 0:  v = J'(y + lam y2)  +  (w2 - 2 J' A1^-1 J w2)                      = g0 + (w2 - g1), g1 of the halved matrix   (lane 0)
     //   mode 1:  v = N_set J'y       +  (x - J' A2^-1 J x) / (1+lam)                 = (1 - p0 s) o g3 + (x - g2)/(1+lam)   (lane 3)
     CLIK_PHASE("meet");
-    const bool hi_pair = (r & 2) != 0;
-    const double kap = hi_pair ? 1.0 / one_lam : 1.0;
-    const double eta = hi_pair ? 1.0 : 2.0;
-    const double hp = hi_pair ? 1.0 : 0.0, oneh = hi_pair ? one_lam : 1.0;
     // (one exchange per entry: lanes swap inside their pair, so lane 0 holds g0 and receives g1, lane 3 holds g3 and
     // receives g2 - the mode-0 velocity forms in lane 0, the mode-1 one in lane 3; lanes 1 / 2 compute unused values)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const double other = quad_perm_f64<0xB1>(g[j]);      // quad_perm:[1,0,3,2]
-        const double hs = hp * sact[j];
-        const double nmul = fma(-p0[j], hs, 1.0);            // 1 in the mode-0 pair, 1 - p0 s in the mode-1 pair
-        const double xx = w2[j] * (oneh - hs);               // w2 | w2 ((1+lam) - s)
-        v[j] = fma(g[j], nmul, kap * fma(-eta, other, xx));
+        const double nmul = fma(-p0[j] * rc.hp, sact[j], 1.0);   // 1 in the mode-0 pair, 1 - p0 s in the mode-1 pair
+        v[j] = fma(g[j], nmul, rc.kap * (X[j] - other));
     }
     // tangent-cone test of the inactive set on the mode-0 candidate (:222-252; the other lanes evaluate it
     // on the other candidate, unused)
     CLIK_PHASE("cone");
-    if constexpr ((CLIK_TEAM_ABLATE & 1) != 0) {
-        in_tc = v[0] + Jt0[0] + e0[0] > 0.0;
-    } else {
+    {
         // (pseudo_inverse.py:222-252, same values; written for few instructions: half signs by bit operations,
         // flags combined bitwise - the short-circuit forms compile to a branch per row -, and everything behind
         // "inside" skipped when every instance of the wave is inside its limits, the normal state of a control loop)
         const clik_task& t = S->tasks[0];
         double le[M0], ue[M0];
-        bool inside = true;
 #pragma unroll
         for (int i = 0; i < M0; ++i) {
             le[i] = e0[i] - t.set_min[i];
             ue[i] = e0[i] - t.set_max[i];
-            inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
         }
+        // all(le >= 1e-12) & all(ue <= 1e-12) through the smallest le and the largest ue: a compare writes a lane mask
+        // into scalar registers and every "and" of two masks is a scalar instruction of its own - 14 compares + 13 ands
+        // against 12 min / max + 2 compares + 1 and
+        double le_min = le[0], ue_max = ue[0];
+#pragma unroll
+        for (int i = 1; i < M0; ++i) {
+            le_min = fmin(le_min, le[i]);
+            ue_max = fmax(ue_max, ue[i]);
+        }
+        // (as "outside" and through the builtin: the lane mask of two compares or-ed is tested as it stands)
+        const bool outside = (le_min < 1e-12) | (ue_max > 1e-12);
         in_tc = true;
-        if (__ballot(!inside) != 0ull) {
-            bool corner = true;
-            double od = 0.0, nde = 0.0, nout = 0.0;
+        if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {
+            double od = 0.0, nde = 0.0, nout = 0.0, ndiff = 0.0;
             static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int col = SD.ucol[0][i] - 1;
                 const double de = Jt0[i] + v[col];
                 const double hl = half_sign(le[i]), hu = half_sign(ue[i]);     // (sign(le) + sign(ue)) / 2 = hl + hu
-                corner = corner & (hl == hu);
+                ndiff += fabs(hl - hu);
                 const double out = hl + hu;
                 od = fma(out, de, od);
                 nde = fma(de, de, nde);
                 nout = fma(out, out, nout);
             });
+            // corner = all(sign(le) == sign(ue)): the half signs are multiples of 1/2, so "no row differs" is "the sum
+            // of |hl - hu| is exactly zero" - arithmetic instead of seven compares and the masks' ands
+            const bool corner = ndiff == 0.0;
             bool going_in = od < 0.0;
-            if (__ballot(corner & !inside) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(corner & outside) != 0ull) {
                 // every joint beyond a limit (a corner of the box): inward only within 45 degrees of the diagonal
                 const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
                 const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
                 going_in = corner ? steep : going_in;
             }
-            in_tc = inside | going_in;
+            in_tc = !outside | going_in;
         }
     }
     CLIK_PHASE_END();
@@ -387,14 +396,23 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     // Value-specialised instantiation: every index into the state / input rows is a literal, so each lane reads its
     // instance's rows straight from global memory into registers (the four lanes of a quad hit the same addresses,
     // a wave's 16 rows are contiguous) and the selected lane stores the velocities itself: no LDS, no barrier.
-    const long long binst = (b0 + inst < B) ? (b0 + inst) : (B - 1);
+    // (this kernel serves batches of at most 32768 instances - launch_solve_values -: the row index is a 32-bit number,
+    // and the rows are addressed as uniform base + 32-bit lane offset: the 64-bit index arithmetic was 17 instructions)
+    const unsigned uinst = (unsigned)blockIdx.x * (unsigned)TEAM_INST + (unsigned)inst;
+    const unsigned ulast = (unsigned)B - 1u;
+    const unsigned urow = uinst < ulast ? uinst : ulast;
+    const long long binst = (long long)urow;
     double zdir[N], ydir[NY > 0 ? NY : 1];
+    RoleConsts rc;
+    if constexpr (VALUES) rc = role_consts_loaded<IMGV>(r);
     if constexpr (VALUES) {
+        const double* __restrict__ qrow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + __umul24(urow, (unsigned)(N * sizeof(double))));
 #pragma unroll
-        for (int j = 0; j < N; ++j) zdir[j] = q[binst * N + j];
+        for (int j = 0; j < N; ++j) zdir[j] = qrow[j];
         if constexpr (NY > 0) {
+            const double* __restrict__ yrow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(y) + __umul24(urow, (unsigned)(NY * sizeof(double))));
 #pragma unroll
-            for (int k = 0; k < NY; ++k) ydir[k] = y[binst * NY + k];
+            for (int k = 0; k < NY; ++k) ydir[k] = yrow[k];
         }
     }
     if constexpr (!VALUES) {
@@ -459,26 +477,36 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     constexpr Img<SD> Sval = []() constexpr { if constexpr (VALUES) return IMGV::value; else return Img<SD>{}; }();
     const Img<SD>* __restrict__ Slds = VALUES ? &Sval : (const Img<SD>*)lds;
     const double* ysl = VALUES ? ydir : ys + inst * NY;
+    if constexpr (!VALUES) rc = role_consts_computed(r, Slds->lam);
     double z[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = VALUES ? zdir[j] : zs[inst * N + j];
 
     const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-    const double a0 = VALUES ? q[binst * N + j0] : zs[inst * N + j0];
-    const double a1 = VALUES ? q[binst * N + j1] : zs[inst * N + j1];
+    double a0, a1;
+    if constexpr (VALUES) {
+        const unsigned qoff = __umul24(urow, (unsigned)(N * sizeof(double)));
+        a0 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j0 * 8u));
+        a1 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j1 * 8u));
+    } else {
+        a0 = zs[inst * N + j0];
+        a1 = zs[inst * N + j1];
+    }
     double v[N];
     bool in_tc;
-    team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, v, in_tc);
+    team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, v, in_tc);
     // the scan of :530-550 as a select: mode 0 if its cone test passes, else mode 1 (the active set
     // has no cone test, so mode 1 is always admissible)
     CLIK_STAMP_W(0, 6);
     CLIK_PHASE("select_store");
     const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
     if constexpr (VALUES) {
-        if (r == (ok0 ? 0 : 3) && inst < rows_valid) {
+        if (r == (ok0 ? 0 : 3) && uinst <= ulast) {
+            double* __restrict__ drow = reinterpret_cast<double*>(reinterpret_cast<char*>(dq) + __umul24(uinst, (unsigned)(N * sizeof(double))));
 #pragma unroll
-            for (int j = 0; j < N; ++j) dq[(b0 + inst) * N + j] = v[j];
-            if (mode_out != nullptr) mode_out[b0 + inst] = ok0 ? 0 : 1;
+            for (int j = 0; j < N; ++j) drow[j] = v[j];
+            if (mode_out != nullptr)
+                *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(mode_out) + uinst * 4u) = ok0 ? 0 : 1;
         }
     } else {
         if (r == (ok0 ? 0 : 3)) {
@@ -507,12 +535,14 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
 // in registers (replicated over the quad).  stages = 1: explicit Euler; 4: classical Runge-Kutta with the
 // controller as the right-hand side (see pinv_rollout_static_kernel).  q is updated in place; dq / mode receive
 // the last tick (Runge-Kutta: the combined rate and the mode of the first stage).
-template <const ShapeDesc& SD, class IMGV = void>
+template <const ShapeDesc& SD, class IMGV = void, int STAGES = 1>
 __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_kernel(
     const void* __restrict__ img_g, double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, int32_t* __restrict__ mode_out, const long long B,
-    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed, const int stages)
+    const double* __restrict__ tterms, const int n_ticks, const double dt, const double max_speed)
 {
+    static_assert(STAGES == 1 || STAGES == 4, "explicit Euler or classical Runge-Kutta");
+    constexpr int stages = STAGES;
     static_assert(shape_team_ok(SD), "shape outside the team kernel's family");
     constexpr bool VALUES = !std::is_void<IMGV>::value;
     extern __shared__ double lds[];
@@ -549,13 +579,58 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
     constexpr Img<SD> Sval = []() constexpr { if constexpr (VALUES) return IMGV::value; else return Img<SD>{}; }();
     const Img<SD>* __restrict__ Slds = VALUES ? &Sval : (const Img<SD>*)lds;
     const double* ysl = VALUES ? ydir : ys + inst * NY;
+    RoleConsts rc;
+    if constexpr (VALUES) rc = role_consts_loaded<IMGV>(r);
+    else rc = role_consts_computed(r, Slds->lam);
     const int nts = Slds->n_tslots;
     double vout[N];
     int acc_mode = -1;
 #pragma unroll
     for (int j = 0; j < N; ++j) vout[j] = 0.0;
+    // (no clamp = a bound no finite velocity reaches: the same two instructions, no test per element)
+    const double vmax = max_speed > 0.0 ? max_speed : 1.7976931348623157e308;
+    // the accepted candidate in every lane of the quad: mode 0 lives in lane 0, mode 1 in lane 3 - lane 0's value is
+    // broadcast, and only quads that rejected mode 0 (a uniform decision inside a quad) fetch lane 3's on top
+    auto accepted = [&](const double (&v)[N], const bool ok0, double (&d)[N]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) d[j] = quad_perm_f64<0x00>(v[j]);
+        if (__builtin_amdgcn_ballot_w64(!ok0) != 0ull) {
+            if (!ok0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) d[j] = quad_perm_f64<0xFF>(v[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) d[j] = fmax(fmin(d[j], vmax), -vmax);
+    };
+    auto sincos_args = [&](const double (&zz)[N], double& a0, double& a1) __attribute__((always_inline)) {
+        // lane r's two sin / cos arguments out of the replicated state (register selects)
+        a0 = zz[N - 1];
+        a1 = zz[N - 1];
+        static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (2 * k < N) a0 = (r == k) ? zz[2 * k] : a0;
+            if constexpr (2 * k + 1 < N) a1 = (r == k) ? zz[2 * k + 1] : a1;
+        });
+    };
 #pragma unroll 1
     for (int tick = 0; tick < n_ticks; ++tick) {
+        if constexpr (STAGES == 1) {
+            // explicit Euler (the notebooks' loop, ur5_moe2016_example2.ipynb:537-545): nothing of the Runge-Kutta
+            // staging - no saved state, no stage sums, no weights
+            asm volatile("" ::: "memory");      // (keeps the image reads inside the loop, see pinv_rollout_static_kernel)
+            const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + (size_t)tick * 2 * nts);
+            double a0, a1;
+            sincos_args(z, a0, a1);
+            double v[N];
+            bool in_tc;
+            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, v, in_tc);
+            const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
+            accepted(v, ok0, vout);
+#pragma unroll
+            for (int j = 0; j < N; ++j) z[j] = fma(vout[j], dt, z[j]);
+            acc_mode = ok0 ? 0 : 1;
+        } else {
         double z0[N], ks[N];
         int mode0 = -1;
 #pragma unroll
@@ -565,39 +640,31 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
         }
 #pragma unroll 1
         for (int st = 0; st < stages; ++st) {
-            asm volatile("" ::: "memory");      // (keeps the image reads inside the loop, see pinv_rollout_static_kernel)
+            asm volatile("" ::: "memory");
             const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + st) * 2 * nts);
-            // lane r's two sin / cos arguments out of the replicated state (register selects)
-            double a0 = z[N - 1], a1 = z[N - 1];
-            static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
-                constexpr int k = decltype(kc)::value;
-                if constexpr (2 * k < N) a0 = (r == k) ? z[2 * k] : a0;
-                if constexpr (2 * k + 1 < N) a1 = (r == k) ? z[2 * k + 1] : a1;
-            });
-            double v[N];
+            double a0, a1;
+            sincos_args(z, a0, a1);
+            double v[N], d[N];
             bool in_tc;
-            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, v, in_tc);
+            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, v, in_tc);
             const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
-            const double wgt = (stages == 1) ? 1.0 : ((st == 0 || st == 3) ? 1.0 : 2.0);
+            accepted(v, ok0, d);
+            const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
             const double cnext = (st == 2) ? dt : 0.5 * dt;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                // the accepted candidate in every lane of the quad: mode 0 lives in lane 0, mode 1 in lane 3
-                const double c0 = quad_perm_f64<0x00>(v[j]), c1 = quad_perm_f64<0xFF>(v[j]);
-                double d = ok0 ? c0 : c1;
-                if (max_speed > 0.0) d = fmax(fmin(d, max_speed), -max_speed);
-                ks[j] = fma(wgt, d, ks[j]);
-                z[j] = fma(d, cnext, z0[j]);
+                ks[j] = fma(wgt, d[j], ks[j]);
+                z[j] = fma(d[j], cnext, z0[j]);
             }
             mode0 = (st == 0) ? (ok0 ? 0 : 1) : mode0;
         }
-        const double scale = (stages == 1) ? 1.0 : 1.0 / 6.0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            vout[j] = ks[j] * scale;
+            vout[j] = ks[j] * (1.0 / 6.0);
             z[j] = fma(vout[j], dt, z0[j]);
         }
         acc_mode = mode0;
+        }
     }
     if (r == 0 && valid) {
 #pragma unroll
@@ -722,6 +789,8 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     const bool valid = b0 + inst < B;
     const long long binst = valid ? (b0 + inst) : (B - 1);
     constexpr Img<SD> Sval = IMGV::value;
+    CLIK_PHASE("res_setup");
+    const RoleConsts rc = role_consts_loaded<IMGV>(r);
     // watchdog: a budget of POLLS over the kernel's whole life (a poll is a cache-missing load plus s_sleep, 1.5-3 us):
     // deterministic, unlike a clock - the first version compared s_memrealtime readings and misfired at the first tick
     // inside the long test run (never alone), leaving the kernel at once with stop = 2
@@ -842,12 +911,14 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     int owed = 0;           // tick whose "done" slot is still to be published (0: none)
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
+        CLIK_PHASE("res_poll_request");
         if (!have_next) {
             poll_for((unsigned)k);
             if (leave) break;
             asm volatile("" ::: "memory");
             request_rows(k);
         }
+        CLIK_PHASE("res_spread");
         spread();
         double z[N], ydir[NY > 0 ? NY : 1];
 #pragma unroll
@@ -869,12 +940,13 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         });
         double v[N];
         bool in_tc;
-        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, v, in_tc, [&]() __attribute__((always_inline)) {
+        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, rc, v, in_tc, [&]() __attribute__((always_inline)) {
             if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen >= (unsigned)(k + 1)) {
                 request_rows(k + 1);
                 have_next = true;
             }
         });
+        CLIK_PHASE("res_accept");
         const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
         // the accepted candidate in every lane of the quad (mode 0 lives in lane 0, mode 1 in lane 3): lane r stores
         // elements 2r and 2r + 1 of the row (write-through stores of one lane per element cost 32 bytes each at the
@@ -889,12 +961,14 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             }
             v[j] = d;
         }
+        CLIK_PHASE("res_publish");
         if (owed != 0) {
             publish_done(owed);         // (the previous tick's stores: issued a whole tick ago)
             owed = 0;
         }
         if (have_next && k + 1 < n_ticks)
             seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
+        CLIK_PHASE("res_store");
         if (valid) {
             // (write-through stores: visible to every agent once acknowledged)
             const long long orow = ((long long)((k - 1) % (int)ring)) * B + b0 + inst;
@@ -918,6 +992,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         else publish_done(k);           // nobody has asked for the next tick yet (or this was the last): at once
     }
     if (owed != 0) publish_done(owed);
+    CLIK_PHASE_END();
 }
 
 // reference producer / test harness of the resident ticks: publishes tickets 1 .. n_ticks from the device, either as

@@ -1,477 +1,23 @@
-// Batched ReactiveQPController tick on gfx950.
-//
-// Replaces, for B instances per launch, the per-tick body of
-//   ReactiveQPController.solve            casclik/controllers/reactive_qp.py:461-528
-// i.e. the H/A/lbA/ubA functions (:175-246, :262-298) and the qpOASES call
-// through cs.conic (:248-260, :491-513).
-//
-// The QP   min 1/2 v'Hv   s.t.  lbA <= A v <= ubA,   H = diag(h) > 0,
-// v = [robot_vel; virtual_vel; slack]  has a unique minimiser, so the solver is
-// free: each lane runs an exact dual active-set method (Goldfarb & Idnani 1983)
-// written in CONSTRAINT space.  With nu the signed multipliers,
-//      v = H^-1 A' nu,      c = A v = Q nu,      Q = A H^-1 A'   (nc x nc, SPD-ish)
-// so the iteration only needs Q (kept in LDS, per lane), nu and c; every change
-// of the working set re-factors the masked Schur matrix  S_W = D Q_WW D  by a
-// fixed-size LDL^T in registers (no updates/downdates, no drift, the same
-// instruction stream for every lane; lanes differ only in masks).
-//   - slack columns never materialise: a soft row i adds 1/h_slack,i to Q_ii
-//     and its slack is  -nu_i / h_slack,i
-//   - rows with lbA == ubA are equalities: once active they stay, their
-//     multiplier is sign-free
-//   - infeasible problems (hard rows only) are reported per instance, like the
-//     reference's RuntimeError from qpOASES
-#include "clik_qp_static.hpp"
-#include <map>
-#include <mutex>
-#include <utility>
+// Batched ReactiveQPController tick on gfx950, dynamic-shape kernels: the variant table and its look-up.  The kernels
+// and their launch templates are clik_qp_dyn.hpp; their instantiations compile in clik_qp_dyn_[a-d].hip.
+#include "clik_qp_dyn.hpp"
 
 namespace clik {
 
-namespace shapes {
-#include "clik_shapes_gen.hpp"
-}  // namespace shapes
+// (instantiated elsewhere: nothing of the kernels is compiled in this translation unit)
+CLIK_QP_VARIANTS_A(CLIK_QP_DECL_EXACT, CLIK_QP_DECL_GUARD, CLIK_QP_DECL_GLOBAL)
+CLIK_QP_VARIANTS_B(CLIK_QP_DECL_EXACT, CLIK_QP_DECL_GUARD, CLIK_QP_DECL_GLOBAL)
+CLIK_QP_VARIANTS_C(CLIK_QP_DECL_EXACT, CLIK_QP_DECL_GUARD, CLIK_QP_DECL_GLOBAL)
+CLIK_QP_VARIANTS_D(CLIK_QP_DECL_EXACT, CLIK_QP_DECL_GUARD, CLIK_QP_DECL_GLOBAL)
 
-// LDS slots per lane: [zs N][ys ny][A rows NC*N (FK frames alias)][Q NC(NC+1)/2][lb NC][ub NC][hinv NC]
-template <int N, int NC>
-__host__ __device__ constexpr int qp_lds_slots(int ny)
-{
-    return N + ny + (NC * N > 6 * N ? NC * N : 6 * N) + NC * (NC + 1) / 2 + 3 * NC;
-}
-
-// Evaluate every constraint row of the QP for the lane's instance:
-//   A_u rows -> As[row*N + j], bounds -> lbs/ubs, slack curvature 1/h_slack (0 = hard) -> hsi
-// Returns the number of rows (wave-uniform).  reactive_qp.py:191-246.
-template <int N>
-__device__ __forceinline__ int qp_rows(const DevSkill* __restrict__ S, const TickArgs& tk, const Kin<N>& K,
-                                       const double (&z)[N], const double* ys, const int lane, const int n,
-                                       double* As, double* lbs, double* ubs, double* hsi)
-{
-    const clik_skill_desc& D = S->d;
-    int row = 0, slack = 0;
-    const double mu = S->qo.weight_shifter;
-    for (int ti = 0; ti < D.n_tasks; ++ti) {
-        const clik_task& t = D.tasks[ti];
-        const int m = t.m;
-        double e[N], J[N][N], Jt[N];
-        task_eval<N, N>(S, ti, m, -1, false, tk, K, z, ys, lane, n, e, J, Jt);
-        double lo[N], hi[N];
-        const int cls = t.cls;
-        if (cls == CLIK_CLS_EQ) {
-            double ke[N];
-            gain_apply<N>(t, m, e, ke);
-#pragma unroll
-            for (int i = 0; i < N; ++i) lo[i] = hi[i] = -Jt[i] - ke[i];
-        } else if (cls == CLIK_CLS_SET) {
-            double d0[N], g[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) d0[i] = (i < m) ? t.set_min[i] - e[i] : 0.0;
-            gain_apply<N>(t, m, d0, g);
-#pragma unroll
-            for (int i = 0; i < N; ++i) lo[i] = -Jt[i] + g[i];
-#pragma unroll
-            for (int i = 0; i < N; ++i) d0[i] = (i < m) ? t.set_max[i] - e[i] : 0.0;
-            gain_apply<N>(t, m, d0, g);
-#pragma unroll
-            for (int i = 0; i < N; ++i) hi[i] = -Jt[i] + g[i];
-        } else if (cls == CLIK_CLS_VELEQ) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) lo[i] = hi[i] = (i < m) ? t.target[i] - Jt[i] : 0.0;
-        } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                lo[i] = (i < m) ? t.set_min[i] - Jt[i] : 0.0;
-                hi[i] = (i < m) ? t.set_max[i] - Jt[i] : 0.0;
-            }
-        }
-        const bool soft = t.soft != 0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (i < m) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (j < n) As[((row + i) * N + j) * WAVE + lane] = J[i][j];
-                lbs[(row + i) * WAVE + lane] = lo[i];
-                ubs[(row + i) * WAVE + lane] = hi[i];
-                hsi[(row + i) * WAVE + lane] = soft ? 1.0 / (mu + S->qo.slack_weights[slack + i]) : 0.0;
-            }
-        }
-        if (soft) slack += m;
-        row += m;
-    }
-    return row;
-}
-
-// GWS: the per-wave work area (state, rows, dual Hessian, bounds: qp_lds_slots doubles per lane) lies in GLOBAL memory
-// handed in by the launch (`gws`, one area per block) instead of LDS - the variants for QPs with more than 16 rows,
-// whose work area (up to 490 KB per wave at 42 x 32) no CU holds.  Same code, slower memory: such skills are served,
-// not refused (the reference puts no bound on the number of constraints, reactive_qp.py:191-246).
-template <int N, int NC, bool EXACT, bool GWS = false>
-__global__ __launch_bounds__(WAVE) void qp_solve_kernel(
-    const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
-    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ dx, double* __restrict__ slack_out,
-    int32_t* __restrict__ status_out, double* __restrict__ gws = nullptr, const int ny_slots = 0)
-{
-    extern __shared__ double lds_shared[];
-    double* lds = GWS ? gws + (size_t)blockIdx.x * (size_t)qp_lds_slots<N, NC>(ny_slots) * WAVE : lds_shared;
-    constexpr int NT = NC * (NC + 1) / 2;
-    const int lane = threadIdx.x;
-    const DevSkill* __restrict__ S = warm_descriptor(S0, wa);
-    const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
-    double* zs = lds;
-    double* ys = zs + N * WAVE;
-    double* As = ys + ny * WAVE;
-    double* Qs = As + (NC * N > 6 * N ? NC * N : 6 * N) * WAVE;
-    double* lbs = Qs + NT * WAVE;
-    double* ubs = lbs + NC * WAVE;
-    double* hsi = ubs + NC * WAVE;
-    // one block per 64 instances when the work area is LDS; the global-memory variants launch only as many blocks as the
-    // device holds at once (their work area is per RESIDENT block, not per 64 instances) and walk the batch
-    const long long nblk = (B + WAVE - 1) / WAVE;
-#pragma unroll 1
-    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const long long b0 = blk * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
-    __syncthreads();
-    stage_in_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_in_dyn(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (ny > 0) stage_in_dyn(y + b0 * ny, ny, rows_valid, ys, lane);
-    __syncthreads();
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = (j < n) ? zs[j * WAVE + lane] : 0.0;
-
-    Kin<N> K;
-    if (S->d.uses_fk) {
-        forward_kinematics<N>(S, zs, As, lane, K);      // frames alias the (not yet written) row area
-        if (S->d.quat_src != 0) orientation_feature<N>(S, ys, lane, K);
-    }
-    const int nc = qp_rows<N>(S, tk, K, z, ys, lane, n, As, lbs, ubs, hsi);
-
-    // Q = A_u diag(1/h_u) A_u' + diag(1/h_slack on soft rows)        (H of reactive_qp.py:175-189)
-    double hinv[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) hinv[j] = (j < n) ? 1.0 / (S->qo.weight_shifter * S->qo.state_weights[j]) : 0.0;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        if (i < nc) {
-            double ri[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) ri[j] = (j < n) ? As[(i * N + j) * WAVE + lane] * hinv[j] : 0.0;
-#pragma unroll
-            for (int k = 0; k <= i; ++k) {
-                double acc = (k == i) ? hsi[i * WAVE + lane] : 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (j < n) acc = fma(ri[j], As[(k * N + j) * WAVE + lane], acc);
-                Qs[tri(i, k) * WAVE + lane] = acc;
-            }
-        }
-    }
-
-    // soft equality rows (wave-uniform): start active
-    uint32_t softeq = 0u;
-    {
-        int row = 0;
-        for (int ti = 0; ti < S->d.n_tasks; ++ti) {
-            const clik_task& t = S->d.tasks[ti];
-            const bool se = t.soft != 0 && (t.cls == CLIK_CLS_EQ || t.cls == CLIK_CLS_VELEQ);
-            for (int i = 0; i < t.m; ++i)
-                if (se) softeq |= 1u << (row + i);
-            row += t.m;
-        }
-    }
-    double nu[NC];
-    const int status = gi_solve<NC, EXACT>(Qs, lbs, ubs, nullptr, softeq, lane, nc, S->qo.max_iter, valid, nu);
-
-    // v = H^-1 A' nu
-    double u[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) u[j] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        if (i < nc) {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (j < n) u[j] = fma(nu[i], As[(i * N + j) * WAVE + lane], u[j]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j) u[j] = u[j] * hinv[j];
-    // safety net in the space of the answer: every row  lbA <= A_u v - s <= ubA  must hold for the
-    // returned v (s = -nu h_s^-1 on soft rows); see the shape-specialised kernel
-    int status_v = status;
-    if (status == 0) {
-        double worst = 0.0;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            if (i < nc) {
-                double cv = nu[i] * hsi[i * WAVE + lane];
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (j < n) cv = fma(As[(i * N + j) * WAVE + lane], u[j], cv);
-                const double lbi = lbs[i * WAVE + lane], ubi = ubs[i * WAVE + lane];
-                worst = fmax(worst, fmax((lbi - cv) / fmax(1.0, fabs(lbi)), (cv - ubi) / fmax(1.0, fabs(ubi))));
-            }
-        }
-        if (!(worst <= 1e-7)) status_v = 2;      // (a net for garbage, not a precision test)
-    }
-    const double bad = (status_v == 2) ? __builtin_nan("") : 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) u[j] += bad;
-    if (slack_out != nullptr && valid) {
-        const int ns = S->n_slack;
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            if (i < nc) {
-                const double hi_ = hsi[i * WAVE + lane];
-                if (hi_ != 0.0) {
-                    slack_out[(b0 + lane) * ns + k] = -nu[i] * hi_ + bad;
-                    ++k;
-                }
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (j < n) zs[j * WAVE + lane] = u[j];
-    __syncthreads();
-    stage_out_dyn(dq + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0 && dx != nullptr) stage_out_dyn(dx + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (status_out != nullptr && valid) status_out[b0 + lane] = status_v;
-    __syncthreads();            // (the work area is reused by the next 64 instances of this block)
-    }
-}
-
-// H diagonal, A, lbA, ubA exactly as the reference's H_func / A_func / Blb_func /
-// Bub_func return them (reactive_qp.py:283-298), for inspection and parity tests.
-template <int N, int NC, bool GWS = false>
-__global__ __launch_bounds__(WAVE) void qp_data_kernel(
-    const DevSkill* __restrict__ S0, const WarmArgs wa, const TickArgs tk, const long long B,
-    const double* __restrict__ q, const double* __restrict__ x, const double* __restrict__ y,
-    double* __restrict__ Hd, double* __restrict__ A, double* __restrict__ lbA, double* __restrict__ ubA,
-    double* __restrict__ gws = nullptr, const int ny_slots = 0)
-{
-    extern __shared__ double lds_shared[];
-    double* lds = GWS ? gws + (size_t)blockIdx.x * (size_t)qp_lds_slots<N, NC>(ny_slots) * WAVE : lds_shared;
-    constexpr int NT = NC * (NC + 1) / 2;
-    const int lane = threadIdx.x;
-    const DevSkill* __restrict__ S = warm_descriptor(S0, wa);
-    const int n = S->n, nq = S->d.n_q, nx = S->d.n_x, ny = S->d.n_y;
-    double* zs = lds;
-    double* ys = zs + N * WAVE;
-    double* As = ys + ny * WAVE;
-    double* Qs = As + (NC * N > 6 * N ? NC * N : 6 * N) * WAVE;
-    double* lbs = Qs + NT * WAVE;
-    double* ubs = lbs + NC * WAVE;
-    double* hsi = ubs + NC * WAVE;
-    const long long nblk = (B + WAVE - 1) / WAVE;
-#pragma unroll 1
-    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const long long b0 = blk * WAVE;
-    const long long left = B - b0;
-    const int rows_valid = left < WAVE ? (int)left : WAVE;
-    const bool valid = lane < rows_valid;
-#pragma unroll
-    for (int j = 0; j < N; ++j) zs[j * WAVE + lane] = 0.0;
-    for (int k = 0; k < ny; ++k) ys[k * WAVE + lane] = 0.0;
-    __syncthreads();
-    stage_in_dyn(q + b0 * nq, nq, rows_valid, zs, lane);
-    if (nx > 0) stage_in_dyn(x + b0 * nx, nx, rows_valid, zs + nq * WAVE, lane);
-    if (ny > 0) stage_in_dyn(y + b0 * ny, ny, rows_valid, ys, lane);
-    __syncthreads();
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) z[j] = (j < n) ? zs[j * WAVE + lane] : 0.0;
-    Kin<N> K;
-    if (S->d.uses_fk) {
-        forward_kinematics<N>(S, zs, As, lane, K);
-        if (S->d.quat_src != 0) orientation_feature<N>(S, ys, lane, K);
-    }
-    const int nc = qp_rows<N>(S, tk, K, z, ys, lane, n, As, lbs, ubs, hsi);
-    if (valid) {
-        const int ns = S->n_slack, nv = n + ns;
-        const long long b = b0 + lane;
-        for (int j = 0; j < n; ++j) Hd[b * nv + j] = S->qo.weight_shifter * S->qo.state_weights[j];
-        for (int k = 0; k < ns; ++k) Hd[b * nv + n + k] = S->qo.weight_shifter + S->qo.slack_weights[k];
-        int k = 0;
-        for (int i = 0; i < nc; ++i) {
-            double* row = A + (b * nc + i) * nv;
-            for (int j = 0; j < nv; ++j) row[j] = 0.0;
-            for (int j = 0; j < n; ++j) row[j] = As[(i * N + j) * WAVE + lane];
-            if (hsi[i * WAVE + lane] != 0.0) {
-                row[n + k] = -1.0;
-                ++k;
-            }
-            lbA[b * nc + i] = lbs[i * WAVE + lane];
-            ubA[b * nc + i] = ubs[i * WAVE + lane];
-        }
-    }
-    __syncthreads();
-    }
-}
-
-// ---- host side -----------------------------------------------------------------------
-struct QpVariant {
-    int N, NC, exact;       // exact: 1 = sizes are the skill's own (no guards), 0 = guarded, 2 = guarded + work area in global memory
-    hipError_t (*solve)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
-                        const double*, const double*, double*, double*, double*, int32_t*, hipStream_t);
-    hipError_t (*data)(const DevSkill*, const WarmArgs&, const TickArgs&, long long, int, const double*,
-                       const double*, const double*, double*, double*, double*, double*, hipStream_t);
-};
-
-template <int N, int NC, bool EXACT>
-static hipError_t qp_solve_launch(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
-                                  const double* q, const double* x, const double* y, double* dq, double* dx,
-                                  double* slack, int32_t* status, hipStream_t stream)
-{
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t shmem = (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)qp_solve_kernel<N, NC, EXACT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((qp_solve_kernel<N, NC, EXACT>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y, dq,
-                       dx, slack, status);
-    return hipGetLastError();
-}
-
-template <int N, int NC>
-static hipError_t qp_data_launch(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
-                                 const double* q, const double* x, const double* y, double* Hd, double* A,
-                                 double* lb, double* ub, hipStream_t stream)
-{
-    const unsigned grid = (unsigned)((B + WAVE - 1) / WAVE);
-    const size_t shmem = (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double);
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)qp_data_kernel<N, NC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((qp_data_kernel<N, NC>), dim3(grid), dim3(WAVE), shmem, stream, dS, wa, tk, B, q, x, y, Hd, A,
-                       lb, ub);
-    return hipGetLastError();
-}
-
-// Work area in global memory for the variants no CU's LDS holds.  One area per RESIDENT block (the kernels walk the batch
-// with a block stride), kept per (device, stream) and grown on demand: a tick costs no allocation, the footprint does
-// not scale with the batch (round 4 allocated grid x area on every tick: 1 GB at 131072 instances, 8 GB at 1 M), and a
-// tick can be captured into a hipGraph once the stream's area exists (the first tick of a stream must run outside a
-// capture - hipMalloc cannot be captured; the error says so).  Ticks of one stream are ordered, so they may share
-// the area; ticks on different streams get different areas.
-namespace {
-struct GwsArea { double* ptr; size_t bytes; };
-std::mutex g_gws_mutex;
-std::map<std::pair<int, hipStream_t>, GwsArea> g_gws;
-
-hipError_t gws_area(hipStream_t stream, size_t bytes, double** out)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lock(g_gws_mutex);
-    GwsArea& a = g_gws[std::make_pair(dev, stream)];
-    if (a.bytes < bytes) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            return hipErrorStreamCaptureUnsupported;    // (run one tick of this skill on the stream before capturing)
-        // (ticks already enqueued on the stream may still use the old area: they finish first)
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return e;
-        if (a.ptr) (void)hipFree(a.ptr);
-        a.ptr = nullptr;
-        a.bytes = 0;
-        e = hipMalloc((void**)&a.ptr, bytes);
-        if (e != hipSuccess) return e;
-        a.bytes = bytes;
-    }
-    *out = a.ptr;
-    return hipSuccess;
-}
-
-// blocks of `kernel` the current device holds at once (64 threads, no LDS); cached per device and kernel
-hipError_t resident_blocks(const void* kernel, unsigned* out)
-{
-    static std::mutex m;
-    static std::map<std::pair<int, const void*>, unsigned> cache;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lock(m);
-    auto it = cache.find(std::make_pair(dev, kernel));
-    if (it != cache.end()) { *out = it->second; return hipSuccess; }
-    int cus = 0, per_cu = 0;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0);
-    if (e != hipSuccess) return e;
-    const unsigned n = (unsigned)(cus > 0 ? cus : 1) * (unsigned)(per_cu > 0 ? per_cu : 1);
-    cache[std::make_pair(dev, kernel)] = n;
-    *out = n;
-    return hipSuccess;
-}
-}  // namespace
-
-template <int N, int NC>
-static hipError_t qp_solve_launch_gws(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
-                                      const double* q, const double* x, const double* y, double* dq, double* dx,
-                                      double* slack, int32_t* status, hipStream_t stream)
-{
-    if (B <= 0) return hipSuccess;
-    unsigned resident = 0;
-    hipError_t e = resident_blocks((const void*)qp_solve_kernel<N, NC, false, true>, &resident);
-    if (e != hipSuccess) return e;
-    const unsigned long long nblk = (unsigned long long)((B + WAVE - 1) / WAVE);
-    const unsigned grid = (unsigned)(nblk < resident ? nblk : resident);
-    double* ws = nullptr;
-    // (the area is sized for the resident blocks whatever this batch needs: it never grows again for this kernel)
-    e = gws_area(stream, (size_t)resident * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double), &ws);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((qp_solve_kernel<N, NC, false, true>), dim3(grid), dim3(WAVE), 0, stream, dS, wa, tk, B, q, x, y, dq,
-                       dx, slack, status, ws, ny);
-    return hipGetLastError();
-}
-
-template <int N, int NC>
-static hipError_t qp_data_launch_gws(const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
-                                     const double* q, const double* x, const double* y, double* Hd, double* A,
-                                     double* lb, double* ub, hipStream_t stream)
-{
-    if (B <= 0) return hipSuccess;
-    unsigned resident = 0;
-    hipError_t e = resident_blocks((const void*)qp_data_kernel<N, NC, true>, &resident);
-    if (e != hipSuccess) return e;
-    const unsigned long long nblk = (unsigned long long)((B + WAVE - 1) / WAVE);
-    const unsigned grid = (unsigned)(nblk < resident ? nblk : resident);
-    double* ws = nullptr;
-    e = gws_area(stream, (size_t)resident * (size_t)qp_lds_slots<N, NC>(ny) * WAVE * sizeof(double), &ws);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((qp_data_kernel<N, NC, true>), dim3(grid), dim3(WAVE), 0, stream, dS, wa, tk, B, q, x, y, Hd, A, lb,
-                       ub, ws, ny);
-    return hipGetLastError();
-}
-
-// exact-size instantiations (no guards in the active-set loop) for the common
-// problem sizes, guarded ones for everything else up to 16 rows
-#define CLIK_QP_EXACT(N, NC) {N, NC, 1, &qp_solve_launch<N, NC, true>, &qp_data_launch<N, NC>}
-#define CLIK_QP_GUARD(N, NC) {N, NC, 0, &qp_solve_launch<N, NC, false>, &qp_data_launch<N, NC>}
-#define CLIK_QP_GLOBAL(N, NC) {N, NC, 2, &qp_solve_launch_gws<N, NC>, &qp_data_launch_gws<N, NC>}
+#define CLIK_QP_EXACT(N, NC) {N, NC, 1, &qp_solve_launch<N, NC, true>, &qp_data_launch<N, NC>},
+#define CLIK_QP_GUARD(N, NC) {N, NC, 0, &qp_solve_launch<N, NC, false>, &qp_data_launch<N, NC>},
+#define CLIK_QP_GLOBAL(N, NC) {N, NC, 2, &qp_solve_launch_gws<N, NC>, &qp_data_launch_gws<N, NC>},
 static const QpVariant kQpVariants[] = {
-    CLIK_QP_EXACT(7, 13), CLIK_QP_EXACT(6, 12), CLIK_QP_EXACT(7, 10), CLIK_QP_EXACT(6, 9),
-    CLIK_QP_GUARD(6, 8),  CLIK_QP_GUARD(6, 16), CLIK_QP_GUARD(7, 8),  CLIK_QP_GUARD(7, 16),
-    CLIK_QP_GUARD(8, 8),  CLIK_QP_GUARD(8, 16),
-    // beyond 16 rows (up to CLIK_MAX_QPROWS) and / or more than eight states or rows per constraint
-    CLIK_QP_GLOBAL(8, 32), CLIK_QP_GLOBAL(12, 16), CLIK_QP_GLOBAL(12, 32),
-    // two 7-DoF arms in one skill (CLIK_MAX_DOF = 14)
-    CLIK_QP_GLOBAL(14, 32),
+    CLIK_QP_VARIANTS_A(CLIK_QP_EXACT, CLIK_QP_GUARD, CLIK_QP_GLOBAL)
+    CLIK_QP_VARIANTS_B(CLIK_QP_EXACT, CLIK_QP_GUARD, CLIK_QP_GLOBAL)
+    CLIK_QP_VARIANTS_C(CLIK_QP_EXACT, CLIK_QP_GUARD, CLIK_QP_GLOBAL)
+    CLIK_QP_VARIANTS_D(CLIK_QP_EXACT, CLIK_QP_GUARD, CLIK_QP_GLOBAL)
 };
 constexpr int kNumQpVariants = (int)(sizeof(kQpVariants) / sizeof(kQpVariants[0]));
 
@@ -507,73 +53,19 @@ size_t qp_variant_lds(int k, int ny)
 
 hipError_t qp_launch_solve(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                            const double* q, const double* x, const double* y, double* dq, double* dx,
-                           double* slack, int32_t* status, hipStream_t stream)
+                           double* slack, int32_t* status, hipStream_t stream, GwsOwner* owner)
 {
     if (k < 0 || k >= kNumQpVariants) return hipErrorInvalidValue;
-    return kQpVariants[k].solve(dS, wa, tk, B, ny, q, x, y, dq, dx, slack, status, stream);
+    return kQpVariants[k].solve(dS, wa, tk, B, ny, q, x, y, dq, dx, slack, status, stream, owner);
 }
 
 hipError_t qp_launch_data(int k, const DevSkill* dS, const WarmArgs& wa, const TickArgs& tk, long long B, int ny,
                           const double* q, const double* x, const double* y, double* Hd, double* A, double* lb,
-                          double* ub, hipStream_t stream)
+                          double* ub, hipStream_t stream, GwsOwner* owner)
 {
     if (k < 0 || k >= kNumQpVariants) return hipErrorInvalidValue;
-    return kQpVariants[k].data(dS, wa, tk, B, ny, q, x, y, Hd, A, lb, ub, stream);
+    return kQpVariants[k].data(dS, wa, tk, B, ny, q, x, y, Hd, A, lb, ub, stream, owner);
 }
-
-// ---- shape-specialised QP kernels (clik_qp_static.hpp): AOT table -------------------------
-struct QpStaticEntry {
-    const char* name;
-    const ShapeDesc* sd;
-    qp_static_fn solve;
-    qp_static_rollout_fn rollout;
-};
-#define CLIK_QP_STATIC_ENTRY(S) {"qp_static_" #S, &shapes::S, &launch_qp_static<shapes::S>, &launch_qp_rollout_static<shapes::S>},
-static const QpStaticEntry kQpShapes[] = {
-#ifdef CLIK_GENERATED_QP_SHAPES
-    CLIK_GENERATED_QP_SHAPES(CLIK_QP_STATIC_ENTRY)
-#endif
-    {nullptr, nullptr, nullptr, nullptr}
-};
-constexpr int kNumQpShapes = (int)(sizeof(kQpShapes) / sizeof(kQpShapes[0])) - 1;
-
-int qp_pick_static(const ShapeDesc& sd)
-{
-    for (int k = 0; k < kNumQpShapes; ++k)
-        if (shape_equal(*kQpShapes[k].sd, sd)) return k;
-    return -1;
-}
-const char* qp_static_name(int k) { return (k >= 0 && k < kNumQpShapes) ? kQpShapes[k].name : "none"; }
-bool qp_box_family_rt(const ShapeDesc& sd) { return CLIK_QP_BOX_OK(sd); }
-// rows the shape-specialised kernels hand to their active set: soft equalities folded, hard bounds on the same state merged
-int qp_plan_rows_rt(const ShapeDesc& sd) { return make_qp_plan(sd).nr; }
-// 64-double LDS slots a shape-specialised QP kernel keeps behind the skill image (QpLayout<SD>::SLOTS on the run-time
-// copy of the shape): the primal families (bound-constrained, mixed) keep no dual Hessian there
-int qp_layout_slots_rt(const ShapeDesc& sd)
-{
-    const QpPlanS p = make_qp_plan(sd);
-    const bool primal = CLIK_QP_BOX_OK(sd) || CLIK_QP_MIXED_OK(sd);
-    const int n = sd.n, ny = sd.n_y > 0 ? sd.n_y : 0, nra = p.nr > 0 ? p.nr : 1, nsa = p.ns > 0 ? p.ns : 1;
-    const int nt = nra * (nra + 1) / 2;
-    return n + ny + (primal ? 0 : nt) + 2 * nra + (primal ? 0 : nra) + (primal ? 0 : nra * n) + nsa;
-}
-hipError_t qp_launch_static(int k, const void* d_img, const TickArgs& tk, long long B, const double* q,
-                            const double* x, const double* y, double* dq, double* dx, double* slack,
-                            int32_t* status, int32_t* hot_set, int use_hot, hipStream_t stream,
-                            const double* t_inst)
-{
-    if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
-    return kQpShapes[k].solve(d_img, tk, B, q, x, y, dq, dx, slack, status, hot_set, use_hot, stream, t_inst);
-}
-
-hipError_t qp_launch_rollout_static(int k, const void* d_img, const double* d_tterms, int n_ticks, double dt,
-                                    double max_speed, long long B, double* q, const double* y, double* dq,
-                                    double* slack, int32_t* status, double* x, double* dx, hipStream_t stream,
-                                    int stages)
-{
-    if (k < 0 || k >= kNumQpShapes) return hipErrorInvalidValue;
-    return kQpShapes[k].rollout(d_img, d_tterms, n_ticks, dt, max_speed, B, q, y, dq, slack, status, x, dx, stream,
-                                stages);
-}
+bool qp_variant_uses_workspace(int k) { return k >= 0 && k < kNumQpVariants && kQpVariants[k].exact == 2; }
 
 }  // namespace clik

@@ -1,0 +1,6 @@
+// Dynamic-shape ReactiveQPController kernels, group A of the variants (clik_qp_dyn.hpp): explicit instantiations.
+#include "clik_qp_dyn.hpp"
+
+namespace clik {
+CLIK_QP_VARIANTS_A(CLIK_QP_DEF_EXACT, CLIK_QP_DEF_GUARD, CLIK_QP_DEF_GLOBAL)
+}  // namespace clik

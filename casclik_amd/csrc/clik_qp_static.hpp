@@ -540,7 +540,7 @@ constexpr bool qp_box_family(const ShapeDesc& sd)
 }
 // Solvers measured for this family on config 4 (16384 instances, cold / hot start per tick, same box):
 //   dual active-set iteration over rows (gi_solve, what every other QP shape runs)      38.7 / 10.4 us
-//   projected Newton, qp_box_solve (-DCLIK_QP_BOX_PN)                                   38.5 / 25.8 us
+//   projected Newton (round 2, tools/experiments/qp_retired.patch)                      38.5 / 25.8 us
 //   block principal pivoting (first attempt, history)                                   93   /  7.4 us
 //   primal active set from the vertex the linear term points to, qp_box_pas (default)   see DESIGN.md section 5
 // The tick is the slowest instance of the batch (every wave has a SIMD to itself), i.e. its pass count times the
@@ -750,211 +750,6 @@ __device__ __forceinline__ double qp_row_s(const Img<SD>* __restrict__ S, const 
     return jac<SD, TI>(S, tc, i, j);
 }
 
-// Projected Newton (Bertsekas 1982) for  min f(x) = 1/2 x'P x - g'x,  lb_c <= x_c <= ub_c  (P symmetric positive
-// definite, packed lower triangle; unbounded states carry -/+ infinity).  x stays feasible.  One pass:
-//   binding set  I = { c : x_c at a bound and the gradient pushes it outward }   (those stay where they are)
-//   Newton direction on the rest: a fixed-size LDL' of P with the rows / columns of I replaced by the identity
-//     (one instruction stream for all lanes, only the masks differ),
-//   x <- clip(x - d) when that decreases f enough (88 % of the passes), else the direction is re-solved without
-//     the states it would push through their bounds and the exact minimiser along its feasible segment is taken
-//     (a 1-D quadratic: no backtracking loop),
-//   the gradient follows by  grad += P (x_new - x)  - the same product gives the decrease of f for the test.
-// A pass that moves nothing is a fixed point = the KKT point (checked against a freshly computed gradient).
-// The method is monotone (no cycling) and identifies the active set in a few passes: on the config-4 bench
-// inputs (5-7 of the 7 speed limits active at the optimum) 2.8 passes per instance on average, 6 at the 99th
-// percentile, 10 worst of 32768 (block principal pivoting: 4.2 / 17 / 30; the dual active-set iteration it
-// replaces for this family: 4 iterations on average, 11-13 worst, at twice the instructions per iteration).
-// Start: the vertex the linear term points to (x_c = ub_c where g_c > 0, lb_c where g_c < 0) - with most bounds
-// active at the optimum that is closer than the unconstrained minimiser and needs no factorisation - or, hot,
-// the partition of the previous tick (hot = atL | atU << 16).
-// Returns 0 (KKT point), 1 (pass cap), 2 (lb > ub: infeasible).
-template <int N>
-__device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
-                                            const double (&lb)[N], const double (&ub)[N], const int max_pass,
-                                            const bool valid, double (&x)[N], int32_t* hot, const bool use_hot)
-{
-    constexpr int NT = N * (N + 1) / 2;
-    bool empty = false;
-#pragma unroll
-    for (int a = 0; a < N; ++a) empty = empty || (lb[a] - ub[a] > 1e-9 * fmax(1.0, fmax(fabs(lb[a]), fabs(ub[a]))));
-    uint32_t hl = 0u, hu = 0u;
-    if (use_hot && hot != nullptr) {
-        const uint32_t h = (uint32_t)*hot;
-        hl = h & 0xffffu;
-        hu = (h >> 16) & ~hl;
-    }
-#pragma unroll
-    for (int a = 0; a < N; ++a) {
-        const double mid = fmin(fmax(0.0, lb[a]), ub[a]);
-        const bool has_l = lb[a] > -1e300, has_u = ub[a] < 1e300;
-        double x0;
-        if (use_hot) x0 = ((hl >> a) & 1u) && has_l ? lb[a] : ((((hu >> a) & 1u) && has_u) ? ub[a] : mid);
-        else x0 = (g[a] > 0.0) ? (has_u ? ub[a] : mid) : ((g[a] < 0.0 && has_l) ? lb[a] : mid);
-        x[a] = empty ? 0.0 : x0;
-    }
-    double gr[N];
-#pragma unroll
-    for (int a = 0; a < N; ++a) {
-        double sacc = -g[a];
-#pragma unroll
-        for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
-        gr[a] = sacc;
-    }
-    bool done = !valid || empty;
-    int status = empty ? 2 : 1;
-    // Newton direction of the face { x_c fixed for c in fix }:  d = P_FF^-1 grad_F, 0 on the fixed states.  The
-    // fixed rows / columns leave the system through a 1e30 penalty on the diagonal (their direction comes out
-    // ~1e-30 and the clip keeps them exactly on the bound; the factor of the free block is the factor of P_FF to
-    // rounding): 2 instructions per state instead of 3 selects per matrix entry, one instruction stream for all lanes
-    auto face_newton = [&](const bool (&fix)[N], double (&dir)[N]) __attribute__((always_inline)) {
-        double M[NT], rd[N];
-#pragma unroll
-        for (int a = 0; a < NT; ++a) M[a] = Pm[a];
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            dir[a] = fix[a] ? 0.0 : gr[a];
-            M[tri(a, a)] += fix[a] ? 1e30 : 0.0;
-        }
-        ldl_factor_s<N>(M, rd);
-        ldl_solve_s<N>(M, rd, dir);
-#pragma unroll
-        for (int a = 0; a < N; ++a) dir[a] = fix[a] ? 0.0 : dir[a];      // (exactly zero: the hit test below divides by it)
-    };
-    // (bitwise & | on the flags below: the short-circuit forms compile to a divergent branch per state)
-#pragma unroll 1
-    for (int pass = 0; pass < max_pass; ++pass) {
-        if (__ballot(!done) == 0ull) break;
-        // binding set: states on a bound that the gradient pushes outward
-        double d[N];
-        bool at_l[N], at_u[N], bind[N];
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            at_l[a] = x[a] <= lb[a];
-            at_u[a] = x[a] >= ub[a];
-            bind[a] = (at_l[a] & (gr[a] > 0.0)) | (at_u[a] & (gr[a] < 0.0));
-        }
-        face_newton(bind, d);
-        // full Newton step, clipped to the box (moves whole blocks of states onto their bounds at once):
-        // dl = x_new - x, pd = P dl; accepted when it decreases f enough (Armijo on the clipped step)
-        double dl[N], pd[N];
-        double lin = 0.0, quad = 0.0;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            const double xn = fmin(fmax(x[a] - d[a], lb[a]), ub[a]);
-            dl[a] = xn - x[a];
-            lin = fma(gr[a], dl[a], lin);
-        }
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], dl[b], sacc);
-            pd[a] = sacc;
-            quad = fma(dl[a], sacc, quad);
-        }
-        const bool full_ok = done | (fma(0.5, quad, lin) <= 1e-4 * lin);
-        if (__ballot(!full_ok) != 0ull) {
-            // (12 % of the passes) the clipped step overshoots.  States that sit on a bound with the gradient pointing
-            // inward but the Newton direction pushing them outward cannot move: they join the fixed set and the
-            // direction is re-solved on the smaller face (at most three times) - zeroing their components instead
-            // leaves a non-Newton direction that zigzags between two faces for dozens of passes.  Then the exact
-            // minimiser along the straight segment x - a dm, a <= the first bound hit: f is a 1-D quadratic there
-            // and dm a descent direction, so there is no backtracking loop.
-            bool stay[N], settled = full_ok;
-#pragma unroll
-            for (int a = 0; a < N; ++a) stay[a] = (at_l[a] & (d[a] > 0.0)) | (at_u[a] & (d[a] < 0.0));
-#pragma unroll 1
-            for (int rf = 0; rf < 3; ++rf) {
-                bool anyz = false;
-#pragma unroll
-                for (int a = 0; a < N; ++a) anyz = anyz | stay[a];
-                const bool need = !settled & anyz;
-                if (__ballot(need) == 0ull) break;
-                bool fix[N], grew = false;
-                double d2[N];
-#pragma unroll
-                for (int a = 0; a < N; ++a) fix[a] = bind[a] | stay[a];
-                face_newton(fix, d2);
-#pragma unroll
-                for (int a = 0; a < N; ++a) {
-                    const bool s2 = stay[a] | (!fix[a] & ((at_l[a] & (d2[a] > 0.0)) | (at_u[a] & (d2[a] < 0.0))));
-                    grew = grew | (s2 != stay[a]);
-                    stay[a] = need ? s2 : stay[a];
-                    d[a] = need ? d2[a] : d[a];
-                }
-                settled = settled | !grew;
-            }
-            double dm[N], pdm[N];
-            double amax = 1.0, sl = 0.0, cv = 0.0;
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-                dm[a] = stay[a] ? 0.0 : d[a];
-                const double room = (dm[a] > 0.0) ? (x[a] - lb[a]) : (x[a] - ub[a]);     // same sign as dm
-                // room / dm by a reciprocal (a hit distance needs no correctly rounded quotient)
-                const double ahit = (dm[a] != 0.0) ? room * recip(dm[a]) : 1.0;
-                amax = fmin(amax, ahit);
-                sl = fma(gr[a], dm[a], sl);
-            }
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], dm[b], sacc);
-                pdm[a] = sacc;
-                cv = fma(dm[a], sacc, cv);
-            }
-            const double astar = (cv > 0.0) ? sl * recip(cv) : 1.0;
-            const double al = full_ok ? 0.0 : fmax(0.0, fmin(amax, astar));
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-                dl[a] = full_ok ? dl[a] : -al * dm[a];
-                pd[a] = full_ok ? pd[a] : -al * pdm[a];
-            }
-        }
-        double mv = 0.0, mx = 0.0;
-        bool kkt = true;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            mv = fmax(mv, fabs(dl[a]));
-            mx = fmax(mx, fabs(x[a]));
-            const double xn = fmin(fmax(x[a] + dl[a], lb[a]), ub[a]);
-            const double gn = gr[a] + pd[a];
-            x[a] = done ? x[a] : xn;
-            gr[a] = done ? gr[a] : gn;
-            const double tol = 1e-9 * fmax(1.0, fabs(g[a]));
-            kkt = kkt & (((x[a] <= lb[a]) & (gr[a] >= -tol)) | ((x[a] >= ub[a]) & (gr[a] <= tol)) | (fabs(gr[a]) <= tol));
-        }
-        // a pass that moves nothing AND satisfies the KKT conditions (on the running gradient; re-checked below
-        // on a fresh one) ends the iteration; a tiny move alone does not: a step can be cut short by a bound
-        // that is 1e-13 away, and the next pass goes on from there
-        done = done | ((mv <= 1e-10 * (1.0 + mx)) & kkt);
-    }
-    if (!empty) {
-        // the KKT conditions of the returned point on a freshly computed gradient
-        bool kkt = true;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            double sacc = -g[a];
-#pragma unroll
-            for (int b = 0; b < N; ++b) sacc = fma(Pm[a >= b ? tri(a, b) : tri(b, a)], x[b], sacc);
-            const double tol = 1e-9 * fmax(1.0, fabs(g[a]));
-            const bool fine = ((x[a] <= lb[a]) & (sacc >= -tol)) | ((x[a] >= ub[a]) & (sacc <= tol)) | (fabs(sacc) <= tol);
-            kkt = kkt & fine;
-        }
-        status = kkt ? 0 : 1;
-    }
-    if (hot != nullptr && valid) {
-        uint32_t atL = 0u, atU = 0u;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            if (x[a] <= lb[a]) atL |= 1u << a;
-            else if (x[a] >= ub[a]) atU |= 1u << a;
-        }
-        *hot = (int32_t)(atL | (atU << 16));
-    }
-    return status;
-}
-
 // Primal active set for  min f(x) = 1/2 x'P x - g'x,  lb_c <= x_c <= ub_c  (P symmetric positive definite, packed
 // lower triangle; unbounded states carry -/+ infinity).  x is feasible throughout, W = the states held on a bound.
 // One pass:
@@ -968,49 +763,13 @@ __device__ __forceinline__ int qp_box_solve(const double (&Pm)[N * (N + 1) / 2],
 //   the gradient is recomputed from x (the same 49 multiply-adds an update would cost, and no drift).
 // Start: see below (cold: coordinate-wise minimisers, clipped; hot: the partition of the previous tick,
 // hot = atL | atU << 16).  Returns 0 (KKT point, checked on the final gradient), 1 (pass cap), 2 (lb > ub).
-// QUAD (experiment, CLIK_QP_LANES=4; profiles/r3_qp_portfolio_study.md): the four lanes of a DPP quad work on the SAME
-// instance with one instruction stream and per-lane data - the over-relaxation factor `omega` of the start sweeps
-// differs per lane, so the lanes end the sweeps on different partitions - and the quad is done as soon as ONE lane has
-// reached the KKT point (the others stop with it).
-// Symmetric sweep of index K of the packed tableau S (lower triangle) in the lanes where m = 1.0 (m = 0.0 leaves a
-// lane's tableau untouched): with F the set of swept indices,  S_FF = -(P_FF)^-1,  S_HF = P_HF (P_FF)^-1,  S_HH = the
-// Schur complement of P_FF.  sgn = +1 sweeps K in (the state becomes free), -1 sweeps it out again (it is held): one
-// reciprocal and a rank-one update per working-set change instead of a masked refactorisation per pass - VERDICT r3
-// item 3(a).  AN EXPERIMENT, off by default (-DCLIK_QP_BOX_SWEEP=1): a lane-uniform instruction stream has to run the
-// sweep of state k for the whole wave whenever ANY lane changes state k, so a pass executes 1-3 masked sweeps (45
-// instructions each) next to the 56-instruction product with the tableau, the seven start sweeps (315) come on top, and
-// the passes are not the shorter for it: measured 13.5 against 11.3 us per tick at 16384 instances, 29.4 against 24.4
-// at 131072 (profiles/r4_qp_sweep.txt; numpy model of the same iteration: tools/qp_sweep_proto.py).
-#ifndef CLIK_QP_BOX_SWEEP
-#define CLIK_QP_BOX_SWEEP 0
-#endif
-template <int N, int K>
-__device__ __forceinline__ void qp_sym_sweep(double (&S)[N * (N + 1) / 2], const double m, const double sgn)
-{
-    const double d = fma(m, S[tri(K, K)] - 1.0, 1.0);          // (1.0 in the lanes that sit this one out)
-    const double p = recip(d);
-    const double pm = m * p;
-    double t[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = (i == K) ? 0.0 : S[i >= K ? tri(i, K) : tri(K, i)] * pm;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j)
-            if (i != K && j != K) S[tri(i, j)] = fma(-t[i], S[j >= K ? tri(j, K) : tri(K, j)], S[tri(i, j)]);
-    const double cf = m * fma(sgn, p, -1.0);                   // column: S_iK <- sgn S_iK / d   (m = 0: unchanged)
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        if (i != K) {
-            double& e = S[i >= K ? tri(i, K) : tri(K, i)];
-            e = fma(e, cf, e);
-        }
-    S[tri(K, K)] = fma(m, -p - S[tri(K, K)], S[tri(K, K)]);
-}
+// (Measured and retired, tools/experiments/qp_retired.patch: the four lanes of a quad on one instance with different
+// relaxation factors - QUAD, profiles/r3_qp_portfolio_study.md - and the swept tableau with one rank-one update per
+// working-set change instead of a masked refactorisation per pass - profiles/r4_qp_sweep.txt.)
 
 // FOLIO (round 4, small batches, cold start): FOUR WAVES of a block - one per SIMD of the CU - work on the SAME 64
 // instances, each with its own START of the active-set passes (number, order and relaxation of the Gauss-Seidel sweeps:
-// different instruction streams cost nothing across waves, unlike across the lanes of QUAD), and an instance is done as
+// different instruction streams cost nothing across waves, unlike across the lanes of a wave), and an instance is done as
 // soon as ANY of them has reached its KKT point.  The tick of a 16384-instance batch is its slowest instance: with the
 // four starts of qp_solve_static_box_folio_values_kernel the slowest instance of a batch of bench inputs needs 4.2 - 5.1 us
 // of sweeps + passes instead of 6.25 - 7.2 (numpy model of the iteration, tools/qp_wave_portfolio_study.py; measured:
@@ -1044,13 +803,14 @@ __device__ __forceinline__ void qp_box_start_sweep(const double (&Pm)[N * (N + 1
     }
 }
 
-template <int N, bool QUAD = false, bool FOLIO = false>
+template <int N, bool FOLIO = false>
 __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], const double (&g)[N],
                                           const double (&lb)[N], const double (&ub)[N], const int max_pass,
                                           const bool valid, double (&x)[N], int32_t* hot, const bool use_hot,
-                                          const double omega = 1.0, const QpFolio* fo = nullptr, int* my_key = nullptr)
+                                          const QpFolio* fo = nullptr, int* my_key = nullptr)
 {
     constexpr int NT = N * (N + 1) / 2;
+    CLIK_PHASE("box_setup");
     constexpr int kOne = 0x3ff00000;        // high word of 1.0: the masks below are doubles 1.0 / 0.0 kept as that word
     auto as_mask = [](const int hi) __attribute__((always_inline)) { return __hiloint2double(hi, 0); };
     bool empty = false;
@@ -1079,6 +839,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
 #ifndef CLIK_QP_BOX_SWEEPS
 #define CLIK_QP_BOX_SWEEPS 12
 #endif
+    CLIK_PHASE("box_cold_sweeps");
     if (!use_hot) {
         double ip[N], res[N];
 #pragma unroll
@@ -1113,8 +874,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         for (int sweep = 0; sweep < CLIK_QP_BOX_SWEEPS; ++sweep) {
 #pragma unroll
             for (int a = 0; a < N; ++a) {
-                const double step = QUAD ? omega * (res[a] * ip[a]) : res[a] * ip[a];
-                const double xa = fmin(fmax(QUAD ? x[a] + step : fma(res[a], ip[a], x[a]), lb[a]), ub[a]);
+                const double xa = fmin(fmax(fma(res[a], ip[a], x[a]), lb[a]), ub[a]);
                 const double dl = xa - x[a];
                 x[a] = xa;
 #pragma unroll
@@ -1123,6 +883,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         }
         }
     }
+    CLIK_PHASE("box_partition_gradient");
 #pragma unroll
     for (int a = 0; a < N; ++a) {
         const double mid = fmin(fmax(0.0, lb[a]), ub[a]);
@@ -1147,7 +908,6 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         }
     };
     gradient();
-    bool quad_over = false;      // (QUAD: some lane of this lane's quad has finished)
     bool done = !valid | empty;
     int status = empty ? 2 : 1;
     bool gave_up = false;        // (FOLIO: another strategy has this lane's instance)
@@ -1159,19 +919,9 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         }
         seen = *(volatile int*)fo->key_slot;
     }
-#if CLIK_QP_BOX_SWEEP
-    // the swept tableau of the starting partition: one sweep per state that is free in SOME lane of the wave
-    double S[NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a) S[a] = Pm[a];
-    static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        const bool fr = (held[k] == 0) & !done;
-        if (__ballot(fr) != 0ull) qp_sym_sweep<N, k>(S, fr ? 1.0 : 0.0, 1.0);
-    });
-#endif
     // (masks applied arithmetically and selections by min / max: a select of a double costs two instructions and
     // a flag test two more, and a lone wave pays every one of them in full)
+    CLIK_PHASE("box_pass");
 #pragma unroll 1
     for (int pass = 0; pass < max_pass; ++pass) {
         if constexpr (FOLIO) {
@@ -1183,25 +933,10 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             gave_up = gave_up | beaten;
             done = done | beaten;
         }
-        if (__ballot(!(done | quad_over)) == 0ull) break;
+        if (__ballot(!done) == 0ull) break;
         const bool done_before = done;
         // Newton direction on the free states
         double d[N];
-#if CLIK_QP_BOX_SWEEP
-        {
-            // d_F = (P_FF)^-1 gr_F = -S_FF gr_F: a masked symmetric matrix-vector product on the tableau
-            double gm[N];
-#pragma unroll
-            for (int a = 0; a < N; ++a) gm[a] = fma(-as_mask(held[a]), gr[a], gr[a]);
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int b = 0; b < N; ++b) sacc = fma(-S[a >= b ? tri(a, b) : tri(b, a)], gm[b], sacc);
-                d[a] = sacc;
-            }
-        }
-#else
         double M[NT], rd[N];
 #pragma unroll
         for (int a = 0; a < NT; ++a) M[a] = Pm[a];
@@ -1222,11 +957,10 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             const bool beaten = !done & (seen_mid < kfin);
             gave_up = gave_up | beaten;
             done = done | beaten;
-            if (__ballot(!(done | quad_over)) == 0ull) break;
+            if (__ballot(!done) == 0ull) break;
         } else {
             (void)seen_mid;
         }
-#endif
         // first bound hit along x - alpha d: alpha = min(1, room_a / d_a).  The quotient needs no correct rounding (a
         // blocked step ends on no face minimum, and the states that land are snapped onto their bounds): hardware
         // reciprocal.  0 * inf = NaN for a held state on its bound, which min ignores.
@@ -1240,27 +974,15 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             amin = fmin(amin, r[a]);
         }
         const bool blocked = amin < 1.0;
-        const double alpha = (done | quad_over) ? 0.0 : amin;
+        const double alpha = done ? 0.0 : amin;
         const double thr = amin * (1.0 + 1e-7);
-#if CLIK_QP_BOX_SWEEP
-        bool lands_a[N];
-#endif
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             const double xn = fma(-alpha, d[a], x[a]);
-            const bool lands = blocked & !(done | quad_over) & (r[a] <= thr);            // the blocking state (and ties): held there
+            const bool lands = blocked & !done & (r[a] <= thr);            // the blocking state (and ties): held there
             x[a] = lands ? tgt[a] : xn;
             held[a] = lands ? kOne : held[a];
-#if CLIK_QP_BOX_SWEEP
-            lands_a[a] = lands;
-#endif
         }
-#if CLIK_QP_BOX_SWEEP
-        static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            if (__ballot(lands_a[k]) != 0ull) qp_sym_sweep<N, k>(S, lands_a[k] ? 1.0 : 0.0, -1.0);
-        });
-#endif
         gradient();
         // at a face minimum: release the held state whose multiplier is wrong by the largest amount, or stop
         double c[N];
@@ -1271,19 +993,10 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             c[a] = fma(push, as_mask(held[a] & free_ok[a]), -tol[a]);
             worst = fmax(worst, c[a]);
         }
-        const bool release = !blocked & !(done | quad_over) & (worst > 0.0);
-#if CLIK_QP_BOX_SWEEP
-        static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            const bool rel = release & (c[k] == worst) & (held[k] != 0);
-            held[k] = rel ? 0 : held[k];
-            if (__ballot(rel) != 0ull) qp_sym_sweep<N, k>(S, rel ? 1.0 : 0.0, 1.0);
-        });
-#else
+        const bool release = !blocked & !done & (worst > 0.0);
 #pragma unroll
         for (int a = 0; a < N; ++a) held[a] = (release & (c[a] == worst)) ? 0 : held[a];
-#endif
-        done = done | (!quad_over & !blocked & !(worst > 0.0));
+        done = done | (!blocked & !(worst > 0.0));
         if constexpr (FOLIO) {
             if (done & !done_before) {
                 mine = ((fo->sweeps + kFolioPassUnits * (pass + 1)) << 2) | fo->sid;
@@ -1292,13 +1005,6 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
             seen = *(volatile int*)fo->key_slot;
         } else {
             (void)done_before;
-        }
-        if constexpr (QUAD) {
-            // a lane that has finished ends its whole quad (mov_dpp quad_perm broadcasts of the flag)
-            const int dn = (done & valid & !empty) ? 1 : 0;
-            const int any = __builtin_amdgcn_mov_dpp(dn, 0x00, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(dn, 0x55, 0xf, 0xf, true) |
-                            __builtin_amdgcn_mov_dpp(dn, 0xAA, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(dn, 0xFF, 0xf, 0xf, true);
-            quad_over = quad_over | (any != 0);
         }
     }
     if constexpr (FOLIO) {
@@ -1312,24 +1018,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         (void)seen;
         (void)mine;
     }
-#if CLIK_QP_BOX_SWEEP
-    if (!empty) {
-        // one more Newton step on the final face: the rank-one updates of the tableau accumulate rounding over the
-        // passes, a Newton step from a point at the minimiser to 1e-12 lands on it to rounding (the held states do not move)
-        double gm[N];
-#pragma unroll
-        for (int a = 0; a < N; ++a) gm[a] = fma(-as_mask(held[a]), gr[a], gr[a]);
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int b = 0; b < N; ++b) sacc = fma(S[a >= b ? tri(a, b) : tri(b, a)], gm[b], sacc);       // = -d_a
-            const double xn = x[a] + fma(-as_mask(held[a]), sacc, sacc);
-            x[a] = done ? fmin(fmax(xn, lb[a]), ub[a]) : x[a];
-        }
-        gradient();
-    }
-#endif
+    CLIK_PHASE("box_kkt_hotword");
     if (!empty) {
         // the KKT conditions of the returned point (gr is the gradient at x)
         bool kkt = true;
@@ -1350,6 +1039,7 @@ __device__ __forceinline__ int qp_box_pas(const double (&Pm)[N * (N + 1) / 2], c
         }
         *hot = (int32_t)(atL | (atU << 16));
     }
+    CLIK_PHASE_END();
     return status;
 }
 
@@ -1759,14 +1449,14 @@ __device__ __forceinline__ int qp_mixed_pas(const double (&Pm)[NZ * (NZ + 1) / 2
 // slots: the block's LDS work area (QpLayout<SD>), reused from tick to tick.
 // HAVE_SC: the sines / cosines of the state variables come from the caller (sns / css: evaluated two per lane of a
 // quad, or two per wave of a FOLIO block, and exchanged), otherwise this lane evaluates all of them
-template <const ShapeDesc& SD, int SSTR = WAVE, bool QUAD = false, bool FOLIO = false, bool HAVE_SC = false>
+template <const ShapeDesc& SD, int SSTR = WAVE, bool FOLIO = false, bool HAVE_SC = false>
 __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, const QpTail* __restrict__ T,
                                               const TickArgs& tk, const double (&z)[SD.n], const double* ysl,
                                               const int lane, const bool valid, double* slots,
                                               double (&v)[SD.n], double (&sl)[QpLayout<SD>::NSA],
-                                              int32_t* hot, const bool use_hot, const double omega = 1.0,
-                                              double* jstash = nullptr, const QpFolio* fo = nullptr, int* my_key = nullptr,
-                                              const double* sns = nullptr, const double* css = nullptr)
+                                              int32_t* hot, const bool use_hot, const QpFolio* fo = nullptr,
+                                              int* my_key = nullptr, const double* sns = nullptr,
+                                              const double* css = nullptr)
 {
     using LY = QpLayout<SD>;
     constexpr int N = SD.n;
@@ -1774,6 +1464,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
     constexpr QpPlanS P = LY::P;
     constexpr int NTN = N * (N + 1) / 2;
     // FK and the state-dependent rows, once
+    CLIK_PHASE("qp_fk_rows");
     TaskCache<SD> tc;
     {
         Kin<N> K;
@@ -1795,6 +1486,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
     }
 
     // P = H_v + sum_soft-eq J' diag(h_s) J,  g = sum J' diag(h_s) b;  bounds of the other rows -> LDS
+    CLIK_PHASE("qp_gather_P_g");
     double L[NTN], rd[N];
 #pragma unroll
     for (int a = 0; a < N; ++a) {
@@ -1909,6 +1601,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
         return status;
     } else if constexpr (LY::BOX) {
         // bounds by state (rows of the plan are unit rows on distinct states), then the primal active set
+        CLIK_PHASE("qp_bounds");
         double lbc[N], ubc[N], gv[N];
 #pragma unroll
         for (int a = 0; a < N; ++a) {
@@ -1922,28 +1615,9 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
             lbc[col] = slots[(LY::O_LB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
             ubc[col] = slots[(LY::O_UB + r) * SSTR + (SSTR == 1 ? 0 : lane)];
         });
-        // (large-batch build: the cached Jacobian rows - needed again only for the slacks - wait in LDS while the solver
-        // runs, so that the solver's working set fits two waves per SIMD; lane-major, one 8-byte column per entry)
-        if (jstash != nullptr) {
-#pragma unroll
-            for (int i = 0; i < TaskCache<SD>::ROWS; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) jstash[(i * N + j) * WAVE + lane] = tc.J[i][j];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#ifdef CLIK_QP_BOX_PN
-        int status = qp_box_solve<N>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot);
-#else
-        int status = qp_box_pas<N, QUAD, FOLIO>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot, omega, fo, my_key);
-#endif
+        int status = qp_box_pas<N, FOLIO>(L, gv, lbc, ubc, T->max_iter, valid, v, hot, use_hot, fo, my_key);
+        CLIK_PHASE("qp_slack");
         if (!valid) status = 0;
-        if (jstash != nullptr) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TaskCache<SD>::ROWS; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) tc.J[i][j] = jstash[(i * N + j) * WAVE + lane];
-        }
         // slack of the folded rows: s = J v - b
 #pragma unroll
         for (int k = 0; k < LY::NSA; ++k) sl[k] = (NS > 0) ? slots[(LY::O_SL + k) * SSTR + (SSTR == 1 ? 0 : lane)] : 0.0;
@@ -1967,6 +1641,7 @@ __device__ __forceinline__ int qp_tick_static(const Img<SD>* __restrict__ S, con
         });
         return status;
     } else {
+    CLIK_PHASE("qp_general_dual");
     ldl_factor_s<N>(L, rd);
     ldl_solve_s<N>(L, rd, v);          // v0 = P^-1 g
 
@@ -2165,17 +1840,17 @@ __device__ __forceinline__ void qp_solve_static_body(
                             : tk_uniform;
     const int status = qp_tick_static<SD>(S, T, tk, z, ysl, lane, valid, slots, v, sl,
                                           hot_set != nullptr ? hot_set + (b0 + lane) : nullptr, use_hot != 0);
-    const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+    const unsigned bad = (status == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
     // outputs through LDS (row-major rows, coalesced stores)
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] += bad;
+    for (int j = 0; j < N; ++j) v[j] = nan_or(v[j], bad);
     state_to_lds<NQ, NX>(v, zs, xs, lane);
     if constexpr (NS > 0) {
         double* so = slots + LY::O_SL * WAVE;
         if (slack_out != nullptr) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) so[lane * NS + k] = sl[k] + bad;
+            for (int k = 0; k < NS; ++k) so[lane * NS + k] = nan_or(sl[k], bad);
         }
     }
     __syncthreads();
@@ -2219,19 +1894,19 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_values_kernel(
 
 // ... for the box family without any LDS: its solver keeps everything in registers, the few work-area slots the row
 // gathering fills become a private array, every lane loads its own rows and stores its own results
-template <const ShapeDesc& SD, class IMGV, bool STASH = false>
+template <const ShapeDesc& SD, class IMGV>
 __device__ __forceinline__ void qp_box_values_body(
     const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
     const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
     const TickArgs& tk)
 {
-    __shared__ double jstash_lds[STASH ? TaskCache<SD>::ROWS * SD.n * WAVE : 1];
     using LY = QpLayout<SD>;
     static_assert(LY::BOX, "box family only");
     constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
     constexpr QpImg<SD> kValues = IMGV::value;
     CLIK_BODY_BEGIN();
+    CLIK_PHASE("rows_in");
     const int lane = threadIdx.x;
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
@@ -2250,22 +1925,22 @@ __device__ __forceinline__ void qp_box_values_body(
     double priv[LY::SLOTS];
     double v[N], sl[LY::NSA];
     const int status = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                             hot_set != nullptr ? hot_set + row : nullptr, use_hot != 0, 1.0,
-                                             STASH ? jstash_lds : nullptr);
+                                             hot_set != nullptr ? hot_set + row : nullptr, use_hot != 0);
+    CLIK_PHASE("store");
     if (valid) {
-        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+        const unsigned bad = (status == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
+        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = nan_or(v[j], bad);
         if constexpr (NX > 0) {
             if (dx != nullptr) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
+                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = nan_or(v[NQ + j], bad);
             }
         }
         if constexpr (NS > 0) {
             if (slack_out != nullptr) {
 #pragma unroll
-                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = nan_or(sl[k], bad);
             }
         }
         if (status_out != nullptr) status_out[inst] = status;
@@ -2283,357 +1958,24 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
     qp_box_values_body<SD, IMGV>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
 }
 
-// The same body held to TWO waves per SIMD (at most 256 registers, accumulation registers included): an EXPERIMENT,
-// off by default (CLIK_QP_OCC2_MIN_BATCH=<batch> turns it on from that batch size).  The default build takes 256 VGPRs +
-// 70 AGPRs = one wave per SIMD, so 131072 instances (2048 waves on 1024 SIMDs) run as two rounds of lone waves; held to
-// 256 registers the compiler spills 288 B per lane to scratch memory and the two resident waves wait on those round
-// trips instead: measured 30.3 against 25.0 us at 131072 instances, 17.4 against 14.2 at 65536, 16.7 against 12.8 at
-// 32768 (profiles/r4_qp_occ2.txt).
-#ifndef CLIK_QP_OCC2_MIN_BATCH
-#define CLIK_QP_OCC2_MIN_BATCH (1ll << 60)
-#endif
-template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void qp_solve_static_box_values_occ2_kernel(
-    const double* __restrict__ q, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
-    const TickArgs tk)
-{
-    qp_box_values_body<SD, IMGV, true>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
-}
-
-// ... with four lanes per instance (experiment, CLIK_QP_LANES=4, batches up to 16384 instances: 1024 waves instead of
-// 256): every lane of a quad runs the whole tick of the same instance with its own over-relaxation factor in the
-// start sweeps; the first lane at the KKT point ends the quad and stores.  Measured against the one-lane kernel in
-// DESIGN.md section 5 / profiles/r3_qp_portfolio_study.md.
-template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(4 * WAVE) void qp_solve_static_box_quad_values_kernel(
-    const double* __restrict__ q, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
-    const TickArgs tk)
-{
-    using LY = QpLayout<SD>;
-    static_assert(LY::BOX, "box family only");
-    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
-    constexpr QpImg<SD> kValues = IMGV::value;
-    const int tid = threadIdx.x;
-    const int r = tid & 3;
-    const long long inst = (long long)blockIdx.x * WAVE + (tid >> 2);
-    const bool valid = inst < B;
-    const long long row = valid ? inst : B - 1;
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
-    if constexpr (NX > 0) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
-    }
-    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
-    double priv[LY::SLOTS];
-    double v[N], sl[LY::NSA];
-    int32_t hot_word = (hot_set != nullptr) ? hot_set[row] : 0;
-    const double omega = (r == 0) ? 1.0 : ((r == 1) ? 1.3 : ((r == 2) ? 1.5 : 1.7));
-    // (round 5: `hot_set != nullptr ? &hot_word : nullptr` had put the working set into scratch memory - 16 bytes of
-    // private segment, a memory round trip per access; round 3's measurements of this experiment carry that cost)
-    const int status = qp_tick_static<SD, 1, true>(&kValues.img, &kValues.tail, tk, z, ysl, tid & (WAVE - 1), valid, priv, v,
-                                                   sl, &hot_word, use_hot != 0 && hot_set != nullptr, omega);
-    // the lowest lane of the quad that reached the KKT point stores (lane 0 when none did: its status is reported)
-    const int okl = (status == 0) ? 1 : 0;
-    const int o0 = __builtin_amdgcn_mov_dpp(okl, 0x00, 0xf, 0xf, true), o1 = __builtin_amdgcn_mov_dpp(okl, 0x55, 0xf, 0xf, true);
-    const int o2 = __builtin_amdgcn_mov_dpp(okl, 0xAA, 0xf, 0xf, true);
-    const int winner = o0 ? 0 : (o1 ? 1 : (o2 ? 2 : (__builtin_amdgcn_mov_dpp(okl, 0xFF, 0xf, 0xf, true) ? 3 : 0)));
-    if (valid && r == winner) {
-        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
-        if constexpr (NX > 0) {
-            if (dx != nullptr) {
-#pragma unroll
-                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
-            }
-        }
-        if constexpr (NS > 0) {
-            if (slack_out != nullptr) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
-            }
-        }
-        if (status_out != nullptr) status_out[inst] = status;
-        if (hot_set != nullptr) hot_set[inst] = hot_word;
-    }
-}
-
-// ... an EXPERIMENT, off by default (see qp_values_choice): ticks of small batches with four lanes per instance that split nothing but the sines / cosines of
-// the state variables (lane r evaluates variables 2r and 2r + 1, DPP exchange: the same split as
-// pinv_solve_static_values_quad_kernel - a wave has one instruction stream, the passes cannot be split): 1024 waves
-// at 16384 instances, one per SIMD, each 265 instructions shorter than the lone-wave kernel's 1814.  All four lanes hold
-// the same answer; lane 0 stores.  ("front4"; CLIK_QP_FRONT4=<waves per CU> turns it on.)
+// (Measured and retired, tools/experiments/qp_retired.patch: the same body held to two waves per SIMD - it spilled 288 B
+// per lane, 30.3 against 25.0 us at 131072 instances, profiles/r4_qp_occ2.txt -; four lanes per instance running the whole
+// tick with different relaxation factors - "quad4", profiles/r3_qp_portfolio_study.md -; and launched ticks with four
+// lanes per instance that share the sin / cos evaluations - "front4": cold ticks +1.5 - 2 %, hot ticks 0.25 - 0.7 us SLOWER
+// although each wave issues 266 instructions fewer, profiles/r5_quad_ab.txt.  The RESIDENT kernel below keeps that
+// four-lane front end: there nobody pays for launching four times the waves.)
 template <const ShapeDesc& SD>
 constexpr bool qp_front4_ok() { return QpLayout<SD>::BOX && SD.uses_fk != 0 && SD.n >= 3 && SD.n <= 8; }
-template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(WAVE) void qp_solve_static_box_front4_values_kernel(
-    const double* __restrict__ q, const double* __restrict__ y,
-    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
-    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const int use_hot,
-    const TickArgs tk)
-{
-    using LY = QpLayout<SD>;
-    static_assert(LY::BOX, "box family only");
-    constexpr int N = SD.n, NX = SD.n_x, NQ = N - NX, NS = LY::NS;
-    constexpr QpImg<SD> kValues = IMGV::value;
-    CLIK_BODY_BEGIN();
-    const int tid = threadIdx.x;
-    const int r = tid & 3;
-    const long long inst = (long long)blockIdx.x * (WAVE / 4) + (tid >> 2);      // (one wave = 16 instances per block)
-    const bool valid = inst < B;
-    const long long row = valid ? inst : B - 1;
-    auto state = [&](const int j) __attribute__((always_inline)) {
-        return (j < NQ) ? q[row * NQ + j] : x[row * NX + (j - NQ)];
-    };
-    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-    const double a0 = state(j0), a1 = state(j1);
-    double z[N];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
-    if constexpr (NX > 0) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
-    }
-    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
-    double sn0, cs0, sn1, cs1;
-    sincos_fast(a0, sn0, cs0);
-    sincos_fast(a1, sn1, cs1);
-    const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
-    if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
-        if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
-        if (fabs(a1) > kSinCosFastMax) { const SinCos sc = sincos_slow(a1); sn1 = sc.s; cs1 = sc.c; }
-    }
-    double sns[N], css[N];
-    static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
-        constexpr int j = decltype(jc)::value;
-        if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
-            constexpr int CTRL = (j / 2) * 0x55;
-            sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
-            css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
-        } else {
-            sns[j] = css[j] = 0.0;
-        }
-    });
-    double priv[LY::SLOTS];
-    double v[N], sl[LY::NSA];
-    // (the working set in a register: a conditional pointer to it would put it into scratch memory - a memory round trip
-    // per access, measured as 0.25 - 0.7 us per hot tick)
-    int32_t hot_word = (hot_set != nullptr) ? hot_set[row] : 0;
-    const int status = qp_tick_static<SD, 1, false, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, tid & (WAVE - 1),
-                                                                 valid, priv, v, sl, &hot_word,
-                                                                 use_hot != 0 && hot_set != nullptr, 1.0, nullptr, nullptr,
-                                                                 nullptr, sns, css);
-    if (valid && r == 0) {
-        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
-        if constexpr (NX > 0) {
-            if (dx != nullptr) {
-#pragma unroll
-                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
-            }
-        }
-        if constexpr (NS > 0) {
-            if (slack_out != nullptr) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
-            }
-        }
-        if (status_out != nullptr) status_out[inst] = status;
-        if (hot_set != nullptr) hot_set[inst] = hot_word;
-    }
-    CLIK_BODY_END();
-}
 
-// ... RESIDENT ticks of the bound-constrained family (round 5): ONE launch that solves tick k's QP whenever ticket k is
-// published (the protocol, the watchdog and the ring of input / output slots of pinv_resident_team_kernel,
-// clik_pinv_team.hpp; reference: the per-tick body of ReactiveQPController.solve, reactive_qp.py:461-528, called from a
-// loop that feeds it fresh targets).  Four lanes per instance as in the front4 kernel above - in a resident kernel nobody
-// pays for launching the waves, so the 266 instructions the quad saves on the sin / cos evaluations count in full - and
-// every instance's working set stays in a register from tick to tick: every tick after the first is hot-started, as the
-// reference's qpOASES instance is (reactive_qp.py:491-513).  Lane r of a quad requests elements 2r, 2r + 1 of its
-// instance's robot_var / input_var rows and stores the same elements of the velocity and slack rows; lane 0 the status.
-template <const ShapeDesc& SD>
-constexpr bool qp_resident_ok() { return qp_front4_ok<SD>() && SD.n_x == 0; }
-template <const ShapeDesc& SD, class IMGV>
-__global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
-    const double* q, const double* y, double* dq, double* slack_out, int32_t* status_out, const long long B,
-    const TickArgs tk, ResidentTicket* ticket, unsigned* done, const int n_ticks, const unsigned long long max_polls)
-{
-    using LY = QpLayout<SD>;
-    static_assert(LY::BOX && SD.n_x == 0, "resident QP ticks: box family, robot variables only");
-    constexpr int N = SD.n, NY = SD.n_y > 0 ? SD.n_y : 0, NS = LY::NS;
-    constexpr QpImg<SD> kValues = IMGV::value;
-    const int tid = threadIdx.x;
-    const int r = tid & 3;
-    const long long inst = (long long)blockIdx.x * (WAVE / 4) + (tid >> 2);
-    const bool valid = inst < B;
-    const long long binst = valid ? inst : (B - 1);
-    ResidentWave rw;
-    rw.init(ticket, done, max_polls, n_ticks, blockIdx.x, gridDim.x, tid);
-    bool have_next = false;
-    const long long ring = rw.ring_depth();
-    static_assert(N <= 8, "resident QP kernel: at most eight state variables");
-    constexpr int RY = NY > 0 ? (NY + 7) / 8 : 1;
-    // (a lane's share of the rows is two doubles each: the NEXT tick's shares are requested before this tick's
-    // arithmetic whenever their ticket is already out, and arrive under it)
-    double zp[2], yp[2 * RY], zp_next[2], yp_next[2 * RY];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) zp[i] = zp_next[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i] = 0.0;
-    auto request_rows = [&](const int k, double (&zq)[2], double (&yq)[2 * RY]) __attribute__((always_inline)) {
-        const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = 2 * r + i;
-            zq[i] = __hip_atomic_load(q + row * N + (e < N ? e : N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if constexpr (NY > 0) {
-#pragma unroll
-            for (int i = 0; i < 2 * RY; ++i) {
-                const int e = 8 * (i / 2) + 2 * r + (i & 1);
-                yq[i] = __hip_atomic_load(y + row * NY + (e < NY ? e : NY - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    };
-    int32_t hot_word = 0;       // the instance's working set: in a register for the whole run
-    int owed = 0;
-#pragma unroll 1
-    for (int k = 1; k <= n_ticks; ++k) {
-        if (!have_next) {
-            rw.poll_for((unsigned)k);
-            if (rw.leave) break;
-            asm volatile("" ::: "memory");
-            request_rows(k, zp, yp);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) zp[i] = zp_next[i];
-#pragma unroll
-            for (int i = 0; i < 2 * RY; ++i) yp[i] = yp_next[i];
-        }
-        have_next = false;
-        if (k < n_ticks && rw.seen >= (unsigned)(k + 1)) {
-            request_rows(k + 1, zp_next, yp_next);
-            have_next = true;
-        }
-        double sn0, cs0, sn1, cs1;
-        sincos_fast(zp[0], sn0, cs0);
-        sincos_fast(zp[1], sn1, cs1);
-        const bool huge = (fabs(zp[0]) > kSinCosFastMax) | (fabs(zp[1]) > kSinCosFastMax);
-        if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
-            if (fabs(zp[0]) > kSinCosFastMax) { const SinCos sc = sincos_slow(zp[0]); sn0 = sc.s; cs0 = sc.c; }
-            if (fabs(zp[1]) > kSinCosFastMax) { const SinCos sc = sincos_slow(zp[1]); sn1 = sc.s; cs1 = sc.c; }
-        }
-        double z[N], sns[N], css[N], yrow[NY > 0 ? NY : 1];
-        static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            constexpr int CTRL = (j / 2) * 0x55;
-            z[j] = quad_perm_f64<CTRL>(zp[j & 1]);
-            if constexpr (shape_state_type(SD, j) == CLIK_JOINT_REVOLUTE) {
-                sns[j] = quad_perm_f64<CTRL>((j & 1) ? sn1 : sn0);
-                css[j] = quad_perm_f64<CTRL>((j & 1) ? cs1 : cs0);
-            } else {
-                sns[j] = css[j] = 0.0;
-            }
-        });
-        if constexpr (NY > 0) {
-            static_for<0, NY>([&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int CTRL = ((j % 8) / 2) * 0x55;
-                yrow[j] = quad_perm_f64<CTRL>(yp[2 * (j / 8) + (j & 1)]);
-            });
-        }
-        double priv[LY::SLOTS];
-        double v[N], sl[LY::NSA];
-        const int status = qp_tick_static<SD, 1, false, false, true>(&kValues.img, &kValues.tail, tk, z, yrow, tid & (WAVE - 1),
-                                                                     valid, priv, v, sl, &hot_word, k > 1, 1.0, nullptr, nullptr,
-                                                                     nullptr, sns, css);
-        if (owed != 0) {
-            rw.publish_done(owed);
-            owed = 0;
-        }
-        if (valid) {
-            const double bad = (status == 2) ? __builtin_nan("") : 0.0;
-            const long long orow = ((long long)((k - 1) % (int)ring)) * B + inst;
-            double s0 = v[N - 1], s1 = v[N - 1];
-            static_for<0, 4>([&](auto kc) __attribute__((always_inline)) {
-                constexpr int kk = decltype(kc)::value;
-                if constexpr (2 * kk < N) s0 = (r == kk) ? v[2 * kk] : s0;
-                if constexpr (2 * kk + 1 < N) s1 = (r == kk) ? v[2 * kk + 1] : s1;
-            });
-            if (2 * r < N) __hip_atomic_store(dq + orow * N + 2 * r, s0 + bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (2 * r + 1 < N) __hip_atomic_store(dq + orow * N + 2 * r + 1, s1 + bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if constexpr (NS > 0) {
-                if (slack_out != nullptr) {
-                    static_for<0, (NS + 7) / 8>([&](auto rc) __attribute__((always_inline)) {
-                        constexpr int rho = decltype(rc)::value;
-                        double t0 = sl[NS - 1], t1 = sl[NS - 1];
-                        static_for<0, 4>([&](auto kc) __attribute__((always_inline)) {
-                            constexpr int kk = decltype(kc)::value;
-                            constexpr int j0 = 8 * rho + 2 * kk;
-                            if constexpr (j0 < NS) t0 = (r == kk) ? sl[j0] : t0;
-                            if constexpr (j0 + 1 < NS) t1 = (r == kk) ? sl[j0 + 1] : t1;
-                        });
-                        const int e = 8 * rho + 2 * r;
-                        if (e < NS) __hip_atomic_store(slack_out + orow * NS + e, t0 + bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (e + 1 < NS) __hip_atomic_store(slack_out + orow * NS + e + 1, t1 + bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    });
-                }
-            }
-            if (status_out != nullptr && r == 0)
-                __hip_atomic_store(status_out + orow, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        // (the next ticket may be out already: then this tick's "done" is published behind the next tick's arithmetic,
-        // its stores a whole tick old; otherwise - a closed loop waits for it - at once)
-        rw.peek();
-        if (have_next) owed = k;
-        else rw.publish_done(k);
-    }
-    if (owed != 0) rw.publish_done(owed);
-}
-
-template <const ShapeDesc& SD, class IMGV>
-inline hipError_t launch_qp_resident_values(const TickArgs& tk, long long B, const double* q, const double* y, double* dq,
-                                            double* slack, int32_t* status, void* ticket, unsigned* done, int n_ticks,
-                                            unsigned long long budget, hipStream_t stream)
-{
-    if constexpr (qp_resident_ok<SD>()) {
-        const unsigned grid = (unsigned)((B + 15) / 16);
-        int dev = 0, cus = 0, per_cu = 0;
-        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_resident_box_front4_kernel<SD, IMGV>, WAVE, 0);
-        if (oe == hipSuccess) oe = hipGetDevice(&dev);
-        if (oe == hipSuccess) oe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (oe != hipSuccess) return oe;
-        // every wave resident at once, and room for the ticket feeder: this kernel takes a SIMD's whole register file
-        // (one wave per SIMD); keep one CU's worth of SIMDs free
-        const long long max_blocks = (long long)(cus - 1) * (per_cu < 4 ? per_cu : 4);
-        if ((long long)grid > max_blocks) return hipErrorNotSupported;
-        hipLaunchKernelGGL((qp_resident_box_front4_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq, slack,
-                           status, B, tk, (ResidentTicket*)ticket, done, n_ticks, budget);
-        return hipGetLastError();
-    } else {
-        return hipErrorNotSupported;
-    }
-}
+}  // namespace clik
+#include "clik_qp_resident.hpp"     // resident ticks of the bound-constrained family (qp_resident_box_front4_kernel)
+namespace clik {
 
 // ... with four WAVES per 64 instances, each with its own start of the passes (FOLIO, see qp_box_pas): cold ticks of
 // batches up to one block per CU.  Every wave runs the whole tick of its lanes' instances; what it finished it leaves in
 // LDS with the key it recorded, and after the block's barrier the first wave stores, per instance, the answer under the
 // smallest key.
-#ifndef CLIK_QP_FOLIO_DEFAULT
-#define CLIK_QP_FOLIO_DEFAULT 1
-#endif
-#ifndef CLIK_QP_FOLIO_WAVES
-#define CLIK_QP_FOLIO_WAVES 4
-#endif
-constexpr int kFolioWaves = CLIK_QP_FOLIO_WAVES;     // (1 and 2: measuring switches - the bookkeeping alone; the pair reverse x 6 | relaxed x 18)
+constexpr int kFolioWaves = 4;
 template <const ShapeDesc& SD, class IMGV>
 __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_values_kernel(
     const double* __restrict__ q, const double* __restrict__ y,
@@ -2649,10 +1991,7 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     // the block's four waves work on the SAME 64 instances: wave w evaluates the sines / cosines of state variables
     // 2w and 2w + 1 only and the block shares them through LDS (2 of N evaluations per wave: 200 instructions fewer
     // in each wave's front end)
-#ifndef CLIK_QP_FOLIO_SHARE_SC
-#define CLIK_QP_FOLIO_SHARE_SC 1
-#endif
-    constexpr bool SHARE_SC = (CLIK_QP_FOLIO_SHARE_SC != 0) && SD.uses_fk != 0 && kFolioWaves == 4 && N >= 3 && N <= 8;
+    constexpr bool SHARE_SC = SD.uses_fk != 0 && N >= 3 && N <= 8;
     __shared__ double sc_lds[SHARE_SC ? 2 * N : 1][WAVE];
     CLIK_BODY_BEGIN();
     const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
@@ -2669,7 +2008,6 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
         for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
     }
     const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
-#ifndef CLIK_QP_FOLIO_IDLE
     if constexpr (SHARE_SC) {
         const long long row_sc = row;
         const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -2685,19 +2023,7 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
             }
         }
     }
-#endif
     __syncthreads();
-#ifdef CLIK_QP_FOLIO_IDLE
-    if (w != 0) return;          // (measuring switch: the block shape alone - the other three waves leave at once)
-#endif
-#ifdef CLIK_QP_FOLIO_DELAY
-    // (test switch, tools/qp_folio_check.py --delays: wave CLIK_QP_FOLIO_DELAY starts some 25 us late - every other wave has
-    // finished by then - and the answers must not change by a bit: the smallest KEY decides, not the first to arrive)
-    if (w == (CLIK_QP_FOLIO_DELAY)) {
-#pragma unroll 1
-        for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     QpFolio fo;
     fo.key_slot = &key_min[lane];
     fo.sid = w;
@@ -2707,7 +2033,7 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     // instance on average over four batches of 16384 bench inputs (numpy model, tools/qp_wave_portfolio_study.py --sets:
     // 4.55 / 4.18 / 5.12 / 4.35 us of sweeps + passes for seeds 0 - 3 against 6.25 / 7.2 / 7.2 / 7.2 of the lone start;
     // round 4's first set - forward x 12 | forward x 6 | reverse x 6 | relaxed x 18 - had 4.55 / 4.55 / 6.45 / 5.3)
-    const int strat = (kFolioWaves == 2) ? w + 2 : w;
+    const int strat = w;
     fo.sweeps = same_start ? CLIK_QP_BOX_SWEEPS : ((strat == 0 || strat == 3) ? 3 : ((strat == 1) ? 6 : 12));
     fo.kind = same_start ? 0 : ((strat == 1) ? 1 : ((strat == 2) ? 2 : ((strat == 3) ? 3 : 0)));
     fo.omega = 1.5;
@@ -2723,28 +2049,28 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
             sns[j] = sc_lds[j][lane];
             css[j] = sc_lds[N + j][lane];
         }
-        status = qp_tick_static<SD, 1, false, true, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                                          &hot_word, false, 1.0, nullptr, &fo, &my_key, sns, css);
+        status = qp_tick_static<SD, 1, true, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
+                                                   &hot_word, false, &fo, &my_key, sns, css);
     } else {
-        status = qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                                    &hot_word, false, 1.0, nullptr, &fo, &my_key);
+        status = qp_tick_static<SD, 1, true>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
+                                             &hot_word, false, &fo, &my_key);
     }
     __syncthreads();             // (every finish of the block is on record)
     // the wave whose key is the smallest on record stores what it holds in its registers
     if (valid && my_key != 0 && key_min[lane] == my_key) {
-        const double bad = (status == 2) ? __builtin_nan("") : 0.0;
+        const unsigned bad = (status == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = v[j] + bad;
+        for (int j = 0; j < NQ; ++j) dq[inst * NQ + j] = nan_or(v[j], bad);
         if constexpr (NX > 0) {
             if (dx != nullptr) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = v[NQ + j] + bad;
+                for (int j = 0; j < NX; ++j) dx[inst * NX + j] = nan_or(v[NQ + j], bad);
             }
         }
         if constexpr (NS > 0) {
             if (slack_out != nullptr) {
 #pragma unroll
-                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = nan_or(sl[k], bad);
             }
         }
         if (status_out != nullptr) status_out[inst] = status;
@@ -2835,23 +2161,23 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_box_values_kernel(
         }
     }
     if (valid) {
-        const double bad = (worst == 2) ? __builtin_nan("") : 0.0;
+        const unsigned bad = (worst == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             q[inst * NQ + j] = z[j];
-            dq[inst * NQ + j] = v[j] + bad;
+            dq[inst * NQ + j] = nan_or(v[j], bad);
         }
         if constexpr (NX > 0) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 x[inst * NX + j] = z[NQ + j];
-                dx[inst * NX + j] = v[NQ + j] + bad;
+                dx[inst * NX + j] = nan_or(v[NQ + j], bad);
             }
         }
         if constexpr (NS > 0) {
             if (slack_out != nullptr) {
 #pragma unroll
-                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = sl[k] + bad;
+                for (int k = 0; k < NS; ++k) slack_out[inst * NS + k] = nan_or(sl[k], bad);
             }
         }
         if (status_out != nullptr) status_out[inst] = worst;
@@ -2881,7 +2207,7 @@ inline hipError_t launch_qp_rollout_static_values(const double* d_tterms, int n_
 
 // which value-specialised QP kernel serves a batch (ONE predicate: the launcher below and the label
 // clik_jit_qp_value_variant hands to the controllers / bench.py both call it)
-enum QpValueKernel { QPV_GENERAL = 0, QPV_LONE, QPV_FOLIO, QPV_QUAD, QPV_OCC2, QPV_FRONT4 };
+enum QpValueKernel { QPV_GENERAL = 0, QPV_LONE, QPV_FOLIO };
 inline int current_device_cus()
 {
     // (per CURRENT device: a process may drive several, or a partition of one)
@@ -2910,25 +2236,9 @@ inline QpValueKernel qp_values_choice(long long B, int use_hot)
         // (profiles/r4_qp_wave_portfolio.txt)
         static const int folio = []() {
             const char* e = getenv("CLIK_QP_FOLIO");
-            return e ? ((e[0] == '1') ? 2 : 0) : ((CLIK_QP_FOLIO_DEFAULT != 0) ? 1 : 0);
+            return e ? ((e[0] == '1') ? 2 : 0) : 1;
         }();
         if (folio != 0 && !use_hot && grid <= (long long)current_device_cus()) return QPV_FOLIO;
-        static const bool quad = []() { const char* e = getenv("CLIK_QP_LANES"); return e && e[0] == '4'; }();
-        if (quad && B <= 16384) return QPV_QUAD;
-        if constexpr (qp_front4_ok<SD>()) {
-            // MEASURED, NOT THE DEFAULT (profiles/r5_quad_ab.txt): cold ticks gain 1.5 - 2 % over the lone wave (FOLIO gains
-            // more), hot-started ticks LOSE 0.25 - 0.7 us at every batch size although each wave issues 266
-            // instructions fewer.  CLIK_QP_FRONT4=<n> (read at every launch: a measuring switch) turns it on for
-            // batches of up to n waves per CU.
-            const char* e = getenv("CLIK_QP_FRONT4");
-            const int front4 = e ? atoi(e) : 0;
-            if (front4 > 0 && 4 * grid <= (long long)front4 * (long long)current_device_cus()) return QPV_FRONT4;
-        }
-        static const long long occ2_from = []() {
-            const char* e = getenv("CLIK_QP_OCC2_MIN_BATCH");
-            return e ? atoll(e) : (long long)CLIK_QP_OCC2_MIN_BATCH;
-        }();
-        if (B >= occ2_from) return QPV_OCC2;
         return QPV_LONE;
     }
 }
@@ -2937,9 +2247,6 @@ inline const char* qp_values_variant(long long B, int use_hot)
 {
     switch (qp_values_choice<SD>(B, use_hot)) {
     case QPV_FOLIO: return "/folio4";
-    case QPV_QUAD: return "/quad4";
-    case QPV_FRONT4: return "/front4";
-    case QPV_OCC2: return "/occ2";
     default: return "";
     }
 }
@@ -2956,22 +2263,6 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
         case QPV_FOLIO:
             hipLaunchKernelGGL((qp_solve_static_box_folio_values_kernel<SD, IMGV>), dim3(grid), dim3(kFolioWaves * WAVE), 0,
                                stream, q, y, dq, slack, status, B, x, dx, hot_set, tk, folio_same);
-            return hipGetLastError();
-        case QPV_QUAD:
-            hipLaunchKernelGGL((qp_solve_static_box_quad_values_kernel<SD, IMGV>), dim3(grid), dim3(4 * WAVE), 0, stream, q,
-                               y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
-            return hipGetLastError();
-        case QPV_FRONT4:
-            if constexpr (qp_front4_ok<SD>()) {
-                // (one wave = 16 instances per block: the dispatcher spreads the blocks over the CUs)
-                hipLaunchKernelGGL((qp_solve_static_box_front4_values_kernel<SD, IMGV>), dim3((unsigned)((B + 15) / 16)),
-                                   dim3(WAVE), 0, stream, q, y, dq, slack, status, B, x, dx, hot_set, use_hot, tk);
-                return hipGetLastError();
-            }
-            break;
-        case QPV_OCC2:
-            hipLaunchKernelGGL((qp_solve_static_box_values_occ2_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y,
-                               dq, slack, status, B, x, dx, hot_set, use_hot, tk);
             return hipGetLastError();
         default:
             break;
@@ -3114,7 +2405,7 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
             }
         }
     }
-    const double bad = (worst == 2) ? __builtin_nan("") : 0.0;
+    const unsigned bad = (worst == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
     __syncthreads();
     state_to_lds<NQ, NX>(z, zs, xs, lane);
     __syncthreads();
@@ -3124,14 +2415,14 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_kernel(
     {
         double vb[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) vb[j] = v[j] + bad;
+        for (int j = 0; j < N; ++j) vb[j] = nan_or(v[j], bad);
         state_to_lds<NQ, NX>(vb, zs, xs, lane);
     }
     if constexpr (NS > 0) {
         double* so = slots + LY::O_SL * WAVE;
         if (slack_out != nullptr) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) so[lane * NS + k] = sl[k] + bad;
+            for (int k = 0; k < NS; ++k) so[lane * NS + k] = nan_or(sl[k], bad);
         }
     }
     __syncthreads();

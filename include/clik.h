@@ -363,6 +363,11 @@ int clik_qp_create_host(const clik_skill_desc* desc, const clik_qp_opts* opts,
 int clik_qp_destroy(clik_qp* h);
 int clik_qp_n_vars(const clik_qp* h);   /* n_state + n_slack                     */
 int clik_qp_n_rows(const clik_qp* h);
+/* device memory the handle holds as work area of the kernels that keep theirs in global memory (QPs beyond 16 rows or
+ * eight states on the built-in kernels; 0 for every other skill): sized for the 64-instance blocks the largest batch
+ * so far needed, at most the device's resident blocks; grown by retiring the smaller area (captured graphs stay
+ * valid); released by clik_qp_destroy.  See INTEGRATION.md. */
+int64_t clik_qp_workspace_bytes(const clik_qp* h);
 /* kernel serving the skill: an AOT shape name, "jit_<hash>" or "dynamic"       */
 const char* clik_qp_kernel_name(const clik_qp* h);
 /* as clik_shape_describe / clik_pinv_attach_kernel, for the QP controller: the

@@ -164,7 +164,11 @@ def test_value_specialised_kernels_of_the_config3_skill_have_no_scratch(tmp_path
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     res = parse_resource_remarks(out.stdout.decode())
     kernels = {k: v for k, v in res.items() if "_static_" in k}
-    assert len(kernels) == 5, sorted(kernels)      # team solve / rollout, lane solve, lane rollout (Euler, Runge-Kutta)
+    # team solve, team rollout (Euler, Runge-Kutta: its own instantiation each since round 6), lane solve, lane rollout
+    # (Euler, Runge-Kutta)
+    assert len(kernels) == 6, sorted(kernels)
+    euler = [r for k, r in kernels.items() if "pinv_rollout_static_team_kernel" in k and "ELi1EE" in k]
+    assert len(euler) == 1 and euler[0].get("AGPRs", 0) <= 8, euler      # (the Euler rollout carries no Runge-Kutta staging)
     for name, r in kernels.items():
         assert r["ScratchSize"] == 0, (name, r)
         if "pinv_solve_static_values_kernel" in name:

@@ -222,11 +222,16 @@ def test_value_specialised_lane_kernel_of_single_mode_skills(iiwa_fk, skill):
     Q, Y = skills.synthetic_inputs(iiwa_fk, 4133, seed=3, distribution="mixed")
     Y = Y[:, :spec.n_input_var]
     dq, _, mode = ctrl.solve_batch(0.0, Q, input_var=Y)
+    from tolerances import pinv_close
     ref, rmode = clik_oracle.pinv_solve_batch(spec, None, 0.0, Q[::7], Y=Y[::7])
     assert np.array_equal(mode[::7], rmode)
-    assert (np.abs(dq[::7] - ref).max(axis=1) / (1.0 + np.abs(ref).max(axis=1))).max() < 1e-7
+    assert pinv_close(dq[::7], ref)                 # (every instance held to ITS bound, 8 u kappa)
     dq2, _, mode2 = plain.solve_batch(0.0, Q, input_var=Y)
-    assert np.array_equal(mode, mode2) and np.allclose(dq, dq2, rtol=1e-9, atol=1e-11)
+    # (two instantiations of the same source: equal to rounding - "mixed" batches of this size hold instances within 1e-4
+    # of a singularity, where either kernel's rounding is amplified by up to 1e7: the rule's ceiling for all, 1e-13 for
+    # the typical instance)
+    assert np.array_equal(mode, mode2) and pinv_close(dq, dq2), np.abs(dq - dq2).max()
+    assert np.median(np.abs(dq - dq2).max(axis=1)) < 1e-13
 
 
 @pytest.mark.parametrize("skill", ["pose", "position"])

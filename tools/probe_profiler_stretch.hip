@@ -1,0 +1,66 @@
+// Calibration of what rocprofv3 --kernel-trace adds to a us-sized kernel's "duration" (VERDICT r5 item 5).
+//   hipcc --offload-arch=gfx950 -O3 tools/probe_profiler_stretch.hip -o tools/_build/probe_profiler_stretch
+//   tools/_build/probe_profiler_stretch                                  -> wall per launch (HIP events), un-profiled
+//   rocprofv3 --kernel-trace --stats -d DIR -- tools/_build/probe_profiler_stretch   -> the profiler's average durations
+// Two kernels in the ticks' own launch shape (a hipGraph of 1024 dependent launches, 256 blocks x 256 threads = 1024
+// waves, one per SIMD): `k_empty` (no body) and `k_spin<N>` whose EVERY wave holds its SIMD for N x 10 ns of the 100 MHz
+// s_memrealtime clock - a body of known length, 2.00 us and 4.00 us, independent of the core clock.  Reconciliation:
+//   wall per launch (un-profiled)  =  body + dependent-launch boundary
+//   profiler's average duration    =  body + what the profiler adds (its timestamps bracket the dispatch packet's
+//                                     processing, not the waves)
+// so  duration(k_spin) - body  and  duration(k_empty)  are the profiler's stretch for a kernel of this shape; the
+// `*_kernel_stats.csv` averages under profiles/ minus that stretch are comparable with `kernel_body_us` of the bench line.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void k_empty(double*) {}
+
+template <int TICKS>
+__global__ __launch_bounds__(256) void k_spin(double* out)
+{
+    unsigned long long t0, t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    do {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    } while (t - t0 < (unsigned long long)TICKS);
+    if (out != nullptr && t == 1ull) out[0] = 1.0;     // (never: keeps the loop)
+}
+
+typedef void (*kern_t)(double*);
+
+int main()
+{
+    const int grid = 256, K = 1024;
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+    struct Case { const char* name; kern_t fn; double body_us; };
+    Case cases[] = {{"k_empty", k_empty, 0.0}, {"k_spin<200> (2.00 us body)", k_spin<200>, 2.0},
+                    {"k_spin<400> (4.00 us body)", k_spin<400>, 4.0}};
+    for (auto& c : cases) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < K; ++i) hipLaunchKernelGGL(c.fn, dim3(grid), dim3(256), 0, s, (double*)nullptr);
+        CHECK(hipStreamEndCapture(s, &g));
+        CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int r = 0; r < 20; ++r) CHECK(hipGraphLaunch(ge, s));       // clock ramp
+        CHECK(hipStreamSynchronize(s));
+        hipEvent_t a, b;
+        CHECK(hipEventCreate(&a));
+        CHECK(hipEventCreate(&b));
+        CHECK(hipEventRecord(a, s));
+        const int R = 20;
+        for (int r = 0; r < R; ++r) CHECK(hipGraphLaunch(ge, s));
+        CHECK(hipEventRecord(b, s));
+        CHECK(hipStreamSynchronize(s));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        const double wall = ms * 1e3 / ((double)R * K);
+        printf("%-28s body %.2f us   wall per launch %.3f us   -> boundary %.3f us\n", c.name, c.body_us, wall, wall - c.body_us);
+        CHECK(hipGraphExecDestroy(ge));
+        CHECK(hipGraphDestroy(g));
+    }
+    return 0;
+}

@@ -6,7 +6,7 @@ G back-to-back ticks is replayed and the stamps of its LAST launch are read back
 Next to it: the per-tick wall time of the same graph (HIP events), i.e. body + launch boundary, and the un-stamped
 kernel's tick time for the stamps' own overhead.
 
-    python tools/stamp_body.py [samples=1000] > gpurun_out/.../body.log     (writes profiles/r3_body_time.json/.csv)
+    python tools/stamp_body.py [samples=1000] > gpurun_out/.../body.log     (writes gpurun_out/r6body/r6_body_time.json/.csv; copied to profiles/)
 """
 import ctypes as C
 import json
@@ -48,7 +48,7 @@ def tick_time_us(tick, n=1024, reps=20):
     return e0.elapsed_time(e1) * 1e3 / (n * reps)
 
 
-def measure(name, workload, B, lanes, key_kernel):
+def measure(name, workload, B, lanes, key_kernel, hot=False):
     import importlib
     os.environ["CLIK_JIT_DEFINES"] = ""
     os.environ.pop("CLIK_LANES", None)
@@ -72,14 +72,15 @@ def measure(name, workload, B, lanes, key_kernel):
     Q, Y = skills.synthetic_inputs(fk, B, seed=0, distribution="mixed")
     Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
     plain = make()
-    kernel = plain.kernel_variant(B)
+    kernel = plain.kernel_variant(B, hot=True) if hot else plain.kernel_variant(B)
     if kernel != key_kernel:
         print("(%s: the library serves this configuration with %s, not %s)" % (name, kernel, key_kernel))
-    t_plain = tick_time_us(plain.bind_batch(Qd, input_var=Yd))
+    bind_kw = dict(hot_start=True) if hot else {}
+    t_plain = tick_time_us(plain.bind_batch(Qd, input_var=Yd, **bind_kw))
     os.environ["CLIK_JIT_DEFINES"] = "-DCLIK_BODY_STAMPS=2" if LIGHT else "-DCLIK_BODY_STAMPS"
     ctrl = make()
     lib = (jit.attach_qp_values if workload == "qp" else jit.attach_values).last_library
-    tick = ctrl.bind_batch(Qd, input_var=Yd)
+    tick = ctrl.bind_batch(Qd, input_var=Yd, **bind_kw)
     t_stamped = tick_time_us(tick)
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
@@ -93,7 +94,7 @@ def measure(name, workload, B, lanes, key_kernel):
     for _ in range(50):
         g.replay()
     torch.cuda.synchronize()
-    waves = min(32768, (B * (4 if "team4" in kernel else 1) + 63) // 64)
+    waves = min(32768, (B * (4 if ("team4" in kernel or "quadv" in kernel or "folio4" in kernel) else 1) + 63) // 64)
     buf = (C.c_ulonglong * (2 * waves))()
     lib.clik_jit_read_body.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     body, spread_start, per_wave = [], [], []
@@ -126,23 +127,26 @@ def measure(name, workload, B, lanes, key_kernel):
                      "max(end) - min(start) over the waves of the last launch of a %d-tick graph; tick_us = HIP events "
                      "around graph replays / ticks; boundary = tick (stamped build) - body" % G
                      + ("; LIGHT stamps: block 0 stamps the start, every eighth block and the last the end" if LIGHT else "")}
-    OUT["%s_mixed_B%d_%s" % (workload, B, kernel)] = ent
+    OUT["%s_mixed_B%d_%s%s" % (workload, B, kernel, "_hot" if hot else "")] = ent
     print("%-34s body %.2f us (p10 %.2f, p90 %.2f)  wave lifetime %.2f  start spread %.2f   tick stamped %.3f / shipped "
           "%.3f us -> boundary %.2f us" % (name, ent["body_us_median"], ent["body_us_p10"], ent["body_us_p90"],
                                            ent["wave_lifetime_us_median"], ent["first_to_last_wave_start_us_median"],
                                            t_stamped, t_plain, ent["boundary_us"]))
 
 
+# round 6: every kernel the bench line reports
 measure("config 3, 16384, team4v", "stack", 16384, 0, "kStackIiwa/team4v")
-measure("config 3, 16384, lanev", "stack", 16384, 1, "kStackIiwa/lanev")
+measure("config 2, 4096, quadv", "pose", 4096, 0, "kPose6Iiwa/quadv")
+measure("config 2, 16384, quadv", "pose", 16384, 0, "kPose6Iiwa/quadv")
+measure("config 4, 16384, cold (folio4)", "qp", 16384, 0, "qp_static_kQpPoseIiwa/v/folio4")
+measure("config 4, 16384, hot-started", "qp", 16384, 0, "qp_static_kQpPoseIiwa/v", hot=True)
 measure("config 3, 131072, lanev", "stack", 131072, 0, "kStackIiwa/lanev")
-measure("config 2, 16384, lanev", "pose", 16384, 0, "kPose6Iiwa/lanev")
-measure("config 4, 16384, qp box values", "qp", 16384, 0, "qp_static_kQpPoseIiwa/v")
-TAG = "r4_body_time_light" if LIGHT else "r4_body_time"
-os.makedirs(os.path.join(ROOT, "gpurun_out", "r4body"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r4body", TAG + ".json"), "w") as f:
+measure("config 4, 131072", "qp", 131072, 0, "qp_static_kQpPoseIiwa/v")
+TAG = "r6_body_time"
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r6body"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "r6body", TAG + ".json"), "w") as f:
     json.dump(OUT, f, indent=1)
-with open(os.path.join(ROOT, "gpurun_out", "r4body", TAG + ".csv"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", "r6body", TAG + ".csv"), "w") as f:
     f.write("key,kernel,batch,waves,samples,body_us_median,body_us_p10,body_us_p90,wave_lifetime_us_median,"
             "tick_us_stamped_build,tick_us_shipped_build,boundary_us\n")
     for k, e in OUT.items():
