@@ -1807,6 +1807,10 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
             request_rows(k + 1, zp_next, yp_next);
             have_next = true;
         }
+        // ... and the ticket word again, for the NEXT tick's decision: a whole tick for it to arrive.  (Round 5 asked for
+        // it at the end of the tick and read it a few instructions later, at the top of the next: an uncached load's
+        // latency on the critical path of every tick - the 1300 wait cycles per tick of profiles/r6_counters.json.)
+        if (have_next) rw.peek();
         // this lane's own two sin / cos arguments are its share of the row
         double sn0, cs0, sn1, cs1;
         sincos_fast(zp[0], sn0, cs0);
@@ -1842,8 +1846,8 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
             rw.publish_done(owed);         // (the previous tick's stores: issued a whole tick ago, nothing to wait for)
             owed = 0;
         }
-        if (have_next && k + 1 < n_ticks)
-            rw.peek();   // (for tick k + 2)
+        // (a producer that runs exactly ONE tick ahead: the early look was too early - look again, as round 5 did)
+        if (have_next && k + 1 < n_ticks && rw.seen < (unsigned)(k + 2)) rw.peek();
         if (valid) {
             const long long orow = ((long long)((k - 1) % (int)ring)) * B + inst;
             double s0 = vout[N - 1], s1 = vout[N - 1];

@@ -1613,12 +1613,14 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
             for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
             Gm[tri(i, k)] = acc;
         }
-    // t = (alpha Gm + beta I)^-1 rhs, in place; the factor stays in A / rd
-    auto shifted = [&](const double alpha, const double beta, double (&A)[NT], double (&rd)[M]) __attribute__((always_inline)) {
+    // the factor of  Gm + beta I  (in A / rd).  Every shifted matrix of the family is this form: A1 = 2 Gm + lam I is
+    // 2 (Gm + lam/2 I) - its inverse is HALF the inverse of the bracket, exactly (a power of two) - so Gm is never scaled,
+    // only its diagonal shifted (round 6; the scaled copy was 21 multiplications per factorisation).
+    auto shifted = [&](const double beta, double (&A)[NT], double (&rd)[M]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? fma(alpha, Gm[tri(i, k)], beta) : alpha * Gm[tri(i, k)];
+            for (int k = 0; k <= i; ++k) A[tri(i, k)] = (i == k) ? Gm[tri(i, k)] + beta : Gm[tri(i, k)];
         ldl_factor_s<M>(A, rd);
     };
     auto jt_times = [&](const double (&t)[M], double (&g)[N]) __attribute__((always_inline)) {
@@ -1647,7 +1649,7 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
         double u[M];
         {
             double A[NT], rd[M], y2[M];
-            shifted(1.0, lam, A, rd);
+            shifted(lam, A, rd);
 #pragma unroll
             for (int i = 0; i < M; ++i) ysol[i] = des1[i];
             ldl_solve_s<M>(A, rd, ysol);
@@ -1659,11 +1661,11 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
         }
         {
             double A[NT], rd[M], t1[M];
-            shifted(2.0, lam, A, rd);
+            shifted(0.5 * lam, A, rd);          // (Gm + lam/2 I: the solution is twice A1's - the "2 t1" of the formula as it stands)
             j_times(w2, t1);
             ldl_solve_s<M>(A, rd, t1);
 #pragma unroll
-            for (int i = 0; i < M; ++i) u[i] = fma(-2.0, t1[i], u[i]);
+            for (int i = 0; i < M; ++i) u[i] -= t1[i];
         }
         double gu[N];
         jt_times(u, gu);
@@ -1677,35 +1679,42 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
     {
         const clik_task& t = S->tasks[0];
         double le[M0], ue[M0];
-        bool inside = true;
 #pragma unroll
         for (int i = 0; i < M0; ++i) {
             le[i] = e0[i] - t.set_min[i];
             ue[i] = e0[i] - t.set_max[i];
-            inside = inside & (le[i] >= 1e-12) & (ue[i] <= 1e-12);
         }
+        // (all(le >= 1e-12) & all(ue <= 1e-12) through the smallest le and the largest ue, "no row's half signs differ"
+        // as a sum of |hl - hu| that is exactly zero: see team_tick)
+        double le_min = le[0], ue_max = ue[0];
+#pragma unroll
+        for (int i = 1; i < M0; ++i) {
+            le_min = fmin(le_min, le[i]);
+            ue_max = fmax(ue_max, ue[i]);
+        }
+        const bool outside = (le_min < 1e-12) | (ue_max > 1e-12);
         in_tc = true;
-        if (__ballot(!inside) != 0ull) {
-            bool corner = true;
-            double od = 0.0, nde = 0.0, nout = 0.0;
+        if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {
+            double od = 0.0, nde = 0.0, nout = 0.0, ndiff = 0.0;
             static_for<0, M0>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int col = SD.ucol[0][i] - 1;
                 const double de = Jt0[i] + v0[col];
                 const double hl = half_sign(le[i]), hu = half_sign(ue[i]);     // (sign(le) + sign(ue)) / 2 = hl + hu
-                corner = corner & (hl == hu);
+                ndiff += fabs(hl - hu);
                 const double out = hl + hu;
                 od = fma(out, de, od);
                 nde = fma(de, de, nde);
                 nout = fma(out, out, nout);
             });
+            const bool corner = ndiff == 0.0;
             bool going_in = od < 0.0;
-            if (__ballot(corner & !inside) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(corner & outside) != 0ull) {
                 const double dists = (sqrt(nde) + 1e-10) * sqrt(nout);
                 const bool steep = (od < 0.0) & (fabs(od) / dists < 0.70710678118654757);
                 going_in = corner ? steep : going_in;
             }
-            in_tc = inside | going_in;
+            in_tc = !outside | going_in;
         }
     }
     acc_mode = valid ? (in_tc ? 0 : 1) : -1;
@@ -1723,7 +1732,7 @@ __device__ __forceinline__ void solo_tick(const Img<SD>* __restrict__ S, const T
 #pragma unroll
         for (int j = 0; j < N; ++j) x[j] = w2[j] * (one_lam - sact[j]);
         double A[NT], rd[M], t2[M], g2[N], g3[N];
-        shifted(1.0, one_lam, A, rd);
+        shifted(one_lam, A, rd);
         j_times(x, t2);
         ldl_solve_s<M>(A, rd, t2);
         jt_times(t2, g2);

@@ -130,10 +130,10 @@ __device__ __forceinline__ RoleConsts role_consts_loaded(const int r)
 }
 
 struct NoMidTick {
-    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void operator()(const double) const {}
 };
-// MID: called once between the Gram build and the factorisations - the resident tick kernel puts its memory
-// traffic for the NEXT tick there (pinv_resident_team_kernel), everyone else nothing
+// MID: called once behind the forward kinematics / task rows - the resident tick kernel requests the NEXT tick's rows
+// there (pinv_resident_team_kernel), everyone else nothing
 template <const ShapeDesc& SD, class MID = NoMidTick>
 __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, const TickArgs& tk,
                                           const double (&z)[SD.n], const double* ysl, const double a0, const double a1,
@@ -236,11 +236,6 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
             for (int j = 0; j < N; ++j) acc = fma(jac<SD, 1>(S, tc, i, j), jac<SD, 1>(S, tc, k, j), acc);
             Gm[tri(i, k)] = acc;
         }
-    if constexpr (!std::is_same<std::decay_t<MID>, NoMidTick>::value) {
-        __builtin_amdgcn_sched_barrier(0);
-        mid();
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
     // ---- per-lane role ------------------------------------------------------------------------
     // The lower-priority task's projected contribution, with the stack matrix G = D + c J'J of the mode
@@ -248,6 +243,13 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
     //     w2 - G^-1 C w2  =  G^-1 (D - S) w2  =  D^-1 (x - c J' A^-1 J x),   x = (D - S) w2,  A = c J J' + D
     // (Woodbury; S = 0 in mode 0).  So lane 1 solves A1 t = J w2 (then x/D = w2, c = 2), lane 2 solves
     // A2 t = J x with x = ((1+lam) - s) o w2 (c = 1), lanes 0 / 3 solve A0 y = d1.
+    if constexpr (!std::is_same<std::decay_t<MID>, NoMidTick>::value) {
+        // The hook gets the first Gram entry as an ANCHOR: what it does has to depend on it (the resident kernel ties its
+        // decision to it through an empty asm), or the compiler - free to sink pure arithmetic below the hook's branch -
+        // puts the hook wherever it likes (round 5: 140 instructions into the tick).  Gm[0] needs the task rows: the hook
+        // runs behind the forward kinematics, ~300 instructions in, ~800 before the tick's end.
+        mid(Gm[0]);
+    }
     CLIK_PHASE("role_rhs");
     // Lane 1's matrix is 2 Gm + lam I = 2 (Gm + lam/2 I): it factors Gm + lam/2 I and its solution is TWICE the one the
     // formula above names - exactly (a power of two), so "2 g1" below is its J' product as it stands.  Every lane
@@ -803,12 +805,11 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     }
     // Software pipeline over the ticks (a wave has its SIMD to itself, nothing else hides memory latency).  In the
     // order the wave issues them:
-    //   end of tick k - 1   request the ticket word again (-> `seen`), THEN store dq of tick k - 1
-    //   middle of tick k    (team_tick's hook, > 1 us later: `seen` has arrived; the stores behind it may still be
-    //                       on their way, nobody waits for them) if the producer has published tick k + 1, request
-    //                       its rows: they arrive while the factorisations of tick k run
-    //   end of tick k       publish tick k - 1's "done" slot - its stores were issued a whole tick ago -, request the
-    //                       ticket word, store dq of tick k
+    //   start of tick k     request the ticket word (read in tick k + 1, see the loop)
+    //   ~300 instructions   (team_tick's hook) if the ticket word requested in tick k - 1 says the producer has
+    //   into tick k         published tick k + 1, request its rows: they arrive while the rest of tick k runs
+    //   end of tick k       publish tick k - 1's "done" slot - its stores were issued a whole tick ago -, store dq of
+    //                       tick k
     // so a wave that is being fed ahead never waits for memory.  If the producer has NOT published the next tick (a
     // closed loop: it waits for "done"), the slot is published at once and the wave polls, as before.
     // Loads of one wave return in order and a row is requested only after a ticket value that covers it has been SEEN
@@ -932,6 +933,17 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         // (requesting the next rows HERE when the producer is two ticks ahead - a whole tick for them to arrive - was
         // measured slower, 3.43 against 3.18 us: their four registers stay live through the whole tick of a kernel
         // that has none to spare)
+        // The ticket word is requested HERE, at the top of tick k, and READ in tick k + 1 (`seen`, copied at the loop's
+        // end: a whole tick for the load to arrive).  Round 5 requested it at the END of the tick into the loop-carried
+        // variable: the copy into that variable's register at the loop's back edge made the compiler wait for the load at
+        // once - `s_waitcnt vmcnt(0)` right behind it, an uncached load's whole latency on the critical path of every
+        // tick (the 1300 - 1400 wait cycles = 0.55 us per tick of profiles/r6_counters.json).  The
+        // price: what the wave knows about the producer is one tick old - it runs fed ahead when the producer is TWO
+        // tickets ahead (rings of three or more slots), else it falls back to publishing at once and polling.
+        unsigned seen_next = seen;
+        if (CLIK_RESIDENT_PIPELINE && k < n_ticks)
+            seen_next = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned seen_mid = seen;
         double a0 = z[N - 1], a1 = z[N - 1];
         static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
             constexpr int kk = decltype(kc)::value;
@@ -940,8 +952,11 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         });
         double v[N];
         bool in_tc;
-        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, rc, v, in_tc, [&]() __attribute__((always_inline)) {
-            if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen >= (unsigned)(k + 1)) {
+        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, rc, v, in_tc, [&](const double anchor) __attribute__((always_inline)) {
+            // (an empty asm that ties the decision to the anchor: see team_tick)
+            asm volatile("" : "+v"(seen_mid) : "v"(anchor));
+            if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen_mid >= (unsigned)(k + 1)) {
+                __atomic_signal_fence(__ATOMIC_ACQUIRE);     // (the rows are requested only after the ticket value is in)
                 request_rows(k + 1);
                 have_next = true;
             }
@@ -966,8 +981,6 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             publish_done(owed);         // (the previous tick's stores: issued a whole tick ago)
             owed = 0;
         }
-        if (have_next && k + 1 < n_ticks)
-            seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (for tick k + 2)
         CLIK_PHASE("res_store");
         if (valid) {
             // (write-through stores: visible to every agent once acknowledged)
@@ -990,6 +1003,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         }
         if (have_next) owed = k;        // published at the end of the next tick
         else publish_done(k);           // nobody has asked for the next tick yet (or this was the last): at once
+        seen = seen_next;               // (requested at the top of this tick)
     }
     if (owed != 0) publish_done(owed);
     CLIK_PHASE_END();

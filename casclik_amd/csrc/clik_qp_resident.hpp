@@ -78,6 +78,9 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
             request_rows(k + 1, zp_next, yp_next);
             have_next = true;
         }
+        // (the ticket word for the next tick's decision is requested NOW - a whole tick to arrive - not at the end of the
+        // tick, a few instructions before it is read: see pinv_resident_quad_kernel)
+        if (have_next) rw.peek();
         double sn0, cs0, sn1, cs1;
         sincos_fast(zp[0], sn0, cs0);
         sincos_fast(zp[1], sn1, cs1);
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         }
         // (the next ticket may be out already: then this tick's "done" is published behind the next tick's arithmetic,
         // its stores a whole tick old; otherwise - a closed loop waits for it - at once)
-        rw.peek();
+        // (a producer that runs exactly ONE tick ahead: the early look was too early - look again, as round 5 did)
+        if (have_next && k + 1 < n_ticks && rw.seen < (unsigned)(k + 2)) rw.peek();
         if (have_next) owed = k;
         else rw.publish_done(k);
     }

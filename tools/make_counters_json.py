@@ -47,12 +47,15 @@ CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per ins
     "qp": ("qp_mixed_B16384_qp_static_kQpPoseIiwa/v", "qp_static_kQpPoseIiwa/v", 168, 16384),
     "pose_lanev": ("pose_mixed_B16384_kPose6Iiwa/lanev", "kPose6Iiwa/lanev", 172, 16384),
 }
+CASES_R6 = dict(CASES_R5)        # round 6 (tools/profile_round6_launched.sh): the same configurations on the round's kernels
 if "r3" in dst:
     CASES = CASES_R3
 if "r4" in dst:
     CASES = CASES_R4
 if "r5" in dst:
     CASES = CASES_R5
+if "r6" in dst:
+    CASES = CASES_R6
 out = {"note3": "round 3: the same passes (tools/profile_round3.sh, 310 dispatches each) incl. 131072 and 1 M instances; "
                 "valu_issue_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the share of the "
                 "kernel's duration in which a SIMD issues a VALU instruction, averaged over all SIMDs; "

@@ -5,6 +5,11 @@ multidimensional set, and the QP skills with general wall rows - at B instances,
 launch against a launch per tick.  The same controllers, through the same `rollout_batch`, retrace
 the notebook's stored figures in tests/test_gpu_figure_pins.py::test_on_device_rollouts_reproduce_the_moe_2016_figures.
     python tools/moe_rollout_bench.py [B=16384] [ticks per launch=256]
+The "rollout" column is HOST-INCLUSIVE: these skills follow a time trajectory, and `rollout_batch` evaluates its value and
+derivative for every tick of the launch on the host (Python) and copies them over before it launches - ~20 us per tick of
+host work that a loop which prepares the next launch's terms beside the running one would hide.  The DEVICE time per tick
+is the rollout kernel's duration / ticks: run this script under `rocprofv3 --kernel-trace --stats` (a 256-tick launch lasts a
+millisecond: the profiler's stretch of ~1 us does not matter) - profiles/r6_moe_rollout_kernel_stats.csv.
 """
 import os
 import sys
@@ -85,5 +90,5 @@ for case in cf.MOE_CASES:
         extra = "modes at the end %s" % np.bincount(res[2].cpu().numpy().astype(int) + 1, minlength=2)[:9]
     else:
         extra = "statuses at the end %s" % np.bincount(res[-1].cpu().numpy().astype(int), minlength=3)
-    print("%-14s kernel %-26s rollout %6.2f us per tick   launch per tick %6.2f us   %s"
+    print("%-14s kernel %-26s rollout (host-inclusive) %6.2f us per tick   launch per tick %6.2f us   %s"
           % (case, ctrl.kernel_variant(B) if hasattr(ctrl, "kernel_variant") else ctrl.kernel_name, us_roll, us_tick, extra))

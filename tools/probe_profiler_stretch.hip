@@ -1,7 +1,7 @@
 // Calibration of what rocprofv3 --kernel-trace adds to a us-sized kernel's "duration" (VERDICT r5 item 5).
-//   hipcc --offload-arch=gfx950 -O3 tools/probe_profiler_stretch.hip -o tools/_build/probe_profiler_stretch
-//   tools/_build/probe_profiler_stretch                                  -> wall per launch (HIP events), un-profiled
-//   rocprofv3 --kernel-trace --stats -d DIR -- tools/_build/probe_profiler_stretch   -> the profiler's average durations
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probe_profiler_stretch.hip -o tools/_build/libprobe_profiler_stretch.so
+//   python3 tools/profiler_stretch.py                                    -> wall per launch (HIP events), un-profiled
+//   rocprofv3 --kernel-trace --stats -d DIR -- python3 tools/profiler_stretch.py   -> the profiler's average durations
 // Two kernels in the ticks' own launch shape (a hipGraph of 1024 dependent launches, 256 blocks x 256 threads = 1024
 // waves, one per SIMD): `k_empty` (no body) and `k_spin<N>` whose EVERY wave holds its SIMD for N x 10 ns of the 100 MHz
 // s_memrealtime clock - a body of known length, 2.00 us and 4.00 us, independent of the core clock.  Reconciliation:
@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void k_spin(double* out)
 
 typedef void (*kern_t)(double*);
 
-int main()
+// (also callable from a Python process - tools/profiler_stretch.py loads this file built as a shared object: rocprofv3 on
+// this image crashes around a bare HIP executable that replays graphs, and profiles Python processes fine)
+extern "C" int probe_profiler_stretch_run()
 {
     const int grid = 256, K = 1024;
     hipStream_t s;
@@ -64,3 +66,5 @@ int main()
     }
     return 0;
 }
+
+int main() { return probe_profiler_stretch_run(); }
