@@ -93,7 +93,8 @@ def parse():
                     help="K > 1: the on-device rollout (K ticks of solve -> clamp -> Euler per launch, "
                          "SURVEY.md 8(d) 'launch-amortised'); steps must be a multiple of K")
     ap.add_argument("--qp-hot", type=int, default=0,
-                    help="qp workload: carry each instance's working set from tick to tick (hot start)")
+                    help="qp workload: carry each instance's working set from tick to tick (hot start); 1 = the target moves "
+                         "1 mm per tick, 2 = the target stands still (no working-set change: the best case)")
     ap.add_argument("--lanes", type=int, default=0,
                     help="lanes per robot instance of the pinv kernel: 0 = the library's choice, 1 = "
                          "lane-per-instance kernels only, 4 / 8 / 16 = the multi-lane kernel (CLIK_LANES)")
@@ -290,7 +291,7 @@ def profiled(workload, dist_name, batch, kernel, hot=False):
 def body_time(workload, dist_name, batch, kernel, hot=False):
     """Kernel body time (first wave start to last wave end, s_memrealtime stamps of the CLIK_STAMP build,
     tools/stamp_body.py) of this configuration if profiles/ holds one."""
-    key = "%s_%s_B%d_%s%s" % (workload, dist_name, batch, kernel, "_hot" if hot else "")
+    key = "%s_%s_B%d_%s%s" % (workload, dist_name, batch, kernel, ("_hot_settled" if hot == 2 else "_hot") if hot else "")
     for fn in BODY_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -431,6 +432,7 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
     ring = max(1, int(ring)) if (TPL == 1 and B > 1) else 1
     slots = [(Qd, Yd, dQ)]
     moving_target = bool(qp_hot) and workload == "qp"
+    settled = moving_target and int(qp_hot) == 2     # (the target stands still: the working set handed over is the optimal one)
     for s_ in range(1, ring):
         if moving_target:
             # hot-started ticks: the SAME instances in every slot (distinct memory), the target moved by a millimetre per slot
@@ -438,7 +440,8 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
             # sees: working sets that are close to, not always equal to, the next tick's (each slot keeping
             # its own set re-solved a QP whose optimal set it already held - zero pivots, a best case)
             y_s = Yd.clone()
-            y_s[:, (s_ - 1) % 3] += 1e-3 * s_
+            if not settled:
+                y_s[:, (s_ - 1) % 3] += 1e-3 * s_
             slots.append((Qd.clone(), y_s.contiguous(), torch.empty_like(dQ)))
             continue
         shift = (s_ * B) // ring
@@ -622,7 +625,8 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
                 "note": "rollout: state stays in registers between ticks; bytes move once per launch"}
     text = WORKLOAD_TEXT[workload] % B
     if workload == "qp" and qp_hot:
-        text += " (hot-started from the previous tick's working set)"
+        text += " (hot-started from the previous tick's working set; %s)" % (
+            "target standing still" if int(qp_hot) == 2 else "target moving")
     entry = {
         "value": value, "unit": "instance-steps/s", "ms_per_step": wall * 1e3 / timed_steps,
         "config": {
@@ -630,8 +634,10 @@ def measure(ctx, fk, workload, B, dist_name, seed, K, W, TPL=1, qp_hot=0, use_gr
             "batch_per_gpu": B, "inputs": "%s seed %d%s%s" % (dist_name, seed, "" if B <= DRAWN_MAX or global_batch else
                                                              " (%d drawn, tiled)" % DRAWN_MAX,
                                                              (", ring of %d buffers" % len(slots) + (
-                                                                 ": the same instances, the target moved 1 mm per slot, one working "
-                                                                 "set handed from tick to tick" if moving_target else ""))
+                                                                 ": the same instances, the target %s, one working "
+                                                                 "set handed from tick to tick" % ("standing still (best case: "
+                                                                 "no working-set change)" if settled else "moved 1 mm per slot")
+                                                                 if moving_target else ""))
                                                              if len(slots) > 1 else ""),
             "kernel": kernel,
             "launch": ("hipGraph of %d ticks (the K ticks x %d)" % (GK, GK // K) if graph is not None
@@ -680,10 +686,10 @@ def measure_resident(fk, dist_name, seed, B=16384, short=20000, ring=4, integrat
     def run(nt):
         best = None
         for _ in range(3):
-            feeder = torch.cuda.Stream(priority=-1)
             torch.cuda.synchronize()
             r = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=ring,
                                     **(dict(integrate_dt=1e-3, max_speed=2.0) if integrate else {}))
+            feeder = ctrl.resident_feed_stream()        # (one that makes progress beside the resident kernel)
             time.sleep(0.01)
             t0 = time.perf_counter()
             ctrl.resident_feed(r, nt, closed_loop=False, timeout_s=3.0, stream=feeder)
@@ -751,9 +757,9 @@ def measure_resident_qp(fk, dist_name, seed, B=16384 - 64, short=10000, ring=4):
     def run(nt):
         best = None
         for _ in range(3):
-            feeder = torch.cuda.Stream(priority=-1)
             torch.cuda.synchronize()
             r = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=ring)
+            feeder = ctrl.resident_feed_stream()        # (one that makes progress beside the resident kernel)
             time.sleep(0.01)
             t0 = time.perf_counter()
             ctrl.resident_feed(r, nt, closed_loop=False, timeout_s=3.0, stream=feeder)
@@ -983,7 +989,7 @@ def main():
         # (config 4 also at 4096 instances: cold ticks of batches below one block per CU run four waves per 64 instances,
         # each with its own start of the active-set passes - clik_qp_static.hpp, FOLIO)
         for (wl, b, hot, tpl) in (("pose", 4096, 0, 1), ("qp", 16384, 0, 1), ("pose", 16384, 0, 1), ("qp", 16384, 1, 1),
-                                  ("qp", 4096, 0, 1),
+                                  ("qp", 16384, 2, 1), ("qp", 4096, 0, 1),
                                   ("stack", 131072, 0, 1), ("qp", 131072, 0, 1), ("stack", 1048576, 0, 1),
                                   ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
             up = lambda v: -(-max(v, tpl) // tpl) * tpl              # noqa: E731  (a whole number of launches)

@@ -100,6 +100,33 @@ def current_stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def free_stream(device, tries=12, wait_s=0.25):
+    """A stream whose work makes progress WHILE a resident kernel holds its own stream's hardware queue.  The runtime
+    multiplexes streams onto a few hardware queues (round-robin by creation order, per priority): a producer stream that
+    lands on the resident kernel's queue waits until the kernel leaves - by its watchdog, seconds later.  Which queue a new
+    stream gets depends on how many streams the process created before, so asking for "another priority" is not enough
+    (seen in the GPU suite: the same test passed or stalled with the number of streams earlier tests had made).  This
+    tries candidate streams of both priorities with a one-word kernel and returns the first on which it completes within
+    ``wait_s``; RuntimeError if none does."""
+    import time
+    torch = _torch()
+    dev = device_of(device)
+    probe = torch.zeros(1, dtype=torch.int32, device=dev)
+    kept = []       # (stalled candidates stay alive until we return: a freed stream's queue slot would be handed out again)
+    for k in range(tries):
+        s = torch.cuda.Stream(device=dev, priority=-1 if k % 2 == 0 else 0)
+        with torch.cuda.stream(s):
+            probe.add_(1)
+        t0 = time.time()
+        while time.time() - t0 < wait_s:
+            if s.query():
+                return s
+            time.sleep(0.002)
+        kept.append(s)
+    raise RuntimeError("no stream makes progress beside the resident kernel (%d candidates tried): is another kernel "
+                       "occupying the device?" % tries)
+
+
 class SingleSlot(object):
     """Persistent staging for the single-instance ``solve()`` call (B = 1): one pinned host
     buffer each way that the kernel reads and writes in place (pinned host memory is mapped into

@@ -18,7 +18,7 @@ from .. import _capi
 from .. import sym as cs
 from ..lowering import lower_skill, DYN_MAX_M
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
-                              to_device_matrix, check_out_tensor, _torch)
+                              to_device_matrix, check_out_tensor, free_stream, _torch)
 
 
 class PseudoInverseController(BaseController):
@@ -440,9 +440,10 @@ class PseudoInverseController(BaseController):
         with the ``ticket`` (int32 device tensor of 64 words: [0] in_seq, [32] stop, [48] waves, [49] ticks_done),
         ``done`` (int32 device tensor, one slot per wave: the last tick that wave finished), ``waves`` per tick,
         ``out`` and ``mode`` tensors and the launch ``stream``.  The kernel
-        leaves after ``n_ticks``, on ``ticket[32] != 0`` or when its poll budget (``timeout_s`` at a nominal 2.5 us per
+        leaves after ``n_ticks``, on ``ticket[32] != 0`` or when its poll budget (``timeout_s`` at a nominal 0.2 us per
         poll) is used up, whatever happens.  Whoever feeds it (copies, producer kernels) must use a stream that does not
-        share a hardware queue with ``stream``: a stream of another priority (``torch.cuda.Stream(priority=-1)``)."""
+        share a hardware queue with ``stream``: ``resident_feed_stream()`` hands one out (asking for another priority is
+        not enough: which queue a new stream lands on depends on how many the process has made)."""
         self._require_handle()
         torch = _torch()
         d = self.descriptor
@@ -512,6 +513,12 @@ class PseudoInverseController(BaseController):
         return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "mode": mode, "stream": stream,
                 "keep": (Q, Y, tt)}
 
+    def resident_feed_stream(self):
+        """A stream for whoever feeds a resident run that is ALREADY launched (copies, producer kernels): one whose work
+        makes progress beside the resident kernel (``base_controller.free_stream``; the runtime may have put a new stream
+        onto the resident kernel's hardware queue, where it would wait for the kernel's watchdog)."""
+        return free_stream(self._device)
+
     def resident_feed(self, run, n_ticks, closed_loop=False, timeout_s=2.0, stream=None):
         """The reference producer of resident ticks (clik_ticket_feed): one device thread that publishes tickets
         1 .. n_ticks on ``stream`` (a stream of its own by default), back to back or - ``closed_loop`` - each only after
@@ -520,7 +527,7 @@ class PseudoInverseController(BaseController):
         dev = self._device
         # (a stream of another PRIORITY: the runtime multiplexes streams of one priority onto a few hardware queues,
         # and a producer queued behind the resident kernel would wait for it to leave - see include/clik.h)
-        stream = stream if stream is not None else torch.cuda.Stream(device=dev, priority=-1)
+        stream = stream if stream is not None else free_stream(dev)
         with torch.cuda.device(dev):
             rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), ptr(run["done"]), int(n_ticks), 1 if closed_loop else 0,
                                             int(run["waves"]),

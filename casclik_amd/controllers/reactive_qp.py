@@ -23,7 +23,7 @@ from ..constraints import (EqualityConstraint, SetConstraint, VelocityEqualityCo
                            VelocitySetConstraint)
 from ..lowering import lower_skill
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
-                              to_device_matrix, check_out_tensor, _torch)
+                              to_device_matrix, check_out_tensor, free_stream, _torch)
 from .pseudo_inverse import _flat, _scalar
 
 
@@ -603,11 +603,15 @@ class ReactiveQPController(BaseController):
         return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "slack": slack, "status": status,
                 "stream": stream, "keep": (robot_var, input_var, tt)}
 
+    def resident_feed_stream(self):
+        """see PseudoInverseController.resident_feed_stream"""
+        return free_stream(self._device)
+
     def resident_feed(self, run, n_ticks, closed_loop=False, timeout_s=2.0, stream=None):
         """The reference producer of resident ticks (clik_ticket_feed, see PseudoInverseController.resident_feed)."""
         torch = _torch()
         dev = self._device
-        stream = stream if stream is not None else torch.cuda.Stream(device=dev, priority=-1)
+        stream = stream if stream is not None else free_stream(dev)
         with torch.cuda.device(dev):
             rc = self._lib.clik_ticket_feed(ptr(run["ticket"]), ptr(run["done"]), int(n_ticks), 1 if closed_loop else 0,
                                             int(run["waves"]), float(timeout_s), C.c_void_p(stream.cuda_stream))

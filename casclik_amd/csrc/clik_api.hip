@@ -960,8 +960,9 @@ static int resident_run_common(const clik_pinv* h, int64_t B, int32_t n_ticks, c
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    // (watchdog budget: polls, at a nominal 2.5 us each)
-    unsigned long long budget = (unsigned long long)(timeout_s * 4e5);
+    // (watchdog budget: polls at a nominal 0.2 us each - a load that hits the L2 plus s_sleep 1; round 6 found the
+    // budget of the earlier 2.5 us figure used up in a tenth of timeout_s)
+    unsigned long long budget = (unsigned long long)(timeout_s * 5e6);
     if (integrate_dt > 0.0) {
         // the step and the clamp travel in the ticket (stream-ordered in front of the kernel); bit 63 of the budget
         // picks the instantiation that keeps the state
@@ -986,7 +987,7 @@ extern "C" int clik_ticket_feed(clik_ticket* ticket, const uint32_t* done, int32
     if (!ticket || !done || n_ticks <= 0 || waves_per_tick <= 0) return fail(CLIK_EINVAL, "bad arguments");
     if (!(timeout_s > 0.0) || timeout_s > 60.0) return fail(CLIK_EINVAL, "timeout_s must lie in (0, 60]");
     hipError_t e = clik::launch_ticket_feed((void*)ticket, (const unsigned*)done, n_ticks, closed_loop, (unsigned)waves_per_tick,
-                                            (unsigned long long)(timeout_s * 4e5), (hipStream_t)stream);
+                                            (unsigned long long)(timeout_s * 5e6), (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "ticket feeder launch");
     return CLIK_OK;
 }
@@ -1513,7 +1514,7 @@ extern "C" int clik_qp_resident_run(const clik_qp* h, int64_t B, int32_t n_ticks
     TickArgs tk;
     int rc = fill_tick(S, tterms, &tk);
     if (rc) return rc;
-    const unsigned long long budget = (unsigned long long)(timeout_s * 4e5);       // (polls, at a nominal 2.5 us each)
+    const unsigned long long budget = (unsigned long long)(timeout_s * 5e6);       // (polls, at a nominal 0.2 us each)
     hipError_t e = h->val_resident(&tk, (long long)B, q, y, dq, slack, status, (void*)ticket, (unsigned*)done, n_ticks,
                                    budget, (hipStream_t)stream);
     if (e == hipErrorNotSupported)

@@ -370,6 +370,13 @@ __device__ __forceinline__ double recip(const double d)
     return r;
 }
 
+// "This value has ARRIVED": an empty statement that reads a load's destination register, so the compiler places the
+// load's wait HERE.  A wave's memory operations complete in order and the compiler waits by count, so where a loaded value
+// is first read decides what ELSE that wait covers: read at the top of a resident kernel's next tick, a row requested a
+// whole tick earlier still cost a wait for the stores issued just before the back edge (round 6, from the listings).
+__device__ __forceinline__ void pin_arrived(double& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_arrived(unsigned& x) { asm volatile("" : "+v"(x)); }
+
 // x, or a quiet NaN where `bad_hi` is 0x7ff80000 (0: x as it is).  As BITS: device code is compiled with
 // -fno-honor-nans (build.py DEVICE_FP), under which arithmetic with a NaN constant is undefined and "x + NaN" was folded
 // to x - the QP kernels mark an infeasible instance's outputs this way.
@@ -406,19 +413,34 @@ inline __constant__ double kSinCosPool[20] = {
     4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07,
     2.08757232129817482790e-09, -1.13596475577881948265e-11, 0.0, 0.0, 0.0, 0.0};
 
-__device__ __forceinline__ void sincos_fast(const double x, double& sn, double& cs)
+// the constants as a value: a kernel that wants their scalar loads issued at a place of its choosing - before its row
+// loads, before its tick loop - takes them there (sincos_consts) and hands them to the evaluations
+struct SinCosK {
+    double c[16];
+};
+__device__ __forceinline__ SinCosK sincos_consts()
 {
+    SinCosK k;
 #if CLIK_SINCOS_POOL
-    const double* __restrict__ P = kSinCosPool;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k.c[i] = kSinCosPool[i];
 #else
     // (-DCLIK_SINCOS_POOL=0: the same constants as literals - two s_mov_b32 each, no scalar loads at kernel start)
-    constexpr double P[16] = {
+    constexpr double L[16] = {
         0.6366197723675814, -1.5707963267948966, -6.123233995736766e-17, 1.4973849048591698e-33,
         -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06,
         -2.50507602534068634195e-08, 1.58969099521155010221e-10,
         4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07,
         2.08757232129817482790e-09, -1.13596475577881948265e-11};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k.c[i] = L[i];
 #endif
+    return k;
+}
+
+__device__ __forceinline__ void sincos_fast(const double x, double& sn, double& cs, const SinCosK& K)
+{
+    const double (&P)[16] = K.c;
     const double k = rint(x * P[0]);
     double r = fma(k, P[1], x);
     r = fma(k, P[2], r);
@@ -444,6 +466,10 @@ __device__ __forceinline__ void sincos_fast(const double x, double& sn, double& 
     const double c0 = (q & 1) ? sr : cr;
     sn = (q & 2) ? -s0 : s0;
     cs = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ void sincos_fast(const double x, double& sn, double& cs)
+{
+    sincos_fast(x, sn, cs, sincos_consts());
 }
 
 __device__ __forceinline__ void sincos_joint(const double x, double& sn, double& cs)

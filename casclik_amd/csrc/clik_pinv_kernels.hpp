@@ -1690,6 +1690,8 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_q
     // (launched for at most kTeamMaxBatch instances: 32-bit row numbers, rows addressed as uniform base + 32-bit lane
     // offset - the 64-bit index arithmetic was a dozen instructions of a lone wave's stream)
     CLIK_PHASE("rows_in");
+    const SinCosK sck = sincos_consts();        // (their scalar loads go out before anything else)
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned inst = (unsigned)blockIdx.x * (unsigned)(WAVE / TEAM) + ((unsigned)tid >> 2);
     const unsigned last = (unsigned)B - 1u;
     const bool valid = inst <= last;
@@ -1700,16 +1702,27 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_q
     const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
     const double a0 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j0 * 8u));
     const double a1 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j1 * 8u));
+    __builtin_amdgcn_sched_barrier(0);
     double z[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = qrow[j];
-    const double* ys = nullptr;
-    if constexpr (SD.n_y > 0)
-        ys = reinterpret_cast<const double*>(reinterpret_cast<const char*>(y) + __umul24(row, (unsigned)(SD.n_y * sizeof(double))));
+    // (the input_var row is requested HERE, with the robot_var row - one memory round trip per tick; left to the compiler
+    // it was requested where it is first used, part of it a few instructions before an `s_waitcnt vmcnt(0)` 670
+    // instructions into the tick: a second, exposed round trip.  The fence keeps the loads above it.)
+    constexpr int NYQ = SD.n_y > 0 ? SD.n_y : 0;
+    double ydir[NYQ > 0 ? NYQ : 1];
+    if constexpr (NYQ > 0) {
+        const double* __restrict__ yrow =
+            reinterpret_cast<const double*>(reinterpret_cast<const char*>(y) + __umul24(row, (unsigned)(NYQ * sizeof(double))));
+#pragma unroll
+        for (int k = 0; k < NYQ; ++k) ydir[k] = yrow[k];
+    }
+    asm volatile("" ::: "memory");
+    const double* ys = NYQ > 0 ? ydir : nullptr;
     CLIK_PHASE("sincos");
     double sn0, cs0, sn1, cs1;
-    sincos_fast(a0, sn0, cs0);
-    sincos_fast(a1, sn1, cs1);
+    sincos_fast(a0, sn0, cs0, sck);
+    sincos_fast(a1, sn1, cs1, sck);
     const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(huge) != 0ull, 0)) {
         if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
@@ -1788,6 +1801,7 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
         }
     };
     int owed = 0;           // tick whose "done" slot is still to be published (0: none)
+    const SinCosK sck = sincos_consts();        // (once per launch)
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
         if (!have_next) {
@@ -1795,6 +1809,14 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
             if (rw.leave) break;
             asm volatile("" ::: "memory");
             request_rows(k, zp, yp);
+            // (waited for inside this branch: left pending, the compiler - whose wait counts are merged over both ways
+            // into the tick - made the fed-ahead path wait for its freshly requested NEXT rows as well)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pin_arrived(zp[i]);
+            if constexpr (NY > 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * RY; ++i) pin_arrived(yp[i]);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) zp[i] = zp_next[i];
@@ -1813,8 +1835,8 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
         if (have_next) rw.peek();
         // this lane's own two sin / cos arguments are its share of the row
         double sn0, cs0, sn1, cs1;
-        sincos_fast(zp[0], sn0, cs0);
-        sincos_fast(zp[1], sn1, cs1);
+        sincos_fast(zp[0], sn0, cs0, sck);
+        sincos_fast(zp[1], sn1, cs1, sck);
         const bool huge = (fabs(zp[0]) > kSinCosFastMax) | (fabs(zp[1]) > kSinCosFastMax);
         if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
             if (fabs(zp[0]) > kSinCosFastMax) { const SinCos sc = sincos_slow(zp[0]); sn0 = sc.s; cs0 = sc.c; }
@@ -1842,12 +1864,27 @@ __global__ __launch_bounds__(WAVE) void pinv_resident_quad_kernel(
         double vout[N];
         int acc_mode;
         pinv_tick_static<SD, true>(&Sval, tk, z, yrow, tid & (WAVE - 1), valid, vout, acc_mode, sns, css);
+        // (the next tick's rows and the ticket word, requested at the top of this tick, are waited for HERE - before this
+        // tick's stores are issued - not at the top of the next tick, where the same wait would also cover those stores:
+        // pin_arrived, clik_device.hpp.  Unconditional: the compiler's wait insertion is not path-sensitive, and with
+        // nothing requested there is nothing to wait for)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pin_arrived(zp_next[i]);
+        if constexpr (NY > 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * RY; ++i) pin_arrived(yp_next[i]);
+        }
+        pin_arrived(rw.seen);
+        // (a producer that runs exactly ONE tick ahead: the early look was too early - look again, and wait for it inside
+        // the branch)
+        if (have_next && k + 1 < n_ticks && rw.seen < (unsigned)(k + 2)) {
+            rw.peek();
+            pin_arrived(rw.seen);
+        }
         if (owed != 0) {
             rw.publish_done(owed);         // (the previous tick's stores: issued a whole tick ago, nothing to wait for)
             owed = 0;
         }
-        // (a producer that runs exactly ONE tick ahead: the early look was too early - look again, as round 5 did)
-        if (have_next && k + 1 < n_ticks && rw.seen < (unsigned)(k + 2)) rw.peek();
         if (valid) {
             const long long orow = ((long long)((k - 1) % (int)ring)) * B + inst;
             double s0 = vout[N - 1], s1 = vout[N - 1];

@@ -137,8 +137,8 @@ struct NoMidTick {
 template <const ShapeDesc& SD, class MID = NoMidTick>
 __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, const TickArgs& tk,
                                           const double (&z)[SD.n], const double* ysl, const double a0, const double a1,
-                                          const int r, const int inst, const RoleConsts& rc, double (&v)[SD.n], bool& in_tc,
-                                          MID&& mid = MID())
+                                          const int r, const int inst, const RoleConsts& rc, const SinCosK& sck,
+                                          double (&v)[SD.n], bool& in_tc, MID&& mid = MID())
 {
     constexpr int N = SD.n, M = SD.m[1], M0 = SD.m[0], M2 = SD.m[2];
     constexpr int NT = M * (M + 1) / 2;
@@ -150,8 +150,8 @@ __device__ __forceinline__ void team_tick(const Img<SD>* __restrict__ Slds, cons
         if constexpr (SD.uses_fk != 0) {
             // lane r evaluated state variables 2r and 2r+1 (a0, a1), the quad exchanges by DPP
             double sn0, cs0, sn1, cs1;
-            sincos_fast(a0, sn0, cs0);
-            sincos_fast(a1, sn1, cs1);
+            sincos_fast(a0, sn0, cs0, sck);
+            sincos_fast(a1, sn1, cs1, sck);
             const bool huge = (fabs(a0) > kSinCosFastMax) | (fabs(a1) > kSinCosFastMax);
             if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
                 if (fabs(a0) > kSinCosFastMax) { const SinCos sc = sincos_slow(a0); sn0 = sc.s; cs0 = sc.c; }
@@ -406,16 +406,33 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
     const long long binst = (long long)urow;
     double zdir[N], ydir[NY > 0 ? NY : 1];
     RoleConsts rc;
-    if constexpr (VALUES) rc = role_consts_loaded<IMGV>(r);
+    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
+    double a0 = 0.0, a1 = 0.0;
+    // (the sin / cos constants: their scalar loads go out before anything else)
+    const SinCosK sck = sincos_consts();
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (VALUES) {
-        const double* __restrict__ qrow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + __umul24(urow, (unsigned)(N * sizeof(double))));
+        // The loads of a wave return IN ORDER: this lane's two sin / cos arguments are requested FIRST (the tick starts
+        // with them), then the robot_var row, the input_var row, and last the role constants (needed 500 instructions
+        // in).  The compiler's scheduler must not reorder them - it had put the two arguments BEHIND both rows, so
+        // the first sine waited for nine loads instead of one (0.2 us per tick: the round-6 diet of 150 instructions
+        // bought nothing until this was seen) - hence the fences.
+        const unsigned qoff = __umul24(urow, (unsigned)(N * sizeof(double)));
+        a0 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j0 * 8u));
+        a1 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j1 * 8u));
+        __builtin_amdgcn_sched_barrier(0);
+        const double* __restrict__ qrow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + qoff);
 #pragma unroll
         for (int j = 0; j < N; ++j) zdir[j] = qrow[j];
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (NY > 0) {
             const double* __restrict__ yrow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(y) + __umul24(urow, (unsigned)(NY * sizeof(double))));
 #pragma unroll
             for (int k = 0; k < NY; ++k) ydir[k] = yrow[k];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        rc = role_consts_loaded<IMGV>(r);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!VALUES) {
         // one memory round trip: image chunks round-robin over the waves, the block's q / y rows
@@ -484,19 +501,13 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_solve_static_team_kern
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = VALUES ? zdir[j] : zs[inst * N + j];
 
-    const int j0 = 2 * r < N ? 2 * r : N - 1, j1 = 2 * r + 1 < N ? 2 * r + 1 : N - 1;
-    double a0, a1;
-    if constexpr (VALUES) {
-        const unsigned qoff = __umul24(urow, (unsigned)(N * sizeof(double)));
-        a0 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j0 * 8u));
-        a1 = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(q) + (qoff + (unsigned)j1 * 8u));
-    } else {
+    if constexpr (!VALUES) {
         a0 = zs[inst * N + j0];
         a1 = zs[inst * N + j1];
     }
     double v[N];
     bool in_tc;
-    team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, v, in_tc);
+    team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, sck, v, in_tc);
     // the scan of :530-550 as a select: mode 0 if its cone test passes, else mode 1 (the active set
     // has no cone test, so mode 1 is always admissible)
     CLIK_STAMP_W(0, 6);
@@ -584,6 +595,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
     RoleConsts rc;
     if constexpr (VALUES) rc = role_consts_loaded<IMGV>(r);
     else rc = role_consts_computed(r, Slds->lam);
+    const SinCosK sck = sincos_consts();        // (once per launch)
     const int nts = Slds->n_tslots;
     double vout[N];
     int acc_mode = -1;
@@ -626,7 +638,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
             sincos_args(z, a0, a1);
             double v[N];
             bool in_tc;
-            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, v, in_tc);
+            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, sck, v, in_tc);
             const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
             accepted(v, ok0, vout);
 #pragma unroll
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_rollout_static_team_ke
             sincos_args(z, a0, a1);
             double v[N], d[N];
             bool in_tc;
-            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, v, in_tc);
+            team_tick<SD>(Slds, tk, z, ysl, a0, a1, r, inst, rc, sck, v, in_tc);
             const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
             accepted(v, ok0, d);
             const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
@@ -704,6 +716,56 @@ __device__ __forceinline__ unsigned long long realtime_100mhz()
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+
+// The rows of a resident wave's SIXTEEN instances (four lanes each), copied memory -> LDS WITHOUT passing through a
+// register (global_load_lds_dwordx4 / _dword: lane l's piece lands at the LDS address in M0 + l x size; sc0 sc1: past the
+// caches, as the resident kernels' other loads).  Round 6: a resident wave has its SIMD to itself, so the next tick's rows
+// must be requested a whole tick ahead - and a load's destination registers then stay reserved for a whole tick in kernels
+// that have none to spare: the compiler parked them in AGPRs, and the copy into the AGPR WAITS for the load (in the QP
+// kernel 150 instructions after it was issued; the config-3 kernel therefore requested its rows only 300 instructions into
+// the tick and still waited 0.4 us per tick at its end - profiles/r6_boundary_free_counters.md).  Through LDS the request
+// costs no register at all.  The wave's rows are ONE contiguous block of 16 x NE doubles; `row0` its first row, the array
+// `total_rows` long: a block that would run past the end of the array is read from `total_rows - 16` instead and the
+// instances find their rows `shift` further down (stage_row).  `al16`: base address and row pitch allow 16-byte pieces
+// (else 4-byte pieces: four times the requests).  Returns the shift.
+template <int NE>
+struct RowStage {
+    static constexpr int BLOCK = 16 * NE * 8;                        // bytes of a wave's rows
+    static constexpr int PIECES = (BLOCK + 1023) / 1024;             // 64 lanes x 16 bytes each
+    static constexpr int DOUBLES = NE > 0 ? PIECES * 128 : 0;        // LDS reserved: the last piece whole
+};
+template <int NE>
+__device__ __forceinline__ int stage_rows(const double* base, const long long row0, const long long total_rows,
+                                          double* lds, const int lane, const bool al16)
+{
+    constexpr int BLOCK = RowStage<NE>::BLOCK;
+    long long r0 = row0 < total_rows - 16 ? row0 : total_rows - 16;
+    r0 = r0 > 0 ? r0 : 0;
+    const char* src = reinterpret_cast<const char*>(base) + r0 * (NE * 8);
+    const long long room = (total_rows - r0) * (NE * 8);             // bytes from src to the end of the array
+    if (al16 && room >= 16) {
+#pragma unroll
+        for (int p = 0; p < RowStage<NE>::PIECES; ++p) {
+            int off = p * 1024 + lane * 16;
+            off = off < BLOCK - 16 ? off : BLOCK - 16;               // (the piece's upper lanes re-read the block's last bytes)
+            off = off < room - 16 ? off : (int)(room - 16);          // (an array shorter than sixteen rows)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                             (__attribute__((address_space(3))) void*)(lds + p * 128), 16, 0, 17);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4 * RowStage<NE>::PIECES; ++p) {
+            int off = p * 256 + lane * 4;
+            off = off < BLOCK - 4 ? off : BLOCK - 4;
+            off = off < room - 4 ? off : (int)(room - 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                             (__attribute__((address_space(3))) void*)(lds + p * 32), 4, 0, 17);
+        }
+    }
+    return (int)(row0 - r0);
+}
+// instance i (0 ... 15) of the wave: its row inside the staged block
+__device__ __forceinline__ int stage_row(const int i, const int shift) { return (i + shift) < 15 ? (i + shift) : 15; }
 
 // One wave's side of the ticket protocol (round 5: shared by the resident kernels that run one wave per block -
 // pinv_resident_quad_kernel, qp_resident_box_front4_kernel; pinv_resident_team_kernel above keeps its own copy, with
@@ -762,6 +824,8 @@ struct ResidentWave {
         }
     }
     __device__ __forceinline__ void peek() { seen = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    // (the same load into a register of the caller's: read a tick later, it has a whole tick to arrive)
+    __device__ __forceinline__ unsigned look() const { return __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     // every lane's stores acknowledged, then the wave's own slot (no shared counter)
     __device__ __forceinline__ void publish_done(const int k)
     {
@@ -793,7 +857,8 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     constexpr Img<SD> Sval = IMGV::value;
     CLIK_PHASE("res_setup");
     const RoleConsts rc = role_consts_loaded<IMGV>(r);
-    // watchdog: a budget of POLLS over the kernel's whole life (a poll is a cache-missing load plus s_sleep, 1.5-3 us):
+    const SinCosK sck = sincos_consts();        // (once per launch)
+    // watchdog: a budget of POLLS over the kernel's whole life (a poll is an L2-hitting load plus s_sleep 1: ~0.2 us measured, the nominal figure of clik_api.hip):
     // deterministic, unlike a clock - the first version compared s_memrealtime readings and misfired at the first tick
     // inside the long test run (never alone), leaving the kernel at once with stop = 2
     unsigned long long polls = 0;
@@ -859,46 +924,36 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
     double zstate[INTEGRATE ? N : 1];
 #pragma unroll
     for (int j = 0; j < (INTEGRATE ? N : 1); ++j) zstate[j] = 0.0;
-    // The rows bypass the caches, so every request goes to memory: lane r of the quad asks for elements 2r and 2r + 1
-    // of its instance's row only (two requests per row for the whole quad, contiguous over the quad) and the quad hands
-    // them round by DPP when the tick starts (`spread`) - all four lanes asking for all N elements re-read every 64-byte
-    // line N times (PMC: 3.8x the algorithmic bytes in the stores, which had the same shape).
-    // (rows longer than eight elements take more rounds of the same: element j lives in round j / 8, lane (j % 8) / 2)
-    constexpr int RQ = (N + 2 * TEAM - 1) / (2 * TEAM), RY = NY > 0 ? (NY + 2 * TEAM - 1) / (2 * TEAM) : 1;
-    double zp[2 * RQ], yp[2 * RY];                               // this lane's share of the next tick's rows
-#pragma unroll
-    for (int i = 0; i < 2 * RQ; ++i) zp[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 2 * RY; ++i) yp[i] = 0.0;
+    // The rows come through LDS (stage_rows above): the wave's sixteen instances' rows are one contiguous block, copied
+    // without a destination register, so the NEXT tick's rows are requested at the very top of a tick - a whole tick for
+    // them to arrive - and read out of LDS at its end (round 5 / early round 6: each lane loaded two elements of its
+    // instance's rows into registers 300 instructions into the tick and the quad handed them round by DPP).
+    constexpr int RQ = (N + 2 * TEAM - 1) / (2 * TEAM);          // (rounds of the stores: lane r writes elements 2r, 2r + 1)
+    using SQ = RowStage<N>;
+    using SY = RowStage<NY>;
+    __shared__ double stage[TEAM_WAVES][SQ::DOUBLES + SY::DOUBLES + 1];
+    const int wv = tid >> 6, lane = tid & (WAVE - 1), iw = inst & 15;
+    double* const zs = &stage[wv][0];
+    double* const ys = &stage[wv][SQ::DOUBLES];
+    const long long total_rows = ring * B;
+    const bool al16 = (((unsigned long long)(uintptr_t)q | (unsigned long long)(uintptr_t)y) & 15ull) == 0ull
+                      && ((B * N) & 1ll) == 0ll && ((B * NY) & 1ll) == 0ll;
+    int shift_q = 0, shift_y = 0;
     auto request_rows = [&](const int k) __attribute__((always_inline)) {
-        const long long row = ((long long)((k - 1) % (int)ring)) * B + binst;
-        if (!integrate || k == 1) {
-#pragma unroll
-            for (int i = 0; i < 2 * RQ; ++i) {
-                const int e = 2 * TEAM * (i / 2) + 2 * r + (i & 1);
-                zp[i] = __hip_atomic_load(q + row * N + (e < N ? e : N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        if constexpr (NY > 0) {
-#pragma unroll
-            for (int i = 0; i < 2 * RY; ++i) {
-                const int e = 2 * TEAM * (i / 2) + 2 * r + (i & 1);
-                yp[i] = __hip_atomic_load(y + row * NY + (e < NY ? e : NY - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        const long long row0 = ((long long)((k - 1) % (int)ring)) * B + b0 + 16 * wv;
+        // (the rows read out last tick are in registers: nothing of the stage is still to be read)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!integrate || k == 1) shift_q = stage_rows<N>(q, row0, total_rows, zs, lane, al16);
+        if constexpr (NY > 0) shift_y = stage_rows<NY>(y, row0, total_rows, ys, lane, al16);
     };
-    auto spread = [&]() __attribute__((always_inline)) {        // shares -> the whole rows in every lane of the quad
-        static_for<0, N>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            constexpr int CTRL = ((j % (2 * TEAM)) / 2) * 0x55;  // quad_perm:[k,k,k,k], k = the lane that holds element j
-            zn[j] = quad_perm_f64<CTRL>(zp[2 * (j / (2 * TEAM)) + (j & 1)]);
-        });
+    auto read_rows = [&]() __attribute__((always_inline)) {      // (after the copies have landed: s_waitcnt vmcnt(0))
+        const int iq = stage_row(iw, shift_q) * N;
+#pragma unroll
+        for (int j = 0; j < N; ++j) zn[j] = zs[iq + j];
         if constexpr (NY > 0) {
-            static_for<0, NY>([&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int CTRL = ((j % (2 * TEAM)) / 2) * 0x55;
-                yn[j] = quad_perm_f64<CTRL>(yp[2 * (j / (2 * TEAM)) + (j & 1)]);
-            });
+            const int iy = stage_row(iw, shift_y) * NY;
+#pragma unroll
+            for (int j = 0; j < NY; ++j) yn[j] = ys[iy + j];
         }
     };
     auto publish_done = [&](const int k) __attribute__((always_inline)) {
@@ -918,9 +973,10 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             if (leave) break;
             asm volatile("" ::: "memory");
             request_rows(k);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_rows();
         }
         CLIK_PHASE("res_spread");
-        spread();
         double z[N], ydir[NY > 0 ? NY : 1];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -930,20 +986,21 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
 #pragma unroll
         for (int j = 0; j < (NY > 0 ? NY : 1); ++j) ydir[j] = yn[j];
         have_next = false;
-        // (requesting the next rows HERE when the producer is two ticks ahead - a whole tick for them to arrive - was
-        // measured slower, 3.43 against 3.18 us: their four registers stay live through the whole tick of a kernel
-        // that has none to spare)
-        // The ticket word is requested HERE, at the top of tick k, and READ in tick k + 1 (`seen`, copied at the loop's
-        // end: a whole tick for the load to arrive).  Round 5 requested it at the END of the tick into the loop-carried
-        // variable: the copy into that variable's register at the loop's back edge made the compiler wait for the load at
-        // once - `s_waitcnt vmcnt(0)` right behind it, an uncached load's whole latency on the critical path of every
-        // tick (the 1300 - 1400 wait cycles = 0.55 us per tick of profiles/r6_counters.json).  The
-        // price: what the wave knows about the producer is one tick old - it runs fed ahead when the producer is TWO
-        // tickets ahead (rings of three or more slots), else it falls back to publishing at once and polling.
+        // The next tick's rows are requested HERE, at the top of tick k, if the ticket word says the producer has
+        // published tick k + 1; and the ticket word itself is requested again, to be READ in tick k + 1 (`seen`, copied at
+        // the loop's end).  Round 5 requested it at the END of the tick into the loop-carried variable: the copy into that
+        // variable's register at the loop's back edge made the compiler wait for the load at once - an uncached load's
+        // whole latency on the critical path of every tick.  The price: what the wave knows about the
+        // producer is one tick old - it runs fed ahead when the producer is TWO tickets ahead (rings of three or more
+        // slots), else it falls back to publishing at once and polling.
+        if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen >= (unsigned)(k + 1)) {
+            __atomic_signal_fence(__ATOMIC_ACQUIRE);     // (the rows are requested only after the ticket value is in)
+            request_rows(k + 1);
+            have_next = true;
+        }
         unsigned seen_next = seen;
         if (CLIK_RESIDENT_PIPELINE && k < n_ticks)
             seen_next = __hip_atomic_load(&ticket->in_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        unsigned seen_mid = seen;
         double a0 = z[N - 1], a1 = z[N - 1];
         static_for<0, TEAM>([&](auto kc) __attribute__((always_inline)) {
             constexpr int kk = decltype(kc)::value;
@@ -952,15 +1009,7 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
         });
         double v[N];
         bool in_tc;
-        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, rc, v, in_tc, [&](const double anchor) __attribute__((always_inline)) {
-            // (an empty asm that ties the decision to the anchor: see team_tick)
-            asm volatile("" : "+v"(seen_mid) : "v"(anchor));
-            if (CLIK_RESIDENT_PIPELINE && k < n_ticks && seen_mid >= (unsigned)(k + 1)) {
-                __atomic_signal_fence(__ATOMIC_ACQUIRE);     // (the rows are requested only after the ticket value is in)
-                request_rows(k + 1);
-                have_next = true;
-            }
-        });
+        team_tick<SD>(&Sval, tk, z, ydir, a0, a1, r, inst, rc, sck, v, in_tc);
         CLIK_PHASE("res_accept");
         const bool ok0 = __builtin_amdgcn_mov_dpp((int)in_tc, QUAD_LANE0, 0xf, 0xf, true) != 0;
         // the accepted candidate in every lane of the quad (mode 0 lives in lane 0, mode 1 in lane 3): lane r stores
@@ -977,6 +1026,16 @@ __global__ __launch_bounds__(TEAM_WAVES * WAVE) void pinv_resident_team_kernel(
             v[j] = d;
         }
         CLIK_PHASE("res_publish");
+        // The next tick's rows are read out of LDS HERE, before this tick's stores go out: a wave's memory operations
+        // complete in order and are waited for by count, so "the copies have landed" waits for everything older - at this
+        // point the previous tick's stores, a whole tick old.  (Round 5 took the rows at the top of the next tick: that
+        // wait also covered THIS tick's write-through stores, issued fifty instructions earlier - a store's whole round
+        // trip at the top of every tick; found in the listing, round 6.)
+        if (have_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_rows();
+        }
+        pin_arrived(seen_next);
         if (owed != 0) {
             publish_done(owed);         // (the previous tick's stores: issued a whole tick ago)
             owed = 0;

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
     };
     int32_t hot_word = 0;       // the instance's working set: in a register for the whole run
     int owed = 0;
+    const SinCosK sck = sincos_consts();        // (once per launch)
 #pragma unroll 1
     for (int k = 1; k <= n_ticks; ++k) {
         if (!have_next) {
@@ -67,6 +68,14 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
             if (rw.leave) break;
             asm volatile("" ::: "memory");
             request_rows(k, zp, yp);
+            // (waited for inside this branch: left pending, the compiler - whose wait counts are merged over both ways
+            // into the tick - made the fed-ahead path wait for its freshly requested NEXT rows as well)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pin_arrived(zp[i]);
+            if constexpr (NY > 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * RY; ++i) pin_arrived(yp[i]);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) zp[i] = zp_next[i];
@@ -82,8 +91,8 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         // tick, a few instructions before it is read: see pinv_resident_quad_kernel)
         if (have_next) rw.peek();
         double sn0, cs0, sn1, cs1;
-        sincos_fast(zp[0], sn0, cs0);
-        sincos_fast(zp[1], sn1, cs1);
+        sincos_fast(zp[0], sn0, cs0, sck);
+        sincos_fast(zp[1], sn1, cs1, sck);
         const bool huge = (fabs(zp[0]) > kSinCosFastMax) | (fabs(zp[1]) > kSinCosFastMax);
         if (__builtin_expect(__ballot(huge) != 0ull, 0)) {
             if (fabs(zp[0]) > kSinCosFastMax) { const SinCos sc = sincos_slow(zp[0]); sn0 = sc.s; cs0 = sc.c; }
@@ -112,6 +121,26 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         double v[N], sl[LY::NSA];
         const int status = qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, yrow, tid & (WAVE - 1),
                                                               valid, priv, v, sl, &hot_word, k > 1, nullptr, nullptr, sns, css);
+        // (the next tick's rows and the ticket word, requested at the top of this tick, are waited for HERE - before this
+        // tick's stores are issued - not at the top of the next tick, where the same wait would also cover those stores:
+        // pin_arrived, clik_device.hpp.  Unconditional: the compiler's wait insertion is not path-sensitive, and with
+        // nothing requested there is nothing to wait for.  The config-3 kernel takes its rows through LDS instead
+        // (stage_rows): measured here too, round 6 - 5.76 against 5.55 us per tick: this kernel's tick is long enough for
+        // the loads to arrive before the compiler's AGPR copy of their registers asks for them, and the copies' address
+        // arithmetic came on top)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pin_arrived(zp_next[i]);
+        if constexpr (NY > 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * RY; ++i) pin_arrived(yp_next[i]);
+        }
+        pin_arrived(rw.seen);
+        // (a producer that runs exactly ONE tick ahead: the early look was too early - look again, and wait for it inside
+        // the branch)
+        if (have_next && k + 1 < n_ticks && rw.seen < (unsigned)(k + 2)) {
+            rw.peek();
+            pin_arrived(rw.seen);
+        }
         if (owed != 0) {
             rw.publish_done(owed);
             owed = 0;
@@ -149,8 +178,6 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         }
         // (the next ticket may be out already: then this tick's "done" is published behind the next tick's arithmetic,
         // its stores a whole tick old; otherwise - a closed loop waits for it - at once)
-        // (a producer that runs exactly ONE tick ahead: the early look was too early - look again, as round 5 did)
-        if (have_next && k + 1 < n_ticks && rw.seen < (unsigned)(k + 2)) rw.peek();
         if (have_next) owed = k;
         else rw.publish_done(k);
     }

@@ -1918,15 +1918,29 @@ __device__ __forceinline__ void qp_box_values_body(
 #pragma unroll
         for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
     }
-    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
-    // (requesting the input_var row behind the robot_var row, as pinv_solve_static_values_kernel does, was measured here
-    // too: +1 - 3 % at every batch size, 16384 ... 524288, cold and hot - the row's registers are seven more in a kernel
-    // that already parks 70 in AGPRs; profiles/r5_defer_input_rows.txt)
+    // The input_var row and the working-set word are requested HERE, with the robot_var row: ONE memory round trip per
+    // tick.  Left to the compiler they were issued where they are first used - behind the sin / cos evaluations and the
+    // cold path's branch -, the working-set word a single instruction before `s_waitcnt vmcnt(0)`: a second, fully
+    // exposed round trip in the middle of every tick (round 6, found in the listing: profiles/r6_load_placement.md).
+    // The fence below keeps the loads above it.
+    constexpr int NY = SD.n_y > 0 ? SD.n_y : 0;
+    double ydir[NY > 0 ? NY : 1];
+    if constexpr (NY > 0) {
+#pragma unroll
+        for (int k = 0; k < NY; ++k) ydir[k] = y[row * NY + k];
+    }
+    int32_t hot_word = 0;
+    if (hot_set != nullptr) hot_word = hot_set[row];
+    asm volatile("" ::: "memory");
+    const double* ysl = ydir;
     double priv[LY::SLOTS];
     double v[N], sl[LY::NSA];
+    // (the working set in a register, its address passed unconditionally: a conditional pointer to it would put it into
+    // scratch memory)
     const int status = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                             hot_set != nullptr ? hot_set + row : nullptr, use_hot != 0);
+                                             &hot_word, use_hot != 0 && hot_set != nullptr);
     CLIK_PHASE("store");
+    if (valid && hot_set != nullptr) hot_set[inst] = hot_word;
     if (valid) {
         const unsigned bad = (status == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
 #pragma unroll
@@ -1996,10 +2010,24 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
     CLIK_BODY_BEGIN();
     const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     if (w == 0) key_min[lane] = 0x7fffffff;
-    // (the rows are requested BEFORE the block's barrier: one memory round trip, not two)
+    // ONE memory round trip: this wave's two sin / cos arguments first, then both rows, all requested before anything
+    // is waited for (the fence keeps the loads up here).  Round 5's listing had THREE round trips in a row: argument,
+    // sin / cos, argument, sin / cos, and only then the rows (round 6: profiles/r6_load_placement.md).
     const long long inst = (long long)blockIdx.x * WAVE + lane;
     const bool valid = inst < B;
     const long long row = valid ? inst : B - 1;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const SinCosK sck = sincos_consts();        // (their scalar loads go out before anything else)
+    __builtin_amdgcn_sched_barrier(0);
+    double aa[2] = {0.0, 0.0};
+    if constexpr (SHARE_SC) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = (2 * wu + k < N) ? 2 * wu + k : N - 1;
+            aa[k] = (j < NQ) ? q[row * NQ + j] : x[row * NX + (j - NQ)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     double z[N];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) z[j] = q[row * NQ + j];
@@ -2007,19 +2035,29 @@ __global__ __launch_bounds__(kFolioWaves * WAVE) void qp_solve_static_box_folio_
 #pragma unroll
         for (int j = 0; j < NX; ++j) z[NQ + j] = x[row * NX + j];
     }
-    const double* ysl = SD.n_y > 0 ? y + row * SD.n_y : nullptr;
+    constexpr int NY = SD.n_y > 0 ? SD.n_y : 0;
+    double ydir[NY > 0 ? NY : 1];
+    if constexpr (NY > 0) {
+#pragma unroll
+        for (int k = 0; k < NY; ++k) ydir[k] = y[row * NY + k];
+    }
+    asm volatile("" ::: "memory");
+    const double* ysl = ydir;
     if constexpr (SHARE_SC) {
-        const long long row_sc = row;
-        const int wu = __builtin_amdgcn_readfirstlane(w);
+        double sn[2], cs[2];
+        sincos_fast(aa[0], sn[0], cs[0], sck);
+        sincos_fast(aa[1], sn[1], cs[1], sck);
+        const bool huge = (fabs(aa[0]) > kSinCosFastMax) | (fabs(aa[1]) > kSinCosFastMax);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(huge) != 0ull, 0)) {
+            if (fabs(aa[0]) > kSinCosFastMax) { const SinCos sc = sincos_slow(aa[0]); sn[0] = sc.s; cs[0] = sc.c; }
+            if (fabs(aa[1]) > kSinCosFastMax) { const SinCos sc = sincos_slow(aa[1]); sn[1] = sc.s; cs[1] = sc.c; }
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int j = 2 * wu + k;
             if (j < N) {
-                const double a = (j < NQ) ? q[row_sc * NQ + j] : x[row_sc * NX + (j - NQ)];
-                double sn, cs;
-                sincos_joint(a, sn, cs);
-                sc_lds[j][lane] = sn;
-                sc_lds[N + j][lane] = cs;
+                sc_lds[j][lane] = sn[k];
+                sc_lds[N + j][lane] = cs[k];
             }
         }
     }

@@ -260,7 +260,7 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  *     so only the TARGETS y come from outside: a producer that streams them ahead through the ring never stalls the
  *     kernel, and the loop over q closes without leaving it; dq (clamped) and mode are written per tick as before;
  *   the kernel leaves after n_ticks, when anyone writes stop != 0, or when its watchdog expires (a budget of polls over
- *     its whole life, timeout_s at a nominal 2.5 us per poll; it then writes stop = 2 itself) - it never spins unguarded.
+ *     its whole life, timeout_s at a nominal 0.2 us per poll; it then writes stop = 2 itself) - it never spins unguarded.
  * clik_ticket_feed launches the reference producer (one device block that publishes tickets 1 .. n_ticks, either
  * back to back or - closed_loop - each only after every slot shows the previous tick) on `stream`, which must not share
  * a HARDWARE QUEUE with the kernel's stream (the runtime multiplexes the streams of one priority onto a few queues; a

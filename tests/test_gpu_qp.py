@@ -1071,7 +1071,7 @@ def test_resident_qp_ticks(iiwa_fk):
     Yd = torch.zeros((B, 7), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     run = ctrl.resident_start(Qd, Yd, NT, timeout_s=30.0)
-    feed = torch.cuda.Stream(priority=-1)
+    feed = ctrl.resident_feed_stream()       # (a stream that makes progress beside the resident kernel)
     assert run["waves"] == (B + 15) // 16
     try:
         for k in range(1, NT + 1):
@@ -1122,3 +1122,36 @@ def test_resident_qp_ticks(iiwa_fk):
         assert np.array_equal(run["status"][s_].cpu().numpy(), wst), s_
         good = wst == 0
         assert _rel(run["out"][s_].cpu().numpy()[good], wants[s_][0].cpu().numpy()[good]).max() < 1e-8, s_
+
+
+def test_resident_qp_ticks_at_odd_and_tiny_batches(iiwa_fk):
+    """Round 6: resident QP ticks at batches whose last wave is ragged, whose row count is odd and with fewer rows than a
+    wave has instances (the kernel's lanes load elements 2r, 2r + 1 of their instance's rows, clamped to the last row for
+    lanes without an instance), a ring of three slots with different inputs, every ticket ahead: every slot's statuses equal
+    and its minimisers equal to rounding to a cold launch on that slot's inputs."""
+    import torch
+    spec = skills.qp_skill(iiwa_fk)
+    ctrl = cc.ReactiveQPController(skill_spec=spec)
+    ctrl.setup_problem_functions()
+    ctrl.setup_solver()
+    if not ctrl.value_kernel:
+        pytest.skip("no value-specialised kernel attached (hipcc missing)")
+    dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
+    D, NT = 3, 3
+    for B in (333, 5, 1000, 16):
+        batches = [skills.synthetic_inputs(iiwa_fk, B, seed=70 + k, distribution="mixed") for k in range(D)]
+        wants = [ctrl.solve_batch(0.0, dev(q), input_var=dev(y), use_hot=False) for q, y in batches]
+        Qr = torch.stack([dev(b[0]) for b in batches]).contiguous()
+        Yr = torch.stack([dev(b[1]) for b in batches]).contiguous()
+        torch.cuda.synchronize()
+        run = ctrl.resident_start(Qr, Yr, NT, timeout_s=10.0, ring_depth=D)
+        feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=10.0)
+        run["stream"].synchronize()
+        feeder.synchronize()
+        tk = run["ticket"].cpu()
+        assert int(tk[32]) == 0 and int(tk[49]) == NT and int(run["done"].min()) == NT, (B, tk[[0, 32, 49]].tolist())
+        for s_ in range(D):
+            wst = wants[s_][3].cpu().numpy()
+            assert np.array_equal(run["status"][s_].cpu().numpy(), wst), (B, s_)
+            good = wst == 0
+            assert _rel(run["out"][s_].cpu().numpy()[good], wants[s_][0].cpu().numpy()[good]).max() < 1e-8, (B, s_)

@@ -293,12 +293,13 @@ def test_resident_ticks_fed_from_outside(iiwa_fk):
     Ys = [skills.synthetic_inputs(iiwa_fk, B, seed=30 + k, distribution="mixed")[1] for k in range(NT)]
     Qd = torch.from_numpy(Q).cuda()
     want = [ctrl.solve_batch(0.0, Qd, input_var=torch.from_numpy(Yk).cuda()) for Yk in Ys]
+    want_host = [(w[0].cpu(), w[2].cpu()) for w in want]
     Yd = torch.zeros((B, 7), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     run = ctrl.resident_start(Qd, Yd, NT, timeout_s=30.0)
     # (a stream of another priority: streams of one priority share a few hardware queues, and copies queued behind the
     # resident kernel would wait until its watchdog lets it go - seen in the long test run, never in this test alone)
-    feed = torch.cuda.Stream(priority=-1)
+    feed = ctrl.resident_feed_stream()       # (a stream that makes progress beside the resident kernel)
     waves = run["waves"]
     assert waves == ((B + 63) // 64) * 4
     try:
@@ -318,10 +319,13 @@ def test_resident_ticks_fed_from_outside(iiwa_fk):
                 "tick %d: ticket [in_seq, stop, waves, ticks_done, max_polls lo / hi, n_ticks, polls, wave] = %s, slots " \
                 "min %d max %d after %.2f s" % (k, tk[[0, 32, 48, 49, 50, 51, 52, 53, 54]].tolist(), int(dn.min()),
                                                 int(dn.max()), time.time() - t0)
+            # (read back and compared on the HOST: a comparison kernel on the default stream can be queued behind the resident
+            # kernel on the same hardware queue and then waits until the watchdog lets it go - which queue the default stream
+            # shares depends on how many streams the process has made: seen in the long test run, never in this test alone)
             with torch.cuda.stream(feed):
-                got, gmode = run["out"].clone(), run["mode"].clone()
+                got, gmode = run["out"].cpu(), run["mode"].cpu()
             feed.synchronize()
-            assert torch.equal(gmode, want[k - 1][2]) and torch.equal(got, want[k - 1][0]), k
+            assert torch.equal(gmode, want_host[k - 1][1]) and torch.equal(got, want_host[k - 1][0]), k
     finally:
         with torch.cuda.stream(feed):
             run["ticket"][32:33].copy_(torch.tensor([1], dtype=torch.int32))      # (leave, whatever happened)
@@ -329,6 +333,30 @@ def test_resident_ticks_fed_from_outside(iiwa_fk):
         run["stream"].synchronize()
     tk = run["ticket"].cpu()
     assert int(tk[48]) == waves and int(tk[49]) == NT
+
+
+def test_resident_kernel_leaves_by_its_watchdog(iiwa_fk):
+    """A resident kernel nobody feeds leaves by itself: its poll budget (timeout_s at a nominal 0.2 us per poll, clik.h)
+    runs out, it writes stop = 2 and every wave returns - within the same order of magnitude as timeout_s (round 6: the
+    earlier nominal figure of 2.5 us per poll made it a tenth of timeout_s)."""
+    import time
+    import torch
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    B = 256
+    if "team4v" not in ctrl.kernel_variant(B):
+        pytest.skip("no value-specialised team kernel attached (hipcc missing)")
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=5, distribution="mixed")
+    Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    run = ctrl.resident_start(Qd, Yd, 3, timeout_s=0.5)
+    run["stream"].synchronize()
+    took = time.time() - t0
+    tk = run["ticket"].cpu()
+    assert int(tk[32]) == 2 and int(tk[49]) == 0, tk[[0, 32, 48, 49]].tolist()
+    assert 0.1 < took < 5.0, took
 
 
 def test_resident_ticks_of_a_single_mode_skill(iiwa_fk):
@@ -355,7 +383,7 @@ def test_resident_ticks_of_a_single_mode_skill(iiwa_fk):
     Yd = torch.zeros((B, 7), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     run = ctrl.resident_start(Qd, Yd, NT, timeout_s=30.0)
-    feed = torch.cuda.Stream(priority=-1)
+    feed = ctrl.resident_feed_stream()       # (a stream that makes progress beside the resident kernel)
     assert run["waves"] == (B + 15) // 16
     try:
         for k in range(1, NT + 1):
@@ -443,7 +471,7 @@ def test_resident_ticks_over_a_ring_of_input_slots(iiwa_fk):
     Yr = torch.zeros((D, B, 7), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     run = ctrl.resident_start(Qr, Yr, NT, timeout_s=30.0, ring_depth=D)
-    feed = torch.cuda.Stream(priority=-1)
+    feed = ctrl.resident_feed_stream()       # (a stream that makes progress beside the resident kernel)
     seen = {}
     try:
         published = 0
@@ -590,6 +618,43 @@ def test_resident_ticks_accept_only_what_fits_on_the_device_at_once(iiwa_fk):
         assert int(tk[32]) == 0 and int(run["done"].min()) == NT, (B, tk[[0, 32, 49]].tolist())
         for s in range(D):
             assert torch.allclose(run["out"][s], want[s][0], rtol=0, atol=1e-9) and torch.equal(run["mode"][s], want[s][2]), (B, s)
+
+
+def test_resident_rows_through_lds_at_odd_and_tiny_batches(iiwa_fk):
+    """Round 6: the config-3 resident kernel copies a wave's rows memory -> LDS without destination registers
+    (stage_rows, clik_pinv_team.hpp) - in 16-byte pieces when base address and row pitch allow, in 4-byte pieces
+    otherwise; a block that would run past the end of the ring is read from the ring's last sixteen rows.  Batches that
+    take each path (odd: 56-byte pitch x odd row count; fewer than sixteen rows; ragged last wave; a misaligned base
+    address), a ring of three slots with different inputs, every ticket ahead: every slot bit-equal to a launch."""
+    import torch
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    if "team4v" not in ctrl.kernel_variant(1000):
+        pytest.skip("no value-specialised team kernel attached (hipcc missing)")
+    dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
+    D, NT = 3, 5
+    for B, skew in ((333, 0), (5, 0), (1000, 0), (16, 0), (1000, 1)):
+        batches = [skills.synthetic_inputs(iiwa_fk, B, seed=80 + k, distribution="mixed") for k in range(D)]
+        want = [ctrl.solve_batch(0.0, dev(q), input_var=dev(y)) for q, y in batches]
+        Qr = torch.stack([dev(q) for q, _ in batches]).contiguous()
+        Yr = torch.stack([dev(y) for _, y in batches]).contiguous()
+        if skew:        # (the same rows at an address that is 8 but not 16 bytes aligned)
+            qb = torch.empty(Qr.numel() + 1, dtype=torch.float64, device="cuda")
+            yb = torch.empty(Yr.numel() + 1, dtype=torch.float64, device="cuda")
+            qb[1:].copy_(Qr.reshape(-1))
+            yb[1:].copy_(Yr.reshape(-1))
+            Qr, Yr = qb[1:].view(D, B, 7), yb[1:].view(D, B, 7)
+            assert Qr.data_ptr() % 16 == 8
+        torch.cuda.synchronize()
+        run = ctrl.resident_start(Qr, Yr, NT, timeout_s=10.0, ring_depth=D)
+        feeder = ctrl.resident_feed(run, NT, closed_loop=False, timeout_s=10.0)
+        run["stream"].synchronize()
+        feeder.synchronize()
+        tk = run["ticket"].cpu()
+        assert int(tk[32]) == 0 and int(run["done"].min()) == NT, (B, tk[[0, 32, 49]].tolist())
+        for s in range(D):
+            assert torch.equal(run["out"][s], want[s][0]) and torch.equal(run["mode"][s], want[s][2]), (B, skew, s)
 
 
 def test_worst_case_of_the_team_sweeps_is_held_to_its_own_bound():

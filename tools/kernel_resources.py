@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Registers / scratch / occupancy of the value-specialised kernels of a BASELINE skill, from the compiler's resource
-remarks (no GPU needed).      python tools/kernel_resources.py [stack|pose|qp] [-DFLAG ...] [--asm=listing.s]"""
+remarks (no GPU needed).      python tools/kernel_resources.py [stack|pose|qp] [-DFLAG ...] [--asm=listing.s] [--obj=device.o]"""
 import os
 import subprocess
 import sys
@@ -21,6 +21,7 @@ for a in sys.argv[2:]:
     if a.startswith("--mllvm="):                      # e.g. --mllvm=-disable-machine-licm
         flags += ["-mllvm", a.split("=", 1)[1]]
 asm_out = [a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--asm=")]
+obj_out = [a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--obj=")]     # device code object (llvm-objdump -d)
 for a in sys.argv[2:]:
     if a.startswith("--csrc="):                       # kernel headers from a scratch copy (experiments next to a running build)
         alt = os.path.abspath(a.split("=", 1)[1])
@@ -61,6 +62,9 @@ with tempfile.TemporaryDirectory() as tmp:
         # (the listing tools/isa_count.py reads)
         subprocess.run([jit._hipcc()] + [f for f in FLAGS if not f.startswith("-Rpass")] + ["-DCLIK_VALUE_KERNEL"] + flags +
                        ["-S", "--cuda-device-only", src, "-o", asm_out[0]], check=True)
+    if obj_out:
+        subprocess.run([jit._hipcc()] + [f for f in FLAGS if not f.startswith("-Rpass")] + ["-DCLIK_VALUE_KERNEL"] + flags +
+                       ["-c", "--cuda-device-only", "--no-gpu-bundle-output", src, "-o", obj_out[0]], check=True)
     for name, r in sorted(parse_resource_remarks(out.stdout.decode()).items()):
         short = name.split("(")[0][-70:]
         print("%-72s VGPR %3d AGPR %3d SGPR %3d scratch %4d occupancy %d" % (

@@ -62,10 +62,10 @@ def run_ticks(nt, closed, integrate=False):
     """best of 5: wall time [s] from the feeder's launch to the resident kernel's exit, for nt ticks"""
     best = None
     for rep in range(5):
-        feeder_stream = torch.cuda.Stream(priority=-1)       # (not the hardware queue of the resident kernel)
         torch.cuda.synchronize()
         run = ctrl.resident_start(Qr, Yr, nt, timeout_s=3.0, ring_depth=RING,
                                   **(dict(integrate_dt=1e-3, max_speed=2.0) if integrate else {}))
+        feeder_stream = ctrl.resident_feed_stream()       # (one that makes progress beside the resident kernel)
         time.sleep(0.02)                      # (the resident kernel is up and polling)
         t0 = time.perf_counter()
         ctrl.resident_feed(run, nt, closed_loop=closed, timeout_s=3.0, stream=feeder_stream)
