@@ -830,7 +830,7 @@ def compact_entry(e):
            "kernel": str(e["config"].get("kernel")).replace("qp_static_kQpPoseIiwa", "kQp").replace("Iiwa", ""),
            "hbm_frac": _r(r.get("frac"), 4), "fp64_frac": _r(f64.get("frac"), 3), "traffic": r.get("traffic")}
     if r.get("traffic_source"):
-        pass        # (the counter case is the entry's own name, workload_inputs_B<batch>, in profiles/r5_counters.json)
+        pass        # (the counter case is the entry's own name, workload_inputs_B<batch>, in profiles/r6_counters.json)
     else:
         # (no counter pass for this entry - the rollouts, the resident ticks: no traffic / fp64 figures)
         out = {k: v for k, v in out.items() if v is not None}
@@ -845,9 +845,9 @@ def compact_entry(e):
 
 
 NOTES = ("us = wall per tick; roofline.achieved = ALGORITHMIC bytes (172 B/instance-step, QP 220) / tick vs 8 TB/s, not DRAM traffic "
-         "(ticks rotate through --ring buffers; `traffic` = PMC bytes per launch, profiles/r5_counters.json); fp64_frac: executed "
+         "(ticks rotate through --ring buffers; `traffic` = PMC bytes per launch, RECORDED in profiles/r6_counters.json); fp64_frac: executed "
          "flops (PMC) vs 78.6 TF; cpu_M_per_s: C port on cpu_baseline.cores threads (quota_cores: cgroup), a baseline not a "
-         "speed-up; cost model: profiles/r5_tick_cost_model.md; --full 1: details")
+         "speed-up; cost model: profiles/r5_tick_cost_model.md, r6_load_placement.md; --full 1: details")
 
 
 def device_uuid(index):
@@ -1058,7 +1058,7 @@ def main():
             out["scaling_note"] = ("weak line: 16384 instances PER GPU - a tick is one wave per SIMD long whatever N is, so "
                                    "value scales ~N by construction (shards are independent, no data-path collective). "
                                    "The STRONG line of BASELINE config 5 is extras.strong_B131072: one GPU runs 131072 "
-                                   "instances in ~9.9 us, eight GPUs at 16384 each take ~3.6 us - expect ~2.7x from 8 GPUs "
+                                   "instances in ~9.6 us, eight GPUs at 16384 each take ~3.7 us - expect ~2.6x from 8 GPUs "
                                    "on that batch, not 8x; extras.weak_B131072_per_gpu is the regime where every GPU is full")
         if extras:
             out["extras"] = extras

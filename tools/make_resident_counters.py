@@ -55,4 +55,7 @@ with open(dst + ".md", "w") as f:
             "One counter group per `rocprofv3 --pmc` run; counters of one dispatch divided by waves x ticks; cycle counters x 4.\n\n"
             "| kernel | build | VALU | SALU | all instructions | issue clocks | wait clocks | wave clocks | us per tick at 2.4 GHz |\n"
             "|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n")
+    notes = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r6_boundary_free_reading.md")
+    if os.path.exists(notes):
+        f.write("\n" + open(notes).read())
 print("\n".join(rows))
