@@ -20,6 +20,7 @@ from casclik_amd.geom import casadi_geom, numpy_geom
 # names the reference's `from casclik.controllers import *` / `from casclik.constraints import *` leave on the package
 # (casclik/__init__.py:1-3): the controller modules and `cs`
 from casclik_amd.controllers import base_controller, pseudo_inverse, reactive_qp
+from casclik_amd.controllers.base_controller import ResidentWatchdog
 from casclik_amd import sym as cs
 
 

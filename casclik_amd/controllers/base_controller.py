@@ -127,6 +127,27 @@ def free_stream(device, tries=12, wait_s=0.25):
                        "occupying the device?" % tries)
 
 
+class ResidentWatchdog(RuntimeError):
+    """A resident run ended by its watchdog (``ticket[32] == 2``): some wave used up the poll budget waiting for a ticket."""
+
+
+def resident_wait(run):
+    """Wait for a resident run (the dict ``resident_start`` returned) to leave and say how: returns the number of ticks
+    every wave finished; raises ``ResidentWatchdog`` when the kernel left by its watchdog instead (nobody published the
+    next ticket within ``timeout_s`` - typically a feeder whose stream shares the kernel's hardware queue, see
+    ``free_stream``).  ``ticket[32] == 1`` (the caller asked it to stop) is not an error."""
+    run["stream"].synchronize()
+    tk = run["ticket"].cpu()
+    stop, ticks_done = int(tk[32]), int(tk[49])
+    if stop == 2:
+        raise ResidentWatchdog(
+            "resident kernel left by its watchdog after %d tick(s): wave %d used up its budget of %d polls waiting for ticket "
+            "%d (in_seq = %d).  Is the producer on a stream that makes progress beside the kernel (resident_feed_stream())?"
+            % (ticks_done, int(tk[54]), (int(tk[50]) & 0xffffffff) | ((int(tk[51]) & 0xffffffff) << 32), ticks_done + 1,
+               int(tk[0])))
+    return ticks_done
+
+
 class SingleSlot(object):
     """Persistent staging for the single-instance ``solve()`` call (B = 1): one pinned host
     buffer each way that the kernel reads and writes in place (pinned host memory is mapped into

@@ -18,7 +18,8 @@ from .. import _capi
 from .. import sym as cs
 from ..lowering import lower_skill, DYN_MAX_M
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
-                              to_device_matrix, check_out_tensor, free_stream, _torch)
+                              to_device_matrix, check_out_tensor, free_stream, resident_wait, ResidentWatchdog,
+                              _torch)
 
 
 class PseudoInverseController(BaseController):
@@ -512,6 +513,10 @@ class PseudoInverseController(BaseController):
         _capi.check(self._lib, rc)
         return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "mode": mode, "stream": stream,
                 "keep": (Q, Y, tt)}
+
+    def resident_wait(self, run):
+        """Wait for a resident run to leave; ticks finished, or ``ResidentWatchdog`` (``base_controller.resident_wait``)."""
+        return resident_wait(run)
 
     def resident_feed_stream(self):
         """A stream for whoever feeds a resident run that is ALREADY launched (copies, producer kernels): one whose work

@@ -23,7 +23,8 @@ from ..constraints import (EqualityConstraint, SetConstraint, VelocityEqualityCo
                            VelocitySetConstraint)
 from ..lowering import lower_skill
 from .base_controller import (BaseController, SingleSlot, current_stream, device_of, ptr,
-                              to_device_matrix, check_out_tensor, free_stream, _torch)
+                              to_device_matrix, check_out_tensor, free_stream, resident_wait, ResidentWatchdog,
+                              _torch)
 from .pseudo_inverse import _flat, _scalar
 
 
@@ -602,6 +603,10 @@ class ReactiveQPController(BaseController):
         _capi.check(self._lib, rc)
         return {"ticket": ticket, "done": done, "waves": waves, "out": dQ, "slack": slack, "status": status,
                 "stream": stream, "keep": (robot_var, input_var, tt)}
+
+    def resident_wait(self, run):
+        """Wait for a resident run to leave; ticks finished, or ``ResidentWatchdog`` (``base_controller.resident_wait``)."""
+        return resident_wait(run)
 
     def resident_feed_stream(self):
         """see PseudoInverseController.resident_feed_stream"""

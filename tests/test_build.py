@@ -159,8 +159,11 @@ def test_value_specialised_kernels_of_the_config3_skill_have_no_scratch(tmp_path
         "%(words)s", ", ".join(w + "ull" for w in words)) % {"init": init, "extern": ""}
     src = tmp_path / "stack_values.hip"
     src.write_text(text)
-    out = subprocess.run([hipcc] + FLAGS + ["-DCLIK_VALUE_KERNEL", "-c", str(src), "-o", str(tmp_path / "stack_values.o")],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # (compiled as shipped: with the scheduling strategy jit.py picks for this translation unit)
+    sched = jit.sched_strategy(text, init)
+    assert sched == "max-memory-clause"
+    out = subprocess.run([hipcc] + FLAGS + ["-DCLIK_VALUE_KERNEL", "-mllvm", "-amdgpu-sched-strategy=" + sched, "-c", str(src),
+                          "-o", str(tmp_path / "stack_values.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     res = parse_resource_remarks(out.stdout.decode())
     kernels = {k: v for k, v in res.items() if "_static_" in k}
@@ -217,3 +220,28 @@ def test_value_kernels_of_the_team_family_compile_for_long_input_rows():
         text = jit._VALUE_TEMPLATE.replace("%(nwords)d", str(len(words))).replace("%(words)s", ", ".join(w + "ull" for w in words))
         so, tag = jit.build_shape_library(init, False, template=text, defines=("-DCLIK_VALUE_KERNEL",), extern="")
         assert so is not None and os.path.exists(so)
+
+
+def test_scheduling_strategy_per_translation_unit(monkeypatch):
+    """casclik_amd/jit.py::sched_strategy (round 6, profiles/r6_sched_ab.txt): QP units max-ilp, value-specialised pinv
+    units of skills with SetConstraints max-memory-clause, everything else the compiler's default; CLIK_JIT_SCHED
+    overrides; the choice is part of the cache tag and not of the recorded request."""
+    import json
+    from casclik_amd import jit
+    monkeypatch.delenv("CLIK_JIT_SCHED", raising=False)
+    stack = "{7, 3, {1, 0, 0, 0, 0, 0, 0, 0}, {7, 6, 7, 0, 0, 0, 0, 0}}"
+    pose = "{7, 1, {0, 0, 0, 0, 0, 0, 0, 0}, {6, 0, 0, 0, 0, 0, 0, 0}}"
+    assert jit.sched_strategy(jit._QP_VALUE_TEMPLATE, stack) == "max-ilp"
+    assert jit.sched_strategy(jit._QP_TEMPLATE, pose) == "max-ilp"
+    assert jit.sched_strategy(jit._VALUE_TEMPLATE, stack) == "max-memory-clause"
+    assert jit.sched_strategy(jit._VALUE_TEMPLATE, pose) is None
+    assert jit.sched_strategy(jit._TEMPLATE, stack) is None
+    monkeypatch.setenv("CLIK_JIT_SCHED", "default")
+    assert jit.sched_strategy(jit._QP_VALUE_TEMPLATE, stack) is None
+    monkeypatch.setenv("CLIK_JIT_SCHED", "max-ilp")
+    assert jit.sched_strategy(jit._TEMPLATE, pose) == "max-ilp"
+    monkeypatch.delenv("CLIK_JIT_SCHED")
+    # every recorded request carries today's choice into its cache tag, none into its own name
+    recs = jit._records()
+    assert recs and all("sched" not in json.dumps(meta.get("flags", [])) for _, meta, _ in recs)
+    assert {meta["_sched"] for _, meta, _ in recs} == {None, "max-ilp", "max-memory-clause"}

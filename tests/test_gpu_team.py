@@ -352,8 +352,10 @@ def test_resident_kernel_leaves_by_its_watchdog(iiwa_fk):
     torch.cuda.synchronize()
     t0 = time.time()
     run = ctrl.resident_start(Qd, Yd, 3, timeout_s=0.5)
-    run["stream"].synchronize()
+    with pytest.raises(cc.ResidentWatchdog) as err:      # (resident_wait: how a caller learns of it)
+        ctrl.resident_wait(run)
     took = time.time() - t0
+    assert "watchdog" in str(err.value) and "ticket 1" in str(err.value)
     tk = run["ticket"].cpu()
     assert int(tk[32]) == 2 and int(tk[49]) == 0, tk[[0, 32, 48, 49]].tolist()
     assert 0.1 < took < 5.0, took

@@ -48,6 +48,7 @@ CASES = {  # pmc file tag -> (bench key, kernel label, algorithmic bytes per ins
     "pose_lanev": ("pose_mixed_B16384_kPose6Iiwa/lanev", "kPose6Iiwa/lanev", 172, 16384),
 }
 CASES_R6 = dict(CASES_R5)        # round 6 (tools/profile_round6_launched.sh): the same configurations on the round's kernels
+CASES_R6["stack_lanev_1M"] = ("stack_mixed_B1048576_kStackIiwa/lanev", "kStackIiwa/lanev", 172, 1048576)
 if "r3" in dst:
     CASES = CASES_R3
 if "r4" in dst:

@@ -41,4 +41,6 @@ profile qp_16384_folio --workload qp
 profile qp_16384_hot --workload qp --qp-hot 1
 profile stack_lanev_131072 --batch 131072
 profile qp_131072 --workload qp --batch 131072
+profile qp_4096_folio --workload qp --batch 4096
+profile stack_lanev_1M --batch 1048576
 ls $OUT
