@@ -291,7 +291,7 @@ def profiled(workload, dist_name, batch, kernel, hot=False):
 def body_time(workload, dist_name, batch, kernel, hot=False):
     """Kernel body time (first wave start to last wave end, s_memrealtime stamps of the CLIK_STAMP build,
     tools/stamp_body.py) of this configuration if profiles/ holds one."""
-    key = "%s_%s_B%d_%s%s" % (workload, dist_name, batch, kernel, ("_hot_settled" if hot == 2 else "_hot") if hot else "")
+    key = "%s_%s_B%d_%s%s" % (workload, dist_name, batch, kernel, "_hot" if hot else "")
     for fn in BODY_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -993,7 +993,8 @@ def main():
                                   ("stack", 131072, 0, 1), ("qp", 131072, 0, 1), ("stack", 1048576, 0, 1),
                                   ("stack", 16384, 0, 256), ("qp", 16384, 0, 64)):
             up = lambda v: -(-max(v, tpl) // tpl) * tpl              # noqa: E731  (a whole number of launches)
-            name = "%s_B%d%s%s" % (wl, b, "_hot" if hot else "", "_rollout%d" % tpl if tpl > 1 else "")
+            name = "%s_B%d%s%s" % (wl, b, ("_hot_settled" if hot == 2 else "_hot") if hot else "",
+                                   "_rollout%d" % tpl if tpl > 1 else "")
             phase(name)
             try:
                 ent, (sp, op, q_, y_) = measure(ctx, fk, wl, b, args.dist, args.seed,

@@ -258,6 +258,7 @@ def test_failed_instantiation_is_loud_and_falls_back_only_where_a_builtin_kernel
         pytest.skip("no compiler on this box: nothing to break")
     from oracle import clik_oracle
     monkeypatch.setenv("CLIK_JIT_DEFINES", "-fthis-flag-does-not-exist-%d" % os.getpid())
+    monkeypatch.delenv("CLIK_JIT_RECORD", raising=False)     # (a request that cannot compile is not one to replay at build())
     t, q = cs.MX.sym("t"), cs.MX.sym("q", 6)
     T = ur5_fk["T_fk"](q)
     spec = cc.SkillSpecification("plain", t, q, constraints=[

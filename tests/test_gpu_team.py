@@ -693,3 +693,51 @@ def test_worst_case_of_the_team_sweeps_is_held_to_its_own_bound():
         assert (err <= tol).all(), (ctrl.kernel_variant(len(Q)), float((err / tol).max()))
         print("%s: worst err %.2e = %.2f u kappa = %.3f of its bound" % (
             ctrl.kernel_variant(len(Q)), err.max(), (err / (U * kappa)).max(), (err / tol).max()))
+
+
+def test_lane_kernels_on_ragged_and_misaligned_batches(iiwa_fk):
+    """The lane-per-instance value kernels (config 3 beyond 16384 instances, config 4 cold beyond 16384) on a batch whose
+    last wave is ragged (20000 = 312 waves + 32 instances), with 16-byte aligned and with misaligned (8 mod 16) input
+    arrays: bit-identical outputs, and the oracle's on a sample from both ends.  (Written for the round-6 experiment that
+    moved the rows through LDS in 16-byte pieces - tools/experiments/lane_rows_lds.patch, retired - which got exactly
+    these cases wrong.)"""
+    import torch
+    from oracle import clik_oracle
+    B = 20000
+    Q, Y = skills.synthetic_inputs(iiwa_fk, B, seed=17, distribution="mixed")
+
+    def skewed(a):
+        buf = torch.empty(a.size + 1, dtype=torch.float64, device="cuda")
+        buf[1:].copy_(torch.from_numpy(a).reshape(-1))
+        v = buf[1:].view(*a.shape)
+        assert v.data_ptr() % 16 == 8
+        return v
+    # ---- config 3, lane kernel
+    spec = skills.stack_skill(iiwa_fk)
+    ctrl = cc.PseudoInverseController(skill_spec=spec, options=dict(skills.STACK_OPTIONS))
+    ctrl.setup_problem_functions()
+    if "lanev" not in ctrl.kernel_variant(B):
+        pytest.skip("no value-specialised lane kernel attached (hipcc missing)")
+    Qd, Yd = torch.from_numpy(Q).cuda(), torch.from_numpy(Y).cuda()
+    a = ctrl.solve_batch(0.0, Qd, input_var=Yd)
+    b = ctrl.solve_batch(0.0, skewed(Q), input_var=skewed(Y))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    idx = np.r_[0:64, B - 96:B]
+    ref, rmode = clik_oracle.pinv_solve_batch(spec, ctrl.options, 0.0, Q[idx], Y=Y[idx])
+    assert np.array_equal(a[2].cpu().numpy()[idx], rmode) and pinv_close(a[0].cpu().numpy()[idx], ref)
+    # ---- config 4, lone-wave kernel (cold ticks beyond 16384 instances; the slack rows are six doubles wide)
+    qspec = skills.qp_skill(iiwa_fk)
+    qctrl = cc.ReactiveQPController(skill_spec=qspec)
+    qctrl.setup_problem_functions()
+    qctrl.setup_solver()
+    if not qctrl.value_kernel:
+        pytest.skip("no value-specialised QP kernel attached (hipcc missing)")
+    qa = qctrl.solve_batch(0.0, Qd, input_var=Yd, use_hot=False)
+    qb = qctrl.solve_batch(0.0, skewed(Q), input_var=skewed(Y), use_hot=False)
+    assert torch.equal(qa[3], qb[3])
+    for k in (0, 2):
+        assert torch.allclose(qa[k], qb[k], rtol=0.0, atol=0.0, equal_nan=True), k
+    rdq, _, rslack, rstatus = clik_oracle.qp_solve_batch(qspec, 0.0, Q[idx], Y=Y[idx])
+    ok = rstatus == 0
+    assert np.array_equal(qa[3].cpu().numpy()[idx] == 0, ok)
+    assert qp_close(qa[0].cpu().numpy()[idx], rdq, rows=ok) and qp_close(qa[2].cpu().numpy()[idx], rslack, rows=ok)
