@@ -727,7 +727,10 @@ __device__ __forceinline__ unsigned long long realtime_100mhz()
 // costs no register at all.  The wave's rows are ONE contiguous block of 16 x NE doubles; `row0` its first row, the array
 // `total_rows` long: a block that would run past the end of the array is read from `total_rows - 16` instead and the
 // instances find their rows `shift` further down (stage_row).  `al16`: base address and row pitch allow 16-byte pieces
-// (else 4-byte pieces: four times the requests).  Returns the shift.
+// (else 4-byte pieces: four times the requests) - the caller's `al16` must also imply that the ARRAY's byte size is a
+// multiple of 16 (the resident kernels: base aligned and B x NE even), because a piece that would run past the end of
+// the array is moved back to end there: for a size of 8 mod 16 that piece would land shifted by 8 bytes (the retired
+// lane-kernel experiment tools/experiments/lane_rows_lds.patch got exactly that wrong).  Returns the shift.
 template <int NE>
 struct RowStage {
     static constexpr int BLOCK = 16 * NE * 8;                        // bytes of a wave's rows

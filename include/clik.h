@@ -267,8 +267,8 @@ int clik_pinv_attach_value_kernel(clik_pinv* h, void* solve_fn, void* rollout_fn
  * producer or copy queued behind the resident kernel waits until the watchdog lets it go): use a stream of another
  * priority (hipStreamCreateWithPriority).  Only for handles with an attached value-specialised kernel of that family
  * (clik_pinv_attach_resident_kernel; casclik_amd/jit.py does it).  Not graph-capturable.  Measured on one MI355X
- * (tools/resident_probe.py), 16384 instances: 3.2 us per tick when the producer publishes
- * ahead (a ring of four slots), 5.2 us when it waits for done[] (closed loop), 3.99 us for one launch per tick.   */
+ * (tools/resident_probe.py, profiles/r6_resident_probe.txt; round 6), 16384 instances: 2.6 us per tick when the producer
+ * publishes ahead (a ring of four slots), 5.4 us when it waits for done[] (closed loop), 3.66 us for one launch per tick. */
 typedef struct clik_ticket {
     uint32_t in_seq;     uint32_t _p0[15];
     uint32_t ring_depth; uint32_t _p1a;      /* input / output slots, set by the caller before the launch (0 or 1: one buffer) */
