@@ -1443,6 +1443,20 @@ constexpr long long kTeamMaxBatch = 16384;
 // lane-per-instance kernel wins (pinv_solve_static_occ2_kernel)
 constexpr long long kOcc2MinBatch = 524288;
 
+// The skills the value-specialised lane-per-instance kernel serves: single-mode skills without virtual variables (skills
+// with SetConstraints keep the one-wave-per-mode kernels at small batches, the config-3 family its four lanes per
+// instance) ...
+constexpr bool shape_value_lane_ok(const ShapeDesc& sd)
+{
+    return sd.n_x == 0 && !sd.qp && (shape_n_sets(sd) <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd));
+}
+// ... and those whose small batches run four lanes per instance with the sin / cos evaluations split over the quad
+// (pinv_solve_static_values_quad_kernel).  ONE predicate for the launcher and for the label.
+constexpr bool shape_quad_front_ok(const ShapeDesc& sd)
+{
+    return shape_value_lane_ok(sd) && !shape_team_ok(sd) && sd.uses_fk != 0 && sd.n >= 3 && sd.n <= 2 * TEAM;
+}
+
 // Which kernel variant serves a batch of B instances of a static shape (the label bench.py and the
 // tests report): the same conditions launch_solve_static evaluates, on the run-time copy of the shape.
 inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long long B)
@@ -1450,11 +1464,10 @@ inline const char* static_variant(const ShapeDesc& sd, int mode_parallel, long l
     if (shape_team_ok(sd) && ((mode_parallel & 8) || ((mode_parallel & 4) && B <= kTeamMaxBatch)))
         return (mode_parallel & 64) ? "team4v" : "team4";       // bit 6: a value-specialised team kernel is attached
     const int ns = shape_n_sets(sd);
-    if ((mode_parallel & 64) && sd.n_x == 0 && !sd.qp && (ns <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd)) && B <= CLIK_VALUE_LANE_MAX_BATCH) {
+    if ((mode_parallel & 64) && shape_value_lane_ok(sd) && B <= CLIK_VALUE_LANE_MAX_BATCH) {
         // value-specialised kernels attached: four lanes per instance (split sin / cos) at small batches of single-mode
-        // skills with forward kinematics, one lane per instance otherwise  (shape_quad_front_ok, spelled out: this
-        // function is compiled before the kernels)
-        if (!shape_team_ok(sd) && sd.uses_fk != 0 && sd.n >= 3 && sd.n <= 8 && B <= kTeamMaxBatch && !(mode_parallel & 128))
+        // skills with forward kinematics, one lane per instance otherwise
+        if (shape_quad_front_ok(sd) && B <= kTeamMaxBatch && !(mode_parallel & 128))
             return "quadv";
         return "lanev";
     }
@@ -1610,12 +1623,7 @@ inline hipError_t launch_rollout_team_values(const LaunchArgs& a, const double* 
 // loads its own robot_var / input_var row and stores its own velocity row.  For the small batches where a tick
 // is the latency of one wave, and - measured - for the large ones too (see CLIK_VALUE_LANE_MAX_BATCH above).
 constexpr long long kValueLaneMaxBatch = CLIK_VALUE_LANE_MAX_BATCH;
-// single-mode skills without virtual variables (skills with SetConstraints keep the one-wave-per-mode kernels at
-// small batches, the config-3 family its four lanes per instance)
-constexpr bool shape_value_lane_ok(const ShapeDesc& sd)
-{
-    return sd.n_x == 0 && !sd.qp && (shape_n_sets(sd) <= CLIK_VALUE_LANE_MAX_SETS || shape_team_ok(sd));
-}
+// (which skills it serves: shape_value_lane_ok, above static_variant)
 template <const ShapeDesc& SD, class IMGV>
 __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_kernel(
     const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
@@ -1670,10 +1678,7 @@ __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_k
 // instead of N evaluations - 170 of the 1240 instructions of the config-2 stream); everything behind is evaluated by
 // all four lanes alike (the entries of the <= 8 x 8 matrices cannot be split: clik_pinv_team.hpp) and lane 0 stores.
 // Up to kTeamMaxBatch instances (one wave per SIMD).  Same values as the lane kernel to rounding.
-constexpr bool shape_quad_front_ok(const ShapeDesc& sd)
-{
-    return shape_value_lane_ok(sd) && !shape_team_ok(sd) && sd.uses_fk != 0 && sd.n >= 3 && sd.n <= 2 * TEAM;
-}
+// (which skills it serves: shape_quad_front_ok, above static_variant)
 template <const ShapeDesc& SD, class IMGV>
 __global__ __launch_bounds__(WAVE) CLIK_OCC_ATTR void pinv_solve_static_values_quad_kernel(
     const double* __restrict__ q, const double* __restrict__ y, double* __restrict__ dq,
