@@ -162,7 +162,7 @@ def test_value_specialised_kernels_of_the_config3_skill_have_no_scratch(tmp_path
     # (compiled as shipped: with the scheduling strategy jit.py picks for this translation unit)
     sched = jit.sched_strategy(text, init)
     assert sched == "max-memory-clause"
-    out = subprocess.run([hipcc] + FLAGS + ["-DCLIK_VALUE_KERNEL", "-mllvm", "-amdgpu-sched-strategy=" + sched, "-c", str(src),
+    out = subprocess.run([hipcc] + FLAGS + ["-DCLIK_VALUE_KERNEL"] + jit.sched_flags(sched) + ["-c", str(src),
                           "-o", str(tmp_path / "stack_values.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     res = parse_resource_remarks(out.stdout.decode())
@@ -236,6 +236,8 @@ def test_scheduling_strategy_per_translation_unit(monkeypatch):
     assert jit.sched_strategy(jit._VALUE_TEMPLATE, stack) == "max-memory-clause"
     assert jit.sched_strategy(jit._VALUE_TEMPLATE, pose) is None
     assert jit.sched_strategy(jit._TEMPLATE, stack) is None
+    assert jit.sched_flags(None) == [] and "-amdgpu-use-amdgpu-trackers" in jit.sched_flags("max-ilp")
+    assert jit.sched_flags("max-memory-clause") == ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
     monkeypatch.setenv("CLIK_JIT_SCHED", "default")
     assert jit.sched_strategy(jit._QP_VALUE_TEMPLATE, stack) is None
     monkeypatch.setenv("CLIK_JIT_SCHED", "max-ilp")

@@ -51,7 +51,7 @@ else:
 # (the scheduling strategy the shipped object is compiled with, casclik_amd/jit.py::sched_strategy - unless one is given)
 sched = jit.sched_strategy(template, init)
 if sched and not any("sched-strategy" in f for f in flags):
-    flags += ["-mllvm", "-amdgpu-sched-strategy=" + sched]
+    flags += jit.sched_flags(sched)
 text = template.replace("%(nwords)d", str(len(words))).replace("%(words)s", ", ".join(w + "ull" for w in words)) % {
     "init": init, "extern": ""}
 with tempfile.TemporaryDirectory() as tmp:
