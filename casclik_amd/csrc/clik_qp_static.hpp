@@ -1894,7 +1894,10 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_values_kernel(
 
 // ... for the box family without any LDS: its solver keeps everything in registers, the few work-area slots the row
 // gathering fills become a private array, every lane loads its own rows and stores its own results
-template <const ShapeDesc& SD, class IMGV>
+// HOT: a launch whose every instance is hot-started (use_hot set, working sets given): the tick with `use_hot` a literal -
+// no start sweeps in the object, the partition read straight off the working-set word (69 instructions fewer on the
+// executed path than the general body, whose selects on a run-time flag the compiler cannot fold: round 6)
+template <const ShapeDesc& SD, class IMGV, bool HOT = false>
 __device__ __forceinline__ void qp_box_values_body(
     const double* __restrict__ q, const double* __restrict__ y,
     double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
@@ -1930,7 +1933,7 @@ __device__ __forceinline__ void qp_box_values_body(
         for (int k = 0; k < NY; ++k) ydir[k] = y[row * NY + k];
     }
     int32_t hot_word = 0;
-    if (hot_set != nullptr) hot_word = hot_set[row];
+    if (HOT || hot_set != nullptr) hot_word = hot_set[row];
     asm volatile("" ::: "memory");
     const double* ysl = ydir;
     double priv[LY::SLOTS];
@@ -1938,9 +1941,9 @@ __device__ __forceinline__ void qp_box_values_body(
     // (the working set in a register, its address passed unconditionally: a conditional pointer to it would put it into
     // scratch memory)
     const int status = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl,
-                                             &hot_word, use_hot != 0 && hot_set != nullptr);
+                                             &hot_word, HOT ? true : (use_hot != 0 && hot_set != nullptr));
     CLIK_PHASE("store");
-    if (valid && hot_set != nullptr) hot_set[inst] = hot_word;
+    if (valid && (HOT || hot_set != nullptr)) hot_set[inst] = hot_word;
     if (valid) {
         const unsigned bad = (status == 2) ? 0x7ff80000u : 0u;      // (nan_or: the NaN of an infeasible instance, as bits)
 #pragma unroll
@@ -1970,6 +1973,14 @@ __global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_kernel(
     const TickArgs tk)
 {
     qp_box_values_body<SD, IMGV>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, use_hot, tk);
+}
+template <const ShapeDesc& SD, class IMGV>
+__global__ __launch_bounds__(WAVE) void qp_solve_static_box_values_hot_kernel(
+    const double* __restrict__ q, const double* __restrict__ y,
+    double* __restrict__ dq, double* __restrict__ slack_out, int32_t* __restrict__ status_out, const long long B,
+    const double* __restrict__ x, double* __restrict__ dx, int32_t* __restrict__ hot_set, const TickArgs tk)
+{
+    qp_box_values_body<SD, IMGV, true>(q, y, dq, slack_out, status_out, B, x, dx, hot_set, 1, tk);
 }
 
 // (Measured and retired, tools/experiments/qp_retired.patch: the same body held to two waves per SIMD - it spilled 288 B
@@ -2305,8 +2316,12 @@ inline hipError_t launch_qp_static_values(const TickArgs& tk, long long B, const
         default:
             break;
         }
-        hipLaunchKernelGGL((qp_solve_static_box_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
-                           slack, status, B, x, dx, hot_set, use_hot, tk);
+        if (use_hot != 0 && hot_set != nullptr)
+            hipLaunchKernelGGL((qp_solve_static_box_values_hot_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
+                               slack, status, B, x, dx, hot_set, tk);
+        else
+            hipLaunchKernelGGL((qp_solve_static_box_values_kernel<SD, IMGV>), dim3(grid), dim3(WAVE), 0, stream, q, y, dq,
+                               slack, status, B, x, dx, hot_set, use_hot, tk);
         return hipGetLastError();
     }
     constexpr size_t shmem = QpLayout<SD>::LDS_BYTES;
