@@ -119,8 +119,12 @@ __global__ __launch_bounds__(WAVE) void qp_resident_box_front4_kernel(
         }
         double priv[LY::SLOTS];
         double v[N], sl[LY::NSA];
-        const int status = qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, yrow, tid & (WAVE - 1),
-                                                              valid, priv, v, sl, &hot_word, k > 1, nullptr, nullptr, sns, css);
+        // (two copies of the tick, `use_hot` a literal in each - qp_box_values_body, clik_qp_static.hpp: tick 1 is the cold one)
+        auto solve = [&](auto hot_c) __attribute__((always_inline)) {
+            return qp_tick_static<SD, 1, false, true>(&kValues.img, &kValues.tail, tk, z, yrow, tid & (WAVE - 1), valid, priv, v,
+                                                      sl, &hot_word, decltype(hot_c)::value, nullptr, nullptr, sns, css);
+        };
+        const int status = (k > 1) ? solve(std::true_type{}) : solve(std::false_type{});
         // (the next tick's rows and the ticket word, requested at the top of this tick, are waited for HERE - before this
         // tick's stores are issued - not at the top of the next tick, where the same wait would also cover those stores:
         // pin_arrived, clik_device.hpp.  Unconditional: the compiler's wait insertion is not path-sensitive, and with

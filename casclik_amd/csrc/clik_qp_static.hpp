@@ -2178,6 +2178,9 @@ __global__ __launch_bounds__(WAVE) void qp_rollout_static_box_values_kernel(
         for (int stg = 0; stg < stages; ++stg) {
             const TickArgs& tk = *reinterpret_cast<const TickArgs*>(tterms + ((size_t)tick * stages + stg) * 2 * nts);
             double priv[LY::SLOTS];
+            // (one copy of the tick with a run-time `use_hot`: two copies with the flag a literal in each - as the launched and the
+            // resident kernels have - measured 85 instructions MORE per tick here, 3.78 against 3.72 us, round 6: the register
+            // allocator's doing)
             const int st = qp_tick_static<SD, 1>(&kValues.img, &kValues.tail, tk, z, ysl, lane, valid, priv, v, sl, &hot,
                                                  (tick | stg) > 0);
             worst = st > worst ? st : worst;
